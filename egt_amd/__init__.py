@@ -1,0 +1,12 @@
+"""egt_amd — MI355X-native EGT edge-augmented attention hot path.
+
+Public surface (mirrors the reference's operator interface for this path):
+    EGT, EGTBlock, EGTStack, custom_layers      (egt_amd.layers)
+    egt_attention, edge_proj, edge_update        (egt_amd.functional)
+    FlatGradAllReduce, shard_batch               (egt_amd.dp)
+"""
+from .layers import EGT, EGTBlock, EGTStack, custom_layers, KerasDense, KerasLayerNorm  # noqa: F401
+from .functional import AttnConfig, egt_attention, edge_proj, edge_update, mask_sample  # noqa: F401
+
+__all__ = ["EGT", "EGTBlock", "EGTStack", "custom_layers", "AttnConfig", "egt_attention",
+           "edge_proj", "edge_update", "mask_sample"]

@@ -1,0 +1,145 @@
+"""ctypes binding of the C-ABI in include/egt_amd.h.
+
+The library is loaded from egt_amd/lib/libegt_amd.so (built in-tree by
+egt_amd/build.py).  There is NO fallback: if the HIP library is missing or a
+call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libegt_amd.so")
+
+# --- constants mirrored from include/egt_amd.h ---------------------------------
+EGT_OK = 0
+EGT_E_NULL, EGT_E_SHAPE, EGT_E_DTYPE, EGT_E_FLAGS, EGT_E_HIP, EGT_E_WORKSPACE = -1, -2, -3, -4, -5, -6
+EGT_F32 = 0
+F_EDGE_INPUT, F_GATE_INPUT, F_ATTN_MASK, F_SCALE_DEGREE = 0x001, 0x002, 0x004, 0x008
+F_SCALER_LINEAR, F_TRAINING, F_CLIP = 0x010, 0x020, 0x040
+EP_LAYERNORM, EP_GATES = 0x1, 0x2
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_ELU = 0, 1, 2, 3
+# egt_block_desc.flags
+BF_GATE, BF_ATTN_MASK, BF_TRAINING, BF_CLIP = 0x1, 0x2, 0x4, 0x8
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("d", C.c_int32),
+                ("dtype", C.c_int32), ("flags", C.c_uint32),
+                ("clip_lo", C.c_float), ("clip_hi", C.c_float),
+                ("random_mask_prob", C.c_float), ("attn_dropout", C.c_float),
+                ("num_virtual_nodes", C.c_int32), ("reserved", C.c_int32),
+                ("seed", C.c_uint64)]
+
+
+class EdgeDesc(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("De", C.c_int32), ("H", C.c_int32),
+                ("dtype", C.c_int32), ("flags", C.c_uint32), ("act", C.c_int32),
+                ("act_alpha", C.c_float), ("ln_eps", C.c_float), ("reserved", C.c_int32)]
+
+
+class BlockDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("d", C.c_int32),
+                ("De", C.c_int32), ("dtype", C.c_int32), ("flags", C.c_uint32),
+                ("clip_lo", C.c_float), ("clip_hi", C.c_float),
+                ("random_mask_prob", C.c_float), ("ln_eps", C.c_float),
+                ("reserved", C.c_int32), ("seed", C.c_uint64)]
+
+
+BLOCK_PARAM_FIELDS = (
+    "norm_edge_gamma", "norm_edge_beta",
+    "attention_gates_kernel", "attention_gates_bias",
+    "dense_edge_b_kernel", "dense_edge_b_bias",
+    "norm_mha_gamma", "norm_mha_beta",
+    "dense_qkv_kernel", "dense_qkv_bias",
+    "dense_mha_kernel", "dense_mha_bias",
+    "dense_edge_r_kernel", "dense_edge_r_bias",
+)
+
+
+class BlockParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in BLOCK_PARAM_FIELDS]
+
+
+class EGTLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_VP = C.c_void_p
+_PROTOS = {
+    "egt_last_error_string": (C.c_char_p, []),
+    "egt_abi_version": (C.c_int, []),
+    "egt_attn_fwd": (C.c_int, [C.POINTER(AttnDesc)] + [_VP] * 12),
+    "egt_attn_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),
+    "egt_attn_bwd": (C.c_int, [C.POINTER(AttnDesc)] + [_VP] * 16),
+    "egt_mask_sample": (C.c_int, [C.c_int, C.c_uint64, C.c_float, C.c_int32, C.c_int32,
+                                  C.c_int32, _VP, _VP]),
+    "egt_edge_proj_fwd": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 10),
+    "egt_edge_proj_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(EdgeDesc)]),
+    "egt_edge_proj_bwd": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 17),
+    "egt_edge_update_fwd": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 6),
+    "egt_edge_update_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(EdgeDesc)]),
+    "egt_edge_update_bwd": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 8),
+}
+# entry points added by later build stages; bound when present, listed here so the
+# "every declared symbol is exported" test sees one table
+_OPTIONAL_PROTOS = {
+    "egt_block_supported": (C.c_int, [C.POINTER(BlockDesc)]),
+    "egt_block_saved_bytes": (C.c_size_t, [C.POINTER(BlockDesc)]),
+    "egt_block_workspace_bytes": (C.c_size_t, [C.POINTER(BlockDesc)]),
+    "egt_block_fwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams)] + [_VP] * 9),
+    "egt_block_bwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams)] + [_VP] * 10
+                      + [C.POINTER(BlockParams)] + [_VP] * 2),
+    "egt_prof_enable": (C.c_int, [C.c_int]),
+    "egt_prof_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+}
+
+
+def load():
+    """Load (once) and return the ctypes library.  Raises EGTLibraryError when the
+    HIP library has not been built — the product path never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EGTLibraryError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or python egt_amd/build.py)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    for name, (res, args) in _OPTIONAL_PROTOS.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+    if lib.egt_abi_version() != 1:
+        raise EGTLibraryError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+_EXC = {EGT_E_NULL: ValueError, EGT_E_SHAPE: AssertionError, EGT_E_DTYPE: TypeError,
+        EGT_E_FLAGS: ValueError, EGT_E_HIP: RuntimeError, EGT_E_WORKSPACE: RuntimeError}
+
+
+def check(rc: int):
+    """Re-raise a C error code as the exception type the reference raises for the
+    same condition (egt_layers.py:20-24 ValueError, :70 AssertionError)."""
+    if rc == EGT_OK:
+        return
+    msg = load().egt_last_error_string().decode(errors="replace")
+    raise _EXC.get(rc, RuntimeError)(f"egt_amd: {msg} (code {rc})")
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,83 @@
+"""Builds the gfx950 C-ABI library in-tree: egt_amd/lib/libegt_amd.so.
+
+hipcc cross-compiles without a GPU; the .so travels to the GPU box with the
+repo snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(ROOT)
+CSRC = os.path.join(ROOT, "csrc")
+LIBDIR = os.path.join(ROOT, "lib")
+LIB = os.path.join(LIBDIR, "libegt_amd.so")
+SOURCES = ["egt_capi.hip", "egt_attn.hip", "egt_edge.hip", "egt_block.hip"]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found; the HIP extension cannot be built")
+
+
+def _digest(paths) -> str:
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        with open(p, "rb") as f:
+            h.update(p.encode())
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def sources():
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(REPO, "include", "egt_amd.h"))
+    return srcs, hdrs
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    srcs, hdrs = sources()
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, ".stamp")
+    dig = _digest(srcs + hdrs)
+    if not force and os.path.exists(LIB) and os.path.exists(stamp):
+        if open(stamp).read().strip() == dig:
+            return LIB
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    for s in srcs:
+        o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
+        objs.append(o)
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o,
+               "-I", CSRC, "-I", os.path.join(REPO, "include"), "-Wno-unused-result"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode(errors="replace"))
+            raise RuntimeError(f"hipcc failed on {s}")
+        if verbose and out:
+            print(out.decode(errors="replace"))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout.decode(errors="replace"))
+        raise RuntimeError("link failed")
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

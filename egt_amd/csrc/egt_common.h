@@ -1,0 +1,53 @@
+// Internal helpers shared by the gfx950 kernels and the C-ABI glue.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "egt_amd.h"
+
+#define EGT_NEG 1.0e9f  // the reference's additive mask constant (egt_layers.py:92,99,106)
+#define EGT_DROPOUT_STREAM 0x5BD1E995u
+
+void egt_set_error(const char* fmt, ...);
+
+#define EGT_FAIL(code, ...)      \
+  do {                           \
+    egt_set_error(__VA_ARGS__);  \
+    return (code);               \
+  } while (0)
+
+#define EGT_HIP_LAUNCH_CHECK(name)                                              \
+  do {                                                                          \
+    hipError_t e__ = hipGetLastError();                                         \
+    if (e__ != hipSuccess)                                                      \
+      EGT_FAIL(EGT_E_HIP, "%s launch failed: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+// ---- counter hash (mirrored bit-exactly by oracle/rng_ref.py) ----------------
+__host__ __device__ inline uint32_t egt_fmix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+__host__ __device__ inline uint32_t egt_hash32(uint32_t idx, uint32_t s0, uint32_t s1) {
+  return egt_fmix32(egt_fmix32(idx ^ s0) + s1);
+}
+// 24-bit threshold: sample u = hash>>8 ; "uniform < p"  <=>  u < floor(p*2^24)
+__host__ inline uint32_t egt_threshold24(float p) {
+  double t = (double)p * 16777216.0;
+  if (t < 0) t = 0;
+  if (t > 16777216.0) t = 16777216.0;
+  return (uint32_t)t;
+}
+
+// ---- small device math --------------------------------------------------------
+__device__ __forceinline__ float egt_sigmoid(float x) {
+  // x = -1e9 -> exp(+1e9) = inf -> 1/inf = 0 exactly, as in the reference's fp32 path
+  return __frcp_rn(1.0f + __expf(-x));
+}
+
+__device__ __forceinline__ float wave_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }

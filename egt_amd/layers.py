@@ -1,0 +1,284 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+* ``EGT``       — lib/models/egt_layers.py:4-218: same constructor kwargs and
+                  defaults, same call convention
+                  ``EGT(...)([QKV, E?, G?, M?], mask=None, training=None)
+                  -> (V_att, H_hat, A_tild)``, same exceptions.
+* ``EGTBlock``  — the closure ``edge_update_{residual,bias,none}(tag, h, e)`` +
+                  ``mha_block`` (graph_xformer_model_base.py:106-223) as one
+                  module ``(h, e, mask[, attn_mask]) -> (h', e')`` owning the
+                  reference's eight named Keras sub-layers' parameters.
+* ``EGTStack``  — the ``model_height`` loop (graph_xformer_model_base.py:336-339)
+                  over the attention blocks.
+All [B,N,N,*] arithmetic runs in the HIP kernels; node-side [B,N,Dh] Dense
+layers of the composed path use torch (library GEMMs).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import functional as EF
+
+LN_EPS = 1e-3  # keras.layers.LayerNormalization default epsilon
+
+
+class EGT(nn.Module):
+    """Drop-in for lib/models/egt_layers.py:4 ``EGT`` (a parameter-free layer)."""
+
+    def __init__(self,
+                 num_heads=8,
+                 clip_logits_value=[-5., 5.],
+                 scale_degree=False,
+                 scaler_type='log',
+                 edge_input=True,
+                 gate_input=True,
+                 attn_mask=False,
+                 num_virtual_nodes=0,
+                 random_mask_prob=0.0,
+                 attn_dropout=0.0,
+                 name=None,
+                 seed=0,
+                 **kwargs):
+        super().__init__()
+        if scale_degree and not gate_input:                       # egt_layers.py:20-21
+            raise ValueError('scale_degree requires gate_input')
+        if scaler_type not in ('log', 'linear'):                  # egt_layers.py:23-24
+            raise ValueError('scaler_type must be log or linear')
+        self.supports_masking = True
+        self.num_heads = num_heads
+        self.clip_logits_value = clip_logits_value
+        self.scale_degree = scale_degree
+        self.edge_input = edge_input
+        self.gate_input = gate_input
+        self.attn_mask = attn_mask
+        self.num_virtual_nodes = num_virtual_nodes
+        self.random_mask_prob = random_mask_prob
+        self.scaler_type = scaler_type
+        self.attn_dropout = attn_dropout
+        self.name = name
+        self.seed = int(seed)
+        self._calls = 0
+        self.return_a_tild = True
+
+    def get_config(self):
+        # egt_layers.py:42-55 (the reference also omits attn_dropout here)
+        return dict(name=self.name,
+                    num_heads=self.num_heads,
+                    clip_logits_value=self.clip_logits_value,
+                    scale_degree=self.scale_degree,
+                    edge_input=self.edge_input,
+                    gate_input=self.gate_input,
+                    attn_mask=self.attn_mask,
+                    num_virtual_nodes=self.num_virtual_nodes,
+                    random_mask_prob=self.random_mask_prob,
+                    scaler_type=self.scaler_type)
+
+    def next_seed(self):
+        self._calls += 1
+        return (self.seed * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+    def forward(self, inputs, mask=None, training=None, rand_mask=None, drop_keep=None):
+        if training is None:
+            training = self.training                               # egt_layers.py:58-59
+        QKV, *inputs = inputs                                      # :62
+        E = G = M = None
+        if self.edge_input:
+            E, *inputs = inputs                                    # :63
+        if self.gate_input:
+            G, *inputs = inputs                                    # :64
+        if self.attn_mask:
+            M, *inputs = inputs                                    # :65
+        if isinstance(mask, (list, tuple)):
+            mask = mask[0]                                         # :66
+        assert QKV.shape[2] % (self.num_heads * 3) == 0            # :70
+        stochastic = training and (self.random_mask_prob > 0.0 or self.attn_dropout > 0.0)
+        cfg = EF.AttnConfig(num_heads=self.num_heads,
+                            clip_logits_value=None if self.clip_logits_value is None
+                            else tuple(self.clip_logits_value),
+                            scale_degree=self.scale_degree, scaler_type=self.scaler_type,
+                            num_virtual_nodes=self.num_virtual_nodes,
+                            random_mask_prob=self.random_mask_prob,
+                            attn_dropout=self.attn_dropout, training=bool(training),
+                            seed=self.next_seed() if stochastic else 0,
+                            need_a_tild=self.return_a_tild)
+        V_att, H_hat, A_tild = EF.egt_attention(QKV, E, G, M, mask, cfg=cfg,
+                                                rand_mask=rand_mask, drop_keep=drop_keep)
+        return V_att, H_hat, (A_tild if self.return_a_tild else None)
+
+    def compute_mask(self, inputs, mask=None):                     # egt_layers.py:215-217
+        if isinstance(mask, (list, tuple)):
+            mask = mask[0]
+        return [mask, None, None]
+
+
+# The reference resolves ``layers.EGT`` through TrackedLayers(custom_layers, ...)
+# (graph_xformer_model_base.py:12,80; track_layers/base.py:43-60); this namespace
+# is what a maintainer registers first to swap the kernel for every scheme.
+custom_layers = SimpleNamespace(EGT=EGT)
+
+
+class KerasDense(nn.Module):
+    """keras.layers.Dense parameters: kernel [in,out] Glorot-uniform, bias zeros."""
+
+    def __init__(self, fan_in, fan_out):
+        super().__init__()
+        self.kernel = nn.Parameter(torch.empty(fan_in, fan_out))
+        self.bias = nn.Parameter(torch.zeros(fan_out))
+        nn.init.xavier_uniform_(self.kernel)
+
+    def forward(self, x):
+        return x @ self.kernel + self.bias
+
+
+class KerasLayerNorm(nn.Module):
+    """keras.layers.LayerNormalization(axis=-1, epsilon=1e-3) parameters."""
+
+    def __init__(self, width):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(width))
+        self.beta = nn.Parameter(torch.zeros(width))
+
+    def forward(self, x):
+        return F.layer_norm(x, (x.shape[-1],), self.gamma, self.beta, LN_EPS)
+
+
+class EGTBlock(nn.Module):
+    """(h, e, mask[, attn_mask]) -> (h', e'): graph_xformer_model_base.py:192-223
+    ('residual'/'constrained'), :173-190 ('bias'), :164-171 ('none'), each around
+    mha_block (:106-145).  Sub-module names are the reference's Keras layer names
+    (tag suffix dropped): norm_edge, attention_gates, dense_edge_b, norm_mha,
+    dense_qkv, mha, dense_mha, dense_edge_r."""
+
+    def __init__(self, model_width=128, edge_width=32, num_heads=8, gate_attention=True,
+                 clip_logits_value=[-5, 5], edge_activation=None,
+                 edge_channel_type='residual', scale_degree=False, scaler_type='log',
+                 num_virtual_nodes=0, random_mask_prob=0., attn_dropout=0.,
+                 node_dropout=0., edge_dropout=0., add_n_norm=False, seed=0, fused='auto'):
+        super().__init__()
+        if not gate_attention and scale_degree:                   # graph_xformer_model_base.py:47-48
+            raise ValueError('scale_degree only works with gate_attention')
+        if edge_channel_type not in ('none', 'constrained', 'bias', 'residual'):
+            raise KeyError(edge_channel_type)                      # edge_update_fn_dict lookup, :328-334
+        self.model_width, self.edge_width, self.num_heads = model_width, edge_width, num_heads
+        self.edge_channel_type = edge_channel_type
+        self.edge_activation = edge_activation
+        self.node_dropout, self.edge_dropout, self.add_n_norm = node_dropout, edge_dropout, add_n_norm
+        self.fused = fused
+        has_edge = edge_channel_type != 'none'
+        # gates exist only on the edge-carrying variants (edge_update_none passes gates=None)
+        self.gated = bool(gate_attention) and has_edge
+        if edge_channel_type in ('residual', 'constrained'):
+            self.norm_edge = KerasLayerNorm(edge_width)
+        if self.gated:
+            self.attention_gates = KerasDense(edge_width, num_heads)
+        if has_edge:
+            self.dense_edge_b = KerasDense(edge_width, num_heads)
+        self.norm_mha = KerasLayerNorm(model_width)
+        self.dense_qkv = KerasDense(model_width, model_width * 3)
+        self.mha = EGT(num_heads=num_heads, clip_logits_value=clip_logits_value,
+                       scale_degree=scale_degree, scaler_type=scaler_type, edge_input=has_edge,
+                       gate_input=self.gated, attn_mask=(edge_channel_type == 'constrained'),
+                       num_virtual_nodes=num_virtual_nodes, random_mask_prob=random_mask_prob,
+                       attn_dropout=attn_dropout, name='mha', seed=seed)
+        self.mha.return_a_tild = False
+        self.dense_mha = KerasDense(model_width, model_width)
+        if edge_channel_type in ('residual', 'constrained'):
+            self.dense_edge_r = KerasDense(num_heads, edge_width)
+
+    # ---- composed path: HIP edge/attention kernels + torch node-side Dense ----
+    def _mha_block(self, h, e_b, gates, mask, attn_mask, rand_mask):
+        y = h                                                       # :107
+        if not self.add_n_norm:
+            h = self.norm_mha(h)                                    # :109
+        qkv = self.dense_qkv(h)                                     # :113
+        inputs = [qkv]
+        if self.mha.edge_input:
+            inputs.append(e_b)
+        if self.mha.gate_input:
+            inputs.append(gates)
+        if self.mha.attn_mask:
+            if attn_mask is None:
+                raise ValueError("edge_channel_type='constrained' needs attn_mask")
+            inputs.append(attn_mask)
+        v_att, h_hat, _ = self.mha(inputs, mask=mask, rand_mask=rand_mask)   # :117-131
+        h = self.dense_mha(v_att)                                   # :136
+        if self.node_dropout > 0:
+            h = F.dropout(h, self.node_dropout, self.training)      # :138-139
+        h = h + y                                                   # :140
+        if self.add_n_norm:
+            h = self.norm_mha(h)                                    # :142-143
+        return h, h_hat
+
+    def forward(self, h, e, mask=None, attn_mask=None, rand_mask=None):
+        ect = self.edge_channel_type
+        if ect == 'none':                                           # :164-171
+            h, _ = self._mha_block(h, None, None, mask, attn_mask, rand_mask)
+            return h, e
+        if self._use_fused(h, e, attn_mask, rand_mask):
+            from .fused import block_fused
+            return block_fused(self, h, e, mask, attn_mask)
+        use_ln = ect in ('residual', 'constrained') and not self.add_n_norm
+        ne = getattr(self, 'norm_edge', None)
+        ag = getattr(self, 'attention_gates', None)
+        gates, e_b = EF.edge_proj(
+            e, ne.gamma if use_ln else None, ne.beta if use_ln else None,
+            ag.kernel if ag is not None else None, ag.bias if ag is not None else None,
+            self.dense_edge_b.kernel, self.dense_edge_b.bias,
+            use_ln=use_ln, edge_activation=self.edge_activation, eps=LN_EPS)   # :195-208
+        h, h_hat = self._mha_block(h, e_b, gates, mask, attn_mask, rand_mask)  # :212
+        if ect == 'bias':
+            return h, e                                             # :190 (returns e0)
+        if self.edge_dropout > 0:
+            # dropout sits between dense_edge_r and the residual add (:214-218)
+            y = h_hat @ self.dense_edge_r.kernel + self.dense_edge_r.bias
+            e = F.dropout(y, self.edge_dropout, self.training) + e
+        else:
+            e = EF.edge_update(e, h_hat, self.dense_edge_r.kernel, self.dense_edge_r.bias)
+        if self.add_n_norm:
+            e = self.norm_edge(e)                                   # :220-221
+        return h, e
+
+    def _use_fused(self, h, e, attn_mask, rand_mask):
+        if self.fused is False or self.fused == 'off':
+            return False
+        try:
+            from . import fused as FZ
+        except ImportError:
+            if self.fused in (True, 'on'):
+                raise
+            return False
+        ok = FZ.block_supported(self, h, e, attn_mask, rand_mask)
+        if not ok and self.fused in (True, 'on'):
+            raise RuntimeError("fused EGT block requested but this configuration is not covered by it")
+        return ok
+
+    def keras_named_parameters(self, tag: str):
+        """Parameters keyed by the reference's Keras variable names for layer
+        `tag` ('00', '01', ...), e.g. 'dense_qkv_00/kernel'."""
+        out = {}
+        for mod_name, mod in self.named_children():
+            for p_name, p in mod.named_parameters(recurse=False):
+                out[f"{mod_name}_{tag}/{p_name}"] = p
+        return out
+
+
+class EGTStack(nn.Module):
+    """model_height attention blocks (graph_xformer_model_base.py:336-339); the
+    ffn_block that alternates with them in the reference (:340-341) is outside
+    this path."""
+
+    def __init__(self, model_height=4, **block_kwargs):
+        super().__init__()
+        seed = block_kwargs.pop('seed', 0)
+        self.blocks = nn.ModuleList(
+            [EGTBlock(seed=seed * 1000 + i, **block_kwargs) for i in range(model_height)])
+
+    def forward(self, h, e, mask=None, attn_mask=None):
+        for blk in self.blocks:
+            h, e = blk(h, e, mask, attn_mask)
+        return h, e

@@ -1,0 +1,169 @@
+/*
+ * egt_amd.h — C-ABI of the MI355X-native EGT edge-augmented attention path.
+ *
+ * The reference (shamim-hussain/egt) has NO FFI for this path: its seam is a
+ * pure-Python plugin registry (lib/base/track_layers/base.py:43-60) through
+ * which lib/models/graph_xformer_model_base.py:117-131 instantiates
+ * lib/models/egt_layers.py:4 `EGT`.  This header is the boundary a native
+ * replacement of that layer binds (see INTEGRATION.md for the ctypes stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer valid on `stream` (a hipStream_t passed
+ *     as void*; NULL = the null stream); the caller allocates everything; the
+ *     library never allocates, frees or keeps user memory and never syncs.
+ *   - tensors are dense row-major fp32 in the reference's layouts:
+ *       qkv   [B,N,3*d*H]   channel c = s*d*H + k*H + h   (egt_layers.py:73-76)
+ *       E,G,M,h_hat,a_tild [B,N,N,H]  (h innermost)       (egt_layers.py:63-65)
+ *       v_att [B,N,d*H]     channel k*H + h               (egt_layers.py:139-141)
+ *       key_mask [B,N] uint8, 1 = real node               (egt_layers.py:91-94)
+ *       h [B,N,Dh], e [B,N,N,De]        (graph_xformer_model_base.py:192-223)
+ *     Dense kernels are Keras-layout [in,out].
+ *   - return value: EGT_OK or a negative EGT_E_* code; egt_last_error_string()
+ *     describes the last failure on the calling thread.  No C++ exception
+ *     crosses this boundary.
+ *   - kernels are stateless and re-entrant; safe from several host threads on
+ *     different streams.
+ */
+#ifndef EGT_AMD_H_
+#define EGT_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGT_ABI_VERSION 1
+
+/* error codes */
+#define EGT_OK 0
+#define EGT_E_NULL (-1)      /* required pointer is NULL                        */
+#define EGT_E_SHAPE (-2)     /* bad / unsupported shape (the reference's assert,
+                                egt_layers.py:70, maps here)                    */
+#define EGT_E_DTYPE (-3)     /* unsupported dtype                               */
+#define EGT_E_FLAGS (-4)     /* inconsistent flags (egt_layers.py:20-24)        */
+#define EGT_E_HIP (-5)       /* a HIP runtime call failed                       */
+#define EGT_E_WORKSPACE (-6) /* workspace too small                             */
+
+/* dtype */
+#define EGT_F32 0
+
+/* egt_attn_desc.flags — the operator attributes of EGT.__init__
+ * (egt_layers.py:5-16) */
+#define EGT_F_EDGE_INPUT 0x001u    /* edge_input: E is added to the logits      */
+#define EGT_F_GATE_INPUT 0x002u    /* gate_input: call_gated, else call_ungated */
+#define EGT_F_ATTN_MASK 0x004u     /* attn_mask: M present                      */
+#define EGT_F_SCALE_DEGREE 0x008u  /* scale_degree                              */
+#define EGT_F_SCALER_LINEAR 0x010u /* scaler_type == 'linear' (else 'log')      */
+#define EGT_F_TRAINING 0x020u      /* training: random mask / dropout active    */
+#define EGT_F_CLIP 0x040u          /* clip_logits_value is not None             */
+
+typedef struct egt_attn_desc {
+  int32_t B, N, H, d;        /* graphs, padded nodes, heads, per-head dot dim   */
+  int32_t dtype;             /* EGT_F32                                         */
+  uint32_t flags;            /* EGT_F_*                                         */
+  float clip_lo, clip_hi;    /* clip_logits_value                               */
+  float random_mask_prob;    /* egt_layers.py:103                               */
+  float attn_dropout;        /* egt_layers.py:116                               */
+  int32_t num_virtual_nodes; /* egt_layers.py:131                               */
+  int32_t reserved;
+  uint64_t seed;             /* counter-hash seed for the in-kernel mask RNG    */
+} egt_attn_desc;
+
+const char* egt_last_error_string(void);
+int egt_abi_version(void);
+
+/* ---- inner op: EGT.call_gated / call_ungated ---------------------------------
+ * Replaces lib/models/egt_layers.py:57-143 (gated) and :145-213 (ungated):
+ *   (V_att, H_hat, A_tild) = EGT([QKV, E?, G?, M?], mask)
+ * key_mask may be NULL (mask=None).  rand_mask / drop_keep ([B,N,N,H] uint8;
+ * rand_mask 1 = key masked, drop_keep 1 = kept) are optional INJECTED samples of
+ * the two stochastic ops (egt_layers.py:103-108,116-117) used by parity tests;
+ * when NULL and (flags & TRAINING) the kernel draws them from the counter hash
+ * on (seed,b,l,m,h) (egt_mask_sample exposes the same stream).
+ * a_tild may be NULL (only lib/models/analysis.py reads it).
+ * rowstats [B,N,H,4] fp32 (softmax max, softmax sum, gate degree, reserved) is
+ * written for egt_attn_bwd. */
+int egt_attn_fwd(const egt_attn_desc* desc, const void* qkv, const void* E,
+                 const void* G, const uint8_t* key_mask, const void* attn_mask,
+                 const uint8_t* rand_mask, const uint8_t* drop_keep, void* v_att,
+                 void* h_hat, void* a_tild, void* rowstats, void* stream);
+
+/* Backward of the above — what TF autodiff derives for egt_layers.py:57-143
+ * (triggered by model.fit, lib/training/training_base.py:294).
+ * d_h_ext (grad w.r.t. output 2, H_hat) may be NULL.  d_E / d_G may be NULL
+ * when the corresponding input is absent.  v_att and rowstats are the forward's
+ * outputs.  workspace: egt_attn_bwd_workspace_bytes() bytes. */
+size_t egt_attn_bwd_workspace_bytes(const egt_attn_desc* desc);
+int egt_attn_bwd(const egt_attn_desc* desc, const void* qkv, const void* E,
+                 const void* G, const uint8_t* key_mask, const void* attn_mask,
+                 const uint8_t* rand_mask, const uint8_t* drop_keep,
+                 const void* v_att, const void* rowstats, const void* d_v_att,
+                 const void* d_h_ext, void* d_qkv, void* d_E, void* d_G,
+                 void* workspace, void* stream);
+
+/* The in-kernel sample streams, materialised ([B,N,N,H] uint8), for bit-exact
+ * checks against oracle/rng_ref.py.  which: 0 = random mask (1 = masked),
+ * 1 = dropout keep (1 = kept). */
+int egt_mask_sample(int which, uint64_t seed, float prob, int32_t B, int32_t N,
+                    int32_t H, uint8_t* out, void* stream);
+
+/* ---- edge-channel projections around the inner op ----------------------------
+ * rows = B*N*N edge rows of width De; H must be 8. */
+#define EGT_EP_LAYERNORM 0x1u /* norm_edge before the projections (residual /
+                                 constrained); absent for 'bias'               */
+#define EGT_EP_GATES 0x2u     /* attention_gates present (gate_attention)       */
+#define EGT_ACT_NONE 0
+#define EGT_ACT_LRELU 1 /* 'lreluN': alpha = N/10 (graph_xformer_model_base.py:150-156) */
+#define EGT_ACT_RELU 2
+#define EGT_ACT_ELU 3
+
+typedef struct egt_edge_desc {
+  int64_t rows;     /* B*N*N                                                   */
+  int32_t De, H;    /* edge_width, num_heads (8)                               */
+  int32_t dtype;    /* EGT_F32                                                 */
+  uint32_t flags;   /* EGT_EP_*                                                */
+  int32_t act;      /* EGT_ACT_* for dense_edge_b                              */
+  float act_alpha;  /* leaky-relu slope                                        */
+  float ln_eps;     /* Keras LayerNormalization default 1e-3                   */
+  int32_t reserved;
+} egt_edge_desc;
+
+/* G = LN(e)·Wg + bg ; E = act(LN(e)·We + be)
+ * Replaces graph_xformer_model_base.py:195 (norm_edge), :201-204
+ * (attention_gates), :149-162 (edge_channel_contrib / dense_edge_b).
+ * Wg/We [De,H], bg/be [H]; G_out may be NULL without EGT_EP_GATES. */
+int egt_edge_proj_fwd(const egt_edge_desc* desc, const void* e,
+                      const void* ln_gamma, const void* ln_beta, const void* Wg,
+                      const void* bg, const void* We, const void* be,
+                      void* G_out, void* E_out, void* stream);
+
+/* Backward: d_e is WRITTEN (not accumulated).  E_out = forward output (only
+ * read when act != NONE).  Parameter grads are written.  workspace:
+ * egt_edge_proj_bwd_workspace_bytes(). */
+size_t egt_edge_proj_bwd_workspace_bytes(const egt_edge_desc* desc);
+int egt_edge_proj_bwd(const egt_edge_desc* desc, const void* e,
+                      const void* ln_gamma, const void* ln_beta, const void* Wg,
+                      const void* We, const void* E_out, const void* d_G,
+                      const void* d_E, void* d_e, void* d_ln_gamma,
+                      void* d_ln_beta, void* d_Wg, void* d_bg, void* d_We,
+                      void* d_be, void* workspace, void* stream);
+
+/* e' = e + H_hat·Wr + br   (dense_edge_r + res_edge,
+ * graph_xformer_model_base.py:214-218).  Wr [H,De], br [De]. */
+int egt_edge_update_fwd(const egt_edge_desc* desc, const void* e,
+                        const void* h_hat, const void* Wr, const void* br,
+                        void* e_out, void* stream);
+
+/* Backward: d_h_hat = d_e_out·Wrᵀ (written); d_Wr, d_br written.  The residual
+ * branch (d_e += d_e_out) is the caller's add. */
+size_t egt_edge_update_bwd_workspace_bytes(const egt_edge_desc* desc);
+int egt_edge_update_bwd(const egt_edge_desc* desc, const void* d_e_out,
+                        const void* h_hat, const void* Wr, void* d_h_hat,
+                        void* d_Wr, void* d_br, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGT_AMD_H_ */

@@ -1,0 +1,135 @@
+"""GPU parity: inner op EGT([QKV,E,G,M],mask) fwd+bwd through the C-ABI vs the
+fp64 oracle and the committed golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases as CS
+from util import assert_close, load_golden, FWD, BWD
+
+pytestmark = pytest.mark.gpu
+
+
+def run_hip(inp, attrs, dev, a_tild=True):
+    from egt_amd import egt_attention, AttnConfig
+    cu = lambda t: None if t is None else t.to(dev)
+    QKV = cu(inp["QKV"]).requires_grad_()
+    E = cu(inp["E"]); G = cu(inp["G"])
+    if E is not None:
+        E.requires_grad_()
+    if G is not None:
+        G.requires_grad_()
+    stochastic = inp["rand_mask"] is not None or inp["drop_keep"] is not None
+    cfg = AttnConfig(num_heads=attrs["num_heads"], clip_logits_value=attrs["clip_logits_value"],
+                     scale_degree=attrs["scale_degree"], scaler_type=attrs["scaler_type"],
+                     num_virtual_nodes=attrs["num_virtual_nodes"],
+                     random_mask_prob=0.5 if inp["rand_mask"] is not None else 0.0,
+                     attn_dropout=attrs["attn_dropout"], training=stochastic, seed=7,
+                     need_a_tild=a_tild)
+    V, Hh, At = egt_attention(QKV, E, G, cu(inp["M"]), cu(inp["mask"]), cfg=cfg,
+                              rand_mask=cu(inp["rand_mask"]), drop_keep=cu(inp["drop_keep"]))
+    wrt = [t for t in (QKV, E, G) if t is not None]
+    grads = torch.autograd.grad((V * cu(inp["dV"])).sum() + (Hh * cu(inp["dH"])).sum(), wrt)
+    gi = iter(grads)
+    out = dict(V_att=V.detach(), H_hat=Hh.detach(), A_tild=At.detach(), dQKV=next(gi))
+    out["dE"] = next(gi) if E is not None else None
+    out["dG"] = next(gi) if G is not None else None
+    return out
+
+
+def compare(out, ref):
+    for k in ("V_att", "H_hat", "A_tild"):
+        assert_close(out[k], ref[k], name=k, **FWD)
+    for k in ("dQKV", "dE", "dG"):
+        if ref.get(k) is not None:
+            assert_close(out[k], ref[k], name=k, **BWD)
+
+
+@pytest.mark.parametrize("name", list(CS.ATTN_CASES))
+def test_attn_vs_oracle(name, gpu, egt_lib):
+    inp, attrs, _ = CS.make_attn_case(name)
+    compare(run_hip(inp, attrs, gpu), CS.attn_oracle(inp, attrs))
+
+
+@pytest.mark.parametrize("name", [n for n in CS.ATTN_CASES if n != "gated_n64"])
+def test_attn_vs_golden(name, gpu, egt_lib):
+    g = load_golden(os.path.join(CS.GOLDEN_DIR, f"attn_{name}.npz"))
+    inp, attrs, _ = CS.make_attn_case(name)
+    for k, v in g["in"].items():
+        assert np.array_equal(CS.to_np(inp[k]), v)
+    out = run_hip(inp, attrs, gpu)
+    compare(out, {k: torch.from_numpy(v) for k, v in g["out"].items()})
+
+
+def test_masked_positions_bit_exact_zero(gpu, egt_lib):
+    inp, attrs, _ = CS.make_attn_case("gated_d8_clip")
+    out = run_hip(inp, attrs, gpu)
+    pad = ~inp["mask"]
+    for b in range(pad.shape[0]):
+        assert (out["A_tild"][b][:, pad[b].to(gpu), :] == 0).all()
+        assert (out["dG"][b][:, pad[b].to(gpu), :] == 0).all()
+    inp, attrs, _ = CS.make_attn_case("gated_allmasked")
+    out = run_hip(inp, attrs, gpu)
+    assert (out["A_tild"][1] == 0).all() and (out["V_att"][1] == 0).all()
+
+
+def test_a_tild_optional(gpu, egt_lib):
+    inp, attrs, _ = CS.make_attn_case("gated_d8_clip")
+    a = run_hip(inp, attrs, gpu, a_tild=True)
+    b = run_hip(inp, attrs, gpu, a_tild=False)
+    assert b["A_tild"].numel() == 0
+    assert torch.equal(a["V_att"], b["V_att"]) and torch.equal(a["dQKV"], b["dQKV"])
+
+
+def test_layer_call_convention(gpu, egt_lib):
+    """EGT(...)([QKV,E,G,M], mask) with list-wrapped mask (egt_layers.py:62-66)."""
+    from egt_amd import EGT
+    inp, attrs, _ = CS.make_attn_case("constrained")
+    layer = EGT(num_heads=8, attn_mask=True, name="mha_00").to(gpu).eval()
+    V, Hh, At = layer([inp["QKV"].to(gpu), inp["E"].to(gpu), inp["G"].to(gpu), inp["M"].to(gpu)],
+                      mask=[inp["mask"].to(gpu)])
+    ref = CS.attn_oracle(inp, attrs)
+    assert_close(V, ref["V_att"], name="V_att", **FWD)
+    assert_close(At, ref["A_tild"], name="A_tild", **FWD)
+    assert layer.compute_mask(None, [inp["mask"]])[1:] == [None, None]
+    with pytest.raises(AssertionError):     # egt_layers.py:70
+        layer([torch.zeros(1, 4, 50, device=gpu)] + [torch.zeros(1, 4, 4, 8, device=gpu)] * 3)
+
+
+def test_device_rng_stream_bit_exact(gpu, egt_lib):
+    from egt_amd import mask_sample
+    from oracle import rng_ref
+    B, N, H = 3, 17, 8
+    for seed, p in ((0, 0.1), (0x1234567890ABCDEF, 0.1), (42, 0.37)):
+        dev = mask_sample(0, seed, p, B, N, H, gpu).cpu().numpy().astype(bool)
+        assert np.array_equal(dev, rng_ref.random_mask(seed, B, N, H, p))
+        devk = mask_sample(1, seed, p, B, N, H, gpu).cpu().numpy().astype(bool)
+        assert np.array_equal(devk, rng_ref.dropout_keep(seed, B, N, H, p))
+
+
+def test_in_kernel_random_mask_matches_injected(gpu, egt_lib):
+    """The in-kernel sample (seeded counter hash) gives the same result as
+    injecting the oracle-side replica of that sample."""
+    from egt_amd import egt_attention, AttnConfig
+    from oracle import rng_ref
+    inp, attrs, _ = CS.make_attn_case("gated_n64")
+    B, N, H = 2, 64, 8
+    seed, p, pd = 99, 0.1, 0.15
+    cfg = AttnConfig(random_mask_prob=p, attn_dropout=pd, training=True, seed=seed, need_a_tild=True)
+    cu = lambda t: t.to(gpu)
+    V, Hh, At = egt_attention(cu(inp["QKV"]), cu(inp["E"]), cu(inp["G"]), None, cu(inp["mask"]), cfg=cfg)
+    inp2 = dict(inp)
+    inp2["rand_mask"] = torch.from_numpy(rng_ref.random_mask(seed, B, N, H, p))
+    inp2["drop_keep"] = torch.from_numpy(rng_ref.dropout_keep(seed, B, N, H, pd))
+    attrs2 = dict(attrs, attn_dropout=pd)
+    ref = CS.attn_oracle(inp2, attrs2)
+    assert_close(V, ref["V_att"], name="V_att", **FWD)
+    assert_close(At, ref["A_tild"], name="A_tild", **FWD)
+    frac = inp2["rand_mask"].float().mean().item()
+    assert abs(frac - p) < 0.01
+    # eval mode: no mask
+    cfg_eval = AttnConfig(random_mask_prob=p, training=False, need_a_tild=True)
+    V2, _, _ = egt_attention(cu(inp["QKV"]), cu(inp["E"]), cu(inp["G"]), None, cu(inp["mask"]), cfg=cfg_eval)
+    assert_close(V2, CS.attn_oracle(inp, attrs)["V_att"], name="V_eval", **FWD)

@@ -1,0 +1,85 @@
+"""CPU checks of the C-ABI boundary: the library builds, loads, and exports every
+symbol include/egt_amd.h declares; argument validation runs without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(REPO, "include", "egt_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(egt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = declared_symbols()
+    for s in ("egt_attn_fwd", "egt_attn_bwd", "egt_edge_proj_fwd", "egt_edge_proj_bwd",
+              "egt_edge_update_fwd", "egt_edge_update_bwd", "egt_last_error_string"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol(egt_lib):
+    raw = C.CDLL(egt_lib._name)
+    missing = [s for s in declared_symbols() if not hasattr(raw, s)]
+    assert not missing, f"declared in include/egt_amd.h but not exported: {missing}"
+
+
+def test_ctypes_table_matches_header(egt_lib):
+    from egt_amd import _lib
+    table = set(_lib._PROTOS) | set(_lib._OPTIONAL_PROTOS)
+    assert set(declared_symbols()) <= table
+
+
+def test_argument_validation_without_gpu(egt_lib):
+    from egt_amd import _lib as L
+    d = L.AttnDesc(B=1, N=4, H=3, d=8, dtype=L.EGT_F32, flags=0)
+    rc = egt_lib.egt_attn_fwd(C.byref(d), *([None] * 12))
+    assert rc == L.EGT_E_SHAPE and b"power of two" in egt_lib.egt_last_error_string()
+    d = L.AttnDesc(B=1, N=4, H=8, d=8, dtype=L.EGT_F32, flags=L.F_SCALE_DEGREE)
+    assert egt_lib.egt_attn_fwd(C.byref(d), *([None] * 12)) == L.EGT_E_FLAGS
+    with pytest.raises(ValueError):
+        L.check(L.EGT_E_FLAGS)
+    d = L.AttnDesc(B=1, N=4, H=8, d=8, dtype=7, flags=0)
+    assert egt_lib.egt_attn_fwd(C.byref(d), *([None] * 12)) == L.EGT_E_DTYPE
+    d = L.AttnDesc(B=1, N=4, H=8, d=8, dtype=L.EGT_F32, flags=0)
+    assert egt_lib.egt_attn_fwd(C.byref(d), *([None] * 12)) == L.EGT_E_NULL
+    e = L.EdgeDesc(rows=10, De=24, H=8, dtype=L.EGT_F32, flags=0, act=0, act_alpha=0, ln_eps=1e-3)
+    assert egt_lib.egt_edge_update_fwd(C.byref(e), *([None] * 6)) == L.EGT_E_SHAPE
+
+
+def test_layer_constructor_errors_match_reference():
+    from egt_amd import EGT, EGTBlock
+    with pytest.raises(ValueError):           # egt_layers.py:20-21
+        EGT(scale_degree=True, gate_input=False)
+    with pytest.raises(ValueError):           # egt_layers.py:23-24
+        EGT(scaler_type="sqrt")
+    with pytest.raises(KeyError):             # graph_xformer_model_base.py:328-334
+        EGTBlock(edge_channel_type="bogus")
+    cfg = EGT(name="mha_00").get_config()
+    assert "attn_dropout" not in cfg and cfg["num_heads"] == 8
+
+
+def test_no_cpu_fallback():
+    import torch
+    from egt_amd import EGT
+    layer = EGT()
+    qkv = torch.zeros(1, 4, 3 * 8 * 8)
+    x = torch.zeros(1, 4, 4, 8)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        layer([qkv, x, x])
+
+
+def test_keras_parameter_names():
+    from egt_amd import EGTBlock
+    blk = EGTBlock(model_width=64, edge_width=64)
+    names = set(blk.keras_named_parameters("03"))
+    want = {f"{n}_03/{p}" for n, ps in dict(
+        norm_edge=("gamma", "beta"), attention_gates=("kernel", "bias"),
+        dense_edge_b=("kernel", "bias"), norm_mha=("gamma", "beta"),
+        dense_qkv=("kernel", "bias"), dense_mha=("kernel", "bias"),
+        dense_edge_r=("kernel", "bias")).items() for p in ps}
+    assert names == want
