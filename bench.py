@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""graphs/sec of the EGT attention-block stack, fwd+bwd, on MI355X.
+
+A "step" = one pass of the hot path over one batch of synthetic padded graphs:
+forward through Ly stacked (h,e,mask)->(h',e') blocks, backward from N(0,1)
+upstream gradients down to (dh, de) and every parameter gradient, and — for
+N>1 ranks — the single flat RCCL gradient all-reduce.  Inputs are resident in
+HBM before the timed region.  Workload = BASELINE.json configs[1]:
+ZINC-500K shapes (Dh=64, De=64, H=8, d=8, Ly=10), padded N=64, fp32, B=128
+graphs per GPU (weak scaling), node counts ~U[9,37], random_mask_prob=0.1.
+
+Usage: python bench.py --gpus N --steps K --warmup W
+(N>1: launched by torch.distributed.run, one rank per GPU).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "zinc500k_n64": dict(B=128, N=64, Dh=64, De=64, H=8, Ly=10, nodes=(9, 37), rand_p=0.1),
+    # BASELINE.json configs[3] shapes (PATTERN-500K), for reference runs
+    "pattern500k_n120": dict(B=16, N=120, Dh=64, De=8, H=8, Ly=16, nodes=(44, 120), rand_p=0.1),
+}
+
+
+def algorithmic_bytes(kernel: str, w: dict) -> float:
+    """ALGORITHMIC HBM bytes one launch of `kernel` must move (fp32, s=4): the
+    per-graph-per-layer figures of SURVEY §8(d) split per launch."""
+    B, N, Dh, De, H = w["B"], w["N"], w["Dh"], w["De"], w["H"]
+    pairs = B * N * N
+    s = 4
+    node = B * N * Dh * s
+    table = {
+        # fused block: fwd reads e, writes e' (+ node rows); bwd reads e, de', writes de
+        "k_block_fwd": pairs * De * s * 2 + 3 * node,
+        "k_block_bwd": pairs * De * s * 3 + 3 * node,
+        # composed path
+        "k_edge_proj_fwd": pairs * (De + 2 * H) * s,
+        "k_edge_proj_bwd": pairs * (2 * De + 2 * H) * s,
+        "k_edge_update_fwd": pairs * (2 * De + H) * s,
+        "k_edge_update_bwd": pairs * (De + 2 * H) * s,
+        "k_attn_fwd": pairs * 3 * H * s + 4 * node,
+        "k_attn_bwd_row": pairs * 7 * H * s + 4 * node,
+        "k_attn_bwd_dq": pairs * H * s + 2 * node,
+        "k_attn_bwd_dkv": pairs * 2 * H * s + 3 * node,
+    }
+    return float(table.get(kernel, 0.0))
+
+
+def make_inputs(w, dev, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    B, N, Dh, De = w["B"], w["N"], w["Dh"], w["De"]
+    lo, hi = w["nodes"]
+    n = torch.randint(lo, hi + 1, (B,), generator=g)
+    mask = torch.arange(N)[None, :] < n[:, None]
+    h = torch.randn(B, N, Dh, generator=g)
+    e = torch.randn(B, N, N, De, generator=g)
+    dh = torch.randn(B, N, Dh, generator=g)
+    de = torch.randn(B, N, N, De, generator=g)
+    return [t.to(dev) for t in (h, e, mask, dh, de)]
+
+
+def prof_read_all(lib):
+    buf = C.create_string_buffer(4096)
+    lib.egt_prof_names(buf, 4096)
+    out = {}
+    for name in buf.value.decode().split():
+        cnt, ms = C.c_int64(0), C.c_double(0.0)
+        lib.egt_prof_read(name.encode(), C.byref(cnt), C.byref(ms))
+        if cnt.value:
+            out[name] = (cnt.value, ms.value)
+    return out
+
+
+def cpu_baseline(w, seconds=12.0):
+    """Reference-equivalent CPU path: the torch-CPU fp32 op-by-op restatement of
+    the TF op sequence (oracle/egt_oracle.py), fwd+bwd by autograd, on the host
+    cores.  Bounded sample of the same workload (fewer graphs per batch)."""
+    from oracle import egt_oracle as O
+    Bs = 8
+    ws = dict(w, B=Bs)
+    h, e, mask, dh, de = make_inputs(ws, "cpu", seed=77)
+    g = torch.Generator().manual_seed(3)
+    layers = [{k: v.requires_grad_() for k, v in
+               O.init_block_params(w["Dh"], w["De"], w["H"], generator=g).items()}
+              for _ in range(w["Ly"])]
+    rms = [torch.rand(Bs, w["N"], w["N"], w["H"], generator=g) < w["rand_p"] for _ in range(w["Ly"])]
+    h.requires_grad_(); e.requires_grad_()
+    flat = [p for L_ in layers for p in L_.values()]
+
+    def step():
+        h2, e2 = O.stack_forward(h, e, mask, layers, num_heads=w["H"], rand_masks=rms)
+        torch.autograd.grad([h2, e2], [h, e] + flat, [dh, de])
+
+    step()  # warm
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        step()
+        reps += 1
+        if time.perf_counter() - t0 >= seconds:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=Bs * reps / dt, unit="graphs/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{reps} fwd+bwd steps of the Ly={w['Ly']} block stack on B={Bs} graphs "
+                       f"(N={w['N']}, fp32, torch-CPU restatement of the TF op sequence, "
+                       f"{dt:.1f}s, host has {os.cpu_count()} cpus)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="zinc500k_n64", choices=list(WORKLOADS))
+    ap.add_argument("--fused", default="auto", choices=["auto", "on", "off"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    from egt_amd import EGTStack, _lib
+    from egt_amd.dp import FlatGradAllReduce
+    lib = _lib.load()
+
+    w = WORKLOADS[args.workload]
+    torch.manual_seed(1234)  # same weights on every rank (replicated parameters)
+    fused = {"auto": "auto", "on": True, "off": False}[args.fused]
+    model = EGTStack(model_height=w["Ly"], model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"],
+                     random_mask_prob=w["rand_p"], seed=1, fused=fused).to(dev).train()
+    h, e, mask, dh, de = make_inputs(w, dev, seed=1234 + rank)  # each rank its own graphs
+    h.requires_grad_(); e.requires_grad_()
+    fa = FlatGradAllReduce(model.parameters())
+
+    def step():
+        fa.zero()
+        h.grad = None; e.grad = None
+        h2, e2 = model(h, e, mask)
+        torch.autograd.backward([h2, e2], [dh, de])
+        fa.all_reduce(average=True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_prof:
+        lib.egt_prof_enable(2)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.egt_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    prof = prof_read_all(lib) if not args.no_prof else {}
+    if rank == 0:
+        roof = None
+        if prof:
+            dom = max(prof, key=lambda k: prof[k][1])
+            cnt, ms = prof[dom]
+            avg_s = ms / cnt / 1e3
+            ab = algorithmic_bytes(dom, w)
+            ach = ab / avg_s / 1e9 if avg_s > 0 and ab > 0 else None
+            roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=(ach / HBM_PEAK_GBS) if ach else None, traffic=None,
+                        avg_launch_us=avg_s * 1e6, launches=cnt, algorithmic_bytes_per_launch=ab,
+                        kernels={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3,
+                                         share=v[1] / sum(x[1] for x in prof.values()))
+                                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(w, args.cpu_seconds)
+        graphs = world * w["B"] * args.steps
+        path = "fused" if any(k.startswith("k_block") for k in prof) else "composed"
+        line = {
+            "metric": "graphs/sec EGT fwd+bwd, ZINC-500K padded N=64",
+            "value": graphs / elapsed, "unit": "graphs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: attention-block stack (h,e,mask)->(h',e') x Ly, fwd+bwd "
+                                   f"+ param grads" + (" + flat RCCL grad all-reduce" if world > 1 else ""),
+                       "graphs_per_gpu": w["B"], "global_batch": w["B"] * world, "N": w["N"],
+                       "Dh": w["Dh"], "De": w["De"], "H": w["H"], "d": w["Dh"] // w["H"], "Ly": w["Ly"],
+                       "random_mask_prob": w["rand_p"], "nodes": list(w["nodes"]), "path": path,
+                       "parallelism": f"dp{world}", "grad_allreduce_bytes": fa.nbytes},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

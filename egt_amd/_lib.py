@@ -83,6 +83,9 @@ _PROTOS = {
     "egt_edge_update_fwd": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 6),
     "egt_edge_update_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(EdgeDesc)]),
     "egt_edge_update_bwd": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 8),
+    "egt_prof_enable": (C.c_int, [C.c_int]),
+    "egt_prof_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "egt_prof_names": (C.c_int, [C.c_char_p, C.c_size_t]),
 }
 # entry points added by later build stages; bound when present, listed here so the
 # "every declared symbol is exported" test sees one table
@@ -93,8 +96,6 @@ _OPTIONAL_PROTOS = {
     "egt_block_fwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams)] + [_VP] * 9),
     "egt_block_bwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams)] + [_VP] * 10
                       + [C.POINTER(BlockParams)] + [_VP] * 2),
-    "egt_prof_enable": (C.c_int, [C.c_int]),
-    "egt_prof_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
 
 

@@ -424,7 +424,7 @@ extern "C" int egt_attn_fwd(const egt_attn_desc* desc, const void* qkv, const vo
   const long rows = (long)a.B * a.N;
   dim3 grid((unsigned)((rows + waves - 1) / waves)), block(64 * waves);
   (void)hipFuncSetAttribute((const void*)k_attn_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(k_attn_fwd, grid, block, lds, (hipStream_t)stream, a);
+  EGT_LAUNCH("k_attn_fwd", k_attn_fwd, grid, block, lds, (hipStream_t)stream, a);
   EGT_HIP_LAUNCH_CHECK("egt_attn_fwd");
   return EGT_OK;
 }
@@ -470,12 +470,12 @@ extern "C" int egt_attn_bwd(const egt_attn_desc* desc, const void* qkv, const vo
   const long rows = (long)a.B * a.N;
   dim3 grid((unsigned)((rows + waves - 1) / waves)), block(64 * waves);
   (void)hipFuncSetAttribute((const void*)k_attn_bwd_row, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(k_attn_bwd_row, grid, block, lds, (hipStream_t)stream, a);
+  EGT_LAUNCH("k_attn_bwd_row", k_attn_bwd_row, grid, block, lds, (hipStream_t)stream, a);
   EGT_HIP_LAUNCH_CHECK("egt_attn_bwd(row)");
   dim3 grid4((unsigned)((rows + 3) / 4)), block4(256);
-  hipLaunchKernelGGL(k_attn_bwd_dq, grid4, block4, 0, (hipStream_t)stream, a);
+  EGT_LAUNCH("k_attn_bwd_dq", k_attn_bwd_dq, grid4, block4, 0, (hipStream_t)stream, a);
   EGT_HIP_LAUNCH_CHECK("egt_attn_bwd(dq)");
-  hipLaunchKernelGGL(k_attn_bwd_dkv, grid4, block4, 0, (hipStream_t)stream, a);
+  EGT_LAUNCH("k_attn_bwd_dkv", k_attn_bwd_dkv, grid4, block4, 0, (hipStream_t)stream, a);
   EGT_HIP_LAUNCH_CHECK("egt_attn_bwd(dkv)");
   return EGT_OK;
 }
@@ -486,7 +486,7 @@ extern "C" int egt_mask_sample(int which, uint64_t seed, float prob, int32_t B, 
   if (which != 0 && which != 1) EGT_FAIL(EGT_E_FLAGS, "which must be 0 or 1");
   const size_t n = (size_t)B * N * N * H;
   if (n > 0xFFFFFFFFull) EGT_FAIL(EGT_E_SHAPE, "B*N*N*H exceeds the 32-bit RNG counter");
-  hipLaunchKernelGGL(k_mask_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+  EGT_LAUNCH("k_mask_sample", k_mask_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, which, (uint32_t)(seed & 0xFFFFFFFFull),
                      (uint32_t)(seed >> 32), egt_threshold24(prob), n, out);
   EGT_HIP_LAUNCH_CHECK("egt_mask_sample");

@@ -1,7 +1,8 @@
-// C-ABI plumbing: per-thread error string, version, kernel timing hooks.
+// C-ABI plumbing: per-thread error string, version, per-kernel HIP-event timing.
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -19,3 +20,92 @@ void egt_set_error(const char* fmt, ...) {
 
 extern "C" const char* egt_last_error_string(void) { return g_err; }
 extern "C" int egt_abi_version(void) { return EGT_ABI_VERSION; }
+
+// ---- kernel timing hooks (bench.py's roofline leg) ----------------------------
+// When enabled, every launch site brackets its kernel with hipEvents recorded on
+// the launch stream; egt_prof_read() resolves them (after the caller has synced).
+namespace {
+struct ProfEntry {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  int64_t count = 0;
+  double ms = 0.0;
+};
+std::mutex g_mu;
+int g_enabled = 0;
+std::unordered_map<std::string, ProfEntry> g_prof;
+std::vector<hipEvent_t> g_pool;
+
+hipEvent_t get_event() {
+  if (!g_pool.empty()) {
+    hipEvent_t e = g_pool.back();
+    g_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+
+int egt_prof_is_enabled() { return g_enabled; }
+
+void egt_prof_begin(const char* name, hipStream_t s, void** tok) {
+  *tok = nullptr;
+  if (!g_enabled) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipEvent_t a = get_event(), b = get_event();
+  (void)hipEventRecord(a, s);
+  auto& e = g_prof[name];
+  e.pending.emplace_back(a, b);
+  *tok = (void*)b;
+}
+
+void egt_prof_end(void* tok, hipStream_t s) {
+  if (tok) (void)hipEventRecord((hipEvent_t)tok, s);
+}
+
+extern "C" int egt_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_enabled = on ? 1 : 0;
+  if (on == 2) {  // reset
+    for (auto& kv : g_prof) {
+      for (auto& p : kv.second.pending) { g_pool.push_back(p.first); g_pool.push_back(p.second); }
+    }
+    g_prof.clear();
+    g_enabled = 1;
+  }
+  return EGT_OK;
+}
+
+// name == NULL: *count receives the number of distinct kernels; otherwise the
+// launch count and summed milliseconds of kernel `name`.  Caller must have
+// synchronised the stream(s).
+extern "C" int egt_prof_read(const char* name, int64_t* count, double* total_ms) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!count || !total_ms) EGT_FAIL(EGT_E_NULL, "count/total_ms is NULL");
+  if (!name) { *count = (int64_t)g_prof.size(); *total_ms = 0; return EGT_OK; }
+  auto it = g_prof.find(name);
+  if (it == g_prof.end()) { *count = 0; *total_ms = 0; return EGT_OK; }
+  auto& e = it->second;
+  for (auto& p : e.pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { e.ms += ms; e.count += 1; }
+    g_pool.push_back(p.first);
+    g_pool.push_back(p.second);
+  }
+  e.pending.clear();
+  *count = e.count;
+  *total_ms = e.ms;
+  return EGT_OK;
+}
+
+// kernel names recorded so far, '\n'-separated, into buf
+extern "C" int egt_prof_names(char* buf, size_t cap) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!buf || !cap) EGT_FAIL(EGT_E_NULL, "buf is NULL");
+  std::string s;
+  for (auto& kv : g_prof) { s += kv.first; s += '\n'; }
+  strncpy(buf, s.c_str(), cap - 1);
+  buf[cap - 1] = 0;
+  return EGT_OK;
+}

@@ -51,3 +51,22 @@ __device__ __forceinline__ float egt_sigmoid(float x) {
 }
 
 __device__ __forceinline__ float wave_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
+
+// ---- kernel timing hooks (egt_capi.hip) ---------------------------------------
+int egt_prof_is_enabled();
+void egt_prof_begin(const char* name, hipStream_t s, void** tok);
+void egt_prof_end(void* tok, hipStream_t s);
+struct EgtProfScope {
+  void* tok = nullptr;
+  hipStream_t s;
+  EgtProfScope(const char* name, hipStream_t st) : s(st) {
+    if (egt_prof_is_enabled()) egt_prof_begin(name, st, &tok);
+  }
+  ~EgtProfScope() { egt_prof_end(tok, s); }
+};
+
+#define EGT_LAUNCH(name, kernel, grid, block, lds, stream, ...)            \
+  do {                                                                      \
+    EgtProfScope ps__(name, stream);                                        \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);      \
+  } while (0)

@@ -424,7 +424,7 @@ extern "C" int egt_edge_proj_fwd(const egt_edge_desc* desc, const void* e, const
   DISPATCH_DE(desc->De, {
     const size_t lds = (size_t)TILE_ROWS * (DE + 1) * 4;
     (void)hipFuncSetAttribute((const void*)k_edge_proj_fwd<DE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(k_edge_proj_fwd<DE>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    EGT_LAUNCH("k_edge_proj_fwd", k_edge_proj_fwd<DE>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
   });
   EGT_HIP_LAUNCH_CHECK("egt_edge_proj_fwd");
   return EGT_OK;
@@ -459,8 +459,8 @@ extern "C" int egt_edge_proj_bwd(const egt_edge_desc* desc, const void* e, const
   DISPATCH_DE(desc->De, {
     const size_t lds = (size_t)TILE_ROWS * (DE + 1 + 17) * 4;
     (void)hipFuncSetAttribute((const void*)k_edge_proj_bwd<DE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(k_edge_proj_bwd<DE>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
-    hipLaunchKernelGGL(k_edge_proj_bwd_final<DE>, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    EGT_LAUNCH("k_edge_proj_bwd", k_edge_proj_bwd<DE>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    EGT_LAUNCH("k_edge_proj_bwd_final", k_edge_proj_bwd_final<DE>, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   });
   EGT_HIP_LAUNCH_CHECK("egt_edge_proj_bwd");
   return EGT_OK;
@@ -478,7 +478,7 @@ extern "C" int egt_edge_update_fwd(const egt_edge_desc* desc, const void* e, con
   size_t g = (total + 255) / 256;
   if (g > 8192) g = 8192;
   DISPATCH_DE(desc->De, {
-    hipLaunchKernelGGL(k_edge_update_fwd<DE>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
+    EGT_LAUNCH("k_edge_update_fwd", k_edge_update_fwd<DE>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
   });
   EGT_HIP_LAUNCH_CHECK("egt_edge_update_fwd");
   return EGT_OK;
@@ -504,8 +504,8 @@ extern "C" int egt_edge_update_bwd(const egt_edge_desc* desc, const void* d_e_ou
   DISPATCH_DE(desc->De, {
     const size_t lds = (size_t)TILE_ROWS * (DE + 1 + 9) * 4;
     (void)hipFuncSetAttribute((const void*)k_edge_update_bwd<DE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(k_edge_update_bwd<DE>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
-    hipLaunchKernelGGL(k_edge_update_bwd_final<DE>, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    EGT_LAUNCH("k_edge_update_bwd", k_edge_update_bwd<DE>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    EGT_LAUNCH("k_edge_update_bwd_final", k_edge_update_bwd_final<DE>, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   });
   EGT_HIP_LAUNCH_CHECK("egt_edge_update_bwd");
   return EGT_OK;

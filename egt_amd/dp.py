@@ -1,0 +1,70 @@
+"""Batch data parallelism for the EGT attention path — one process per GPU.
+
+The reference's only parallelism is tf.distribute.MirroredStrategy
+(lib/training/training_base.py:230-247): synchronous single-node DP whose one
+collective is the per-step gradient all-reduce.  Here: graphs are independent
+units, so the global batch is sharded into contiguous slices per rank (no
+data-path collective) and the gradients of all parameters live in ONE flat
+contiguous fp32 buffer that is all-reduced once per step over RCCL/xGMI
+(torch.distributed backend "nccl" on ROCm; "gloo" in the CPU tests).  The
+payload is <= ~2.2 MB, i.e. latency-bound — a single collective, no bucketing.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+import torch.distributed as dist
+
+
+def shard_batch(n_graphs: int, world_size: int, rank: int):
+    """Contiguous slice [lo, hi) of the global batch owned by `rank` (Keras splits
+    the global batch across replicas; sizes differ by at most one)."""
+    base, rem = divmod(n_graphs, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class FlatGradAllReduce:
+    """Owns one flat gradient buffer aliasing every parameter's .grad."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, device=dev, dtype=dt)
+        self.group = process_group
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    @property
+    def nbytes(self) -> int:
+        return self.flat.numel() * self.flat.element_size()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def rebind(self):
+        """Re-alias .grad after something replaced it (e.g. zero_grad(set_to_none))."""
+        off = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != self.flat[off:].data_ptr():
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def all_reduce(self, average: bool = True):
+        """Sum over ranks, then /world: the loss is a mean over the GLOBAL batch
+        (MirroredStrategy semantics)."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return self.flat
+        ws = dist.get_world_size(self.group)
+        if ws == 1:
+            return self.flat
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if average:
+            self.flat.div_(ws)
+        return self.flat

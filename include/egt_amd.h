@@ -163,6 +163,15 @@ int egt_edge_update_bwd(const egt_edge_desc* desc, const void* d_e_out,
                         const void* h_hat, const void* Wr, void* d_h_hat,
                         void* d_Wr, void* d_br, void* workspace, void* stream);
 
+/* ---- per-kernel timing (measurement only) ------------------------------------
+ * egt_prof_enable(1) makes every launch site bracket its kernel with hipEvents
+ * on the launch stream (2 = reset counters and enable, 0 = off).  After the
+ * caller has synchronised, egt_prof_read(name, ...) returns the launch count
+ * and summed milliseconds of kernel `name`; egt_prof_names lists the names. */
+int egt_prof_enable(int on);
+int egt_prof_read(const char* name, int64_t* count, double* total_ms);
+int egt_prof_names(char* buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,102 @@
+"""world_size-2 gloo tests of the data-parallel plumbing on CPU: batch sharding
+with no data-path collective + one flat gradient all-reduce reproduces the
+full-batch gradient.  Per-rank gradients come from the CPU oracle (the HIP
+kernels need a GPU); what is under test is egt_amd.dp."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from egt_amd.dp import FlatGradAllReduce, shard_batch
+        from oracle import egt_oracle as O
+        torch.manual_seed(0)
+        Bg, N, Dh, De, H = 6, 5, 16, 8, 8
+        g = torch.Generator().manual_seed(5)
+        h = torch.randn(Bg, N, Dh, generator=g, dtype=torch.float64)
+        e = torch.randn(Bg, N, N, De, generator=g, dtype=torch.float64)
+        mask = torch.ones(Bg, N, dtype=torch.bool)
+        mask[:, 4:] = False
+        params = O.init_block_params(Dh, De, H, dtype=torch.float64, generator=g, randomize_norm=True)
+
+        def grads(lo, hi, denom):
+            ps = {k: torch.nn.Parameter(v.clone()) for k, v in params.items()}
+            h2, e2 = O.block_forward(h[lo:hi], e[lo:hi], mask[lo:hi], ps, num_heads=H)
+            loss = (h2.pow(2).sum() + e2.pow(2).sum()) / denom   # mean over the GLOBAL batch
+            return ps, loss
+
+        lo, hi = shard_batch(Bg, world, rank)
+        ps, loss = grads(lo, hi, Bg)
+        fa = FlatGradAllReduce(ps.values())
+        loss.backward()
+        # per-rank loss is scaled by 1/Bg, so SUM over ranks is the global gradient
+        fa.all_reduce(average=False)
+        ps_full, loss_full = grads(0, Bg, Bg)
+        loss_full.backward()
+        err = max(float((a.grad - b.grad).abs().max()) for a, b in zip(ps.values(), ps_full.values()))
+        # average=True semantics: mean of per-rank grads
+        fa2 = FlatGradAllReduce([torch.nn.Parameter(torch.full((3,), float(rank + 1)))])
+        fa2.flat.copy_(torch.full((3,), float(rank + 1)))
+        fa2.all_reduce(average=True)
+        q.put((rank, lo, hi, err, fa2.flat.tolist(), fa.nbytes))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_gloo_ws2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [(r[1], r[2]) for r in res] == [(0, 3), (3, 6)]
+    for r in res:
+        assert r[3] < 1e-12, f"rank {r[0]} grad mismatch {r[3]}"
+        assert r[4] == [1.5, 1.5, 1.5]
+
+
+def test_shard_batch_covers_everything():
+    from egt_amd.dp import shard_batch
+    for n in (1, 7, 128, 130):
+        for w in (1, 2, 3, 8):
+            spans = [shard_batch(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_flat_buffer_aliases_grads():
+    from egt_amd.dp import FlatGradAllReduce
+    ps = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5))]
+    fa = FlatGradAllReduce(ps)
+    (ps[0].sum() * 2 + ps[1].sum() * 3).backward()
+    assert torch.equal(fa.flat, torch.cat([torch.full((12,), 2.0), torch.full((5,), 3.0)]))
+    assert fa.nbytes == 17 * 4
+    fa.zero()
+    assert float(ps[0].grad.abs().sum()) == 0.0
