@@ -93,7 +93,7 @@ _OPTIONAL_PROTOS = {
     "egt_block_supported": (C.c_int, [C.POINTER(BlockDesc)]),
     "egt_block_saved_bytes": (C.c_size_t, [C.POINTER(BlockDesc)]),
     "egt_block_workspace_bytes": (C.c_size_t, [C.POINTER(BlockDesc)]),
-    "egt_block_fwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams)] + [_VP] * 9),
+    "egt_block_fwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams)] + [_VP] * 10),
     "egt_block_bwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams)] + [_VP] * 10
                       + [C.POINTER(BlockParams)] + [_VP] * 2),
 }

@@ -1,0 +1,121 @@
+"""Fused attention block: one C-ABI call per layer per direction
+(egt_block_fwd / egt_block_bwd in include/egt_amd.h)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .functional import _f32c, _u8c, _need_gpu
+
+_GRAD_ORDER = (("norm_edge", "gamma"), ("norm_edge", "beta"),
+               ("attention_gates", "kernel"), ("attention_gates", "bias"),
+               ("dense_edge_b", "kernel"), ("dense_edge_b", "bias"),
+               ("norm_mha", "gamma"), ("norm_mha", "beta"),
+               ("dense_qkv", "kernel"), ("dense_qkv", "bias"),
+               ("dense_mha", "kernel"), ("dense_mha", "bias"),
+               ("dense_edge_r", "kernel"), ("dense_edge_r", "bias"))
+
+
+def _desc(blk, B, N, training, seed) -> L.BlockDesc:
+    flags = 0
+    if blk.gated:
+        flags |= L.BF_GATE
+    if blk.edge_channel_type == "constrained":
+        flags |= L.BF_ATTN_MASK
+    if training:
+        flags |= L.BF_TRAINING
+    lo = hi = 0.0
+    if blk.mha.clip_logits_value is not None:
+        flags |= L.BF_CLIP
+        lo, hi = float(blk.mha.clip_logits_value[0]), float(blk.mha.clip_logits_value[1])
+    return L.BlockDesc(B=B, N=N, H=blk.num_heads, d=blk.model_width // blk.num_heads,
+                       De=blk.edge_width, dtype=L.EGT_F32, flags=flags, clip_lo=lo, clip_hi=hi,
+                       random_mask_prob=float(blk.mha.random_mask_prob), ln_eps=1e-3, reserved=0,
+                       seed=int(seed) & 0xFFFFFFFFFFFFFFFF)
+
+
+def block_supported(blk, h, e, attn_mask, rand_mask) -> bool:
+    """Configurations the fused kernels cover (everything else composes)."""
+    if blk.edge_channel_type not in ("residual", "constrained"):
+        return False
+    if blk.add_n_norm or blk.edge_activation is not None:
+        return False
+    if blk.mha.scale_degree or blk.mha.attn_dropout > 0 or blk.mha.num_virtual_nodes > 0:
+        return False
+    if blk.training and (blk.node_dropout > 0 or blk.edge_dropout > 0):
+        return False
+    if blk.edge_channel_type == "constrained" and attn_mask is None:
+        return False
+    if not (h.is_cuda and e.is_cuda) or h.dtype != torch.float32 or e.dtype != torch.float32:
+        return False
+    if blk.model_width % blk.num_heads:
+        return False
+    lib = L.load()
+    if not hasattr(lib, "egt_block_fwd"):
+        return False
+    d = _desc(blk, h.shape[0], h.shape[1], False, 0)
+    return bool(lib.egt_block_supported(C.byref(d)))
+
+
+def _params_struct(tensors) -> L.BlockParams:
+    st = L.BlockParams()
+    for name, t in zip(L.BLOCK_PARAM_FIELDS, tensors):
+        setattr(st, name, None if t is None else t.data_ptr())
+    return st
+
+
+class _FusedBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, e, key_mask, attn_mask, rand_mask, desc, *params):
+        _need_gpu(h, e)
+        lib = L.load()
+        h = _f32c(h); e = _f32c(e)
+        key_mask = _u8c(key_mask); rand_mask = _u8c(rand_mask)
+        attn_mask = None if attn_mask is None else _f32c(attn_mask.to(torch.float32))
+        params = tuple(None if p is None else _f32c(p) for p in params)
+        dev = h.device
+        h_out = torch.empty_like(h)
+        e_out = torch.empty_like(e)
+        saved = torch.empty(lib.egt_block_saved_bytes(C.byref(desc)), dtype=torch.uint8, device=dev)
+        ws = torch.empty(lib.egt_block_workspace_bytes(C.byref(desc)), dtype=torch.uint8, device=dev)
+        pst = _params_struct(params)
+        L.check(lib.egt_block_fwd(C.byref(desc), C.byref(pst), L.ptr(h), L.ptr(e), L.ptr(key_mask),
+                                  L.ptr(attn_mask), L.ptr(rand_mask), L.ptr(h_out), L.ptr(e_out),
+                                  L.ptr(saved), L.ptr(ws), L.current_stream()))
+        ctx.desc = desc
+        ctx.nparams = len(params)
+        ctx.save_for_backward(h, e, key_mask, attn_mask, rand_mask, saved, *params)
+        return h_out, e_out
+
+    @staticmethod
+    def backward(ctx, dh_out, de_out):
+        lib = L.load()
+        h, e, key_mask, attn_mask, rand_mask, saved, *params = ctx.saved_tensors
+        desc = ctx.desc
+        dev = h.device
+        dh_out = _f32c(dh_out); de_out = _f32c(de_out)
+        dh = torch.empty_like(h)
+        de = torch.empty_like(e)
+        grads = [None if p is None else torch.empty_like(p) for p in params]
+        ws = torch.empty(lib.egt_block_workspace_bytes(C.byref(desc)), dtype=torch.uint8, device=dev)
+        pst, gst = _params_struct(params), _params_struct(grads)
+        L.check(lib.egt_block_bwd(C.byref(desc), C.byref(pst), L.ptr(h), L.ptr(e), L.ptr(key_mask),
+                                  L.ptr(attn_mask), L.ptr(rand_mask), L.ptr(saved), L.ptr(dh_out),
+                                  L.ptr(de_out), L.ptr(dh), L.ptr(de), C.byref(gst), L.ptr(ws),
+                                  L.current_stream()))
+        return (dh, de, None, None, None, None, *grads)
+
+
+def block_fused(blk, h, e, mask, attn_mask, rand_mask=None):
+    training = blk.training and blk.mha.random_mask_prob > 0.0
+    seed = blk.mha.next_seed() if (training and rand_mask is None) else 0
+    desc = _desc(blk, h.shape[0], h.shape[1], training, seed)
+    params = []
+    for mod, attr in _GRAD_ORDER:
+        m = getattr(blk, mod, None)
+        params.append(None if m is None else getattr(m, attr))
+    if blk.edge_channel_type != "constrained":
+        attn_mask = None
+    return _FusedBlock.apply(h, e, mask, attn_mask, rand_mask, desc, *params)

@@ -221,7 +221,7 @@ class EGTBlock(nn.Module):
             return h, e
         if self._use_fused(h, e, attn_mask, rand_mask):
             from .fused import block_fused
-            return block_fused(self, h, e, mask, attn_mask)
+            return block_fused(self, h, e, mask, attn_mask, rand_mask)
         use_ln = ect in ('residual', 'constrained') and not self.add_n_norm
         ne = getattr(self, 'norm_edge', None)
         ag = getattr(self, 'attention_gates', None)

@@ -163,6 +163,75 @@ int egt_edge_update_bwd(const egt_edge_desc* desc, const void* d_e_out,
                         const void* h_hat, const void* Wr, void* d_h_hat,
                         void* d_Wr, void* d_br, void* workspace, void* stream);
 
+/* ---- outer op: the fused attention block (the data-parallel hot path) ---------
+ *   (h', e') = edge_update_residual(h, e) with mha_block inside, pre-norm
+ * Replaces graph_xformer_model_base.py:192-223 + :106-145 for
+ * edge_channel_type 'residual' / 'constrained' (add_n_norm=False, no dropout,
+ * scale_degree=False): norm_edge -> attention_gates / dense_edge_b -> norm_mha ->
+ * dense_qkv -> EGT -> dense_mha + res_mha ; dense_edge_r + res_edge.
+ * One launch streams e once: LN, the two De->H projections, QK^T, clip, +E,
+ * masks, softmax x sigmoid gate, A.V and e' = e + H_hat.Wr + br never leave the
+ * CU (E, G, H_hat, A_tild are not materialised).  Everything else (other
+ * variants, dropout, degree scalers, d > 8) composes the kernels above.
+ * Parameter pointers carry the reference's Keras layer names. */
+#define EGT_BF_GATE 0x1u      /* gate_attention                                  */
+#define EGT_BF_ATTN_MASK 0x2u /* 'constrained': attn_mask [B,N,N,H] fp32 present */
+#define EGT_BF_TRAINING 0x4u  /* random attention mask active                    */
+#define EGT_BF_CLIP 0x8u      /* clip_logits_value is not None                   */
+
+typedef struct egt_block_desc {
+  int32_t B, N, H, d, De;   /* model_width Dh = d*H                             */
+  int32_t dtype;            /* EGT_F32                                          */
+  uint32_t flags;           /* EGT_BF_*                                         */
+  float clip_lo, clip_hi;
+  float random_mask_prob;
+  float ln_eps;             /* 1e-3                                             */
+  int32_t reserved;
+  uint64_t seed;
+} egt_block_desc;
+
+typedef struct egt_block_params {
+  const void* norm_edge_gamma;        /* [De]      norm_edge_XX/gamma            */
+  const void* norm_edge_beta;         /* [De]                                    */
+  const void* attention_gates_kernel; /* [De,H]    attention_gates_XX            */
+  const void* attention_gates_bias;   /* [H]                                     */
+  const void* dense_edge_b_kernel;    /* [De,H]    dense_edge_b_XX               */
+  const void* dense_edge_b_bias;      /* [H]                                     */
+  const void* norm_mha_gamma;         /* [Dh]      norm_mha_XX                   */
+  const void* norm_mha_beta;          /* [Dh]                                    */
+  const void* dense_qkv_kernel;       /* [Dh,3Dh]  dense_qkv_XX                  */
+  const void* dense_qkv_bias;         /* [3Dh]                                   */
+  const void* dense_mha_kernel;       /* [Dh,Dh]   dense_mha_XX                  */
+  const void* dense_mha_bias;         /* [Dh]                                    */
+  const void* dense_edge_r_kernel;    /* [H,De]    dense_edge_r_XX               */
+  const void* dense_edge_r_bias;      /* [De]                                    */
+} egt_block_params;
+
+/* 1 when the fused kernels cover `desc`, else 0 (caller composes instead). */
+int egt_block_supported(const egt_block_desc* desc);
+/* bytes of the forward->backward buffer (V_att, softmax row statistics, packed
+ * Q/K/V) and of the scratch workspace (max of forward and backward needs). */
+size_t egt_block_saved_bytes(const egt_block_desc* desc);
+size_t egt_block_workspace_bytes(const egt_block_desc* desc);
+
+/* rand_mask: optional injected sample ([B,N,N,H] uint8, 1 = masked) as in
+ * egt_attn_fwd; NULL => in-kernel counter hash when TRAINING and prob > 0. */
+int egt_block_fwd(const egt_block_desc* desc, const egt_block_params* params,
+                  const void* h, const void* e, const uint8_t* key_mask,
+                  const void* attn_mask, const uint8_t* rand_mask, void* h_out,
+                  void* e_out, void* saved, void* workspace, void* stream);
+
+/* Backward.  h, e are the block's INPUTS (nothing else of size [B,N,N,*] is
+ * kept: LN, projections, logits and softmax are recomputed from e).  d_e may
+ * alias d_e_out.  Every pointer of `grads` (same layout as the params, but
+ * writable) is written. */
+int egt_block_bwd(const egt_block_desc* desc, const egt_block_params* params,
+                  const void* h, const void* e, const uint8_t* key_mask,
+                  const void* attn_mask, const uint8_t* rand_mask,
+                  const void* saved, const void* d_h_out, const void* d_e_out,
+                  void* d_h, void* d_e, const egt_block_params* grads,
+                  void* workspace, void* stream);
+
 /* ---- per-kernel timing (measurement only) ------------------------------------
  * egt_prof_enable(1) makes every launch site bracket its kernel with hipEvents
  * on the launch stream (2 = reset counters and enable, 0 = off).  After the

@@ -79,3 +79,67 @@ def test_block_composed_vs_golden(name, gpu, egt_lib):
     ref = {k: torch.from_numpy(v) for k, v in g["out"].items()}
     ref.setdefault("de", None)
     compare(out, dparams, ref, {k: torch.from_numpy(v) for k, v in g["dparams"].items()})
+
+
+FUSED_CASES = ["residual_zinc500k", "residual_zinc100k", "residual_pattern", "residual_randmask",
+               "constrained", "ungated_residual", "residual_n64"]
+
+
+@pytest.mark.parametrize("name", FUSED_CASES)
+def test_block_fused_vs_oracle(name, gpu, egt_lib):
+    out, dparams, (inp, params, attrs) = run_block(name, gpu, fused=True)
+    ref = CS.block_oracle(inp, params, attrs)
+    compare(out, dparams, ref, ref.pop("dparams"))
+
+
+@pytest.mark.parametrize("name", [n for n in FUSED_CASES if n != "residual_n64"])
+def test_block_fused_vs_golden(name, gpu, egt_lib):
+    g = load_golden(os.path.join(CS.GOLDEN_DIR, f"block_{name}.npz"))
+    out, dparams, _ = run_block(name, gpu, fused=True)
+    ref = {k: torch.from_numpy(v) for k, v in g["out"].items()}
+    compare(out, dparams, ref, {k: torch.from_numpy(v) for k, v in g["dparams"].items()})
+
+
+def test_fused_refuses_uncovered_config(gpu, egt_lib):
+    from egt_amd import EGTBlock
+    blk = EGTBlock(model_width=64, edge_width=16, edge_channel_type="bias", fused=True).to(gpu)
+    with pytest.raises(RuntimeError, match="not covered"):
+        blk(torch.zeros(1, 4, 64, device=gpu), torch.zeros(1, 4, 4, 16, device=gpu))
+
+
+def test_fused_in_kernel_random_mask(gpu, egt_lib):
+    """Training-mode fused block with the in-kernel counter-hash mask == composed
+    block fed the oracle-side replica of that mask; backward reuses the sample."""
+    from egt_amd import EGTBlock
+    from oracle import rng_ref
+    inp, params, attrs, c = CS.make_block_case("residual_n64")
+    p = 0.1
+    blk = build_block(dict(c, rand_p=p), attrs, params, gpu, fused=True)
+    blk.mha.random_mask_prob = p
+    blk.train()
+    cu = lambda t: None if t is None else t.to(gpu)
+    h = cu(inp["h"]).requires_grad_(); e = cu(inp["e"]).requires_grad_()
+    h2, e2 = blk(h, e, cu(inp["mask"]))
+    seed = (blk.mha.seed * 0x9E3779B97F4A7C15 + blk.mha._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    (h2 * cu(inp["dh"])).sum().add((e2 * cu(inp["de"])).sum()).backward()
+    inp2 = dict(inp)
+    inp2["rand_mask"] = torch.from_numpy(rng_ref.random_mask(seed, c["B"], c["N"], 8, p))
+    ref = CS.block_oracle(inp2, params, attrs)
+    assert_close(h2, ref["h_out"], name="h_out", **FWD)
+    assert_close(e2, ref["e_out"], name="e_out", **FWD)
+    assert_close(e.grad, ref["de"], name="de", **BWD)
+    assert_close(h.grad, ref["dh"], name="dh", **BWD)
+
+
+def test_fused_stack_matches_composed(gpu, egt_lib):
+    from egt_amd import EGTStack
+    torch.manual_seed(3)
+    kw = dict(model_height=3, model_width=64, edge_width=64, num_heads=8)
+    a = EGTStack(fused=True, **kw).to(gpu).eval()
+    b = EGTStack(fused=False, **kw).to(gpu).eval()
+    b.load_state_dict(a.state_dict())
+    h = torch.randn(2, 24, 64, device=gpu); e = torch.randn(2, 24, 24, 64, device=gpu)
+    mask = torch.ones(2, 24, dtype=torch.bool, device=gpu); mask[1, 17:] = False
+    (h1, e1), (h2, e2) = a(h, e, mask), b(h, e, mask)
+    assert_close(h1, h2, name="h", rtol=1e-4, arel=5e-5)
+    assert_close(e1, e2, name="e", rtol=1e-4, arel=5e-5)

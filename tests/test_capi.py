@@ -18,7 +18,8 @@ def declared_symbols():
 def test_header_declares_expected_entry_points():
     syms = declared_symbols()
     for s in ("egt_attn_fwd", "egt_attn_bwd", "egt_edge_proj_fwd", "egt_edge_proj_bwd",
-              "egt_edge_update_fwd", "egt_edge_update_bwd", "egt_last_error_string"):
+              "egt_edge_update_fwd", "egt_edge_update_bwd", "egt_block_fwd", "egt_block_bwd",
+              "egt_last_error_string"):
         assert s in syms
 
 
@@ -31,7 +32,7 @@ def test_library_exports_every_declared_symbol(egt_lib):
 def test_ctypes_table_matches_header(egt_lib):
     from egt_amd import _lib
     table = set(_lib._PROTOS) | set(_lib._OPTIONAL_PROTOS)
-    assert set(declared_symbols()) <= table
+    assert set(declared_symbols()) == table
 
 
 def test_argument_validation_without_gpu(egt_lib):
