@@ -960,12 +960,12 @@ __global__ void __launch_bounds__(256) k_edge_param_grads(BlockArgs a) {
   for (int idx = threadIdx.x; idx < DE * 16; idx += 256) {
     const int c = idx >> 4, i = idx & 15, hd = col_head(i);
     const float v = a.ne_g[c] * T[c * 16 + i] + a.ne_b[c] * s[i];
-    if (col_is_gate(i)) a.g_Wg[c * BH + hd] = gated ? v : 0.f;
+    if (col_is_gate(i)) { if (gated) a.g_Wg[c * BH + hd] = v; }
     else a.g_We[c * BH + hd] = v;
   }
   if (threadIdx.x < 16) {
     const int i = threadIdx.x, hd = col_head(i);
-    if (col_is_gate(i)) a.g_bg[hd] = gated ? s[i] : 0.f;
+    if (col_is_gate(i)) { if (gated) a.g_bg[hd] = s[i]; }
     else a.g_be[hd] = s[i];
   }
   for (int c = threadIdx.x; c < DE; c += 256) {
