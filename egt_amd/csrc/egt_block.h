@@ -1,0 +1,61 @@
+// Shared declarations of the fused attention-block path (egt_block.hip: pair
+// kernels; egt_node.hip: node-side kernels, partial reductions, parameter grads).
+#pragma once
+#include "egt_common.h"
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+#define BH 8        // heads (all reference configs)
+#define QKVP 192    // packed floats per node row: [3][4 head-pairs][8 k][2]
+
+struct BlockArgs {
+  int B, N, De, DK, Dh;  // DK = per-head dim (<= 8)
+  uint32_t flags;
+  float clip_lo, clip_hi, scale, ln_eps;
+  uint32_t rm_thr, s0, s1;
+  int rng_rm;
+  int TL, NLR;  // backward: query rows per workgroup, row-ranges per graph
+  // params
+  const float *ne_g, *ne_b, *Wg, *bg, *We, *be, *nm_g, *nm_b, *Wqkv, *bqkv, *Wo, *bo, *Wr, *br;
+  // tensors
+  const float *h, *e, *M;
+  const uint8_t *km, *rm;
+  float *h_out, *e_out;
+  // saved (forward -> backward)
+  float *v_att, *stats, *qkvp;
+  // workspace
+  float *pw;        // prepared edge weights: Wp[DEP][16], c2[16]
+  float *dvp, *dqp, *dkvp, *epart, *npart, *ered;
+  // backward
+  const float *dh_out, *de_out;
+  float *dh, *de;
+  float *g_ne_g, *g_ne_b, *g_Wg, *g_bg, *g_We, *g_be, *g_nm_g, *g_nm_b, *g_Wqkv, *g_bqkv, *g_Wo,
+      *g_bo, *g_Wr, *g_br;
+};
+
+template <int DE>
+struct Geo {
+  static constexpr int TILES = (DE + 15) / 16;
+  static constexpr int DEP = TILES * 16;
+  static constexpr int NSLOT = DE / 4;          // 16-byte slots per pair row
+  static constexpr int TILE_FLOATS = 16 * DE;   // one 16-pair tile
+  static constexpr int NF4 = 4 * DE;            // float4s per tile
+  static constexpr int EP = DEP * 16 + 16 + DEP * 16;  // edge partial: T, s, R
+};
+
+// row order of the 16 projection columns: i = 4*q + r ->
+//   r=0: gate head 2q, r=1: edge-bias head 2q, r=2: gate head 2q+1, r=3: edge-bias head 2q+1
+__host__ __device__ inline int col_is_gate(int i) { return ((i & 1) == 0); }
+__host__ __device__ inline int col_head(int i) { return 2 * (i >> 2) + ((i >> 1) & 1); }
+
+
+#define BWD_TL 16   // backward: query rows per workgroup
+#define NODE_RC 64  // node rows staged per chunk in the node kernels
+
+// launchers implemented in egt_node.hip
+void egt_node_launch_pre(BlockArgs& a, hipStream_t st);
+void egt_node_launch_post(BlockArgs& a, hipStream_t st);
+void egt_node_launch_post_bwd(BlockArgs& a, hipStream_t st);
+void egt_node_launch_pre_bwd(BlockArgs& a, hipStream_t st);
+void egt_node_launch_reduce(BlockArgs& a, int nwg_bwd, int EP, int npart_stride, hipStream_t st);

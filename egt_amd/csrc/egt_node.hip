@@ -1,0 +1,491 @@
+// Node-side kernels of the fused attention block (O(N*Dh) work, once per layer):
+//   k_node_pre      : norm_mha -> dense_qkv, written packed per head-pair
+//                     (graph_xformer_model_base.py:109,113)         [+ edge-weight prep]
+//   k_node_post     : dense_mha + res_mha (:136,140)
+//   k_node_post_bwd : dV_att = dh'.Wo^T (packed), delta = sum_k dV_att*V_att,
+//                     dWo/dbo partials                              [+ edge-weight prep]
+//   k_node_pre_bwd  : dQKV -> d(h_ln) -> LN backward -> dh ; dWqkv/dbqkv/dgamma/dbeta partials
+//   k_sum_segments  : deterministic reduction of all per-workgroup partials
+//   k_edge_param_grads : T,s,R -> grads of norm_edge / attention_gates / dense_edge_b / dense_edge_r
+// One workgroup per graph; every contraction is a 16x16 tile on
+// v_mfma_f32_16x16x4_f32 with the activation rows staged in LDS.
+#include "egt_block.h"
+
+#define LDP 4  // LDS row padding (floats)
+
+__device__ __forceinline__ float sum16(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+// acc += X[16 rows][K] . W[K][16 cols]; X in LDS (stride ld), W global row-major (row stride ldw,
+// pointer already at column 0 of the tile); colok: this lane's output column exists
+__device__ __forceinline__ v4f mm_xw(const float* xs, int ld, const float* __restrict__ W, int ldw,
+                                     int K, int p, int q, bool colok, v4f acc) {
+  for (int t = 0; t < K; t += 4) {
+    const float bv = colok ? W[(size_t)(t + q) * ldw + p] : 0.f;
+    acc = MFMA(xs[p * ld + t + q], bv, acc);
+  }
+  return acc;
+}
+// acc += X[16 rows][K] . W^T, W = [16 out-rows][K] (row stride ldw, pointer at out-row 0)
+__device__ __forceinline__ v4f mm_xwt(const float* xs, int ld, const float* __restrict__ W, int ldw,
+                                      int K, int p, int q, bool colok, v4f acc) {
+  for (int t = 0; t < K; t += 4) {
+    const float bv = colok ? W[(size_t)p * ldw + t + q] : 0.f;
+    acc = MFMA(xs[p * ld + t + q], bv, acc);
+  }
+  return acc;
+}
+
+// ---- edge-weight preparation (runs as one extra workgroup of the first node kernel) ----
+// Wp[c][i] = gamma_c * Wsel[c][head(i)], c2[i] = sum_c beta_c * Wsel[c][head(i)] + bias
+__device__ void prep_device(const BlockArgs& a, float* red) {
+  const int De = a.De, DEP = ((De + 15) / 16) * 16, t = threadIdx.x;
+  const bool gated = (a.flags & EGT_BF_GATE) != 0;
+  for (int idx = t; idx < DEP * 16; idx += 256) {
+    const int c = idx >> 4, i = idx & 15;
+    float v = 0.f;
+    if (c < De) {
+      const int hd = col_head(i);
+      if (col_is_gate(i)) v = gated ? a.ne_g[c] * a.Wg[c * BH + hd] : 0.f;
+      else v = a.ne_g[c] * a.We[c * BH + hd];
+    }
+    a.pw[idx] = v;
+  }
+  {
+    const int i = t & 15, part = t >> 4, hd = col_head(i);
+    const bool isg = col_is_gate(i);
+    float v = 0.f;
+    if (!isg || gated) {
+      const float* W = isg ? a.Wg : a.We;
+      for (int c = part; c < De; c += 16) v = fmaf(a.ne_b[c], W[c * BH + hd], v);
+    }
+    red[part * 16 + i] = v;
+  }
+  __syncthreads();
+  if (t < 16) {
+    const int hd = col_head(t);
+    const bool isg = col_is_gate(t);
+    float v = 0.f;
+    if (!isg || gated) {
+      v = isg ? a.bg[hd] : a.be[hd];
+      for (int part = 0; part < 16; ++part) v += red[part * 16 + t];
+    }
+    a.pw[DEP * 16 + t] = v;
+  }
+}
+
+// stage `nr` rows of a [.., width] tensor into LDS (stride ld), zero-padding up to nrp rows
+__device__ __forceinline__ void stage_rows(float* xs, int ld, const float* src, int width, int nr, int nrp) {
+  for (int i = threadIdx.x; i < nrp * width; i += 256) {
+    const int r = i / width, c = i % width;
+    xs[r * ld + c] = r < nr ? src[(size_t)r * width + c] : 0.f;
+  }
+}
+
+// --------------------------------------------------------------- node: pre -----
+__global__ void __launch_bounds__(256) k_node_pre(BlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  if ((int)blockIdx.x == a.B) { prep_device(a, sm); return; }
+  const int Dh = a.Dh, N = a.N, b = blockIdx.x, t = threadIdx.x, ld = Dh + LDP, D3 = 3 * Dh;
+  const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4;
+  float* xs = sm;  // [NODE_RC][ld]
+  const int nct = (D3 + 15) / 16;
+  for (int r0 = 0; r0 < N; r0 += NODE_RC) {
+    const int nr = min(NODE_RC, N - r0), nrp = (nr + 15) & ~15;
+    const size_t row0 = (size_t)b * N + r0;
+    __syncthreads();
+    stage_rows(xs, ld, a.h + row0 * Dh, Dh, nr, nrp);
+    __syncthreads();
+    for (int rb = wave * 4; rb < nrp; rb += 16) {  // LayerNorm: 16 lanes per row
+      float* x = xs + (rb + q) * ld;
+      float v[4], s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int c = p + 16 * i; v[i] = c < Dh ? x[c] : 0.f; s += v[i]; }
+      const float mu = sum16(s) / Dh;
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int c = p + 16 * i; if (c < Dh) { v[i] -= mu; ss = fmaf(v[i], v[i], ss); } }
+      const float rstd = rsqrtf(sum16(ss) / Dh + a.ln_eps);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int c = p + 16 * i; if (c < Dh) x[c] = fmaf(v[i] * rstd, a.nm_g[c], a.nm_b[c]); }
+    }
+    __syncthreads();
+    const int ntr = nrp / 16;
+    for (int tile = wave; tile < ntr * nct; tile += 4) {
+      const int rt = tile / nct, ct = tile % nct, c = ct * 16 + p;
+      const bool colok = c < D3;
+      const float bias = colok ? a.bqkv[c] : 0.f;
+      v4f acc = {bias, bias, bias, bias};
+      acc = mm_xw(xs + rt * 16 * ld, ld, a.Wqkv + ct * 16, D3, Dh, p, q, colok, acc);
+      if (colok) {
+        const int s = c / Dh, cc = c % Dh, k = cc >> 3, hh = cc & 7;
+        const int pos = s * 64 + (hh >> 1) * 16 + k * 2 + (hh & 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rt * 16 + 4 * q + r;
+          if (row < nr) a.qkvp[(row0 + row) * QKVP + pos] = acc[r];
+        }
+      }
+    }
+    if (a.DK < 8) {
+      for (int i = t; i < nr * QKVP; i += 256) {
+        const int pos = i % QKVP;
+        if (((pos >> 1) & 7) >= a.DK) a.qkvp[row0 * QKVP + i] = 0.f;
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------- node: post -----
+__global__ void __launch_bounds__(256) k_node_post(BlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Dh = a.Dh, N = a.N, b = blockIdx.x, t = threadIdx.x, ld = Dh + LDP;
+  const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4;
+  float* xs = sm;
+  const int nct = (Dh + 15) / 16;
+  for (int r0 = 0; r0 < N; r0 += NODE_RC) {
+    const int nr = min(NODE_RC, N - r0), nrp = (nr + 15) & ~15;
+    const size_t row0 = (size_t)b * N + r0;
+    __syncthreads();
+    stage_rows(xs, ld, a.v_att + row0 * Dh, Dh, nr, nrp);
+    __syncthreads();
+    const int ntr = nrp / 16;
+    for (int tile = wave; tile < ntr * nct; tile += 4) {
+      const int rt = tile / nct, ct = tile % nct, c = ct * 16 + p;
+      const bool colok = c < Dh;
+      const float bias = colok ? a.bo[c] : 0.f;
+      v4f acc = {bias, bias, bias, bias};
+      acc = mm_xw(xs + rt * 16 * ld, ld, a.Wo + ct * 16, Dh, Dh, p, q, colok, acc);
+      if (colok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rt * 16 + 4 * q + r;
+          if (row < nr) {
+            const size_t o = (row0 + row) * Dh + c;
+            a.h_out[o] = acc[r] + a.h[o];   // dense_mha output, then res_mha: y + h
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------ node: post backward -----
+// node partial layout per graph: [dWqkv Dh*3Dh | dbqkv 3Dh | dgamma Dh | dbeta Dh | dWo Dh*Dh | dbo Dh]
+__global__ void __launch_bounds__(256) k_node_post_bwd(BlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  if ((int)blockIdx.x == a.B) { prep_device(a, sm); return; }
+  const int Dh = a.Dh, N = a.N, b = blockIdx.x, t = threadIdx.x, ld = Dh + LDP;
+  const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4;
+  float* ds = sm;                    // dh'   [NODE_RC][ld]
+  float* vs = ds + NODE_RC * ld;     // v_att [NODE_RC][ld]
+  const int nit = (Dh + 15) / 16;    // <= 4
+  v4f accW[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) accW[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  float accB = 0.f;
+  for (int r0 = 0; r0 < N; r0 += NODE_RC) {
+    const int nr = min(NODE_RC, N - r0), nrp = (nr + 15) & ~15;
+    const size_t row0 = (size_t)b * N + r0;
+    __syncthreads();
+    stage_rows(ds, ld, a.dh_out + row0 * Dh, Dh, nr, nrp);
+    stage_rows(vs, ld, a.v_att + row0 * Dh, Dh, nr, nrp);
+    __syncthreads();
+    // (1) dV_att = dh'.Wo^T per 16-row tile (a wave owns a row tile: delta stays in registers)
+    for (int rt = wave; rt < nrp / 16; rt += 4) {
+      float dl[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int it = 0; it < nit; ++it) {
+        const int i = it * 16 + p;
+        const bool colok = i < Dh;
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mm_xwt(ds + rt * 16 * ld, ld, a.Wo + (size_t)it * 16 * Dh, Dh, Dh, p, q, colok, acc);
+        const int k = i >> 3, hh = i & 7;
+        const int pos = (hh >> 1) * 16 + k * 2 + (hh & 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rt * 16 + 4 * q + r;
+          if (colok && row < nr) a.dvp[(row0 + row) * 64 + pos] = acc[r];
+          float pr = colok ? acc[r] * vs[row * ld + i] : 0.f;
+          pr += __shfl_xor(pr, 8, 64);   // the tile's two k values of head p&7
+          dl[r] += pr;
+        }
+      }
+      if (p < 8) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rt * 16 + 4 * q + r;
+          if (row < nr) a.stats[((row0 + row) * BH + p) * 4 + 2] = dl[r];
+        }
+      }
+    }
+    if (a.DK < 8) {
+      for (int i = t; i < nr * 64; i += 256)
+        if ((((i & 63) >> 1) & 7) >= a.DK) a.dvp[row0 * 64 + i] = 0.f;
+    }
+    // (2) dWo[i][c] += sum_rows v_att[row][i] * dh'[row][c]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = wave + 4 * j;
+      if (idx < nit * nit) {
+        const int it = idx / nit, ct = idx % nit;
+        for (int rr = 0; rr < nrp; rr += 4)
+          accW[j] = MFMA(vs[(rr + q) * ld + it * 16 + p], ds[(rr + q) * ld + ct * 16 + p], accW[j]);
+      }
+    }
+    if (t < Dh)
+      for (int r = 0; r < nr; ++r) accB += ds[r * ld + t];
+  }
+  float* part = a.npart + (size_t)b * (Dh * 3 * Dh + 3 * Dh + 2 * Dh + Dh * Dh + Dh) + Dh * 3 * Dh + 3 * Dh + 2 * Dh;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = wave + 4 * j;
+    if (idx < nit * nit) {
+      const int it = idx / nit, ct = idx % nit, c = ct * 16 + p;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = it * 16 + 4 * q + r;
+        if (i < Dh && c < Dh) part[i * Dh + c] = accW[j][r];
+      }
+    }
+  }
+  if (t < Dh) part[Dh * Dh + t] = accB;
+}
+
+// ------------------------------------------------------- node: pre backward -----
+__global__ void __launch_bounds__(256) k_node_pre_bwd(BlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Dh = a.Dh, N = a.N, b = blockIdx.x, t = threadIdx.x, D3 = 3 * Dh;
+  const int ld = Dh + LDP, ld3 = D3 + LDP;
+  const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4;
+  float* xs = sm;                        // xhat  [NODE_RC][ld]
+  float* dqs = xs + NODE_RC * ld;        // dQKV  [NODE_RC][ld3]
+  float* dls = dqs + NODE_RC * ld3;      // d h_ln [NODE_RC][ld]
+  float* rs = dls + NODE_RC * ld;        // rstd  [NODE_RC]
+  const int nkt = (Dh + 15) / 16, nct = (D3 + 15) / 16, ntl = nkt * nct;  // <= 4 x 12
+  v4f accW[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) accW[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  float accBq = 0.f, accG = 0.f, accBt = 0.f;
+  for (int r0 = 0; r0 < N; r0 += NODE_RC) {
+    const int nr = min(NODE_RC, N - r0), nrp = (nr + 15) & ~15;
+    const size_t row0 = (size_t)b * N + r0;
+    __syncthreads();
+    stage_rows(xs, ld, a.h + row0 * Dh, Dh, nr, nrp);
+    // dQKV rows: packed dq + dK/dV partials summed over the row-ranges
+    for (int i = t; i < nrp * QKVP; i += 256) {
+      const int r = i / QKVP, pos = i % QKVP;
+      const int s = pos >> 6, qq = (pos >> 4) & 3, k = (pos >> 1) & 7, j = pos & 1;
+      if (k < a.DK) {
+        float v = 0.f;
+        if (r < nr) {
+          if (s == 0) v = a.dqp[(row0 + r) * 64 + (pos & 63)];
+          else
+            for (int lr = 0; lr < a.NLR; ++lr)
+              v += a.dkvp[(((((size_t)b * a.NLR + lr) * N + r0 + r) * 2 + (s - 1)) * 4 + qq) * 16 + k * 2 + j];
+        }
+        dqs[r * ld3 + s * Dh + k * 8 + 2 * qq + j] = v;
+      }
+    }
+    __syncthreads();
+    for (int rb = wave * 4; rb < nrp; rb += 16) {  // LN forward statistics -> xhat in place
+      float* x = xs + (rb + q) * ld;
+      float v[4], s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int c = p + 16 * i; v[i] = c < Dh ? x[c] : 0.f; s += v[i]; }
+      const float mu = sum16(s) / Dh;
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int c = p + 16 * i; if (c < Dh) { v[i] -= mu; ss = fmaf(v[i], v[i], ss); } }
+      const float rstd = rsqrtf(sum16(ss) / Dh + a.ln_eps);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int c = p + 16 * i; if (c < Dh) x[c] = v[i] * rstd; }
+      if (p == 0) rs[rb + q] = rstd;
+    }
+    // d(h_ln)[row][kk] = sum_c dQKV[row][c] * Wqkv[kk][c]
+    const int ntr = nrp / 16;
+    for (int tile = wave; tile < ntr * nkt; tile += 4) {
+      const int rt = tile / nkt, kt = tile % nkt, kk = kt * 16 + p;
+      const bool colok = kk < Dh;
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
+      acc = mm_xwt(dqs + rt * 16 * ld3, ld3, a.Wqkv + (size_t)kt * 16 * D3, D3, D3, p, q, colok, acc);
+      if (colok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dls[(rt * 16 + 4 * q + r) * ld + kk] = acc[r];
+      }
+    }
+    __syncthreads();
+    for (int rb = wave * 4; rb < nrp; rb += 16) {  // LayerNorm backward + residual
+      const int row = rb + q;
+      const float* x = xs + row * ld;
+      const float* dl = dls + row * ld;
+      float dx[4], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = p + 16 * i;
+        dx[i] = c < Dh ? dl[c] * a.nm_g[c] : 0.f;
+        m1 += dx[i];
+        m2 = fmaf(dx[i], c < Dh ? x[c] : 0.f, m2);
+      }
+      m1 = sum16(m1) / Dh;
+      m2 = sum16(m2) / Dh;
+      const float rstd = rs[row];
+      if (row < nr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = p + 16 * i;
+          if (c < Dh) {
+            const size_t o = (row0 + row) * Dh + c;
+            a.dh[o] = a.dh_out[o] + rstd * (dx[i] - m1 - x[c] * m2);
+          }
+        }
+      }
+    }
+    // dWqkv[kk][c] += sum_rows h_ln[row][kk] * dQKV[row][c]
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const int idx = wave + 4 * j;
+      if (idx < ntl) {
+        const int kt = idx / nct, ct = idx % nct, kk = kt * 16 + p;
+        const float g = kk < Dh ? a.nm_g[kk] : 0.f, bt = kk < Dh ? a.nm_b[kk] : 0.f;
+        for (int rr = 0; rr < nrp; rr += 4)
+          accW[j] = MFMA(fmaf(xs[(rr + q) * ld + kk], g, bt), dqs[(rr + q) * ld3 + ct * 16 + p], accW[j]);
+      }
+    }
+    if (t < D3)
+      for (int r = 0; r < nr; ++r) accBq += dqs[r * ld3 + t];
+    if (t < Dh)
+      for (int r = 0; r < nr; ++r) {
+        const float dl = dls[r * ld + t];
+        accG = fmaf(dl, xs[r * ld + t], accG);
+        accBt += dl;
+      }
+  }
+  float* part = a.npart + (size_t)b * (Dh * D3 + D3 + 2 * Dh + Dh * Dh + Dh);
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    const int idx = wave + 4 * j;
+    if (idx < ntl) {
+      const int kt = idx / nct, ct = idx % nct, c = ct * 16 + p;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kk = kt * 16 + 4 * q + r;
+        if (kk < Dh && c < D3) part[kk * D3 + c] = accW[j][r];
+      }
+    }
+  }
+  if (t < D3) part[Dh * D3 + t] = accBq;
+  if (t < Dh) {
+    part[Dh * D3 + D3 + t] = accG;
+    part[Dh * D3 + D3 + Dh + t] = accBt;
+  }
+}
+
+// ------------------------------------------------------------ final reduce -----
+struct SumSeg { const float* src; float* dst; int n, np, stride, nblk; };
+struct SumArgs { SumSeg seg[8]; };
+
+// 64 outputs per workgroup, the partial axis split over 4 wavefronts
+__global__ void __launch_bounds__(256) k_sum_segments(SumArgs s) {
+  __shared__ float red[4][64];
+  const SumSeg sg = s.seg[blockIdx.y];
+  if ((int)blockIdx.x >= sg.nblk) return;
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  if (o < sg.n) {
+    int pi = pg;
+    for (; pi + 12 < sg.np; pi += 16) {
+      v0 += sg.src[(size_t)pi * sg.stride + o];
+      v1 += sg.src[(size_t)(pi + 4) * sg.stride + o];
+      v2 += sg.src[(size_t)(pi + 8) * sg.stride + o];
+      v3 += sg.src[(size_t)(pi + 12) * sg.stride + o];
+    }
+    for (; pi < sg.np; pi += 4) v0 += sg.src[(size_t)pi * sg.stride + o];
+  }
+  red[pg][threadIdx.x & 63] = (v0 + v1) + (v2 + v3);
+  __syncthreads();
+  if (pg == 0 && o < sg.n) sg.dst[o] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// T[c][i], s[i], R[c][h|8] -> grads of norm_edge, attention_gates, dense_edge_b, dense_edge_r
+__global__ void __launch_bounds__(256) k_edge_param_grads(BlockArgs a) {
+  const int DE = a.De, DEP = ((DE + 15) / 16) * 16;
+  const bool gated = (a.flags & EGT_BF_GATE) != 0;
+  const float* T = a.ered;
+  const float* s = a.ered + DEP * 16;
+  const float* R = s + 16;
+  for (int idx = threadIdx.x; idx < DE * 16; idx += 256) {
+    const int c = idx >> 4, i = idx & 15, hd = col_head(i);
+    const float v = a.ne_g[c] * T[c * 16 + i] + a.ne_b[c] * s[i];
+    if (col_is_gate(i)) { if (gated) a.g_Wg[c * BH + hd] = v; }
+    else a.g_We[c * BH + hd] = v;
+  }
+  if (threadIdx.x < 16) {
+    const int i = threadIdx.x, hd = col_head(i);
+    if (col_is_gate(i)) { if (gated) a.g_bg[hd] = s[i]; }
+    else a.g_be[hd] = s[i];
+  }
+  for (int c = threadIdx.x; c < DE; c += 256) {
+    float dg = 0.f, db = 0.f;
+    for (int i = 0; i < 16; ++i) {
+      const int hd = col_head(i);
+      float w;
+      if (col_is_gate(i)) w = gated ? a.Wg[c * BH + hd] : 0.f;
+      else w = a.We[c * BH + hd];
+      dg = fmaf(w, T[c * 16 + i], dg);
+      db = fmaf(w, s[i], db);
+    }
+    a.g_ne_g[c] = dg;
+    a.g_ne_b[c] = db;
+    a.g_br[c] = R[c * 16 + 8];
+  }
+  for (int idx = threadIdx.x; idx < BH * DE; idx += 256) {
+    const int hd = idx / DE, c = idx % DE;
+    a.g_Wr[idx] = R[c * 16 + hd];
+  }
+}
+
+// ---------------------------------------------------------------- launchers ----
+static size_t lds_rows(int Dh, int mult) { return (size_t)mult * NODE_RC * (Dh + LDP) * 4; }
+
+void egt_node_launch_pre(BlockArgs& a, hipStream_t st) {
+  size_t lds = lds_rows(a.Dh, 1);
+  if (lds < 1024) lds = 1024;  // prep workgroup scratch
+  EGT_LAUNCH("k_node_pre", k_node_pre, dim3(a.B + 1), dim3(256), lds, st, a);
+}
+
+void egt_node_launch_post(BlockArgs& a, hipStream_t st) {
+  EGT_LAUNCH("k_node_post", k_node_post, dim3(a.B), dim3(256), lds_rows(a.Dh, 1), st, a);
+}
+
+void egt_node_launch_post_bwd(BlockArgs& a, hipStream_t st) {
+  EGT_LAUNCH("k_node_post_bwd", k_node_post_bwd, dim3(a.B + 1), dim3(256), lds_rows(a.Dh, 2), st, a);
+}
+
+void egt_node_launch_pre_bwd(BlockArgs& a, hipStream_t st) {
+  const size_t lds = lds_rows(a.Dh, 2) + ((size_t)NODE_RC * (3 * a.Dh + LDP) + NODE_RC) * 4;
+  (void)hipFuncSetAttribute((const void*)k_node_pre_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  EGT_LAUNCH("k_node_pre_bwd", k_node_pre_bwd, dim3(a.B), dim3(256), lds, st, a);
+}
+
+void egt_node_launch_reduce(BlockArgs& a, int nwg_bwd, int EP, int npart_stride, hipStream_t st) {
+  const int Dh = a.Dh, D3 = 3 * Dh;
+  SumArgs s{};
+  const float* np = a.npart;
+  int o = 0, maxblk = 0;
+  auto seg = [&](int k, const float* src, float* dst, int n, int npart, int stride) {
+    s.seg[k] = SumSeg{src, dst, n, npart, stride, (n + 63) / 64};
+    if (s.seg[k].nblk > maxblk) maxblk = s.seg[k].nblk;
+  };
+  seg(0, np + o, a.g_Wqkv, Dh * D3, a.B, npart_stride); o += Dh * D3;
+  seg(1, np + o, a.g_bqkv, D3, a.B, npart_stride); o += D3;
+  seg(2, np + o, a.g_nm_g, Dh, a.B, npart_stride); o += Dh;
+  seg(3, np + o, a.g_nm_b, Dh, a.B, npart_stride); o += Dh;
+  seg(4, np + o, a.g_Wo, Dh * Dh, a.B, npart_stride); o += Dh * Dh;
+  seg(5, np + o, a.g_bo, Dh, a.B, npart_stride);
+  seg(6, a.epart, a.ered, EP, nwg_bwd, EP);
+  EGT_LAUNCH("k_sum_segments", k_sum_segments, dim3(maxblk, 7), dim3(256), 0, st, s);
+  EGT_LAUNCH("k_edge_param_grads", k_edge_param_grads, dim3(1), dim3(256), 0, st, a);
+}
