@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--dominant", default="k_block_bwd",
+                    help="kernel timed with hipEvents inside the timed region")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,7 +177,11 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # Timed region.  hipEvents bracket ONLY the dominant kernel's launches here (an event pair
+    # around every launch costs ~15% of the step); the per-kernel table comes from a second,
+    # untimed pass over the same steps below.
     if not args.no_prof:
+        lib.egt_prof_filter(args.dominant.encode())
         lib.egt_prof_enable(2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -187,17 +193,30 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    dom_prof = prof_read_all(lib) if not args.no_prof else {}
+    all_prof = {}
+    if not args.no_prof:   # every rank runs it (the step contains the collective)
+        lib.egt_prof_filter(b"")
+        lib.egt_prof_enable(2)
+        for _ in range(min(args.steps, 10)):
+            step()
+        fence()
+        lib.egt_prof_enable(0)
+        all_prof = prof_read_all(lib)
 
-    prof = prof_read_all(lib) if not args.no_prof else {}
+    prof = all_prof
     if rank == 0:
         roof = None
         if prof:
             dom = max(prof, key=lambda k: prof[k][1])
-            cnt, ms = prof[dom]
+            if dom in dom_prof:      # the figure measured inside the timed region
+                cnt, ms = dom_prof[dom]
+            else:
+                cnt, ms = prof[dom]
             avg_s = ms / cnt / 1e3
             ab = algorithmic_bytes(dom, w)
             ach = ab / avg_s / 1e9 if avg_s > 0 and ab > 0 else None
-            roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+            roof = dict(bound="hbm", kernel=dom, timed_in_region=dom in dom_prof, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=(ach / HBM_PEAK_GBS) if ach else None, traffic=None,
                         avg_launch_us=avg_s * 1e6, launches=cnt, algorithmic_bytes_per_launch=ab,
                         kernels={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3,

@@ -84,6 +84,7 @@ _PROTOS = {
     "egt_edge_update_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(EdgeDesc)]),
     "egt_edge_update_bwd": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 8),
     "egt_prof_enable": (C.c_int, [C.c_int]),
+    "egt_prof_filter": (C.c_int, [C.c_char_p]),
     "egt_prof_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "egt_prof_names": (C.c_int, [C.c_char_p, C.c_size_t]),
 }
@@ -95,6 +96,11 @@ _OPTIONAL_PROTOS = {
     "egt_block_workspace_bytes": (C.c_size_t, [C.POINTER(BlockDesc)]),
     "egt_block_fwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams)] + [_VP] * 10),
     "egt_block_bwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams)] + [_VP] * 10
+                      + [C.POINTER(BlockParams)] + [_VP] * 2),
+    "egt_stack_saved_bytes": (C.c_size_t, [C.POINTER(BlockDesc), C.c_int32]),
+    "egt_stack_workspace_bytes": (C.c_size_t, [C.POINTER(BlockDesc), C.c_int32]),
+    "egt_stack_fwd": (C.c_int, [C.POINTER(BlockDesc), C.c_int32, C.POINTER(BlockParams)] + [_VP] * 9),
+    "egt_stack_bwd": (C.c_int, [C.POINTER(BlockDesc), C.c_int32, C.POINTER(BlockParams)] + [_VP] * 9
                       + [C.POINTER(BlockParams)] + [_VP] * 2),
 }
 

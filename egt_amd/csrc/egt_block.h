@@ -51,11 +51,11 @@ __host__ __device__ inline int col_head(int i) { return 2 * (i >> 2) + ((i >> 1)
 
 
 #define BWD_TL 16   // backward: query rows per workgroup
-#define NODE_RC 64  // node rows staged per chunk in the node kernels
+#define NODE_RC 32  // node rows per workgroup in the node kernels
 
 // launchers implemented in egt_node.hip
 void egt_node_launch_pre(BlockArgs& a, hipStream_t st);
 void egt_node_launch_post(BlockArgs& a, hipStream_t st);
 void egt_node_launch_post_bwd(BlockArgs& a, hipStream_t st);
 void egt_node_launch_pre_bwd(BlockArgs& a, hipStream_t st);
-void egt_node_launch_reduce(BlockArgs& a, int nwg_bwd, int EP, int npart_stride, hipStream_t st);
+void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, int npart_stride, hipStream_t st);

@@ -240,7 +240,8 @@ __device__ __forceinline__ float reduce16_keep_own(const float (&v)[16], int p) 
 // KVL: K/V of the graph, Q of the 16 rows and the key-mask adds are staged in LDS.
 // ML: attention-mask / injected-random-mask byte streams are present (their loads are
 // compiled out of the headline kernel).
-template <int DE, bool KVL, bool ML>
+// FULL: N is a multiple of 16 (no ragged key tile): validity selects and address clamps fold away.
+template <int DE, bool KVL, bool ML, bool FULL>
 __global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
   using G = Geo<DE>;
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -298,7 +299,7 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
   auto prefetch = [&](int it) {
     const int l = lg * 16 + wave + 4 * (it / ntile), m0 = (it % ntile) * 16;
     const size_t pair0 = ((size_t)b * N + l) * N + m0;
-    tile_gload<DE>(tr, a.e + pair0 * DE, lane, min(16, N - m0));
+    tile_gload<DE>(tr, a.e + pair0 * DE, lane, FULL ? 16 : min(16, N - m0));
   };
   if (total > 0) prefetch(0);
 
@@ -306,8 +307,8 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
   for (int it = 0; it < total; ++it) {
     const int li = it / ntile, mt = it % ntile;
     const int l = lg * 16 + wave + 4 * li, m0 = mt * 16, m = m0 + p;
-    const bool valid = m < N;
-    const int rows_valid = min(16, N - m0);
+    const bool valid = FULL ? true : (m < N);
+    const int rows_valid = FULL ? 16 : min(16, N - m0);
     const size_t rowl = (size_t)b * N + l;
     const size_t pair0 = rowl * N + m0;
     if (mt == 0) {
@@ -329,7 +330,7 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
     if (it > 0) {   // stream out e' of the previous tile from the other buffer
       const int itp = it - 1, lp = lg * 16 + wave + 4 * (itp / ntile), m0p = (itp % ntile) * 16;
       tile_from_lds<DE>(tl0 + (itp & 1) * G::TILE_FLOATS, a.e_out + (((size_t)b * N + lp) * N + m0p) * DE,
-                        lane, min(16, N - m0p));
+                        lane, FULL ? 16 : min(16, N - m0p));
     }
     tile_lds_put<DE>(tl, tr, lane, rows_valid);
     if (it + 1 < total) prefetch(it + 1);
@@ -440,7 +441,7 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
 // Workgroup = (graph b, TL query rows); wave w owns key tiles w, w+4, ...; for each
 // it walks the TL rows.  Q / dV_att / softmax statistics of the rows sit in LDS.
 #define QD_LD 160  // per row: Q[64] | dV_att[64] | stats[32]
-template <int DE, bool ML>
+template <int DE, bool ML, bool FULL>
 __global__ void __launch_bounds__(256, 1) k_block_bwd(BlockArgs a) {
   using G = Geo<DE>;
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -498,8 +499,8 @@ __global__ void __launch_bounds__(256, 1) k_block_bwd(BlockArgs a) {
   const int ntile = (N + 15) / 16;
   for (int mt = wave; mt < ntile; mt += 4) {
     const int m0 = mt * 16, m = m0 + p;
-    const bool valid = m < N;
-    const int rows_valid = min(16, N - m0);
+    const bool valid = FULL ? true : (m < N);
+    const int rows_valid = FULL ? 16 : min(16, N - m0);
     float Kf[16], Vf[16], dKa[16], dVa[16];
     const size_t rowm = (size_t)b * N + (valid ? m : 0);
     {
@@ -770,7 +771,7 @@ static BlockLayout layout(const egt_block_desc* d) {
   L.dqp = o; o += al(rows * 64);
   L.dkvp = o; o += al((size_t)d->B * L.NLR * d->N * 128);
   L.epart = o; o += al((size_t)L.nwg_bwd * L.EP);
-  L.npart = o; o += al((size_t)d->B * L.npart_stride);
+  L.npart = o; o += al((size_t)d->B * ((d->N + NODE_RC - 1) / NODE_RC) * L.npart_stride);
   L.ered = o; o += al(L.EP);
   L.ws_total = o;
   return L;
@@ -848,34 +849,40 @@ static void launch_fwd(BlockArgs& a, hipStream_t st) {
   const bool ml = a.M != nullptr || a.rm != nullptr;
   const dim3 grid(a.B * lgroups), block(256);
   const size_t lds = lds_tiles + (kvl ? lds_kv : 0);
-#define FWD_VARIANT(KVL_, ML_)                                                                         \
+#define FWD_VARIANT(KVL_, ML_, FULL_)                                                                  \
   do {                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)k_block_fwd<DE, KVL_, ML_>,                                 \
+    (void)hipFuncSetAttribute((const void*)k_block_fwd<DE, KVL_, ML_, FULL_>,                          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
-    EGT_LAUNCH("k_block_fwd", (k_block_fwd<DE, KVL_, ML_>), grid, block, lds, st, a);                  \
+    EGT_LAUNCH("k_block_fwd", (k_block_fwd<DE, KVL_, ML_, FULL_>), grid, block, lds, st, a);           \
   } while (0)
-  if (kvl) { if (ml) FWD_VARIANT(true, true); else FWD_VARIANT(true, false); }
-  else { if (ml) FWD_VARIANT(false, true); else FWD_VARIANT(false, false); }
+  const bool full = (a.N % 16) == 0;
+  if (full && kvl && !ml) FWD_VARIANT(true, false, true);      // the headline variant
+  else if (kvl) { if (ml) FWD_VARIANT(true, true, false); else FWD_VARIANT(true, false, false); }
+  else { if (ml) FWD_VARIANT(false, true, false); else FWD_VARIANT(false, false, false); }
 #undef FWD_VARIANT
   egt_node_launch_post(a, st);  // dense_mha + res_mha
 }
 
 template <int DE>
-static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st) {
+static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool reduce_now) {
   using GG = Geo<DE>;
   egt_node_launch_post_bwd(a, st);  // dV_att (packed), delta, dWo/dbo partials, edge-weight prep
   constexpr int PW = 3 * GG::TILE_FLOATS + 256 + 192;
   static_assert(4 * GG::EP <= 4 * PW, "edge partial staging must fit the LDS tile area");
   const size_t lds = ((size_t)4 * PW + (size_t)4 * BWD_TL * 64 + (size_t)BWD_TL * QD_LD) * 4;
-  if (a.M != nullptr || a.rm != nullptr) {
-    (void)hipFuncSetAttribute((const void*)k_block_bwd<DE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    EGT_LAUNCH("k_block_bwd", (k_block_bwd<DE, true>), dim3(L.nwg_bwd), dim3(256), lds, st, a);
-  } else {
-    (void)hipFuncSetAttribute((const void*)k_block_bwd<DE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    EGT_LAUNCH("k_block_bwd", (k_block_bwd<DE, false>), dim3(L.nwg_bwd), dim3(256), lds, st, a);
-  }
+#define BWD_VARIANT(ML_, FULL_)                                                                        \
+  do {                                                                                                 \
+    (void)hipFuncSetAttribute((const void*)k_block_bwd<DE, ML_, FULL_>,                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
+    EGT_LAUNCH("k_block_bwd", (k_block_bwd<DE, ML_, FULL_>), dim3(L.nwg_bwd), dim3(256), lds, st, a);  \
+  } while (0)
+  const bool ml = a.M != nullptr || a.rm != nullptr;
+  if (!ml && (a.N % 16) == 0) BWD_VARIANT(false, true);         // the headline variant
+  else if (ml) BWD_VARIANT(true, false);
+  else BWD_VARIANT(false, false);
+#undef BWD_VARIANT
   egt_node_launch_pre_bwd(a, st);   // dQKV -> dh, dWqkv/dbqkv/dgamma/dbeta partials
-  egt_node_launch_reduce(a, L.nwg_bwd, L.EP, L.npart_stride, st);  // partial sums + edge param grads
+  if (reduce_now) egt_node_launch_reduce(&a, 1, L.nwg_bwd, L.EP, L.npart_stride, st);  // partial sums + edge param grads
 }
 
 
@@ -926,7 +933,141 @@ extern "C" int egt_block_bwd(const egt_block_desc* desc, const egt_block_params*
   a.g_Wo = (float*)grads->dense_mha_kernel; a.g_bo = (float*)grads->dense_mha_bias;
   a.g_Wr = (float*)grads->dense_edge_r_kernel; a.g_br = (float*)grads->dense_edge_r_bias;
   const BlockLayout L = layout(desc);
-  DISPATCH_BDE(desc->De, launch_bwd<DE>(a, L, (hipStream_t)stream));
+  DISPATCH_BDE(desc->De, launch_bwd<DE>(a, L, (hipStream_t)stream, true));
   EGT_HIP_LAUNCH_CHECK("egt_block_bwd");
+  return EGT_OK;
+}
+
+
+// ============================================================ layer stack =====
+// The model_height loop over attention blocks (graph_xformer_model_base.py:336-339) as ONE
+// call per direction: Ly x {node_pre, block_fwd, node_post} enqueued back to back, and in
+// backward the per-workgroup partial sums of ALL layers reduced by a single launch at the end
+// (they are off the dh/de critical path).  Layer l draws its random mask from
+// seed ^ golden * (l + 1).
+static uint64_t layer_seed(uint64_t seed, int l) { return seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(l + 1)); }
+
+struct StackLayout {
+  size_t h_act, e_act, blk, saved_total;      // floats
+  size_t common, per_layer, per_layer_stride, ws_total;
+  size_t h_sz, e_sz;
+};
+
+static StackLayout stack_layout(const egt_block_desc* d, int layers) {
+  StackLayout S{};
+  const BlockLayout L = layout(d);
+  S.h_sz = al((size_t)d->B * d->N * d->d * d->H);
+  S.e_sz = al((size_t)d->B * d->N * d->N * d->De);
+  size_t o = 0;
+  S.h_act = o; o += S.h_sz * (size_t)(layers > 1 ? layers - 1 : 0);
+  S.e_act = o; o += S.e_sz * (size_t)(layers > 1 ? layers - 1 : 0);
+  S.blk = o; o += L.saved_total * (size_t)layers;
+  S.saved_total = o;
+  // workspace: [pw dvp dqp dkvp] shared by all layers, then per layer [epart npart ered]
+  S.common = L.epart;                       // everything before epart in the block layout
+  S.per_layer_stride = L.ws_total - L.epart;
+  S.ws_total = S.common + S.per_layer_stride * (size_t)layers;
+  return S;
+}
+
+extern "C" size_t egt_stack_saved_bytes(const egt_block_desc* d, int32_t layers) {
+  if (block_check(d, false) || layers < 1) return 0;
+  return stack_layout(d, layers).saved_total * sizeof(float);
+}
+extern "C" size_t egt_stack_workspace_bytes(const egt_block_desc* d, int32_t layers) {
+  if (block_check(d, false) || layers < 1) return 0;
+  return stack_layout(d, layers).ws_total * sizeof(float);
+}
+
+static void bind_layer(const egt_block_desc* d, const StackLayout& S, const BlockLayout& L, int l,
+                       BlockArgs& a, float* saved, float* ws) {
+  float* bs = saved + S.blk + L.saved_total * (size_t)l;
+  a.v_att = bs + L.v_att; a.stats = bs + L.stats; a.qkvp = bs + L.qkvp;
+  a.pw = ws + L.pw; a.dvp = ws + L.dvp; a.dqp = ws + L.dqp; a.dkvp = ws + L.dkvp;
+  float* pl = ws + S.common + S.per_layer_stride * (size_t)l;
+  a.epart = pl; a.npart = pl + (L.npart - L.epart); a.ered = pl + (L.ered - L.epart);
+  a.TL = BWD_TL; a.NLR = L.NLR;
+  (void)d;
+}
+
+extern "C" int egt_stack_fwd(const egt_block_desc* desc, int32_t layers, const egt_block_params* params,
+                             const void* h, const void* e, const uint8_t* key_mask,
+                             const void* attn_mask, void* h_out, void* e_out, void* saved,
+                             void* workspace, void* stream) {
+  if (layers < 1) EGT_FAIL(EGT_E_SHAPE, "layers must be >= 1");
+  if (!params || !h || !e || !h_out || !e_out || !saved || !workspace)
+    EGT_FAIL(EGT_E_NULL, "params/h/e/h_out/e_out/saved/workspace is NULL");
+  if (block_check(desc, true)) return block_check(desc, true);
+  if ((desc->flags & EGT_BF_ATTN_MASK) && !attn_mask) EGT_FAIL(EGT_E_NULL, "ATTN_MASK set but attn_mask is NULL");
+  const StackLayout S = stack_layout(desc, layers);
+  const BlockLayout L = layout(desc);
+  float* sv = (float*)saved;
+  for (int l = 0; l < layers; ++l) {
+    egt_block_desc dl = *desc;
+    dl.seed = layer_seed(desc->seed, l);
+    BlockArgs a;
+    int rc = fill_block(&dl, params + l, a);
+    if (rc) return rc;
+    const float* hin = l == 0 ? (const float*)h : sv + S.h_act + S.h_sz * (size_t)(l - 1);
+    const float* ein = l == 0 ? (const float*)e : sv + S.e_act + S.e_sz * (size_t)(l - 1);
+    bind_common(&dl, a, hin, ein, key_mask, attn_mask, nullptr, sv, (float*)workspace);
+    bind_layer(&dl, S, L, l, a, sv, (float*)workspace);
+    a.h_out = l == layers - 1 ? (float*)h_out : sv + S.h_act + S.h_sz * (size_t)l;
+    a.e_out = l == layers - 1 ? (float*)e_out : sv + S.e_act + S.e_sz * (size_t)l;
+    DISPATCH_BDE(desc->De, launch_fwd<DE>(a, (hipStream_t)stream));
+  }
+  EGT_HIP_LAUNCH_CHECK("egt_stack_fwd");
+  return EGT_OK;
+}
+
+extern "C" int egt_stack_bwd(const egt_block_desc* desc, int32_t layers, const egt_block_params* params,
+                             const void* h, const void* e, const uint8_t* key_mask,
+                             const void* attn_mask, const void* saved, const void* d_h_out,
+                             const void* d_e_out, void* d_h, void* d_e,
+                             const egt_block_params* grads, void* workspace, void* stream) {
+  if (layers < 1) EGT_FAIL(EGT_E_SHAPE, "layers must be >= 1");
+  if (layers > 64) EGT_FAIL(EGT_E_SHAPE, "at most 64 layers per stack call");
+  if (!params || !grads || !h || !e || !saved || !d_h_out || !d_e_out || !d_h || !d_e || !workspace)
+    EGT_FAIL(EGT_E_NULL, "params/grads/h/e/saved/d_h_out/d_e_out/d_h/d_e/workspace is NULL");
+  if (block_check(desc, true)) return block_check(desc, true);
+  if ((desc->flags & EGT_BF_ATTN_MASK) && !attn_mask) EGT_FAIL(EGT_E_NULL, "ATTN_MASK set but attn_mask is NULL");
+  const StackLayout S = stack_layout(desc, layers);
+  const BlockLayout L = layout(desc);
+  float* sv = (float*)saved;
+  const bool gated = (desc->flags & EGT_BF_GATE) != 0;
+  BlockArgs as[64];
+  for (int l = layers - 1; l >= 0; --l) {
+    egt_block_desc dl = *desc;
+    dl.seed = layer_seed(desc->seed, l);
+    BlockArgs& a = as[l];
+    int rc = fill_block(&dl, params + l, a);
+    if (rc) return rc;
+    const egt_block_params* g = grads + l;
+    {
+      const void* const* gp = reinterpret_cast<const void* const*>(g);
+      for (int i = 0; i < 14; ++i) {
+        if (!gated && (i == 2 || i == 3)) continue;
+        if (!gp[i]) EGT_FAIL(EGT_E_NULL, "layer %d gradient pointer #%d is NULL", l, i);
+      }
+    }
+    const float* hin = l == 0 ? (const float*)h : sv + S.h_act + S.h_sz * (size_t)(l - 1);
+    const float* ein = l == 0 ? (const float*)e : sv + S.e_act + S.e_sz * (size_t)(l - 1);
+    bind_common(&dl, a, hin, ein, key_mask, attn_mask, nullptr, sv, (float*)workspace);
+    bind_layer(&dl, S, L, l, a, sv, (float*)workspace);
+    // grads flow through d_h / d_e in place below the top layer
+    a.dh_out = l == layers - 1 ? (const float*)d_h_out : (const float*)d_h;
+    a.de_out = l == layers - 1 ? (const float*)d_e_out : (const float*)d_e;
+    a.dh = (float*)d_h; a.de = (float*)d_e;
+    a.g_ne_g = (float*)g->norm_edge_gamma; a.g_ne_b = (float*)g->norm_edge_beta;
+    a.g_Wg = (float*)g->attention_gates_kernel; a.g_bg = (float*)g->attention_gates_bias;
+    a.g_We = (float*)g->dense_edge_b_kernel; a.g_be = (float*)g->dense_edge_b_bias;
+    a.g_nm_g = (float*)g->norm_mha_gamma; a.g_nm_b = (float*)g->norm_mha_beta;
+    a.g_Wqkv = (float*)g->dense_qkv_kernel; a.g_bqkv = (float*)g->dense_qkv_bias;
+    a.g_Wo = (float*)g->dense_mha_kernel; a.g_bo = (float*)g->dense_mha_bias;
+    a.g_Wr = (float*)g->dense_edge_r_kernel; a.g_br = (float*)g->dense_edge_r_bias;
+    DISPATCH_BDE(desc->De, launch_bwd<DE>(a, L, (hipStream_t)stream, false));
+  }
+  egt_node_launch_reduce(as, layers, L.nwg_bwd, L.EP, L.npart_stride, (hipStream_t)stream);
+  EGT_HIP_LAUNCH_CHECK("egt_stack_bwd");
   return EGT_OK;
 }

@@ -19,9 +19,9 @@ __device__ __forceinline__ float sum16(float v) {
   return v;
 }
 
-// acc += X[16 rows][K] . W[K][16 cols]; X in LDS (stride ld), W global row-major (row stride ldw,
-// pointer already at column 0 of the tile); colok: this lane's output column exists
-__device__ __forceinline__ v4f mm_xw(const float* xs, int ld, const float* __restrict__ W, int ldw,
+// acc += X[16 rows][K] . W[K][16 cols]; X and W staged in LDS (strides ld / ldw, W pointer
+// already at column 0 of the tile); colok: this lane's output column exists
+__device__ __forceinline__ v4f mm_xw(const float* xs, int ld, const float* W, int ldw,
                                      int K, int p, int q, bool colok, v4f acc) {
   for (int t = 0; t < K; t += 4) {
     const float bv = colok ? W[(size_t)(t + q) * ldw + p] : 0.f;
@@ -29,8 +29,8 @@ __device__ __forceinline__ v4f mm_xw(const float* xs, int ld, const float* __res
   }
   return acc;
 }
-// acc += X[16 rows][K] . W^T, W = [16 out-rows][K] (row stride ldw, pointer at out-row 0)
-__device__ __forceinline__ v4f mm_xwt(const float* xs, int ld, const float* __restrict__ W, int ldw,
+// acc += X[16 rows][K] . W^T, W = [16 out-rows][K] in LDS (row stride ldw, pointer at out-row 0)
+__device__ __forceinline__ v4f mm_xwt(const float* xs, int ld, const float* W, int ldw,
                                       int K, int p, int q, bool colok, v4f acc) {
   for (int t = 0; t < K; t += 4) {
     const float bv = colok ? W[(size_t)p * ldw + t + q] : 0.f;
@@ -77,23 +77,61 @@ __device__ void prep_device(const BlockArgs& a, float* red) {
   }
 }
 
+// stage a dense [rows][width] weight matrix into LDS (row stride ldw): 16-byte loads, four in
+// flight per thread before the LDS writes
+__device__ __forceinline__ void stage_weight(float* ws, int ldw, const float* W, int rows, int width) {
+  const int n4 = rows * width / 4;
+  for (int i0 = threadIdx.x; i0 < n4; i0 += 1024) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256;
+      v[u] = *reinterpret_cast<const float4*>(W + (size_t)(i < n4 ? i : 0) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256;
+      if (i < n4) {
+        const int r = (i * 4) / width, c = (i * 4) % width;
+        *reinterpret_cast<float4*>(ws + r * ldw + c) = v[u];
+      }
+    }
+  }
+}
+
 // stage `nr` rows of a [.., width] tensor into LDS (stride ld), zero-padding up to nrp rows
 __device__ __forceinline__ void stage_rows(float* xs, int ld, const float* src, int width, int nr, int nrp) {
-  for (int i = threadIdx.x; i < nrp * width; i += 256) {
-    const int r = i / width, c = i % width;
-    xs[r * ld + c] = r < nr ? src[(size_t)r * width + c] : 0.f;
+  const int w4 = width >> 2, n4 = nrp * w4;
+  for (int i0 = threadIdx.x; i0 < n4; i0 += 1024) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256, r = i / w4, c4 = i % w4;
+      const bool ok = i < n4 && r < nr;
+      v[u] = *reinterpret_cast<const float4*>(src + (ok ? (size_t)r * width + c4 * 4 : 0));
+      if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256, r = i / w4, c4 = i % w4;
+      if (i < n4) *reinterpret_cast<float4*>(xs + r * ld + c4 * 4) = v[u];
+    }
   }
 }
 
 // --------------------------------------------------------------- node: pre -----
 __global__ void __launch_bounds__(256) k_node_pre(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  if ((int)blockIdx.x == a.B) { prep_device(a, sm); return; }
-  const int Dh = a.Dh, N = a.N, b = blockIdx.x, t = threadIdx.x, ld = Dh + LDP, D3 = 3 * Dh;
+  const int NCH = (a.N + NODE_RC - 1) / NODE_RC;
+  if ((int)blockIdx.x == a.B * NCH) { prep_device(a, sm); return; }
+  const int Dh = a.Dh, N = a.N, b = blockIdx.x / NCH, chunk = blockIdx.x % NCH, t = threadIdx.x, ld = Dh + LDP, D3 = 3 * Dh;
   const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4;
-  float* xs = sm;  // [NODE_RC][ld]
+  float* xs = sm;                 // [NODE_RC][ld]
+  float* ws = xs + NODE_RC * ld;  // Wqkv [Dh][ldw]
+  const int ldw = D3 + LDP;
+  stage_weight(ws, ldw, a.Wqkv, Dh, D3);
   const int nct = (D3 + 15) / 16;
-  for (int r0 = 0; r0 < N; r0 += NODE_RC) {
+  for (int r0 = chunk * NODE_RC; r0 < min(N, (chunk + 1) * NODE_RC); r0 += NODE_RC) {  // one chunk
     const int nr = min(NODE_RC, N - r0), nrp = (nr + 15) & ~15;
     const size_t row0 = (size_t)b * N + r0;
     __syncthreads();
@@ -119,7 +157,7 @@ __global__ void __launch_bounds__(256) k_node_pre(BlockArgs a) {
       const bool colok = c < D3;
       const float bias = colok ? a.bqkv[c] : 0.f;
       v4f acc = {bias, bias, bias, bias};
-      acc = mm_xw(xs + rt * 16 * ld, ld, a.Wqkv + ct * 16, D3, Dh, p, q, colok, acc);
+      acc = mm_xw(xs + rt * 16 * ld, ld, ws + ct * 16, ldw, Dh, p, q, colok, acc);
       if (colok) {
         const int s = c / Dh, cc = c % Dh, k = cc >> 3, hh = cc & 7;
         const int pos = s * 64 + (hh >> 1) * 16 + k * 2 + (hh & 1);
@@ -142,11 +180,14 @@ __global__ void __launch_bounds__(256) k_node_pre(BlockArgs a) {
 // -------------------------------------------------------------- node: post -----
 __global__ void __launch_bounds__(256) k_node_post(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int Dh = a.Dh, N = a.N, b = blockIdx.x, t = threadIdx.x, ld = Dh + LDP;
+  const int NCH = (a.N + NODE_RC - 1) / NODE_RC;
+  const int Dh = a.Dh, N = a.N, b = blockIdx.x / NCH, chunk = blockIdx.x % NCH, t = threadIdx.x, ld = Dh + LDP;
   const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4;
   float* xs = sm;
+  float* ws = xs + NODE_RC * ld;  // Wo [Dh][ld]
+  stage_weight(ws, ld, a.Wo, Dh, Dh);
   const int nct = (Dh + 15) / 16;
-  for (int r0 = 0; r0 < N; r0 += NODE_RC) {
+  for (int r0 = chunk * NODE_RC; r0 < min(N, (chunk + 1) * NODE_RC); r0 += NODE_RC) {  // one chunk
     const int nr = min(NODE_RC, N - r0), nrp = (nr + 15) & ~15;
     const size_t row0 = (size_t)b * N + r0;
     __syncthreads();
@@ -158,7 +199,7 @@ __global__ void __launch_bounds__(256) k_node_post(BlockArgs a) {
       const bool colok = c < Dh;
       const float bias = colok ? a.bo[c] : 0.f;
       v4f acc = {bias, bias, bias, bias};
-      acc = mm_xw(xs + rt * 16 * ld, ld, a.Wo + ct * 16, Dh, Dh, p, q, colok, acc);
+      acc = mm_xw(xs + rt * 16 * ld, ld, ws + ct * 16, ld, Dh, p, q, colok, acc);
       if (colok) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -177,17 +218,20 @@ __global__ void __launch_bounds__(256) k_node_post(BlockArgs a) {
 // node partial layout per graph: [dWqkv Dh*3Dh | dbqkv 3Dh | dgamma Dh | dbeta Dh | dWo Dh*Dh | dbo Dh]
 __global__ void __launch_bounds__(256) k_node_post_bwd(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  if ((int)blockIdx.x == a.B) { prep_device(a, sm); return; }
-  const int Dh = a.Dh, N = a.N, b = blockIdx.x, t = threadIdx.x, ld = Dh + LDP;
+  const int NCH = (a.N + NODE_RC - 1) / NODE_RC;
+  if ((int)blockIdx.x == a.B * NCH) { prep_device(a, sm); return; }
+  const int Dh = a.Dh, N = a.N, b = blockIdx.x / NCH, chunk = blockIdx.x % NCH, t = threadIdx.x, ld = Dh + LDP;
   const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4;
   float* ds = sm;                    // dh'   [NODE_RC][ld]
   float* vs = ds + NODE_RC * ld;     // v_att [NODE_RC][ld]
+  float* ws = vs + NODE_RC * ld;     // Wo    [Dh][ld]
+  stage_weight(ws, ld, a.Wo, Dh, Dh);
   const int nit = (Dh + 15) / 16;    // <= 4
   v4f accW[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) accW[j] = (v4f){0.f, 0.f, 0.f, 0.f};
   float accB = 0.f;
-  for (int r0 = 0; r0 < N; r0 += NODE_RC) {
+  for (int r0 = chunk * NODE_RC; r0 < min(N, (chunk + 1) * NODE_RC); r0 += NODE_RC) {  // one chunk
     const int nr = min(NODE_RC, N - r0), nrp = (nr + 15) & ~15;
     const size_t row0 = (size_t)b * N + r0;
     __syncthreads();
@@ -201,7 +245,7 @@ __global__ void __launch_bounds__(256) k_node_post_bwd(BlockArgs a) {
         const int i = it * 16 + p;
         const bool colok = i < Dh;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
-        acc = mm_xwt(ds + rt * 16 * ld, ld, a.Wo + (size_t)it * 16 * Dh, Dh, Dh, p, q, colok, acc);
+        acc = mm_xwt(ds + rt * 16 * ld, ld, ws + it * 16 * ld, ld, Dh, p, q, colok, acc);
         const int k = i >> 3, hh = i & 7;
         const int pos = (hh >> 1) * 16 + k * 2 + (hh & 1);
 #pragma unroll
@@ -238,7 +282,7 @@ __global__ void __launch_bounds__(256) k_node_post_bwd(BlockArgs a) {
     if (t < Dh)
       for (int r = 0; r < nr; ++r) accB += ds[r * ld + t];
   }
-  float* part = a.npart + (size_t)b * (Dh * 3 * Dh + 3 * Dh + 2 * Dh + Dh * Dh + Dh) + Dh * 3 * Dh + 3 * Dh + 2 * Dh;
+  float* part = a.npart + (size_t)blockIdx.x * (Dh * 3 * Dh + 3 * Dh + 2 * Dh + Dh * Dh + Dh) + Dh * 3 * Dh + 3 * Dh + 2 * Dh;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int idx = wave + 4 * j;
@@ -257,36 +301,58 @@ __global__ void __launch_bounds__(256) k_node_post_bwd(BlockArgs a) {
 // ------------------------------------------------------- node: pre backward -----
 __global__ void __launch_bounds__(256) k_node_pre_bwd(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int Dh = a.Dh, N = a.N, b = blockIdx.x, t = threadIdx.x, D3 = 3 * Dh;
+  const int NCH = (a.N + NODE_RC - 1) / NODE_RC;
+  const int Dh = a.Dh, N = a.N, b = blockIdx.x / NCH, chunk = blockIdx.x % NCH, t = threadIdx.x, D3 = 3 * Dh;
   const int ld = Dh + LDP, ld3 = D3 + LDP;
   const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4;
   float* xs = sm;                        // xhat  [NODE_RC][ld]
   float* dqs = xs + NODE_RC * ld;        // dQKV  [NODE_RC][ld3]
   float* dls = dqs + NODE_RC * ld3;      // d h_ln [NODE_RC][ld]
   float* rs = dls + NODE_RC * ld;        // rstd  [NODE_RC]
+  float* ws = rs + NODE_RC;              // Wqkv  [Dh][ld3]
+  stage_weight(ws, ld3, a.Wqkv, Dh, D3);
   const int nkt = (Dh + 15) / 16, nct = (D3 + 15) / 16, ntl = nkt * nct;  // <= 4 x 12
   v4f accW[12];
 #pragma unroll
   for (int j = 0; j < 12; ++j) accW[j] = (v4f){0.f, 0.f, 0.f, 0.f};
   float accBq = 0.f, accG = 0.f, accBt = 0.f;
-  for (int r0 = 0; r0 < N; r0 += NODE_RC) {
+  for (int r0 = chunk * NODE_RC; r0 < min(N, (chunk + 1) * NODE_RC); r0 += NODE_RC) {  // one chunk
     const int nr = min(NODE_RC, N - r0), nrp = (nr + 15) & ~15;
     const size_t row0 = (size_t)b * N + r0;
     __syncthreads();
     stage_rows(xs, ld, a.h + row0 * Dh, Dh, nr, nrp);
-    // dQKV rows: packed dq + dK/dV partials summed over the row-ranges
-    for (int i = t; i < nrp * QKVP; i += 256) {
-      const int r = i / QKVP, pos = i % QKVP;
-      const int s = pos >> 6, qq = (pos >> 4) & 3, k = (pos >> 1) & 7, j = pos & 1;
-      if (k < a.DK) {
-        float v = 0.f;
-        if (r < nr) {
-          if (s == 0) v = a.dqp[(row0 + r) * 64 + (pos & 63)];
-          else
-            for (int lr = 0; lr < a.NLR; ++lr)
-              v += a.dkvp[(((((size_t)b * a.NLR + lr) * N + r0 + r) * 2 + (s - 1)) * 4 + qq) * 16 + k * 2 + j];
+    // dQKV rows: packed dq + dK/dV partials summed over the row-ranges (16-byte units)
+    {
+      const int U = nrp * 48;
+      for (int i0 = t; i0 < U; i0 += 512) {
+        float4 v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = i0 + u * 256, r = i / 48, pos4 = (i % 48) * 4, s = pos4 >> 6;
+          float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (i < U && r < nr) {
+            if (s == 0) acc4 = *reinterpret_cast<const float4*>(a.dqp + (row0 + r) * 64 + pos4);
+            else {
+#pragma unroll 4
+              for (int lr = 0; lr < a.NLR; ++lr) {
+                const float4 w = *reinterpret_cast<const float4*>(
+                    a.dkvp + ((((size_t)b * a.NLR + lr) * N + r0 + r) * 2 + (s - 1)) * 64 + (pos4 & 63));
+                acc4.x += w.x; acc4.y += w.y; acc4.z += w.z; acc4.w += w.w;
+              }
+            }
+          }
+          v[u] = acc4;
         }
-        dqs[r * ld3 + s * Dh + k * 8 + 2 * qq + j] = v;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = i0 + u * 256, r = i / 48, pos4 = (i % 48) * 4, s = pos4 >> 6;
+          if (i < U) {
+            const int qq = (pos4 >> 4) & 3, k0 = (pos4 >> 1) & 7;
+            float* d = dqs + r * ld3 + s * Dh + k0 * 8 + 2 * qq;
+            if (k0 < a.DK) { d[0] = v[u].x; d[1] = v[u].y; }
+            if (k0 + 1 < a.DK) { d[8] = v[u].z; d[9] = v[u].w; }
+          }
+        }
       }
     }
     __syncthreads();
@@ -310,7 +376,7 @@ __global__ void __launch_bounds__(256) k_node_pre_bwd(BlockArgs a) {
       const int rt = tile / nkt, kt = tile % nkt, kk = kt * 16 + p;
       const bool colok = kk < Dh;
       v4f acc = {0.f, 0.f, 0.f, 0.f};
-      acc = mm_xwt(dqs + rt * 16 * ld3, ld3, a.Wqkv + (size_t)kt * 16 * D3, D3, D3, p, q, colok, acc);
+      acc = mm_xwt(dqs + rt * 16 * ld3, ld3, ws + kt * 16 * ld3, ld3, D3, p, q, colok, acc);
       if (colok) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) dls[(rt * 16 + 4 * q + r) * ld + kk] = acc[r];
@@ -363,7 +429,7 @@ __global__ void __launch_bounds__(256) k_node_pre_bwd(BlockArgs a) {
         accBt += dl;
       }
   }
-  float* part = a.npart + (size_t)b * (Dh * D3 + D3 + 2 * Dh + Dh * Dh + Dh);
+  float* part = a.npart + (size_t)blockIdx.x * (Dh * D3 + D3 + 2 * Dh + Dh * Dh + Dh);
 #pragma unroll
   for (int j = 0; j < 12; ++j) {
     const int idx = wave + 4 * j;
@@ -385,7 +451,8 @@ __global__ void __launch_bounds__(256) k_node_pre_bwd(BlockArgs a) {
 
 // ------------------------------------------------------------ final reduce -----
 struct SumSeg { const float* src; float* dst; int n, np, stride, nblk; };
-struct SumArgs { SumSeg seg[8]; };
+#define SUM_MAX_SEG 77  // 11 layers x 7 segments: fits the 4 KiB kernel-argument block
+struct SumArgs { SumSeg seg[SUM_MAX_SEG]; };
 
 // 64 outputs per workgroup, the partial axis split over 4 wavefronts
 __global__ void __launch_bounds__(256) k_sum_segments(SumArgs s) {
@@ -448,44 +515,60 @@ __global__ void __launch_bounds__(256) k_edge_param_grads(BlockArgs a) {
 }
 
 // ---------------------------------------------------------------- launchers ----
+static int node_chunks(const BlockArgs& a) { return (a.N + NODE_RC - 1) / NODE_RC; }
 static size_t lds_rows(int Dh, int mult) { return (size_t)mult * NODE_RC * (Dh + LDP) * 4; }
 
 void egt_node_launch_pre(BlockArgs& a, hipStream_t st) {
-  size_t lds = lds_rows(a.Dh, 1);
+  size_t lds = lds_rows(a.Dh, 1) + (size_t)a.Dh * (3 * a.Dh + LDP) * 4;
   if (lds < 1024) lds = 1024;  // prep workgroup scratch
-  EGT_LAUNCH("k_node_pre", k_node_pre, dim3(a.B + 1), dim3(256), lds, st, a);
+  (void)hipFuncSetAttribute((const void*)k_node_pre, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  EGT_LAUNCH("k_node_pre", k_node_pre, dim3(a.B * node_chunks(a) + 1), dim3(256), lds, st, a);
 }
 
 void egt_node_launch_post(BlockArgs& a, hipStream_t st) {
-  EGT_LAUNCH("k_node_post", k_node_post, dim3(a.B), dim3(256), lds_rows(a.Dh, 1), st, a);
+  const size_t lds = lds_rows(a.Dh, 1) + (size_t)a.Dh * (a.Dh + LDP) * 4;
+  EGT_LAUNCH("k_node_post", k_node_post, dim3(a.B * node_chunks(a)), dim3(256), lds, st, a);
 }
 
 void egt_node_launch_post_bwd(BlockArgs& a, hipStream_t st) {
-  EGT_LAUNCH("k_node_post_bwd", k_node_post_bwd, dim3(a.B + 1), dim3(256), lds_rows(a.Dh, 2), st, a);
+  const size_t lds = lds_rows(a.Dh, 2) + (size_t)a.Dh * (a.Dh + LDP) * 4;
+  EGT_LAUNCH("k_node_post_bwd", k_node_post_bwd, dim3(a.B * node_chunks(a) + 1), dim3(256), lds, st, a);
 }
 
 void egt_node_launch_pre_bwd(BlockArgs& a, hipStream_t st) {
-  const size_t lds = lds_rows(a.Dh, 2) + ((size_t)NODE_RC * (3 * a.Dh + LDP) + NODE_RC) * 4;
+  const size_t lds = lds_rows(a.Dh, 2) + ((size_t)NODE_RC * (3 * a.Dh + LDP) + NODE_RC +
+                                           (size_t)a.Dh * (3 * a.Dh + LDP)) * 4;
   (void)hipFuncSetAttribute((const void*)k_node_pre_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  EGT_LAUNCH("k_node_pre_bwd", k_node_pre_bwd, dim3(a.B), dim3(256), lds, st, a);
+  EGT_LAUNCH("k_node_pre_bwd", k_node_pre_bwd, dim3(a.B * node_chunks(a)), dim3(256), lds, st, a);
 }
 
-void egt_node_launch_reduce(BlockArgs& a, int nwg_bwd, int EP, int npart_stride, hipStream_t st) {
-  const int Dh = a.Dh, D3 = 3 * Dh;
-  SumArgs s{};
-  const float* np = a.npart;
-  int o = 0, maxblk = 0;
-  auto seg = [&](int k, const float* src, float* dst, int n, int npart, int stride) {
-    s.seg[k] = SumSeg{src, dst, n, npart, stride, (n + 63) / 64};
-    if (s.seg[k].nblk > maxblk) maxblk = s.seg[k].nblk;
-  };
-  seg(0, np + o, a.g_Wqkv, Dh * D3, a.B, npart_stride); o += Dh * D3;
-  seg(1, np + o, a.g_bqkv, D3, a.B, npart_stride); o += D3;
-  seg(2, np + o, a.g_nm_g, Dh, a.B, npart_stride); o += Dh;
-  seg(3, np + o, a.g_nm_b, Dh, a.B, npart_stride); o += Dh;
-  seg(4, np + o, a.g_Wo, Dh * Dh, a.B, npart_stride); o += Dh * Dh;
-  seg(5, np + o, a.g_bo, Dh, a.B, npart_stride);
-  seg(6, a.epart, a.ered, EP, nwg_bwd, EP);
-  EGT_LAUNCH("k_sum_segments", k_sum_segments, dim3(maxblk, 7), dim3(256), 0, st, s);
-  EGT_LAUNCH("k_edge_param_grads", k_edge_param_grads, dim3(1), dim3(256), 0, st, a);
+// Reduce the per-workgroup partials of `n` layers (one BlockArgs each, with their own
+// npart / epart / ered and gradient pointers) and finish the edge-parameter gradients.
+void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, int npart_stride, hipStream_t st) {
+  for (int l0 = 0; l0 < n; l0 += 11) {
+    const int nl = (n - l0 < 11) ? (n - l0) : 11;
+    SumArgs s{};
+    int maxblk = 0, k = 0;
+    auto seg = [&](const float* src, float* dst, int cnt, int npart, int stride) {
+      s.seg[k] = SumSeg{src, dst, cnt, npart, stride, (cnt + 63) / 64};
+      if (s.seg[k].nblk > maxblk) maxblk = s.seg[k].nblk;
+      ++k;
+    };
+    for (int l = l0; l < l0 + nl; ++l) {
+      BlockArgs& a = as[l];
+      const int Dh = a.Dh, D3 = 3 * Dh, nnp = a.B * node_chunks(a);
+      const float* np = a.npart;
+      int o = 0;
+      seg(np + o, a.g_Wqkv, Dh * D3, nnp, npart_stride); o += Dh * D3;
+      seg(np + o, a.g_bqkv, D3, nnp, npart_stride); o += D3;
+      seg(np + o, a.g_nm_g, Dh, nnp, npart_stride); o += Dh;
+      seg(np + o, a.g_nm_b, Dh, nnp, npart_stride); o += Dh;
+      seg(np + o, a.g_Wo, Dh * Dh, nnp, npart_stride); o += Dh * Dh;
+      seg(np + o, a.g_bo, Dh, nnp, npart_stride);
+      seg(a.epart, a.ered, EP, nwg_bwd, EP);
+    }
+    EGT_LAUNCH("k_sum_segments", k_sum_segments, dim3(maxblk, k), dim3(256), 0, st, s);
+  }
+  for (int l = 0; l < n; ++l)
+    EGT_LAUNCH("k_edge_param_grads", k_edge_param_grads, dim3(1), dim3(256), 0, st, as[l]);
 }

@@ -119,3 +119,86 @@ def block_fused(blk, h, e, mask, attn_mask, rand_mask=None):
     if blk.edge_channel_type != "constrained":
         attn_mask = None
     return _FusedBlock.apply(h, e, mask, attn_mask, rand_mask, desc, *params)
+
+
+# ------------------------------------------------------------------ layer stack ---
+class _FusedStack(torch.autograd.Function):
+    """All model_height attention blocks in one C-ABI call per direction
+    (egt_stack_fwd / egt_stack_bwd)."""
+
+    @staticmethod
+    def forward(ctx, h, e, key_mask, attn_mask, desc, layers, *params):
+        _need_gpu(h, e)
+        lib = L.load()
+        h = _f32c(h); e = _f32c(e)
+        key_mask = _u8c(key_mask)
+        attn_mask = None if attn_mask is None else _f32c(attn_mask.to(torch.float32))
+        params = tuple(None if p is None else _f32c(p) for p in params)
+        dev = h.device
+        h_out, e_out = torch.empty_like(h), torch.empty_like(e)
+        saved = torch.empty(lib.egt_stack_saved_bytes(C.byref(desc), layers), dtype=torch.uint8, device=dev)
+        ws = torch.empty(lib.egt_stack_workspace_bytes(C.byref(desc), layers), dtype=torch.uint8, device=dev)
+        parr = (L.BlockParams * layers)(*[_params_struct(params[14 * i:14 * i + 14]) for i in range(layers)])
+        L.check(lib.egt_stack_fwd(C.byref(desc), layers, parr, L.ptr(h), L.ptr(e), L.ptr(key_mask),
+                                  L.ptr(attn_mask), L.ptr(h_out), L.ptr(e_out), L.ptr(saved), L.ptr(ws),
+                                  L.current_stream()))
+        ctx.desc, ctx.layers = desc, layers
+        ctx.save_for_backward(h, e, key_mask, attn_mask, saved, *params)
+        return h_out, e_out
+
+    @staticmethod
+    def backward(ctx, dh_out, de_out):
+        lib = L.load()
+        h, e, key_mask, attn_mask, saved, *params = ctx.saved_tensors
+        desc, layers = ctx.desc, ctx.layers
+        dev = h.device
+        dh_out = _f32c(dh_out); de_out = _f32c(de_out)
+        dh, de = torch.empty_like(h), torch.empty_like(e)
+        grads = [None if p is None else torch.empty_like(p) for p in params]
+        ws = torch.empty(lib.egt_stack_workspace_bytes(C.byref(desc), layers), dtype=torch.uint8, device=dev)
+        parr = (L.BlockParams * layers)(*[_params_struct(params[14 * i:14 * i + 14]) for i in range(layers)])
+        garr = (L.BlockParams * layers)(*[_params_struct(grads[14 * i:14 * i + 14]) for i in range(layers)])
+        L.check(lib.egt_stack_bwd(C.byref(desc), layers, parr, L.ptr(h), L.ptr(e), L.ptr(key_mask),
+                                  L.ptr(attn_mask), L.ptr(saved), L.ptr(dh_out), L.ptr(de_out), L.ptr(dh),
+                                  L.ptr(de), garr, L.ptr(ws), L.current_stream()))
+        return (dh, de, None, None, None, None, *grads)
+
+
+def stack_supported(stack, h, e, attn_mask) -> bool:
+    blocks = list(stack.blocks)
+    if not blocks or not hasattr(L.load(), "egt_stack_fwd"):
+        return False
+    b0 = blocks[0]
+    for b in blocks:
+        if b.fused is False or b.fused == "off":
+            return False
+        if not block_supported(b, h, e, attn_mask, None):
+            return False
+        same = (b.model_width == b0.model_width and b.edge_width == b0.edge_width and
+                b.edge_channel_type == b0.edge_channel_type and b.gated == b0.gated and
+                b.mha.clip_logits_value == b0.mha.clip_logits_value and
+                b.mha.random_mask_prob == b0.mha.random_mask_prob and b.training == b0.training)
+        if not same:
+            return False
+    return True
+
+
+def stack_fused(stack, h, e, mask, attn_mask):
+    blocks = list(stack.blocks)
+    b0 = blocks[0]
+    training = b0.training and b0.mha.random_mask_prob > 0.0
+    seed = b0.mha.next_seed() if training else 0
+    desc = _desc(b0, h.shape[0], h.shape[1], training, seed)
+    params = []
+    for blk in blocks:
+        for mod, attr in _GRAD_ORDER:
+            m = getattr(blk, mod, None)
+            params.append(None if m is None else getattr(m, attr))
+    if b0.edge_channel_type != "constrained":
+        attn_mask = None
+    return _FusedStack.apply(h, e, mask, attn_mask, desc, len(blocks), *params)
+
+
+def layer_seed(seed: int, layer: int) -> int:
+    """Seed of layer `layer` inside egt_stack_* (mirrors egt_block.hip:layer_seed)."""
+    return (seed ^ (0x9E3779B97F4A7C15 * (layer + 1))) & 0xFFFFFFFFFFFFFFFF

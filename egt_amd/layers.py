@@ -275,10 +275,15 @@ class EGTStack(nn.Module):
     def __init__(self, model_height=4, **block_kwargs):
         super().__init__()
         seed = block_kwargs.pop('seed', 0)
+        self.stack_call = block_kwargs.pop('stack_call', True)
         self.blocks = nn.ModuleList(
             [EGTBlock(seed=seed * 1000 + i, **block_kwargs) for i in range(model_height)])
 
     def forward(self, h, e, mask=None, attn_mask=None):
+        if self.stack_call and h.is_cuda:
+            from . import fused as FZ
+            if FZ.stack_supported(self, h, e, attn_mask):
+                return FZ.stack_fused(self, h, e, mask, attn_mask)   # one C-ABI call per direction
         for blk in self.blocks:
             h, e = blk(h, e, mask, attn_mask)
         return h, e

@@ -232,12 +232,35 @@ int egt_block_bwd(const egt_block_desc* desc, const egt_block_params* params,
                   void* d_h, void* d_e, const egt_block_params* grads,
                   void* workspace, void* stream);
 
+/* ---- the model_height loop over attention blocks -------------------------------
+ * Replaces the `for ii in range(model_height): h, e = edge_update(tag, h, e)` half
+ * of graph_xformer_model_base.py:336-339 when the blocks are applied back to back
+ * (the measurement configuration; the reference interleaves ffn_block, for which
+ * egt_block_fwd/bwd is the per-layer drop-in).  params / grads are arrays of
+ * `layers` structs.  saved keeps the layer activations h_l, e_l (l = 1..layers-1)
+ * and each layer's egt_block_saved buffer; in backward d_h / d_e carry the
+ * gradients down the stack in place and all parameter-gradient partial sums are
+ * reduced by one launch at the end.  Layer l draws its random attention mask from
+ * the counter hash seeded with desc->seed ^ 0x9E3779B97F4A7C15*(l+1). */
+size_t egt_stack_saved_bytes(const egt_block_desc* desc, int32_t layers);
+size_t egt_stack_workspace_bytes(const egt_block_desc* desc, int32_t layers);
+int egt_stack_fwd(const egt_block_desc* desc, int32_t layers,
+                  const egt_block_params* params, const void* h, const void* e,
+                  const uint8_t* key_mask, const void* attn_mask, void* h_out,
+                  void* e_out, void* saved, void* workspace, void* stream);
+int egt_stack_bwd(const egt_block_desc* desc, int32_t layers,
+                  const egt_block_params* params, const void* h, const void* e,
+                  const uint8_t* key_mask, const void* attn_mask, const void* saved,
+                  const void* d_h_out, const void* d_e_out, void* d_h, void* d_e,
+                  const egt_block_params* grads, void* workspace, void* stream);
+
 /* ---- per-kernel timing (measurement only) ------------------------------------
  * egt_prof_enable(1) makes every launch site bracket its kernel with hipEvents
  * on the launch stream (2 = reset counters and enable, 0 = off).  After the
  * caller has synchronised, egt_prof_read(name, ...) returns the launch count
  * and summed milliseconds of kernel `name`; egt_prof_names lists the names. */
 int egt_prof_enable(int on);
+int egt_prof_filter(const char* kernel_name); /* time only this kernel (NULL/"" = all) */
 int egt_prof_read(const char* name, int64_t* count, double* total_ms);
 int egt_prof_names(char* buf, size_t cap);
 

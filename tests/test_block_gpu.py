@@ -135,7 +135,7 @@ def test_fused_stack_matches_composed(gpu, egt_lib):
     from egt_amd import EGTStack
     torch.manual_seed(3)
     kw = dict(model_height=3, model_width=64, edge_width=64, num_heads=8)
-    a = EGTStack(fused=True, **kw).to(gpu).eval()
+    a = EGTStack(fused=True, stack_call=False, **kw).to(gpu).eval()
     b = EGTStack(fused=False, **kw).to(gpu).eval()
     b.load_state_dict(a.state_dict())
     h = torch.randn(2, 24, 64, device=gpu); e = torch.randn(2, 24, 24, 64, device=gpu)
@@ -143,3 +143,55 @@ def test_fused_stack_matches_composed(gpu, egt_lib):
     (h1, e1), (h2, e2) = a(h, e, mask), b(h, e, mask)
     assert_close(h1, h2, name="h", rtol=1e-4, arel=5e-5)
     assert_close(e1, e2, name="e", rtol=1e-4, arel=5e-5)
+
+
+@pytest.mark.parametrize("N,De,Dh,train", [(24, 64, 64, False), (32, 64, 64, True), (11, 48, 48, False),
+                                           (20, 8, 64, True)])
+def test_stack_call_vs_oracle(N, De, Dh, train, gpu, egt_lib):
+    """egt_stack_fwd/bwd (one C call per direction, deferred partial reduction) vs the fp64 oracle,
+    including the per-layer in-kernel random masks."""
+    from egt_amd import EGTStack
+    from egt_amd.fused import layer_seed
+    from oracle import egt_oracle as O, rng_ref
+    B, Ly, p = 2, 3, 0.2
+    torch.manual_seed(11)
+    st = EGTStack(model_height=Ly, model_width=Dh, edge_width=De, num_heads=8,
+                  random_mask_prob=p if train else 0.0, seed=5, fused=True).to(gpu).train(train)
+    with torch.no_grad():
+        for prm in st.parameters():
+            if prm.dim() == 1:
+                prm.add_(0.2 * torch.randn_like(prm))
+    g = torch.Generator().manual_seed(N * 7 + De)
+    h = torch.randn(B, N, Dh, generator=g); e = torch.randn(B, N, N, De, generator=g) * 1.3
+    mask = torch.ones(B, N, dtype=torch.bool); mask[1, N - 3:] = False
+    dh = torch.randn(B, N, Dh, generator=g); de = torch.randn(B, N, N, De, generator=g)
+    hg = h.to(gpu).requires_grad_(); eg = e.to(gpu).requires_grad_()
+    h2, e2 = st(hg, eg, mask.to(gpu))
+    torch.autograd.backward([h2, e2], [dh.to(gpu), de.to(gpu)])
+    # oracle
+    names = {"norm_edge.gamma": ("norm_edge", "gamma"), "norm_edge.beta": ("norm_edge", "beta"),
+             "attention_gates.kernel": ("attention_gates", "kernel"), "attention_gates.bias": ("attention_gates", "bias"),
+             "dense_edge_b.kernel": ("dense_edge_b", "kernel"), "dense_edge_b.bias": ("dense_edge_b", "bias"),
+             "norm_mha.gamma": ("norm_mha", "gamma"), "norm_mha.beta": ("norm_mha", "beta"),
+             "dense_qkv.kernel": ("dense_qkv", "kernel"), "dense_qkv.bias": ("dense_qkv", "bias"),
+             "dense_mha.kernel": ("dense_mha", "kernel"), "dense_mha.bias": ("dense_mha", "bias"),
+             "dense_edge_r.kernel": ("dense_edge_r", "kernel"), "dense_edge_r.bias": ("dense_edge_r", "bias")}
+    layers = [{k: getattr(getattr(blk, m), a_).detach().double().cpu().requires_grad_()
+               for k, (m, a_) in names.items()} for blk in st.blocks]
+    rms = None
+    if train:
+        b0 = st.blocks[0].mha
+        seed = (b0.seed * 0x9E3779B97F4A7C15 + b0._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        rms = [torch.from_numpy(rng_ref.random_mask(layer_seed(seed, l), B, N, 8, p)) for l in range(Ly)]
+    h64 = h.double().requires_grad_(); e64 = e.double().requires_grad_()
+    ho, eo = O.stack_forward(h64, e64, mask, layers, num_heads=8, rand_masks=rms)
+    flat = [t for lp in layers for t in lp.values()]
+    gr = torch.autograd.grad([ho, eo], [h64, e64] + flat, [dh.double(), de.double()])
+    assert_close(h2, ho, name="h_out", rtol=2e-4, arel=5e-5)
+    assert_close(e2, eo, name="e_out", rtol=2e-4, arel=5e-5)
+    assert_close(hg.grad, gr[0], name="dh", **BWD)
+    assert_close(eg.grad, gr[1], name="de", **BWD)
+    gi = iter(gr[2:])
+    for li, blk in enumerate(st.blocks):
+        for k, (m, a_) in names.items():
+            assert_close(getattr(getattr(blk, m), a_).grad, next(gi), name=f"L{li}.{k}", **BWD)
