@@ -68,3 +68,30 @@ class FlatGradAllReduce:
         if average:
             self.flat.div_(ws)
         return self.flat
+
+
+def flat_grad_view(params, flat) -> bool:
+    """True iff `flat` already aliases every parameter's .grad, in order (the layout the
+    fused stack backward produces) — then one collective on `flat` reduces everything."""
+    if flat is None:
+        return False
+    off, base = 0, flat.data_ptr()
+    for p in params:
+        g = p.grad
+        if g is None or not g.is_contiguous() or g.data_ptr() != base + off * flat.element_size():
+            return False
+        off += p.numel()
+    return off == flat.numel()
+
+
+def all_reduce_flat(flat, process_group=None, average=True):
+    """The single per-step collective: sum over ranks, then /world."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat
+    ws = dist.get_world_size(process_group)
+    if ws == 1:
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
+    if average:
+        flat.div_(ws)
+    return flat

@@ -127,7 +127,7 @@ class _FusedStack(torch.autograd.Function):
     (egt_stack_fwd / egt_stack_bwd)."""
 
     @staticmethod
-    def forward(ctx, h, e, key_mask, attn_mask, desc, layers, *params):
+    def forward(ctx, h, e, key_mask, attn_mask, desc, layers, holder, *params):
         _need_gpu(h, e)
         lib = L.load()
         h = _f32c(h); e = _f32c(e)
@@ -142,7 +142,7 @@ class _FusedStack(torch.autograd.Function):
         L.check(lib.egt_stack_fwd(C.byref(desc), layers, parr, L.ptr(h), L.ptr(e), L.ptr(key_mask),
                                   L.ptr(attn_mask), L.ptr(h_out), L.ptr(e_out), L.ptr(saved), L.ptr(ws),
                                   L.current_stream()))
-        ctx.desc, ctx.layers = desc, layers
+        ctx.desc, ctx.layers, ctx.holder = desc, layers, holder
         ctx.save_for_backward(h, e, key_mask, attn_mask, saved, *params)
         return h_out, e_out
 
@@ -154,14 +154,26 @@ class _FusedStack(torch.autograd.Function):
         dev = h.device
         dh_out = _f32c(dh_out); de_out = _f32c(de_out)
         dh, de = torch.empty_like(h), torch.empty_like(e)
-        grads = [None if p is None else torch.empty_like(p) for p in params]
+        # every parameter gradient is a view of ONE flat buffer: the data-parallel all-reduce
+        # (egt_amd.dp) runs on it directly, and autograd adopts the views without copies
+        total = sum(p.numel() for p in params if p is not None)
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        grads, off = [], 0
+        for p in params:
+            if p is None:
+                grads.append(None)
+            else:
+                grads.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        if ctx.holder is not None:
+            ctx.holder.flat = flat
         ws = torch.empty(lib.egt_stack_workspace_bytes(C.byref(desc), layers), dtype=torch.uint8, device=dev)
         parr = (L.BlockParams * layers)(*[_params_struct(params[14 * i:14 * i + 14]) for i in range(layers)])
         garr = (L.BlockParams * layers)(*[_params_struct(grads[14 * i:14 * i + 14]) for i in range(layers)])
         L.check(lib.egt_stack_bwd(C.byref(desc), layers, parr, L.ptr(h), L.ptr(e), L.ptr(key_mask),
                                   L.ptr(attn_mask), L.ptr(saved), L.ptr(dh_out), L.ptr(de_out), L.ptr(dh),
                                   L.ptr(de), garr, L.ptr(ws), L.current_stream()))
-        return (dh, de, None, None, None, None, *grads)
+        return (dh, de, None, None, None, None, None, *grads)
 
 
 def stack_supported(stack, h, e, attn_mask) -> bool:
@@ -196,7 +208,7 @@ def stack_fused(stack, h, e, mask, attn_mask):
             params.append(None if m is None else getattr(m, attr))
     if b0.edge_channel_type != "constrained":
         attn_mask = None
-    return _FusedStack.apply(h, e, mask, attn_mask, desc, len(blocks), *params)
+    return _FusedStack.apply(h, e, mask, attn_mask, desc, len(blocks), stack.grad_holder, *params)
 
 
 def layer_seed(seed: int, layer: int) -> int:

@@ -276,8 +276,21 @@ class EGTStack(nn.Module):
         super().__init__()
         seed = block_kwargs.pop('seed', 0)
         self.stack_call = block_kwargs.pop('stack_call', True)
+        self.grad_holder = SimpleNamespace(flat=None)   # flat gradient buffer of the last fused backward
         self.blocks = nn.ModuleList(
             [EGTBlock(seed=seed * 1000 + i, **block_kwargs) for i in range(model_height)])
+
+    def fused_parameters(self):
+        """Parameters in the order the fused stack lays their gradients out in
+        grad_holder.flat (layer-major, the C-ABI egt_block_params order)."""
+        from .fused import _GRAD_ORDER
+        out = []
+        for blk in self.blocks:
+            for mod, attr in _GRAD_ORDER:
+                m = getattr(blk, mod, None)
+                if m is not None:
+                    out.append(getattr(m, attr))
+        return out
 
     def forward(self, h, e, mask=None, attn_mask=None):
         if self.stack_call and h.is_cuda:
