@@ -16,6 +16,7 @@ struct BlockArgs {
   uint32_t rm_thr, s0, s1;
   int rng_rm;
   int TL, NLR;  // backward: query rows per workgroup, row-ranges per graph
+  int NQP;      // backward: dQ partials per row (key tiles) in dqp [B][NQP][N][64]
   // params
   const float *ne_g, *ne_b, *Wg, *bg, *We, *be, *nm_g, *nm_b, *Wqkv, *bqkv, *Wo, *bo, *Wr, *br;
   // tensors

@@ -52,6 +52,42 @@ __device__ __forceinline__ float egt_sigmoid(float x) {
 
 __device__ __forceinline__ float wave_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
 
+// ---- cross-lane exchange on the VALU (no LDS-crossbar round trip) -------------------
+// DPP: value of lane (i ^ MASK) for MASK in {1,2,4,8} inside each 16-lane row.
+template <int CTRL>
+__device__ __forceinline__ float egt_dpp(float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xF, 0xF, false));
+}
+template <int MASK>
+__device__ __forceinline__ float lane_xor(float v) {
+  static_assert(MASK == 1 || MASK == 2 || MASK == 4 || MASK == 8, "row-local xor only");
+  if (MASK == 1) return egt_dpp<0xB1>(v);                      // quad_perm [1,0,3,2]
+  if (MASK == 2) return egt_dpp<0x4E>(v);                      // quad_perm [2,3,0,1]
+  if (MASK == 4) return egt_dpp<0x1B>(egt_dpp<0x141>(v));      // row_half_mirror (i^7) o quad reverse (i^3)
+  return egt_dpp<0x141>(egt_dpp<0x140>(v));                    // row_mirror (i^15) o row_half_mirror (i^7)
+}
+// v_permlane16_swap / v_permlane32_swap with both operands = v leave {own, partner} of the
+// lanes i and i^16 (resp. i^32) in the two results: any commutative op of the pair is the
+// two-lane reduction.
+__device__ __forceinline__ float sum_xor16(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_xor32(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// all-reduce over the 16 lanes of a row
+__device__ __forceinline__ float row_sum16(float v) {
+  v += lane_xor<1>(v); v += lane_xor<2>(v); v += lane_xor<4>(v); v += lane_xor<8>(v);
+  return v;
+}
+__device__ __forceinline__ float row_max16(float v) {
+  v = fmaxf(v, lane_xor<1>(v)); v = fmaxf(v, lane_xor<2>(v));
+  v = fmaxf(v, lane_xor<4>(v)); v = fmaxf(v, lane_xor<8>(v));
+  return v;
+}
+
 // ---- kernel timing hooks (egt_capi.hip) ---------------------------------------
 int egt_prof_is_enabled();
 void egt_prof_begin(const char* name, hipStream_t s, void** tok);

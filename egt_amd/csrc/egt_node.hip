@@ -13,11 +13,7 @@
 
 #define LDP 4  // LDS row padding (floats)
 
-__device__ __forceinline__ float sum16(float v) {
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-  return v;
-}
+__device__ __forceinline__ float sum16(float v) { return row_sum16(v); }
 
 // acc += X[16 rows][K] . W[K][16 cols]; X and W staged in LDS (strides ld / ldw, W pointer
 // already at column 0 of the tile); colok: this lane's output column exists
@@ -253,7 +249,7 @@ __global__ void __launch_bounds__(256) k_node_post_bwd(BlockArgs a) {
           const int row = rt * 16 + 4 * q + r;
           if (colok && row < nr) a.dvp[(row0 + row) * 64 + pos] = acc[r];
           float pr = colok ? acc[r] * vs[row * ld + i] : 0.f;
-          pr += __shfl_xor(pr, 8, 64);   // the tile's two k values of head p&7
+          pr += lane_xor<8>(pr);   // the tile's two k values of head p&7
           dl[r] += pr;
         }
       }
@@ -331,7 +327,14 @@ __global__ void __launch_bounds__(256) k_node_pre_bwd(BlockArgs a) {
           const int i = i0 + u * 256, r = i / 48, pos4 = (i % 48) * 4, s = pos4 >> 6;
           float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
           if (i < U && r < nr) {
-            if (s == 0) acc4 = *reinterpret_cast<const float4*>(a.dqp + (row0 + r) * 64 + pos4);
+            if (s == 0) {
+#pragma unroll 4
+              for (int qp = 0; qp < a.NQP; ++qp) {
+                const float4 w = *reinterpret_cast<const float4*>(
+                    a.dqp + (((size_t)b * a.NQP + qp) * N + r0 + r) * 64 + pos4);
+                acc4.x += w.x; acc4.y += w.y; acc4.z += w.z; acc4.w += w.w;
+              }
+            }
             else {
 #pragma unroll 4
               for (int lr = 0; lr < a.NLR; ++lr) {
