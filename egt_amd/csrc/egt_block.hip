@@ -1005,6 +1005,314 @@ __global__ void __launch_bounds__(256, WPS) k_block_bwd_dma(BlockArgs a) {
     out[i] = (sm[i] + sm[G::EP + i]) + (sm[2 * G::EP + i] + sm[3 * G::EP + i]);
 }
 
+
+// ================================================ backward, register-lean ("v4") ====
+// Same math as k_block_bwd for full 16-key tiles, restructured so that two wavefronts fit a
+// SIMD (<= 256 registers, <= 80 KiB LDS per workgroup): the long per-tile dependency chain
+// (LayerNorm -> MFMA chain -> exp/sigmoid -> MFMA chain -> LayerNorm backward) is latency-,
+// not throughput-bound, so a second resident wave is worth more than fat register tiles.
+//  * all lane-constant MFMA weight operands live in LDS as [t][lane] float4 slabs
+//    (conflict-free ds_read_b128) and are fetched right before their MFMA group;
+//  * xhat and de' fragments are re-read from their LDS tiles where they are needed again
+//    (LayerNorm backward) instead of being held across the tile;
+//  * dQ partials go to HBM per key tile (summed in k_node_pre_bwd) instead of an LDS slab;
+//  * scheduling fences between the phases keep the compiler from hoisting every LDS read to
+//    the top of the tile (which is what blows the register budget).
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// PF: how many of the two streamed tiles (e, de') are register-prefetched one row ahead.
+template <int DE, bool ML, int PF>
+__global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
+  using G = Geo<DE>;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = lane & 15, q = lane >> 4;
+  const int N = a.N, TL = a.TL;
+  const int b = blockIdx.x / a.NLR, lr = blockIdx.x % a.NLR;
+  const int l_begin = lr * TL, l_end = min(N, l_begin + TL), nl = l_end - l_begin;
+  const bool gated = (a.flags & EGT_BF_GATE) != 0;
+  const bool clip = (a.flags & EGT_BF_CLIP) != 0;
+  constexpr int PW = 3 * G::TILE_FLOATS + 256 + 192;
+  constexpr int WSLAB = G::TILES * 256;      // one weight slab: [TILES][64 lanes] float4
+  float* et = sm + wave * PW;
+  float* dt0 = et + G::TILE_FLOATS;
+  float* sc1 = dt0 + 2 * G::TILE_FLOATS;
+  float* sc2 = sc1 + 256;
+  float* qd = sm + 4 * PW;                   // [TL][QD_LD]
+  float* wsA = qd + TL * QD_LD;              // prologue weights   wA[4t+u]
+  float* wsB = wsA + WSLAB;                  // dH_ext weights     wrB[4t+u]
+  float* wsD = wsB + WSLAB;                  // d(ehat) weights    wD[t][s]
+  for (int i = threadIdx.x; i < nl * 40; i += 256) {
+    const int r = i / 40, f = i % 40;
+    const size_t rowl = (size_t)b * N + l_begin + r;
+    const float* src = f < 16 ? a.qkvp + rowl * QKVP + f * 4
+                     : f < 32 ? a.dvp + rowl * 64 + (f - 16) * 4
+                              : a.stats + rowl * 32 + (f - 32) * 4;
+    float4 v = *reinterpret_cast<const float4*>(src);
+    if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
+    *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
+  }
+  // weight slabs: element (t, lane, u)
+  for (int i = threadIdx.x; i < G::TILES * 256; i += 256) {
+    const int t = i >> 8, ln = (i >> 2) & 63, u = i & 3, pp = ln & 15, qq = ln >> 4;
+    const int c = 16 * t + 4 * qq + u;
+    wsA[i] = a.pw[c * 16 + pp];
+    const int hd = 2 * (pp >> 2) + (pp & 1);
+    wsB[i] = ((pp & 2) == 0 && c < DE) ? a.Wr[hd * DE + c] : 0.f;
+    wsD[i] = a.pw[(16 * t + pp) * 16 + 4 * qq + u];
+  }
+  float c2r[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c2r[r] = a.pw[G::DEP * 16 + 4 * q + r];
+
+  v4f accT[G::TILES], accR[G::TILES];
+#pragma unroll
+  for (int t = 0; t < G::TILES; ++t) { accT[t] = (v4f){0.f, 0.f, 0.f, 0.f}; accR[t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  const int ntile = N / 16;
+  for (int mt = wave; mt < ntile; mt += 4) {
+    const int m0 = mt * 16, m = m0 + p;
+    float Kf[16], Vf[16], dKa[16], dVa[16];
+    const size_t rowm = (size_t)b * N + m;
+    {
+      const float4* kp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 64 + q * 16);
+      const float4* vp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 128 + q * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 kv = kp[i], vv = vp[i];
+        Kf[4*i] = kv.x; Kf[4*i+1] = kv.y; Kf[4*i+2] = kv.z; Kf[4*i+3] = kv.w;
+        Vf[4*i] = vv.x; Vf[4*i+1] = vv.y; Vf[4*i+2] = vv.z; Vf[4*i+3] = vv.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { dKa[i] = 0.f; dVa[i] = 0.f; }
+    }
+    const float kadd = (a.km && a.km[rowm] == 0) ? -EGT_NEG : 0.0f;
+
+    TileRegs<DE> te, td;
+    {
+      const size_t pair0 = ((size_t)b * N + l_begin) * N + m0;
+      if (PF >= 1) tile_gload<DE>(te, a.e + pair0 * DE, lane, 16);
+      if (PF >= 2) tile_gload<DE>(td, a.de_out + pair0 * DE, lane, 16);
+    }
+    for (int l = l_begin; l < l_end; ++l) {
+      const int li = l - l_begin;
+      const size_t rowl = (size_t)b * N + l;
+      const size_t pair0 = rowl * N + m0;
+      float* dt = dt0 + (li & 1) * G::TILE_FLOATS;
+      MaskRegs mr{make_float2(1.f, 1.f), 0};
+      mask_gload<ML>(a, mr, pair0 + p, q);
+      // memory order per step: [stores of row l-1] then [loads of row l+1] (see k_block_fwd)
+      lds_sync();
+      if (li > 0)
+        tile_from_lds<DE>(dt0 + ((li - 1) & 1) * G::TILE_FLOATS, a.de + (pair0 - (size_t)N) * DE, lane, 16);
+      if (PF < 2) tile_gload<DE>(td, a.de_out + pair0 * DE, lane, 16);
+      if (PF < 1) tile_gload<DE>(te, a.e + pair0 * DE, lane, 16);
+      tile_lds_put<DE>(et, te, lane, 16);
+      tile_lds_put<DE>(dt, td, lane, 16);
+      if (l + 1 < l_end) {
+        if (PF >= 1) tile_gload<DE>(te, a.e + (pair0 + (size_t)N) * DE, lane, 16);
+        if (PF >= 2) tile_gload<DE>(td, a.de_out + (pair0 + (size_t)N) * DE, lane, 16);
+      }
+      lds_sync();
+      SCHED_FENCE();
+      // ---- P1: norm_edge, projections (recompute) ----
+      float rstd;
+      v4f acc = {c2r[0], c2r[1], c2r[2], c2r[3]};
+      {
+        float4 x[G::TILES];
+#pragma unroll
+        for (int t = 0; t < G::TILES; ++t) x[t] = frag_read<DE>(et, p, q, t);
+        rstd = ln_frags<DE>(x, q, a.ln_eps);
+#pragma unroll
+        for (int t = 0; t < G::TILES; ++t) {
+          frag_write<DE>(et, p, q, t, x[t]);     // xhat stays in the tile for the later phases
+          const float4 w = *reinterpret_cast<const float4*>(wsA + (t * 64 + lane) * 4);
+          acc = MFMA(w.x, x[t].x, acc);
+          acc = MFMA(w.y, x[t].y, acc);
+          acc = MFMA(w.z, x[t].z, acc);
+          acc = MFMA(w.w, x[t].w, acc);
+        }
+      }
+      SCHED_FENCE();
+      // ---- P2: dH_ext = de'.Wr^T ----
+      v4f dhx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < G::TILES; ++t) {
+        const float4 dyv = frag_read<DE>(dt, p, q, t);
+        const float4 w = *reinterpret_cast<const float4*>(wsB + (t * 64 + lane) * 4);
+        dhx = MFMA(w.x, dyv.x, dhx);
+        dhx = MFMA(w.y, dyv.y, dhx);
+        dhx = MFMA(w.z, dyv.z, dhx);
+        dhx = MFMA(w.w, dyv.w, dhx);
+      }
+      SCHED_FENCE();
+      // ---- P3: logits, softmax/gate backward, dQ/dK/dV ----
+      // Q / dV_att fragments are fetched from LDS twice (once for the dot products, once for the
+      // dK/dV accumulation) instead of being held across the exp / sigmoid chain.
+      float dge[4], hh[2], dA[2], at[2];
+      {
+        const float* qr = qd + li * QD_LD;
+        float dots[2], dAd[2];
+        {
+          const float4* qp = reinterpret_cast<const float4*>(qr + q * 16);
+          const float4* dp = reinterpret_cast<const float4*>(qr + 64 + q * 16);
+          float d0 = 0.f, d1 = 0.f, e0 = 0.f, e1 = 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float4 u = qp[i], v = dp[i];
+            d0 = fmaf(u.x, Kf[4*i], d0);   d1 = fmaf(u.y, Kf[4*i+1], d1);
+            d0 = fmaf(u.z, Kf[4*i+2], d0); d1 = fmaf(u.w, Kf[4*i+3], d1);
+            e0 = fmaf(v.x, Vf[4*i], e0);   e1 = fmaf(v.y, Vf[4*i+1], e1);
+            e0 = fmaf(v.z, Vf[4*i+2], e0); e1 = fmaf(v.w, Vf[4*i+3], e1);
+          }
+          dots[0] = d0; dots[1] = d1; dAd[0] = e0; dAd[1] = e1;
+        }
+        const float4* sp = reinterpret_cast<const float4*>(qr + 128 + q * 8);
+        const float4 s0 = sp[0], s1 = sp[1];
+        const float st[8] = {s0.x, s0.y, s0.z, 0.f, s1.x, s1.y, s1.z, 0.f};
+        float xl[2], gl[2], inr[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float araw = dots[j] * a.scale;
+          float ah = araw;
+          inr[j] = 1.0f;
+          if (clip) {
+            inr[j] = (araw >= a.clip_lo && araw <= a.clip_hi) ? 1.0f : 0.0f;
+            ah = fminf(fmaxf(araw, a.clip_lo), a.clip_hi);
+          }
+          hh[j] = ah + acc[2 * j + 1];
+          xl[j] = hh[j];
+          gl[j] = acc[2 * j];
+        }
+        apply_masks<ML>(a, kadd, mr, (pair0 + p) * BH, q, xl, gl);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float S = __expf(xl[j] - st[4 * j]) * st[4 * j + 1];
+          const float g = gated ? egt_sigmoid(gl[j]) : 1.0f;
+          const float dS = dAd[j] * g;
+          const float dGl = gated ? dAd[j] * S * g * (1.0f - g) : 0.f;
+          const float dH = S * (dS - st[4 * j + 2]) + dhx[j];
+          dA[j] = dH * inr[j] * a.scale;
+          at[j] = S * g;
+          dge[2 * j] = dGl;
+          dge[2 * j + 1] = dH;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ssum[r] += dge[r];
+      *reinterpret_cast<float4*>(sc1 + p * 16 + 4 * q) = make_float4(dge[0], dge[1], dge[2], dge[3]);
+      *reinterpret_cast<float2*>(sc2 + p * 12 + 2 * q) = make_float2(hh[0], hh[1]);
+      if (q == 0) sc2[p * 12 + 8] = 1.0f;
+      lds_sync();
+      SCHED_FENCE();
+      {
+        const float* qr = qd + li * QD_LD;
+        const float4* qp = reinterpret_cast<const float4*>(qr + q * 16);
+        const float4* dp = reinterpret_cast<const float4*>(qr + 64 + q * 16);
+        float dq[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 u = qp[i], v = dp[i];
+          dKa[4*i]   = fmaf(dA[0], u.x, dKa[4*i]);   dKa[4*i+1] = fmaf(dA[1], u.y, dKa[4*i+1]);
+          dKa[4*i+2] = fmaf(dA[0], u.z, dKa[4*i+2]); dKa[4*i+3] = fmaf(dA[1], u.w, dKa[4*i+3]);
+          dVa[4*i]   = fmaf(at[0], v.x, dVa[4*i]);   dVa[4*i+1] = fmaf(at[1], v.y, dVa[4*i+1]);
+          dVa[4*i+2] = fmaf(at[0], v.z, dVa[4*i+2]); dVa[4*i+3] = fmaf(at[1], v.w, dVa[4*i+3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { dq[2 * k] = dA[0] * Kf[2 * k]; dq[2 * k + 1] = dA[1] * Kf[2 * k + 1]; }
+        // dQ[l] partial over this tile's 16 keys -> HBM, summed over key tiles in k_node_pre_bwd
+        a.dqp[(((size_t)b * ntile + mt) * N + l) * 64 + lane] = reduce16_keep_own(dq, p);
+      }
+      SCHED_FENCE();
+      // ---- P4: weight-gradient contractions over the 16 pairs of the tile ----
+      {
+        float bT[4], bR[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          bT[s] = sc1[(q + 4 * s) * 16 + p];
+          bR[s] = (p < 9) ? sc2[(q + 4 * s) * 12 + p] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < G::TILES; ++t)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            accT[t] = MFMA(elem_read<DE>(et, q + 4 * s, 16 * t + p), bT[s], accT[t]);
+            accR[t] = MFMA(elem_read<DE>(dt, q + 4 * s, 16 * t + p), bR[s], accR[t]);
+          }
+      }
+      lds_sync();
+      SCHED_FENCE();
+      // ---- P5: d(ehat) = Wp . dGE, LayerNorm backward, de = de' + ... in place over the de' tile ----
+      {
+        float4 dxh[G::TILES];
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < G::TILES; ++t) {
+          const float4 w = *reinterpret_cast<const float4*>(wsD + (t * 64 + lane) * 4);
+          const float4 xh = frag_read<DE>(et, p, q, t);
+          v4f d = {0.f, 0.f, 0.f, 0.f};
+          d = MFMA(w.x, dge[0], d);
+          d = MFMA(w.y, dge[1], d);
+          d = MFMA(w.z, dge[2], d);
+          d = MFMA(w.w, dge[3], d);
+          dxh[t] = make_float4(d[0], d[1], d[2], d[3]);
+          m1 += (d[0] + d[1]) + (d[2] + d[3]);
+          m2 = fmaf(d[0], xh.x, m2); m2 = fmaf(d[1], xh.y, m2);
+          m2 = fmaf(d[2], xh.z, m2); m2 = fmaf(d[3], xh.w, m2);
+        }
+        m1 = sum_over_q(m1) * (1.0f / DE);
+        m2 = sum_over_q(m2) * (1.0f / DE);
+        lds_sync();
+#pragma unroll
+        for (int t = 0; t < G::TILES; ++t) {
+          const float4 dyv = frag_read<DE>(dt, p, q, t);
+          const float4 xh = frag_read<DE>(et, p, q, t);
+          float4 o;
+          o.x = dyv.x + rstd * (dxh[t].x - m1 - xh.x * m2);
+          o.y = dyv.y + rstd * (dxh[t].y - m1 - xh.y * m2);
+          o.z = dyv.z + rstd * (dxh[t].z - m1 - xh.z * m2);
+          o.w = dyv.w + rstd * (dxh[t].w - m1 - xh.w * m2);
+          frag_write<DE>(dt, p, q, t, o);
+        }
+      }
+      SCHED_FENCE();
+    }
+    {  // flush the last row of this key tile
+      lds_sync();
+      tile_from_lds<DE>(dt0 + ((nl - 1) & 1) * G::TILE_FLOATS,
+                        a.de + (((size_t)b * N + l_end - 1) * N + m0) * DE, lane, 16);
+    }
+    float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
+    float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
+      vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ssum[r] = row_sum16(ssum[r]);
+  __syncthreads();
+  float* ep = sm + wave * G::EP;
+#pragma unroll
+  for (int t = 0; t < G::TILES; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ep[(16 * t + 4 * q + r) * 16 + p] = accT[t][r];
+      ep[G::DEP * 16 + 16 + (16 * t + 4 * q + r) * 16 + p] = accR[t][r];
+    }
+  if (p == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ep[G::DEP * 16 + 4 * q + r] = ssum[r];
+  }
+  __syncthreads();
+  float* out = a.epart + (size_t)blockIdx.x * G::EP;
+  for (int i = threadIdx.x; i < G::EP; i += 256)
+    out[i] = (sm[i] + sm[G::EP + i]) + (sm[2 * G::EP + i] + sm[3 * G::EP + i]);
+}
+
 // ================================================================ host glue ====
 
 
@@ -1167,6 +1475,24 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
   const bool ml = a.M != nullptr || a.rm != nullptr;
   const bool full = (a.N % 16) == 0;
   if constexpr (DE % 16 == 0) {
+    if (full && !egt_env_flag("EGT_BWD_V2") && !egt_env_flag("EGT_BWD_DMA")) {   // register-lean, 2 waves/SIMD
+      const size_t lds_v4 = ((size_t)4 * PW + (size_t)BWD_TL * QD_LD + 3 * GG::TILES * 256) * 4;
+      a.NQP = a.N / 16;
+#define V4_VARIANT(ML_, PF_)                                                                           \
+  do {                                                                                                 \
+    (void)hipFuncSetAttribute((const void*)k_block_bwd_v4<DE, ML_, PF_>,                               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
+    EGT_LAUNCH("k_block_bwd", (k_block_bwd_v4<DE, ML_, PF_>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a); \
+  } while (0)
+      const char* pfe = getenv("EGT_BWD_PF");
+      const int pf = pfe ? atoi(pfe) : 0;   // two resident waves hide the HBM latency; prefetch registers only spill
+      if (ml) V4_VARIANT(true, 0);
+      else if (pf == 0) V4_VARIANT(false, 0);
+      else if (pf == 1) V4_VARIANT(false, 1);
+      else V4_VARIANT(false, 2);
+#undef V4_VARIANT
+      goto pair_done;
+    }
     if (full && egt_env_flag("EGT_BWD_DMA")) {   // experimental DMA-staged variant (hipcc drains vmcnt after every LDS-DMA)
       constexpr int WL = GG::DEP + 4;
       const size_t lds_dma = ((size_t)4 * PW + (size_t)BWD_TL * QD_LD + 24 * WL) * 4;
