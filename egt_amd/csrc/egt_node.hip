@@ -19,6 +19,7 @@ __device__ __forceinline__ float sum16(float v) { return row_sum16(v); }
 // already at column 0 of the tile); colok: this lane's output column exists
 __device__ __forceinline__ v4f mm_xw(const float* xs, int ld, const float* W, int ldw,
                                      int K, int p, int q, bool colok, v4f acc) {
+#pragma unroll 4
   for (int t = 0; t < K; t += 4) {
     const float bv = colok ? W[(size_t)(t + q) * ldw + p] : 0.f;
     acc = MFMA(xs[p * ld + t + q], bv, acc);
@@ -28,6 +29,7 @@ __device__ __forceinline__ v4f mm_xw(const float* xs, int ld, const float* W, in
 // acc += X[16 rows][K] . W^T, W = [16 out-rows][K] in LDS (row stride ldw, pointer at out-row 0)
 __device__ __forceinline__ v4f mm_xwt(const float* xs, int ld, const float* W, int ldw,
                                       int K, int p, int q, bool colok, v4f acc) {
+#pragma unroll 4
   for (int t = 0; t < K; t += 4) {
     const float bv = colok ? W[(size_t)p * ldw + t + q] : 0.f;
     acc = MFMA(xs[p * ld + t + q], bv, acc);
@@ -40,7 +42,7 @@ __device__ __forceinline__ v4f mm_xwt(const float* xs, int ld, const float* W, i
 __device__ void prep_device(const BlockArgs& a, float* red) {
   const int De = a.De, DEP = ((De + 15) / 16) * 16, t = threadIdx.x;
   const bool gated = (a.flags & EGT_BF_GATE) != 0;
-  for (int idx = t; idx < DEP * 16; idx += 256) {
+  for (int idx = t; idx < DEP * 16; idx += blockDim.x) {
     const int c = idx >> 4, i = idx & 15;
     float v = 0.f;
     if (c < De) {
@@ -50,7 +52,7 @@ __device__ void prep_device(const BlockArgs& a, float* red) {
     }
     a.pw[idx] = v;
   }
-  {
+  if (t < 256) {
     const int i = t & 15, part = t >> 4, hd = col_head(i);
     const bool isg = col_is_gate(i);
     float v = 0.f;
@@ -77,16 +79,17 @@ __device__ void prep_device(const BlockArgs& a, float* red) {
 // flight per thread before the LDS writes
 __device__ __forceinline__ void stage_weight(float* ws, int ldw, const float* W, int rows, int width) {
   const int n4 = rows * width / 4;
-  for (int i0 = threadIdx.x; i0 < n4; i0 += 1024) {
+  const int NT = blockDim.x;
+  for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * NT) {
     float4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * 256;
+      const int i = i0 + u * NT;
       v[u] = *reinterpret_cast<const float4*>(W + (size_t)(i < n4 ? i : 0) * 4);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * 256;
+      const int i = i0 + u * NT;
       if (i < n4) {
         const int r = (i * 4) / width, c = (i * 4) % width;
         *reinterpret_cast<float4*>(ws + r * ldw + c) = v[u];
@@ -97,31 +100,31 @@ __device__ __forceinline__ void stage_weight(float* ws, int ldw, const float* W,
 
 // stage `nr` rows of a [.., width] tensor into LDS (stride ld), zero-padding up to nrp rows
 __device__ __forceinline__ void stage_rows(float* xs, int ld, const float* src, int width, int nr, int nrp) {
-  const int w4 = width >> 2, n4 = nrp * w4;
-  for (int i0 = threadIdx.x; i0 < n4; i0 += 1024) {
+  const int w4 = width >> 2, n4 = nrp * w4, NT = blockDim.x;
+  for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * NT) {
     float4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * 256, r = i / w4, c4 = i % w4;
+      const int i = i0 + u * NT, r = i / w4, c4 = i % w4;
       const bool ok = i < n4 && r < nr;
       v[u] = *reinterpret_cast<const float4*>(src + (ok ? (size_t)r * width + c4 * 4 : 0));
       if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * 256, r = i / w4, c4 = i % w4;
+      const int i = i0 + u * NT, r = i / w4, c4 = i % w4;
       if (i < n4) *reinterpret_cast<float4*>(xs + r * ld + c4 * 4) = v[u];
     }
   }
 }
 
 // --------------------------------------------------------------- node: pre -----
-__global__ void __launch_bounds__(256) k_node_pre(BlockArgs a) {
+__global__ void __launch_bounds__(512) k_node_pre(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int NCH = (a.N + NODE_RC - 1) / NODE_RC;
   if ((int)blockIdx.x == a.B * NCH) { prep_device(a, sm); return; }
   const int Dh = a.Dh, N = a.N, b = blockIdx.x / NCH, chunk = blockIdx.x % NCH, t = threadIdx.x, ld = Dh + LDP, D3 = 3 * Dh;
-  const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4;
+  const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4, NW = blockDim.x >> 6;
   float* xs = sm;                 // [NODE_RC][ld]
   float* ws = xs + NODE_RC * ld;  // Wqkv [Dh][ldw]
   const int ldw = D3 + LDP;
@@ -133,7 +136,7 @@ __global__ void __launch_bounds__(256) k_node_pre(BlockArgs a) {
     __syncthreads();
     stage_rows(xs, ld, a.h + row0 * Dh, Dh, nr, nrp);
     __syncthreads();
-    for (int rb = wave * 4; rb < nrp; rb += 16) {  // LayerNorm: 16 lanes per row
+    for (int rb = wave * 4; rb < nrp; rb += 4 * NW) {  // LayerNorm: 16 lanes per row
       float* x = xs + (rb + q) * ld;
       float v[4], s = 0.f;
 #pragma unroll
@@ -148,7 +151,7 @@ __global__ void __launch_bounds__(256) k_node_pre(BlockArgs a) {
     }
     __syncthreads();
     const int ntr = nrp / 16;
-    for (int tile = wave; tile < ntr * nct; tile += 4) {
+    for (int tile = wave; tile < ntr * nct; tile += NW) {
       const int rt = tile / nct, ct = tile % nct, c = ct * 16 + p;
       const bool colok = c < D3;
       const float bias = colok ? a.bqkv[c] : 0.f;
@@ -165,7 +168,7 @@ __global__ void __launch_bounds__(256) k_node_pre(BlockArgs a) {
       }
     }
     if (a.DK < 8) {
-      for (int i = t; i < nr * QKVP; i += 256) {
+      for (int i = t; i < nr * QKVP; i += blockDim.x) {
         const int pos = i % QKVP;
         if (((pos >> 1) & 7) >= a.DK) a.qkvp[row0 * QKVP + i] = 0.f;
       }
@@ -174,11 +177,11 @@ __global__ void __launch_bounds__(256) k_node_pre(BlockArgs a) {
 }
 
 // -------------------------------------------------------------- node: post -----
-__global__ void __launch_bounds__(256) k_node_post(BlockArgs a) {
+__global__ void __launch_bounds__(512) k_node_post(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int NCH = (a.N + NODE_RC - 1) / NODE_RC;
   const int Dh = a.Dh, N = a.N, b = blockIdx.x / NCH, chunk = blockIdx.x % NCH, t = threadIdx.x, ld = Dh + LDP;
-  const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4;
+  const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4, NW = blockDim.x >> 6;
   float* xs = sm;
   float* ws = xs + NODE_RC * ld;  // Wo [Dh][ld]
   stage_weight(ws, ld, a.Wo, Dh, Dh);
@@ -190,7 +193,7 @@ __global__ void __launch_bounds__(256) k_node_post(BlockArgs a) {
     stage_rows(xs, ld, a.v_att + row0 * Dh, Dh, nr, nrp);
     __syncthreads();
     const int ntr = nrp / 16;
-    for (int tile = wave; tile < ntr * nct; tile += 4) {
+    for (int tile = wave; tile < ntr * nct; tile += NW) {
       const int rt = tile / nct, ct = tile % nct, c = ct * 16 + p;
       const bool colok = c < Dh;
       const float bias = colok ? a.bo[c] : 0.f;
@@ -212,15 +215,16 @@ __global__ void __launch_bounds__(256) k_node_post(BlockArgs a) {
 
 // ------------------------------------------------------ node: post backward -----
 // node partial layout per graph: [dWqkv Dh*3Dh | dbqkv 3Dh | dgamma Dh | dbeta Dh | dWo Dh*Dh | dbo Dh]
-__global__ void __launch_bounds__(256) k_node_post_bwd(BlockArgs a) {
+__global__ void __launch_bounds__(512) k_node_post_bwd(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int NCH = (a.N + NODE_RC - 1) / NODE_RC;
   if ((int)blockIdx.x == a.B * NCH) { prep_device(a, sm); return; }
   const int Dh = a.Dh, N = a.N, b = blockIdx.x / NCH, chunk = blockIdx.x % NCH, t = threadIdx.x, ld = Dh + LDP;
-  const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4;
+  const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4, NW = blockDim.x >> 6;
   float* ds = sm;                    // dh'   [NODE_RC][ld]
   float* vs = ds + NODE_RC * ld;     // v_att [NODE_RC][ld]
   float* ws = vs + NODE_RC * ld;     // Wo    [Dh][ld]
+  float* dlp = ws + Dh * ld;         // delta partials [nit][NODE_RC][8]
   stage_weight(ws, ld, a.Wo, Dh, Dh);
   const int nit = (Dh + 15) / 16;    // <= 4
   v4f accW[4];
@@ -234,43 +238,42 @@ __global__ void __launch_bounds__(256) k_node_post_bwd(BlockArgs a) {
     stage_rows(ds, ld, a.dh_out + row0 * Dh, Dh, nr, nrp);
     stage_rows(vs, ld, a.v_att + row0 * Dh, Dh, nr, nrp);
     __syncthreads();
-    // (1) dV_att = dh'.Wo^T per 16-row tile (a wave owns a row tile: delta stays in registers)
-    for (int rt = wave; rt < nrp / 16; rt += 4) {
-      float dl[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int it = 0; it < nit; ++it) {
-        const int i = it * 16 + p;
-        const bool colok = i < Dh;
-        v4f acc = {0.f, 0.f, 0.f, 0.f};
-        acc = mm_xwt(ds + rt * 16 * ld, ld, ws + it * 16 * ld, ld, Dh, p, q, colok, acc);
-        const int k = i >> 3, hh = i & 7;
-        const int pos = (hh >> 1) * 16 + k * 2 + (hh & 1);
+    // (1) dV_att = dh'.Wo^T: (row tile, i tile) pairs spread over the waves; the per-head
+    //     delta contributions of each i tile go through LDS and are summed in fixed order
+    for (int tile = wave; tile < (nrp / 16) * nit; tile += NW) {
+      const int rt = tile / nit, it = tile % nit;
+      const int i = it * 16 + p;
+      const bool colok = i < Dh;
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
+      acc = mm_xwt(ds + rt * 16 * ld, ld, ws + it * 16 * ld, ld, Dh, p, q, colok, acc);
+      const int k = i >> 3, hh = i & 7;
+      const int pos = (hh >> 1) * 16 + k * 2 + (hh & 1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rt * 16 + 4 * q + r;
-          if (colok && row < nr) a.dvp[(row0 + row) * 64 + pos] = acc[r];
-          float pr = colok ? acc[r] * vs[row * ld + i] : 0.f;
-          pr += lane_xor<8>(pr);   // the tile's two k values of head p&7
-          dl[r] += pr;
-        }
-      }
-      if (p < 8) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rt * 16 + 4 * q + r;
-          if (row < nr) a.stats[((row0 + row) * BH + p) * 4 + 2] = dl[r];
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 16 + 4 * q + r;
+        if (colok && row < nr) a.dvp[(row0 + row) * 64 + pos] = acc[r];
+        float pr = colok ? acc[r] * vs[row * ld + i] : 0.f;
+        pr += lane_xor<8>(pr);   // the tile's two k values of head p&7
+        if (p < 8) dlp[(it * NODE_RC + row) * 8 + p] = pr;
       }
     }
+    __syncthreads();
+    for (int i = t; i < nr * 8; i += blockDim.x) {
+      float dl = 0.f;
+      for (int it = 0; it < nit; ++it) dl += dlp[it * NODE_RC * 8 + i];
+      a.stats[(row0 * BH + i) * 4 + 2] = dl;
+    }
     if (a.DK < 8) {
-      for (int i = t; i < nr * 64; i += 256)
+      for (int i = t; i < nr * 64; i += blockDim.x)
         if ((((i & 63) >> 1) & 7) >= a.DK) a.dvp[row0 * 64 + i] = 0.f;
     }
     // (2) dWo[i][c] += sum_rows v_att[row][i] * dh'[row][c]
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int idx = wave + 4 * j;
+      const int idx = wave + NW * j;
       if (idx < nit * nit) {
         const int it = idx / nit, ct = idx % nit;
+#pragma unroll 4
         for (int rr = 0; rr < nrp; rr += 4)
           accW[j] = MFMA(vs[(rr + q) * ld + it * 16 + p], ds[(rr + q) * ld + ct * 16 + p], accW[j]);
       }
@@ -281,7 +284,7 @@ __global__ void __launch_bounds__(256) k_node_post_bwd(BlockArgs a) {
   float* part = a.npart + (size_t)blockIdx.x * (Dh * 3 * Dh + 3 * Dh + 2 * Dh + Dh * Dh + Dh) + Dh * 3 * Dh + 3 * Dh + 2 * Dh;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int idx = wave + 4 * j;
+    const int idx = wave + NW * j;
     if (idx < nit * nit) {
       const int it = idx / nit, ct = idx % nit, c = ct * 16 + p;
 #pragma unroll
@@ -295,12 +298,12 @@ __global__ void __launch_bounds__(256) k_node_post_bwd(BlockArgs a) {
 }
 
 // ------------------------------------------------------- node: pre backward -----
-__global__ void __launch_bounds__(256) k_node_pre_bwd(BlockArgs a) {
+__global__ void __launch_bounds__(512) k_node_pre_bwd(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int NCH = (a.N + NODE_RC - 1) / NODE_RC;
   const int Dh = a.Dh, N = a.N, b = blockIdx.x / NCH, chunk = blockIdx.x % NCH, t = threadIdx.x, D3 = 3 * Dh;
   const int ld = Dh + LDP, ld3 = D3 + LDP;
-  const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4;
+  const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4, NW = blockDim.x >> 6;
   float* xs = sm;                        // xhat  [NODE_RC][ld]
   float* dqs = xs + NODE_RC * ld;        // dQKV  [NODE_RC][ld3]
   float* dls = dqs + NODE_RC * ld3;      // d h_ln [NODE_RC][ld]
@@ -320,11 +323,11 @@ __global__ void __launch_bounds__(256) k_node_pre_bwd(BlockArgs a) {
     // dQKV rows: packed dq + dK/dV partials summed over the row-ranges (16-byte units)
     {
       const int U = nrp * 48;
-      for (int i0 = t; i0 < U; i0 += 512) {
+      for (int i0 = t; i0 < U; i0 += 2 * (int)blockDim.x) {
         float4 v[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int i = i0 + u * 256, r = i / 48, pos4 = (i % 48) * 4, s = pos4 >> 6;
+          const int i = i0 + u * (int)blockDim.x, r = i / 48, pos4 = (i % 48) * 4, s = pos4 >> 6;
           float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
           if (i < U && r < nr) {
             if (s == 0) {
@@ -348,7 +351,7 @@ __global__ void __launch_bounds__(256) k_node_pre_bwd(BlockArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int i = i0 + u * 256, r = i / 48, pos4 = (i % 48) * 4, s = pos4 >> 6;
+          const int i = i0 + u * (int)blockDim.x, r = i / 48, pos4 = (i % 48) * 4, s = pos4 >> 6;
           if (i < U) {
             const int qq = (pos4 >> 4) & 3, k0 = (pos4 >> 1) & 7;
             float* d = dqs + r * ld3 + s * Dh + k0 * 8 + 2 * qq;
@@ -359,7 +362,7 @@ __global__ void __launch_bounds__(256) k_node_pre_bwd(BlockArgs a) {
       }
     }
     __syncthreads();
-    for (int rb = wave * 4; rb < nrp; rb += 16) {  // LN forward statistics -> xhat in place
+    for (int rb = wave * 4; rb < nrp; rb += 4 * NW) {  // LN forward statistics -> xhat in place
       float* x = xs + (rb + q) * ld;
       float v[4], s = 0.f;
 #pragma unroll
@@ -375,7 +378,7 @@ __global__ void __launch_bounds__(256) k_node_pre_bwd(BlockArgs a) {
     }
     // d(h_ln)[row][kk] = sum_c dQKV[row][c] * Wqkv[kk][c]
     const int ntr = nrp / 16;
-    for (int tile = wave; tile < ntr * nkt; tile += 4) {
+    for (int tile = wave; tile < ntr * nkt; tile += NW) {
       const int rt = tile / nkt, kt = tile % nkt, kk = kt * 16 + p;
       const bool colok = kk < Dh;
       v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -386,7 +389,7 @@ __global__ void __launch_bounds__(256) k_node_pre_bwd(BlockArgs a) {
       }
     }
     __syncthreads();
-    for (int rb = wave * 4; rb < nrp; rb += 16) {  // LayerNorm backward + residual
+    for (int rb = wave * 4; rb < nrp; rb += 4 * NW) {  // LayerNorm backward + residual
       const int row = rb + q;
       const float* x = xs + row * ld;
       const float* dl = dls + row * ld;
@@ -415,10 +418,11 @@ __global__ void __launch_bounds__(256) k_node_pre_bwd(BlockArgs a) {
     // dWqkv[kk][c] += sum_rows h_ln[row][kk] * dQKV[row][c]
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
-      const int idx = wave + 4 * j;
+      const int idx = wave + NW * j;
       if (idx < ntl) {
         const int kt = idx / nct, ct = idx % nct, kk = kt * 16 + p;
         const float g = kk < Dh ? a.nm_g[kk] : 0.f, bt = kk < Dh ? a.nm_b[kk] : 0.f;
+#pragma unroll 4
         for (int rr = 0; rr < nrp; rr += 4)
           accW[j] = MFMA(fmaf(xs[(rr + q) * ld + kk], g, bt), dqs[(rr + q) * ld3 + ct * 16 + p], accW[j]);
       }
@@ -435,7 +439,7 @@ __global__ void __launch_bounds__(256) k_node_pre_bwd(BlockArgs a) {
   float* part = a.npart + (size_t)blockIdx.x * (Dh * D3 + D3 + 2 * Dh + Dh * Dh + Dh);
 #pragma unroll
   for (int j = 0; j < 12; ++j) {
-    const int idx = wave + 4 * j;
+    const int idx = wave + NW * j;
     if (idx < ntl) {
       const int kt = idx / nct, ct = idx % nct, c = ct * 16 + p;
 #pragma unroll
@@ -525,24 +529,24 @@ void egt_node_launch_pre(BlockArgs& a, hipStream_t st) {
   size_t lds = lds_rows(a.Dh, 1) + (size_t)a.Dh * (3 * a.Dh + LDP) * 4;
   if (lds < 1024) lds = 1024;  // prep workgroup scratch
   (void)hipFuncSetAttribute((const void*)k_node_pre, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  EGT_LAUNCH("k_node_pre", k_node_pre, dim3(a.B * node_chunks(a) + 1), dim3(256), lds, st, a);
+  EGT_LAUNCH("k_node_pre", k_node_pre, dim3(a.B * node_chunks(a) + 1), dim3(512), lds, st, a);
 }
 
 void egt_node_launch_post(BlockArgs& a, hipStream_t st) {
   const size_t lds = lds_rows(a.Dh, 1) + (size_t)a.Dh * (a.Dh + LDP) * 4;
-  EGT_LAUNCH("k_node_post", k_node_post, dim3(a.B * node_chunks(a)), dim3(256), lds, st, a);
+  EGT_LAUNCH("k_node_post", k_node_post, dim3(a.B * node_chunks(a)), dim3(512), lds, st, a);
 }
 
 void egt_node_launch_post_bwd(BlockArgs& a, hipStream_t st) {
-  const size_t lds = lds_rows(a.Dh, 2) + (size_t)a.Dh * (a.Dh + LDP) * 4;
-  EGT_LAUNCH("k_node_post_bwd", k_node_post_bwd, dim3(a.B * node_chunks(a) + 1), dim3(256), lds, st, a);
+  const size_t lds = lds_rows(a.Dh, 2) + (size_t)a.Dh * (a.Dh + LDP) * 4 + (size_t)4 * NODE_RC * 8 * 4;
+  EGT_LAUNCH("k_node_post_bwd", k_node_post_bwd, dim3(a.B * node_chunks(a) + 1), dim3(512), lds, st, a);
 }
 
 void egt_node_launch_pre_bwd(BlockArgs& a, hipStream_t st) {
   const size_t lds = lds_rows(a.Dh, 2) + ((size_t)NODE_RC * (3 * a.Dh + LDP) + NODE_RC +
                                            (size_t)a.Dh * (3 * a.Dh + LDP)) * 4;
   (void)hipFuncSetAttribute((const void*)k_node_pre_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  EGT_LAUNCH("k_node_pre_bwd", k_node_pre_bwd, dim3(a.B * node_chunks(a)), dim3(256), lds, st, a);
+  EGT_LAUNCH("k_node_pre_bwd", k_node_pre_bwd, dim3(a.B * node_chunks(a)), dim3(512), lds, st, a);
 }
 
 // Reduce the per-workgroup partials of `n` layers (one BlockArgs each, with their own
