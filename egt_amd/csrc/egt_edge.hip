@@ -372,6 +372,18 @@ __global__ void __launch_bounds__(256) k_edge_update_bwd_final(EdgeArgs a) {
   }
 }
 
+// out[i] = sum_p part[p][i]: 64 outputs per workgroup, the partial axis split over 4 wavefronts
+__global__ void __launch_bounds__(256) k_edge_reduce_partials(const float* part, int n, int np, float* out) {
+  __shared__ float red[4][64];
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
+  float v = 0.f;
+  if (o < n)
+    for (int pi = pg; pi < np; pi += 4) v += part[(size_t)pi * n + o];
+  red[pg][threadIdx.x & 63] = v;
+  __syncthreads();
+  if (pg == 0 && o < n) out[o] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // ------------------------------------------------------------------ host glue --
 #define EDGE_MAX_PARTIALS 512
 
@@ -432,7 +444,7 @@ extern "C" int egt_edge_proj_fwd(const egt_edge_desc* desc, const void* e, const
 
 extern "C" size_t egt_edge_proj_bwd_workspace_bytes(const egt_edge_desc* d) {
   if (!d) return 0;
-  return (size_t)EDGE_MAX_PARTIALS * (d->De * 16 + 16) * sizeof(float);
+  return (size_t)(EDGE_MAX_PARTIALS + 1) * (d->De * 16 + 16) * sizeof(float);
 }
 
 extern "C" int egt_edge_proj_bwd(const egt_edge_desc* desc, const void* e, const void* ln_gamma,
@@ -460,6 +472,11 @@ extern "C" int egt_edge_proj_bwd(const egt_edge_desc* desc, const void* e, const
     const size_t lds = (size_t)TILE_ROWS * (DE + 1 + 17) * 4;
     (void)hipFuncSetAttribute((const void*)k_edge_proj_bwd<DE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     EGT_LAUNCH("k_edge_proj_bwd", k_edge_proj_bwd<DE>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    constexpr int PSZ = DE * 16 + 16;
+    float* red = a.ws + (size_t)EDGE_MAX_PARTIALS * PSZ;
+    EGT_LAUNCH("k_edge_reduce_partials", k_edge_reduce_partials, dim3((PSZ + 63) / 64), dim3(256), 0,
+               (hipStream_t)stream, (const float*)a.ws, PSZ, grid, red);
+    a.ws = red; a.n_partials = 1;
     EGT_LAUNCH("k_edge_proj_bwd_final", k_edge_proj_bwd_final<DE>, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   });
   EGT_HIP_LAUNCH_CHECK("egt_edge_proj_bwd");
@@ -486,7 +503,7 @@ extern "C" int egt_edge_update_fwd(const egt_edge_desc* desc, const void* e, con
 
 extern "C" size_t egt_edge_update_bwd_workspace_bytes(const egt_edge_desc* d) {
   if (!d) return 0;
-  return (size_t)EDGE_MAX_PARTIALS * (EDGE_H * d->De + d->De) * sizeof(float);
+  return (size_t)(EDGE_MAX_PARTIALS + 1) * (EDGE_H * d->De + d->De) * sizeof(float);
 }
 
 extern "C" int egt_edge_update_bwd(const egt_edge_desc* desc, const void* d_e_out,
@@ -505,6 +522,11 @@ extern "C" int egt_edge_update_bwd(const egt_edge_desc* desc, const void* d_e_ou
     const size_t lds = (size_t)TILE_ROWS * (DE + 1 + 9) * 4;
     (void)hipFuncSetAttribute((const void*)k_edge_update_bwd<DE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     EGT_LAUNCH("k_edge_update_bwd", k_edge_update_bwd<DE>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    constexpr int PSZ = EDGE_H * DE + DE;
+    float* red = a.ws + (size_t)EDGE_MAX_PARTIALS * PSZ;
+    EGT_LAUNCH("k_edge_reduce_partials", k_edge_reduce_partials, dim3((PSZ + 63) / 64), dim3(256), 0,
+               (hipStream_t)stream, (const float*)a.ws, PSZ, grid, red);
+    a.ws = red; a.n_partials = 1;
     EGT_LAUNCH("k_edge_update_bwd_final", k_edge_update_bwd_final<DE>, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   });
   EGT_HIP_LAUNCH_CHECK("egt_edge_update_bwd");

@@ -483,10 +483,19 @@ __global__ void __launch_bounds__(256) k_sum_segments(SumArgs s) {
   if (pg == 0 && o < sg.n) sg.dst[o] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// T[c][i], s[i], R[c][h|8] -> grads of norm_edge, attention_gates, dense_edge_b, dense_edge_r
-__global__ void __launch_bounds__(256) k_edge_param_grads(BlockArgs a) {
-  const int DE = a.De, DEP = ((DE + 15) / 16) * 16;
-  const bool gated = (a.flags & EGT_BF_GATE) != 0;
+// T[c][i], s[i], R[c][h|8] -> grads of norm_edge, attention_gates, dense_edge_b, dense_edge_r.
+// One workgroup per layer (blockIdx.x), so a whole stack finishes in one launch.
+struct EdgeGradLayer {
+  const float *ne_g, *ne_b, *Wg, *We, *ered;
+  float *g_ne_g, *g_ne_b, *g_Wg, *g_bg, *g_We, *g_be, *g_Wr, *g_br;
+};
+#define EPG_MAX_LAYERS 16
+struct EdgeGradArgs { EdgeGradLayer L[EPG_MAX_LAYERS]; int De; uint32_t flags; };
+
+__global__ void __launch_bounds__(256) k_edge_param_grads(EdgeGradArgs ga) {
+  const EdgeGradLayer a = ga.L[blockIdx.x];
+  const int DE = ga.De, DEP = ((DE + 15) / 16) * 16;
+  const bool gated = (ga.flags & EGT_BF_GATE) != 0;
   const float* T = a.ered;
   const float* s = a.ered + DEP * 16;
   const float* R = s + 16;
@@ -576,6 +585,15 @@ void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, int npart
     }
     EGT_LAUNCH("k_sum_segments", k_sum_segments, dim3(maxblk, k), dim3(256), 0, st, s);
   }
-  for (int l = 0; l < n; ++l)
-    EGT_LAUNCH("k_edge_param_grads", k_edge_param_grads, dim3(1), dim3(256), 0, st, as[l]);
+  for (int l0 = 0; l0 < n; l0 += EPG_MAX_LAYERS) {
+    const int nl = (n - l0 < EPG_MAX_LAYERS) ? (n - l0) : EPG_MAX_LAYERS;
+    EdgeGradArgs ga{};
+    ga.De = as[0].De; ga.flags = as[0].flags;
+    for (int l = 0; l < nl; ++l) {
+      const BlockArgs& a = as[l0 + l];
+      ga.L[l] = EdgeGradLayer{a.ne_g, a.ne_b, a.Wg, a.We, a.ered, a.g_ne_g, a.g_ne_b, a.g_Wg, a.g_bg,
+                              a.g_We, a.g_be, a.g_Wr, a.g_br};
+    }
+    EGT_LAUNCH("k_edge_param_grads", k_edge_param_grads, dim3(nl), dim3(256), 0, st, ga);
+  }
 }
