@@ -234,8 +234,14 @@ def main():
             avg_s = ms / cnt / 1e3
             ab = algorithmic_bytes(dom, w)
             ach = ab / avg_s / 1e9 if avg_s > 0 and ab > 0 else None
+            traffic = None   # PMC HBM bytes per launch of this kernel, from the committed rocprofv3 passes
+            try:
+                if args.workload == "zinc500k_n64":
+                    traffic = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json"))).get(dom)
+            except Exception:
+                traffic = None
             roof = dict(bound="hbm", kernel=dom, timed_in_region=dom in dom_prof, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=(ach / HBM_PEAK_GBS) if ach else None, traffic=None,
+                        frac=(ach / HBM_PEAK_GBS) if ach else None, traffic=traffic,
                         avg_launch_us=avg_s * 1e6, launches=cnt, algorithmic_bytes_per_launch=ab,
                         kernels={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3,
                                          share=v[1] / sum(x[1] for x in prof.values()))
