@@ -100,3 +100,38 @@ def test_flat_buffer_aliases_grads():
     assert fa.nbytes == 17 * 4
     fa.zero()
     assert float(ps[0].grad.abs().sum()) == 0.0
+
+
+def _worker_flat(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from egt_amd.dp import all_reduce_flat, flat_grad_view
+        ps = [torch.nn.Parameter(torch.zeros(2, 3)), torch.nn.Parameter(torch.zeros(4))]
+        flat = torch.arange(10, dtype=torch.float32) * (rank + 1)      # what the fused stack backward hands over
+        ps[0].grad = flat[:6].view(2, 3); ps[1].grad = flat[6:]
+        ok = flat_grad_view(ps, flat)
+        other = torch.zeros(10)
+        not_ok = flat_grad_view(ps, other)
+        all_reduce_flat(flat, average=True)
+        q.put((rank, ok, not_ok, flat.tolist(), ps[1].grad.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_reduce_flat_adopted_views_gloo_ws2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_flat, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = [i * 1.5 for i in range(10)]            # mean of 1x and 2x
+    for r in res:
+        assert r[1] is True and r[2] is False
+        assert r[3] == want and r[4] == want[6:]   # the .grad views see the reduced values
