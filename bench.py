@@ -150,6 +150,11 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
+    from egt_amd import build as _build
+    if local_rank == 0:
+        _build.build()           # no-op when egt_amd/lib/libegt_amd.so is current (hipcc otherwise)
+    if use_dist:
+        dist.barrier()
     from egt_amd import EGTStack, _lib
     from egt_amd.dp import FlatGradAllReduce, flat_grad_view, all_reduce_flat
     lib = _lib.load()

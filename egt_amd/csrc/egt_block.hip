@@ -285,8 +285,9 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
     const int c = 16 * t + p;
     wrA[t][0] = c < DE ? a.Wr[(2 * q + 0) * DE + c] : 0.f;
     wrA[t][1] = c < DE ? a.Wr[(2 * q + 1) * DE + c] : 0.f;
-    brv[t] = (16 * t + 4 * q < DE) ? *reinterpret_cast<const float4*>(a.br + 16 * t + 4 * q)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int cb = 16 * t + 4 * q;   // scalar loads: parameter tensors need not be 16-byte aligned
+    brv[t] = (cb < DE) ? make_float4(a.br[cb], a.br[cb + 1], a.br[cb + 2], a.br[cb + 3])
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (KVL) __syncthreads();
 

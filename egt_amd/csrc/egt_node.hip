@@ -80,6 +80,10 @@ __device__ void prep_device(const BlockArgs& a, float* red) {
 __device__ __forceinline__ void stage_weight(float* ws, int ldw, const float* W, int rows, int width) {
   const int n4 = rows * width / 4;
   const int NT = blockDim.x;
+  if ((reinterpret_cast<uintptr_t>(W) & 15) != 0) {   // parameter views need not be 16-byte aligned
+    for (int i = threadIdx.x; i < rows * width; i += NT) ws[(i / width) * ldw + (i % width)] = W[i];
+    return;
+  }
   for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * NT) {
     float4 v[4];
 #pragma unroll

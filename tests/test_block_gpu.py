@@ -195,3 +195,33 @@ def test_stack_call_vs_oracle(N, De, Dh, train, gpu, egt_lib):
     for li, blk in enumerate(st.blocks):
         for k, (m, a_) in names.items():
             assert_close(getattr(getattr(blk, m), a_).grad, next(gi), name=f"L{li}.{k}", **BWD)
+
+
+def test_fused_accepts_unaligned_parameter_views(gpu, egt_lib):
+    """Parameters living at odd float offsets of one flat buffer (a common optimizer layout)
+    must work: no 16-byte alignment is assumed for parameter tensors."""
+    from egt_amd import EGTBlock
+    torch.manual_seed(4)
+    a = EGTBlock(model_width=64, edge_width=64, fused=True).to(gpu).eval()
+    b = EGTBlock(model_width=64, edge_width=64, fused=False).to(gpu).eval()
+    b.load_state_dict(a.state_dict())
+    total = sum(p.numel() + 3 for p in a.parameters()) + 1
+    flat = torch.zeros(total, device=gpu)
+    off = 1
+    for p in a.parameters():
+        v = flat[off:off + p.numel()].view_as(p)
+        v.copy_(p.data)
+        p.data = v
+        assert p.data_ptr() % 16 != 0 or True
+        off += p.numel() + 3
+    assert any(p.data_ptr() % 16 != 0 for p in a.parameters())
+    h = torch.randn(2, 32, 64, device=gpu); e = torch.randn(2, 32, 32, 64, device=gpu)
+    mask = torch.ones(2, 32, dtype=torch.bool, device=gpu); mask[0, 20:] = False
+    outs = []
+    for blk in (a, b):
+        hh = h.clone().requires_grad_(); ee = e.clone().requires_grad_()
+        h2, e2 = blk(hh, ee, mask)
+        (h2.sum() + (e2 * e2).sum()).backward()
+        outs.append((h2.detach(), e2.detach(), hh.grad, ee.grad, blk.dense_qkv.kernel.grad, blk.dense_edge_r.bias.grad))
+    for n, u, v in zip(("h", "e", "dh", "de", "dWqkv", "dbr"), *outs):
+        assert_close(u, v, name=n, rtol=1e-3, arel=2e-4, floor=0.1)
