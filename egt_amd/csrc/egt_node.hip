@@ -282,8 +282,13 @@ __global__ void __launch_bounds__(512) k_node_post_bwd(BlockArgs a) {
           accW[j] = MFMA(vs[(rr + q) * ld + it * 16 + p], ds[(rr + q) * ld + ct * 16 + p], accW[j]);
       }
     }
-    if (t < Dh)
-      for (int r = 0; r < nr; ++r) accB += ds[r * ld + t];
+    if (t < Dh) {
+      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;   // independent partial sums: the LDS reads pipeline
+      for (int r = 0; r < nrp; r += 4) {
+        b0 += ds[r * ld + t]; b1 += ds[(r + 1) * ld + t]; b2 += ds[(r + 2) * ld + t]; b3 += ds[(r + 3) * ld + t];
+      }
+      accB += (b0 + b1) + (b2 + b3);
+    }
   }
   float* part = a.npart + (size_t)blockIdx.x * (Dh * 3 * Dh + 3 * Dh + 2 * Dh + Dh * Dh + Dh) + Dh * 3 * Dh + 3 * Dh + 2 * Dh;
 #pragma unroll
@@ -431,14 +436,24 @@ __global__ void __launch_bounds__(512) k_node_pre_bwd(BlockArgs a) {
           accW[j] = MFMA(fmaf(xs[(rr + q) * ld + kk], g, bt), dqs[(rr + q) * ld3 + ct * 16 + p], accW[j]);
       }
     }
-    if (t < D3)
-      for (int r = 0; r < nr; ++r) accBq += dqs[r * ld3 + t];
-    if (t < Dh)
-      for (int r = 0; r < nr; ++r) {
-        const float dl = dls[r * ld + t];
-        accG = fmaf(dl, xs[r * ld + t], accG);
-        accBt += dl;
+    // column sums with independent partial accumulators (rows >= nr are zero-padded in LDS)
+    if (t < D3) {
+      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+      for (int r = 0; r < nrp; r += 4) {
+        b0 += dqs[r * ld3 + t]; b1 += dqs[(r + 1) * ld3 + t]; b2 += dqs[(r + 2) * ld3 + t]; b3 += dqs[(r + 3) * ld3 + t];
       }
+      accBq += (b0 + b1) + (b2 + b3);
+    } else if (t >= 256 && t < 256 + Dh) {   // a different wavefront takes the LayerNorm parameter sums
+      const int c = t - 256;
+      float g0 = 0.f, g1 = 0.f, s0 = 0.f, s1 = 0.f;
+      for (int r = 0; r < nrp; r += 2) {
+        const float d0 = dls[r * ld + c], d1 = dls[(r + 1) * ld + c];
+        g0 = fmaf(d0, xs[r * ld + c], g0); g1 = fmaf(d1, xs[(r + 1) * ld + c], g1);
+        s0 += d0; s1 += d1;
+      }
+      accG += g0 + g1;
+      accBt += s0 + s1;
+    }
   }
   float* part = a.npart + (size_t)blockIdx.x * (Dh * D3 + D3 + 2 * Dh + Dh * Dh + Dh);
 #pragma unroll
@@ -454,9 +469,9 @@ __global__ void __launch_bounds__(512) k_node_pre_bwd(BlockArgs a) {
     }
   }
   if (t < D3) part[Dh * D3 + t] = accBq;
-  if (t < Dh) {
-    part[Dh * D3 + D3 + t] = accG;
-    part[Dh * D3 + D3 + Dh + t] = accBt;
+  else if (t >= 256 && t < 256 + Dh) {
+    part[Dh * D3 + D3 + (t - 256)] = accG;
+    part[Dh * D3 + D3 + Dh + (t - 256)] = accBt;
   }
 }
 
