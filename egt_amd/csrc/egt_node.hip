@@ -331,12 +331,12 @@ __global__ void __launch_bounds__(512) k_node_pre_bwd(BlockArgs a) {
     stage_rows(xs, ld, a.h + row0 * Dh, Dh, nr, nrp);
     // dQKV rows: packed dq + dK/dV partials summed over the row-ranges (16-byte units)
     {
-      const int U = nrp * 48;
-      for (int i0 = t; i0 < U; i0 += 2 * (int)blockDim.x) {
-        float4 v[2];
+      const int U = nrp * 48, NT = (int)blockDim.x;
+      for (int i0 = t; i0 < U; i0 += 4 * NT) {   // up to 4 units x (NQP | NLR) 16-byte loads in flight
+        float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int i = i0 + u * (int)blockDim.x, r = i / 48, pos4 = (i % 48) * 4, s = pos4 >> 6;
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * NT, r = i / 48, pos4 = (i % 48) * 4, s = pos4 >> 6;
           float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
           if (i < U && r < nr) {
             if (s == 0) {
@@ -346,8 +346,7 @@ __global__ void __launch_bounds__(512) k_node_pre_bwd(BlockArgs a) {
                     a.dqp + (((size_t)b * a.NQP + qp) * N + r0 + r) * 64 + pos4);
                 acc4.x += w.x; acc4.y += w.y; acc4.z += w.z; acc4.w += w.w;
               }
-            }
-            else {
+            } else {
 #pragma unroll 4
               for (int lr = 0; lr < a.NLR; ++lr) {
                 const float4 w = *reinterpret_cast<const float4*>(
@@ -359,8 +358,8 @@ __global__ void __launch_bounds__(512) k_node_pre_bwd(BlockArgs a) {
           v[u] = acc4;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int i = i0 + u * (int)blockDim.x, r = i / 48, pos4 = (i % 48) * 4, s = pos4 >> 6;
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * NT, r = i / 48, pos4 = (i % 48) * 4, s = pos4 >> 6;
           if (i < U) {
             const int qq = (pos4 >> 4) & 3, k0 = (pos4 >> 1) & 7;
             float* d = dqs + r * ld3 + s * Dh + k0 * 8 + 2 * qq;
