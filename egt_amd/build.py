@@ -16,7 +16,7 @@ REPO = os.path.dirname(ROOT)
 CSRC = os.path.join(ROOT, "csrc")
 LIBDIR = os.path.join(ROOT, "lib")
 LIB = os.path.join(LIBDIR, "libegt_amd.so")
-SOURCES = ["egt_capi.hip", "egt_attn.hip", "egt_edge.hip", "egt_block.hip", "egt_node.hip"]
+SOURCES = ["egt_capi.hip", "egt_attn.hip", "egt_attn_mfma.hip", "egt_edge.hip", "egt_block.hip", "egt_node.hip"]
 ARCH = "gfx950"
 
 

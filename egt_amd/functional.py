@@ -53,6 +53,7 @@ class AttnConfig:
     training: bool = False
     seed: int = 0
     need_a_tild: bool = False
+    use_mfma: bool = True   # MFMA-tiled kernels where they cover the configuration
 
 
 def _attn_desc(cfg: AttnConfig, B, N, d, has_E, has_G, has_M) -> L.AttnDesc:
@@ -97,9 +98,16 @@ class _EGTAttention(torch.autograd.Function):
         h_hat = torch.empty(B, N, N, H, device=qkv.device, dtype=torch.float32)
         a_tild = torch.empty(B, N, N, H, device=qkv.device, dtype=torch.float32) if cfg.need_a_tild else None
         rowstats = torch.empty(B, N, H, 4, device=qkv.device, dtype=torch.float32)
-        L.check(lib.egt_attn_fwd(C.byref(desc), L.ptr(qkv), L.ptr(E), L.ptr(G), L.ptr(key_mask),
-                                 L.ptr(M), L.ptr(rand_mask), L.ptr(drop_keep), L.ptr(v_att),
-                                 L.ptr(h_hat), L.ptr(a_tild), L.ptr(rowstats), L.current_stream()))
+        if (cfg.use_mfma and drop_keep is None
+                and lib.egt_attn_mfma_supported(C.byref(desc), 1 if cfg.need_a_tild else 0)):
+            # large-head geometry: QK^T / A.V on MFMA tiles (egt_attn_mfma.hip)
+            L.check(lib.egt_attn_mfma_fwd(C.byref(desc), L.ptr(qkv), L.ptr(E), L.ptr(G), L.ptr(key_mask),
+                                          L.ptr(M), L.ptr(rand_mask), L.ptr(v_att), L.ptr(h_hat),
+                                          L.ptr(rowstats), L.current_stream()))
+        else:
+            L.check(lib.egt_attn_fwd(C.byref(desc), L.ptr(qkv), L.ptr(E), L.ptr(G), L.ptr(key_mask),
+                                     L.ptr(M), L.ptr(rand_mask), L.ptr(drop_keep), L.ptr(v_att),
+                                     L.ptr(h_hat), L.ptr(a_tild), L.ptr(rowstats), L.current_stream()))
         ctx.cfg = cfg
         ctx.desc = desc
         ctx.has = (E is not None, G is not None, M is not None)

@@ -103,6 +103,18 @@ int egt_attn_bwd(const egt_attn_desc* desc, const void* qkv, const void* E,
                  const void* d_h_ext, void* d_qkv, void* d_E, void* d_G,
                  void* workspace, void* stream);
 
+/* MFMA-tiled (flash-style) variant of the inner op for the large-head geometry
+ * (H = 8, d in {16,32,64}; BASELINE config 5): QK^T and A.V on
+ * v_mfma_f32_16x16x4_f32, probabilities never leave registers.  Same outputs and the
+ * same rowstats as egt_attn_fwd (so egt_attn_bwd pairs with either); not covered:
+ * attention dropout, degree scalers, the A_tild output.  egt_attn_mfma_supported
+ * returns 1 when `desc` (and the A_tild request) is covered. */
+int egt_attn_mfma_supported(const egt_attn_desc* desc, int need_a_tild);
+int egt_attn_mfma_fwd(const egt_attn_desc* desc, const void* qkv, const void* E,
+                      const void* G, const uint8_t* key_mask, const void* attn_mask,
+                      const uint8_t* rand_mask, void* v_att, void* h_hat, void* rowstats,
+                      void* stream);
+
 /* The in-kernel sample streams, materialised ([B,N,N,H] uint8), for bit-exact
  * checks against oracle/rng_ref.py.  which: 0 = random mask (1 = masked),
  * 1 = dropout keep (1 = kept). */

@@ -133,3 +133,49 @@ def test_in_kernel_random_mask_matches_injected(gpu, egt_lib):
     cfg_eval = AttnConfig(random_mask_prob=p, training=False, need_a_tild=True)
     V2, _, _ = egt_attention(cu(inp["QKV"]), cu(inp["E"]), cu(inp["G"]), None, cu(inp["mask"]), cfg=cfg_eval)
     assert_close(V2, CS.attn_oracle(inp, attrs)["V_att"], name="V_eval", **FWD)
+
+
+@pytest.mark.parametrize("B,N,d,opts", [
+    (1, 24, 64, {}), (2, 37, 16, {}), (1, 64, 32, dict(attn_mask=True)), (1, 40, 64, dict(gate=False)),
+    (2, 16, 16, dict(rand_p=0.3)), (1, 33, 64, dict(clip=None, nomask=True)), (1, 128, 64, {}),
+])
+def test_attn_mfma_kernel_vs_oracle(B, N, d, opts, gpu, egt_lib):
+    """MFMA-tiled inner op (d in {16,32,64}) forward + general backward vs the fp64 oracle, and
+    bit-level agreement of its H_hat with the general kernel's."""
+    from egt_amd import egt_attention, AttnConfig
+    H = 8
+    g = torch.Generator().manual_seed(B * 100 + N + d)
+    QKV = torch.randn(B, N, 3 * d * H, generator=g) * 0.7
+    E = torch.randn(B, N, N, H, generator=g)
+    G = torch.randn(B, N, N, H, generator=g) if opts.get("gate", True) else None
+    mask = None
+    if not opts.get("nomask"):
+        mask = torch.ones(B, N, dtype=torch.bool); mask[0, N - 5:] = False
+    M = None
+    if opts.get("attn_mask"):
+        M = (torch.rand(B, N, N, generator=g) > 0.4).float()[..., None].repeat(1, 1, 1, H).contiguous()
+    rm = (torch.rand(B, N, N, H, generator=g) < opts["rand_p"]) if opts.get("rand_p") else None
+    dV = torch.randn(B, N, d * H, generator=g); dH = torch.randn(B, N, N, H, generator=g)
+    inp = dict(QKV=QKV, E=E, G=G, M=M, mask=mask, rand_mask=rm, drop_keep=None, dV=dV, dH=dH)
+    attrs = dict(num_heads=H, clip_logits_value=opts.get("clip", (-5.0, 5.0)), scale_degree=False,
+                 scaler_type="log", num_virtual_nodes=0, attn_dropout=0.0)
+    ref = CS.attn_oracle(inp, attrs)
+    cu = lambda t: None if t is None else t.to(gpu)
+    outs = {}
+    for use_mfma in (True, False):
+        q = cu(QKV).requires_grad_(); e_ = cu(E).requires_grad_()
+        g_ = cu(G).requires_grad_() if G is not None else None
+        cfg = AttnConfig(num_heads=H, clip_logits_value=attrs["clip_logits_value"],
+                         random_mask_prob=0.5 if rm is not None else 0.0, training=rm is not None,
+                         need_a_tild=False, use_mfma=use_mfma)
+        V, Hh, _ = egt_attention(q, e_, g_, cu(M), cu(mask), cfg=cfg, rand_mask=cu(rm))
+        torch.autograd.backward([V, Hh], [cu(dV), cu(dH)])
+        outs[use_mfma] = (V.detach(), Hh.detach(), q.grad, e_.grad, None if g_ is None else g_.grad)
+    V, Hh, dq, de_, dg = outs[True]
+    assert_close(V, ref["V_att"], name="V_att", **FWD)
+    assert_close(Hh, ref["H_hat"], name="H_hat", **FWD)
+    assert_close(dq, ref["dQKV"], name="dQKV", **BWD)
+    assert_close(de_, ref["dE"], name="dE", **BWD)
+    if dg is not None:
+        assert_close(dg, ref["dG"], name="dG", **BWD)
+    assert_close(outs[True][0], outs[False][0], name="V_att(mfma vs general)", rtol=1e-4, arel=2e-5)
