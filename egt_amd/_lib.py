@@ -77,6 +77,7 @@ _PROTOS = {
     "egt_attn_bwd": (C.c_int, [C.POINTER(AttnDesc)] + [_VP] * 16),
     "egt_attn_mfma_supported": (C.c_int, [C.POINTER(AttnDesc), C.c_int]),
     "egt_attn_mfma_fwd": (C.c_int, [C.POINTER(AttnDesc)] + [_VP] * 10),
+    "egt_attn_mfma_bwd": (C.c_int, [C.POINTER(AttnDesc)] + [_VP] * 15),
     "egt_mask_sample": (C.c_int, [C.c_int, C.c_uint64, C.c_float, C.c_int32, C.c_int32,
                                   C.c_int32, _VP, _VP]),
     "egt_edge_proj_fwd": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 10),

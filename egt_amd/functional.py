@@ -132,10 +132,16 @@ class _EGTAttention(torch.autograd.Function):
         d_G = torch.empty_like(G) if G is not None else None
         ws = torch.empty(lib.egt_attn_bwd_workspace_bytes(C.byref(desc)), device=qkv.device,
                          dtype=torch.uint8)
-        L.check(lib.egt_attn_bwd(C.byref(desc), L.ptr(qkv), L.ptr(E), L.ptr(G), L.ptr(key_mask),
-                                 L.ptr(M), L.ptr(rand_mask), L.ptr(drop_keep), L.ptr(v_att),
-                                 L.ptr(rowstats), L.ptr(d_v_att), L.ptr(d_h_hat), L.ptr(d_qkv),
-                                 L.ptr(d_E), L.ptr(d_G), L.ptr(ws), L.current_stream()))
+        if (ctx.cfg.use_mfma and drop_keep is None and lib.egt_attn_mfma_supported(C.byref(desc), 0)):
+            L.check(lib.egt_attn_mfma_bwd(C.byref(desc), L.ptr(qkv), L.ptr(E), L.ptr(G), L.ptr(key_mask),
+                                          L.ptr(M), L.ptr(rand_mask), L.ptr(v_att), L.ptr(rowstats),
+                                          L.ptr(d_v_att), L.ptr(d_h_hat), L.ptr(d_qkv), L.ptr(d_E),
+                                          L.ptr(d_G), L.ptr(ws), L.current_stream()))
+        else:
+            L.check(lib.egt_attn_bwd(C.byref(desc), L.ptr(qkv), L.ptr(E), L.ptr(G), L.ptr(key_mask),
+                                     L.ptr(M), L.ptr(rand_mask), L.ptr(drop_keep), L.ptr(v_att),
+                                     L.ptr(rowstats), L.ptr(d_v_att), L.ptr(d_h_hat), L.ptr(d_qkv),
+                                     L.ptr(d_E), L.ptr(d_G), L.ptr(ws), L.current_stream()))
         return d_qkv, d_E, d_G, None, None, None, None, None
 
 

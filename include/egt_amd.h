@@ -114,6 +114,13 @@ int egt_attn_mfma_fwd(const egt_attn_desc* desc, const void* qkv, const void* E,
                       const void* G, const uint8_t* key_mask, const void* attn_mask,
                       const uint8_t* rand_mask, void* v_att, void* h_hat, void* rowstats,
                       void* stream);
+/* Backward on MFMA tiles (three launches: delta, dK/dV/dE/dG per key tile, dQ per query
+ * tile).  rowstats is read and its 4th slot written; workspace as for egt_attn_bwd. */
+int egt_attn_mfma_bwd(const egt_attn_desc* desc, const void* qkv, const void* E,
+                      const void* G, const uint8_t* key_mask, const void* attn_mask,
+                      const uint8_t* rand_mask, const void* v_att, void* rowstats,
+                      const void* d_v_att, const void* d_h_ext, void* d_qkv, void* d_E,
+                      void* d_G, void* workspace, void* stream);
 
 /* The in-kernel sample streams, materialised ([B,N,N,H] uint8), for bit-exact
  * checks against oracle/rng_ref.py.  which: 0 = random mask (1 = masked),
