@@ -17,6 +17,10 @@ struct BlockArgs {
   int rng_rm;
   int TL, NLR;  // backward: query rows per workgroup, row-ranges per graph
   int NQP;      // backward: dQ partials per row (key tiles) in dqp [B][NQP][N][64]
+  int epi;      // forward epilogue in k_block_fwd: 0 none, 1 dense_mha+res, 2 + next block's norm_mha/dense_qkv
+  int prep;     // node kernels: add the edge-weight preparation workgroup
+  const float *nx_nm_g, *nx_nm_b, *nx_Wqkv, *nx_bqkv;   // next block (epi == 2)
+  float* nx_qkvp;
   // params
   const float *ne_g, *ne_b, *Wg, *bg, *We, *be, *nm_g, *nm_b, *Wqkv, *bqkv, *Wo, *bo, *Wr, *br;
   // tensors
@@ -59,4 +63,5 @@ void egt_node_launch_pre(BlockArgs& a, hipStream_t st);
 void egt_node_launch_post(BlockArgs& a, hipStream_t st);
 void egt_node_launch_post_bwd(BlockArgs& a, hipStream_t st);
 void egt_node_launch_pre_bwd(BlockArgs& a, hipStream_t st);
+void egt_node_launch_prep(BlockArgs* as, int n, hipStream_t st);   // n <= 64 layers
 void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, int npart_stride, hipStream_t st);

@@ -234,6 +234,7 @@ __device__ __forceinline__ float reduce16_keep_own(const float (&v)[16], int p) 
 }
 
 #define KV_LD 132  // LDS row stride (floats) of the staged [K|V] rows
+#define QS_LD 68   // LDS row stride of the staged Q rows (reused for the V_att rows of the epilogue)
 
 // ================================================================= forward =====
 // Workgroup = (graph b, 16 query rows); wave w owns rows l = 16*lg + w + 4*i.
@@ -252,8 +253,8 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
   const int b = blockIdx.x / lgroups, lg = blockIdx.x % lgroups;
   float* tl0 = sm + wave * 2 * G::TILE_FLOATS;  // two tiles per wave (ping-pong)
   float* kvs = sm + 8 * G::TILE_FLOATS;         // [N][KV_LD]   (KVL)
-  float* qs = kvs + (KVL ? N * KV_LD : 0);     // [16][64]     (KVL)
-  float* kms = qs + (KVL ? 16 * 64 : 0);       // [N]          (KVL)
+  float* qs = kvs + (KVL ? N * KV_LD : 0);     // [16][QS_LD]  (KVL)
+  float* kms = qs + (KVL ? 16 * QS_LD : 0);    // [N]          (KVL)
   const bool gated = (a.flags & EGT_BF_GATE) != 0;
   const bool clip = (a.flags & EGT_BF_CLIP) != 0;
 
@@ -266,7 +267,7 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
     }
     for (int i = threadIdx.x; i < 16 * 16; i += 256) {
       const int row = i >> 4, f = i & 15, l = min(lg * 16 + row, N - 1);
-      *reinterpret_cast<float4*>(qs + row * 64 + f * 4) =
+      *reinterpret_cast<float4*>(qs + row * QS_LD + f * 4) =
           *reinterpret_cast<const float4*>(src + (size_t)l * QKVP + f * 4);
     }
     for (int i = threadIdx.x; i < N; i += 256)
@@ -313,7 +314,7 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
     const size_t rowl = (size_t)b * N + l;
     const size_t pair0 = rowl * N + m0;
     if (mt == 0) {
-      const float4* qp = KVL ? reinterpret_cast<const float4*>(qs + (wave + 4 * li) * 64 + q * 16)
+      const float4* qp = KVL ? reinterpret_cast<const float4*>(qs + (wave + 4 * li) * QS_LD + q * 16)
                              : reinterpret_cast<const float4*>(a.qkvp + rowl * QKVP + q * 16);
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const float4 v = qp[i]; Qf[4*i] = v.x; Qf[4*i+1] = v.y; Qf[4*i+2] = v.z; Qf[4*i+3] = v.w; }
@@ -423,11 +424,79 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
       // element i = p: k = p>>1, j = p&1 -> head 2q + j
       const int k = p >> 1, j = p & 1;
       const float sj = j ? sum[1] : sum[0];
-      if (k < a.DK) a.v_att[rowl * a.Dh + k * BH + 2 * q + j] = o / sj;
+      const float vo = o / sj;
+      if (k < a.DK) a.v_att[rowl * a.Dh + k * BH + 2 * q + j] = vo;
+      // the row's Q is dead (read at mt == 0 by this wave only): its slot keeps V_att for the epilogue
+      if (KVL && a.epi) qs[(wave + 4 * li) * QS_LD + k * BH + 2 * q + j] = vo;
       if (p < 2) {
         float* st = a.stats + (rowl * BH + 2 * q + p) * 4;
         st[0] = p ? mx[1] : mx[0];
         st[1] = sj;
+      }
+    }
+  }
+
+  // ---- node-side epilogue (Dh = 64): the workgroup holds V_att of its 16 rows ----
+  //   epi >= 1: h' = V_att.Wo + bo + h                      (dense_mha + res_mha, :136,140)
+  //   epi == 2: qkv of the NEXT block = LN(h').Wqkv' + bqkv' (norm_mha + dense_qkv, :109,113), packed
+  // Contraction order k = 4s + q on both MFMA operands; weights come straight from L2.
+  if (KVL && a.epi) {
+    float wo[16], wq[3][16];
+    const int c = wave * 16 + p;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) wo[s] = a.Wo[(4 * s + q) * 64 + c];
+    if (a.epi == 2) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) wq[j][s] = a.nx_Wqkv[(4 * s + q) * 192 + (wave + 4 * j) * 16 + p];
+    }
+    const float bo = a.bo[c];
+    float hres[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hres[r] = a.h[((size_t)b * N + min(lg * 16 + 4 * q + r, N - 1)) * 64 + c];
+    __syncthreads();   // every row's V_att is in qs; the tile area is idle from here on
+    float* hs = sm;    // [16][QS_LD]
+    v4f acc = {bo, bo, bo, bo};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = MFMA(qs[p * QS_LD + 4 * s + q], wo[s], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * q + r, l = lg * 16 + row;
+      const float hv = acc[r] + hres[r];
+      if (l < N) a.h_out[((size_t)b * N + l) * 64 + c] = hv;
+      hs[row * QS_LD + c] = hv;
+    }
+    if (a.epi == 2) {
+      __syncthreads();
+      {   // LayerNorm of row 4*wave + q: 16 lanes x 4 columns
+        float* x = hs + (4 * wave + q) * QS_LD;
+        float v[4], sm1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = x[p + 16 * i]; sm1 += v[i]; }
+        const float mu = row_sum16(sm1) * (1.0f / 64);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] -= mu; ss = fmaf(v[i], v[i], ss); }
+        const float rstd = rsqrtf(row_sum16(ss) * (1.0f / 64) + a.ln_eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[p + 16 * i] = fmaf(v[i] * rstd, a.nx_nm_g[p + 16 * i], a.nx_nm_b[p + 16 * i]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int cq = (wave + 4 * j) * 16 + p;
+        const float bq = a.nx_bqkv[cq];
+        v4f aq = {bq, bq, bq, bq};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) aq = MFMA(hs[p * QS_LD + 4 * s + q], wq[j][s], aq);
+        const int sx = cq >> 6, cc = cq & 63, kk = cc >> 3, hh = cc & 7;
+        const int pos = sx * 64 + (hh >> 1) * 16 + kk * 2 + (hh & 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int l = lg * 16 + 4 * q + r;
+          if (l < N) a.nx_qkvp[((size_t)b * N + l) * QKVP + pos] = aq[r];
+        }
       }
     }
   }
@@ -1420,6 +1489,7 @@ static void bind_common(const egt_block_desc* d, BlockArgs& a, const void* h, co
   a.pw = ws + L.pw; a.dvp = ws + L.dvp; a.dqp = ws + L.dqp; a.dkvp = ws + L.dkvp;
   a.epart = ws + L.epart; a.npart = ws + L.npart; a.ered = ws + L.ered;
   a.TL = BWD_TL; a.NLR = L.NLR; a.NQP = 1;
+  a.prep = 1;
 }
 
 static bool egt_env_flag(const char* name) {
@@ -1436,13 +1506,18 @@ static bool egt_env_flag(const char* name) {
     default: { constexpr int DE = 64; CALL; } break;  \
   }
 
+// Forward of one block.  `skip_pre`: qkvp (and pw) of this block were already produced (by the
+// previous block's epilogue / k_edge_prep).  a.epi is the epilogue the caller would like; the
+// value actually used is returned (0 when the geometry is outside the epilogue's cover, in
+// which case k_node_post runs and the next block needs its own k_node_pre).
 template <int DE>
-static void launch_fwd(BlockArgs& a, hipStream_t st) {
+static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   const int lgroups = (a.N + 15) / 16;
-  egt_node_launch_pre(a, st);   // norm_mha + dense_qkv (packed) + edge-weight prep
+  if (!skip_pre) egt_node_launch_pre(a, st);   // norm_mha + dense_qkv (packed) [+ edge-weight prep]
   const size_t lds_tiles = (size_t)8 * Geo<DE>::TILE_FLOATS * 4;
-  const size_t lds_kv = ((size_t)a.N * KV_LD + 16 * 64 + a.N) * 4;
+  const size_t lds_kv = ((size_t)a.N * KV_LD + 16 * QS_LD + a.N) * 4;
   const bool kvl = lds_tiles + lds_kv <= 80 * 1024 - 512;   // two workgroups per CU keep their K/V in LDS
+  if (!(kvl && a.Dh == 64 && a.DK == 8) || egt_env_flag("EGT_NO_EPILOGUE")) a.epi = 0;
   const bool ml = a.M != nullptr || a.rm != nullptr;
   const dim3 grid(a.B * lgroups), block(256);
   const size_t lds = lds_tiles + (kvl ? lds_kv : 0);
@@ -1457,7 +1532,8 @@ static void launch_fwd(BlockArgs& a, hipStream_t st) {
   else if (kvl) { if (ml) FWD_VARIANT(true, true, false); else FWD_VARIANT(true, false, false); }
   else { if (ml) FWD_VARIANT(false, true, false); else FWD_VARIANT(false, false, false); }
 #undef FWD_VARIANT
-  egt_node_launch_post(a, st);  // dense_mha + res_mha
+  if (a.epi == 0) egt_node_launch_post(a, st);  // dense_mha + res_mha
+  return a.epi;
 }
 
 template <int DE>
@@ -1533,7 +1609,8 @@ extern "C" int egt_block_fwd(const egt_block_desc* desc, const egt_block_params*
   if ((desc->flags & EGT_BF_ATTN_MASK) && !attn_mask) EGT_FAIL(EGT_E_NULL, "ATTN_MASK set but attn_mask is NULL");
   bind_common(desc, a, h, e, key_mask, attn_mask, rand_mask, (float*)saved, (float*)workspace);
   a.h_out = (float*)h_out; a.e_out = (float*)e_out;
-  DISPATCH_BDE(desc->De, launch_fwd<DE>(a, (hipStream_t)stream));
+  a.epi = 1;
+  DISPATCH_BDE(desc->De, launch_fwd<DE>(a, (hipStream_t)stream, false));
   EGT_HIP_LAUNCH_CHECK("egt_block_fwd");
   return EGT_OK;
 }
@@ -1584,7 +1661,7 @@ static uint64_t layer_seed(uint64_t seed, int l) { return seed ^ (0x9E3779B97F4A
 
 struct StackLayout {
   size_t h_act, e_act, blk, saved_total;      // floats
-  size_t common, per_layer, per_layer_stride, ws_total;
+  size_t common, per_layer, per_layer_stride, pw_off, ws_total;
   size_t h_sz, e_sz;
 };
 
@@ -1598,9 +1675,10 @@ static StackLayout stack_layout(const egt_block_desc* d, int layers) {
   S.e_act = o; o += S.e_sz * (size_t)(layers > 1 ? layers - 1 : 0);
   S.blk = o; o += L.saved_total * (size_t)layers;
   S.saved_total = o;
-  // workspace: [pw dvp dqp dkvp] shared by all layers, then per layer [epart npart ered]
+  // workspace: [(pw) dvp dqp dkvp] shared by all layers, then per layer [epart npart ered pw]
   S.common = L.epart;                       // everything before epart in the block layout
-  S.per_layer_stride = L.ws_total - L.epart;
+  S.pw_off = L.ws_total - L.epart;
+  S.per_layer_stride = S.pw_off + (L.dvp - L.pw);
   S.ws_total = S.common + S.per_layer_stride * (size_t)layers;
   return S;
 }
@@ -1621,6 +1699,7 @@ static void bind_layer(const egt_block_desc* d, const StackLayout& S, const Bloc
   a.pw = ws + L.pw; a.dvp = ws + L.dvp; a.dqp = ws + L.dqp; a.dkvp = ws + L.dkvp;
   float* pl = ws + S.common + S.per_layer_stride * (size_t)l;
   a.epart = pl; a.npart = pl + (L.npart - L.epart); a.ered = pl + (L.ered - L.epart);
+  a.pw = pl + S.pw_off;   // per layer: block l's epilogue must not race block l+1's weights
   a.TL = BWD_TL; a.NLR = L.NLR; a.NQP = 1;
   (void)d;
 }
@@ -1634,13 +1713,15 @@ extern "C" int egt_stack_fwd(const egt_block_desc* desc, int32_t layers, const e
     EGT_FAIL(EGT_E_NULL, "params/h/e/h_out/e_out/saved/workspace is NULL");
   if (block_check(desc, true)) return block_check(desc, true);
   if ((desc->flags & EGT_BF_ATTN_MASK) && !attn_mask) EGT_FAIL(EGT_E_NULL, "ATTN_MASK set but attn_mask is NULL");
+  if (layers > 64) EGT_FAIL(EGT_E_SHAPE, "at most 64 layers per stack call");
   const StackLayout S = stack_layout(desc, layers);
   const BlockLayout L = layout(desc);
   float* sv = (float*)saved;
+  BlockArgs as[64];
   for (int l = 0; l < layers; ++l) {
     egt_block_desc dl = *desc;
     dl.seed = layer_seed(desc->seed, l);
-    BlockArgs a;
+    BlockArgs& a = as[l];
     int rc = fill_block(&dl, params + l, a);
     if (rc) return rc;
     const float* hin = l == 0 ? (const float*)h : sv + S.h_act + S.h_sz * (size_t)(l - 1);
@@ -1649,7 +1730,23 @@ extern "C" int egt_stack_fwd(const egt_block_desc* desc, int32_t layers, const e
     bind_layer(&dl, S, L, l, a, sv, (float*)workspace);
     a.h_out = l == layers - 1 ? (float*)h_out : sv + S.h_act + S.h_sz * (size_t)l;
     a.e_out = l == layers - 1 ? (float*)e_out : sv + S.e_act + S.e_sz * (size_t)l;
-    DISPATCH_BDE(desc->De, launch_fwd<DE>(a, (hipStream_t)stream));
+  }
+  // edge weights of every layer in one launch; each block's epilogue then finishes the node side
+  // (dense_mha + residual) and already produces the next block's packed QKV, so a layer is ONE
+  // launch wherever the epilogue covers the geometry
+  egt_node_launch_prep(as, layers, (hipStream_t)stream);
+  int prev_epi = 0;
+  for (int l = 0; l < layers; ++l) {
+    BlockArgs& a = as[l];
+    a.prep = 0;
+    a.epi = 1;
+    if (l + 1 < layers) {
+      const BlockArgs& nx = as[l + 1];
+      a.epi = 2;
+      a.nx_nm_g = nx.nm_g; a.nx_nm_b = nx.nm_b; a.nx_Wqkv = nx.Wqkv; a.nx_bqkv = nx.bqkv;
+      a.nx_qkvp = nx.qkvp;
+    }
+    DISPATCH_BDE(desc->De, prev_epi = launch_fwd<DE>(a, (hipStream_t)stream, prev_epi == 2));
   }
   EGT_HIP_LAUNCH_CHECK("egt_stack_fwd");
   return EGT_OK;

@@ -39,9 +39,10 @@ __device__ __forceinline__ v4f mm_xwt(const float* xs, int ld, const float* W, i
 
 // ---- edge-weight preparation (runs as one extra workgroup of the first node kernel) ----
 // Wp[c][i] = gamma_c * Wsel[c][head(i)], c2[i] = sum_c beta_c * Wsel[c][head(i)] + bias
-__device__ void prep_device(const BlockArgs& a, float* red) {
-  const int De = a.De, DEP = ((De + 15) / 16) * 16, t = threadIdx.x;
-  const bool gated = (a.flags & EGT_BF_GATE) != 0;
+struct PrepLayer { const float *ne_g, *ne_b, *Wg, *bg, *We, *be; float* pw; };
+
+__device__ void prep_layer(const PrepLayer& a, int De, bool gated, float* red) {
+  const int DEP = ((De + 15) / 16) * 16, t = threadIdx.x;
   for (int idx = t; idx < DEP * 16; idx += blockDim.x) {
     const int c = idx >> 4, i = idx & 15;
     float v = 0.f;
@@ -73,6 +74,18 @@ __device__ void prep_device(const BlockArgs& a, float* red) {
     }
     a.pw[DEP * 16 + t] = v;
   }
+}
+__device__ void prep_device(const BlockArgs& a, float* red) {
+  const PrepLayer L{a.ne_g, a.ne_b, a.Wg, a.bg, a.We, a.be, a.pw};
+  prep_layer(L, a.De, (a.flags & EGT_BF_GATE) != 0, red);
+}
+
+// the same preparation for every layer of a stack in one launch (one workgroup per layer)
+#define PREP_MAX_LAYERS 64
+struct PrepArgs { PrepLayer L[PREP_MAX_LAYERS]; int De; uint32_t flags; };
+__global__ void __launch_bounds__(256) k_edge_prep(PrepArgs pa) {
+  __shared__ float red[256];
+  prep_layer(pa.L[blockIdx.x], pa.De, (pa.flags & EGT_BF_GATE) != 0, red);
 }
 
 // stage a dense [rows][width] weight matrix into LDS (row stride ldw): 16-byte loads, four in
@@ -556,7 +569,7 @@ void egt_node_launch_pre(BlockArgs& a, hipStream_t st) {
   size_t lds = lds_rows(a.Dh, 1) + (size_t)a.Dh * (3 * a.Dh + LDP) * 4;
   if (lds < 1024) lds = 1024;  // prep workgroup scratch
   (void)hipFuncSetAttribute((const void*)k_node_pre, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  EGT_LAUNCH("k_node_pre", k_node_pre, dim3(a.B * node_chunks(a) + 1), dim3(512), lds, st, a);
+  EGT_LAUNCH("k_node_pre", k_node_pre, dim3(a.B * node_chunks(a) + (a.prep ? 1 : 0)), dim3(512), lds, st, a);
 }
 
 void egt_node_launch_post(BlockArgs& a, hipStream_t st) {
@@ -566,7 +579,7 @@ void egt_node_launch_post(BlockArgs& a, hipStream_t st) {
 
 void egt_node_launch_post_bwd(BlockArgs& a, hipStream_t st) {
   const size_t lds = lds_rows(a.Dh, 2) + (size_t)a.Dh * (a.Dh + LDP) * 4 + (size_t)4 * NODE_RC * 8 * 4;
-  EGT_LAUNCH("k_node_post_bwd", k_node_post_bwd, dim3(a.B * node_chunks(a) + 1), dim3(512), lds, st, a);
+  EGT_LAUNCH("k_node_post_bwd", k_node_post_bwd, dim3(a.B * node_chunks(a) + (a.prep ? 1 : 0)), dim3(512), lds, st, a);
 }
 
 void egt_node_launch_pre_bwd(BlockArgs& a, hipStream_t st) {
@@ -574,6 +587,16 @@ void egt_node_launch_pre_bwd(BlockArgs& a, hipStream_t st) {
                                            (size_t)a.Dh * (3 * a.Dh + LDP)) * 4;
   (void)hipFuncSetAttribute((const void*)k_node_pre_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   EGT_LAUNCH("k_node_pre_bwd", k_node_pre_bwd, dim3(a.B * node_chunks(a)), dim3(512), lds, st, a);
+}
+
+void egt_node_launch_prep(BlockArgs* as, int n, hipStream_t st) {
+  PrepArgs pa{};
+  pa.De = as[0].De; pa.flags = as[0].flags;
+  for (int l = 0; l < n; ++l) {
+    const BlockArgs& a = as[l];
+    pa.L[l] = PrepLayer{a.ne_g, a.ne_b, a.Wg, a.bg, a.We, a.be, a.pw};
+  }
+  EGT_LAUNCH("k_edge_prep", k_edge_prep, dim3(n), dim3(256), 0, st, pa);
 }
 
 // Reduce the per-workgroup partials of `n` layers (one BlockArgs each, with their own
