@@ -31,7 +31,9 @@ struct BlockArgs {
   float *v_att, *stats, *qkvp;
   // workspace
   float *pw;        // prepared edge weights: Wp[DEP][16], c2[16]
-  float *dvp, *dqp, *dkvp, *epart, *npart, *ered;
+  float *dvp, *dqp, *dkvp, *epart, *ered;
+  float *spart, *wpart;   // node-side partials: small column sums per workgroup; dWqkv|dWo per row chunk
+  float *dqkv_sv;         // dQKV rows [B*N][3Dh] kept for the deferred weight-gradient kernel
   // backward
   const float *dh_out, *de_out;
   float *dh, *de;
@@ -61,7 +63,8 @@ __host__ __device__ inline int col_head(int i) { return 2 * (i >> 2) + ((i >> 1)
 // launchers implemented in egt_node.hip
 void egt_node_launch_pre(BlockArgs& a, hipStream_t st);
 void egt_node_launch_post(BlockArgs& a, hipStream_t st);
-void egt_node_launch_post_bwd(BlockArgs& a, hipStream_t st);
-void egt_node_launch_pre_bwd(BlockArgs& a, hipStream_t st);
+void egt_node_launch_bwd(BlockArgs& a, const BlockArgs* dv_layer, bool do_pre, hipStream_t st);
+void egt_node_launch_wgrads(BlockArgs* as, int n, hipStream_t st);   // n <= 64 layers
+int egt_node_wgrad_chunks(int rows);
 void egt_node_launch_prep(BlockArgs* as, int n, hipStream_t st);   // n <= 64 layers
-void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, int npart_stride, hipStream_t st);
+void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, hipStream_t st);

@@ -794,7 +794,7 @@ __global__ void __launch_bounds__(256, 1) k_block_bwd(BlockArgs a) {
 //  * the dH_ext and d(ehat) weight operands are read from LDS instead of living in registers;
 //  * the pair-major xhat operands of the T contraction are lifted into registers right after
 //    LayerNorm, which frees the e tile for the next row's DMA three quarters of a row early;
-//  * dQ partials go to HBM per key tile (summed in k_node_pre_bwd) instead of an LDS slab.
+//  * dQ partials go to HBM per key tile (summed in k_node_bwd) instead of an LDS slab.
 typedef __attribute__((address_space(3))) void* lds_vptr;
 typedef const __attribute__((address_space(1))) void* gbl_vptr;
 
@@ -1085,7 +1085,7 @@ __global__ void __launch_bounds__(256, WPS) k_block_bwd_dma(BlockArgs a) {
 //    (conflict-free ds_read_b128) and are fetched right before their MFMA group;
 //  * xhat and de' fragments are re-read from their LDS tiles where they are needed again
 //    (LayerNorm backward) instead of being held across the tile;
-//  * dQ partials go to HBM per key tile (summed in k_node_pre_bwd) instead of an LDS slab;
+//  * dQ partials go to HBM per key tile (summed in k_node_bwd) instead of an LDS slab;
 //  * scheduling fences between the phases keep the compiler from hoisting every LDS read to
 //    the top of the tile (which is what blows the register budget).
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -1408,8 +1408,10 @@ static size_t al(size_t x) { return (x + 63) & ~(size_t)63; }  // in floats
 
 struct BlockLayout {
   size_t v_att, stats, qkvp, saved_total;
-  size_t pw, dvp, dqp, dkvp, epart, npart, ered, ws_total;
-  int NLR, nwg_bwd, EP, npart_stride;
+  // workspace = [common: dvp dqp dkvp] + per layer [pw epart spart wpart ered dqkv dhbuf]
+  size_t dvp, dqp, dkvp, common_total;
+  size_t pw, epart, spart, wpart, ered, dqkv, dhbuf, layer_total;
+  int NLR, nwg_bwd, EP;
 };
 
 static BlockLayout layout(const egt_block_desc* d) {
@@ -1425,17 +1427,29 @@ static BlockLayout layout(const egt_block_desc* d) {
   L.saved_total = o;
   L.NLR = (d->N + BWD_TL - 1) / BWD_TL;
   L.nwg_bwd = d->B * L.NLR;
-  L.npart_stride = Dh * 3 * Dh + 3 * Dh + 2 * Dh + Dh * Dh + Dh;
   o = 0;
-  L.pw = o; o += al((size_t)DEP * 16 + 16);
   L.dvp = o; o += al(rows * 64);
   L.dqp = o; o += al(rows * 64 * (size_t)((d->N + 15) / 16));
   L.dkvp = o; o += al((size_t)d->B * L.NLR * d->N * 128);
+  L.common_total = o;
+  o = 0;
+  L.pw = o; o += al((size_t)DEP * 16 + 16);
   L.epart = o; o += al((size_t)L.nwg_bwd * L.EP);
-  L.npart = o; o += al((size_t)d->B * ((d->N + NODE_RC - 1) / NODE_RC) * L.npart_stride);
+  L.spart = o; o += al((size_t)d->B * ((d->N + NODE_RC - 1) / NODE_RC) * (6 * Dh));
+  L.wpart = o; o += al((size_t)egt_node_wgrad_chunks((int)rows) * (Dh * 3 * Dh + Dh * Dh));
   L.ered = o; o += al(L.EP);
-  L.ws_total = o;
+  L.dqkv = o; o += al(rows * 3 * Dh);
+  L.dhbuf = o; o += al(rows * Dh);
+  L.layer_total = o;
   return L;
+}
+
+// workspace pointers of one layer: `wc` = common region, `wl` = that layer's region
+static void bind_ws(const BlockLayout& L, BlockArgs& a, float* wc, float* wl) {
+  a.dvp = wc + L.dvp; a.dqp = wc + L.dqp; a.dkvp = wc + L.dkvp;
+  a.pw = wl + L.pw; a.epart = wl + L.epart; a.spart = wl + L.spart; a.wpart = wl + L.wpart;
+  a.ered = wl + L.ered; a.dqkv_sv = wl + L.dqkv;
+  a.TL = BWD_TL; a.NLR = L.NLR; a.NQP = 1;
 }
 
 extern "C" size_t egt_block_saved_bytes(const egt_block_desc* d) {
@@ -1444,7 +1458,8 @@ extern "C" size_t egt_block_saved_bytes(const egt_block_desc* d) {
 }
 extern "C" size_t egt_block_workspace_bytes(const egt_block_desc* d) {
   if (block_check(d, false)) return 0;
-  return layout(d).ws_total * sizeof(float);
+  const BlockLayout L = layout(d);
+  return (L.common_total + L.layer_total) * sizeof(float);
 }
 
 static int fill_block(const egt_block_desc* d, const egt_block_params* p, BlockArgs& a) {
@@ -1486,9 +1501,7 @@ static void bind_common(const egt_block_desc* d, BlockArgs& a, const void* h, co
     if (rm) a.rm = rm; else a.rng_rm = 1;
   }
   a.v_att = saved + L.v_att; a.stats = saved + L.stats; a.qkvp = saved + L.qkvp;
-  a.pw = ws + L.pw; a.dvp = ws + L.dvp; a.dqp = ws + L.dqp; a.dkvp = ws + L.dkvp;
-  a.epart = ws + L.epart; a.npart = ws + L.npart; a.ered = ws + L.ered;
-  a.TL = BWD_TL; a.NLR = L.NLR; a.NQP = 1;
+  bind_ws(L, a, ws, ws + L.common_total);
   a.prep = 1;
 }
 
@@ -1536,10 +1549,14 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   return a.epi;
 }
 
+// Backward of one block.  `top`: first block of the chain (its dV_att / delta come from an own
+// launch); otherwise they were produced by the node kernel of the block above.  `below`: the
+// next block of the chain (NULL at the bottom), whose dV_att / delta this block's node kernel
+// produces.  GEMM-shaped weight gradients and all partial reductions are left to the caller.
 template <int DE>
-static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool reduce_now) {
+static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool top, const BlockArgs* below) {
   using GG = Geo<DE>;
-  egt_node_launch_post_bwd(a, st);  // dV_att (packed), delta, dWo/dbo partials, edge-weight prep
+  if (top) egt_node_launch_bwd(a, &a, false, st);  // dV_att (packed), delta, dbo sums [+ edge-weight prep]
   constexpr int PW = 3 * GG::TILE_FLOATS + 256 + 192;
   static_assert(4 * GG::EP <= 4 * PW, "edge partial staging must fit the LDS tile area");
   const size_t lds = ((size_t)4 * PW + (size_t)4 * BWD_TL * 64 + (size_t)BWD_TL * QD_LD) * 4;
@@ -1592,8 +1609,7 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
   else BWD_VARIANT(false, false);
 pair_done:
 #undef BWD_VARIANT
-  egt_node_launch_pre_bwd(a, st);   // dQKV -> dh, dWqkv/dbqkv/dgamma/dbeta partials
-  if (reduce_now) egt_node_launch_reduce(&a, 1, L.nwg_bwd, L.EP, L.npart_stride, st);  // partial sums + edge param grads
+  egt_node_launch_bwd(a, below, true, st);   // dQKV -> dh, bias/LN sums; dV_att + delta of the block below
 }
 
 
@@ -1645,7 +1661,9 @@ extern "C" int egt_block_bwd(const egt_block_desc* desc, const egt_block_params*
   a.g_Wo = (float*)grads->dense_mha_kernel; a.g_bo = (float*)grads->dense_mha_bias;
   a.g_Wr = (float*)grads->dense_edge_r_kernel; a.g_br = (float*)grads->dense_edge_r_bias;
   const BlockLayout L = layout(desc);
-  DISPATCH_BDE(desc->De, launch_bwd<DE>(a, L, (hipStream_t)stream, true));
+  DISPATCH_BDE(desc->De, launch_bwd<DE>(a, L, (hipStream_t)stream, true, nullptr));
+  egt_node_launch_wgrads(&a, 1, (hipStream_t)stream);
+  egt_node_launch_reduce(&a, 1, L.nwg_bwd, L.EP, (hipStream_t)stream);  // partial sums + edge param grads
   EGT_HIP_LAUNCH_CHECK("egt_block_bwd");
   return EGT_OK;
 }
@@ -1661,7 +1679,7 @@ static uint64_t layer_seed(uint64_t seed, int l) { return seed ^ (0x9E3779B97F4A
 
 struct StackLayout {
   size_t h_act, e_act, blk, saved_total;      // floats
-  size_t common, per_layer, per_layer_stride, pw_off, ws_total;
+  size_t ws_total;
   size_t h_sz, e_sz;
 };
 
@@ -1675,11 +1693,7 @@ static StackLayout stack_layout(const egt_block_desc* d, int layers) {
   S.e_act = o; o += S.e_sz * (size_t)(layers > 1 ? layers - 1 : 0);
   S.blk = o; o += L.saved_total * (size_t)layers;
   S.saved_total = o;
-  // workspace: [(pw) dvp dqp dkvp] shared by all layers, then per layer [epart npart ered pw]
-  S.common = L.epart;                       // everything before epart in the block layout
-  S.pw_off = L.ws_total - L.epart;
-  S.per_layer_stride = S.pw_off + (L.dvp - L.pw);
-  S.ws_total = S.common + S.per_layer_stride * (size_t)layers;
+  S.ws_total = L.common_total + L.layer_total * (size_t)layers;
   return S;
 }
 
@@ -1696,11 +1710,9 @@ static void bind_layer(const egt_block_desc* d, const StackLayout& S, const Bloc
                        BlockArgs& a, float* saved, float* ws) {
   float* bs = saved + S.blk + L.saved_total * (size_t)l;
   a.v_att = bs + L.v_att; a.stats = bs + L.stats; a.qkvp = bs + L.qkvp;
-  a.pw = ws + L.pw; a.dvp = ws + L.dvp; a.dqp = ws + L.dqp; a.dkvp = ws + L.dkvp;
-  float* pl = ws + S.common + S.per_layer_stride * (size_t)l;
-  a.epart = pl; a.npart = pl + (L.npart - L.epart); a.ered = pl + (L.ered - L.epart);
-  a.pw = pl + S.pw_off;   // per layer: block l's epilogue must not race block l+1's weights
-  a.TL = BWD_TL; a.NLR = L.NLR; a.NQP = 1;
+  // per-layer workspace: block l's epilogue must not race block l+1's prepared weights, and the
+  // deferred reductions / weight gradients need every layer's partials and dQKV rows at the end
+  bind_ws(L, a, ws, ws + L.common_total + L.layer_total * (size_t)l);
   (void)d;
 }
 
@@ -1786,10 +1798,13 @@ extern "C" int egt_stack_bwd(const egt_block_desc* desc, int32_t layers, const e
     const float* ein = l == 0 ? (const float*)e : sv + S.e_act + S.e_sz * (size_t)(l - 1);
     bind_common(&dl, a, hin, ein, key_mask, attn_mask, nullptr, sv, (float*)workspace);
     bind_layer(&dl, S, L, l, a, sv, (float*)workspace);
-    // grads flow through d_h / d_e in place below the top layer
-    a.dh_out = l == layers - 1 ? (const float*)d_h_out : (const float*)d_h;
+    // d_e flows in place below the top layer; every layer keeps its own dh (the deferred dWo
+    // contraction reads dh' of each layer at the end)
+    auto dhbuf = [&](int ll) { return (float*)workspace + L.common_total + L.layer_total * (size_t)ll + L.dhbuf; };
+    a.dh_out = l == layers - 1 ? (const float*)d_h_out : (const float*)dhbuf(l + 1);
     a.de_out = l == layers - 1 ? (const float*)d_e_out : (const float*)d_e;
-    a.dh = (float*)d_h; a.de = (float*)d_e;
+    a.dh = l == 0 ? (float*)d_h : dhbuf(l);
+    a.de = (float*)d_e;
     a.g_ne_g = (float*)g->norm_edge_gamma; a.g_ne_b = (float*)g->norm_edge_beta;
     a.g_Wg = (float*)g->attention_gates_kernel; a.g_bg = (float*)g->attention_gates_bias;
     a.g_We = (float*)g->dense_edge_b_kernel; a.g_be = (float*)g->dense_edge_b_bias;
@@ -1797,9 +1812,14 @@ extern "C" int egt_stack_bwd(const egt_block_desc* desc, int32_t layers, const e
     a.g_Wqkv = (float*)g->dense_qkv_kernel; a.g_bqkv = (float*)g->dense_qkv_bias;
     a.g_Wo = (float*)g->dense_mha_kernel; a.g_bo = (float*)g->dense_mha_bias;
     a.g_Wr = (float*)g->dense_edge_r_kernel; a.g_br = (float*)g->dense_edge_r_bias;
-    DISPATCH_BDE(desc->De, launch_bwd<DE>(a, L, (hipStream_t)stream, false));
   }
-  egt_node_launch_reduce(as, layers, L.nwg_bwd, L.EP, L.npart_stride, (hipStream_t)stream);
+  egt_node_launch_prep(as, layers, (hipStream_t)stream);
+  for (int l = layers - 1; l >= 0; --l) {
+    as[l].prep = 0;
+    DISPATCH_BDE(desc->De, launch_bwd<DE>(as[l], L, (hipStream_t)stream, l == layers - 1, l > 0 ? &as[l - 1] : nullptr));
+  }
+  egt_node_launch_wgrads(as, layers, (hipStream_t)stream);
+  egt_node_launch_reduce(as, layers, L.nwg_bwd, L.EP, (hipStream_t)stream);
   EGT_HIP_LAUNCH_CHECK("egt_stack_bwd");
   return EGT_OK;
 }

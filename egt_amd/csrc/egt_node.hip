@@ -2,13 +2,15 @@
 //   k_node_pre      : norm_mha -> dense_qkv, written packed per head-pair
 //                     (graph_xformer_model_base.py:109,113)         [+ edge-weight prep]
 //   k_node_post     : dense_mha + res_mha (:136,140)
-//   k_node_post_bwd : dV_att = dh'.Wo^T (packed), delta = sum_k dV_att*V_att,
-//                     dWo/dbo partials                              [+ edge-weight prep]
-//   k_node_pre_bwd  : dQKV -> d(h_ln) -> LN backward -> dh ; dWqkv/dbqkv/dgamma/dbeta partials
+//   k_node_bwd      : [layer l] dQKV -> d(h_ln) -> LN backward -> dh ; bias / LN-parameter sums
+//                     [layer l-1] dV_att = dh.Wo^T (packed), delta = sum_k dV_att*V_att
+//   k_node_wgrads   : dWqkv, dWo of every layer in one launch (deferred, off the critical path)
 //   k_sum_segments  : deterministic reduction of all per-workgroup partials
 //   k_edge_param_grads : T,s,R -> grads of norm_edge / attention_gates / dense_edge_b / dense_edge_r
 // One workgroup per graph; every contraction is a 16x16 tile on
 // v_mfma_f32_16x16x4_f32 with the activation rows staged in LDS.
+#include <stdlib.h>
+
 #include "egt_block.h"
 
 #define LDP 4  // LDS row padding (floats)
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(512) k_node_pre(BlockArgs a) {
   const int NCH = (a.N + NODE_RC - 1) / NODE_RC;
   if ((int)blockIdx.x == a.B * NCH) { prep_device(a, sm); return; }
   const int Dh = a.Dh, N = a.N, b = blockIdx.x / NCH, chunk = blockIdx.x % NCH, t = threadIdx.x, ld = Dh + LDP, D3 = 3 * Dh;
-  const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4, NW = blockDim.x >> 6;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), p = lane & 15, q = lane >> 4, NW = blockDim.x >> 6;
   float* xs = sm;                 // [NODE_RC][ld]
   float* ws = xs + NODE_RC * ld;  // Wqkv [Dh][ldw]
   const int ldw = D3 + LDP;
@@ -198,7 +200,7 @@ __global__ void __launch_bounds__(512) k_node_post(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int NCH = (a.N + NODE_RC - 1) / NODE_RC;
   const int Dh = a.Dh, N = a.N, b = blockIdx.x / NCH, chunk = blockIdx.x % NCH, t = threadIdx.x, ld = Dh + LDP;
-  const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4, NW = blockDim.x >> 6;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), p = lane & 15, q = lane >> 4, NW = blockDim.x >> 6;
   float* xs = sm;
   float* ws = xs + NODE_RC * ld;  // Wo [Dh][ld]
   stage_weight(ws, ld, a.Wo, Dh, Dh);
@@ -230,171 +232,106 @@ __global__ void __launch_bounds__(512) k_node_post(BlockArgs a) {
   }
 }
 
-// ------------------------------------------------------ node: post backward -----
-// node partial layout per graph: [dWqkv Dh*3Dh | dbqkv 3Dh | dgamma Dh | dbeta Dh | dWo Dh*Dh | dbo Dh]
-__global__ void __launch_bounds__(512) k_node_post_bwd(BlockArgs a) {
+// ------------------------------------------------------------ node: backward -----
+// One launch per layer on the d_h critical path (plus one at the top of the chain):
+//   pre part (layer l):  dQKV rows = packed dQ + dK/dV partial sums  -> d(h_ln) = dQKV.Wqkv^T
+//                        -> LayerNorm backward + residual -> dh(l);  dQKV rows are kept for
+//                        the deferred weight-gradient kernel; bias / LN-parameter column sums
+//   dv part (layer l-1, or the top layer itself in the first call):
+//                        dV_att = dh.Wo^T (packed), delta = sum_k dV_att*V_att, dbo column sums
+// The GEMM-shaped weight gradients (dWqkv, dWo) are NOT computed here: k_node_wgrads does them
+// for every layer of the stack in one launch, off the critical path.
+// small per-workgroup partials of a layer: [dbqkv 3Dh | dgamma Dh | dbeta Dh | dbo Dh]
+struct NodeBwdArgs {
+  int do_pre, do_dv;
+  const float *dv_Wo, *dv_v_att, *dv_dh_src;   // dv_dh_src: rows of dh' when do_pre == 0
+  float *dv_stats, *dv_dvp, *dv_spart;
+};
+
+__global__ void __launch_bounds__(512) k_node_bwd(BlockArgs a, NodeBwdArgs x) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int NCH = (a.N + NODE_RC - 1) / NODE_RC;
   if ((int)blockIdx.x == a.B * NCH) { prep_device(a, sm); return; }
-  const int Dh = a.Dh, N = a.N, b = blockIdx.x / NCH, chunk = blockIdx.x % NCH, t = threadIdx.x, ld = Dh + LDP;
-  const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4, NW = blockDim.x >> 6;
-  float* ds = sm;                    // dh'   [NODE_RC][ld]
-  float* vs = ds + NODE_RC * ld;     // v_att [NODE_RC][ld]
-  float* ws = vs + NODE_RC * ld;     // Wo    [Dh][ld]
-  float* dlp = ws + Dh * ld;         // delta partials [nit][NODE_RC][8]
-  stage_weight(ws, ld, a.Wo, Dh, Dh);
-  const int nit = (Dh + 15) / 16;    // <= 4
-  v4f accW[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) accW[j] = (v4f){0.f, 0.f, 0.f, 0.f};
-  float accB = 0.f;
-  for (int r0 = chunk * NODE_RC; r0 < min(N, (chunk + 1) * NODE_RC); r0 += NODE_RC) {  // one chunk
-    const int nr = min(NODE_RC, N - r0), nrp = (nr + 15) & ~15;
-    const size_t row0 = (size_t)b * N + r0;
-    __syncthreads();
-    stage_rows(ds, ld, a.dh_out + row0 * Dh, Dh, nr, nrp);
-    stage_rows(vs, ld, a.v_att + row0 * Dh, Dh, nr, nrp);
-    __syncthreads();
-    // (1) dV_att = dh'.Wo^T: (row tile, i tile) pairs spread over the waves; the per-head
-    //     delta contributions of each i tile go through LDS and are summed in fixed order
-    for (int tile = wave; tile < (nrp / 16) * nit; tile += NW) {
-      const int rt = tile / nit, it = tile % nit;
-      const int i = it * 16 + p;
-      const bool colok = i < Dh;
-      v4f acc = {0.f, 0.f, 0.f, 0.f};
-      acc = mm_xwt(ds + rt * 16 * ld, ld, ws + it * 16 * ld, ld, Dh, p, q, colok, acc);
-      const int k = i >> 3, hh = i & 7;
-      const int pos = (hh >> 1) * 16 + k * 2 + (hh & 1);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rt * 16 + 4 * q + r;
-        if (colok && row < nr) a.dvp[(row0 + row) * 64 + pos] = acc[r];
-        float pr = colok ? acc[r] * vs[row * ld + i] : 0.f;
-        pr += lane_xor<8>(pr);   // the tile's two k values of head p&7
-        if (p < 8) dlp[(it * NODE_RC + row) * 8 + p] = pr;
-      }
-    }
-    __syncthreads();
-    for (int i = t; i < nr * 8; i += blockDim.x) {
-      float dl = 0.f;
-      for (int it = 0; it < nit; ++it) dl += dlp[it * NODE_RC * 8 + i];
-      a.stats[(row0 * BH + i) * 4 + 2] = dl;
-    }
-    if (a.DK < 8) {
-      for (int i = t; i < nr * 64; i += blockDim.x)
-        if ((((i & 63) >> 1) & 7) >= a.DK) a.dvp[row0 * 64 + i] = 0.f;
-    }
-    // (2) dWo[i][c] += sum_rows v_att[row][i] * dh'[row][c]
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int idx = wave + NW * j;
-      if (idx < nit * nit) {
-        const int it = idx / nit, ct = idx % nit;
-#pragma unroll 4
-        for (int rr = 0; rr < nrp; rr += 4)
-          accW[j] = MFMA(vs[(rr + q) * ld + it * 16 + p], ds[(rr + q) * ld + ct * 16 + p], accW[j]);
-      }
-    }
-    if (t < Dh) {
-      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;   // independent partial sums: the LDS reads pipeline
-      for (int r = 0; r < nrp; r += 4) {
-        b0 += ds[r * ld + t]; b1 += ds[(r + 1) * ld + t]; b2 += ds[(r + 2) * ld + t]; b3 += ds[(r + 3) * ld + t];
-      }
-      accB += (b0 + b1) + (b2 + b3);
-    }
-  }
-  float* part = a.npart + (size_t)blockIdx.x * (Dh * 3 * Dh + 3 * Dh + 2 * Dh + Dh * Dh + Dh) + Dh * 3 * Dh + 3 * Dh + 2 * Dh;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int idx = wave + NW * j;
-    if (idx < nit * nit) {
-      const int it = idx / nit, ct = idx % nit, c = ct * 16 + p;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = it * 16 + 4 * q + r;
-        if (i < Dh && c < Dh) part[i * Dh + c] = accW[j][r];
-      }
-    }
-  }
-  if (t < Dh) part[Dh * Dh + t] = accB;
-}
-
-// ------------------------------------------------------- node: pre backward -----
-__global__ void __launch_bounds__(512) k_node_pre_bwd(BlockArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int NCH = (a.N + NODE_RC - 1) / NODE_RC;
   const int Dh = a.Dh, N = a.N, b = blockIdx.x / NCH, chunk = blockIdx.x % NCH, t = threadIdx.x, D3 = 3 * Dh;
-  const int ld = Dh + LDP, ld3 = D3 + LDP;
-  const int lane = t & 63, wave = t >> 6, p = lane & 15, q = lane >> 4, NW = blockDim.x >> 6;
-  float* xs = sm;                        // xhat  [NODE_RC][ld]
-  float* dqs = xs + NODE_RC * ld;        // dQKV  [NODE_RC][ld3]
-  float* dls = dqs + NODE_RC * ld3;      // d h_ln [NODE_RC][ld]
-  float* rs = dls + NODE_RC * ld;        // rstd  [NODE_RC]
-  float* ws = rs + NODE_RC;              // Wqkv  [Dh][ld3]
-  stage_weight(ws, ld3, a.Wqkv, Dh, D3);
-  const int nkt = (Dh + 15) / 16, nct = (D3 + 15) / 16, ntl = nkt * nct;  // <= 4 x 12
-  v4f accW[12];
-#pragma unroll
-  for (int j = 0; j < 12; ++j) accW[j] = (v4f){0.f, 0.f, 0.f, 0.f};
-  float accBq = 0.f, accG = 0.f, accBt = 0.f;
-  for (int r0 = chunk * NODE_RC; r0 < min(N, (chunk + 1) * NODE_RC); r0 += NODE_RC) {  // one chunk
-    const int nr = min(NODE_RC, N - r0), nrp = (nr + 15) & ~15;
-    const size_t row0 = (size_t)b * N + r0;
-    __syncthreads();
+  const int ld = Dh + LDP, ld3 = D3 + LDP, SP = D3 + 3 * Dh;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), p = lane & 15, q = lane >> 4, NW = blockDim.x >> 6;
+  float* xs = sm;                        // xhat   [NODE_RC][ld]
+  float* dls = xs + NODE_RC * ld;        // d h_ln [NODE_RC][ld]
+  float* dhs = dls + NODE_RC * ld;       // dh     [NODE_RC][ld]
+  float* vs = dhs + NODE_RC * ld;        // v_att  [NODE_RC][ld]   (dv layer)
+  float* rs = vs + NODE_RC * ld;         // rstd   [NODE_RC]
+  float* dlp = rs + NODE_RC;             // delta partials [4][NODE_RC][8]
+  float* wo = dlp + 4 * NODE_RC * 8;     // Wo     [Dh][ld]        (dv layer)
+  float* dqs = wo + Dh * ld;             // dQKV   [NODE_RC][ld3]
+  float* ws = dqs + NODE_RC * ld3;       // Wqkv   [Dh][ld3]
+  const int r0 = chunk * NODE_RC;
+  const int nr = min(NODE_RC, N - r0), nrp = (nr + 15) & ~15;
+  const size_t row0 = (size_t)b * N + r0;
+  const int nkt = (Dh + 15) / 16;
+
+  if (x.do_pre) stage_weight(ws, ld3, a.Wqkv, Dh, D3);
+  if (x.do_dv) {
+    stage_weight(wo, ld, x.dv_Wo, Dh, Dh);
+    stage_rows(vs, ld, x.dv_v_att + row0 * Dh, Dh, nr, nrp);
+  }
+  if (x.do_pre) {
     stage_rows(xs, ld, a.h + row0 * Dh, Dh, nr, nrp);
     // dQKV rows: packed dq + dK/dV partials summed over the row-ranges (16-byte units)
-    {
-      const int U = nrp * 48, NT = (int)blockDim.x;
-      for (int i0 = t; i0 < U; i0 += 4 * NT) {   // up to 4 units x (NQP | NLR) 16-byte loads in flight
-        float4 v[4];
+    const int U = nrp * 48, NT = (int)blockDim.x;
+    for (int i0 = t; i0 < U; i0 += 4 * NT) {   // up to 4 units x (NQP | NLR) 16-byte loads in flight
+      float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = i0 + u * NT, r = i / 48, pos4 = (i % 48) * 4, s = pos4 >> 6;
-          float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (i < U && r < nr) {
-            if (s == 0) {
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * NT, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
+        float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < U && r < nr) {
+          if (sx == 0) {
 #pragma unroll 4
-              for (int qp = 0; qp < a.NQP; ++qp) {
-                const float4 w = *reinterpret_cast<const float4*>(
-                    a.dqp + (((size_t)b * a.NQP + qp) * N + r0 + r) * 64 + pos4);
-                acc4.x += w.x; acc4.y += w.y; acc4.z += w.z; acc4.w += w.w;
-              }
-            } else {
+            for (int qp = 0; qp < a.NQP; ++qp) {
+              const float4 w = *reinterpret_cast<const float4*>(
+                  a.dqp + (((size_t)b * a.NQP + qp) * N + r0 + r) * 64 + pos4);
+              acc4.x += w.x; acc4.y += w.y; acc4.z += w.z; acc4.w += w.w;
+            }
+          } else {
 #pragma unroll 4
-              for (int lr = 0; lr < a.NLR; ++lr) {
-                const float4 w = *reinterpret_cast<const float4*>(
-                    a.dkvp + ((((size_t)b * a.NLR + lr) * N + r0 + r) * 2 + (s - 1)) * 64 + (pos4 & 63));
-                acc4.x += w.x; acc4.y += w.y; acc4.z += w.z; acc4.w += w.w;
-              }
+            for (int lr = 0; lr < a.NLR; ++lr) {
+              const float4 w = *reinterpret_cast<const float4*>(
+                  a.dkvp + ((((size_t)b * a.NLR + lr) * N + r0 + r) * 2 + (sx - 1)) * 64 + (pos4 & 63));
+              acc4.x += w.x; acc4.y += w.y; acc4.z += w.z; acc4.w += w.w;
             }
           }
-          v[u] = acc4;
         }
+        v[u] = acc4;
+      }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = i0 + u * NT, r = i / 48, pos4 = (i % 48) * 4, s = pos4 >> 6;
-          if (i < U) {
-            const int qq = (pos4 >> 4) & 3, k0 = (pos4 >> 1) & 7;
-            float* d = dqs + r * ld3 + s * Dh + k0 * 8 + 2 * qq;
-            if (k0 < a.DK) { d[0] = v[u].x; d[1] = v[u].y; }
-            if (k0 + 1 < a.DK) { d[8] = v[u].z; d[9] = v[u].w; }
-          }
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * NT, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
+        if (i < U) {
+          const int qq = (pos4 >> 4) & 3, k0 = (pos4 >> 1) & 7;
+          float* d = dqs + r * ld3 + sx * Dh + k0 * 8 + 2 * qq;
+          if (k0 < a.DK) { d[0] = v[u].x; d[1] = v[u].y; }
+          if (k0 + 1 < a.DK) { d[8] = v[u].z; d[9] = v[u].w; }
         }
       }
     }
-    __syncthreads();
+  } else {
+    stage_rows(dhs, ld, x.dv_dh_src + row0 * Dh, Dh, nr, nrp);
+  }
+  __syncthreads();
+
+  if (x.do_pre) {
     for (int rb = wave * 4; rb < nrp; rb += 4 * NW) {  // LN forward statistics -> xhat in place
-      float* x = xs + (rb + q) * ld;
-      float v[4], s = 0.f;
+      float* xr = xs + (rb + q) * ld;
+      float v[4], s1 = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int c = p + 16 * i; v[i] = c < Dh ? x[c] : 0.f; s += v[i]; }
-      const float mu = sum16(s) / Dh;
+      for (int i = 0; i < 4; ++i) { const int c = p + 16 * i; v[i] = c < Dh ? xr[c] : 0.f; s1 += v[i]; }
+      const float mu = sum16(s1) / Dh;
       float ss = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const int c = p + 16 * i; if (c < Dh) { v[i] -= mu; ss = fmaf(v[i], v[i], ss); } }
       const float rstd = rsqrtf(sum16(ss) / Dh + a.ln_eps);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int c = p + 16 * i; if (c < Dh) x[c] = v[i] * rstd; }
+      for (int i = 0; i < 4; ++i) { const int c = p + 16 * i; if (c < Dh) xr[c] = v[i] * rstd; }
       if (p == 0) rs[rb + q] = rstd;
     }
     // d(h_ln)[row][kk] = sum_c dQKV[row][c] * Wqkv[kk][c]
@@ -409,10 +346,15 @@ __global__ void __launch_bounds__(512) k_node_pre_bwd(BlockArgs a) {
         for (int r = 0; r < 4; ++r) dls[(rt * 16 + 4 * q + r) * ld + kk] = acc[r];
       }
     }
+    // dQKV rows out, natural channel order, for k_node_wgrads
+    for (int i = t; i < nr * (D3 / 4); i += blockDim.x) {
+      const int r = i / (D3 / 4), c4 = (i % (D3 / 4)) * 4;
+      *reinterpret_cast<float4*>(a.dqkv_sv + (row0 + r) * D3 + c4) = *reinterpret_cast<const float4*>(dqs + r * ld3 + c4);
+    }
     __syncthreads();
     for (int rb = wave * 4; rb < nrp; rb += 4 * NW) {  // LayerNorm backward + residual
       const int row = rb + q;
-      const float* x = xs + row * ld;
+      const float* xr = xs + row * ld;
       const float* dl = dls + row * ld;
       float dx[4], m1 = 0.f, m2 = 0.f;
 #pragma unroll
@@ -420,41 +362,33 @@ __global__ void __launch_bounds__(512) k_node_pre_bwd(BlockArgs a) {
         const int c = p + 16 * i;
         dx[i] = c < Dh ? dl[c] * a.nm_g[c] : 0.f;
         m1 += dx[i];
-        m2 = fmaf(dx[i], c < Dh ? x[c] : 0.f, m2);
+        m2 = fmaf(dx[i], c < Dh ? xr[c] : 0.f, m2);
       }
       m1 = sum16(m1) / Dh;
       m2 = sum16(m2) / Dh;
       const float rstd = rs[row];
-      if (row < nr) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int c = p + 16 * i;
-          if (c < Dh) {
+      for (int i = 0; i < 4; ++i) {
+        const int c = p + 16 * i;
+        if (c < Dh) {
+          float dv = 0.f;
+          if (row < nr) {
             const size_t o = (row0 + row) * Dh + c;
-            a.dh[o] = a.dh_out[o] + rstd * (dx[i] - m1 - x[c] * m2);
+            dv = a.dh_out[o] + rstd * (dx[i] - m1 - xr[c] * m2);
+            a.dh[o] = dv;
           }
+          dhs[row * ld + c] = dv;
         }
       }
     }
-    // dWqkv[kk][c] += sum_rows h_ln[row][kk] * dQKV[row][c]
-#pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      const int idx = wave + NW * j;
-      if (idx < ntl) {
-        const int kt = idx / nct, ct = idx % nct, kk = kt * 16 + p;
-        const float g = kk < Dh ? a.nm_g[kk] : 0.f, bt = kk < Dh ? a.nm_b[kk] : 0.f;
-#pragma unroll 4
-        for (int rr = 0; rr < nrp; rr += 4)
-          accW[j] = MFMA(fmaf(xs[(rr + q) * ld + kk], g, bt), dqs[(rr + q) * ld3 + ct * 16 + p], accW[j]);
-      }
-    }
-    // column sums with independent partial accumulators (rows >= nr are zero-padded in LDS)
+    // column sums (rows >= nr are zero-padded in LDS): dbqkv | dgamma, dbeta
+    float* sp = a.spart + (size_t)blockIdx.x * SP;
     if (t < D3) {
       float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
       for (int r = 0; r < nrp; r += 4) {
         b0 += dqs[r * ld3 + t]; b1 += dqs[(r + 1) * ld3 + t]; b2 += dqs[(r + 2) * ld3 + t]; b3 += dqs[(r + 3) * ld3 + t];
       }
-      accBq += (b0 + b1) + (b2 + b3);
+      sp[t] = (b0 + b1) + (b2 + b3);
     } else if (t >= 256 && t < 256 + Dh) {   // a different wavefront takes the LayerNorm parameter sums
       const int c = t - 256;
       float g0 = 0.f, g1 = 0.f, s0 = 0.f, s1 = 0.f;
@@ -463,27 +397,189 @@ __global__ void __launch_bounds__(512) k_node_pre_bwd(BlockArgs a) {
         g0 = fmaf(d0, xs[r * ld + c], g0); g1 = fmaf(d1, xs[(r + 1) * ld + c], g1);
         s0 += d0; s1 += d1;
       }
-      accG += g0 + g1;
-      accBt += s0 + s1;
+      sp[D3 + c] = g0 + g1;
+      sp[D3 + Dh + c] = s0 + s1;
     }
+    if (x.do_dv) __syncthreads();
   }
-  float* part = a.npart + (size_t)blockIdx.x * (Dh * D3 + D3 + 2 * Dh + Dh * Dh + Dh);
-#pragma unroll
-  for (int j = 0; j < 12; ++j) {
-    const int idx = wave + NW * j;
-    if (idx < ntl) {
-      const int kt = idx / nct, ct = idx % nct, c = ct * 16 + p;
+
+  if (x.do_dv) {
+    // dV_att = dh'.Wo^T: (row tile, i tile) pairs spread over the waves; the per-head delta
+    // contributions of each i tile go through LDS and are summed in fixed order
+    const int nit = nkt;
+    for (int tile = wave; tile < (nrp / 16) * nit; tile += NW) {
+      const int rt = tile / nit, it = tile % nit;
+      const int i = it * 16 + p;
+      const bool colok = i < Dh;
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
+      acc = mm_xwt(dhs + rt * 16 * ld, ld, wo + it * 16 * ld, ld, Dh, p, q, colok, acc);
+      const int k = i >> 3, hh = i & 7;
+      const int pos = (hh >> 1) * 16 + k * 2 + (hh & 1);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int kk = kt * 16 + 4 * q + r;
-        if (kk < Dh && c < D3) part[kk * D3 + c] = accW[j][r];
+        const int row = rt * 16 + 4 * q + r;
+        if (colok && row < nr) x.dv_dvp[(row0 + row) * 64 + pos] = acc[r];
+        float pr = colok ? acc[r] * vs[row * ld + i] : 0.f;
+        pr += lane_xor<8>(pr);   // the tile's two k values of head p&7
+        if (p < 8) dlp[(it * NODE_RC + row) * 8 + p] = pr;
+      }
+    }
+    if (t >= 256 && t < 256 + Dh) {   // dbo of the dv layer
+      const int c = t - 256;
+      float b0 = 0.f, b1 = 0.f;
+      for (int r = 0; r < nrp; r += 2) { b0 += dhs[r * ld + c]; b1 += dhs[(r + 1) * ld + c]; }
+      x.dv_spart[(size_t)blockIdx.x * SP + D3 + 2 * Dh + c] = b0 + b1;
+    }
+    __syncthreads();
+    for (int i = t; i < nr * 8; i += blockDim.x) {
+      float dl = 0.f;
+      for (int it = 0; it < nit; ++it) dl += dlp[it * NODE_RC * 8 + i];
+      x.dv_stats[(row0 * BH + i) * 4 + 2] = dl;
+    }
+    if (a.DK < 8) {
+      for (int i = t; i < nr * 64; i += blockDim.x)
+        if ((((i & 63) >> 1) & 7) >= a.DK) x.dv_dvp[row0 * 64 + i] = 0.f;
+    }
+  }
+}
+
+// ----------------------------------------------------- node: weight gradients -----
+// dWqkv[l] = h_ln(l)^T . dQKV(l)   and   dWo[l] = V_att(l)^T . dh'(l)   for EVERY layer in one
+// launch: grid = (row chunks, layers).  A workgroup walks WG_ROWS node rows (rows are flat over
+// the batch: no graph structure is needed) in steps of 32, recomputes norm_mha for them, and
+// accumulates its 16x16 output tiles on MFMA with the row index as the contraction axis.
+// Partials [layer][chunk][Dh*3Dh + Dh*Dh] are reduced by k_sum_segments.
+#define WG_ROWS 128
+struct WGradLayer { const float *h, *nm_g, *nm_b, *dqkv, *v_att, *dh_out; float* part; };
+struct WGradArgs { WGradLayer L[64]; int rows, Dh; float ln_eps; };
+
+template <bool D64>   // D64: Dh == 64, every tile exists -> no guards around the MFMAs
+__global__ void __launch_bounds__(512, 4) k_node_wgrads(WGradArgs wa) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const WGradLayer L = wa.L[blockIdx.y];
+  const int Dh = D64 ? 64 : wa.Dh, D3 = 3 * Dh, t = threadIdx.x;
+  const int ld = Dh + 16, ld3 = D3 + 16;   // row shift of 16 banks: the transposed operand reads are conflict-free
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), p = lane & 15, q = lane >> 4, NW = blockDim.x >> 6;
+  float* xs = sm;                 // h -> h_ln [32][ld]
+  float* vs = xs + 32 * ld;       // v_att     [32][ld]
+  float* ds = vs + 32 * ld;       // dh'       [32][ld]
+  float* dqs = ds + 32 * ld;      // dQKV      [32][ld3]
+  const int nkt = (Dh + 15) / 16, nct = (D3 + 15) / 16;  // <= 4 x 12
+  const int kt = wave >> 1, ct0 = (wave & 1) * 6, co0 = (wave & 1) * 2;
+  v4f accW[6], accO[2];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) accW[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) accO[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const int rbeg = blockIdx.x * WG_ROWS, rend = min(wa.rows, rbeg + WG_ROWS);
+  // per-thread 16-byte units of a 32-row step: one of h / v_att / dh' each, three of dQKV.  The
+  // loads of step i+1 are issued before the arithmetic of step i (register prefetch); addresses
+  // are clamped so that every load is unconditional, rows past the end are zeroed at the LDS store
+  const int w4 = Dh >> 2, w43 = 3 * w4;
+  const bool xok = t < 32 * w4;
+  const int xr = xok ? t / w4 : 0, xc = xok ? t % w4 : 0;
+  int qr[3], qc[3];
+  bool qok[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int i = t + 512 * u;
+    qok[u] = i < 32 * w43;
+    qr[u] = qok[u] ? i / w43 : 0;
+    qc[u] = qok[u] ? i % w43 : 0;
+  }
+  float gam[4], bet[4];   // norm_mha parameters of the lane's LayerNorm columns
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = p + 16 * i;
+    gam[i] = c < Dh ? L.nm_g[c] : 0.f;
+    bet[i] = c < Dh ? L.nm_b[c] : 0.f;
+  }
+  float4 ph, pv, pd, pq[3];
+#define WG_LOAD(R0)                                                                              \
+  do {                                                                                           \
+    const size_t rx = (size_t)min((R0) + xr, wa.rows - 1);                                       \
+    ph = *reinterpret_cast<const float4*>(L.h + rx * Dh + xc * 4);                               \
+    pv = *reinterpret_cast<const float4*>(L.v_att + rx * Dh + xc * 4);                           \
+    pd = *reinterpret_cast<const float4*>(L.dh_out + rx * Dh + xc * 4);                          \
+    _Pragma("unroll") for (int u = 0; u < 3; ++u)                                                \
+      pq[u] = *reinterpret_cast<const float4*>(L.dqkv + (size_t)min((R0) + qr[u], wa.rows - 1) * D3 + qc[u] * 4); \
+  } while (0)
+  WG_LOAD(rbeg);
+  for (int r0 = rbeg; r0 < rend; r0 += 32) {
+    const int nr = min(32, rend - r0), nrp = 32;
+    __syncthreads();
+    {
+      // component-wise selects (a float4 ternary is lowered through scratch memory)
+#define SEL4(ok, v) make_float4((ok) ? (v).x : 0.f, (ok) ? (v).y : 0.f, (ok) ? (v).z : 0.f, (ok) ? (v).w : 0.f)
+      if (xok) {
+        const bool ok = xr < nr;
+        *reinterpret_cast<float4*>(xs + xr * ld + xc * 4) = SEL4(ok, ph);
+        *reinterpret_cast<float4*>(vs + xr * ld + xc * 4) = SEL4(ok, pv);
+        *reinterpret_cast<float4*>(ds + xr * ld + xc * 4) = SEL4(ok, pd);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (qok[u]) *reinterpret_cast<float4*>(dqs + qr[u] * ld3 + qc[u] * 4) = SEL4(qr[u] < nr, pq[u]);
+#undef SEL4
+    }
+    if (r0 + 32 < rend) WG_LOAD(r0 + 32);
+    __syncthreads();
+    for (int rb = wave * 4; rb < nrp; rb += 4 * NW) {  // norm_mha forward, in place
+      float* xr = xs + (rb + q) * ld;
+      float v[4], s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int c = p + 16 * i; v[i] = c < Dh ? xr[c] : 0.f; s1 += v[i]; }
+      const float mu = sum16(s1) / Dh;
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int c = p + 16 * i; if (c < Dh) { v[i] -= mu; ss = fmaf(v[i], v[i], ss); } }
+      const float rstd = rsqrtf(sum16(ss) / Dh + wa.ln_eps);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int c = p + 16 * i; if (c < Dh) xr[c] = fmaf(v[i] * rstd, gam[i], bet[i]); }
+    }
+    __syncthreads();
+    // wave -> (k tile kt = wave/2, half of the column tiles): the h_ln / v_att operand is read
+    // once per row step and feeds all of the wave's output tiles
+    if (D64 || kt < nkt) {
+#pragma unroll
+      for (int rr = 0; rr < 32; rr += 4) {
+        const float av = xs[(rr + q) * ld + kt * 16 + p];
+        const float vv = vs[(rr + q) * ld + kt * 16 + p];
+        const float* dr = dqs + (rr + q) * ld3 + p;
+        const float* dd = ds + (rr + q) * ld + p;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          if (D64 || ct0 + j < nct) accW[j] = MFMA(av, dr[(ct0 + j) * 16], accW[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (D64 || co0 + j < nkt) accO[j] = MFMA(vv, dd[(co0 + j) * 16], accO[j]);
       }
     }
   }
-  if (t < D3) part[Dh * D3 + t] = accBq;
-  else if (t >= 256 && t < 256 + Dh) {
-    part[Dh * D3 + D3 + (t - 256)] = accG;
-    part[Dh * D3 + D3 + Dh + (t - 256)] = accBt;
+  float* part = L.part + (size_t)blockIdx.x * (Dh * D3 + Dh * Dh);
+  if (kt < nkt) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int c = (ct0 + j) * 16 + p;
+      if (ct0 + j < nct) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kk = kt * 16 + 4 * q + r;
+          if (kk < Dh && c < D3) part[kk * D3 + c] = accW[j][r];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = (co0 + j) * 16 + p;
+      if (co0 + j < nkt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = kt * 16 + 4 * q + r;
+          if (i < Dh && c < Dh) part[Dh * D3 + i * Dh + c] = accO[j][r];
+        }
+      }
+    }
   }
 }
 
@@ -577,16 +673,41 @@ void egt_node_launch_post(BlockArgs& a, hipStream_t st) {
   EGT_LAUNCH("k_node_post", k_node_post, dim3(a.B * node_chunks(a)), dim3(512), lds, st, a);
 }
 
-void egt_node_launch_post_bwd(BlockArgs& a, hipStream_t st) {
-  const size_t lds = lds_rows(a.Dh, 2) + (size_t)a.Dh * (a.Dh + LDP) * 4 + (size_t)4 * NODE_RC * 8 * 4;
-  EGT_LAUNCH("k_node_post_bwd", k_node_post_bwd, dim3(a.B * node_chunks(a) + (a.prep ? 1 : 0)), dim3(512), lds, st, a);
+// dv_layer: the layer whose dense_mha is differentiated in this launch (NULL: none).  do_pre == 0
+// is the first call of a chain: the dh' rows come from a.dh_out and dv_layer must be &a.
+void egt_node_launch_bwd(BlockArgs& a, const BlockArgs* dv_layer, bool do_pre, hipStream_t st) {
+  NodeBwdArgs x{};
+  x.do_pre = do_pre ? 1 : 0;
+  x.do_dv = dv_layer ? 1 : 0;
+  if (dv_layer) {
+    x.dv_Wo = dv_layer->Wo; x.dv_v_att = dv_layer->v_att; x.dv_dh_src = a.dh_out;
+    x.dv_stats = dv_layer->stats; x.dv_dvp = dv_layer->dvp; x.dv_spart = dv_layer->spart;
+  }
+  const int Dh = a.Dh, ld = Dh + LDP, ld3 = 3 * Dh + LDP;
+  size_t lds = ((size_t)4 * NODE_RC * ld + NODE_RC + 4 * NODE_RC * 8 + (size_t)Dh * ld) * 4;
+  if (do_pre) lds += ((size_t)NODE_RC * ld3 + (size_t)Dh * ld3) * 4;
+  (void)hipFuncSetAttribute((const void*)k_node_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const bool prep = !do_pre && a.prep;
+  EGT_LAUNCH(do_pre ? "k_node_bwd" : "k_node_bwd_top", k_node_bwd, dim3(a.B * node_chunks(a) + (prep ? 1 : 0)),
+             dim3(512), lds, st, a, x);
 }
 
-void egt_node_launch_pre_bwd(BlockArgs& a, hipStream_t st) {
-  const size_t lds = lds_rows(a.Dh, 2) + ((size_t)NODE_RC * (3 * a.Dh + LDP) + NODE_RC +
-                                           (size_t)a.Dh * (3 * a.Dh + LDP)) * 4;
-  (void)hipFuncSetAttribute((const void*)k_node_pre_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  EGT_LAUNCH("k_node_pre_bwd", k_node_pre_bwd, dim3(a.B * node_chunks(a)), dim3(512), lds, st, a);
+int egt_node_wgrad_chunks(int rows) { return (rows + WG_ROWS - 1) / WG_ROWS; }
+
+// deferred GEMM-shaped weight gradients of `n` layers (n <= 64) in one launch
+void egt_node_launch_wgrads(BlockArgs* as, int n, hipStream_t st) {
+  WGradArgs wa{};
+  const BlockArgs& a0 = as[0];
+  wa.rows = a0.B * a0.N; wa.Dh = a0.Dh; wa.ln_eps = a0.ln_eps;
+  for (int l = 0; l < n; ++l) {
+    const BlockArgs& a = as[l];
+    wa.L[l] = WGradLayer{a.h, a.nm_g, a.nm_b, a.dqkv_sv, a.v_att, a.dh_out, a.wpart};
+  }
+  const int Dh = a0.Dh;
+  const size_t lds = ((size_t)3 * 32 * (Dh + 16) + (size_t)32 * (3 * Dh + 16)) * 4;
+  const dim3 grid(egt_node_wgrad_chunks(wa.rows), n);
+  if (Dh == 64) EGT_LAUNCH("k_node_wgrads", k_node_wgrads<true>, grid, dim3(512), lds, st, wa);
+  else EGT_LAUNCH("k_node_wgrads", k_node_wgrads<false>, grid, dim3(512), lds, st, wa);
 }
 
 void egt_node_launch_prep(BlockArgs* as, int n, hipStream_t st) {
@@ -601,7 +722,7 @@ void egt_node_launch_prep(BlockArgs* as, int n, hipStream_t st) {
 
 // Reduce the per-workgroup partials of `n` layers (one BlockArgs each, with their own
 // npart / epart / ered and gradient pointers) and finish the edge-parameter gradients.
-void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, int npart_stride, hipStream_t st) {
+void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, hipStream_t st) {
   for (int l0 = 0; l0 < n; l0 += 11) {
     const int nl = (n - l0 < 11) ? (n - l0) : 11;
     SumArgs s{};
@@ -613,15 +734,14 @@ void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, int npart
     };
     for (int l = l0; l < l0 + nl; ++l) {
       BlockArgs& a = as[l];
-      const int Dh = a.Dh, D3 = 3 * Dh, nnp = a.B * node_chunks(a);
-      const float* np = a.npart;
-      int o = 0;
-      seg(np + o, a.g_Wqkv, Dh * D3, nnp, npart_stride); o += Dh * D3;
-      seg(np + o, a.g_bqkv, D3, nnp, npart_stride); o += D3;
-      seg(np + o, a.g_nm_g, Dh, nnp, npart_stride); o += Dh;
-      seg(np + o, a.g_nm_b, Dh, nnp, npart_stride); o += Dh;
-      seg(np + o, a.g_Wo, Dh * Dh, nnp, npart_stride); o += Dh * Dh;
-      seg(np + o, a.g_bo, Dh, nnp, npart_stride);
+      const int Dh = a.Dh, D3 = 3 * Dh, nnp = a.B * node_chunks(a), SP = D3 + 3 * Dh;
+      const int nwc = egt_node_wgrad_chunks(a.B * a.N), WS = Dh * D3 + Dh * Dh;
+      seg(a.wpart, a.g_Wqkv, Dh * D3, nwc, WS);
+      seg(a.wpart + Dh * D3, a.g_Wo, Dh * Dh, nwc, WS);
+      seg(a.spart, a.g_bqkv, D3, nnp, SP);
+      seg(a.spart + D3, a.g_nm_g, Dh, nnp, SP);
+      seg(a.spart + D3 + Dh, a.g_nm_b, Dh, nnp, SP);
+      seg(a.spart + D3 + 2 * Dh, a.g_bo, Dh, nnp, SP);
       seg(a.epart, a.ered, EP, nwg_bwd, EP);
     }
     EGT_LAUNCH("k_sum_segments", k_sum_segments, dim3(maxblk, k), dim3(256), 0, st, s);
