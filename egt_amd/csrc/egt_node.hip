@@ -137,6 +137,72 @@ __device__ __forceinline__ void stage_rows(float* xs, int ld, const float* src, 
   }
 }
 
+// Two-phase staging for kernels with several independent inputs: issue every global load
+// first (unconditional, clamped addresses), commit to LDS afterwards, so that one memory
+// round trip covers all of them.  Unit i = threadIdx.x + u * blockDim.x is one 16-byte load.
+template <int NU>
+struct Stg { float4 v[NU]; };
+
+// Pin a staged value: the compiler may neither sink the load below this point nor reorder the
+// commits above it, so all loads issued before the first pin share one memory round trip.
+__device__ __forceinline__ void pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+template <int NU>
+__device__ __forceinline__ void stg_pin(Stg<NU>& s) {
+#pragma unroll
+  for (int u = 0; u < NU; ++u) pin4(s.v[u]);
+}
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) {   // component-wise (a float4 ternary goes through scratch)
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+// weights: `Wa` is W rounded down to 16 bytes by the host (parameter views need not be aligned;
+// the unaligned case loads harmlessly from Wa and commits with scalar copies from W)
+template <int NU>
+__device__ __forceinline__ void stg_issue_weight(Stg<NU>& s, const float* Wa, int n4) {
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int i = threadIdx.x + u * blockDim.x;
+    s.v[u] = *reinterpret_cast<const float4*>(Wa + (size_t)(i < n4 ? i : 0) * 4);
+  }
+}
+template <int NU>
+__device__ __forceinline__ void stg_commit_weight(const Stg<NU>& s, float* ws, int ldw, const float* W, bool al,
+                                                  int rows, int width) {
+  const int n4 = rows * width / 4;
+  if (al) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int i = threadIdx.x + u * blockDim.x;
+      if (i < n4) {
+        const int r = (i * 4) / width, c = (i * 4) % width;
+        *reinterpret_cast<float4*>(ws + r * ldw + c) = s.v[u];
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < rows * width; i += blockDim.x) ws[(i / width) * ldw + (i % width)] = W[i];
+  }
+}
+// rows of a [.., width] tensor: rows >= nr read row 0 and are committed as zeros (up to nrp rows)
+template <int NU>
+__device__ __forceinline__ void stg_issue_rows(Stg<NU>& s, const float* src, int width, int nr, int nrp) {
+  const int w4 = width >> 2, n4 = nrp * w4;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int i = threadIdx.x + u * blockDim.x, r = i / w4, c4 = i % w4;
+    const bool ok = i < n4 && r < nr;
+    s.v[u] = *reinterpret_cast<const float4*>(src + (ok ? (size_t)r * width + c4 * 4 : 0));
+  }
+}
+template <int NU>
+__device__ __forceinline__ void stg_commit_rows(const Stg<NU>& s, float* xs, int ld, int width, int nr, int nrp) {
+  const int w4 = width >> 2, n4 = nrp * w4;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int i = threadIdx.x + u * blockDim.x, r = i / w4, c4 = i % w4;
+    if (i < n4) *reinterpret_cast<float4*>(xs + r * ld + c4 * 4) = sel4(r < nr, s.v[u]);
+  }
+}
+
 // --------------------------------------------------------------- node: pre -----
 __global__ void __launch_bounds__(512) k_node_pre(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -243,12 +309,14 @@ __global__ void __launch_bounds__(512) k_node_post(BlockArgs a) {
 // for every layer of the stack in one launch, off the critical path.
 // small per-workgroup partials of a layer: [dbqkv 3Dh | dgamma Dh | dbeta Dh | dbo Dh]
 struct NodeBwdArgs {
-  int do_pre, do_dv;
+  const float *wq_a, *wo_a;   // Wqkv / dv_Wo rounded down to 16 bytes
+  int wq_al, wo_al;           // ... and whether they were aligned to begin with
   const float *dv_Wo, *dv_v_att, *dv_dh_src;   // dv_dh_src: rows of dh' when do_pre == 0
   float *dv_stats, *dv_dvp, *dv_spart;
 };
 
-__global__ void __launch_bounds__(512) k_node_bwd(BlockArgs a, NodeBwdArgs x) {
+template <bool PRE, bool DV, int NP>   // compile-time roles; NP: partials per gathered unit (0: run-time counts)
+__global__ void __launch_bounds__(512, 2) k_node_bwd(BlockArgs a, NodeBwdArgs x) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int NCH = (a.N + NODE_RC - 1) / NODE_RC;
   if ((int)blockIdx.x == a.B * NCH) { prep_device(a, sm); return; }
@@ -269,57 +337,94 @@ __global__ void __launch_bounds__(512) k_node_bwd(BlockArgs a, NodeBwdArgs x) {
   const size_t row0 = (size_t)b * N + r0;
   const int nkt = (Dh + 15) / 16;
 
-  if (x.do_pre) stage_weight(ws, ld3, a.Wqkv, Dh, D3);
-  if (x.do_dv) {
-    stage_weight(wo, ld, x.dv_Wo, Dh, Dh);
-    stage_rows(vs, ld, x.dv_v_att + row0 * Dh, Dh, nr, nrp);
+  // ---- every global input of the kernel in ONE memory round trip: issue, then commit ----
+  // (512 threads: Wqkv <= 6 units/thread, Wo <= 2, the 32-row tensors 1, the dQKV gather 3)
+  Stg<6> sWq;
+  Stg<2> sWo;
+  Stg<1> sV, sX;
+  float4 gq[3];
+  float dho[4], gmm[4];   // dh' and gamma of the lane's LayerNorm-backward elements: row 4*wave + q, columns p + 16 i
+  if (DV) {
+    stg_issue_weight(sWo, x.wo_a, Dh * Dh / 4);
+    stg_issue_rows(sV, x.dv_v_att + row0 * Dh, Dh, nr, nrp);
   }
-  if (x.do_pre) {
-    stage_rows(xs, ld, a.h + row0 * Dh, Dh, nr, nrp);
-    // dQKV rows: packed dq + dK/dV partials summed over the row-ranges (16-byte units)
-    const int U = nrp * 48, NT = (int)blockDim.x;
-    for (int i0 = t; i0 < U; i0 += 4 * NT) {   // up to 4 units x (NQP | NLR) 16-byte loads in flight
-      float4 v[4];
+  if (PRE) {
+    stg_issue_weight(sWq, x.wq_a, Dh * D3 / 4);
+    stg_issue_rows(sX, a.h + row0 * Dh, Dh, nr, nrp);
+    {
+      const int row = 4 * wave + q;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * NT, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
-        float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < U && r < nr) {
-          if (sx == 0) {
-#pragma unroll 4
-            for (int qp = 0; qp < a.NQP; ++qp) {
-              const float4 w = *reinterpret_cast<const float4*>(
-                  a.dqp + (((size_t)b * a.NQP + qp) * N + r0 + r) * 64 + pos4);
-              acc4.x += w.x; acc4.y += w.y; acc4.z += w.z; acc4.w += w.w;
-            }
-          } else {
-#pragma unroll 4
-            for (int lr = 0; lr < a.NLR; ++lr) {
-              const float4 w = *reinterpret_cast<const float4*>(
-                  a.dkvp + ((((size_t)b * a.NLR + lr) * N + r0 + r) * 2 + (sx - 1)) * 64 + (pos4 & 63));
-              acc4.x += w.x; acc4.y += w.y; acc4.z += w.z; acc4.w += w.w;
-            }
-          }
-        }
-        v[u] = acc4;
+      for (int i = 0; i < 4; ++i) {
+        const int c = p + 16 * i;
+        const bool ok = row < nr && c < Dh;
+        dho[i] = a.dh_out[ok ? (row0 + row) * Dh + c : row0 * Dh];
+        gmm[i] = a.nm_g[c < Dh ? c : 0];
       }
+    }
+    // dQKV rows: packed dq + dK/dV partials summed over the row-ranges (16-byte units)
+    const int U = nrp * 48;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * NT, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
-        if (i < U) {
-          const int qq = (pos4 >> 4) & 3, k0 = (pos4 >> 1) & 7;
-          float* d = dqs + r * ld3 + sx * Dh + k0 * 8 + 2 * qq;
-          if (k0 < a.DK) { d[0] = v[u].x; d[1] = v[u].y; }
-          if (k0 + 1 < a.DK) { d[8] = v[u].z; d[9] = v[u].w; }
+    for (int u = 0; u < 3; ++u) {
+      const int i = t + u * 512, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
+      const bool ok = i < U && r < nr;
+      const int rc = ok ? r : 0;
+      float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int np = sx == 0 ? a.NQP : a.NLR;
+      const float* base = sx == 0 ? a.dqp + ((size_t)b * a.NQP * N + r0 + rc) * 64 + pos4
+                                  : a.dkvp + (((size_t)b * a.NLR * N + r0 + rc) * 2 + (sx - 1)) * 64 + (pos4 & 63);
+      const size_t pstride = sx == 0 ? (size_t)N * 64 : (size_t)N * 128;
+      if (NP > 0) {   // NQP == NLR == NP: every load of the gather is issued back to back
+#pragma unroll
+        for (int pi = 0; pi < NP; ++pi) {
+          const float4 w = *reinterpret_cast<const float4*>(base + pi * pstride);
+          acc4.x += w.x; acc4.y += w.y; acc4.z += w.z; acc4.w += w.w;
         }
+      } else {
+        const int npmax = max(a.NQP, a.NLR);   // uniform trip count; lanes past their own count re-read and drop
+#pragma unroll 4
+        for (int pi = 0; pi < npmax; ++pi) {
+          const float4 w = *reinterpret_cast<const float4*>(base + min(pi, np - 1) * pstride);
+          const float f = pi < np ? 1.0f : 0.0f;
+          acc4.x = fmaf(w.x, f, acc4.x); acc4.y = fmaf(w.y, f, acc4.y);
+          acc4.z = fmaf(w.z, f, acc4.z); acc4.w = fmaf(w.w, f, acc4.w);
+        }
+      }
+      gq[u] = sel4(ok, acc4);
+    }
+  } else {
+    stg_issue_rows(sX, x.dv_dh_src + row0 * Dh, Dh, nr, nrp);
+  }
+  if (DV) { stg_pin(sWo); stg_pin(sV); }
+  stg_pin(sX);
+  if (PRE) {
+    stg_pin(sWq);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) pin4(gq[u]);
+  }
+  if (DV) {
+    stg_commit_weight(sWo, wo, ld, x.dv_Wo, x.wo_al != 0, Dh, Dh);
+    stg_commit_rows(sV, vs, ld, Dh, nr, nrp);
+  }
+  if (PRE) {
+    stg_commit_weight(sWq, ws, ld3, a.Wqkv, x.wq_al != 0, Dh, D3);
+    stg_commit_rows(sX, xs, ld, Dh, nr, nrp);
+    const int U = nrp * 48;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = t + u * 512, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
+      if (i < U) {
+        const int qq = (pos4 >> 4) & 3, k0 = (pos4 >> 1) & 7;
+        float* d = dqs + r * ld3 + sx * Dh + k0 * 8 + 2 * qq;
+        if (k0 < a.DK) { d[0] = gq[u].x; d[1] = gq[u].y; }
+        if (k0 + 1 < a.DK) { d[8] = gq[u].z; d[9] = gq[u].w; }
       }
     }
   } else {
-    stage_rows(dhs, ld, x.dv_dh_src + row0 * Dh, Dh, nr, nrp);
+    stg_commit_rows(sX, dhs, ld, Dh, nr, nrp);
   }
   __syncthreads();
 
-  if (x.do_pre) {
+  if (PRE) {
     for (int rb = wave * 4; rb < nrp; rb += 4 * NW) {  // LN forward statistics -> xhat in place
       float* xr = xs + (rb + q) * ld;
       float v[4], s1 = 0.f;
@@ -360,7 +465,7 @@ __global__ void __launch_bounds__(512) k_node_bwd(BlockArgs a, NodeBwdArgs x) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c = p + 16 * i;
-        dx[i] = c < Dh ? dl[c] * a.nm_g[c] : 0.f;
+        dx[i] = c < Dh ? dl[c] * gmm[i] : 0.f;
         m1 += dx[i];
         m2 = fmaf(dx[i], c < Dh ? xr[c] : 0.f, m2);
       }
@@ -374,7 +479,7 @@ __global__ void __launch_bounds__(512) k_node_bwd(BlockArgs a, NodeBwdArgs x) {
           float dv = 0.f;
           if (row < nr) {
             const size_t o = (row0 + row) * Dh + c;
-            dv = a.dh_out[o] + rstd * (dx[i] - m1 - xr[c] * m2);
+            dv = dho[i] + rstd * (dx[i] - m1 - xr[c] * m2);
             a.dh[o] = dv;
           }
           dhs[row * ld + c] = dv;
@@ -400,10 +505,10 @@ __global__ void __launch_bounds__(512) k_node_bwd(BlockArgs a, NodeBwdArgs x) {
       sp[D3 + c] = g0 + g1;
       sp[D3 + Dh + c] = s0 + s1;
     }
-    if (x.do_dv) __syncthreads();
+    if (DV) __syncthreads();
   }
 
-  if (x.do_dv) {
+  if (DV) {
     // dV_att = dh'.Wo^T: (row tile, i tile) pairs spread over the waves; the per-head delta
     // contributions of each i tile go through LDS and are summed in fixed order
     const int nit = nkt;
@@ -677,19 +782,28 @@ void egt_node_launch_post(BlockArgs& a, hipStream_t st) {
 // is the first call of a chain: the dh' rows come from a.dh_out and dv_layer must be &a.
 void egt_node_launch_bwd(BlockArgs& a, const BlockArgs* dv_layer, bool do_pre, hipStream_t st) {
   NodeBwdArgs x{};
-  x.do_pre = do_pre ? 1 : 0;
-  x.do_dv = dv_layer ? 1 : 0;
+  auto down16 = [](const float* p) { return reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)15); };
+  x.wq_a = down16(a.Wqkv); x.wq_al = x.wq_a == a.Wqkv;
   if (dv_layer) {
+    x.wo_a = down16(dv_layer->Wo); x.wo_al = x.wo_a == dv_layer->Wo;
     x.dv_Wo = dv_layer->Wo; x.dv_v_att = dv_layer->v_att; x.dv_dh_src = a.dh_out;
     x.dv_stats = dv_layer->stats; x.dv_dvp = dv_layer->dvp; x.dv_spart = dv_layer->spart;
   }
   const int Dh = a.Dh, ld = Dh + LDP, ld3 = 3 * Dh + LDP;
   size_t lds = ((size_t)4 * NODE_RC * ld + NODE_RC + 4 * NODE_RC * 8 + (size_t)Dh * ld) * 4;
   if (do_pre) lds += ((size_t)NODE_RC * ld3 + (size_t)Dh * ld3) * 4;
-  (void)hipFuncSetAttribute((const void*)k_node_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const bool prep = !do_pre && a.prep;
-  EGT_LAUNCH(do_pre ? "k_node_bwd" : "k_node_bwd_top", k_node_bwd, dim3(a.B * node_chunks(a) + (prep ? 1 : 0)),
-             dim3(512), lds, st, a, x);
+  const dim3 grid(a.B * node_chunks(a) + (prep ? 1 : 0));
+#define NODE_BWD(PRE_, DV_, NP_, NAME)                                                                     \
+  do {                                                                                                 \
+    (void)hipFuncSetAttribute((const void*)k_node_bwd<PRE_, DV_, NP_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    EGT_LAUNCH(NAME, (k_node_bwd<PRE_, DV_, NP_>), grid, dim3(512), lds, st, a, x);                    \
+  } while (0)
+  const bool np4 = a.NQP == 4 && a.NLR == 4;   // N = 64 with 16-row workgroups
+  if (!do_pre) NODE_BWD(false, true, 0, "k_node_bwd_top");
+  else if (dv_layer) { if (np4) NODE_BWD(true, true, 4, "k_node_bwd"); else NODE_BWD(true, true, 0, "k_node_bwd"); }
+  else { if (np4) NODE_BWD(true, false, 4, "k_node_bwd"); else NODE_BWD(true, false, 0, "k_node_bwd"); }
+#undef NODE_BWD
 }
 
 int egt_node_wgrad_chunks(int rows) { return (rows + WG_ROWS - 1) / WG_ROWS; }
