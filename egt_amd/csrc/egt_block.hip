@@ -250,7 +250,8 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
   const int p = lane & 15, q = lane >> 4;
   const int N = a.N;
   const int lgroups = (N + 15) / 16;
-  const int b = blockIdx.x / lgroups, lg = blockIdx.x % lgroups;
+  const int wg = a.xcd ? egt_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int b = wg / lgroups, lg = wg % lgroups;
   float* tl0 = sm + wave * 2 * G::TILE_FLOATS;  // two tiles per wave (ping-pong)
   float* kvs = sm + 8 * G::TILE_FLOATS;         // [N][KV_LD]   (KVL)
   float* qs = kvs + (KVL ? N * KV_LD : 0);     // [16][QS_LD]  (KVL)
@@ -1098,7 +1099,8 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 15, q = lane >> 4;
   const int N = a.N, TL = a.TL;
-  const int b = blockIdx.x / a.NLR, lr = blockIdx.x % a.NLR;
+  const int wg = a.xcd ? egt_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int b = wg / a.NLR, lr = wg % a.NLR;
   const int l_begin = lr * TL, l_end = min(N, l_begin + TL), nl = l_end - l_begin;
   const bool gated = (a.flags & EGT_BF_GATE) != 0;
   const bool clip = (a.flags & EGT_BF_CLIP) != 0;
@@ -1378,13 +1380,18 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
     for (int r = 0; r < 4; ++r) ep[G::DEP * 16 + 4 * q + r] = ssum[r];
   }
   __syncthreads();
-  float* out = a.epart + (size_t)blockIdx.x * G::EP;
+  float* out = a.epart + (size_t)wg * G::EP;
   for (int i = threadIdx.x; i < G::EP; i += 256)
     out[i] = (sm[i] + sm[G::EP + i]) + (sm[2 * G::EP + i] + sm[3 * G::EP + i]);
 }
 
 // ================================================================ host glue ====
 
+
+static bool egt_env_flag(const char* name) {
+  const char* v = getenv(name);
+  return v && v[0] && v[0] != '0';
+}
 
 static int block_check(const egt_block_desc* d, bool report) {
 #define BAD(code, ...) do { if (report) egt_set_error(__VA_ARGS__); return (code); } while (0)
@@ -1450,6 +1457,7 @@ static void bind_ws(const BlockLayout& L, BlockArgs& a, float* wc, float* wl) {
   a.pw = wl + L.pw; a.epart = wl + L.epart; a.spart = wl + L.spart; a.wpart = wl + L.wpart;
   a.ered = wl + L.ered; a.dqkv_sv = wl + L.dqkv;
   a.TL = BWD_TL; a.NLR = L.NLR; a.NQP = 1;
+  a.xcd = egt_env_flag("EGT_NO_XCD_REMAP") ? 0 : 1;
 }
 
 extern "C" size_t egt_block_saved_bytes(const egt_block_desc* d) {
@@ -1503,11 +1511,6 @@ static void bind_common(const egt_block_desc* d, BlockArgs& a, const void* h, co
   a.v_att = saved + L.v_att; a.stats = saved + L.stats; a.qkvp = saved + L.qkvp;
   bind_ws(L, a, ws, ws + L.common_total);
   a.prep = 1;
-}
-
-static bool egt_env_flag(const char* name) {
-  const char* v = getenv(name);
-  return v && v[0] && v[0] != '0';
 }
 
 #define DISPATCH_BDE(De, CALL)                        \

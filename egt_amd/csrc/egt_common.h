@@ -106,3 +106,10 @@ struct EgtProfScope {
     EgtProfScope ps__(name, stream);                                        \
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);      \
   } while (0)
+
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Remap the hardware
+// index so that CONSECUTIVE logical indices (the workgroups of one graph, which share its
+// K/V rows) land on the same XCD: logical = (hw % 8) * (n / 8) + hw / 8.
+__device__ __forceinline__ int egt_xcd_remap(int hw, int n) {
+  return (n & 7) == 0 ? (hw & 7) * (n >> 3) + (hw >> 3) : hw;
+}
