@@ -76,7 +76,9 @@ _PROTOS = {
     "egt_attn_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),
     "egt_attn_bwd": (C.c_int, [C.POINTER(AttnDesc)] + [_VP] * 16),
     "egt_attn_mfma_supported": (C.c_int, [C.POINTER(AttnDesc), C.c_int]),
-    "egt_attn_mfma_fwd": (C.c_int, [C.POINTER(AttnDesc)] + [_VP] * 10),
+    "egt_attn_mfma_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),
+    "egt_attn_mfma_workspace_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),
+    "egt_attn_mfma_fwd": (C.c_int, [C.POINTER(AttnDesc)] + [_VP] * 11),
     "egt_attn_mfma_bwd": (C.c_int, [C.POINTER(AttnDesc)] + [_VP] * 15),
     "egt_mask_sample": (C.c_int, [C.c_int, C.c_uint64, C.c_float, C.c_int32, C.c_int32,
                                   C.c_int32, _VP, _VP]),

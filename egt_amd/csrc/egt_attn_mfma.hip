@@ -1,29 +1,39 @@
-// Inner op, MFMA-tiled (flash-style) for the large-head geometry (d % 16 == 0, H = 8):
+// Inner op, MFMA-tiled (flash-style) for the large-head geometry (d in {16,32,64}, H = 8):
 //   (V_att, H_hat) = EGT([QKV, E?, G?, M?], mask)     lib/models/egt_layers.py:57-213
-// This is the shape where QK^T / A.V dominate (BASELINE config 5: N=512, d=64: fp32
-// arithmetic intensity above the ridge), so both contractions run on
-// v_mfma_f32_16x16x4_f32 and the N x N probabilities never exist outside registers.
+// and its backward (SURVEY.md appendix A / egt_layers.py semantics under autodiff).
+// This is the shape where QK^T / A.V dominate (BASELINE config 5: N=512, d=64: fp32 arithmetic
+// intensity at the ridge), so every contraction runs on v_mfma_f32_16x16x4_f32 and the N x N
+// probabilities never exist outside registers.
 //
-// Workgroup = (graph b, 16 query rows); wave w owns heads 2w, 2w+1.  Per 16-key tile:
-//   K/V rows are staged head-major in LDS ([h][m][k], padded), E/G/(M) tiles are copied
-//   coalesced; S^T = K.Q^T is computed with the key index on the MFMA row axis so that a lane
-//   holds one query row l = lane&15 and four keys m = 4q+r: the softmax reductions over keys
-//   are 3 in-lane ops + two permlane swaps, the online-softmax rescale factor is lane-uniform,
-//   and the gated probabilities feed the A.V MFMA as its B operand WITHOUT any data movement
-//   (O^T[k][l] += V^T[k][m] . P^T[m][l], contraction order m = 4q + t).
-//   H_hat leaves through an LDS tile as whole 512-byte rows.
-// Attributes outside this kernel's cover (dropout, degree scalers, A_tild output, H != 8,
-// d % 16 != 0) use the general kernels of egt_attn.hip.
+// Layout decision: a pack kernel first rewrites Q/K/V (and dV_att) head-major, both row-major
+// [B,H,NP,d] and transposed [B,H,d,NP] (NP = N rounded up to 16, zero padded).  With that,
+// EVERY MFMA operand that comes from Q/K/V/dO is one aligned 16-byte global load per four
+// contraction steps, straight into the lane that feeds the matrix core:
+//   operand "rows x contraction":  lane (row = lane&15, q = lane>>4) holds X[row][16T + 4q + u]
+//   (the contraction order kappa(T,u,q) = 16T + 4q + u is used on both operands, so it is free).
+// There is no LDS staging, no block barrier and no cross-wave dependency anywhere: a wave owns
+// one head, a workgroup (8 waves = 8 heads) one 16-row tile; the eight waves touch the same
+// 32-byte sectors of the [N,N,8] pair tensors, which the CU's vector L1 merges.
+// The pair-tensor elements of a lane sit in the MFMA accumulator layout (row = 4q + r), which is
+// exactly what the second contraction of each phase needs as its B operand: probabilities never
+// move between lanes.  Softmax reductions over the key axis are 3 in-lane ops + two permlane
+// swaps.
+// Attributes outside this cover (dropout, degree scalers, A_tild output, H != 8, other d) use
+// the general kernels of egt_attn.hip.
+#include <stdlib.h>
+
 #include "egt_common.h"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 #define AH 8
-#define PT_LD 132  // pair-tile row stride: [16 l][16 m][8 h] + 4 floats of padding per l
+
+// packed operand arrays, each B*H*NP*d floats, in this order inside the workspace
+enum { PK_KH = 0, PK_VT, PK_QH, PK_QT, PK_KT, PK_VH, PK_OH, PK_OT, PK_COUNT };
 
 struct AttnMfmaArgs {
-  int B, N, d;
+  int B, N, NP, d;
   uint32_t flags;
   float clip_lo, clip_hi, scale;
   uint32_t rm_thr, s0, s1;
@@ -31,6 +41,11 @@ struct AttnMfmaArgs {
   const float *qkv, *E, *G, *M;
   const uint8_t *km, *rm;
   float *v_att, *h_hat, *rowstats;
+  float* pk;   // packed arrays
+  // backward
+  const float *v_att_in, *d_v_att, *d_h_ext;
+  float *d_qkv, *d_E, *d_G, *ws_dA;
+  int pack_bwd;
 };
 
 __device__ __forceinline__ float pair_max_q(float v) {   // max over lanes l, l+16, l+32, l+48
@@ -41,453 +56,523 @@ __device__ __forceinline__ float pair_max_q(float v) {   // max over lanes l, l+
 }
 __device__ __forceinline__ float pair_sum_q(float v) { return sum_xor32(sum_xor16(v)); }
 
+// ------------------------------------------------------------------- pack --------
+// workgroup = (graph, 16 node rows): the rows' QKV (and dV_att) channels go through an LDS tile
+// and leave head-major.  Channel index of the source: c = s*d*H + k*H + h (egt_layers.py:70-76).
 template <int D>
-__global__ void __launch_bounds__(256, 1) k_attn_mfma_fwd(AttnMfmaArgs a) {
-  constexpr int KT = D / 16;        // 16-wide k tiles
-  constexpr int KLD = D + 4;        // padded k stride of the staged K/V rows
-  constexpr int DH = D * AH;
+__global__ void __launch_bounds__(256) k_attn_pack(AttnMfmaArgs a) {
+  constexpr int DH = D * AH, SRC = 4 * DH, LD = SRC + 4;   // [q | k | v | dO] per row
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* Ks = sm;                          // [8][16][KLD]
-  float* Vs = Ks + AH * 16 * KLD;          // [8][16][KLD]
-  float* Et = Vs + AH * 16 * KLD;          // [16][PT_LD]
-  float* Gt = Et + 16 * PT_LD;
-  float* Mt = Gt + 16 * PT_LD;
-  float* Ht = Mt + 16 * PT_LD;             // H_hat out
-  float* kmadd = Ht + 16 * PT_LD;          // [16]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N, NP = a.NP, tid = threadIdx.x;
+  const int tiles = NP / 16;
+  const int b = blockIdx.x / tiles, n0 = (blockIdx.x % tiles) * 16;
+  const bool bwd = a.pack_bwd != 0;
+  for (int i = tid; i < 16 * (SRC / 4); i += 256) {
+    const int r = i / (SRC / 4), c = (i % (SRC / 4)) * 4;
+    const int n = n0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) {
+      if (c < 3 * DH) v = *reinterpret_cast<const float4*>(a.qkv + ((size_t)b * N + n) * 3 * DH + c);
+      else if (bwd) v = *reinterpret_cast<const float4*>(a.d_v_att + ((size_t)b * N + n) * DH + (c - 3 * DH));
+    }
+    *reinterpret_cast<float4*>(sm + r * LD + c) = v;
+  }
+  __syncthreads();
+  const size_t arr = (size_t)a.B * AH * NP * D;
+  // section s of the source rows -> row-major [b,h,n,k] array `which`
+#define PUT_ROWS(s, which)                                                                       \
+  do {                                                                                           \
+    float* dst = a.pk + (size_t)(which) * arr;                                                   \
+    for (int i = tid; i < AH * 16 * (D / 4); i += 256) {                                         \
+      const int k4 = i % (D / 4), r = (i / (D / 4)) % 16, h = i / (16 * (D / 4));                \
+      const float* src = sm + r * LD + (s) * DH + (k4 * 4) * AH + h;                             \
+      *reinterpret_cast<float4*>(dst + (((size_t)b * AH + h) * NP + n0 + r) * D + k4 * 4) =      \
+          make_float4(src[0], src[AH], src[2 * AH], src[3 * AH]);                                \
+    }                                                                                            \
+  } while (0)
+  // ... -> transposed [b,h,k,n] array
+#define PUT_COLS(s, which)                                                                       \
+  do {                                                                                           \
+    float* dst = a.pk + (size_t)(which) * arr;                                                   \
+    for (int i = tid; i < AH * D * 4; i += 256) {                                                \
+      const int r4 = i & 3, k = (i >> 2) % D, h = i / (4 * D);                                   \
+      const float* src = sm + (r4 * 4) * LD + (s) * DH + k * AH + h;                             \
+      *reinterpret_cast<float4*>(dst + (((size_t)b * AH + h) * D + k) * NP + n0 + r4 * 4) =      \
+          make_float4(src[0], src[LD], src[2 * LD], src[3 * LD]);                                \
+    }                                                                                            \
+  } while (0)
+  PUT_ROWS(1, PK_KH);
+  PUT_COLS(2, PK_VT);
+  if (bwd) {
+    PUT_ROWS(0, PK_QH); PUT_COLS(0, PK_QT); PUT_COLS(1, PK_KT);
+    PUT_ROWS(2, PK_VH); PUT_ROWS(3, PK_OH); PUT_COLS(3, PK_OT);
+  }
+#undef PUT_ROWS
+#undef PUT_COLS
+}
+
+// Feature set of a kernel instance.  V = 0 reads every switch at run time (any combination);
+// V = 1 / 2 are the straight-line instances of the main configuration (edge bias + gates + key
+// padding + clip, no attention-mask tensor, no injected mask bytes; 2 = in-kernel random mask):
+// without the per-feature branches the compiler interleaves the MFMAs with the VALU work.
+template <int V>
+struct Feat {
+  bool E, G, M, km, clip, rmb, rng, X;
+  __device__ __forceinline__ Feat(const AttnMfmaArgs& a) {
+    E = V ? true : a.E != nullptr;
+    G = V ? true : (a.flags & EGT_F_GATE_INPUT) != 0;
+    M = V ? false : a.M != nullptr;
+    km = V ? true : a.km != nullptr;
+    clip = V ? true : (a.flags & EGT_F_CLIP) != 0;
+    rmb = V ? false : a.rm != nullptr;
+    rng = V == 2 ? true : (V == 1 ? false : a.rng_rm != 0);
+    X = V ? true : a.d_h_ext != nullptr;
+  }
+};
+
+// additive masks of one element, in the reference's order (egt_layers.py:91-108)
+template <int V>
+__device__ __forceinline__ float mask_add(const AttnMfmaArgs& a, const Feat<V>& f, float kadd, float mval, size_t gi) {
+  float add = 0.f;
+  if (f.km) add += kadd;
+  if (f.M) add += (mval - 1.0f) * EGT_NEG;
+  if (f.rmb || f.rng) {
+    const bool hit = f.rmb ? (a.rm[gi] != 0) : ((egt_hash32((uint32_t)gi, a.s0, a.s1) >> 8) < a.rm_thr);
+    add += hit ? -EGT_NEG : 0.0f;
+  }
+  return add;
+}
+
+// ---- cooperative pair-tile transfers: a [16 rows][16 cols x 8 heads] tile of a [B,N,N,8]
+// tensor is 16 contiguous 512-byte runs; the workgroup's 512 threads move it with one 16-byte
+// access each (thread -> row tid>>5, floats 4*(tid&31)...), through an LDS tile of row stride
+// PT_LD.  Rows / columns past N read a valid address and are zeroed (component-wise selects).
+#define PT_LD 132
+#define PT_SZ (16 * PT_LD)
+
+__device__ __forceinline__ float4 ptile_gload(const float* src, int b, int N, int row0, int col0, int tid) {
+  const int row = tid >> 5, c4 = (tid & 31) * 4;
+  const int rr = min(row0 + row, N - 1), cc = min(col0 + (c4 >> 3), N - 1);
+  return *reinterpret_cast<const float4*>(src + (((size_t)b * N + rr) * N + cc) * AH + (c4 & 7));
+}
+__device__ __forceinline__ void ptile_lds_put(float* tl, float4 v, int N, int row0, int col0, int tid) {
+  const int row = tid >> 5, c4 = (tid & 31) * 4;
+  const bool ok = row0 + row < N && col0 + (c4 >> 3) < N;
+  *reinterpret_cast<float4*>(tl + row * PT_LD + c4) =
+      make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+__device__ __forceinline__ void ptile_gstore(float* dst, const float* tl, int b, int N, int row0, int col0, int tid) {
+  const int row = tid >> 5, c4 = (tid & 31) * 4;
+  if (row0 + row < N && col0 + (c4 >> 3) < N)
+    *reinterpret_cast<float4*>(dst + (((size_t)b * N + row0 + row) * N + col0 + (c4 >> 3)) * AH + (c4 & 7)) =
+        *reinterpret_cast<const float4*>(tl + row * PT_LD + c4);
+}
+
+// key-mask bytes of keys m .. m+3 (clamped).  Kept as four separate registers: packing them
+// would consume the loads at once, and a wait on these (the youngest loads of the prefetch
+// group) would drain the whole group.
+struct Km4 { uint32_t v[4]; };
+__device__ __forceinline__ Km4 km_load4(const uint8_t* km, int N, int m) {
+  Km4 k;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) k.v[r] = km[min(m + r, N - 1)];
+  return k;
+}
+
+// ================================================================== forward =====
+// workgroup = (graph b, 16 query rows), wave = head.  Lane (ll = lane&15, q = lane>>4) owns
+// query row l0 + ll and, in every key tile, keys m0 + 4q + r.  K / V^T operands come straight
+// from the packed arrays (register prefetch one tile ahead); the E / G / M tiles are fetched
+// coalesced by the whole workgroup one tile ahead into double-buffered LDS tiles, H_hat leaves
+// through one: ONE barrier per key tile.
+template <int D, int V>
+__global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
+  constexpr int KT = D / 16, DH = D * AH;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* In = sm;                    // [2][E | G | M][PT_SZ]
+  float* Hout = sm + 2 * 3 * PT_SZ;  // [2][PT_SZ]
+  const int tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ll = lane & 15, q = lane >> 4;
-  const int N = a.N;
-  const int ltiles = (N + 15) / 16;
-  const int b = blockIdx.x / ltiles, l0 = (blockIdx.x % ltiles) * 16;
+  const int N = a.N, NP = a.NP;
+  const int ltiles = NP / 16;
+  const int wg = egt_xcd_remap(blockIdx.x, gridDim.x);   // a graph's K / V^T stay within one XCD's L2
+  const int b = wg / ltiles, l0 = (wg % ltiles) * 16;
   const int l = l0 + ll, lc = min(l, N - 1);
-  const bool gated = (a.flags & EGT_F_GATE_INPUT) != 0;
-  const bool clip = (a.flags & EGT_F_CLIP) != 0;
+  const Feat<V> f(a);
+  const bool gated = f.G, clip = f.clip;
+  const size_t arr = (size_t)a.B * AH * NP * D;
+  const float* Kh = a.pk + PK_KH * arr + ((size_t)b * AH + h) * NP * D;   // [NP][D]
+  const float* VT = a.pk + PK_VT * arr + ((size_t)b * AH + h) * D * NP;   // [D][NP]
 
-  // Q fragments (B operand of S^T = K.Q^T): lane (l, q) holds Q[l][16T + 4q + u] of its two heads
-  float Qr[2][4 * KT];
+  // Q fragments (B operand of S^T = K.Q^T): Q[l][16T + 4q + u]
+  float Qr[4 * KT];
   {
-    const float* qrow = a.qkv + ((size_t)b * N + lc) * 3 * DH;
+    const float* qrow = a.qkv + ((size_t)b * N + lc) * 3 * DH + h;
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-      for (int t = 0; t < 4 * KT; ++t) {
-        const int k = 16 * (t >> 2) + 4 * q + (t & 3);
-        Qr[hh][t] = qrow[k * AH + 2 * wave + hh];
-      }
+    for (int t = 0; t < 4 * KT; ++t) Qr[t] = qrow[(16 * (t >> 2) + 4 * q + (t & 3)) * AH];
   }
-  v4f oacc[2][KT];
-  float mrun[2], lrun[2];
+  v4f oacc[KT];
 #pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    mrun[hh] = -3.0e38f; lrun[hh] = 0.f;
+  for (int kt = 0; kt < KT; ++kt) oacc[kt] = (v4f){0.f, 0.f, 0.f, 0.f};
+  float mrun = -3.0e38f, lrun = 0.f;
+
+  float4 kc[KT], vc[KT], kn[KT], vn[KT];   // current / next key tile operands
+  float4 pe4 = make_float4(0.f, 0.f, 0.f, 0.f), pg4 = pe4, pm4 = pe4;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) oacc[hh][kt] = (v4f){0.f, 0.f, 0.f, 0.f};
+  for (int T = 0; T < KT; ++T) {
+    kc[T] = *reinterpret_cast<const float4*>(Kh + (size_t)ll * D + 16 * T + 4 * q);
+    vc[T] = *reinterpret_cast<const float4*>(VT + (size_t)(16 * T + ll) * NP + 4 * q);
+    kn[T] = kc[T]; vn[T] = vc[T];
   }
+  Km4 kmc{{1u, 1u, 1u, 1u}};
+  if (f.km) kmc = km_load4(a.km + (size_t)b * N, N, 4 * q);
+  Km4 kmn = kmc;
+  if (f.E) ptile_lds_put(In + 0 * PT_SZ, ptile_gload(a.E, b, N, l0, 0, tid), N, l0, 0, tid);
+  if (f.G) ptile_lds_put(In + 1 * PT_SZ, ptile_gload(a.G, b, N, l0, 0, tid), N, l0, 0, tid);
+  if (f.M) ptile_lds_put(In + 2 * PT_SZ, ptile_gload(a.M, b, N, l0, 0, tid), N, l0, 0, tid);
+  __syncthreads();
 
-  for (int m0 = 0; m0 < N; m0 += 16) {
-    __syncthreads();
-    // ---- stage K, V rows m0..m0+15 head-major; E/G/M tiles as whole rows ----
-    for (int idx = tid; idx < 16 * (DH / 4); idx += 256) {
-      const int row = idx / (DH / 4), c = (idx % (DH / 4)) * 4;   // channel c = k*8 + h
-      const int m = m0 + row;
-      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-      if (m < N) {
-        const float* src = a.qkv + ((size_t)b * N + m) * 3 * DH + DH + c;
-        kv = *reinterpret_cast<const float4*>(src);
-        vv = *reinterpret_cast<const float4*>(src + DH);
-      }
-      const int k = c >> 3, h = c & 7;
-      float* kd = Ks + (h * 16 + row) * KLD + k;
-      float* vd = Vs + (h * 16 + row) * KLD + k;
-      kd[0] = kv.x; kd[16 * KLD] = kv.y; kd[32 * KLD] = kv.z; kd[48 * KLD] = kv.w;
-      vd[0] = vv.x; vd[16 * KLD] = vv.y; vd[32 * KLD] = vv.z; vd[48 * KLD] = vv.w;
-    }
-    for (int idx = tid; idx < 16 * 32; idx += 256) {
-      const int row = idx >> 5, c4 = (idx & 31) * 4;     // row l0+row, 128 floats = [16 m][8 h]
-      const int lr = min(l0 + row, N - 1);
-      const int m = m0 + (c4 >> 3);
-      const size_t g = (((size_t)b * N + lr) * N + m0) * AH + c4;
-      const bool ok = m < N;
-      float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.E) *reinterpret_cast<float4*>(Et + row * PT_LD + c4) = ok ? *reinterpret_cast<const float4*>(a.E + g) : z;
-      if (a.G) *reinterpret_cast<float4*>(Gt + row * PT_LD + c4) = ok ? *reinterpret_cast<const float4*>(a.G + g) : z;
-      if (a.M) *reinterpret_cast<float4*>(Mt + row * PT_LD + c4) = ok ? *reinterpret_cast<const float4*>(a.M + g) : z;
-    }
-    if (tid < 16) {
-      const int m = m0 + tid;
-      kmadd[tid] = (a.km && m < N && a.km[(size_t)b * N + m] == 0) ? -EGT_NEG : 0.0f;
-    }
-    __syncthreads();
-
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int h = 2 * wave + hh;
-      // ---- S^T[m][l] = sum_k K[m][k] Q[l][k]  (A = K rows, B = Q fragments) ----
-      v4f s = {0.f, 0.f, 0.f, 0.f};
-      const float* krow = Ks + (h * 16 + ll) * KLD + 4 * q;
+  for (int m0 = 0, it = 0; m0 < NP; m0 += 16, ++it) {
+    const bool more = m0 + 16 < NP;
+    if (more) {   // next tile's loads fly during this tile's arithmetic
 #pragma unroll
       for (int T = 0; T < KT; ++T) {
-        const float4 ka = *reinterpret_cast<const float4*>(krow + 16 * T);
-        s = MFMA(ka.x, Qr[hh][4 * T + 0], s);
-        s = MFMA(ka.y, Qr[hh][4 * T + 1], s);
-        s = MFMA(ka.z, Qr[hh][4 * T + 2], s);
-        s = MFMA(ka.w, Qr[hh][4 * T + 3], s);
+        kn[T] = *reinterpret_cast<const float4*>(Kh + (size_t)(m0 + 16 + ll) * D + 16 * T + 4 * q);
+        vn[T] = *reinterpret_cast<const float4*>(VT + (size_t)(16 * T + ll) * NP + m0 + 16 + 4 * q);
       }
-      // lane (l = ll, q): keys m = m0 + 4q + r
-      float x[4], pa[4];
-      float tmax = -3.0e38f;
+      if (f.E) pe4 = ptile_gload(a.E, b, N, l0, m0 + 16, tid);
+      if (f.G) pg4 = ptile_gload(a.G, b, N, l0, m0 + 16, tid);
+      if (f.M) pm4 = ptile_gload(a.M, b, N, l0, m0 + 16, tid);
+      if (f.km) kmn = km_load4(a.km + (size_t)b * N, N, m0 + 16 + 4 * q);
+    }
+    const float* Et = In + (it & 1) * 3 * PT_SZ;
+    const float* Gt = Et + PT_SZ;
+    const float* Mt = Gt + PT_SZ;
+    float* Ht = Hout + (it & 1) * PT_SZ;
+    // ---- S^T[m][l] = sum_k K[m][k] Q[l][k] ----
+    v4f s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int mi = 4 * q + r, m = m0 + mi;
-        const bool valid = m < N;
-        float ah = s[r] * a.scale;
-        if (clip) ah = fminf(fmaxf(ah, a.clip_lo), a.clip_hi);
-        const int po = ll * PT_LD + mi * AH + h;
-        float hv = ah;
-        if (a.E) hv += Et[po];
-        Ht[po] = hv;                                         // H_hat: post-clip, pre-mask (egt_layers.py:85-86)
-        float xv = hv, gv = gated ? Gt[po] : 0.f;
-        if (a.km) { xv += kmadd[mi]; gv += kmadd[mi]; }
-        if (a.M) { const float mm = (Mt[po] - 1.0f) * EGT_NEG; xv += mm; gv += mm; }
-        if (a.rm || a.rng_rm) {
-          const size_t gi = (((size_t)b * N + lc) * N + (valid ? m : 0)) * AH + h;
-          const bool hit = a.rm ? (a.rm[gi] != 0) : ((egt_hash32((uint32_t)gi, a.s0, a.s1) >> 8) < a.rm_thr);
-          const float mr = hit ? -EGT_NEG : 0.0f;
-          xv += mr; gv += mr;
-        }
-        x[r] = valid ? xv : -3.0e38f;
-        pa[r] = gated ? egt_sigmoid(gv) : 1.0f;            // gate (multiplied into p below)
-        tmax = fmaxf(tmax, x[r]);
-      }
-      // ---- online softmax over the key axis: in-lane over r, then across q ----
-      tmax = pair_max_q(tmax);
-      const float mnew = fmaxf(mrun[hh], tmax);
-      const float alpha = __expf(mrun[hh] - mnew);
-      float psum = 0.f;
+    for (int T = 0; T < KT; ++T) {
+      s = MFMA(kc[T].x, Qr[4 * T + 0], s);
+      s = MFMA(kc[T].y, Qr[4 * T + 1], s);
+      s = MFMA(kc[T].z, Qr[4 * T + 2], s);
+      s = MFMA(kc[T].w, Qr[4 * T + 3], s);
+    }
+    float x[4], pa[4];
+    float tmax = -3.0e38f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pe = (x[r] > -2.9e38f) ? __expf(x[r] - mnew) : 0.f;
-        psum += pe;
-        pa[r] *= pe;
-      }
-      psum = pair_sum_q(psum);
-      lrun[hh] = fmaf(lrun[hh], alpha, psum);
-      mrun[hh] = mnew;
-      // ---- O^T[k][l] = alpha * O^T + sum_m V[m][k] * P[l][m]  (contraction order m = 4q + t) ----
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 4 * q + r;
+      const bool valid = m < N;
+      float ah = s[r] * a.scale;
+      if (clip) ah = fminf(fmaxf(ah, a.clip_lo), a.clip_hi);
+      const int po = ll * PT_LD + (4 * q + r) * AH + h;
+      const size_t gi = (((size_t)b * N + lc) * N + min(m, N - 1)) * AH + h;
+      const float hv = ah + (f.E ? Et[po] : 0.f);
+      Ht[po] = hv;                                         // H_hat: post-clip, pre-mask (egt_layers.py:85-86)
+      const float kadd = kmc.v[r] ? 0.0f : -EGT_NEG;
+      const float add = mask_add(a, f, kadd, f.M ? Mt[po] : 1.f, gi);
+      x[r] = valid ? hv + add : -3.0e38f;
+      pa[r] = gated ? egt_sigmoid(Gt[po] + add) : 1.0f;    // gate (multiplied into p below)
+      tmax = fmaxf(tmax, x[r]);
+    }
+    // ---- online softmax over the key axis: in-lane over r, then across q ----
+    tmax = pair_max_q(tmax);
+    const float mnew = fmaxf(mrun, tmax);
+    const float alpha = __expf(mrun - mnew);
+    float psum = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        v4f o = oacc[hh][kt];
-        o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
-        const float* vcol = Vs + (h * 16 + 4 * q) * KLD + 16 * kt + ll;
-        o = MFMA(vcol[0], pa[0], o);
-        o = MFMA(vcol[KLD], pa[1], o);
-        o = MFMA(vcol[2 * KLD], pa[2], o);
-        o = MFMA(vcol[3 * KLD], pa[3], o);
-        oacc[hh][kt] = o;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const float pe = (x[r] > -2.9e38f) ? __expf(x[r] - mnew) : 0.f;
+      psum += pe;
+      pa[r] *= pe;
+    }
+    psum = pair_sum_q(psum);
+    lrun = fmaf(lrun, alpha, psum);
+    mrun = mnew;
+    // ---- O^T[k][l] = alpha * O^T + sum_m V^T[k][m] P^T[m][l]  (contraction order m = 4q + t) ----
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      v4f o = oacc[kt];
+      o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+      o = MFMA(vc[kt].x, pa[0], o);
+      o = MFMA(vc[kt].y, pa[1], o);
+      o = MFMA(vc[kt].z, pa[2], o);
+      o = MFMA(vc[kt].w, pa[3], o);
+      oacc[kt] = o;
+    }
+    if (more) {
+      float* nx = In + ((it + 1) & 1) * 3 * PT_SZ;
+      if (f.E) ptile_lds_put(nx, pe4, N, l0, m0 + 16, tid);
+      if (f.G) ptile_lds_put(nx + PT_SZ, pg4, N, l0, m0 + 16, tid);
+      if (f.M) ptile_lds_put(nx + 2 * PT_SZ, pm4, N, l0, m0 + 16, tid);
     }
     __syncthreads();
-    // ---- H_hat tile out: 16 rows of 16*8 floats ----
-    for (int idx = tid; idx < 16 * 32; idx += 256) {
-      const int row = idx >> 5, c4 = (idx & 31) * 4;
-      const int lr = l0 + row, m = m0 + (c4 >> 3);
-      if (lr < N && m < N)
-        *reinterpret_cast<float4*>(a.h_hat + (((size_t)b * N + lr) * N + m0) * AH + c4) =
-            *reinterpret_cast<const float4*>(Ht + row * PT_LD + c4);
-    }
+    ptile_gstore(a.h_hat, Ht, b, N, l0, m0, tid);   // whole 512-byte runs
+#pragma unroll
+    for (int T = 0; T < KT; ++T) { kc[T] = kn[T]; vc[T] = vn[T]; }
+    kmc = kmn;
   }
   // ---- finalize: V_att[l][k*8+h] = O[l][k] / l_run ; row statistics for the backward ----
   if (l < N) {
+    const float inv = 1.0f / lrun;
+    float* vo = a.v_att + ((size_t)b * N + l) * DH + h;
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int h = 2 * wave + hh;
-      const float inv = 1.0f / lrun[hh];
-      float* vo = a.v_att + ((size_t)b * N + l) * DH;
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vo[(16 * kt + 4 * q + r) * AH + h] = oacc[hh][kt][r] * inv;
-      if (q == 0) {
-        float* rs = a.rowstats + (((size_t)b * N + l) * AH + h) * 4;
-        rs[0] = mrun[hh]; rs[1] = lrun[hh]; rs[2] = 0.f; rs[3] = 0.f;
-      }
+      for (int r = 0; r < 4; ++r) vo[(16 * kt + 4 * q + r) * AH] = oacc[kt][r] * inv;
+    if (q == 0) {
+      float* rs = a.rowstats + (((size_t)b * N + l) * AH + h) * 4;
+      rs[0] = mrun; rs[1] = lrun; rs[2] = 0.f; rs[3] = 0.f;
     }
   }
 }
-
 
 // ================================================================= backward =====
-// Three launches (flash-attention style, the [N,N,H] probabilities are recomputed):
-//   k_attn_mfma_delta : delta[l,h] = sum_k dO[l,k,h] * O[l,k,h]            -> rowstats[...][3]
-//   k_attn_mfma_bwd_kv: workgroup = (graph, 16-key tile), walks the query tiles; K/V fragments of
-//                       the key tile live in registers; per tile S = Q.K^T and dP = dO.V^T on
-//                       MFMA, softmax/gate/clip backward on the VALU, then dV^T += dO^T.A and
-//                       dK^T += Q^T.dA on MFMA with the probabilities as B operands in place;
-//                       writes dE, dG (through an LDS tile, whole rows) and dA = dH*c*scale
-//   k_attn_mfma_bwd_q : workgroup = (graph, 16 query rows), walks the key tiles:
-//                       dQ^T += K^T.dA^T on MFMA from the dA tensor
-struct AttnMfmaBwdArgs {
-  AttnMfmaArgs f;
-  const float *v_att, *rowstats_in, *d_v_att, *d_h_ext;
-  float *rowstats_rw, *d_qkv, *d_E, *d_G, *ws_dA;
-};
-
-__global__ void __launch_bounds__(256) k_attn_mfma_delta(AttnMfmaBwdArgs a) {
-  const int d = a.f.d, DH = d * AH;
+// Launches (flash-attention style, the [N,N,H] probabilities are recomputed):
+//   k_attn_pack        : head-major operand arrays of Q, K, V, dV_att
+//   k_attn_mfma_delta  : delta[l,h] = sum_k dO[l,k,h] * O[l,k,h]            -> rowstats[...][3]
+//   k_attn_mfma_bwd_kv : workgroup = (graph, 16-key tile), wave = head, walks the query tiles;
+//                        K/V fragments of the key tile live in registers; per tile S = Q.K^T and
+//                        dP = dO.V^T on MFMA, softmax/gate/clip backward on the VALU, then
+//                        dV^T += dO^T.A and dK^T += Q^T.dA on MFMA with the probabilities as B
+//                        operands in place; writes dE, dG and dA = dH*c*scale
+//   k_attn_mfma_bwd_q  : workgroup = (graph, 16 query rows), wave = head, walks the key tiles:
+//                        dQ^T += K^T.dA^T on MFMA from the dA tensor
+__global__ void __launch_bounds__(256) k_attn_mfma_delta(AttnMfmaArgs a) {
+  const int d = a.d, DH = d * AH;
   const long row = (long)blockIdx.x * 32 + (threadIdx.x >> 3);   // 8 threads (heads) per row
   const int h = threadIdx.x & 7;
-  if (row >= (long)a.f.B * a.f.N) return;
+  if (row >= (long)a.B * a.N) return;
   const float* dv = a.d_v_att + row * DH + h;
-  const float* vo = a.v_att + row * DH + h;
+  const float* vo = a.v_att_in + row * DH + h;
   float s = 0.f;
   for (int k = 0; k < d; ++k) s = fmaf(dv[k * AH], vo[k * AH], s);
-  a.rowstats_rw[(row * AH + h) * 4 + 3] = s;
+  a.rowstats[(row * AH + h) * 4 + 3] = s;
 }
 
-template <int D>
-__global__ void __launch_bounds__(256, 1) k_attn_mfma_bwd_kv(AttnMfmaBwdArgs a) {
-  constexpr int KT = D / 16, KLD = D + 4, DH = D * AH;
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* Qs = sm;                          // [8][16][KLD]   Q rows of the query tile, head-major
-  float* Os = Qs + AH * 16 * KLD;          // [8][16][KLD]   dO rows
-  float* Et = Os + AH * 16 * KLD;          // [16 l][PT_LD]
-  float* Gt = Et + 16 * PT_LD;
-  float* Mt = Gt + 16 * PT_LD;
-  float* Xt = Mt + 16 * PT_LD;             // d_h_ext in
-  float* dEt = Xt + 16 * PT_LD;            // dE out
-  float* dGt = dEt + 16 * PT_LD;           // dG out
-  float* dAt = dGt + 16 * PT_LD;           // dA out
-  float* st = dAt + 16 * PT_LD;            // [16 l][8 h][4]
-  const AttnMfmaArgs& f = a.f;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Lane (mm = lane&15, q): key m0 + mm; in every query tile rows l0 + 4q + r.
+template <int D, int V>
+__global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
+  constexpr int KT = D / 16, DH = D * AH;
+  const int lane = threadIdx.x & 63, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int mm = lane & 15, q = lane >> 4;
-  const int N = f.N;
-  const int mtiles = (N + 15) / 16;
-  const int b = blockIdx.x / mtiles, m0 = (blockIdx.x % mtiles) * 16;
+  const int N = a.N, NP = a.NP;
+  const int mtiles = NP / 16;
+  const int wg = egt_xcd_remap(blockIdx.x, gridDim.x);
+  const int b = wg / mtiles, m0 = (wg % mtiles) * 16;
   const int m = m0 + mm, mc = min(m, N - 1);
   const bool mvalid = m < N;
-  const bool gated = (f.flags & EGT_F_GATE_INPUT) != 0;
-  const bool clip = (f.flags & EGT_F_CLIP) != 0;
+  const Feat<V> f(a);
+  const bool gated = f.G, clip = f.clip;
+  const size_t arr = (size_t)a.B * AH * NP * D;
+  const size_t hb = ((size_t)b * AH + h) * NP * D;
+  const float* Kh = a.pk + PK_KH * arr + hb;
+  const float* Vh = a.pk + PK_VH * arr + hb;
+  const float* Qh = a.pk + PK_QH * arr + hb;
+  const float* Oh = a.pk + PK_OH * arr + hb;
+  const float* QT = a.pk + PK_QT * arr + hb;
+  const float* OT = a.pk + PK_OT * arr + hb;
 
-  // K / V fragments of this lane's key (B operands of S = Q.K^T and dP = dO.V^T)
-  float Kr[2][4 * KT], Vr[2][4 * KT];
-  {
-    const float* krow = f.qkv + ((size_t)b * N + mc) * 3 * DH + DH;
+  // K / V fragments of this lane's key (B operands of S = Q.K^T and dP = dO.V^T); padded keys are zero
+  float4 Kr[KT], Vr[KT];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-      for (int t = 0; t < 4 * KT; ++t) {
-        const int k = 16 * (t >> 2) + 4 * q + (t & 3);
-        Kr[hh][t] = mvalid ? krow[k * AH + 2 * wave + hh] : 0.f;
-        Vr[hh][t] = mvalid ? krow[DH + k * AH + 2 * wave + hh] : 0.f;
-      }
+  for (int T = 0; T < KT; ++T) {
+    Kr[T] = *reinterpret_cast<const float4*>(Kh + (size_t)m * D + 16 * T + 4 * q);
+    Vr[T] = *reinterpret_cast<const float4*>(Vh + (size_t)m * D + 16 * T + 4 * q);
   }
-  const float kadd = (f.km && mvalid && f.km[(size_t)b * N + m] == 0) ? -EGT_NEG : 0.0f;
-  v4f dKacc[2][KT], dVacc[2][KT];
+  const float kadd = (f.km && a.km[(size_t)b * N + mc] == 0) ? -EGT_NEG : 0.0f;
+  v4f dKacc[KT], dVacc[KT];
 #pragma unroll
-  for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) { dKacc[hh][kt] = (v4f){0.f, 0.f, 0.f, 0.f}; dVacc[hh][kt] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+  for (int kt = 0; kt < KT; ++kt) { dKacc[kt] = (v4f){0.f, 0.f, 0.f, 0.f}; dVacc[kt] = (v4f){0.f, 0.f, 0.f, 0.f}; }
 
-  for (int l0 = 0; l0 < N; l0 += 16) {
-    __syncthreads();
-    // ---- stage Q and dO rows l0..l0+15 head-major; E/G/M/dH_ext tiles; row statistics ----
-    for (int idx = tid; idx < 16 * (DH / 4); idx += 256) {
-      const int row = idx / (DH / 4), c = (idx % (DH / 4)) * 4;
-      const int l = l0 + row;
-      float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), ov = qv;
-      if (l < N) {
-        qv = *reinterpret_cast<const float4*>(f.qkv + ((size_t)b * N + l) * 3 * DH + c);
-        ov = *reinterpret_cast<const float4*>(a.d_v_att + ((size_t)b * N + l) * DH + c);
-      }
-      const int k = c >> 3, h = c & 7;
-      float* qd = Qs + (h * 16 + row) * KLD + k;
-      float* od = Os + (h * 16 + row) * KLD + k;
-      qd[0] = qv.x; qd[16 * KLD] = qv.y; qd[32 * KLD] = qv.z; qd[48 * KLD] = qv.w;
-      od[0] = ov.x; od[16 * KLD] = ov.y; od[32 * KLD] = ov.z; od[48 * KLD] = ov.w;
-    }
-    for (int idx = tid; idx < 16 * 32; idx += 256) {
-      const int row = idx >> 5, c4 = (idx & 31) * 4;
-      const int lr = min(l0 + row, N - 1);
-      const int mt = m0 + (c4 >> 3);
-      const size_t g = (((size_t)b * N + lr) * N + m0) * AH + c4;
-      const bool ok = mt < N;
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f.E) *reinterpret_cast<float4*>(Et + row * PT_LD + c4) = ok ? *reinterpret_cast<const float4*>(f.E + g) : z;
-      if (f.G) *reinterpret_cast<float4*>(Gt + row * PT_LD + c4) = ok ? *reinterpret_cast<const float4*>(f.G + g) : z;
-      if (f.M) *reinterpret_cast<float4*>(Mt + row * PT_LD + c4) = ok ? *reinterpret_cast<const float4*>(f.M + g) : z;
-      if (a.d_h_ext) *reinterpret_cast<float4*>(Xt + row * PT_LD + c4) = ok ? *reinterpret_cast<const float4*>(a.d_h_ext + g) : z;
-    }
-    for (int idx = tid; idx < 16 * AH; idx += 256) {
-      const int row = idx >> 3, h = idx & 7;
-      const int lr = min(l0 + row, N - 1);
-      const float4 v = *reinterpret_cast<const float4*>(a.rowstats_in + (((size_t)b * N + lr) * AH + h) * 4);
-      *reinterpret_cast<float4*>(st + idx * 4) = make_float4(v.x, 1.0f / v.y, v.w, 0.f);   // max, 1/sum, delta
-    }
-    __syncthreads();
-
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* In = sm;                     // [2][E | G | M | dH_ext][PT_SZ]
+  float* Out = sm + 2 * 4 * PT_SZ;    // [2][dE | dG | dA][PT_SZ]
+  const int tid = threadIdx.x;
+  float4 pe4 = make_float4(0.f, 0.f, 0.f, 0.f), pg4 = pe4, pm4 = pe4, px4 = pe4;
+  if (f.E) ptile_lds_put(In + 0 * PT_SZ, ptile_gload(a.E, b, N, 0, m0, tid), N, 0, m0, tid);
+  if (f.G) ptile_lds_put(In + 1 * PT_SZ, ptile_gload(a.G, b, N, 0, m0, tid), N, 0, m0, tid);
+  if (f.M) ptile_lds_put(In + 2 * PT_SZ, ptile_gload(a.M, b, N, 0, m0, tid), N, 0, m0, tid);
+  if (f.X) ptile_lds_put(In + 3 * PT_SZ, ptile_gload(a.d_h_ext, b, N, 0, m0, tid), N, 0, m0, tid);
+  float4 qan[KT], oan[KT], stn[4];   // row operands / statistics of the next query tile
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int h = 2 * wave + hh;
-      // ---- S[l][m] = sum_k Q[l][k] K[m][k] ; dP[l][m] = sum_k dO[l][k] V[m][k] ----
-      v4f s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-      const float* qrow = Qs + (h * 16 + mm) * KLD + 4 * q;   // A rows are query rows: row index = lane&15
-      const float* orow = Os + (h * 16 + mm) * KLD + 4 * q;
+  for (int T = 0; T < KT; ++T) {
+    qan[T] = *reinterpret_cast<const float4*>(Qh + (size_t)mm * D + 16 * T + 4 * q);
+    oan[T] = *reinterpret_cast<const float4*>(Oh + (size_t)mm * D + 16 * T + 4 * q);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    stn[r] = *reinterpret_cast<const float4*>(a.rowstats + (((size_t)b * N + min(4 * q + r, N - 1)) * AH + h) * 4);
+  __syncthreads();
+
+  for (int l0 = 0, it = 0; l0 < NP; l0 += 16, ++it) {
+    const bool more = l0 + 16 < NP;
+    // ---- loads, oldest first: transposed operands of THIS tile (consumed after the elementwise
+    //      phase), then the row operands / statistics / pair tiles of the NEXT tile ----
+    float4 qt[KT], ot[KT];
+#pragma unroll
+    for (int T = 0; T < KT; ++T) {
+      qt[T] = *reinterpret_cast<const float4*>(QT + (size_t)(16 * T + mm) * NP + l0 + 4 * q);  // A rows are channels
+      ot[T] = *reinterpret_cast<const float4*>(OT + (size_t)(16 * T + mm) * NP + l0 + 4 * q);
+    }
+    float4 qa[KT], oa[KT], st[4];
+#pragma unroll
+    for (int T = 0; T < KT; ++T) { qa[T] = qan[T]; oa[T] = oan[T]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st[r] = stn[r];
+    size_t gi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gi[r] = (((size_t)b * N + min(l0 + 4 * q + r, N - 1)) * N + mc) * AH + h;
+    if (more) {
 #pragma unroll
       for (int T = 0; T < KT; ++T) {
-        const float4 qa = *reinterpret_cast<const float4*>(qrow + 16 * T);
-        const float4 oa = *reinterpret_cast<const float4*>(orow + 16 * T);
-        s = MFMA(qa.x, Kr[hh][4 * T + 0], s);   dp = MFMA(oa.x, Vr[hh][4 * T + 0], dp);
-        s = MFMA(qa.y, Kr[hh][4 * T + 1], s);   dp = MFMA(oa.y, Vr[hh][4 * T + 1], dp);
-        s = MFMA(qa.z, Kr[hh][4 * T + 2], s);   dp = MFMA(oa.z, Vr[hh][4 * T + 2], dp);
-        s = MFMA(qa.w, Kr[hh][4 * T + 3], s);   dp = MFMA(oa.w, Vr[hh][4 * T + 3], dp);
+        qan[T] = *reinterpret_cast<const float4*>(Qh + (size_t)(l0 + 16 + mm) * D + 16 * T + 4 * q);   // A rows are query rows
+        oan[T] = *reinterpret_cast<const float4*>(Oh + (size_t)(l0 + 16 + mm) * D + 16 * T + 4 * q);
       }
-      // lane (m = mm, q): query rows l = l0 + 4q + r
-      float at[4], da[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int li = 4 * q + r, l = l0 + li;
-        const bool valid = mvalid && l < N;
-        const float araw = s[r] * f.scale;
-        float ah = araw, inr = 1.0f;
-        if (clip) {
-          inr = (araw >= f.clip_lo && araw <= f.clip_hi) ? 1.0f : 0.0f;
-          ah = fminf(fmaxf(araw, f.clip_lo), f.clip_hi);
-        }
-        const int po = li * PT_LD + mm * AH + h;
-        float xv = ah, gv = gated ? Gt[po] : 0.f;
-        if (f.E) xv += Et[po];
-        if (f.km) { xv += kadd; gv += kadd; }
-        if (f.M) { const float mk = (Mt[po] - 1.0f) * EGT_NEG; xv += mk; gv += mk; }
-        if (f.rm || f.rng_rm) {
-          const size_t gi = (((size_t)b * N + min(l, N - 1)) * N + mc) * AH + h;
-          const bool hit = f.rm ? (f.rm[gi] != 0) : ((egt_hash32((uint32_t)gi, f.s0, f.s1) >> 8) < f.rm_thr);
-          const float mr = hit ? -EGT_NEG : 0.0f;
-          xv += mr; gv += mr;
-        }
-        const float* sr = st + (li * AH + h) * 4;
-        const float S = valid ? __expf(xv - sr[0]) * sr[1] : 0.f;
-        const float g = gated ? egt_sigmoid(gv) : 1.0f;
-        const float dAt_ = dp[r];
-        const float dS = dAt_ * g;
-        float dH = S * (dS - sr[2]);
-        if (a.d_h_ext) dH += Xt[po];
-        if (!valid) dH = 0.f;
-        dEt[po] = dH;
-        dGt[po] = gated ? dAt_ * S * g * (1.0f - g) : 0.f;
-        da[r] = dH * inr * f.scale;
-        dAt[po] = da[r];
-        at[r] = S * g;
-      }
-      // ---- dV^T[k][m] += sum_l dO[l][k] A[l][m] ; dK^T[k][m] += sum_l Q[l][k] dA[l][m] ----
+      for (int r = 0; r < 4; ++r)
+        stn[r] = *reinterpret_cast<const float4*>(a.rowstats + (((size_t)b * N + min(l0 + 16 + 4 * q + r, N - 1)) * AH + h) * 4);
+      if (f.E) pe4 = ptile_gload(a.E, b, N, l0 + 16, m0, tid);
+      if (f.G) pg4 = ptile_gload(a.G, b, N, l0 + 16, m0, tid);
+      if (f.M) pm4 = ptile_gload(a.M, b, N, l0 + 16, m0, tid);
+      if (f.X) px4 = ptile_gload(a.d_h_ext, b, N, l0 + 16, m0, tid);
+    }
+    const float* Et = In + (it & 1) * 4 * PT_SZ;
+    const float* Gt = Et + PT_SZ;
+    const float* Mt = Gt + PT_SZ;
+    const float* Xt = Mt + PT_SZ;
+    float* dEt = Out + (it & 1) * 3 * PT_SZ;
+    float* dGt = dEt + PT_SZ;
+    float* dAt = dGt + PT_SZ;
+    // ---- S[l][m] = sum_k Q[l][k] K[m][k] ; dP[l][m] = sum_k dO[l][k] V[m][k] ----
+    v4f s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        const float* ocol = Os + (h * 16 + 4 * q) * KLD + 16 * kt + mm;
-        const float* qcol = Qs + (h * 16 + 4 * q) * KLD + 16 * kt + mm;
-        v4f dv = dVacc[hh][kt], dk = dKacc[hh][kt];
-        dv = MFMA(ocol[0], at[0], dv);           dk = MFMA(qcol[0], da[0], dk);
-        dv = MFMA(ocol[KLD], at[1], dv);         dk = MFMA(qcol[KLD], da[1], dk);
-        dv = MFMA(ocol[2 * KLD], at[2], dv);     dk = MFMA(qcol[2 * KLD], da[2], dk);
-        dv = MFMA(ocol[3 * KLD], at[3], dv);     dk = MFMA(qcol[3 * KLD], da[3], dk);
-        dVacc[hh][kt] = dv; dKacc[hh][kt] = dk;
+    for (int T = 0; T < KT; ++T) {
+      s = MFMA(qa[T].x, Kr[T].x, s);   dp = MFMA(oa[T].x, Vr[T].x, dp);
+      s = MFMA(qa[T].y, Kr[T].y, s);   dp = MFMA(oa[T].y, Vr[T].y, dp);
+      s = MFMA(qa[T].z, Kr[T].z, s);   dp = MFMA(oa[T].z, Vr[T].z, dp);
+      s = MFMA(qa[T].w, Kr[T].w, s);   dp = MFMA(oa[T].w, Vr[T].w, dp);
+    }
+    float at[4], da[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int l = l0 + 4 * q + r;
+      const bool valid = mvalid && l < N;
+      const float araw = s[r] * a.scale;
+      float ah = araw, inr = 1.0f;
+      if (clip) {
+        inr = (araw >= a.clip_lo && araw <= a.clip_hi) ? 1.0f : 0.0f;
+        ah = fminf(fmaxf(araw, a.clip_lo), a.clip_hi);
       }
+      const int po = (4 * q + r) * PT_LD + mm * AH + h;
+      const float add = mask_add(a, f, kadd, f.M ? Mt[po] : 1.f, gi[r]);
+      const float xv = ah + (f.E ? Et[po] : 0.f) + add;
+      const float S = valid ? __expf(xv - st[r].x) / st[r].y : 0.f;
+      const float g = gated ? egt_sigmoid(Gt[po] + add) : 1.0f;
+      const float dAt_ = dp[r];
+      float dH = S * (dAt_ * g - st[r].w) + (f.X ? Xt[po] : 0.f);
+      if (!valid) dH = 0.f;
+      da[r] = dH * inr * a.scale;
+      at[r] = S * g;
+      dEt[po] = dH;
+      dGt[po] = gated ? dAt_ * S * g * (1.0f - g) : 0.f;
+      dAt[po] = da[r];
+    }
+    // ---- dV^T[k][m] += sum_l dO[l][k] A[l][m] ; dK^T[k][m] += sum_l Q[l][k] dA[l][m] ----
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      v4f dv = dVacc[kt], dk = dKacc[kt];
+      dv = MFMA(ot[kt].x, at[0], dv);   dk = MFMA(qt[kt].x, da[0], dk);
+      dv = MFMA(ot[kt].y, at[1], dv);   dk = MFMA(qt[kt].y, da[1], dk);
+      dv = MFMA(ot[kt].z, at[2], dv);   dk = MFMA(qt[kt].z, da[2], dk);
+      dv = MFMA(ot[kt].w, at[3], dv);   dk = MFMA(qt[kt].w, da[3], dk);
+      dVacc[kt] = dv; dKacc[kt] = dk;
+    }
+    if (more) {
+      float* nx = In + ((it + 1) & 1) * 4 * PT_SZ;
+      if (f.E) ptile_lds_put(nx, pe4, N, l0 + 16, m0, tid);
+      if (f.G) ptile_lds_put(nx + PT_SZ, pg4, N, l0 + 16, m0, tid);
+      if (f.M) ptile_lds_put(nx + 2 * PT_SZ, pm4, N, l0 + 16, m0, tid);
+      if (f.X) ptile_lds_put(nx + 3 * PT_SZ, px4, N, l0 + 16, m0, tid);
     }
     __syncthreads();
-    // ---- dE / dG / dA tiles out as whole rows ----
-    for (int idx = tid; idx < 16 * 32; idx += 256) {
-      const int row = idx >> 5, c4 = (idx & 31) * 4;
-      const int lr = l0 + row, mt = m0 + (c4 >> 3);
-      if (lr < N && mt < N) {
-        const size_t g = (((size_t)b * N + lr) * N + m0) * AH + c4;
-        if (a.d_E) *reinterpret_cast<float4*>(a.d_E + g) = *reinterpret_cast<const float4*>(dEt + row * PT_LD + c4);
-        if (a.d_G) *reinterpret_cast<float4*>(a.d_G + g) = *reinterpret_cast<const float4*>(dGt + row * PT_LD + c4);
-        *reinterpret_cast<float4*>(a.ws_dA + g) = *reinterpret_cast<const float4*>(dAt + row * PT_LD + c4);
-      }
-    }
+    if (f.E) ptile_gstore(a.d_E, dEt, b, N, l0, m0, tid);
+    if (f.G) ptile_gstore(a.d_G, dGt, b, N, l0, m0, tid);
+    ptile_gstore(a.ws_dA, dAt, b, N, l0, m0, tid);
   }
   if (mvalid) {
-    float* o = a.d_qkv + ((size_t)b * N + m) * 3 * DH;
+    float* o = a.d_qkv + ((size_t)b * N + m) * 3 * DH + h;
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int h = 2 * wave + hh;
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = 16 * kt + 4 * q + r;
-          o[DH + k * AH + h] = dKacc[hh][kt][r];
-          o[2 * DH + k * AH + h] = dVacc[hh][kt][r];
-        }
-    }
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * kt + 4 * q + r;
+        o[DH + k * AH] = dKacc[kt][r];
+        o[2 * DH + k * AH] = dVacc[kt][r];
+      }
   }
 }
 
+// Lane (ll = lane&15, q): query row l0 + ll; keys m0 + 4q + t as the contraction index.
 template <int D>
-__global__ void __launch_bounds__(256, 2) k_attn_mfma_bwd_q(AttnMfmaBwdArgs a) {
-  constexpr int KT = D / 16, KLD = D + 4, DH = D * AH;
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* Ks = sm;                          // [8][16][KLD]
-  float* At = Ks + AH * 16 * KLD;          // dA tile [16 l][PT_LD]
-  const AttnMfmaArgs& f = a.f;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_q(AttnMfmaArgs a) {
+  constexpr int KT = D / 16, DH = D * AH;
+  const int lane = threadIdx.x & 63, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ll = lane & 15, q = lane >> 4;
-  const int N = f.N;
-  const int ltiles = (N + 15) / 16;
-  const int b = blockIdx.x / ltiles, l0 = (blockIdx.x % ltiles) * 16;
+  const int N = a.N, NP = a.NP;
+  const int ltiles = NP / 16;
+  const int wg = egt_xcd_remap(blockIdx.x, gridDim.x);
+  const int b = wg / ltiles, l0 = (wg % ltiles) * 16;
   const int l = l0 + ll;
-  v4f dQacc[2][KT];
+  const size_t arr = (size_t)a.B * AH * NP * D;
+  const float* KTp = a.pk + PK_KT * arr + ((size_t)b * AH + h) * D * NP;
+  v4f dQacc[KT];
 #pragma unroll
-  for (int hh = 0; hh < 2; ++hh)
+  for (int kt = 0; kt < KT; ++kt) dQacc[kt] = (v4f){0.f, 0.f, 0.f, 0.f};
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // dA tiles [2][PT_SZ]
+  const int tid = threadIdx.x;
+  float4 kc[KT], kn[KT], pa4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) dQacc[hh][kt] = (v4f){0.f, 0.f, 0.f, 0.f};
-  for (int m0 = 0; m0 < N; m0 += 16) {
-    __syncthreads();
-    for (int idx = tid; idx < 16 * (DH / 4); idx += 256) {
-      const int row = idx / (DH / 4), c = (idx % (DH / 4)) * 4;
-      const int m = m0 + row;
-      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < N) kv = *reinterpret_cast<const float4*>(f.qkv + ((size_t)b * N + m) * 3 * DH + DH + c);
-      const int k = c >> 3, h = c & 7;
-      float* kd = Ks + (h * 16 + row) * KLD + k;
-      kd[0] = kv.x; kd[16 * KLD] = kv.y; kd[32 * KLD] = kv.z; kd[48 * KLD] = kv.w;
-    }
-    for (int idx = tid; idx < 16 * 32; idx += 256) {
-      const int row = idx >> 5, c4 = (idx & 31) * 4;
-      const int lr = l0 + row, mt = m0 + (c4 >> 3);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (lr < N && mt < N) v = *reinterpret_cast<const float4*>(a.ws_dA + (((size_t)b * N + lr) * N + m0) * AH + c4);
-      *reinterpret_cast<float4*>(At + row * PT_LD + c4) = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int h = 2 * wave + hh;
-      float da[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) da[t] = At[ll * PT_LD + (4 * q + t) * AH + h];   // dA[l][m = 4q + t]
-      // dQ^T[k][l] += sum_m K[m][k] dA[l][m]
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        const float* kcol = Ks + (h * 16 + 4 * q) * KLD + 16 * kt + ll;
-        v4f dq = dQacc[hh][kt];
-        dq = MFMA(kcol[0], da[0], dq);
-        dq = MFMA(kcol[KLD], da[1], dq);
-        dq = MFMA(kcol[2 * KLD], da[2], dq);
-        dq = MFMA(kcol[3 * KLD], da[3], dq);
-        dQacc[hh][kt] = dq;
-      }
-    }
+  for (int kt = 0; kt < KT; ++kt) {
+    kc[kt] = *reinterpret_cast<const float4*>(KTp + (size_t)(16 * kt + ll) * NP + 4 * q);
+    kn[kt] = kc[kt];
   }
-  if (l < N) {
-    float* o = a.d_qkv + ((size_t)b * N + l) * 3 * DH;
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int h = 2 * wave + hh;
+  ptile_lds_put(sm, ptile_gload(a.ws_dA, b, N, l0, 0, tid), N, l0, 0, tid);
+  __syncthreads();
+  for (int m0 = 0, it = 0; m0 < NP; m0 += 16, ++it) {
+    const bool more = m0 + 16 < NP;
+    if (more) {
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[(16 * kt + 4 * q + r) * AH + h] = dQacc[hh][kt][r];
+        kn[kt] = *reinterpret_cast<const float4*>(KTp + (size_t)(16 * kt + ll) * NP + m0 + 16 + 4 * q);
+      pa4 = ptile_gload(a.ws_dA, b, N, l0, m0 + 16, tid);
     }
+    const float* At = sm + (it & 1) * PT_SZ;
+    float da[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) da[t] = At[ll * PT_LD + (4 * q + t) * AH + h];   // dA[l][m = 4q + t] (zero past N)
+    // dQ^T[k][l] += sum_m K^T[k][m] dA[l][m]
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      v4f dq = dQacc[kt];
+      dq = MFMA(kc[kt].x, da[0], dq);
+      dq = MFMA(kc[kt].y, da[1], dq);
+      dq = MFMA(kc[kt].z, da[2], dq);
+      dq = MFMA(kc[kt].w, da[3], dq);
+      dQacc[kt] = dq;
+    }
+    if (more) ptile_lds_put(sm + ((it + 1) & 1) * PT_SZ, pa4, N, l0, m0 + 16, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) kc[kt] = kn[kt];
+  }
+  if (l < N) {
+    float* o = a.d_qkv + ((size_t)b * N + l) * 3 * DH + h;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[(16 * kt + 4 * q + r) * AH] = dQacc[kt][r];
   }
 }
 
@@ -502,25 +587,30 @@ extern "C" int egt_attn_mfma_supported(const egt_attn_desc* d, int need_a_tild) 
   return 1;
 }
 
-template <int D>
-static void launch_fwd(const AttnMfmaArgs& a, hipStream_t st) {
-  const int ltiles = (a.N + 15) / 16;
-  const size_t lds = ((size_t)2 * AH * 16 * (D + 4) + 4 * 16 * PT_LD + 16) * 4;
-  (void)hipFuncSetAttribute((const void*)k_attn_mfma_fwd<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  EGT_LAUNCH("k_attn_mfma_fwd", k_attn_mfma_fwd<D>, dim3(a.B * ltiles), dim3(256), lds, st, a);
+static int np_of(int N) { return (N + 15) & ~15; }
+
+// forward uses the first 2 packed arrays, backward all 8 followed by the dA tensor
+extern "C" size_t egt_attn_mfma_workspace_bytes(const egt_attn_desc* d) {
+  if (!egt_attn_mfma_supported(d, 0)) return 0;
+  const size_t arr = (size_t)d->B * AH * np_of(d->N) * d->d;
+  return (PK_COUNT * arr + (size_t)d->B * d->N * d->N * AH) * sizeof(float);
 }
 
-extern "C" int egt_attn_mfma_fwd(const egt_attn_desc* desc, const void* qkv, const void* E,
-                                 const void* G, const uint8_t* key_mask, const void* attn_mask,
-                                 const uint8_t* rand_mask, void* v_att, void* h_hat, void* rowstats,
-                                 void* stream) {
+extern "C" size_t egt_attn_mfma_fwd_workspace_bytes(const egt_attn_desc* d) {
+  if (!egt_attn_mfma_supported(d, 0)) return 0;
+  return (size_t)2 * d->B * AH * np_of(d->N) * d->d * sizeof(float);
+}
+
+static int fill(const egt_attn_desc* desc, const void* qkv, const void* E, const void* G,
+                const uint8_t* key_mask, const void* attn_mask, const uint8_t* rand_mask, void* workspace,
+                AttnMfmaArgs& a) {
   if (!egt_attn_mfma_supported(desc, 0)) EGT_FAIL(EGT_E_SHAPE, "configuration not covered by the MFMA inner-op kernel");
-  if (!qkv || !v_att || !h_hat || !rowstats) EGT_FAIL(EGT_E_NULL, "qkv/v_att/h_hat/rowstats is NULL");
+  if (!qkv || !workspace) EGT_FAIL(EGT_E_NULL, "qkv/workspace is NULL");
   if ((desc->flags & EGT_F_EDGE_INPUT) && !E) EGT_FAIL(EGT_E_NULL, "edge_input set but E is NULL");
   if ((desc->flags & EGT_F_GATE_INPUT) && !G) EGT_FAIL(EGT_E_NULL, "gate_input set but G is NULL");
   if ((desc->flags & EGT_F_ATTN_MASK) && !attn_mask) EGT_FAIL(EGT_E_NULL, "attn_mask set but M is NULL");
-  AttnMfmaArgs a{};
-  a.B = desc->B; a.N = desc->N; a.d = desc->d; a.flags = desc->flags;
+  a = AttnMfmaArgs{};
+  a.B = desc->B; a.N = desc->N; a.NP = np_of(desc->N); a.d = desc->d; a.flags = desc->flags;
   a.clip_lo = desc->clip_lo; a.clip_hi = desc->clip_hi;
   a.scale = 1.0f / sqrtf((float)desc->d);
   a.rm_thr = egt_threshold24(desc->random_mask_prob);
@@ -533,7 +623,50 @@ extern "C" int egt_attn_mfma_fwd(const egt_attn_desc* desc, const void* qkv, con
   if ((desc->flags & EGT_F_TRAINING) && desc->random_mask_prob > 0.0f) {
     if (rand_mask) a.rm = rand_mask; else a.rng_rm = 1;
   }
+  a.pk = (float*)workspace;
+  return EGT_OK;
+}
+
+template <int D>
+static void launch_pack(const AttnMfmaArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)16 * (4 * D * AH + 4) * 4;
+  (void)hipFuncSetAttribute((const void*)k_attn_pack<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  EGT_LAUNCH("k_attn_pack", k_attn_pack<D>, dim3(a.B * (a.NP / 16)), dim3(256), lds, st, a);
+}
+
+// 1 / 2: the straight-line instances (see Feat), 0: the run-time-switched one
+static int variant_of(const AttnMfmaArgs& a, bool bwd) {
+  const bool main_cfg = a.E && (a.flags & EGT_F_GATE_INPUT) && a.G && !a.M && a.km && (a.flags & EGT_F_CLIP) && !a.rm &&
+                        (!bwd || (a.d_h_ext && a.d_E && a.d_G));
+  if (!main_cfg || getenv("EGT_ATTN_GENERIC")) return 0;
+  return a.rng_rm ? 2 : 1;
+}
+
+template <int D, int V>
+static void launch_fwd_v(const AttnMfmaArgs& a, hipStream_t st) {
+  (void)hipFuncSetAttribute((const void*)k_attn_mfma_fwd<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  EGT_LAUNCH("k_attn_mfma_fwd", (k_attn_mfma_fwd<D, V>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)8 * PT_SZ * 4, st, a);
+}
+template <int D>
+static void launch_fwd(const AttnMfmaArgs& a, hipStream_t st) {
+  launch_pack<D>(a, st);
+  switch (variant_of(a, false)) {
+    case 1: launch_fwd_v<D, 1>(a, st); break;
+    case 2: launch_fwd_v<D, 2>(a, st); break;
+    default: launch_fwd_v<D, 0>(a, st); break;
+  }
+}
+
+extern "C" int egt_attn_mfma_fwd(const egt_attn_desc* desc, const void* qkv, const void* E,
+                                 const void* G, const uint8_t* key_mask, const void* attn_mask,
+                                 const uint8_t* rand_mask, void* v_att, void* h_hat, void* rowstats,
+                                 void* workspace, void* stream) {
+  AttnMfmaArgs a;
+  int rc = fill(desc, qkv, E, G, key_mask, attn_mask, rand_mask, workspace, a);
+  if (rc) return rc;
+  if (!v_att || !h_hat || !rowstats) EGT_FAIL(EGT_E_NULL, "v_att/h_hat/rowstats is NULL");
   a.v_att = (float*)v_att; a.h_hat = (float*)h_hat; a.rowstats = (float*)rowstats;
+  a.pack_bwd = 0;
   switch (desc->d) {
     case 16: launch_fwd<16>(a, (hipStream_t)stream); break;
     case 32: launch_fwd<32>(a, (hipStream_t)stream); break;
@@ -543,51 +676,43 @@ extern "C" int egt_attn_mfma_fwd(const egt_attn_desc* desc, const void* qkv, con
   return EGT_OK;
 }
 
+template <int D, int V>
+static void launch_bwd_kv_v(const AttnMfmaArgs& a, hipStream_t st) {
+  (void)hipFuncSetAttribute((const void*)k_attn_mfma_bwd_kv<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  EGT_LAUNCH("k_attn_mfma_bwd_kv", (k_attn_mfma_bwd_kv<D, V>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)14 * PT_SZ * 4, st, a);
+}
 template <int D>
-static void launch_bwd(const AttnMfmaBwdArgs& a, hipStream_t st) {
-  const int N = a.f.N, tiles = (N + 15) / 16;
-  const long rows = (long)a.f.B * N;
+static void launch_bwd(const AttnMfmaArgs& a, hipStream_t st) {
+  const long rows = (long)a.B * a.N;
+  launch_pack<D>(a, st);
   EGT_LAUNCH("k_attn_mfma_delta", k_attn_mfma_delta, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, a);
-  const size_t lds_kv = ((size_t)2 * AH * 16 * (D + 4) + 7 * 16 * PT_LD + 16 * AH * 4) * 4;
-  (void)hipFuncSetAttribute((const void*)k_attn_mfma_bwd_kv<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  EGT_LAUNCH("k_attn_mfma_bwd_kv", k_attn_mfma_bwd_kv<D>, dim3(a.f.B * tiles), dim3(256), lds_kv, st, a);
-  const size_t lds_q = ((size_t)AH * 16 * (D + 4) + 16 * PT_LD) * 4;
-  EGT_LAUNCH("k_attn_mfma_bwd_q", k_attn_mfma_bwd_q<D>, dim3(a.f.B * tiles), dim3(256), lds_q, st, a);
+  switch (variant_of(a, true)) {
+    case 1: launch_bwd_kv_v<D, 1>(a, st); break;
+    case 2: launch_bwd_kv_v<D, 2>(a, st); break;
+    default: launch_bwd_kv_v<D, 0>(a, st); break;
+  }
+  EGT_LAUNCH("k_attn_mfma_bwd_q", k_attn_mfma_bwd_q<D>, dim3(a.B * (a.NP / 16)), dim3(512), (size_t)2 * PT_SZ * 4, st, a);
 }
 
-// rowstats is read AND written (slot 3 receives delta); workspace: egt_attn_bwd_workspace_bytes()
+// rowstats is read AND written (slot 3 receives delta); workspace: egt_attn_mfma_workspace_bytes()
 extern "C" int egt_attn_mfma_bwd(const egt_attn_desc* desc, const void* qkv, const void* E,
                                  const void* G, const uint8_t* key_mask, const void* attn_mask,
                                  const uint8_t* rand_mask, const void* v_att, void* rowstats,
                                  const void* d_v_att, const void* d_h_ext, void* d_qkv, void* d_E,
                                  void* d_G, void* workspace, void* stream) {
-  if (!egt_attn_mfma_supported(desc, 0)) EGT_FAIL(EGT_E_SHAPE, "configuration not covered by the MFMA inner-op kernel");
-  if (!qkv || !v_att || !rowstats || !d_v_att || !d_qkv || !workspace)
-    EGT_FAIL(EGT_E_NULL, "qkv/v_att/rowstats/d_v_att/d_qkv/workspace is NULL");
-  if ((desc->flags & EGT_F_EDGE_INPUT) && !E) EGT_FAIL(EGT_E_NULL, "edge_input set but E is NULL");
-  if ((desc->flags & EGT_F_GATE_INPUT) && !G) EGT_FAIL(EGT_E_NULL, "gate_input set but G is NULL");
-  if ((desc->flags & EGT_F_ATTN_MASK) && !attn_mask) EGT_FAIL(EGT_E_NULL, "attn_mask set but M is NULL");
-  AttnMfmaBwdArgs a{};
-  AttnMfmaArgs& f = a.f;
-  f.B = desc->B; f.N = desc->N; f.d = desc->d; f.flags = desc->flags;
-  f.clip_lo = desc->clip_lo; f.clip_hi = desc->clip_hi;
-  f.scale = 1.0f / sqrtf((float)desc->d);
-  f.rm_thr = egt_threshold24(desc->random_mask_prob);
-  f.s0 = (uint32_t)(desc->seed & 0xFFFFFFFFull); f.s1 = (uint32_t)(desc->seed >> 32);
-  f.qkv = (const float*)qkv;
-  f.E = (desc->flags & EGT_F_EDGE_INPUT) ? (const float*)E : nullptr;
-  f.G = (desc->flags & EGT_F_GATE_INPUT) ? (const float*)G : nullptr;
-  f.M = (desc->flags & EGT_F_ATTN_MASK) ? (const float*)attn_mask : nullptr;
-  f.km = key_mask;
-  if ((desc->flags & EGT_F_TRAINING) && desc->random_mask_prob > 0.0f) {
-    if (rand_mask) f.rm = rand_mask; else f.rng_rm = 1;
-  }
-  a.v_att = (const float*)v_att; a.rowstats_in = (const float*)rowstats; a.rowstats_rw = (float*)rowstats;
+  AttnMfmaArgs a;
+  int rc = fill(desc, qkv, E, G, key_mask, attn_mask, rand_mask, workspace, a);
+  if (rc) return rc;
+  if (!v_att || !rowstats || !d_v_att || !d_qkv) EGT_FAIL(EGT_E_NULL, "v_att/rowstats/d_v_att/d_qkv is NULL");
+  if ((desc->flags & EGT_F_EDGE_INPUT) && !d_E) EGT_FAIL(EGT_E_NULL, "edge_input set but d_E is NULL");
+  if ((desc->flags & EGT_F_GATE_INPUT) && !d_G) EGT_FAIL(EGT_E_NULL, "gate_input set but d_G is NULL");
+  a.v_att_in = (const float*)v_att; a.rowstats = (float*)rowstats;
   a.d_v_att = (const float*)d_v_att; a.d_h_ext = (const float*)d_h_ext;
   a.d_qkv = (float*)d_qkv;
   a.d_E = (desc->flags & EGT_F_EDGE_INPUT) ? (float*)d_E : nullptr;
   a.d_G = (desc->flags & EGT_F_GATE_INPUT) ? (float*)d_G : nullptr;
-  a.ws_dA = (float*)workspace;
+  a.ws_dA = a.pk + (size_t)PK_COUNT * a.B * AH * a.NP * a.d;
+  a.pack_bwd = 1;
   switch (desc->d) {
     case 16: launch_bwd<16>(a, (hipStream_t)stream); break;
     case 32: launch_bwd<32>(a, (hipStream_t)stream); break;

@@ -101,9 +101,11 @@ class _EGTAttention(torch.autograd.Function):
         if (cfg.use_mfma and drop_keep is None
                 and lib.egt_attn_mfma_supported(C.byref(desc), 1 if cfg.need_a_tild else 0)):
             # large-head geometry: QK^T / A.V on MFMA tiles (egt_attn_mfma.hip)
+            ws = torch.empty(lib.egt_attn_mfma_fwd_workspace_bytes(C.byref(desc)), device=qkv.device,
+                             dtype=torch.uint8)
             L.check(lib.egt_attn_mfma_fwd(C.byref(desc), L.ptr(qkv), L.ptr(E), L.ptr(G), L.ptr(key_mask),
                                           L.ptr(M), L.ptr(rand_mask), L.ptr(v_att), L.ptr(h_hat),
-                                          L.ptr(rowstats), L.current_stream()))
+                                          L.ptr(rowstats), L.ptr(ws), L.current_stream()))
         else:
             L.check(lib.egt_attn_fwd(C.byref(desc), L.ptr(qkv), L.ptr(E), L.ptr(G), L.ptr(key_mask),
                                      L.ptr(M), L.ptr(rand_mask), L.ptr(drop_keep), L.ptr(v_att),
@@ -130,9 +132,10 @@ class _EGTAttention(torch.autograd.Function):
         d_qkv = torch.empty_like(qkv)
         d_E = torch.empty_like(E) if E is not None else None
         d_G = torch.empty_like(G) if G is not None else None
-        ws = torch.empty(lib.egt_attn_bwd_workspace_bytes(C.byref(desc)), device=qkv.device,
-                         dtype=torch.uint8)
-        if (ctx.cfg.use_mfma and drop_keep is None and lib.egt_attn_mfma_supported(C.byref(desc), 0)):
+        mfma = bool(ctx.cfg.use_mfma and drop_keep is None and lib.egt_attn_mfma_supported(C.byref(desc), 0))
+        nbytes = (lib.egt_attn_mfma_workspace_bytes if mfma else lib.egt_attn_bwd_workspace_bytes)(C.byref(desc))
+        ws = torch.empty(nbytes, device=qkv.device, dtype=torch.uint8)
+        if mfma:
             L.check(lib.egt_attn_mfma_bwd(C.byref(desc), L.ptr(qkv), L.ptr(E), L.ptr(G), L.ptr(key_mask),
                                           L.ptr(M), L.ptr(rand_mask), L.ptr(v_att), L.ptr(rowstats),
                                           L.ptr(d_v_att), L.ptr(d_h_hat), L.ptr(d_qkv), L.ptr(d_E),

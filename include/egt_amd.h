@@ -110,12 +110,16 @@ int egt_attn_bwd(const egt_attn_desc* desc, const void* qkv, const void* E,
  * attention dropout, degree scalers, the A_tild output.  egt_attn_mfma_supported
  * returns 1 when `desc` (and the A_tild request) is covered. */
 int egt_attn_mfma_supported(const egt_attn_desc* desc, int need_a_tild);
+/* Workspace of the MFMA path: head-major operand copies of Q/K/V/dV_att (+ the dA tensor in
+ * the backward).  *_fwd_* is what egt_attn_mfma_fwd needs; the other covers both directions. */
+size_t egt_attn_mfma_fwd_workspace_bytes(const egt_attn_desc* desc);
+size_t egt_attn_mfma_workspace_bytes(const egt_attn_desc* desc);
 int egt_attn_mfma_fwd(const egt_attn_desc* desc, const void* qkv, const void* E,
                       const void* G, const uint8_t* key_mask, const void* attn_mask,
                       const uint8_t* rand_mask, void* v_att, void* h_hat, void* rowstats,
-                      void* stream);
-/* Backward on MFMA tiles (three launches: delta, dK/dV/dE/dG per key tile, dQ per query
- * tile).  rowstats is read and its 4th slot written; workspace as for egt_attn_bwd. */
+                      void* workspace, void* stream);
+/* Backward on MFMA tiles (launches: pack, delta, dK/dV/dE/dG per key tile, dQ per query
+ * tile).  rowstats is read and its 4th slot written; workspace: egt_attn_mfma_workspace_bytes. */
 int egt_attn_mfma_bwd(const egt_attn_desc* desc, const void* qkv, const void* E,
                       const void* G, const uint8_t* key_mask, const void* attn_mask,
                       const uint8_t* rand_mask, const void* v_att, void* rowstats,

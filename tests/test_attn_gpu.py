@@ -179,3 +179,31 @@ def test_attn_mfma_kernel_vs_oracle(B, N, d, opts, gpu, egt_lib):
     if dg is not None:
         assert_close(dg, ref["dG"], name="dG", **BWD)
     assert_close(outs[True][0], outs[False][0], name="V_att(mfma vs general)", rtol=1e-4, arel=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,d", [(48, 64), (37, 16)])
+def test_attn_mfma_in_kernel_random_mask(N, d, gpu, egt_lib):
+    """The straight-line MFMA instances with the in-kernel random-mask stream (training, no injected
+    bytes): forward + backward equal the fp64 oracle fed the same mask, materialised by mask_sample."""
+    from egt_amd import egt_attention, mask_sample, AttnConfig
+    B, H, seed, p = 2, 8, 4242, 0.25
+    g = torch.Generator().manual_seed(N + d)
+    QKV = torch.randn(B, N, 3 * d * H, generator=g) * 0.7
+    E = torch.randn(B, N, N, H, generator=g); G = torch.randn(B, N, N, H, generator=g)
+    mask = torch.ones(B, N, dtype=torch.bool); mask[1, N - 7:] = False
+    dV = torch.randn(B, N, d * H, generator=g); dH = torch.randn(B, N, N, H, generator=g)
+    rm = mask_sample(0, seed, p, B, N, H, gpu).cpu().bool()
+    inp = dict(QKV=QKV, E=E, G=G, M=None, mask=mask, rand_mask=rm, drop_keep=None, dV=dV, dH=dH)
+    attrs = dict(num_heads=H, clip_logits_value=(-5.0, 5.0), scale_degree=False, scaler_type="log",
+                 num_virtual_nodes=0, attn_dropout=0.0)
+    ref = CS.attn_oracle(inp, attrs)
+    q = QKV.to(gpu).requires_grad_(); e_ = E.to(gpu).requires_grad_(); g_ = G.to(gpu).requires_grad_()
+    cfg = AttnConfig(num_heads=H, random_mask_prob=p, training=True, seed=seed, need_a_tild=False, use_mfma=True)
+    V, Hh, _ = egt_attention(q, e_, g_, None, mask.to(gpu), cfg=cfg)
+    torch.autograd.backward([V, Hh], [dV.to(gpu), dH.to(gpu)])
+    assert_close(V, ref["V_att"], name="V_att", **FWD)
+    assert_close(Hh, ref["H_hat"], name="H_hat", **FWD)
+    assert_close(q.grad, ref["dQKV"], name="dQKV", **BWD)
+    assert_close(e_.grad, ref["dE"], name="dE", **BWD)
+    assert_close(g_.grad, ref["dG"], name="dG", **BWD)
