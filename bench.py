@@ -32,8 +32,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 WORKLOADS = {
     # BASELINE.json configs[1]
     "zinc500k_n64": dict(B=128, N=64, Dh=64, De=64, H=8, Ly=10, nodes=(9, 37), rand_p=0.1),
-    # BASELINE.json configs[3] shapes (PATTERN-500K), for reference runs
+    # the other BASELINE.json configs' shapes, for reference runs -- not bench lines
+    "zinc100k_n37": dict(B=128, N=37, Dh=48, De=48, H=8, Ly=4, nodes=(9, 37), rand_p=0.1),
+    "cifar10_n150_fp32": dict(B=128, N=150, Dh=64, De=8, H=8, Ly=4, nodes=(85, 150), rand_p=0.1),
     "pattern500k_n120": dict(B=16, N=120, Dh=64, De=8, H=8, Ly=16, nodes=(44, 120), rand_p=0.1),
+    "pattern500k_n120_b128": dict(B=128, N=120, Dh=64, De=8, H=8, Ly=16, nodes=(44, 120), rand_p=0.1),
 }
 
 
@@ -127,6 +130,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="zinc500k_n64", choices=list(WORKLOADS))
+    ap.add_argument("--layers", type=int, default=0, help="override the workload's layer count (1 = single-block scope)")
     ap.add_argument("--fused", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -159,7 +163,9 @@ def main():
     from egt_amd.dp import FlatGradAllReduce, flat_grad_view, all_reduce_flat
     lib = _lib.load()
 
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    if args.layers > 0:
+        w["Ly"] = args.layers
     torch.manual_seed(1234)  # same weights on every rank (replicated parameters)
     fused = {"auto": "auto", "on": True, "off": False}[args.fused]
     model = EGTStack(model_height=w["Ly"], model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"],
