@@ -246,8 +246,9 @@ int egt_block_fwd(const egt_block_desc* desc, const egt_block_params* params,
 
 /* Backward.  h, e are the block's INPUTS (nothing else of size [B,N,N,*] is
  * kept: LN, projections, logits and softmax are recomputed from e).  d_e may
- * alias d_e_out.  Every pointer of `grads` (same layout as the params, but
- * writable) is written. */
+ * alias d_e_out; d_h must NOT alias d_h_out (the deferred dense_mha weight
+ * gradient reads d_h_out after d_h has been written).  Every pointer of `grads`
+ * (same layout as the params, but writable) is written. */
 int egt_block_bwd(const egt_block_desc* desc, const egt_block_params* params,
                   const void* h, const void* e, const uint8_t* key_mask,
                   const void* attn_mask, const uint8_t* rand_mask,
@@ -261,9 +262,12 @@ int egt_block_bwd(const egt_block_desc* desc, const egt_block_params* params,
  * (the measurement configuration; the reference interleaves ffn_block, for which
  * egt_block_fwd/bwd is the per-layer drop-in).  params / grads are arrays of
  * `layers` structs.  saved keeps the layer activations h_l, e_l (l = 1..layers-1)
- * and each layer's egt_block_saved buffer; in backward d_h / d_e carry the
- * gradients down the stack in place and all parameter-gradient partial sums are
- * reduced by one launch at the end.  Layer l draws its random attention mask from
+ * and each layer's egt_block_saved buffer.  Forward: one launch per layer where the
+ * node-side epilogue covers the geometry (Dh = 64), else three.  Backward: d_e carries
+ * the edge gradient down the stack in place, every layer's dh and dQKV rows are kept
+ * in the workspace, and the GEMM-shaped weight gradients plus all partial sums of ALL
+ * layers are finished by three launches at the end (d_h must not alias d_h_out; at
+ * most 64 layers per call).  Layer l draws its random attention mask from
  * the counter hash seeded with desc->seed ^ 0x9E3779B97F4A7C15*(l+1). */
 size_t egt_stack_saved_bytes(const egt_block_desc* desc, int32_t layers);
 size_t egt_stack_workspace_bytes(const egt_block_desc* desc, int32_t layers);
