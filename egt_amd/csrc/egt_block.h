@@ -19,6 +19,7 @@ struct BlockArgs {
   int NQP;      // backward: dQ partials per row (key tiles) in dqp [B][NQP][N][64]
   int epi;      // forward epilogue in k_block_fwd: 0 none, 1 dense_mha+res, 2 + next block's norm_mha/dense_qkv
   int xcd;      // pair kernels: XCD-aware workgroup order
+  int guard;    // backward phase guards (always 0 in production, see k_block_bwd_v4)
   int prep;     // node kernels: add the edge-weight preparation workgroup
   const float *nx_nm_g, *nx_nm_b, *nx_Wqkv, *nx_bqkv;   // next block (epi == 2)
   float* nx_qkvp;

@@ -1088,7 +1088,11 @@ __global__ void __launch_bounds__(256, WPS) k_block_bwd_dma(BlockArgs a) {
 //    (LayerNorm backward) instead of being held across the tile;
 //  * dQ partials go to HBM per key tile (summed in k_node_bwd) instead of an LDS slab;
 //  * scheduling fences between the phases keep the compiler from hoisting every LDS read to
-//    the top of the tile (which is what blows the register budget).
+//    the top of the tile (which is what blows the register budget);
+//  * phase guards: P2, the dQ/dK/dV block, P4 and P5 sit behind `if (!(a.guard & bit))` with
+//    a.guard == 0 at run time.  The always-taken uniform branches split the tile body into
+//    basic blocks, which stops hipcc from stretching live ranges across phases: 19 -> 4 spilled
+//    registers, 116 -> 104 us.  (EGT_BWD_ABLATE sets the bits for phase-cost measurements.)
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // PF: how many of the two streamed tiles (e, de') are register-prefetched one row ahead.
@@ -1179,8 +1183,9 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
       lds_sync();
       if (li > 0)
         tile_from_lds<DE>(dt0 + ((li - 1) & 1) * G::TILE_FLOATS, a.de + (pair0 - (size_t)N) * DE, lane, 16);
-      if (PF < 2) tile_gload<DE>(td, a.de_out + pair0 * DE, lane, 16);
-      if (PF < 1) tile_gload<DE>(te, a.e + pair0 * DE, lane, 16);
+      const size_t lp0 = (a.guard & 16) ? (size_t)wave * 16 : pair0;
+      if (PF < 2) tile_gload<DE>(td, a.de_out + lp0 * DE, lane, 16);
+      if (PF < 1) tile_gload<DE>(te, a.e + lp0 * DE, lane, 16);
       tile_lds_put<DE>(et, te, lane, 16);
       tile_lds_put<DE>(dt, td, lane, 16);
       if (l + 1 < l_end) {
@@ -1210,6 +1215,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
       SCHED_FENCE();
       // ---- P2: dH_ext = de'.Wr^T ----
       v4f dhx = {0.f, 0.f, 0.f, 0.f};
+      if (!(a.guard & 8))
 #pragma unroll
       for (int t = 0; t < G::TILES; ++t) {
         const float4 dyv = frag_read<DE>(dt, p, q, t);
@@ -1279,7 +1285,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
       if (q == 0) sc2[p * 12 + 8] = 1.0f;
       lds_sync();
       SCHED_FENCE();
-      {
+      if (!(a.guard & 4)) {
         const float* qr = qd + li * QD_LD;
         const float4* qp = reinterpret_cast<const float4*>(qr + q * 16);
         const float4* dp = reinterpret_cast<const float4*>(qr + 64 + q * 16);
@@ -1299,7 +1305,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
       }
       SCHED_FENCE();
       // ---- P4: weight-gradient contractions over the 16 pairs of the tile ----
-      {
+      if (!(a.guard & 1)) {
         float bT[4], bR[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -1317,7 +1323,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
       lds_sync();
       SCHED_FENCE();
       // ---- P5: d(ehat) = Wp . dGE, LayerNorm backward, de = de' + ... in place over the de' tile ----
-      {
+      if (!(a.guard & 2)) {
         float4 dxh[G::TILES];
         float m1 = 0.f, m2 = 0.f;
 #pragma unroll
@@ -1575,6 +1581,7 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
     if (full && !egt_env_flag("EGT_BWD_V2") && !egt_env_flag("EGT_BWD_DMA")) {   // register-lean, 2 waves/SIMD
       const size_t lds_v4 = ((size_t)4 * PW + (size_t)BWD_TL * QD_LD + 3 * GG::TILES * 256) * 4;
       a.NQP = a.N / 16;
+      { const char* e = getenv("EGT_BWD_ABLATE"); a.guard = e ? atoi(e) : 0; }   // measurement only: drops phases
 #define V4_VARIANT(ML_, PF_)                                                                           \
   do {                                                                                                 \
     (void)hipFuncSetAttribute((const void*)k_block_bwd_v4<DE, ML_, PF_>,                               \
