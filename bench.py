@@ -35,6 +35,7 @@ WORKLOADS = {
     # the other BASELINE.json configs' shapes, for reference runs -- not bench lines
     "zinc100k_n37": dict(B=128, N=37, Dh=48, De=48, H=8, Ly=4, nodes=(9, 37), rand_p=0.1),
     "cifar10_n150_fp32": dict(B=128, N=150, Dh=64, De=8, H=8, Ly=4, nodes=(85, 150), rand_p=0.1),
+    "cifar10_n150": dict(B=128, N=150, Dh=64, De=8, H=8, Ly=4, nodes=(85, 150), rand_p=0.1, edge_dtype="bf16"),
     "pattern500k_n120": dict(B=16, N=120, Dh=64, De=8, H=8, Ly=16, nodes=(44, 120), rand_p=0.1),
     "pattern500k_n120_b128": dict(B=128, N=120, Dh=64, De=8, H=8, Ly=16, nodes=(44, 120), rand_p=0.1),
 }
@@ -46,11 +47,12 @@ def algorithmic_bytes(kernel: str, w: dict) -> float:
     B, N, Dh, De, H = w["B"], w["N"], w["Dh"], w["De"], w["H"]
     pairs = B * N * N
     s = 4
+    se = 2 if w.get("edge_dtype", "f32") == "bf16" else 4   # edge tensors in HBM
     node = B * N * Dh * s
     table = {
         # fused block: fwd reads e, writes e' (+ node rows); bwd reads e, de', writes de
-        "k_block_fwd": pairs * De * s * 2 + 3 * node,
-        "k_block_bwd": pairs * De * s * 3 + 3 * node,
+        "k_block_fwd": pairs * De * se * 2 + 3 * node,
+        "k_block_bwd": pairs * De * se * 3 + 3 * node,
         # composed path
         "k_edge_proj_fwd": pairs * (De + 2 * H) * s,
         "k_edge_proj_bwd": pairs * (2 * De + 2 * H) * s,
@@ -130,6 +132,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="zinc500k_n64", choices=list(WORKLOADS))
+    ap.add_argument("--edge-dtype", default="", choices=["", "f32", "bf16"],
+                    help="storage type of the edge tensors (EGT_BF16: bf16 in HBM, fp32 arithmetic); default: the workload's")
     ap.add_argument("--layers", type=int, default=0, help="override the workload's layer count (1 = single-block scope)")
     ap.add_argument("--fused", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -166,11 +170,16 @@ def main():
     w = dict(WORKLOADS[args.workload])
     if args.layers > 0:
         w["Ly"] = args.layers
+    if args.edge_dtype:
+        w["edge_dtype"] = args.edge_dtype
+    bf16 = w.get("edge_dtype", "f32") == "bf16"
     torch.manual_seed(1234)  # same weights on every rank (replicated parameters)
     fused = {"auto": "auto", "on": True, "off": False}[args.fused]
     model = EGTStack(model_height=w["Ly"], model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"],
                      random_mask_prob=w["rand_p"], seed=1, fused=fused).to(dev).train()
     h, e, mask, dh, de = make_inputs(w, dev, seed=1234 + rank)  # each rank its own graphs
+    if bf16:
+        e, de = e.bfloat16(), de.bfloat16()
     h.requires_grad_(); e.requires_grad_()
     params = model.fused_parameters()
     nbytes = sum(p.numel() for p in params) * 4
@@ -268,7 +277,8 @@ def main():
             "metric": "graphs/sec EGT fwd+bwd, ZINC-500K padded N=64",
             "value": graphs / elapsed, "unit": "graphs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (edge tensors stored bf16)" if bf16 else "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: attention-block stack (h,e,mask)->(h',e') x Ly, fwd+bwd "
                                    f"+ param grads" + (" + flat RCCL grad all-reduce" if world > 1 else ""),

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libegt_amd.so")
 EGT_OK = 0
 EGT_E_NULL, EGT_E_SHAPE, EGT_E_DTYPE, EGT_E_FLAGS, EGT_E_HIP, EGT_E_WORKSPACE = -1, -2, -3, -4, -5, -6
 EGT_F32 = 0
+EGT_BF16 = 1   # fused block/stack: edge tensors bf16 in HBM, everything else fp32
 F_EDGE_INPUT, F_GATE_INPUT, F_ATTN_MASK, F_SCALE_DEGREE = 0x001, 0x002, 0x004, 0x008
 F_SCALER_LINEAR, F_TRAINING, F_CLIP = 0x010, 0x020, 0x040
 EP_LAYERNORM, EP_GATES = 0x1, 0x2

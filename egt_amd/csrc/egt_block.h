@@ -12,6 +12,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 struct BlockArgs {
   int B, N, De, DK, Dh;  // DK = per-head dim (<= 8)
   uint32_t flags;
+  int bf16;   // edge tensors e / e' / de' / de are bf16 in HBM (arithmetic stays fp32)
   float clip_lo, clip_hi, scale, ln_eps;
   uint32_t rm_thr, s0, s1;
   int rng_rm;

@@ -91,6 +91,51 @@ __device__ __forceinline__ void tile_from_lds(const float* tl, float* dst, int l
   }
 }
 
+// ---- bf16 edge tensors (desc.dtype == EGT_BF16): same tiles, 8-byte global accesses; the
+// arithmetic, the LDS tiles and everything node-side stay fp32 ----
+__device__ __forceinline__ float4 bf4_to_f4(uint2 u) {
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
+                     __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ uint32_t f_to_bf(float f) {   // round to nearest even (NaN stays NaN)
+  uint32_t u = __float_as_uint(f);
+  const uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u);
+  return ((u & 0x7FFFFFFFu) > 0x7F800000u) ? ((u >> 16) | 0x40u) : (r >> 16);
+}
+__device__ __forceinline__ uint2 f4_to_bf4(float4 v) {
+  return make_uint2(f_to_bf(v.x) | (f_to_bf(v.y) << 16), f_to_bf(v.z) | (f_to_bf(v.w) << 16));
+}
+template <int DE>
+__device__ __forceinline__ void tile_gload(TileRegs<DE>& r, const uint16_t* src, int lane, int rows_valid) {
+  using G = Geo<DE>;
+  constexpr int NI = (G::NF4 + 63) / 64;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    int f = i * 64 + lane;
+    if (G::NF4 < 64) f &= (G::NF4 - 1);
+    const int row = f / G::NSLOT;
+    const int fc = row < rows_valid ? f : f - row * G::NSLOT;
+    r.v[i] = bf4_to_f4(*reinterpret_cast<const uint2*>(src + (size_t)fc * 4));
+  }
+}
+template <int DE>
+__device__ __forceinline__ void tile_from_lds(const float* tl, uint16_t* dst, int lane, int rows_valid) {
+  using G = Geo<DE>;
+  constexpr int NI = (G::NF4 + 63) / 64;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int f = i * 64 + lane;
+    if (G::NF4 >= 64 || f < G::NF4) {
+      const int row = f / G::NSLOT, slot = f % G::NSLOT;
+      if (row < rows_valid)
+        *reinterpret_cast<uint2*>(dst + (size_t)f * 4) =
+            f4_to_bf4(*reinterpret_cast<const float4*>(tl + row * DE + ((slot ^ swz<DE>(row)) << 2)));
+    }
+  }
+}
+template <bool BF> struct EdgeT { typedef float type; };
+template <> struct EdgeT<true> { typedef uint16_t type; };
+
 template <int DE>
 __device__ __forceinline__ void tile_lds_get(const float* tl, TileRegs<DE>& r, int lane) {
   using G = Geo<DE>;
@@ -242,9 +287,15 @@ __device__ __forceinline__ float reduce16_keep_own(const float (&v)[16], int p) 
 // ML: attention-mask / injected-random-mask byte streams are present (their loads are
 // compiled out of the headline kernel).
 // FULL: N is a multiple of 16 (no ragged key tile): validity selects and address clamps fold away.
-template <int DE, bool KVL, bool ML, bool FULL>
+template <int DE, bool KVL, bool ML, bool FULL, bool BF>
 __global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
   using G = Geo<DE>;
+  typedef typename EdgeT<BF>::type ET;   // element type of the edge tensors in HBM
+  const ET* e_in = reinterpret_cast<const ET*>(a.e);
+  ET* e_o = reinterpret_cast<ET*>(a.e_out);
+  const ET* dey_in = reinterpret_cast<const ET*>(a.de_out);
+  ET* dex_o = reinterpret_cast<ET*>(a.de);
+  (void)e_in; (void)e_o; (void)dey_in; (void)dex_o;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 15, q = lane >> 4;
@@ -302,7 +353,7 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
   auto prefetch = [&](int it) {
     const int l = lg * 16 + wave + 4 * (it / ntile), m0 = (it % ntile) * 16;
     const size_t pair0 = ((size_t)b * N + l) * N + m0;
-    tile_gload<DE>(tr, a.e + pair0 * DE, lane, FULL ? 16 : min(16, N - m0));
+    tile_gload<DE>(tr, e_in + pair0 * DE, lane, FULL ? 16 : min(16, N - m0));
   };
   if (total > 0) prefetch(0);
 
@@ -332,7 +383,7 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
     lds_sync();
     if (it > 0) {   // stream out e' of the previous tile from the other buffer
       const int itp = it - 1, lp = lg * 16 + wave + 4 * (itp / ntile), m0p = (itp % ntile) * 16;
-      tile_from_lds<DE>(tl0 + (itp & 1) * G::TILE_FLOATS, a.e_out + (((size_t)b * N + lp) * N + m0p) * DE,
+      tile_from_lds<DE>(tl0 + (itp & 1) * G::TILE_FLOATS, e_o + (((size_t)b * N + lp) * N + m0p) * DE,
                         lane, FULL ? 16 : min(16, N - m0p));
     }
     tile_lds_put<DE>(tl, tr, lane, rows_valid);
@@ -407,7 +458,7 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
     }
     if (it + 1 == total) {   // last tile of the wave: flush
       lds_sync();
-      tile_from_lds<DE>(tl, a.e_out + pair0 * DE, lane, rows_valid);
+      tile_from_lds<DE>(tl, e_o + pair0 * DE, lane, rows_valid);
     }
 
     if (mt == ntile - 1) {
@@ -507,9 +558,15 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
 // Workgroup = (graph b, TL query rows); wave w owns key tiles w, w+4, ...; for each
 // it walks the TL rows.  Q / dV_att / softmax statistics of the rows sit in LDS.
 #define QD_LD 160  // per row: Q[64] | dV_att[64] | stats[32]
-template <int DE, bool ML, bool FULL>
+template <int DE, bool ML, bool FULL, bool BF>
 __global__ void __launch_bounds__(256, 1) k_block_bwd(BlockArgs a) {
   using G = Geo<DE>;
+  typedef typename EdgeT<BF>::type ET;   // element type of the edge tensors in HBM
+  const ET* e_in = reinterpret_cast<const ET*>(a.e);
+  ET* e_o = reinterpret_cast<ET*>(a.e_out);
+  const ET* dey_in = reinterpret_cast<const ET*>(a.de_out);
+  ET* dex_o = reinterpret_cast<ET*>(a.de);
+  (void)e_in; (void)e_o; (void)dey_in; (void)dex_o;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 15, q = lane >> 4;
@@ -586,8 +643,8 @@ __global__ void __launch_bounds__(256, 1) k_block_bwd(BlockArgs a) {
     TileRegs<DE> te, td;
     auto prefetch = [&](int l) {
       const size_t pair0 = ((size_t)b * N + l) * N + m0;
-      tile_gload<DE>(te, a.e + pair0 * DE, lane, rows_valid);
-      tile_gload<DE>(td, a.de_out + pair0 * DE, lane, rows_valid);
+      tile_gload<DE>(te, e_in + pair0 * DE, lane, rows_valid);
+      tile_gload<DE>(td, dey_in + pair0 * DE, lane, rows_valid);
     };
     prefetch(l_begin);
 
@@ -600,7 +657,7 @@ __global__ void __launch_bounds__(256, 1) k_block_bwd(BlockArgs a) {
       float* dt = dt0 + ((l - l_begin) & 1) * G::TILE_FLOATS;
       lds_sync();
       if (l > l_begin)   // stream out de of the previous row from the other buffer
-        tile_from_lds<DE>(dt0 + ((l - l_begin - 1) & 1) * G::TILE_FLOATS, a.de + (pair0 - (size_t)N) * DE,
+        tile_from_lds<DE>(dt0 + ((l - l_begin - 1) & 1) * G::TILE_FLOATS, dex_o + (pair0 - (size_t)N) * DE,
                           lane, rows_valid);
       tile_lds_put<DE>(et, te, lane, rows_valid);
       tile_lds_put<DE>(dt, td, lane, rows_valid);
@@ -737,7 +794,7 @@ __global__ void __launch_bounds__(256, 1) k_block_bwd(BlockArgs a) {
       }
       if (l + 1 == l_end) {   // last row of this key tile: flush
         lds_sync();
-        tile_from_lds<DE>(dt, a.de + pair0 * DE, lane, rows_valid);
+        tile_from_lds<DE>(dt, dex_o + pair0 * DE, lane, rows_valid);
       }
       // ---- dQ[l] partial over this tile's 16 keys ----
       dql[(l - l_begin) * 64 + q * 16 + p] += reduce16_keep_own(dq, p);
@@ -1096,9 +1153,15 @@ __global__ void __launch_bounds__(256, WPS) k_block_bwd_dma(BlockArgs a) {
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // PF: how many of the two streamed tiles (e, de') are register-prefetched one row ahead.
-template <int DE, bool ML, int PF>
+template <int DE, bool ML, int PF, bool BF>
 __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
   using G = Geo<DE>;
+  typedef typename EdgeT<BF>::type ET;   // element type of the edge tensors in HBM
+  const ET* e_in = reinterpret_cast<const ET*>(a.e);
+  ET* e_o = reinterpret_cast<ET*>(a.e_out);
+  const ET* dey_in = reinterpret_cast<const ET*>(a.de_out);
+  ET* dex_o = reinterpret_cast<ET*>(a.de);
+  (void)e_in; (void)e_o; (void)dey_in; (void)dex_o;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 15, q = lane >> 4;
@@ -1169,8 +1232,8 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
     TileRegs<DE> te, td;
     {
       const size_t pair0 = ((size_t)b * N + l_begin) * N + m0;
-      if (PF >= 1) tile_gload<DE>(te, a.e + pair0 * DE, lane, 16);
-      if (PF >= 2) tile_gload<DE>(td, a.de_out + pair0 * DE, lane, 16);
+      if (PF >= 1) tile_gload<DE>(te, e_in + pair0 * DE, lane, 16);
+      if (PF >= 2) tile_gload<DE>(td, dey_in + pair0 * DE, lane, 16);
     }
     for (int l = l_begin; l < l_end; ++l) {
       const int li = l - l_begin;
@@ -1182,15 +1245,15 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
       // memory order per step: [stores of row l-1] then [loads of row l+1] (see k_block_fwd)
       lds_sync();
       if (li > 0)
-        tile_from_lds<DE>(dt0 + ((li - 1) & 1) * G::TILE_FLOATS, a.de + (pair0 - (size_t)N) * DE, lane, 16);
+        tile_from_lds<DE>(dt0 + ((li - 1) & 1) * G::TILE_FLOATS, dex_o + (pair0 - (size_t)N) * DE, lane, 16);
       const size_t lp0 = (a.guard & 16) ? (size_t)wave * 16 : pair0;
-      if (PF < 2) tile_gload<DE>(td, a.de_out + lp0 * DE, lane, 16);
-      if (PF < 1) tile_gload<DE>(te, a.e + lp0 * DE, lane, 16);
+      if (PF < 2) tile_gload<DE>(td, dey_in + lp0 * DE, lane, 16);
+      if (PF < 1) tile_gload<DE>(te, e_in + lp0 * DE, lane, 16);
       tile_lds_put<DE>(et, te, lane, 16);
       tile_lds_put<DE>(dt, td, lane, 16);
       if (l + 1 < l_end) {
-        if (PF >= 1) tile_gload<DE>(te, a.e + (pair0 + (size_t)N) * DE, lane, 16);
-        if (PF >= 2) tile_gload<DE>(td, a.de_out + (pair0 + (size_t)N) * DE, lane, 16);
+        if (PF >= 1) tile_gload<DE>(te, e_in + (pair0 + (size_t)N) * DE, lane, 16);
+        if (PF >= 2) tile_gload<DE>(td, dey_in + (pair0 + (size_t)N) * DE, lane, 16);
       }
       lds_sync();
       SCHED_FENCE();
@@ -1360,7 +1423,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
     {  // flush the last row of this key tile
       lds_sync();
       tile_from_lds<DE>(dt0 + ((nl - 1) & 1) * G::TILE_FLOATS,
-                        a.de + (((size_t)b * N + l_end - 1) * N + m0) * DE, lane, 16);
+                        dex_o + (((size_t)b * N + l_end - 1) * N + m0) * DE, lane, 16);
     }
     float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
     float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
@@ -1402,7 +1465,7 @@ static bool egt_env_flag(const char* name) {
 static int block_check(const egt_block_desc* d, bool report) {
 #define BAD(code, ...) do { if (report) egt_set_error(__VA_ARGS__); return (code); } while (0)
   if (!d) BAD(EGT_E_NULL, "desc is NULL");
-  if (d->dtype != EGT_F32) BAD(EGT_E_DTYPE, "only EGT_F32 is supported (got %d)", d->dtype);
+  if (d->dtype != EGT_F32 && d->dtype != EGT_BF16) BAD(EGT_E_DTYPE, "dtype must be EGT_F32 or EGT_BF16 (got %d)", d->dtype);
   if (d->B <= 0 || d->N <= 0) BAD(EGT_E_SHAPE, "B and N must be positive");
   if (d->H != BH) BAD(EGT_E_SHAPE, "fused block is built for num_heads=8 (got %d)", d->H);
   if (d->d < 1 || d->d > 8) BAD(EGT_E_SHAPE, "fused block covers per-head dim <= 8 (got %d)", d->d);
@@ -1489,6 +1552,7 @@ static int fill_block(const egt_block_desc* d, const egt_block_params* p, BlockA
   a = BlockArgs{};
   a.B = d->B; a.N = d->N; a.De = d->De; a.DK = d->d; a.Dh = d->d * d->H;
   a.flags = d->flags;
+  a.bf16 = d->dtype == EGT_BF16;
   a.clip_lo = d->clip_lo; a.clip_hi = d->clip_hi;
   a.scale = 1.0f / sqrtf((float)d->d);
   a.ln_eps = d->ln_eps;
@@ -1543,16 +1607,19 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   const bool ml = a.M != nullptr || a.rm != nullptr;
   const dim3 grid(a.B * lgroups), block(256);
   const size_t lds = lds_tiles + (kvl ? lds_kv : 0);
-#define FWD_VARIANT(KVL_, ML_, FULL_)                                                                  \
+#define FWD_VARIANT_T(KVL_, ML_, FULL_, BF_)                                                           \
   do {                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)k_block_fwd<DE, KVL_, ML_, FULL_>,                          \
+    (void)hipFuncSetAttribute((const void*)k_block_fwd<DE, KVL_, ML_, FULL_, BF_>,                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
-    EGT_LAUNCH("k_block_fwd", (k_block_fwd<DE, KVL_, ML_, FULL_>), grid, block, lds, st, a);           \
+    EGT_LAUNCH("k_block_fwd", (k_block_fwd<DE, KVL_, ML_, FULL_, BF_>), grid, block, lds, st, a);      \
   } while (0)
+#define FWD_VARIANT(KVL_, ML_, FULL_)                                                                  \
+  do { if (a.bf16) FWD_VARIANT_T(KVL_, ML_, FULL_, true); else FWD_VARIANT_T(KVL_, ML_, FULL_, false); } while (0)
   const bool full = (a.N % 16) == 0;
   if (full && kvl && !ml) FWD_VARIANT(true, false, true);      // the headline variant
   else if (kvl) { if (ml) FWD_VARIANT(true, true, false); else FWD_VARIANT(true, false, false); }
   else { if (ml) FWD_VARIANT(false, true, false); else FWD_VARIANT(false, false, false); }
+#undef FWD_VARIANT_T
 #undef FWD_VARIANT
   if (a.epi == 0) egt_node_launch_post(a, st);  // dense_mha + res_mha
   return a.epi;
@@ -1569,35 +1636,38 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
   constexpr int PW = 3 * GG::TILE_FLOATS + 256 + 192;
   static_assert(4 * GG::EP <= 4 * PW, "edge partial staging must fit the LDS tile area");
   const size_t lds = ((size_t)4 * PW + (size_t)4 * BWD_TL * 64 + (size_t)BWD_TL * QD_LD) * 4;
-#define BWD_VARIANT(ML_, FULL_)                                                                        \
+#define BWD_VARIANT_T(ML_, FULL_, BF_)                                                                 \
   do {                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)k_block_bwd<DE, ML_, FULL_>,                                \
+    (void)hipFuncSetAttribute((const void*)k_block_bwd<DE, ML_, FULL_, BF_>,                           \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
-    EGT_LAUNCH("k_block_bwd", (k_block_bwd<DE, ML_, FULL_>), dim3(L.nwg_bwd), dim3(256), lds, st, a);  \
+    EGT_LAUNCH("k_block_bwd", (k_block_bwd<DE, ML_, FULL_, BF_>), dim3(L.nwg_bwd), dim3(256), lds, st, a); \
   } while (0)
+#define BWD_VARIANT(ML_, FULL_)                                                                        \
+  do { if (a.bf16) BWD_VARIANT_T(ML_, FULL_, true); else BWD_VARIANT_T(ML_, FULL_, false); } while (0)
   const bool ml = a.M != nullptr || a.rm != nullptr;
   const bool full = (a.N % 16) == 0;
   if constexpr (DE % 16 == 0) {
-    if (full && !egt_env_flag("EGT_BWD_V2") && !egt_env_flag("EGT_BWD_DMA")) {   // register-lean, 2 waves/SIMD
+    if (full && !egt_env_flag("EGT_BWD_V2") && (a.bf16 || !egt_env_flag("EGT_BWD_DMA"))) {   // register-lean, 2 waves/SIMD
       const size_t lds_v4 = ((size_t)4 * PW + (size_t)BWD_TL * QD_LD + 3 * GG::TILES * 256) * 4;
       a.NQP = a.N / 16;
       { const char* e = getenv("EGT_BWD_ABLATE"); a.guard = e ? atoi(e) : 0; }   // measurement only: drops phases
-#define V4_VARIANT(ML_, PF_)                                                                           \
+#define V4_VARIANT(ML_, PF_, BF_)                                                                          \
   do {                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)k_block_bwd_v4<DE, ML_, PF_>,                               \
+    (void)hipFuncSetAttribute((const void*)k_block_bwd_v4<DE, ML_, PF_, BF_>,                          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
-    EGT_LAUNCH("k_block_bwd", (k_block_bwd_v4<DE, ML_, PF_>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a); \
+    EGT_LAUNCH("k_block_bwd", (k_block_bwd_v4<DE, ML_, PF_, BF_>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a); \
   } while (0)
       const char* pfe = getenv("EGT_BWD_PF");
       const int pf = pfe ? atoi(pfe) : 0;   // two resident waves hide the HBM latency; prefetch registers only spill
-      if (ml) V4_VARIANT(true, 0);
-      else if (pf == 0) V4_VARIANT(false, 0);
-      else if (pf == 1) V4_VARIANT(false, 1);
-      else V4_VARIANT(false, 2);
+      if (a.bf16) { if (ml) V4_VARIANT(true, 0, true); else V4_VARIANT(false, 0, true); }
+      else if (ml) V4_VARIANT(true, 0, false);
+      else if (pf == 0) V4_VARIANT(false, 0, false);
+      else if (pf == 1) V4_VARIANT(false, 1, false);
+      else V4_VARIANT(false, 2, false);
 #undef V4_VARIANT
       goto pair_done;
     }
-    if (full && egt_env_flag("EGT_BWD_DMA")) {   // experimental DMA-staged variant (hipcc drains vmcnt after every LDS-DMA)
+    if (full && !a.bf16 && egt_env_flag("EGT_BWD_DMA")) {   // experimental DMA-staged variant (hipcc drains vmcnt after every LDS-DMA)
       constexpr int WL = GG::DEP + 4;
       const size_t lds_dma = ((size_t)4 * PW + (size_t)BWD_TL * QD_LD + 24 * WL) * 4;
       a.NQP = a.N / 16;
@@ -1619,6 +1689,7 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
   else BWD_VARIANT(false, false);
 pair_done:
 #undef BWD_VARIANT
+#undef BWD_VARIANT_T
   egt_node_launch_bwd(a, below, true, st);   // dQKV -> dh, bias/LN sums; dV_att + delta of the block below
 }
 
@@ -1697,7 +1768,7 @@ static StackLayout stack_layout(const egt_block_desc* d, int layers) {
   StackLayout S{};
   const BlockLayout L = layout(d);
   S.h_sz = al((size_t)d->B * d->N * d->d * d->H);
-  S.e_sz = al((size_t)d->B * d->N * d->N * d->De);
+  S.e_sz = al((size_t)d->B * d->N * d->N * d->De / (d->dtype == EGT_BF16 ? 2 : 1));   // in floats
   size_t o = 0;
   S.h_act = o; o += S.h_sz * (size_t)(layers > 1 ? layers - 1 : 0);
   S.e_act = o; o += S.e_sz * (size_t)(layers > 1 ? layers - 1 : 0);

@@ -18,7 +18,7 @@ _GRAD_ORDER = (("norm_edge", "gamma"), ("norm_edge", "beta"),
                ("dense_edge_r", "kernel"), ("dense_edge_r", "bias"))
 
 
-def _desc(blk, B, N, training, seed) -> L.BlockDesc:
+def _desc(blk, B, N, training, seed, edge_dtype=torch.float32) -> L.BlockDesc:
     flags = 0
     if blk.gated:
         flags |= L.BF_GATE
@@ -31,7 +31,7 @@ def _desc(blk, B, N, training, seed) -> L.BlockDesc:
         flags |= L.BF_CLIP
         lo, hi = float(blk.mha.clip_logits_value[0]), float(blk.mha.clip_logits_value[1])
     return L.BlockDesc(B=B, N=N, H=blk.num_heads, d=blk.model_width // blk.num_heads,
-                       De=blk.edge_width, dtype=L.EGT_F32, flags=flags, clip_lo=lo, clip_hi=hi,
+                       De=blk.edge_width, dtype=L.EGT_BF16 if edge_dtype == torch.bfloat16 else L.EGT_F32, flags=flags, clip_lo=lo, clip_hi=hi,
                        random_mask_prob=float(blk.mha.random_mask_prob), ln_eps=1e-3, reserved=0,
                        seed=int(seed) & 0xFFFFFFFFFFFFFFFF)
 
@@ -48,15 +48,30 @@ def block_supported(blk, h, e, attn_mask, rand_mask) -> bool:
         return False
     if blk.edge_channel_type == "constrained" and attn_mask is None:
         return False
-    if not (h.is_cuda and e.is_cuda) or h.dtype != torch.float32 or e.dtype != torch.float32:
+    if not (h.is_cuda and e.is_cuda) or e.dtype not in (torch.float32, torch.bfloat16):
+        return False
+    if h.dtype not in (torch.float32, torch.bfloat16):
         return False
     if blk.model_width % blk.num_heads:
         return False
     lib = L.load()
     if not hasattr(lib, "egt_block_fwd"):
         return False
-    d = _desc(blk, h.shape[0], h.shape[1], False, 0)
+    d = _desc(blk, h.shape[0], h.shape[1], False, 0, e.dtype)
     return bool(lib.egt_block_supported(C.byref(d)))
+
+
+def _edge_c(t, dtype=None):
+    """edge tensor as the kernels take it: contiguous fp32 or bf16 (EGT_BF16: bf16 in HBM, fp32 math)"""
+    if t is None:
+        return None
+    want = dtype if dtype is not None else (torch.bfloat16 if t.dtype == torch.bfloat16 else torch.float32)
+    return t.to(want).contiguous()
+
+
+def _node_io(h):
+    """node tensors are fp32 at the C boundary; a bf16 caller gets its dtype back"""
+    return (h.float(), h.dtype) if h.dtype != torch.float32 else (h, None)
 
 
 def _params_struct(tensors) -> L.BlockParams:
@@ -71,7 +86,7 @@ class _FusedBlock(torch.autograd.Function):
     def forward(ctx, h, e, key_mask, attn_mask, rand_mask, desc, *params):
         _need_gpu(h, e)
         lib = L.load()
-        h = _f32c(h); e = _f32c(e)
+        h = _f32c(h); e = _edge_c(e)
         key_mask = _u8c(key_mask); rand_mask = _u8c(rand_mask)
         attn_mask = None if attn_mask is None else _f32c(attn_mask.to(torch.float32))
         params = tuple(None if p is None else _f32c(p) for p in params)
@@ -95,7 +110,7 @@ class _FusedBlock(torch.autograd.Function):
         h, e, key_mask, attn_mask, rand_mask, saved, *params = ctx.saved_tensors
         desc = ctx.desc
         dev = h.device
-        dh_out = _f32c(dh_out); de_out = _f32c(de_out)
+        dh_out = _f32c(dh_out); de_out = _edge_c(de_out, e.dtype)
         dh = torch.empty_like(h)
         de = torch.empty_like(e)
         grads = [None if p is None else torch.empty_like(p) for p in params]
@@ -111,14 +126,16 @@ class _FusedBlock(torch.autograd.Function):
 def block_fused(blk, h, e, mask, attn_mask, rand_mask=None):
     training = blk.training and blk.mha.random_mask_prob > 0.0
     seed = blk.mha.next_seed() if (training and rand_mask is None) else 0
-    desc = _desc(blk, h.shape[0], h.shape[1], training, seed)
+    desc = _desc(blk, h.shape[0], h.shape[1], training, seed, e.dtype)
     params = []
     for mod, attr in _GRAD_ORDER:
         m = getattr(blk, mod, None)
         params.append(None if m is None else getattr(m, attr))
     if blk.edge_channel_type != "constrained":
         attn_mask = None
-    return _FusedBlock.apply(h, e, mask, attn_mask, rand_mask, desc, *params)
+    h, hdt = _node_io(h)
+    h2, e2 = _FusedBlock.apply(h, e, mask, attn_mask, rand_mask, desc, *params)
+    return (h2 if hdt is None else h2.to(hdt)), e2
 
 
 # ------------------------------------------------------------------ layer stack ---
@@ -130,7 +147,7 @@ class _FusedStack(torch.autograd.Function):
     def forward(ctx, h, e, key_mask, attn_mask, desc, layers, holder, *params):
         _need_gpu(h, e)
         lib = L.load()
-        h = _f32c(h); e = _f32c(e)
+        h = _f32c(h); e = _edge_c(e)
         key_mask = _u8c(key_mask)
         attn_mask = None if attn_mask is None else _f32c(attn_mask.to(torch.float32))
         params = tuple(None if p is None else _f32c(p) for p in params)
@@ -152,7 +169,7 @@ class _FusedStack(torch.autograd.Function):
         h, e, key_mask, attn_mask, saved, *params = ctx.saved_tensors
         desc, layers = ctx.desc, ctx.layers
         dev = h.device
-        dh_out = _f32c(dh_out); de_out = _f32c(de_out)
+        dh_out = _f32c(dh_out); de_out = _edge_c(de_out, e.dtype)
         dh, de = torch.empty_like(h), torch.empty_like(e)
         # every parameter gradient is a view of ONE flat buffer: the data-parallel all-reduce
         # (egt_amd.dp) runs on it directly, and autograd adopts the views without copies
@@ -200,7 +217,7 @@ def stack_fused(stack, h, e, mask, attn_mask):
     b0 = blocks[0]
     training = b0.training and b0.mha.random_mask_prob > 0.0
     seed = b0.mha.next_seed() if training else 0
-    desc = _desc(b0, h.shape[0], h.shape[1], training, seed)
+    desc = _desc(b0, h.shape[0], h.shape[1], training, seed, e.dtype)
     params = []
     for blk in blocks:
         for mod, attr in _GRAD_ORDER:
@@ -208,7 +225,9 @@ def stack_fused(stack, h, e, mask, attn_mask):
             params.append(None if m is None else getattr(m, attr))
     if b0.edge_channel_type != "constrained":
         attn_mask = None
-    return _FusedStack.apply(h, e, mask, attn_mask, desc, len(blocks), stack.grad_holder, *params)
+    h, hdt = _node_io(h)
+    h2, e2 = _FusedStack.apply(h, e, mask, attn_mask, desc, len(blocks), stack.grad_holder, *params)
+    return (h2 if hdt is None else h2.to(hdt)), e2
 
 
 def layer_seed(seed: int, layer: int) -> int:

@@ -296,7 +296,9 @@ class EGTStack(nn.Module):
         if self.stack_call and h.is_cuda:
             from . import fused as FZ
             if FZ.stack_supported(self, h, e, attn_mask):
+                self.last_path = "fused-stack"
                 return FZ.stack_fused(self, h, e, mask, attn_mask)   # one C-ABI call per direction
+        self.last_path = "per-block"
         for blk in self.blocks:
             h, e = blk(h, e, mask, attn_mask)
         return h, e

@@ -48,6 +48,9 @@ extern "C" {
 
 /* dtype */
 #define EGT_F32 0
+#define EGT_BF16 1 /* fused block/stack only: the EDGE tensors (e, e', d e', d e and the stack's
+                      saved e_l) are bfloat16 in HBM; node tensors, parameters, gradients of
+                      parameters and all arithmetic stay fp32 */
 
 /* egt_attn_desc.flags — the operator attributes of EGT.__init__
  * (egt_layers.py:5-16) */

@@ -225,3 +225,67 @@ def test_fused_accepts_unaligned_parameter_views(gpu, egt_lib):
         outs.append((h2.detach(), e2.detach(), hh.grad, ee.grad, blk.dense_qkv.kernel.grad, blk.dense_edge_r.bias.grad))
     for n, u, v in zip(("h", "e", "dh", "de", "dWqkv", "dbr"), *outs):
         assert_close(u, v, name=n, rtol=1e-3, arel=2e-4, floor=0.1)
+
+
+@pytest.mark.parametrize("N,De,Dh,train,Ly", [(32, 64, 64, True, 3), (20, 8, 64, False, 2), (37, 48, 48, True, 2),
+                                              (64, 64, 64, False, 1)])
+def test_stack_bf16_edge_tensors_vs_oracle(N, De, Dh, train, Ly, gpu, egt_lib):
+    """EGT_BF16 (BASELINE config 3's dtype): e / e' / de' / de are bfloat16 in HBM, arithmetic fp32.
+    The fp64 oracle gets the SAME bf16-rounded inputs; tolerance is SURVEY §8(c)'s bf16 figure
+    (rtol 2e-2, plus the rounding of the intermediate e_l the oracle does not do)."""
+    from egt_amd import EGTStack
+    from egt_amd.fused import layer_seed
+    from oracle import egt_oracle as O, rng_ref
+    B, p = 2, 0.2
+    torch.manual_seed(23)
+    st = EGTStack(model_height=Ly, model_width=Dh, edge_width=De, num_heads=8,
+                  random_mask_prob=p if train else 0.0, seed=9, fused=True).to(gpu).train(train)
+    with torch.no_grad():
+        for prm in st.parameters():
+            if prm.dim() == 1:
+                prm.add_(0.2 * torch.randn_like(prm))
+    g = torch.Generator().manual_seed(N * 5 + De)
+    h = torch.randn(B, N, Dh, generator=g)
+    e = (torch.randn(B, N, N, De, generator=g) * 1.3).bfloat16()
+    mask = torch.ones(B, N, dtype=torch.bool); mask[1, N - 3:] = False
+    dh = torch.randn(B, N, Dh, generator=g); de = torch.randn(B, N, N, De, generator=g).bfloat16()
+    hg = h.to(gpu).requires_grad_(); eg = e.to(gpu).requires_grad_()
+    h2, e2 = st(hg, eg, mask.to(gpu))
+    assert e2.dtype == torch.bfloat16 and h2.dtype == torch.float32
+    assert st.last_path == "fused-stack"
+    torch.autograd.backward([h2, e2], [dh.to(gpu), de.to(gpu)])
+    assert eg.grad.dtype == torch.bfloat16
+    layers = [{k: getattr(getattr(blk, m), a_).detach().double().cpu().requires_grad_()
+               for k, (m, a_) in PMAP.items()} for blk in st.blocks]
+    rms = None
+    if train:
+        b0 = st.blocks[0].mha
+        seed = (b0.seed * 0x9E3779B97F4A7C15 + b0._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        rms = [torch.from_numpy(rng_ref.random_mask(layer_seed(seed, l), B, N, 8, p)) for l in range(Ly)]
+    h64 = h.double().requires_grad_(); e64 = e.double().requires_grad_()
+    ho, eo = O.stack_forward(h64, e64, mask, layers, num_heads=8, rand_masks=rms)
+    flat = [t for lp in layers for t in lp.values()]
+    gr = torch.autograd.grad([ho, eo], [h64, e64] + flat, [dh.double(), de.double()])
+    tol = dict(rtol=2e-2, arel=1e-2)
+    assert_close(h2, ho, name="h_out", **tol)
+    assert_close(e2.float(), eo, name="e_out", **tol)
+    assert_close(hg.grad, gr[0], name="dh", **tol)
+    assert_close(eg.grad.float(), gr[1], name="de", **tol)
+    gi = iter(gr[2:])
+    for li, blk in enumerate(st.blocks):
+        for k, (m, a_) in PMAP.items():
+            assert_close(getattr(getattr(blk, m), a_).grad, next(gi), name=f"L{li}.{k}", rtol=3e-2, arel=2e-2, floor=0.1)
+
+
+def test_block_bf16_single_block_and_dtype_errors(gpu, egt_lib):
+    """single-block C call with bf16 edge tensors; a bf16 caller of h gets bf16 back."""
+    from egt_amd import EGTBlock
+    torch.manual_seed(3)
+    blk = EGTBlock(model_width=64, edge_width=64, num_heads=8, fused=True).to(gpu).eval()
+    B, N = 2, 32
+    h = torch.randn(B, N, 64, device=gpu); e = torch.randn(B, N, N, 64, device=gpu)
+    mask = torch.ones(B, N, dtype=torch.bool, device=gpu)
+    h32, e32 = blk(h, e.bfloat16().float(), mask)
+    hb, eb = blk(h.bfloat16(), e.bfloat16(), mask)
+    assert hb.dtype == torch.bfloat16 and eb.dtype == torch.bfloat16
+    assert_close(eb.float(), e32, name="e_out(bf16 vs fp32 on rounded input)", rtol=1e-2, arel=5e-3)
