@@ -48,6 +48,18 @@ class BlockDesc(C.Structure):
                 ("reserved", C.c_int32), ("seed", C.c_uint64)]
 
 
+class FfnDesc(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("width", C.c_int32), ("dtype", C.c_int32),
+                ("activation", C.c_int32), ("ln_eps", C.c_float)]
+
+
+FFN_PARAM_FIELDS = ("norm_gamma", "norm_beta", "lr1_kernel", "lr1_bias", "lr2_kernel", "lr2_bias")
+
+
+class FfnParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in FFN_PARAM_FIELDS]
+
+
 BLOCK_PARAM_FIELDS = (
     "norm_edge_gamma", "norm_edge_beta",
     "attention_gates_kernel", "attention_gates_bias",
@@ -108,6 +120,11 @@ _OPTIONAL_PROTOS = {
     "egt_stack_fwd": (C.c_int, [C.POINTER(BlockDesc), C.c_int32, C.POINTER(BlockParams)] + [_VP] * 9),
     "egt_stack_bwd": (C.c_int, [C.POINTER(BlockDesc), C.c_int32, C.POINTER(BlockParams)] + [_VP] * 9
                       + [C.POINTER(BlockParams)] + [_VP] * 2),
+    "egt_ffn_supported": (C.c_int, [C.POINTER(FfnDesc)]),
+    "egt_ffn_workspace_bytes": (C.c_size_t, [C.POINTER(FfnDesc)]),
+    "egt_ffn_fwd": (C.c_int, [C.POINTER(FfnDesc), C.POINTER(FfnParams)] + [_VP] * 4),
+    "egt_ffn_bwd": (C.c_int, [C.POINTER(FfnDesc), C.POINTER(FfnParams)] + [_VP] * 3
+                    + [C.POINTER(FfnParams)] + [_VP] * 2),
 }
 
 

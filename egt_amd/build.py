@@ -16,8 +16,13 @@ REPO = os.path.dirname(ROOT)
 CSRC = os.path.join(ROOT, "csrc")
 LIBDIR = os.path.join(ROOT, "lib")
 LIB = os.path.join(LIBDIR, "libegt_amd.so")
-SOURCES = ["egt_capi.hip", "egt_attn.hip", "egt_attn_mfma.hip", "egt_edge.hip", "egt_block.hip", "egt_node.hip"]
+SOURCES = ["egt_capi.hip", "egt_attn.hip", "egt_attn_mfma.hip", "egt_edge.hip", "egt_block.hip", "egt_node.hip", "egt_ffn.hip"]
 ARCH = "gfx950"
+# per-source compiler flags.  egt_ffn.hip: the backward keeps 256 weight-gradient accumulator
+# registers per wave; with hipcc's default (AGPR-form MFMA everywhere) the short-lived GEMM
+# accumulators compete for the same 256 AccVGPRs and 300+ registers spill; VGPR-form MFMA lets
+# the allocator park the long-lived tiles in AccVGPRs instead (0 spills).
+EXTRA_FLAGS = {"egt_ffn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -59,6 +64,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(o)
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o,
                "-I", CSRC, "-I", os.path.join(REPO, "include"), "-Wno-unused-result"]
+        cmd += EXTRA_FLAGS.get(os.path.basename(s), [])
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -28,181 +28,7 @@
 #include <stdlib.h>
 
 #include "egt_block.h"
-
-template <int DE>
-__device__ __forceinline__ int swz(int row) { return DE == 64 ? (row & 15) : 0; }
-
-// LDS hand-offs inside one wavefront: DS operations of a wave complete in order,
-// so draining lgkmcnt (never vmcnt: global loads/stores stay in flight) plus a
-// scheduling barrier is all the ordering the tile round-trips need.
-__device__ __forceinline__ void lds_sync() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
-
-// ------------------------------------------------------------ tile helpers -----
-template <int DE>
-struct TileRegs { float4 v[(Geo<DE>::NF4 + 63) / 64]; };
-
-// issue the coalesced 16-byte loads of one 16-pair tile; rows >= rows_valid are
-// redirected to row 0 (always valid) so every load is unconditional
-template <int DE>
-__device__ __forceinline__ void tile_gload(TileRegs<DE>& r, const float* src, int lane, int rows_valid) {
-  using G = Geo<DE>;
-  constexpr int NI = (G::NF4 + 63) / 64;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    int f = i * 64 + lane;
-    if (G::NF4 < 64) f &= (G::NF4 - 1);
-    const int row = f / G::NSLOT;
-    const int fc = row < rows_valid ? f : f - row * G::NSLOT;
-    r.v[i] = *reinterpret_cast<const float4*>(src + (size_t)fc * 4);
-  }
-}
-template <int DE>
-__device__ __forceinline__ void tile_lds_put(float* tl, const TileRegs<DE>& r, int lane, int rows_valid) {
-  using G = Geo<DE>;
-  constexpr int NI = (G::NF4 + 63) / 64;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int f = i * 64 + lane;
-    if (G::NF4 >= 64 || f < G::NF4) {
-      const int row = f / G::NSLOT, slot = f % G::NSLOT;
-      const bool ok = row < rows_valid;
-      float4 v = r.v[i];
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      *reinterpret_cast<float4*>(tl + row * DE + ((slot ^ swz<DE>(row)) << 2)) = v;
-    }
-  }
-}
-template <int DE>
-__device__ __forceinline__ void tile_from_lds(const float* tl, float* dst, int lane, int rows_valid) {
-  using G = Geo<DE>;
-  constexpr int NI = (G::NF4 + 63) / 64;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int f = i * 64 + lane;
-    if (G::NF4 >= 64 || f < G::NF4) {
-      const int row = f / G::NSLOT, slot = f % G::NSLOT;
-      if (row < rows_valid)
-        *reinterpret_cast<float4*>(dst + (size_t)f * 4) =
-            *reinterpret_cast<const float4*>(tl + row * DE + ((slot ^ swz<DE>(row)) << 2));
-    }
-  }
-}
-
-// ---- bf16 edge tensors (desc.dtype == EGT_BF16): same tiles, 8-byte global accesses; the
-// arithmetic, the LDS tiles and everything node-side stay fp32 ----
-__device__ __forceinline__ float4 bf4_to_f4(uint2 u) {
-  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
-                     __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
-}
-__device__ __forceinline__ uint32_t f_to_bf(float f) {   // round to nearest even (NaN stays NaN)
-  uint32_t u = __float_as_uint(f);
-  const uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u);
-  return ((u & 0x7FFFFFFFu) > 0x7F800000u) ? ((u >> 16) | 0x40u) : (r >> 16);
-}
-__device__ __forceinline__ uint2 f4_to_bf4(float4 v) {
-  return make_uint2(f_to_bf(v.x) | (f_to_bf(v.y) << 16), f_to_bf(v.z) | (f_to_bf(v.w) << 16));
-}
-template <int DE>
-__device__ __forceinline__ void tile_gload(TileRegs<DE>& r, const uint16_t* src, int lane, int rows_valid) {
-  using G = Geo<DE>;
-  constexpr int NI = (G::NF4 + 63) / 64;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    int f = i * 64 + lane;
-    if (G::NF4 < 64) f &= (G::NF4 - 1);
-    const int row = f / G::NSLOT;
-    const int fc = row < rows_valid ? f : f - row * G::NSLOT;
-    r.v[i] = bf4_to_f4(*reinterpret_cast<const uint2*>(src + (size_t)fc * 4));
-  }
-}
-template <int DE>
-__device__ __forceinline__ void tile_from_lds(const float* tl, uint16_t* dst, int lane, int rows_valid) {
-  using G = Geo<DE>;
-  constexpr int NI = (G::NF4 + 63) / 64;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int f = i * 64 + lane;
-    if (G::NF4 >= 64 || f < G::NF4) {
-      const int row = f / G::NSLOT, slot = f % G::NSLOT;
-      if (row < rows_valid)
-        *reinterpret_cast<uint2*>(dst + (size_t)f * 4) =
-            f4_to_bf4(*reinterpret_cast<const float4*>(tl + row * DE + ((slot ^ swz<DE>(row)) << 2)));
-    }
-  }
-}
-template <bool BF> struct EdgeT { typedef float type; };
-template <> struct EdgeT<true> { typedef uint16_t type; };
-
-template <int DE>
-__device__ __forceinline__ void tile_lds_get(const float* tl, TileRegs<DE>& r, int lane) {
-  using G = Geo<DE>;
-  constexpr int NI = (G::NF4 + 63) / 64;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    int f = i * 64 + lane;
-    if (G::NF4 < 64) f &= (G::NF4 - 1);
-    const int row = f / G::NSLOT, slot = f % G::NSLOT;
-    r.v[i] = *reinterpret_cast<const float4*>(tl + row * DE + ((slot ^ swz<DE>(row)) << 2));
-  }
-}
-template <int DE>
-__device__ __forceinline__ void tile_gstore(const TileRegs<DE>& r, float* dst, int lane, int rows_valid) {
-  using G = Geo<DE>;
-  constexpr int NI = (G::NF4 + 63) / 64;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int f = i * 64 + lane;
-    if ((G::NF4 >= 64 || f < G::NF4) && f / G::NSLOT < rows_valid)
-      *reinterpret_cast<float4*>(dst + (size_t)f * 4) = r.v[i];
-  }
-}
-
-// fragment (p,q): channels 16*t + 4*q + {0..3}
-template <int DE>
-__device__ __forceinline__ float4 frag_read(const float* tl, int p, int q, int t) {
-  if (16 * t + 4 * q < DE)
-    return *reinterpret_cast<const float4*>(tl + p * DE + (((4 * t + q) ^ swz<DE>(p)) << 2));
-  return make_float4(0.f, 0.f, 0.f, 0.f);
-}
-template <int DE>
-__device__ __forceinline__ void frag_write(float* tl, int p, int q, int t, float4 v) {
-  if (16 * t + 4 * q < DE)
-    *reinterpret_cast<float4*>(tl + p * DE + (((4 * t + q) ^ swz<DE>(p)) << 2)) = v;
-}
-template <int DE>
-__device__ __forceinline__ float elem_read(const float* tl, int row, int c) {
-  return tl[row * DE + ((((c >> 2) ^ swz<DE>(row)) << 2) | (c & 3))];
-}
-
-__device__ __forceinline__ float sum_over_q(float v) {  // lanes p, p+16, p+32, p+48
-  return sum_xor32(sum_xor16(v));
-}
-
-// LayerNorm of the lane's fragments (two-pass moments like tf.nn.moments); returns rstd
-template <int DE>
-__device__ __forceinline__ float ln_frags(float4 (&x)[Geo<DE>::TILES], int q, float eps) {
-  using G = Geo<DE>;
-  float s = 0.f;
-#pragma unroll
-  for (int t = 0; t < G::TILES; ++t) s += (x[t].x + x[t].y) + (x[t].z + x[t].w);
-  const float mu = sum_over_q(s) * (1.0f / DE);
-  float v = 0.f;
-#pragma unroll
-  for (int t = 0; t < G::TILES; ++t) {
-    if (16 * t + 4 * q < DE) {
-      x[t].x -= mu; x[t].y -= mu; x[t].z -= mu; x[t].w -= mu;
-      v = fmaf(x[t].x, x[t].x, v); v = fmaf(x[t].y, x[t].y, v);
-      v = fmaf(x[t].z, x[t].z, v); v = fmaf(x[t].w, x[t].w, v);
-    }
-  }
-  const float rstd = rsqrtf(sum_over_q(v) * (1.0f / DE) + eps);
-#pragma unroll
-  for (int t = 0; t < G::TILES; ++t) { x[t].x *= rstd; x[t].y *= rstd; x[t].z *= rstd; x[t].w *= rstd; }
-  return rstd;
-}
+#include "egt_tile.h"
 
 // 16 projection columns of the lane's pair: acc[r] = column 4q+r
 template <int DE>

@@ -1,0 +1,545 @@
+// Fused channel FFN of the reference's ffn_block, for gfx950:
+//   y = x + Dense_2( act( Dense_1( LayerNorm(x) ) ) )        width W = 64, hidden 2W = 128
+//   lib/models/graph_xformer_model_base.py:230-258 (ffnlr1 / ffnact / ffnlr2, pre-norm, no
+//   cross-talk), applied to the edge channels [B,N,N,De] and the node channels [B,N,Dh] (:309-324).
+// At De = 64 this is the largest FLOP consumer of the model (24*W^2 flop per row fwd+bwd) and
+// a true dense contraction: MFMA-bound (fp32 v_mfma_f32_16x16x4_f32, 256 flop/clk/CU).
+//
+// One wave owns 16 rows ("tile": 4 KiB of contiguous HBM).  Rows sit on the MFMA COLUMN axis
+// and the weights are the A operand, so (as in egt_block.hip) lane (p = lane&15, q = lane>>4)
+// keeps row p's channels 16t + 4q + {0..3}: the accumulator layout of the first GEMM IS the B
+// operand layout of the second one (contraction order kappa = 16j + 4q + u on both operands) --
+// the 128 hidden activations of a row never leave the registers of its four lanes.  The
+// LN-folded weights live in LDS as [tile][k-tile][lane] float4 slabs (conflict-free
+// ds_read_b128, four contraction steps per read), built once per call by k_ffn_prep.
+//   forward : 256 MFMA / tile, 2 waves per SIMD, tiles streamed through ping-pong LDS buffers.
+//   backward: recompute + dHid + dXhat (384 MFMA) and the two weight-gradient contractions over
+//             the row axis (256 MFMA) in ONE kernel: 1 wave per SIMD so that a wave owns 512
+//             registers and keeps all 64 weight-gradient tiles (256 accumulator registers)
+//             for its whole row range; per-workgroup partials are reduced deterministically.
+#include <stdlib.h>
+
+#include "egt_tile.h"
+
+#define FW 64
+#define FH 128
+#define SLABF (FW * FH)   // floats per weight slab (32 KiB)
+#define FFN_PART (2 * SLABF + FH + FW)   // T1 | T2 | s1 | s2
+
+struct FfnArgs {
+  long rows;
+  float ln_eps;
+  const float *x, *dy;
+  float *y, *dx;
+  // parameters (Keras layout: kernel [in,out])
+  const float *gamma, *beta, *W1, *b1, *W2, *b2;
+  // prepared operands (workspace)
+  float *slab1, *slab2, *slab3, *slab4, *b1p;
+  float *part, *red;   // backward: per-workgroup partials, reduced sums
+  float *g_gamma, *g_beta, *g_W1, *g_b1, *g_W2, *g_b2;
+  int nwg;
+  int guard;   // always 0: opaque phase guards of the backward (see k_ffn_bwd)
+};
+
+// slab1[j][t][lane].u = gamma[c] W1[c][16j+pl],            c = 16t+4q+u     (A operand of  pre  = W1p^T . xhat)
+// slab2[i][j][lane].u = W2[16j+4q+u][16i+pl]                                (A operand of  y    = W2^T . hid)
+// slab3[j][t][lane].u = W2[16j+pl][16t+4q+u]                                (A operand of  dhid = W2 . dy)
+// slab4[i][j][lane].u = gamma[16i+pl] W1[16i+pl][16j+4q+u]                  (A operand of  dxhat= W1p . dpre)
+// b1p[h] = b1[h] + sum_c beta[c] W1[c][h]
+__global__ void __launch_bounds__(256) k_ffn_prep(FfnArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < SLABF) {
+    const int u = idx & 3, lane = (idx >> 2) & 63, pl = lane & 15, q = lane >> 4;
+    {
+      const int t = (idx >> 8) & 3, j = idx >> 10;
+      const int c = 16 * t + 4 * q + u;
+      a.slab1[idx] = a.gamma[c] * a.W1[c * FH + 16 * j + pl];
+      a.slab3[idx] = a.W2[(16 * j + pl) * FW + c];
+    }
+    {
+      const int j = (idx >> 8) & 7, i = idx >> 11;
+      const int hc = 16 * j + 4 * q + u;
+      a.slab2[idx] = a.W2[hc * FW + 16 * i + pl];
+      a.slab4[idx] = a.gamma[16 * i + pl] * a.W1[(16 * i + pl) * FH + hc];
+    }
+  }
+  if (idx < FH) {
+    float s = a.b1[idx];
+    for (int c = 0; c < FW; ++c) s = fmaf(a.beta[c], a.W1[c * FH + idx], s);
+    a.b1p[idx] = s;
+  }
+}
+
+template <int ACT>   // EGT_ACT_RELU (2), EGT_ACT_ELU (3, Keras default alpha = 1)
+__device__ __forceinline__ float ffn_act(float v) {
+  if (ACT == EGT_ACT_RELU) return fmaxf(v, 0.f);
+  return v > 0.f ? v : __expf(v) - 1.0f;
+}
+template <int ACT>   // derivative from the activation's OUTPUT (hid > 0 <=> pre > 0 for both)
+__device__ __forceinline__ float ffn_dact(float hid) {
+  if (ACT == EGT_ACT_RELU) return hid > 0.f ? 1.f : 0.f;
+  return hid > 0.f ? 1.f : hid + 1.0f;
+}
+
+__device__ __forceinline__ void slab_to_lds(float* dst, const float* src, int nthreads) {
+  for (int i = threadIdx.x; i < SLABF / 4; i += nthreads)
+    reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+}
+
+// pre-activation tile j of the lane's row: W1p^T . xhat + b1p   (16 MFMA)
+__device__ __forceinline__ v4f ffn_gemm1(const float* s1, const float* b1s, const float4 (&x)[4], int j, int lane, int q) {
+  const float4 bj = *reinterpret_cast<const float4*>(b1s + 16 * j + 4 * q);
+  v4f acc = {bj.x, bj.y, bj.z, bj.w};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float4 w = *reinterpret_cast<const float4*>(s1 + ((j * 4 + t) * 64 + lane) * 4);
+    acc = MFMA(w.x, x[t].x, acc);
+    acc = MFMA(w.y, x[t].y, acc);
+    acc = MFMA(w.z, x[t].z, acc);
+    acc = MFMA(w.w, x[t].w, acc);
+  }
+  return acc;
+}
+
+// ================================================================== forward =====
+template <int ACT>
+__global__ void __launch_bounds__(512, 2) k_ffn_fwd(FfnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s1 = sm;
+  float* s2 = s1 + SLABF;
+  float* b1s = s2 + SLABF;          // [128]
+  float* b2s = b1s + FH;            // [64]
+  float* tiles = b2s + FW;          // [8 waves][2][1024]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = lane & 15, q = lane >> 4;
+  slab_to_lds(s1, a.slab1, 512);
+  slab_to_lds(s2, a.slab2, 512);
+  if (threadIdx.x < FH) b1s[threadIdx.x] = a.b1p[threadIdx.x];
+  if (threadIdx.x < FW) b2s[threadIdx.x] = a.b2[threadIdx.x];
+  __syncthreads();
+  float* tl0 = tiles + wave * 2 * 1024;
+  const long ntiles = (a.rows + 15) / 16;
+  const long stride = (long)gridDim.x * 8;
+  long tile = (long)blockIdx.x * 8 + wave;
+  TileRegs<FW> tr;
+  if (tile < ntiles) tile_gload<FW>(tr, a.x + tile * 1024, lane, (int)min(16L, a.rows - tile * 16));
+  long prev = -1;
+  for (int it = 0; tile < ntiles; tile += stride, ++it) {
+    const int rows_valid = (int)min(16L, a.rows - tile * 16);
+    float* tl = tl0 + (it & 1) * 1024;
+    lds_sync();
+    if (prev >= 0)   // stream out the previous tile's y from the other buffer
+      tile_from_lds<FW>(tl0 + ((it - 1) & 1) * 1024, a.y + prev * 1024, lane, (int)min(16L, a.rows - prev * 16));
+    tile_lds_put<FW>(tl, tr, lane, rows_valid);
+    const long nxt = tile + stride;
+    if (nxt < ntiles) tile_gload<FW>(tr, a.x + nxt * 1024, lane, (int)min(16L, a.rows - nxt * 16));
+    lds_sync();
+    float4 x[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[t] = frag_read<FW>(tl, p, q, t);
+    ln_frags<FW>(x, q, a.ln_eps);                                   // norm_fnn (gamma/beta folded into the weights)
+    v4f h[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                                    // fnn_lr1 + activation
+      const v4f pre = ffn_gemm1(s1, b1s, x, j, lane, q);
+      h[j] = (v4f){ffn_act<ACT>(pre[0]), ffn_act<ACT>(pre[1]), ffn_act<ACT>(pre[2]), ffn_act<ACT>(pre[3])};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                    // fnn_lr2 + res_fnn
+      const float4 xr = frag_read<FW>(tl, p, q, i);
+      const float4 b = *reinterpret_cast<const float4*>(b2s + 16 * i + 4 * q);
+      v4f acc = {xr.x + b.x, xr.y + b.y, xr.z + b.z, xr.w + b.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 w = *reinterpret_cast<const float4*>(s2 + ((i * 8 + j) * 64 + lane) * 4);
+        acc = MFMA(w.x, h[j][0], acc);
+        acc = MFMA(w.y, h[j][1], acc);
+        acc = MFMA(w.z, h[j][2], acc);
+        acc = MFMA(w.w, h[j][3], acc);
+      }
+      frag_write<FW>(tl, p, q, i, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    }
+    prev = tile;
+    if (nxt >= ntiles) {   // last tile of this wave: flush
+      lds_sync();
+      tile_from_lds<FW>(tl, a.y + tile * 1024, lane, rows_valid);
+    }
+  }
+}
+
+// ================================================================= backward =====
+template <int ACT>
+__global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s1 = sm;
+  float* s3 = s1 + SLABF;
+  float* s4 = s3 + SLABF;
+  float* b1s = s4 + SLABF;          // [128]
+  float* tiles = b1s + FH;          // [4 waves][x | dy | hid/dpre half][1024]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p0 = lane & 15, q0 = lane >> 4;
+  slab_to_lds(s1, a.slab1, 256);
+  slab_to_lds(s3, a.slab3, 256);
+  slab_to_lds(s4, a.slab4, 256);
+  if (threadIdx.x < FH) b1s[threadIdx.x] = a.b1p[threadIdx.x];
+  __syncthreads();
+  float* et = tiles + wave * 3 * 1024;
+  float* dt = et + 1024;
+  float* hd = dt + 1024;
+  v4f accT1[32], accT2[32];   // T1[in 16t+4q+r][hid 16j+pl] = accT1[t*8+j][r] ; T2[hid 16j+4q+r][out 16i+pl] = accT2[j*4+i][r]
+#pragma unroll
+  for (int k = 0; k < 32; ++k) { accT1[k] = (v4f){0.f, 0.f, 0.f, 0.f}; accT2[k] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+  v4f sp[8];                  // per-lane sums of dpre (hid 16j+4q+r)
+  float4 sd[4];               // per-lane sums of dy   (out 16t+4q+r)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sp[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) sd[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  const long ntiles = (a.rows + 15) / 16;
+  const long stride = (long)gridDim.x * 4;
+  long tile = (long)blockIdx.x * 4 + wave;
+  TileRegs<FW> te, td;
+  if (tile < ntiles) {
+    const int rv = (int)min(16L, a.rows - tile * 16);
+    tile_gload<FW>(te, a.x + tile * 1024, lane, rv);
+    tile_gload<FW>(td, a.dy + tile * 1024, lane, rv);
+  }
+  long prev = -1;
+  for (; tile < ntiles; tile += stride) {
+    const int rows_valid = (int)min(16L, a.rows - tile * 16);
+    lds_sync();
+    if (prev >= 0) tile_from_lds<FW>(dt, a.dx + prev * 1024, lane, (int)min(16L, a.rows - prev * 16));   // dx of the previous tile
+    lds_sync();
+    tile_lds_put<FW>(et, te, lane, rows_valid);     // rows past the end are zero: they add nothing to the sums
+    tile_lds_put<FW>(dt, td, lane, rows_valid);
+    const long nxt = tile + stride;
+    if (nxt < ntiles) {
+      const int rv = (int)min(16L, a.rows - nxt * 16);
+      tile_gload<FW>(te, a.x + nxt * 1024, lane, rv);
+      tile_gload<FW>(td, a.dy + nxt * 1024, lane, rv);
+    }
+    lds_sync();
+    // The phases below sit behind opaque always-true guards (a.guard == 0): the uniform branches
+    // split the tile body into basic blocks so that hipcc keeps every phase's operands local
+    // (re-read from the LDS tiles) instead of stretching 200+ live registers across the tile.
+    // ---- recompute: xhat, hid ----
+    float rstd;
+    v4f h[8], dp[8];
+    {
+      int p = p0, q = q0;
+      asm volatile("" : "+v"(p), "+v"(q));   // keep this phase's LDS address math inside the phase (no hoisting out of the tile loop)
+      float4 x[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) x[t] = frag_read<FW>(et, p, q, t);
+      rstd = ln_frags<FW>(x, q, a.ln_eps);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) frag_write<FW>(et, p, q, t, x[t]);   // xhat: A operand of T1 (other rows) + LN backward
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const v4f pre = ffn_gemm1(s1, b1s, x, j, lane, q);
+        h[j] = (v4f){ffn_act<ACT>(pre[0]), ffn_act<ACT>(pre[1]), ffn_act<ACT>(pre[2]), ffn_act<ACT>(pre[3])};
+      }
+    }
+    lds_sync();
+    // ---- dhid = W2 . dy ; dpre = dhid * act'(pre) ----
+    if (a.guard == 0) {
+      int p = p0, q = q0;
+      asm volatile("" : "+v"(p), "+v"(q));   // keep this phase's LDS address math inside the phase (no hoisting out of the tile loop)
+      float4 dyf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        dyf[t] = frag_read<FW>(dt, p, q, t);
+        sd[t].x += dyf[t].x; sd[t].y += dyf[t].y; sd[t].z += dyf[t].z; sd[t].w += dyf[t].w;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float4 w = *reinterpret_cast<const float4*>(s3 + ((j * 4 + t) * 64 + lane) * 4);
+          acc = MFMA(w.x, dyf[t].x, acc);
+          acc = MFMA(w.y, dyf[t].y, acc);
+          acc = MFMA(w.z, dyf[t].z, acc);
+          acc = MFMA(w.w, dyf[t].w, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] *= ffn_dact<ACT>(h[j][r]);
+        dp[j] = acc;
+        sp[j] += acc;
+      }
+    }
+    // ---- weight gradients: contractions over the 16 rows of the tile (row index rho = q + 4s) ----
+    if (a.guard == 0) {                             // T2 += hid^T . dy
+      int p = p0, q = q0;
+      asm volatile("" : "+v"(p), "+v"(q));   // keep this phase's LDS address math inside the phase (no hoisting out of the tile loop)
+      float bdy[4][4];   // dy[rho][16i+pl]
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bdy[i][s] = elem_read<FW>(dt, q + 4 * s, 16 * i + p);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        lds_sync();
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          frag_write<FW>(hd, p, q, jj, make_float4(h[4 * half + jj][0], h[4 * half + jj][1], h[4 * half + jj][2], h[4 * half + jj][3]));
+        lds_sync();
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float ah = elem_read<FW>(hd, q + 4 * s, 16 * jj + p);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accT2[(4 * half + jj) * 4 + i] = MFMA(ah, bdy[i][s], accT2[(4 * half + jj) * 4 + i]);
+          }
+      }
+    }
+    if (a.guard == 0) {                             // T1 += xhat^T . dpre
+      int p = p0, q = q0;
+      asm volatile("" : "+v"(p), "+v"(q));   // keep this phase's LDS address math inside the phase (no hoisting out of the tile loop)
+      float axh[4][4];   // xhat[rho][16t+pl]
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) axh[t][s] = elem_read<FW>(et, q + 4 * s, 16 * t + p);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        lds_sync();
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          frag_write<FW>(hd, p, q, jj, make_float4(dp[4 * half + jj][0], dp[4 * half + jj][1], dp[4 * half + jj][2], dp[4 * half + jj][3]));
+        lds_sync();
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float bd = elem_read<FW>(hd, q + 4 * s, 16 * jj + p);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) accT1[t * 8 + 4 * half + jj] = MFMA(axh[t][s], bd, accT1[t * 8 + 4 * half + jj]);
+          }
+      }
+    }
+    // ---- dxhat = W1p . dpre ; LayerNorm backward ; dx = dy + ... (in place over the dy tile) ----
+    if (a.guard == 0) {
+      int p = p0, q = q0;
+      asm volatile("" : "+v"(p), "+v"(q));   // keep this phase's LDS address math inside the phase (no hoisting out of the tile loop)
+      float4 dxh[4], x[4];
+      float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        x[i] = frag_read<FW>(et, p, q, i);          // xhat
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float4 w = *reinterpret_cast<const float4*>(s4 + ((i * 8 + j) * 64 + lane) * 4);
+          acc = MFMA(w.x, dp[j][0], acc);
+          acc = MFMA(w.y, dp[j][1], acc);
+          acc = MFMA(w.z, dp[j][2], acc);
+          acc = MFMA(w.w, dp[j][3], acc);
+        }
+        dxh[i] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        m1 += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        m2 = fmaf(acc[0], x[i].x, m2); m2 = fmaf(acc[1], x[i].y, m2);
+        m2 = fmaf(acc[2], x[i].z, m2); m2 = fmaf(acc[3], x[i].w, m2);
+      }
+      m1 = sum_over_q(m1) * (1.0f / FW);
+      m2 = sum_over_q(m2) * (1.0f / FW);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 dyv = frag_read<FW>(dt, p, q, i);
+        float4 o;
+        o.x = dyv.x + rstd * (dxh[i].x - m1 - x[i].x * m2);
+        o.y = dyv.y + rstd * (dxh[i].y - m1 - x[i].y * m2);
+        o.z = dyv.z + rstd * (dxh[i].z - m1 - x[i].z * m2);
+        o.w = dyv.w + rstd * (dxh[i].w - m1 - x[i].w * m2);
+        frag_write<FW>(dt, p, q, i, o);
+      }
+    }
+    prev = tile;
+  }
+  lds_sync();
+  if (prev >= 0) tile_from_lds<FW>(dt, a.dx + prev * 1024, lane, (int)min(16L, a.rows - prev * 16));
+
+  // ---- per-workgroup partial: the four waves add their tiles into ONE LDS image, one wave
+  //      after the other (same lane -> same element in every wave: fixed summation order) ----
+  const int p = p0, q = q0;
+  __syncthreads();
+  float* red = sm;   // [FFN_PART] = 65 KiB over the (now idle) slabs
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      const bool first = w == 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* d = red + (16 * t + 4 * q + r) * FH + 16 * j + p;
+            *d = first ? accT1[t * 8 + j][r] : *d + accT1[t * 8 + j][r];
+          }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* d = red + SLABF + (16 * j + 4 * q + r) * FW + 16 * i + p;
+            *d = first ? accT2[j * 4 + i][r] : *d + accT2[j * 4 + i][r];
+          }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = row_sum16(sp[j][r]);
+          float* d = red + 2 * SLABF + 16 * j + 4 * q + r;
+          if (p == 0) *d = first ? v : *d + v;
+        }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float v[4] = {row_sum16(sd[t].x), row_sum16(sd[t].y), row_sum16(sd[t].z), row_sum16(sd[t].w)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* d = red + 2 * SLABF + FH + 16 * t + 4 * q + r;
+          if (p == 0) *d = first ? v[r] : *d + v[r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* out = a.part + (size_t)blockIdx.x * FFN_PART;
+  for (int i = threadIdx.x; i < FFN_PART; i += 256) out[i] = red[i];
+}
+
+// deterministic sum over the workgroup partials: 64 outputs per workgroup, partial axis over 4 waves
+__global__ void __launch_bounds__(256) k_ffn_sum(FfnArgs a) {
+  __shared__ float red[4][64];
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
+  float v0 = 0.f, v1 = 0.f;
+  if (o < FFN_PART) {
+    int pi = pg;
+    for (; pi + 4 < a.nwg; pi += 8) {
+      v0 += a.part[(size_t)pi * FFN_PART + o];
+      v1 += a.part[(size_t)(pi + 4) * FFN_PART + o];
+    }
+    for (; pi < a.nwg; pi += 4) v0 += a.part[(size_t)pi * FFN_PART + o];
+  }
+  red[pg][threadIdx.x & 63] = v0 + v1;
+  __syncthreads();
+  if (pg == 0 && o < FFN_PART)
+    a.red[o] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// T1 = sum xhat^T.dpre, s1 = sum dpre, T2 = sum hid^T.dy, s2 = sum dy  ->  parameter gradients
+//   dW1[c][h] = gamma_c T1[c][h] + beta_c s1[h] ; dgamma_c = sum_h W1[c][h] T1[c][h] ; dbeta_c = sum_h W1[c][h] s1[h]
+//   db1 = s1 ; dW2 = T2 ; db2 = s2
+__global__ void __launch_bounds__(256) k_ffn_param_grads(FfnArgs a) {
+  const float* T1 = a.red;
+  const float* T2 = a.red + SLABF;
+  const float* s1 = a.red + 2 * SLABF;
+  const float* s2 = s1 + FH;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < SLABF; i += gridDim.x * 256) {
+    a.g_W1[i] = fmaf(a.gamma[i / FH], T1[i], a.beta[i / FH] * s1[i % FH]);
+    a.g_W2[i] = T2[i];
+  }
+  if (blockIdx.x == 0) {
+    const int t = threadIdx.x;
+    if (t < FH) a.g_b1[t] = s1[t];
+    if (t < FW) {
+      a.g_b2[t] = s2[t];
+      float dg = 0.f, db = 0.f;
+      for (int h = 0; h < FH; ++h) {
+        const float w = a.W1[t * FH + h];
+        dg = fmaf(w, T1[t * FH + h], dg);
+        db = fmaf(w, s1[h], db);
+      }
+      a.g_gamma[t] = dg;
+      a.g_beta[t] = db;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host glue --
+#define FFN_NWG 256   // one backward workgroup per CU (4 waves, 1 per SIMD)
+
+static size_t ffn_al(size_t x) { return (x + 63) & ~(size_t)63; }
+
+extern "C" int egt_ffn_supported(const egt_ffn_desc* d) {
+  return d && d->dtype == EGT_F32 && d->width == FW && d->rows > 0 && (d->activation == EGT_ACT_RELU || d->activation == EGT_ACT_ELU);
+}
+
+// [slab1 slab2 slab3 slab4 b1p | red | part x FFN_NWG]
+extern "C" size_t egt_ffn_workspace_bytes(const egt_ffn_desc* d) {
+  if (!egt_ffn_supported(d)) return 0;
+  return (4 * (size_t)SLABF + ffn_al(FH) + ffn_al(FFN_PART) + (size_t)FFN_NWG * FFN_PART) * sizeof(float);
+}
+
+static int ffn_fill(const egt_ffn_desc* d, const egt_ffn_params* p, void* ws, FfnArgs& a) {
+  if (!d || !p || !ws) EGT_FAIL(EGT_E_NULL, "desc/params/workspace is NULL");
+  if (!egt_ffn_supported(d)) EGT_FAIL(EGT_E_SHAPE, "fused FFN covers width 64, fp32, relu/elu (got width %d, act %d)", d->width, d->activation);
+  if (!p->norm_gamma || !p->norm_beta || !p->lr1_kernel || !p->lr1_bias || !p->lr2_kernel || !p->lr2_bias)
+    EGT_FAIL(EGT_E_NULL, "an FFN parameter pointer is NULL");
+  a = FfnArgs{};
+  a.rows = d->rows; a.ln_eps = d->ln_eps;
+  a.gamma = (const float*)p->norm_gamma; a.beta = (const float*)p->norm_beta;
+  a.W1 = (const float*)p->lr1_kernel; a.b1 = (const float*)p->lr1_bias;
+  a.W2 = (const float*)p->lr2_kernel; a.b2 = (const float*)p->lr2_bias;
+  float* w = (float*)ws;
+  a.slab1 = w; a.slab2 = w + SLABF; a.slab3 = w + 2 * SLABF; a.slab4 = w + 3 * SLABF;
+  a.b1p = w + 4 * SLABF;
+  a.red = a.b1p + ffn_al(FH);
+  a.part = a.red + ffn_al(FFN_PART);
+  a.nwg = FFN_NWG;
+  return EGT_OK;
+}
+
+extern "C" int egt_ffn_fwd(const egt_ffn_desc* desc, const egt_ffn_params* params, const void* x, void* y,
+                           void* workspace, void* stream) {
+  FfnArgs a;
+  int rc = ffn_fill(desc, params, workspace, a);
+  if (rc) return rc;
+  if (!x || !y) EGT_FAIL(EGT_E_NULL, "x/y is NULL");
+  a.x = (const float*)x; a.y = (float*)y;
+  hipStream_t st = (hipStream_t)stream;
+  EGT_LAUNCH("k_ffn_prep", k_ffn_prep, dim3(SLABF / 256), dim3(256), 0, st, a);
+  const size_t lds = (2 * (size_t)SLABF + FH + FW + 8 * 2 * 1024) * 4;
+  const long ntiles = (a.rows + 15) / 16;
+  const int grid = (int)((ntiles + 7) / 8 < 256 ? (ntiles + 7) / 8 : 256);
+  if (desc->activation == EGT_ACT_RELU) {
+    (void)hipFuncSetAttribute((const void*)k_ffn_fwd<EGT_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_LAUNCH("k_ffn_fwd", k_ffn_fwd<EGT_ACT_RELU>, dim3(grid), dim3(512), lds, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)k_ffn_fwd<EGT_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_LAUNCH("k_ffn_fwd", k_ffn_fwd<EGT_ACT_ELU>, dim3(grid), dim3(512), lds, st, a);
+  }
+  EGT_HIP_LAUNCH_CHECK("egt_ffn_fwd");
+  return EGT_OK;
+}
+
+extern "C" int egt_ffn_bwd(const egt_ffn_desc* desc, const egt_ffn_params* params, const void* x, const void* dy,
+                           void* dx, const egt_ffn_params* grads, void* workspace, void* stream) {
+  FfnArgs a;
+  int rc = ffn_fill(desc, params, workspace, a);
+  if (rc) return rc;
+  if (!x || !dy || !dx || !grads) EGT_FAIL(EGT_E_NULL, "x/dy/dx/grads is NULL");
+  if (!grads->norm_gamma || !grads->norm_beta || !grads->lr1_kernel || !grads->lr1_bias || !grads->lr2_kernel || !grads->lr2_bias)
+    EGT_FAIL(EGT_E_NULL, "an FFN gradient pointer is NULL");
+  a.x = (const float*)x; a.dy = (const float*)dy; a.dx = (float*)dx;
+  a.g_gamma = (float*)grads->norm_gamma; a.g_beta = (float*)grads->norm_beta;
+  a.g_W1 = (float*)grads->lr1_kernel; a.g_b1 = (float*)grads->lr1_bias;
+  a.g_W2 = (float*)grads->lr2_kernel; a.g_b2 = (float*)grads->lr2_bias;
+  hipStream_t st = (hipStream_t)stream;
+  EGT_LAUNCH("k_ffn_prep", k_ffn_prep, dim3(SLABF / 256), dim3(256), 0, st, a);
+  const size_t lds = (3 * (size_t)SLABF + FH + 4 * 3 * 1024) * 4;
+  if (desc->activation == EGT_ACT_RELU) {
+    (void)hipFuncSetAttribute((const void*)k_ffn_bwd<EGT_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_LAUNCH("k_ffn_bwd", k_ffn_bwd<EGT_ACT_RELU>, dim3(FFN_NWG), dim3(256), lds, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)k_ffn_bwd<EGT_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_LAUNCH("k_ffn_bwd", k_ffn_bwd<EGT_ACT_ELU>, dim3(FFN_NWG), dim3(256), lds, st, a);
+  }
+  EGT_LAUNCH("k_ffn_sum", k_ffn_sum, dim3((FFN_PART + 63) / 64), dim3(256), 0, st, a);
+  EGT_LAUNCH("k_ffn_param_grads", k_ffn_param_grads, dim3(16), dim3(256), 0, st, a);
+  EGT_HIP_LAUNCH_CHECK("egt_ffn_bwd");
+  return EGT_OK;
+}

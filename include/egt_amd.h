@@ -284,6 +284,41 @@ int egt_stack_bwd(const egt_block_desc* desc, int32_t layers,
                   const void* d_h_out, const void* d_e_out, void* d_h, void* d_e,
                   const egt_block_params* grads, void* workspace, void* stream);
 
+/* ---- channel FFN (the step after the attention block in every layer) ----
+ * Replaces ffnlr1 / ffnact / ffnlr2 of lib/models/graph_xformer_model_base.py:230-258 as
+ * ffn_block applies them (:309-324; pre-norm, no cross-talk, ffn_multiplier = 2):
+ *   y = x + Dense_2( act( Dense_1( LayerNorm(x) ) ) )
+ * on `rows` rows of `width` channels: the edge channels [B*N*N, De] or the node channels
+ * [B*N, Dh].  Keras layouts: kernels are [in,out]; LayerNormalization epsilon = ln_eps.
+ * Fused MFMA kernels for width = 64, fp32, activation EGT_ACT_ELU (config default) or
+ * EGT_ACT_RELU; egt_ffn_supported says whether a desc is covered. */
+typedef struct egt_ffn_desc {
+  int64_t rows;
+  int32_t width;
+  int32_t dtype;      /* EGT_F32 */
+  int32_t activation; /* EGT_ACT_* (config.activation) */
+  float ln_eps;       /* 1e-3 */
+} egt_ffn_desc;
+
+typedef struct egt_ffn_params {
+  const void* norm_gamma;  /* [W]     norm_fnn_{node,edge}_XX */
+  const void* norm_beta;   /* [W]                              */
+  const void* lr1_kernel;  /* [W,2W]  fnn_lr1_XX               */
+  const void* lr1_bias;    /* [2W]                             */
+  const void* lr2_kernel;  /* [2W,W]  fnn_lr2_XX               */
+  const void* lr2_bias;    /* [W]                              */
+} egt_ffn_params;
+
+int egt_ffn_supported(const egt_ffn_desc* desc);
+size_t egt_ffn_workspace_bytes(const egt_ffn_desc* desc);
+int egt_ffn_fwd(const egt_ffn_desc* desc, const egt_ffn_params* params, const void* x, void* y,
+                void* workspace, void* stream);
+/* x is the layer INPUT (the hidden activations are recomputed); dx may alias dy; every pointer
+ * of `grads` (same layout as the params, writable) is written. */
+int egt_ffn_bwd(const egt_ffn_desc* desc, const egt_ffn_params* params, const void* x,
+                const void* dy, void* dx, const egt_ffn_params* grads, void* workspace,
+                void* stream);
+
 /* ---- per-kernel timing (measurement only) ------------------------------------
  * egt_prof_enable(1) makes every launch site bracket its kernel with hipEvents
  * on the launch stream (2 = reset counters and enable, 0 = off).  After the

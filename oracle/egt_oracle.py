@@ -344,6 +344,23 @@ def block_forward(h, e, mask, params, *, num_heads=8,
     return out
 
 
+def ffn_forward(x, p, activation="elu"):
+    """One channel type of ffn_block: graph_xformer_model_base.py:230-258 (ffnlr1 :230-239,
+    ffnact :241-246 -- identity without cross-talk, the activation then sits in fnn_lr1 --,
+    ffnlr2 :248-258), pre-norm (add_n_norm False), dropout 0, as called by :309-324.
+    p: norm_gamma, norm_beta, lr1_kernel [W,2W], lr1_bias, lr2_kernel [2W,W], lr2_bias."""
+    y = x
+    xn = layer_norm(x, p["norm_gamma"], p["norm_beta"])
+    hid = dense(xn, p["lr1_kernel"], p["lr1_bias"])
+    if activation == "elu":
+        hid = torch.nn.functional.elu(hid)
+    elif activation == "relu":
+        hid = torch.relu(hid)
+    elif activation is not None:
+        raise ValueError(activation)
+    return dense(hid, p["lr2_kernel"], p["lr2_bias"]) + y
+
+
 def stack_forward(h, e, mask, layer_params, **kw):
     """The Ly-layer attention stack of graph_xformer_model_base.py:336-339
     (edge_update only; the ffn_block at :340-341 is outside this path)."""

@@ -1,0 +1,68 @@
+"""GPU parity of the fused channel FFN vs the fp64 oracle."""
+import pytest
+import torch
+
+from util import assert_close, FWD, BWD
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("norm_gamma", "norm_beta", "lr1_kernel", "lr1_bias", "lr2_kernel", "lr2_bias")
+
+
+def _run(shape, act, gpu, seed=0):
+    from egt_amd import FFN
+    from oracle import egt_oracle as O
+    torch.manual_seed(seed)
+    m = FFN(64, activation=act).to(gpu)
+    with torch.no_grad():
+        for n in ("norm_gamma", "norm_beta", "lr1_bias", "lr2_bias"):
+            getattr(m, n).add_(0.3 * torch.randn_like(getattr(m, n)))
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(*shape, 64, generator=g) * 1.5 + 0.2
+    dy = torch.randn(*shape, 64, generator=g)
+    xg = x.to(gpu).requires_grad_()
+    y = m(xg)
+    y.backward(dy.to(gpu))
+    p64 = {n: getattr(m, n).detach().double().cpu().requires_grad_() for n in NAMES}
+    x64 = x.double().requires_grad_()
+    yo = O.ffn_forward(x64, p64, activation=act)
+    gr = torch.autograd.grad(yo, [x64] + [p64[n] for n in NAMES], dy.double())
+    assert_close(y, yo, name="y", **FWD)
+    assert_close(xg.grad, gr[0], name="dx", **BWD)
+    for n, gref in zip(NAMES, gr[1:]):
+        assert_close(getattr(m, n).grad, gref, name="d" + n, **BWD)
+
+
+@pytest.mark.parametrize("shape,act", [((2, 24, 24), "elu"), ((3, 17, 17), "elu"), ((2, 37), "relu"),
+                                        ((1, 5), "elu"), ((4, 64, 64), "elu")])
+def test_ffn_vs_oracle(shape, act, gpu, egt_lib):
+    """edge [B,N,N,64] and node [B,N,64] shapes, ragged row counts (rows % 16 != 0), both activations"""
+    _run(shape, act, gpu)
+
+
+def test_ffn_bit_reproducible_and_linear_in_dy(gpu, egt_lib):
+    from egt_amd import FFN
+    torch.manual_seed(5)
+    m = FFN(64).to(gpu)
+    x = torch.randn(2, 40, 40, 64, device=gpu)
+    dy = torch.randn_like(x)
+    outs = []
+    for scale in (1.0, 1.0, 2.0):
+        for prm in m.parameters():
+            prm.grad = None
+        xg = x.clone().requires_grad_()
+        y = m(xg)
+        y.backward(dy * scale)
+        outs.append((y.detach().clone(), xg.grad.clone(), m.lr1_kernel.grad.clone(), m.lr2_kernel.grad.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)                       # deterministic partial reductions
+    for a, b in zip(outs[0][1:], outs[2][1:]):
+        assert_close(b, 2.0 * a, name="linearity", rtol=1e-5, arel=1e-6)
+
+
+def test_ffn_rejects_uncovered(gpu, egt_lib):
+    from egt_amd import ffn
+    x = torch.randn(4, 48, device=gpu)
+    z = torch.zeros(48, device=gpu)
+    with pytest.raises(ValueError):
+        ffn(x, z, z, torch.zeros(48, 96, device=gpu), torch.zeros(96, device=gpu), torch.zeros(96, 48, device=gpu), z)
