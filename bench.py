@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--workload", default="zinc500k_n64", choices=list(WORKLOADS))
     ap.add_argument("--edge-dtype", default="", choices=["", "f32", "bf16"],
                     help="storage type of the edge tensors (EGT_BF16: bf16 in HBM, fp32 arithmetic); default: the workload's")
+    ap.add_argument("--with-ffn", action="store_true",
+                    help="whole-layer scope: every attention block is followed by the fused node + edge FFN "
+                         "(graph_xformer_model_base.py:336-341); NOT the headline workload")
     ap.add_argument("--layers", type=int, default=0, help="override the workload's layer count (1 = single-block scope)")
     ap.add_argument("--fused", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -175,8 +178,16 @@ def main():
     bf16 = w.get("edge_dtype", "f32") == "bf16"
     torch.manual_seed(1234)  # same weights on every rank (replicated parameters)
     fused = {"auto": "auto", "on": True, "off": False}[args.fused]
-    model = EGTStack(model_height=w["Ly"], model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"],
-                     random_mask_prob=w["rand_p"], seed=1, fused=fused).to(dev).train()
+    if args.with_ffn:
+        from egt_amd import EGTLayerStack
+        model = EGTLayerStack(model_height=w["Ly"], model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"],
+                              random_mask_prob=w["rand_p"], seed=1, fused=fused).to(dev).train()
+        model.fused_parameters = lambda: list(model.parameters())
+        from types import SimpleNamespace
+        model.grad_holder = SimpleNamespace(flat=None)   # per-block calls: classic flat buffer bound to .grad
+    else:
+        model = EGTStack(model_height=w["Ly"], model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"],
+                         random_mask_prob=w["rand_p"], seed=1, fused=fused).to(dev).train()
     h, e, mask, dh, de = make_inputs(w, dev, seed=1234 + rank)  # each rank its own graphs
     if bf16:
         e, de = e.bfloat16(), de.bfloat16()
@@ -273,6 +284,8 @@ def main():
             cpu = cpu_baseline(w, args.cpu_seconds)
         graphs = world * w["B"] * args.steps
         path = "fused-stack" if state["flat_ok"] else ("fused" if any(k.startswith("k_block") for k in prof) else "composed")
+        if args.with_ffn:
+            path += "+ffn"
         line = {
             "metric": "graphs/sec EGT fwd+bwd, ZINC-500K padded N=64",
             "value": graphs / elapsed, "unit": "graphs/s", "n_gpus": world,

@@ -6,9 +6,9 @@ Public surface (mirrors the reference's operator interface for this path):
     FlatGradAllReduce, shard_batch               (egt_amd.dp)
     FFN, ffn                                     (egt_amd.ffn: the ffn_block step after the attention block)
 """
-from .layers import EGT, EGTBlock, EGTStack, custom_layers, KerasDense, KerasLayerNorm  # noqa: F401
+from .layers import EGT, EGTBlock, EGTStack, EGTLayerStack, custom_layers, KerasDense, KerasLayerNorm  # noqa: F401
 from .functional import AttnConfig, egt_attention, edge_proj, edge_update, mask_sample  # noqa: F401
 from .ffn import FFN, ffn  # noqa: F401
 
-__all__ = ["EGT", "EGTBlock", "EGTStack", "custom_layers", "AttnConfig", "egt_attention",
+__all__ = ["EGT", "EGTBlock", "EGTStack", "EGTLayerStack", "custom_layers", "AttnConfig", "egt_attention",
            "edge_proj", "edge_update", "mask_sample", "FFN", "ffn"]

@@ -302,3 +302,31 @@ class EGTStack(nn.Module):
         for blk in self.blocks:
             h, e = blk(h, e, mask, attn_mask)
         return h, e
+
+
+class EGTLayerStack(nn.Module):
+    """The reference's full layer loop (graph_xformer_model_base.py:336-341):
+        for ii in range(model_height):  h, e = edge_update(tag, h, e);  h, e = ffn_block(tag, h, e)
+    with the attention block on the fused path (EGTBlock) and one fused FFN per channel type
+    (egt_amd.ffn.FFN; widths 64).  `edge_channel_type` in ('residual', 'constrained') updates
+    both channels in ffn_block (:312-320); otherwise only the node channels (:322-323)."""
+
+    def __init__(self, model_height=4, model_width=64, edge_width=64, activation='elu', **block_kwargs):
+        super().__init__()
+        from .ffn import FFN
+        seed = block_kwargs.pop('seed', 0)
+        self.blocks = nn.ModuleList(
+            [EGTBlock(seed=seed * 1000 + i, model_width=model_width, edge_width=edge_width, **block_kwargs)
+             for i in range(model_height)])
+        ect = block_kwargs.get('edge_channel_type', 'residual')
+        self.ffn_node = nn.ModuleList([FFN(model_width, activation=activation) for _ in range(model_height)])
+        self.ffn_edge = nn.ModuleList([FFN(edge_width, activation=activation) for _ in range(model_height)]) \
+            if ect in ('residual', 'constrained') else None
+
+    def forward(self, h, e, mask=None, attn_mask=None):
+        for i, blk in enumerate(self.blocks):
+            h, e = blk(h, e, mask, attn_mask)                  # layer/{i}/attention
+            if self.ffn_edge is not None:                      # layer/{i}/ffn
+                e = self.ffn_edge[i](e)
+            h = self.ffn_node[i](h)
+        return h, e

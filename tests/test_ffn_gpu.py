@@ -66,3 +66,33 @@ def test_ffn_rejects_uncovered(gpu, egt_lib):
     z = torch.zeros(48, device=gpu)
     with pytest.raises(ValueError):
         ffn(x, z, z, torch.zeros(48, 96, device=gpu), torch.zeros(96, device=gpu), torch.zeros(96, 48, device=gpu), z)
+
+
+def test_layer_stack_attention_plus_ffn_vs_oracle(gpu, egt_lib):
+    """EGTLayerStack = the reference's full layer loop (attention block, then ffn_block on both
+    channel types; graph_xformer_model_base.py:336-341) vs the fp64 oracle composition."""
+    from egt_amd import EGTLayerStack
+    from oracle import egt_oracle as O
+    from test_block_gpu import PMAP
+    torch.manual_seed(17)
+    B, N, Ly = 2, 32, 2
+    st = EGTLayerStack(model_height=Ly, model_width=64, edge_width=64, num_heads=8, fused=True).to(gpu).eval()
+    g = torch.Generator().manual_seed(2)
+    h = torch.randn(B, N, 64, generator=g); e = torch.randn(B, N, N, 64, generator=g)
+    mask = torch.ones(B, N, dtype=torch.bool); mask[0, N - 4:] = False
+    dh = torch.randn(B, N, 64, generator=g); de = torch.randn(B, N, N, 64, generator=g)
+    hg = h.to(gpu).requires_grad_(); eg = e.to(gpu).requires_grad_()
+    h2, e2 = st(hg, eg, mask.to(gpu))
+    torch.autograd.backward([h2, e2], [dh.to(gpu), de.to(gpu)])
+    h64 = h.double().requires_grad_(); e64 = e.double().requires_grad_()
+    ho, eo = h64, e64
+    for i in range(Ly):
+        bp = {k: getattr(getattr(st.blocks[i], m), a_).detach().double().cpu() for k, (m, a_) in PMAP.items()}
+        ho, eo = O.block_forward(ho, eo, mask, bp, num_heads=8)
+        eo = O.ffn_forward(eo, {n: getattr(st.ffn_edge[i], n).detach().double().cpu() for n in NAMES})
+        ho = O.ffn_forward(ho, {n: getattr(st.ffn_node[i], n).detach().double().cpu() for n in NAMES})
+    gr = torch.autograd.grad([ho, eo], [h64, e64], [dh.double(), de.double()])
+    assert_close(h2, ho, name="h_out", rtol=3e-4, arel=1e-4)
+    assert_close(e2, eo, name="e_out", rtol=3e-4, arel=1e-4)
+    assert_close(hg.grad, gr[0], name="dh", **BWD)
+    assert_close(eg.grad, gr[1], name="de", **BWD)
