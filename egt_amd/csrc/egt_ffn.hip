@@ -489,7 +489,12 @@ static int ffn_fill(const egt_ffn_desc* d, const egt_ffn_params* p, void* ws, Ff
   a.b1p = w + 4 * SLABF;
   a.red = a.b1p + ffn_al(FH);
   a.part = a.red + ffn_al(FFN_PART);
-  a.nwg = FFN_NWG;
+  {   // backward workgroups: one per CU for large inputs; small inputs (node channels) one tile
+      // per wave (a tile is ~16 us of dependent work: spreading beats amortising the slab staging)
+    const long ntiles = (a.rows + 15) / 16;
+    const long want = (ntiles + 3) / 4;
+    a.nwg = (int)(want < 1 ? 1 : (want > FFN_NWG ? FFN_NWG : want));
+  }
   return EGT_OK;
 }
 
@@ -504,7 +509,8 @@ extern "C" int egt_ffn_fwd(const egt_ffn_desc* desc, const egt_ffn_params* param
   EGT_LAUNCH("k_ffn_prep", k_ffn_prep, dim3(SLABF / 256), dim3(256), 0, st, a);
   const size_t lds = (2 * (size_t)SLABF + FH + FW + 8 * 2 * 1024) * 4;
   const long ntiles = (a.rows + 15) / 16;
-  const int grid = (int)((ntiles + 7) / 8 < 256 ? (ntiles + 7) / 8 : 256);
+  const long wantf = (ntiles + 7) / 8;
+  const int grid = (int)(wantf < 1 ? 1 : (wantf > 256 ? 256 : wantf));
   if (desc->activation == EGT_ACT_RELU) {
     (void)hipFuncSetAttribute((const void*)k_ffn_fwd<EGT_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     EGT_LAUNCH("k_ffn_fwd", k_ffn_fwd<EGT_ACT_RELU>, dim3(grid), dim3(512), lds, st, a);
@@ -533,10 +539,10 @@ extern "C" int egt_ffn_bwd(const egt_ffn_desc* desc, const egt_ffn_params* param
   const size_t lds = (3 * (size_t)SLABF + FH + 4 * 3 * 1024) * 4;
   if (desc->activation == EGT_ACT_RELU) {
     (void)hipFuncSetAttribute((const void*)k_ffn_bwd<EGT_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    EGT_LAUNCH("k_ffn_bwd", k_ffn_bwd<EGT_ACT_RELU>, dim3(FFN_NWG), dim3(256), lds, st, a);
+    EGT_LAUNCH("k_ffn_bwd", k_ffn_bwd<EGT_ACT_RELU>, dim3(a.nwg), dim3(256), lds, st, a);
   } else {
     (void)hipFuncSetAttribute((const void*)k_ffn_bwd<EGT_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    EGT_LAUNCH("k_ffn_bwd", k_ffn_bwd<EGT_ACT_ELU>, dim3(FFN_NWG), dim3(256), lds, st, a);
+    EGT_LAUNCH("k_ffn_bwd", k_ffn_bwd<EGT_ACT_ELU>, dim3(a.nwg), dim3(256), lds, st, a);
   }
   EGT_LAUNCH("k_ffn_sum", k_ffn_sum, dim3((FFN_PART + 63) / 64), dim3(256), 0, st, a);
   EGT_LAUNCH("k_ffn_param_grads", k_ffn_param_grads, dim3(16), dim3(256), 0, st, a);
