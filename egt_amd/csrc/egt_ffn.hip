@@ -1,5 +1,5 @@
 // Fused channel FFN of the reference's ffn_block, for gfx950:
-//   y = x + Dense_2( act( Dense_1( LayerNorm(x) ) ) )        width W = 64, hidden 2W = 128
+//   y = x + Dense_2( act( Dense_1( LayerNorm(x) ) ) )        width W in {16,32,48,64}, hidden 2W
 //   lib/models/graph_xformer_model_base.py:230-258 (ffnlr1 / ffnact / ffnlr2, pre-norm, no
 //   cross-talk), applied to the edge channels [B,N,N,De] and the node channels [B,N,Dh] (:309-324).
 // At De = 64 this is the largest FLOP consumer of the model (24*W^2 flop per row fwd+bwd) and
@@ -21,10 +21,11 @@
 
 #include "egt_tile.h"
 
-#define FW 64
-#define FH 128
-#define SLABF (FW * FH)   // floats per weight slab (32 KiB)
-#define FFN_PART (2 * SLABF + FH + FW)   // T1 | T2 | s1 | s2
+// geometry of width W (multiple of 16, <= 64): TW channel tiles, hidden 2W = TH tiles
+#define FFN_GEO(W)                                                                          \
+  constexpr int FW = (W), FH = 2 * (W), TW = (W) / 16, TH = 2 * TW, SLABF = FW * FH,        \
+                TILEF = 16 * (W), FFN_PART = 2 * SLABF + FH + FW;                           \
+  (void)TW; (void)TH; (void)TILEF; (void)FFN_PART   /* slab = W*2W floats; partial = T1 | T2 | s1 | s2 */
 
 struct FfnArgs {
   long rows;
@@ -38,6 +39,7 @@ struct FfnArgs {
   float *part, *red;   // backward: per-workgroup partials, reduced sums
   float *g_gamma, *g_beta, *g_W1, *g_b1, *g_W2, *g_b2;
   int nwg;
+  int W;       // channel width (host copy for the run-time-sized helper kernels)
   int guard;   // always 0: opaque phase guards of the backward (see k_ffn_bwd)
 };
 
@@ -47,17 +49,18 @@ struct FfnArgs {
 // slab4[i][j][lane].u = gamma[16i+pl] W1[16i+pl][16j+4q+u]                  (A operand of  dxhat= W1p . dpre)
 // b1p[h] = b1[h] + sum_c beta[c] W1[c][h]
 __global__ void __launch_bounds__(256) k_ffn_prep(FfnArgs a) {
+  const int FW = a.W, FH = 2 * FW, TW = FW / 16, TH = 2 * TW, SLABF = FW * FH;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx < SLABF) {
-    const int u = idx & 3, lane = (idx >> 2) & 63, pl = lane & 15, q = lane >> 4;
+    const int u = idx & 3, lane = (idx >> 2) & 63, pl = lane & 15, q = lane >> 4, blk = idx >> 8;
     {
-      const int t = (idx >> 8) & 3, j = idx >> 10;
+      const int t = blk % TW, j = blk / TW;
       const int c = 16 * t + 4 * q + u;
       a.slab1[idx] = a.gamma[c] * a.W1[c * FH + 16 * j + pl];
       a.slab3[idx] = a.W2[(16 * j + pl) * FW + c];
     }
     {
-      const int j = (idx >> 8) & 7, i = idx >> 11;
+      const int j = blk % TH, i = blk / TH;
       const int hc = 16 * j + 4 * q + u;
       a.slab2[idx] = a.W2[hc * FW + 16 * i + pl];
       a.slab4[idx] = a.gamma[16 * i + pl] * a.W1[(16 * i + pl) * FH + hc];
@@ -81,18 +84,20 @@ __device__ __forceinline__ float ffn_dact(float hid) {
   return hid > 0.f ? 1.f : hid + 1.0f;
 }
 
-__device__ __forceinline__ void slab_to_lds(float* dst, const float* src, int nthreads) {
-  for (int i = threadIdx.x; i < SLABF / 4; i += nthreads)
+__device__ __forceinline__ void slab_to_lds(float* dst, const float* src, int nfloats, int nthreads) {
+  for (int i = threadIdx.x; i < nfloats / 4; i += nthreads)
     reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
 }
 
 // pre-activation tile j of the lane's row: W1p^T . xhat + b1p   (16 MFMA)
-__device__ __forceinline__ v4f ffn_gemm1(const float* s1, const float* b1s, const float4 (&x)[4], int j, int lane, int q) {
+template <int W>
+__device__ __forceinline__ v4f ffn_gemm1(const float* s1, const float* b1s, const float4 (&x)[W / 16], int j, int lane, int q) {
+  constexpr int TW = W / 16;
   const float4 bj = *reinterpret_cast<const float4*>(b1s + 16 * j + 4 * q);
   v4f acc = {bj.x, bj.y, bj.z, bj.w};
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const float4 w = *reinterpret_cast<const float4*>(s1 + ((j * 4 + t) * 64 + lane) * 4);
+  for (int t = 0; t < TW; ++t) {
+    const float4 w = *reinterpret_cast<const float4*>(s1 + ((j * TW + t) * 64 + lane) * 4);
     acc = MFMA(w.x, x[t].x, acc);
     acc = MFMA(w.y, x[t].y, acc);
     acc = MFMA(w.z, x[t].z, acc);
@@ -102,56 +107,57 @@ __device__ __forceinline__ v4f ffn_gemm1(const float* s1, const float* b1s, cons
 }
 
 // ================================================================== forward =====
-template <int ACT>
+template <int W, int ACT>
 __global__ void __launch_bounds__(512, 2) k_ffn_fwd(FfnArgs a) {
+  FFN_GEO(W);
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s1 = sm;
   float* s2 = s1 + SLABF;
   float* b1s = s2 + SLABF;          // [128]
   float* b2s = b1s + FH;            // [64]
-  float* tiles = b2s + FW;          // [8 waves][2][1024]
+  float* tiles = b2s + FW;          // [8 waves][2][16 W]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p = lane & 15, q = lane >> 4;
-  slab_to_lds(s1, a.slab1, 512);
-  slab_to_lds(s2, a.slab2, 512);
+  slab_to_lds(s1, a.slab1, SLABF, 512);
+  slab_to_lds(s2, a.slab2, SLABF, 512);
   if (threadIdx.x < FH) b1s[threadIdx.x] = a.b1p[threadIdx.x];
   if (threadIdx.x < FW) b2s[threadIdx.x] = a.b2[threadIdx.x];
   __syncthreads();
-  float* tl0 = tiles + wave * 2 * 1024;
+  float* tl0 = tiles + wave * 2 * TILEF;
   const long ntiles = (a.rows + 15) / 16;
   const long stride = (long)gridDim.x * 8;
   long tile = (long)blockIdx.x * 8 + wave;
   TileRegs<FW> tr;
-  if (tile < ntiles) tile_gload<FW>(tr, a.x + tile * 1024, lane, (int)min(16L, a.rows - tile * 16));
+  if (tile < ntiles) tile_gload<FW>(tr, a.x + tile * TILEF, lane, (int)min(16L, a.rows - tile * 16));
   long prev = -1;
   for (int it = 0; tile < ntiles; tile += stride, ++it) {
     const int rows_valid = (int)min(16L, a.rows - tile * 16);
-    float* tl = tl0 + (it & 1) * 1024;
+    float* tl = tl0 + (it & 1) * TILEF;
     lds_sync();
     if (prev >= 0)   // stream out the previous tile's y from the other buffer
-      tile_from_lds<FW>(tl0 + ((it - 1) & 1) * 1024, a.y + prev * 1024, lane, (int)min(16L, a.rows - prev * 16));
+      tile_from_lds<FW>(tl0 + ((it - 1) & 1) * TILEF, a.y + prev * TILEF, lane, (int)min(16L, a.rows - prev * 16));
     tile_lds_put<FW>(tl, tr, lane, rows_valid);
     const long nxt = tile + stride;
-    if (nxt < ntiles) tile_gload<FW>(tr, a.x + nxt * 1024, lane, (int)min(16L, a.rows - nxt * 16));
+    if (nxt < ntiles) tile_gload<FW>(tr, a.x + nxt * TILEF, lane, (int)min(16L, a.rows - nxt * 16));
     lds_sync();
-    float4 x[4];
+    float4 x[TW];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) x[t] = frag_read<FW>(tl, p, q, t);
+    for (int t = 0; t < TW; ++t) x[t] = frag_read<FW>(tl, p, q, t);
     ln_frags<FW>(x, q, a.ln_eps);                                   // norm_fnn (gamma/beta folded into the weights)
-    v4f h[8];
+    v4f h[TH];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {                                    // fnn_lr1 + activation
-      const v4f pre = ffn_gemm1(s1, b1s, x, j, lane, q);
+    for (int j = 0; j < TH; ++j) {                                    // fnn_lr1 + activation
+      const v4f pre = ffn_gemm1<W>(s1, b1s, x, j, lane, q);
       h[j] = (v4f){ffn_act<ACT>(pre[0]), ffn_act<ACT>(pre[1]), ffn_act<ACT>(pre[2]), ffn_act<ACT>(pre[3])};
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {                                    // fnn_lr2 + res_fnn
+    for (int i = 0; i < TW; ++i) {                                    // fnn_lr2 + res_fnn
       const float4 xr = frag_read<FW>(tl, p, q, i);
       const float4 b = *reinterpret_cast<const float4*>(b2s + 16 * i + 4 * q);
       v4f acc = {xr.x + b.x, xr.y + b.y, xr.z + b.z, xr.w + b.w};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float4 w = *reinterpret_cast<const float4*>(s2 + ((i * 8 + j) * 64 + lane) * 4);
+      for (int j = 0; j < TH; ++j) {
+        const float4 w = *reinterpret_cast<const float4*>(s2 + ((i * TH + j) * 64 + lane) * 4);
         acc = MFMA(w.x, h[j][0], acc);
         acc = MFMA(w.y, h[j][1], acc);
         acc = MFMA(w.z, h[j][2], acc);
@@ -162,39 +168,40 @@ __global__ void __launch_bounds__(512, 2) k_ffn_fwd(FfnArgs a) {
     prev = tile;
     if (nxt >= ntiles) {   // last tile of this wave: flush
       lds_sync();
-      tile_from_lds<FW>(tl, a.y + tile * 1024, lane, rows_valid);
+      tile_from_lds<FW>(tl, a.y + tile * TILEF, lane, rows_valid);
     }
   }
 }
 
 // ================================================================= backward =====
-template <int ACT>
+template <int W, int ACT>
 __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
+  FFN_GEO(W);
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s1 = sm;
   float* s3 = s1 + SLABF;
   float* s4 = s3 + SLABF;
   float* b1s = s4 + SLABF;          // [128]
-  float* tiles = b1s + FH;          // [4 waves][x | dy | hid/dpre half][1024]
+  float* tiles = b1s + FH;          // [4 waves][x | dy | hid/dpre half][TILEF]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p0 = lane & 15, q0 = lane >> 4;
-  slab_to_lds(s1, a.slab1, 256);
-  slab_to_lds(s3, a.slab3, 256);
-  slab_to_lds(s4, a.slab4, 256);
+  slab_to_lds(s1, a.slab1, SLABF, 256);
+  slab_to_lds(s3, a.slab3, SLABF, 256);
+  slab_to_lds(s4, a.slab4, SLABF, 256);
   if (threadIdx.x < FH) b1s[threadIdx.x] = a.b1p[threadIdx.x];
   __syncthreads();
-  float* et = tiles + wave * 3 * 1024;
-  float* dt = et + 1024;
-  float* hd = dt + 1024;
-  v4f accT1[32], accT2[32];   // T1[in 16t+4q+r][hid 16j+pl] = accT1[t*8+j][r] ; T2[hid 16j+4q+r][out 16i+pl] = accT2[j*4+i][r]
+  float* et = tiles + wave * 3 * TILEF;
+  float* dt = et + TILEF;
+  float* hd = dt + TILEF;
+  v4f accT1[TW * TH], accT2[TH * TW];   // T1[in 16t+4q+r][hid 16j+pl] = accT1[t*8+j][r] ; T2[hid 16j+4q+r][out 16i+pl] = accT2[j*4+i][r]
 #pragma unroll
-  for (int k = 0; k < 32; ++k) { accT1[k] = (v4f){0.f, 0.f, 0.f, 0.f}; accT2[k] = (v4f){0.f, 0.f, 0.f, 0.f}; }
-  v4f sp[8];                  // per-lane sums of dpre (hid 16j+4q+r)
-  float4 sd[4];               // per-lane sums of dy   (out 16t+4q+r)
+  for (int k = 0; k < TW * TH; ++k) { accT1[k] = (v4f){0.f, 0.f, 0.f, 0.f}; accT2[k] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+  v4f sp[TH];                  // per-lane sums of dpre (hid 16j+4q+r)
+  float4 sd[TW];               // per-lane sums of dy   (out 16t+4q+r)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) sp[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < TH; ++j) sp[j] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int t = 0; t < 4; ++t) sd[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < TW; ++t) sd[t] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   const long ntiles = (a.rows + 15) / 16;
   const long stride = (long)gridDim.x * 4;
@@ -202,22 +209,22 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
   TileRegs<FW> te, td;
   if (tile < ntiles) {
     const int rv = (int)min(16L, a.rows - tile * 16);
-    tile_gload<FW>(te, a.x + tile * 1024, lane, rv);
-    tile_gload<FW>(td, a.dy + tile * 1024, lane, rv);
+    tile_gload<FW>(te, a.x + tile * TILEF, lane, rv);
+    tile_gload<FW>(td, a.dy + tile * TILEF, lane, rv);
   }
   long prev = -1;
   for (; tile < ntiles; tile += stride) {
     const int rows_valid = (int)min(16L, a.rows - tile * 16);
     lds_sync();
-    if (prev >= 0) tile_from_lds<FW>(dt, a.dx + prev * 1024, lane, (int)min(16L, a.rows - prev * 16));   // dx of the previous tile
+    if (prev >= 0) tile_from_lds<FW>(dt, a.dx + prev * TILEF, lane, (int)min(16L, a.rows - prev * 16));   // dx of the previous tile
     lds_sync();
     tile_lds_put<FW>(et, te, lane, rows_valid);     // rows past the end are zero: they add nothing to the sums
     tile_lds_put<FW>(dt, td, lane, rows_valid);
     const long nxt = tile + stride;
     if (nxt < ntiles) {
       const int rv = (int)min(16L, a.rows - nxt * 16);
-      tile_gload<FW>(te, a.x + nxt * 1024, lane, rv);
-      tile_gload<FW>(td, a.dy + nxt * 1024, lane, rv);
+      tile_gload<FW>(te, a.x + nxt * TILEF, lane, rv);
+      tile_gload<FW>(td, a.dy + nxt * TILEF, lane, rv);
     }
     lds_sync();
     // The phases below sit behind opaque always-true guards (a.guard == 0): the uniform branches
@@ -225,19 +232,19 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
     // (re-read from the LDS tiles) instead of stretching 200+ live registers across the tile.
     // ---- recompute: xhat, hid ----
     float rstd;
-    v4f h[8], dp[8];
+    v4f h[TH], dp[TH];
     {
       int p = p0, q = q0;
       asm volatile("" : "+v"(p), "+v"(q));   // keep this phase's LDS address math inside the phase (no hoisting out of the tile loop)
-      float4 x[4];
+      float4 x[TW];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) x[t] = frag_read<FW>(et, p, q, t);
+      for (int t = 0; t < TW; ++t) x[t] = frag_read<FW>(et, p, q, t);
       rstd = ln_frags<FW>(x, q, a.ln_eps);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) frag_write<FW>(et, p, q, t, x[t]);   // xhat: A operand of T1 (other rows) + LN backward
+      for (int t = 0; t < TW; ++t) frag_write<FW>(et, p, q, t, x[t]);   // xhat: A operand of T1 (other rows) + LN backward
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const v4f pre = ffn_gemm1(s1, b1s, x, j, lane, q);
+      for (int j = 0; j < TH; ++j) {
+        const v4f pre = ffn_gemm1<W>(s1, b1s, x, j, lane, q);
         h[j] = (v4f){ffn_act<ACT>(pre[0]), ffn_act<ACT>(pre[1]), ffn_act<ACT>(pre[2]), ffn_act<ACT>(pre[3])};
       }
     }
@@ -246,18 +253,18 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
     if (a.guard == 0) {
       int p = p0, q = q0;
       asm volatile("" : "+v"(p), "+v"(q));   // keep this phase's LDS address math inside the phase (no hoisting out of the tile loop)
-      float4 dyf[4];
+      float4 dyf[TW];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < TW; ++t) {
         dyf[t] = frag_read<FW>(dt, p, q, t);
         sd[t].x += dyf[t].x; sd[t].y += dyf[t].y; sd[t].z += dyf[t].z; sd[t].w += dyf[t].w;
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < TH; ++j) {
         v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float4 w = *reinterpret_cast<const float4*>(s3 + ((j * 4 + t) * 64 + lane) * 4);
+        for (int t = 0; t < TW; ++t) {
+          const float4 w = *reinterpret_cast<const float4*>(s3 + ((j * TW + t) * 64 + lane) * 4);
           acc = MFMA(w.x, dyf[t].x, acc);
           acc = MFMA(w.y, dyf[t].y, acc);
           acc = MFMA(w.z, dyf[t].z, acc);
@@ -273,50 +280,50 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
     if (a.guard == 0) {                             // T2 += hid^T . dy
       int p = p0, q = q0;
       asm volatile("" : "+v"(p), "+v"(q));   // keep this phase's LDS address math inside the phase (no hoisting out of the tile loop)
-      float bdy[4][4];   // dy[rho][16i+pl]
+      float bdy[TW][4];   // dy[rho][16i+pl]
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TW; ++i)
 #pragma unroll
         for (int s = 0; s < 4; ++s) bdy[i][s] = elem_read<FW>(dt, q + 4 * s, 16 * i + p);
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         lds_sync();
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          frag_write<FW>(hd, p, q, jj, make_float4(h[4 * half + jj][0], h[4 * half + jj][1], h[4 * half + jj][2], h[4 * half + jj][3]));
+        for (int jj = 0; jj < TW; ++jj)
+          frag_write<FW>(hd, p, q, jj, make_float4(h[TW * half + jj][0], h[TW * half + jj][1], h[TW * half + jj][2], h[TW * half + jj][3]));
         lds_sync();
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < TW; ++jj)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const float ah = elem_read<FW>(hd, q + 4 * s, 16 * jj + p);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) accT2[(4 * half + jj) * 4 + i] = MFMA(ah, bdy[i][s], accT2[(4 * half + jj) * 4 + i]);
+            for (int i = 0; i < TW; ++i) accT2[(TW * half + jj) * TW + i] = MFMA(ah, bdy[i][s], accT2[(TW * half + jj) * TW + i]);
           }
       }
     }
     if (a.guard == 0) {                             // T1 += xhat^T . dpre
       int p = p0, q = q0;
       asm volatile("" : "+v"(p), "+v"(q));   // keep this phase's LDS address math inside the phase (no hoisting out of the tile loop)
-      float axh[4][4];   // xhat[rho][16t+pl]
+      float axh[TW][4];   // xhat[rho][16t+pl]
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < TW; ++t)
 #pragma unroll
         for (int s = 0; s < 4; ++s) axh[t][s] = elem_read<FW>(et, q + 4 * s, 16 * t + p);
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         lds_sync();
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          frag_write<FW>(hd, p, q, jj, make_float4(dp[4 * half + jj][0], dp[4 * half + jj][1], dp[4 * half + jj][2], dp[4 * half + jj][3]));
+        for (int jj = 0; jj < TW; ++jj)
+          frag_write<FW>(hd, p, q, jj, make_float4(dp[TW * half + jj][0], dp[TW * half + jj][1], dp[TW * half + jj][2], dp[TW * half + jj][3]));
         lds_sync();
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < TW; ++jj)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const float bd = elem_read<FW>(hd, q + 4 * s, 16 * jj + p);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) accT1[t * 8 + 4 * half + jj] = MFMA(axh[t][s], bd, accT1[t * 8 + 4 * half + jj]);
+            for (int t = 0; t < TW; ++t) accT1[t * TH + TW * half + jj] = MFMA(axh[t][s], bd, accT1[t * TH + TW * half + jj]);
           }
       }
     }
@@ -324,15 +331,15 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
     if (a.guard == 0) {
       int p = p0, q = q0;
       asm volatile("" : "+v"(p), "+v"(q));   // keep this phase's LDS address math inside the phase (no hoisting out of the tile loop)
-      float4 dxh[4], x[4];
+      float4 dxh[TW], x[TW];
       float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < TW; ++i) {
         x[i] = frag_read<FW>(et, p, q, i);          // xhat
         v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float4 w = *reinterpret_cast<const float4*>(s4 + ((i * 8 + j) * 64 + lane) * 4);
+        for (int j = 0; j < TH; ++j) {
+          const float4 w = *reinterpret_cast<const float4*>(s4 + ((i * TH + j) * 64 + lane) * 4);
           acc = MFMA(w.x, dp[j][0], acc);
           acc = MFMA(w.y, dp[j][1], acc);
           acc = MFMA(w.z, dp[j][2], acc);
@@ -346,7 +353,7 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
       m1 = sum_over_q(m1) * (1.0f / FW);
       m2 = sum_over_q(m2) * (1.0f / FW);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < TW; ++i) {
         const float4 dyv = frag_read<FW>(dt, p, q, i);
         float4 o;
         o.x = dyv.x + rstd * (dxh[i].x - m1 - x[i].x * m2);
@@ -359,7 +366,7 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
     prev = tile;
   }
   lds_sync();
-  if (prev >= 0) tile_from_lds<FW>(dt, a.dx + prev * 1024, lane, (int)min(16L, a.rows - prev * 16));
+  if (prev >= 0) tile_from_lds<FW>(dt, a.dx + prev * TILEF, lane, (int)min(16L, a.rows - prev * 16));
 
   // ---- per-workgroup partial: the four waves add their tiles into ONE LDS image, one wave
   //      after the other (same lane -> same element in every wave: fixed summation order) ----
@@ -370,25 +377,25 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
     if (wave == w) {
       const bool first = w == 0;
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < TW; ++t)
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < TH; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float* d = red + (16 * t + 4 * q + r) * FH + 16 * j + p;
-            *d = first ? accT1[t * 8 + j][r] : *d + accT1[t * 8 + j][r];
+            *d = first ? accT1[t * TH + j][r] : *d + accT1[t * TH + j][r];
           }
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+      for (int j = 0; j < TH; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TW; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float* d = red + SLABF + (16 * j + 4 * q + r) * FW + 16 * i + p;
-            *d = first ? accT2[j * 4 + i][r] : *d + accT2[j * 4 + i][r];
+            *d = first ? accT2[j * TW + i][r] : *d + accT2[j * TW + i][r];
           }
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+      for (int j = 0; j < TH; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = row_sum16(sp[j][r]);
@@ -396,7 +403,7 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
           if (p == 0) *d = first ? v : *d + v;
         }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < TW; ++t) {
         const float v[4] = {row_sum16(sd[t].x), row_sum16(sd[t].y), row_sum16(sd[t].z), row_sum16(sd[t].w)};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -413,6 +420,7 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
 
 // deterministic sum over the workgroup partials: 64 outputs per workgroup, partial axis over 4 waves
 __global__ void __launch_bounds__(256) k_ffn_sum(FfnArgs a) {
+  const int FFN_PART = 4 * a.W * a.W + 3 * a.W;
   __shared__ float red[4][64];
   const int o = blockIdx.x * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
   float v0 = 0.f, v1 = 0.f;
@@ -434,6 +442,7 @@ __global__ void __launch_bounds__(256) k_ffn_sum(FfnArgs a) {
 //   dW1[c][h] = gamma_c T1[c][h] + beta_c s1[h] ; dgamma_c = sum_h W1[c][h] T1[c][h] ; dbeta_c = sum_h W1[c][h] s1[h]
 //   db1 = s1 ; dW2 = T2 ; db2 = s2
 __global__ void __launch_bounds__(256) k_ffn_param_grads(FfnArgs a) {
+  const int FW = a.W, FH = 2 * FW, SLABF = FW * FH;
   const float* T1 = a.red;
   const float* T2 = a.red + SLABF;
   const float* s1 = a.red + 2 * SLABF;
@@ -460,35 +469,40 @@ __global__ void __launch_bounds__(256) k_ffn_param_grads(FfnArgs a) {
 }
 
 // ------------------------------------------------------------------ host glue --
-#define FFN_NWG 256   // one backward workgroup per CU (4 waves, 1 per SIMD)
+#define FFN_NWG 256   // at most one backward workgroup per CU (4 waves, 1 per SIMD)
 
 static size_t ffn_al(size_t x) { return (x + 63) & ~(size_t)63; }
 
 extern "C" int egt_ffn_supported(const egt_ffn_desc* d) {
-  return d && d->dtype == EGT_F32 && d->width == FW && d->rows > 0 && (d->activation == EGT_ACT_RELU || d->activation == EGT_ACT_ELU);
+  if (!d || d->dtype != EGT_F32 || d->rows <= 0) return 0;
+  if (d->width != 16 && d->width != 32 && d->width != 48 && d->width != 64) return 0;
+  return d->activation == EGT_ACT_RELU || d->activation == EGT_ACT_ELU;
 }
 
 // [slab1 slab2 slab3 slab4 b1p | red | part x FFN_NWG]
 extern "C" size_t egt_ffn_workspace_bytes(const egt_ffn_desc* d) {
   if (!egt_ffn_supported(d)) return 0;
-  return (4 * (size_t)SLABF + ffn_al(FH) + ffn_al(FFN_PART) + (size_t)FFN_NWG * FFN_PART) * sizeof(float);
+  const size_t W = d->width, slab = 2 * W * W, part = 2 * slab + 3 * W;
+  return (4 * slab + ffn_al(2 * W) + ffn_al(part) + (size_t)FFN_NWG * part) * sizeof(float);
 }
 
 static int ffn_fill(const egt_ffn_desc* d, const egt_ffn_params* p, void* ws, FfnArgs& a) {
   if (!d || !p || !ws) EGT_FAIL(EGT_E_NULL, "desc/params/workspace is NULL");
-  if (!egt_ffn_supported(d)) EGT_FAIL(EGT_E_SHAPE, "fused FFN covers width 64, fp32, relu/elu (got width %d, act %d)", d->width, d->activation);
+  if (!egt_ffn_supported(d))
+    EGT_FAIL(EGT_E_SHAPE, "fused FFN covers widths 16/32/48/64, fp32, relu/elu (got width %d, act %d)", d->width, d->activation);
   if (!p->norm_gamma || !p->norm_beta || !p->lr1_kernel || !p->lr1_bias || !p->lr2_kernel || !p->lr2_bias)
     EGT_FAIL(EGT_E_NULL, "an FFN parameter pointer is NULL");
   a = FfnArgs{};
-  a.rows = d->rows; a.ln_eps = d->ln_eps;
+  a.rows = d->rows; a.ln_eps = d->ln_eps; a.W = d->width;
   a.gamma = (const float*)p->norm_gamma; a.beta = (const float*)p->norm_beta;
   a.W1 = (const float*)p->lr1_kernel; a.b1 = (const float*)p->lr1_bias;
   a.W2 = (const float*)p->lr2_kernel; a.b2 = (const float*)p->lr2_bias;
+  const size_t W = d->width, slab = 2 * W * W, part = 2 * slab + 3 * W;
   float* w = (float*)ws;
-  a.slab1 = w; a.slab2 = w + SLABF; a.slab3 = w + 2 * SLABF; a.slab4 = w + 3 * SLABF;
-  a.b1p = w + 4 * SLABF;
-  a.red = a.b1p + ffn_al(FH);
-  a.part = a.red + ffn_al(FFN_PART);
+  a.slab1 = w; a.slab2 = w + slab; a.slab3 = w + 2 * slab; a.slab4 = w + 3 * slab;
+  a.b1p = w + 4 * slab;
+  a.red = a.b1p + ffn_al(2 * W);
+  a.part = a.red + ffn_al(part);
   {   // backward workgroups: one per CU for large inputs; small inputs (node channels) one tile
       // per wave (a tile is ~16 us of dependent work: spreading beats amortising the slab staging)
     const long ntiles = (a.rows + 15) / 16;
@@ -498,6 +512,41 @@ static int ffn_fill(const egt_ffn_desc* d, const egt_ffn_params* p, void* ws, Ff
   return EGT_OK;
 }
 
+template <int W>
+static void ffn_launch_fwd(const FfnArgs& a, int act, hipStream_t st) {
+  const size_t lds = (2 * (size_t)(2 * W * W) + 3 * W + 8 * 2 * 16 * W) * 4;
+  const long ntiles = (a.rows + 15) / 16;
+  const long wantf = (ntiles + 7) / 8;
+  const int grid = (int)(wantf < 1 ? 1 : (wantf > 256 ? 256 : wantf));
+  if (act == EGT_ACT_RELU) {
+    (void)hipFuncSetAttribute((const void*)k_ffn_fwd<W, EGT_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_LAUNCH("k_ffn_fwd", (k_ffn_fwd<W, EGT_ACT_RELU>), dim3(grid), dim3(512), lds, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)k_ffn_fwd<W, EGT_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_LAUNCH("k_ffn_fwd", (k_ffn_fwd<W, EGT_ACT_ELU>), dim3(grid), dim3(512), lds, st, a);
+  }
+}
+
+template <int W>
+static void ffn_launch_bwd(const FfnArgs& a, int act, hipStream_t st) {
+  const size_t lds = (3 * (size_t)(2 * W * W) + 2 * W + 4 * 3 * 16 * W) * 4;
+  if (act == EGT_ACT_RELU) {
+    (void)hipFuncSetAttribute((const void*)k_ffn_bwd<W, EGT_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_LAUNCH("k_ffn_bwd", (k_ffn_bwd<W, EGT_ACT_RELU>), dim3(a.nwg), dim3(256), lds, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)k_ffn_bwd<W, EGT_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_LAUNCH("k_ffn_bwd", (k_ffn_bwd<W, EGT_ACT_ELU>), dim3(a.nwg), dim3(256), lds, st, a);
+  }
+}
+
+#define FFN_DISPATCH_W(width, CALL)               \
+  switch (width) {                                \
+    case 16: { constexpr int W = 16; CALL; } break; \
+    case 32: { constexpr int W = 32; CALL; } break; \
+    case 48: { constexpr int W = 48; CALL; } break; \
+    default: { constexpr int W = 64; CALL; } break; \
+  }
+
 extern "C" int egt_ffn_fwd(const egt_ffn_desc* desc, const egt_ffn_params* params, const void* x, void* y,
                            void* workspace, void* stream) {
   FfnArgs a;
@@ -506,18 +555,8 @@ extern "C" int egt_ffn_fwd(const egt_ffn_desc* desc, const egt_ffn_params* param
   if (!x || !y) EGT_FAIL(EGT_E_NULL, "x/y is NULL");
   a.x = (const float*)x; a.y = (float*)y;
   hipStream_t st = (hipStream_t)stream;
-  EGT_LAUNCH("k_ffn_prep", k_ffn_prep, dim3(SLABF / 256), dim3(256), 0, st, a);
-  const size_t lds = (2 * (size_t)SLABF + FH + FW + 8 * 2 * 1024) * 4;
-  const long ntiles = (a.rows + 15) / 16;
-  const long wantf = (ntiles + 7) / 8;
-  const int grid = (int)(wantf < 1 ? 1 : (wantf > 256 ? 256 : wantf));
-  if (desc->activation == EGT_ACT_RELU) {
-    (void)hipFuncSetAttribute((const void*)k_ffn_fwd<EGT_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    EGT_LAUNCH("k_ffn_fwd", k_ffn_fwd<EGT_ACT_RELU>, dim3(grid), dim3(512), lds, st, a);
-  } else {
-    (void)hipFuncSetAttribute((const void*)k_ffn_fwd<EGT_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    EGT_LAUNCH("k_ffn_fwd", k_ffn_fwd<EGT_ACT_ELU>, dim3(grid), dim3(512), lds, st, a);
-  }
+  EGT_LAUNCH("k_ffn_prep", k_ffn_prep, dim3((2 * a.W * a.W + 255) / 256), dim3(256), 0, st, a);
+  FFN_DISPATCH_W(desc->width, ffn_launch_fwd<W>(a, desc->activation, st));
   EGT_HIP_LAUNCH_CHECK("egt_ffn_fwd");
   return EGT_OK;
 }
@@ -535,16 +574,10 @@ extern "C" int egt_ffn_bwd(const egt_ffn_desc* desc, const egt_ffn_params* param
   a.g_W1 = (float*)grads->lr1_kernel; a.g_b1 = (float*)grads->lr1_bias;
   a.g_W2 = (float*)grads->lr2_kernel; a.g_b2 = (float*)grads->lr2_bias;
   hipStream_t st = (hipStream_t)stream;
-  EGT_LAUNCH("k_ffn_prep", k_ffn_prep, dim3(SLABF / 256), dim3(256), 0, st, a);
-  const size_t lds = (3 * (size_t)SLABF + FH + 4 * 3 * 1024) * 4;
-  if (desc->activation == EGT_ACT_RELU) {
-    (void)hipFuncSetAttribute((const void*)k_ffn_bwd<EGT_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    EGT_LAUNCH("k_ffn_bwd", k_ffn_bwd<EGT_ACT_RELU>, dim3(a.nwg), dim3(256), lds, st, a);
-  } else {
-    (void)hipFuncSetAttribute((const void*)k_ffn_bwd<EGT_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    EGT_LAUNCH("k_ffn_bwd", k_ffn_bwd<EGT_ACT_ELU>, dim3(a.nwg), dim3(256), lds, st, a);
-  }
-  EGT_LAUNCH("k_ffn_sum", k_ffn_sum, dim3((FFN_PART + 63) / 64), dim3(256), 0, st, a);
+  EGT_LAUNCH("k_ffn_prep", k_ffn_prep, dim3((2 * a.W * a.W + 255) / 256), dim3(256), 0, st, a);
+  FFN_DISPATCH_W(desc->width, ffn_launch_bwd<W>(a, desc->activation, st));
+  const int part = 4 * a.W * a.W + 3 * a.W;
+  EGT_LAUNCH("k_ffn_sum", k_ffn_sum, dim3((part + 63) / 64), dim3(256), 0, st, a);
   EGT_LAUNCH("k_ffn_param_grads", k_ffn_param_grads, dim3(16), dim3(256), 0, st, a);
   EGT_HIP_LAUNCH_CHECK("egt_ffn_bwd");
   return EGT_OK;

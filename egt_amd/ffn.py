@@ -2,7 +2,7 @@
     y = x + Dense_2(act(Dense_1(LayerNorm(x))))
 (lib/models/graph_xformer_model_base.py:230-258, applied per channel type by ffn_block :309-324;
 pre-norm, no cross-talk, ffn_multiplier 2).  One C-ABI call per direction (egt_ffn_fwd / egt_ffn_bwd
-in include/egt_amd.h) for width 64, fp32, elu / relu; there is no CPU fallback."""
+in include/egt_amd.h) for widths 16/32/48/64, fp32, elu / relu; there is no CPU fallback."""
 from __future__ import annotations
 
 import ctypes as C
@@ -65,7 +65,7 @@ def ffn(x, norm_gamma, norm_beta, lr1_kernel, lr1_bias, lr2_kernel, lr2_bias, ac
     W = x.shape[-1]
     desc = _desc(x.numel() // W, W, activation, eps)
     if not L.load().egt_ffn_supported(C.byref(desc)):
-        raise ValueError(f"fused FFN covers width 64 fp32 (got width {W}, dtype {x.dtype})")
+        raise ValueError(f"fused FFN covers widths 16/32/48/64 in fp32 (got width {W}, dtype {x.dtype})")
     return _FusedFFN.apply(x, desc, norm_gamma, norm_beta, lr1_kernel, lr1_bias, lr2_kernel, lr2_bias)
 
 

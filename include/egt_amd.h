@@ -290,7 +290,7 @@ int egt_stack_bwd(const egt_block_desc* desc, int32_t layers,
  *   y = x + Dense_2( act( Dense_1( LayerNorm(x) ) ) )
  * on `rows` rows of `width` channels: the edge channels [B*N*N, De] or the node channels
  * [B*N, Dh].  Keras layouts: kernels are [in,out]; LayerNormalization epsilon = ln_eps.
- * Fused MFMA kernels for width = 64, fp32, activation EGT_ACT_ELU (config default) or
+ * Fused MFMA kernels for width in {16,32,48,64}, fp32, activation EGT_ACT_ELU (config default) or
  * EGT_ACT_RELU; egt_ffn_supported says whether a desc is covered. */
 typedef struct egt_ffn_desc {
   int64_t rows;

@@ -9,17 +9,17 @@ pytestmark = pytest.mark.gpu
 NAMES = ("norm_gamma", "norm_beta", "lr1_kernel", "lr1_bias", "lr2_kernel", "lr2_bias")
 
 
-def _run(shape, act, gpu, seed=0):
+def _run(shape, act, gpu, seed=0, W=64):
     from egt_amd import FFN
     from oracle import egt_oracle as O
     torch.manual_seed(seed)
-    m = FFN(64, activation=act).to(gpu)
+    m = FFN(W, activation=act).to(gpu)
     with torch.no_grad():
         for n in ("norm_gamma", "norm_beta", "lr1_bias", "lr2_bias"):
             getattr(m, n).add_(0.3 * torch.randn_like(getattr(m, n)))
     g = torch.Generator().manual_seed(seed + 1)
-    x = torch.randn(*shape, 64, generator=g) * 1.5 + 0.2
-    dy = torch.randn(*shape, 64, generator=g)
+    x = torch.randn(*shape, W, generator=g) * 1.5 + 0.2
+    dy = torch.randn(*shape, W, generator=g)
     xg = x.to(gpu).requires_grad_()
     y = m(xg)
     y.backward(dy.to(gpu))
@@ -38,6 +38,13 @@ def _run(shape, act, gpu, seed=0):
 def test_ffn_vs_oracle(shape, act, gpu, egt_lib):
     """edge [B,N,N,64] and node [B,N,64] shapes, ragged row counts (rows % 16 != 0), both activations"""
     _run(shape, act, gpu)
+
+
+@pytest.mark.parametrize("W,shape,act", [(48, (2, 37, 37), "elu"), (48, (3, 21), "relu"), (32, (2, 19, 19), "elu"),
+                                          (16, (2, 23, 23), "elu"), (16, (5, 7), "relu")])
+def test_ffn_other_widths_vs_oracle(W, shape, act, gpu, egt_lib):
+    """widths 16 / 32 / 48 (BASELINE config 1 is Dh = De = 48)"""
+    _run(shape, act, gpu, seed=W, W=W)
 
 
 def test_ffn_bit_reproducible_and_linear_in_dy(gpu, egt_lib):
@@ -62,10 +69,10 @@ def test_ffn_bit_reproducible_and_linear_in_dy(gpu, egt_lib):
 
 def test_ffn_rejects_uncovered(gpu, egt_lib):
     from egt_amd import ffn
-    x = torch.randn(4, 48, device=gpu)
-    z = torch.zeros(48, device=gpu)
+    x = torch.randn(4, 40, device=gpu)
+    z = torch.zeros(40, device=gpu)
     with pytest.raises(ValueError):
-        ffn(x, z, z, torch.zeros(48, 96, device=gpu), torch.zeros(96, device=gpu), torch.zeros(96, 48, device=gpu), z)
+        ffn(x, z, z, torch.zeros(40, 80, device=gpu), torch.zeros(80, device=gpu), torch.zeros(80, 40, device=gpu), z)
 
 
 def test_layer_stack_attention_plus_ffn_vs_oracle(gpu, egt_lib):
