@@ -48,8 +48,9 @@ struct FfnArgs {
 // slab3[j][t][lane].u = W2[16j+pl][16t+4q+u]                                (A operand of  dhid = W2 . dy)
 // slab4[i][j][lane].u = gamma[16i+pl] W1[16i+pl][16j+4q+u]                  (A operand of  dxhat= W1p . dpre)
 // b1p[h] = b1[h] + sum_c beta[c] W1[c][h]
+template <int W>
 __global__ void __launch_bounds__(256) k_ffn_prep(FfnArgs a) {
-  const int FW = a.W, FH = 2 * FW, TW = FW / 16, TH = 2 * TW, SLABF = FW * FH;
+  FFN_GEO(W);
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx < SLABF) {
     const int u = idx & 3, lane = (idx >> 2) & 63, pl = lane & 15, q = lane >> 4, blk = idx >> 8;
@@ -89,19 +90,60 @@ __device__ __forceinline__ void slab_to_lds(float* dst, const float* src, int nf
     reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
 }
 
+// N consecutive [lane] float4 slabs (1 KiB apart) of one MFMA group in ONE LDS round trip.  hipcc,
+// short of registers, emits ds_read_b128 -> s_waitcnt -> 4 MFMA per slab (one exposed LDS latency
+// per four MFMAs at one wave per SIMD); the asm issues the group's reads back to back and
+// waits once.
+template <int N>
+__device__ __forceinline__ void slab_read(v4f (&w)[N], const float* slab_lane) {
+  const unsigned addr = (unsigned)(size_t)slab_lane;   // LDS byte offset = low 32 bits of the flat address
+  static_assert(N >= 1 && N <= 8, "slab group size");
+  if constexpr (N == 1)
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w[0]) : "v"(addr));
+  else if constexpr (N == 2)
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1]) : "v"(addr));
+  else if constexpr (N == 3)
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]) : "v"(addr));
+  else if constexpr (N == 4)
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                 "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(addr));
+  else if constexpr (N == 6)
+    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %6 offset:2048\n\t"
+                 "ds_read_b128 %3, %6 offset:3072\n\tds_read_b128 %4, %6 offset:4096\n\tds_read_b128 %5, %6 offset:5120\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]) : "v"(addr));
+  else if constexpr (N == 8)
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\t"
+                 "ds_read_b128 %3, %8 offset:3072\n\tds_read_b128 %4, %8 offset:4096\n\tds_read_b128 %5, %8 offset:5120\n\t"
+                 "ds_read_b128 %6, %8 offset:6144\n\tds_read_b128 %7, %8 offset:7168\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
+                 : "v"(addr));
+  else {
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const float4 t = *reinterpret_cast<const float4*>(slab_lane + n * 256);
+      w[n] = (v4f){t.x, t.y, t.z, t.w};
+    }
+  }
+}
+
 // pre-activation tile j of the lane's row: W1p^T . xhat + b1p   (16 MFMA)
 template <int W>
 __device__ __forceinline__ v4f ffn_gemm1(const float* s1, const float* b1s, const float4 (&x)[W / 16], int j, int lane, int q) {
   constexpr int TW = W / 16;
   const float4 bj = *reinterpret_cast<const float4*>(b1s + 16 * j + 4 * q);
   v4f acc = {bj.x, bj.y, bj.z, bj.w};
+  v4f w[TW];
+  slab_read<TW>(w, s1 + (j * TW * 64 + lane) * 4);
 #pragma unroll
   for (int t = 0; t < TW; ++t) {
-    const float4 w = *reinterpret_cast<const float4*>(s1 + ((j * TW + t) * 64 + lane) * 4);
-    acc = MFMA(w.x, x[t].x, acc);
-    acc = MFMA(w.y, x[t].y, acc);
-    acc = MFMA(w.z, x[t].z, acc);
-    acc = MFMA(w.w, x[t].w, acc);
+    acc = MFMA(w[t][0], x[t].x, acc);
+    acc = MFMA(w[t][1], x[t].y, acc);
+    acc = MFMA(w[t][2], x[t].z, acc);
+    acc = MFMA(w[t][3], x[t].w, acc);
   }
   return acc;
 }
@@ -155,13 +197,14 @@ __global__ void __launch_bounds__(512, 2) k_ffn_fwd(FfnArgs a) {
       const float4 xr = frag_read<FW>(tl, p, q, i);
       const float4 b = *reinterpret_cast<const float4*>(b2s + 16 * i + 4 * q);
       v4f acc = {xr.x + b.x, xr.y + b.y, xr.z + b.z, xr.w + b.w};
+      v4f w[TH];
+      slab_read<TH>(w, s2 + (i * TH * 64 + lane) * 4);
 #pragma unroll
       for (int j = 0; j < TH; ++j) {
-        const float4 w = *reinterpret_cast<const float4*>(s2 + ((i * TH + j) * 64 + lane) * 4);
-        acc = MFMA(w.x, h[j][0], acc);
-        acc = MFMA(w.y, h[j][1], acc);
-        acc = MFMA(w.z, h[j][2], acc);
-        acc = MFMA(w.w, h[j][3], acc);
+        acc = MFMA(w[j][0], h[j][0], acc);
+        acc = MFMA(w[j][1], h[j][1], acc);
+        acc = MFMA(w[j][2], h[j][2], acc);
+        acc = MFMA(w[j][3], h[j][3], acc);
       }
       frag_write<FW>(tl, p, q, i, make_float4(acc[0], acc[1], acc[2], acc[3]));
     }
@@ -262,13 +305,14 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
 #pragma unroll
       for (int j = 0; j < TH; ++j) {
         v4f acc = {0.f, 0.f, 0.f, 0.f};
+        v4f w[TW];
+        slab_read<TW>(w, s3 + (j * TW * 64 + lane) * 4);
 #pragma unroll
         for (int t = 0; t < TW; ++t) {
-          const float4 w = *reinterpret_cast<const float4*>(s3 + ((j * TW + t) * 64 + lane) * 4);
-          acc = MFMA(w.x, dyf[t].x, acc);
-          acc = MFMA(w.y, dyf[t].y, acc);
-          acc = MFMA(w.z, dyf[t].z, acc);
-          acc = MFMA(w.w, dyf[t].w, acc);
+          acc = MFMA(w[t][0], dyf[t].x, acc);
+          acc = MFMA(w[t][1], dyf[t].y, acc);
+          acc = MFMA(w[t][2], dyf[t].z, acc);
+          acc = MFMA(w[t][3], dyf[t].w, acc);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] *= ffn_dact<ACT>(h[j][r]);
@@ -337,13 +381,14 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
       for (int i = 0; i < TW; ++i) {
         x[i] = frag_read<FW>(et, p, q, i);          // xhat
         v4f acc = {0.f, 0.f, 0.f, 0.f};
+        v4f w[TH];
+        slab_read<TH>(w, s4 + (i * TH * 64 + lane) * 4);
 #pragma unroll
         for (int j = 0; j < TH; ++j) {
-          const float4 w = *reinterpret_cast<const float4*>(s4 + ((i * TH + j) * 64 + lane) * 4);
-          acc = MFMA(w.x, dp[j][0], acc);
-          acc = MFMA(w.y, dp[j][1], acc);
-          acc = MFMA(w.z, dp[j][2], acc);
-          acc = MFMA(w.w, dp[j][3], acc);
+          acc = MFMA(w[j][0], dp[j][0], acc);
+          acc = MFMA(w[j][1], dp[j][1], acc);
+          acc = MFMA(w[j][2], dp[j][2], acc);
+          acc = MFMA(w[j][3], dp[j][3], acc);
         }
         dxh[i] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         m1 += (acc[0] + acc[1]) + (acc[2] + acc[3]);
@@ -441,8 +486,9 @@ __global__ void __launch_bounds__(256) k_ffn_sum(FfnArgs a) {
 // T1 = sum xhat^T.dpre, s1 = sum dpre, T2 = sum hid^T.dy, s2 = sum dy  ->  parameter gradients
 //   dW1[c][h] = gamma_c T1[c][h] + beta_c s1[h] ; dgamma_c = sum_h W1[c][h] T1[c][h] ; dbeta_c = sum_h W1[c][h] s1[h]
 //   db1 = s1 ; dW2 = T2 ; db2 = s2
+template <int W>
 __global__ void __launch_bounds__(256) k_ffn_param_grads(FfnArgs a) {
-  const int FW = a.W, FH = 2 * FW, SLABF = FW * FH;
+  FFN_GEO(W);
   const float* T1 = a.red;
   const float* T2 = a.red + SLABF;
   const float* s1 = a.red + 2 * SLABF;
@@ -555,7 +601,7 @@ extern "C" int egt_ffn_fwd(const egt_ffn_desc* desc, const egt_ffn_params* param
   if (!x || !y) EGT_FAIL(EGT_E_NULL, "x/y is NULL");
   a.x = (const float*)x; a.y = (float*)y;
   hipStream_t st = (hipStream_t)stream;
-  EGT_LAUNCH("k_ffn_prep", k_ffn_prep, dim3((2 * a.W * a.W + 255) / 256), dim3(256), 0, st, a);
+  FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep<W>, dim3((2 * W * W + 255) / 256), dim3(256), 0, st, a));
   FFN_DISPATCH_W(desc->width, ffn_launch_fwd<W>(a, desc->activation, st));
   EGT_HIP_LAUNCH_CHECK("egt_ffn_fwd");
   return EGT_OK;
@@ -574,11 +620,11 @@ extern "C" int egt_ffn_bwd(const egt_ffn_desc* desc, const egt_ffn_params* param
   a.g_W1 = (float*)grads->lr1_kernel; a.g_b1 = (float*)grads->lr1_bias;
   a.g_W2 = (float*)grads->lr2_kernel; a.g_b2 = (float*)grads->lr2_bias;
   hipStream_t st = (hipStream_t)stream;
-  EGT_LAUNCH("k_ffn_prep", k_ffn_prep, dim3((2 * a.W * a.W + 255) / 256), dim3(256), 0, st, a);
+  FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep<W>, dim3((2 * W * W + 255) / 256), dim3(256), 0, st, a));
   FFN_DISPATCH_W(desc->width, ffn_launch_bwd<W>(a, desc->activation, st));
   const int part = 4 * a.W * a.W + 3 * a.W;
   EGT_LAUNCH("k_ffn_sum", k_ffn_sum, dim3((part + 63) / 64), dim3(256), 0, st, a);
-  EGT_LAUNCH("k_ffn_param_grads", k_ffn_param_grads, dim3(16), dim3(256), 0, st, a);
+  FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_param_grads", k_ffn_param_grads<W>, dim3(16), dim3(256), 0, st, a));
   EGT_HIP_LAUNCH_CHECK("egt_ffn_bwd");
   return EGT_OK;
 }
