@@ -114,7 +114,7 @@ __device__ __forceinline__ float reduce16_keep_own(const float (&v)[16], int p) 
 // compiled out of the headline kernel).
 // FULL: N is a multiple of 16 (no ragged key tile): validity selects and address clamps fold away.
 template <int DE, bool KVL, bool ML, bool FULL, bool BF>
-__global__ void __launch_bounds__(256, 2) k_block_fwd(BlockArgs a) {
+__global__ void __launch_bounds__(256, (DE <= 16 ? 4 : 2)) k_block_fwd(BlockArgs a) {   // narrow edge channels: small tiles, more resident waves
   using G = Geo<DE>;
   typedef typename EdgeT<BF>::type ET;   // element type of the edge tensors in HBM
   const ET* e_in = reinterpret_cast<const ET*>(a.e);
