@@ -163,3 +163,35 @@ def save_npz(path, tree):
         elif v is not None:
             flat[k] = to_np(v)
     np.savez_compressed(path, **flat)
+
+
+# ----------------------------------------------------------------- channel FFN -----
+FFN_NAMES = ("norm_gamma", "norm_beta", "lr1_kernel", "lr1_bias", "lr2_kernel", "lr2_bias")
+FFN_CASES = {
+    "edge_w64_elu": dict(shape=(2, 12, 12), W=64, act="elu"),
+    "node_w48_relu": dict(shape=(3, 11), W=48, act="relu"),
+    "edge_w16_elu": dict(shape=(2, 9, 9), W=16, act="elu"),
+}
+
+
+def make_ffn_case(name, seed=777):
+    c = FFN_CASES[name]
+    g = torch.Generator().manual_seed(seed + c["W"])
+    W, H = c["W"], 2 * c["W"]
+    lim = (6.0 / (W + H)) ** 0.5
+    params = {
+        "norm_gamma": 1.0 + 0.3 * torch.randn(W, generator=g), "norm_beta": 0.3 * torch.randn(W, generator=g),
+        "lr1_kernel": (torch.rand(W, H, generator=g) * 2 - 1) * lim, "lr1_bias": 0.2 * torch.randn(H, generator=g),
+        "lr2_kernel": (torch.rand(H, W, generator=g) * 2 - 1) * lim, "lr2_bias": 0.2 * torch.randn(W, generator=g),
+    }
+    inp = {"x": torch.randn(*c["shape"], W, generator=g) * 1.5 + 0.2, "dy": torch.randn(*c["shape"], W, generator=g)}
+    return inp, params, c
+
+
+def ffn_oracle(inp, params, c, dtype=torch.float64):
+    from oracle import egt_oracle as O
+    x = inp["x"].to(dtype).requires_grad_()
+    p = {k: v.to(dtype).requires_grad_() for k, v in params.items()}
+    y = O.ffn_forward(x, p, activation=c["act"])
+    gr = torch.autograd.grad(y, [x] + [p[k] for k in FFN_NAMES], inp["dy"].to(dtype))
+    return {"y": y.detach(), "dx": gr[0], "dparams": dict(zip(FFN_NAMES, gr[1:]))}

@@ -32,6 +32,12 @@ def main():
         tree = {"in": inp, "params": params,
                 "out": {k: v.float() for k, v in out.items()}, "dparams": dparams}
         CS.save_npz(os.path.join(CS.GOLDEN_DIR, f"block_{name}.npz"), tree)
+    for name in CS.FFN_CASES:
+        inp, params, c = CS.make_ffn_case(name)
+        out = CS.ffn_oracle(inp, params, c)
+        tree = {"in": inp, "params": params, "out": {"y": out["y"].float(), "dx": out["dx"].float()},
+                "dparams": {k: v.float() for k, v in out["dparams"].items()}}
+        CS.save_npz(os.path.join(CS.GOLDEN_DIR, f"ffn_{name}.npz"), tree)
     print("wrote", len(os.listdir(CS.GOLDEN_DIR)) - 1, "fixtures to", CS.GOLDEN_DIR)
 
 

@@ -103,3 +103,22 @@ def test_layer_stack_attention_plus_ffn_vs_oracle(gpu, egt_lib):
     assert_close(e2, eo, name="e_out", rtol=3e-4, arel=1e-4)
     assert_close(hg.grad, gr[0], name="dh", **BWD)
     assert_close(eg.grad, gr[1], name="de", **BWD)
+
+
+@pytest.mark.parametrize("name", ["edge_w64_elu", "node_w48_relu", "edge_w16_elu"])
+def test_ffn_vs_golden(name, gpu, egt_lib):
+    """the committed fixtures (tests/golden/ffn_*.npz, written by the oracle) through the C-ABI"""
+    import os
+    import cases as CS
+    from util import load_golden
+    from egt_amd import ffn
+    g = load_golden(os.path.join(CS.GOLDEN_DIR, f"ffn_{name}.npz"))
+    c = CS.FFN_CASES[name]
+    prm = {k: torch.from_numpy(g["params"][k]).to(gpu).requires_grad_() for k in CS.FFN_NAMES}
+    x = torch.from_numpy(g["in"]["x"]).to(gpu).requires_grad_()
+    y = ffn(x, *[prm[k] for k in CS.FFN_NAMES], activation=c["act"])
+    y.backward(torch.from_numpy(g["in"]["dy"]).to(gpu))
+    assert_close(y, g["out"]["y"], name="y", **FWD)
+    assert_close(x.grad, g["out"]["dx"], name="dx", **BWD)
+    for k in CS.FFN_NAMES:
+        assert_close(prm[k].grad, g["dparams"][k], name=k, **BWD)

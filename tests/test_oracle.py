@@ -127,6 +127,36 @@ def test_oracle_reproduces_block_golden(path):
         assert_close(out["dparams"][k].float(), v, rtol=1e-6, arel=1e-6, name=k)
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(CS.GOLDEN_DIR, "ffn_*.npz"))))
+def test_oracle_reproduces_ffn_golden(path):
+    name = os.path.basename(path)[len("ffn_"):-4]
+    g = load_golden(path)
+    inp, params, c = CS.make_ffn_case(name)
+    for k, v in g["in"].items():
+        assert np.array_equal(CS.to_np(inp[k]), v), f"input {k} drifted"
+    out = CS.ffn_oracle(inp, params, c)
+    assert_close(out["y"].float(), g["out"]["y"], rtol=1e-6, arel=1e-6, name="y")
+    assert_close(out["dx"].float(), g["out"]["dx"], rtol=1e-6, arel=1e-6, name="dx")
+    for k, v in g["dparams"].items():
+        assert_close(out["dparams"][k].float(), v, rtol=1e-6, arel=1e-6, name=k)
+
+
+def test_ffn_oracle_backward_and_identities():
+    """autograd of the restatement vs finite differences (fp64), and: zero second Dense => identity;
+    the LayerNorm makes the FFN branch invariant to a per-row shift of x."""
+    from oracle import egt_oracle as O
+    inp, params, c = CS.make_ffn_case("edge_w16_elu")
+    x = inp["x"][:1, :2, :2].double().requires_grad_()
+    p = {k: v.double().requires_grad_() for k, v in params.items()}
+    assert torch.autograd.gradcheck(lambda xx, *ps: O.ffn_forward(xx, dict(zip(CS.FFN_NAMES, ps)), activation="elu"),
+                                    (x, *[p[k] for k in CS.FFN_NAMES]), eps=1e-6, atol=1e-6)
+    p0 = dict(p); p0["lr2_kernel"] = torch.zeros_like(p["lr2_kernel"]); p0["lr2_bias"] = torch.zeros_like(p["lr2_bias"])
+    assert torch.equal(O.ffn_forward(x, p0), x)
+    y0 = O.ffn_forward(x, p) - x
+    y1 = O.ffn_forward(x + 3.0, p) - (x + 3.0)
+    assert_close(y1, y0, rtol=1e-9, arel=1e-9, name="shift invariance")
+
+
 def test_fp32_oracle_close_to_fp64():
     inp, params, attrs, _ = CS.make_block_case("residual_zinc500k")
     o64 = CS.block_oracle(inp, params, attrs, torch.float64)
