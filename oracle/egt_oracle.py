@@ -37,6 +37,19 @@ NEG = 1e9  # the reference's additive mask constant (egt_layers.py:92,99,106)
 # --------------------------------------------------------------------------
 # inner op: EGT.call_gated / call_ungated
 # --------------------------------------------------------------------------
+def _add_mask(x, m):
+    """x + m as the reference computes it.  The reference runs in fp32, where a logit plus -1e9
+    ROUNDS to exactly -1e9 (|x| < 32; SURVEY.md 8(a) a5, probed): a row whose keys are all masked
+    therefore gets a UNIFORM softmax over its least-masked keys (egt_layers.py:111 on such rows;
+    visible in the ungated variant, :145-213).  Evaluated in fp64 the plain sum would keep the
+    logit differences, so at masked positions the fp32 rounding is reproduced; unmasked positions
+    keep the evaluation precision.  Differentiable like the plain add."""
+    if x.dtype == torch.float64:
+        y32 = (x.to(torch.float32) + m.to(torch.float32)).to(torch.float64)
+        return torch.where(m != 0, y32, x)
+    return x + m
+
+
 def egt_forward(QKV: torch.Tensor,
                 E: Optional[torch.Tensor],
                 G: Optional[torch.Tensor],
@@ -78,20 +91,20 @@ def egt_forward(QKV: torch.Tensor,
     G_ = G                                                    # :90
     if mask is not None:                                      # :91-94
         mask_ = (mask[:, None, :, None].to(dt) - 1) * NEG
-        H_hat_ = H_hat_ + mask_
+        H_hat_ = _add_mask(H_hat_, mask_)
         if G is not None:
-            G_ = G_ + mask_
+            G_ = _add_mask(G_, mask_)
     if M is not None:                                         # :96-101
         M_ = (M.to(dt) - 1) * NEG
-        H_hat_ = H_hat_ + M_
+        H_hat_ = _add_mask(H_hat_, M_)
         if G is not None:
-            G_ = G_ + M_
+            G_ = _add_mask(G_, M_)
     if rand_mask is not None:                                 # :103-108
         random_mask_ = torch.where(rand_mask, torch.tensor(-NEG, dtype=dt),
                                    torch.tensor(0.0, dtype=dt))
-        H_hat_ = H_hat_ + random_mask_
+        H_hat_ = _add_mask(H_hat_, random_mask_)
         if G is not None:
-            G_ = G_ + random_mask_
+            G_ = _add_mask(G_, random_mask_)
 
     A_tild = torch.softmax(H_hat_, dim=2)                     # :111
     gates = None
@@ -150,17 +163,17 @@ def egt_backward(QKV, E, G, M, mask, dV_att, dH_ext, *, num_heads=8,
         cpred = torch.ones_like(A_raw)
         A_hat = A_raw
     H_hat = A_hat if E is None else A_hat + E
-    madd = torch.zeros_like(H_hat)
-    if mask is not None:
-        madd = madd + (mask[:, None, :, None].to(dt) - 1) * NEG
-    if M is not None:
-        madd = madd + (M.to(dt) - 1) * NEG
-    if rand_mask is not None:
-        madd = madd + torch.where(rand_mask, torch.tensor(-NEG, dtype=dt),
-                                  torch.tensor(0.0, dtype=dt))
-    S = torch.softmax(H_hat + madd, dim=2)
+    Hm, Gm = H_hat, G                                         # masks added one by one, as in egt_forward
+    for m_ in ([] if mask is None else [(mask[:, None, :, None].to(dt) - 1) * NEG]) + \
+              ([] if M is None else [(M.to(dt) - 1) * NEG]) + \
+              ([] if rand_mask is None else [torch.where(rand_mask, torch.tensor(-NEG, dtype=dt),
+                                                         torch.tensor(0.0, dtype=dt))]):
+        Hm = _add_mask(Hm, m_.expand_as(Hm))
+        if G is not None:
+            Gm = _add_mask(Gm, m_.expand_as(Gm))
+    S = torch.softmax(Hm, dim=2)
     if G is not None:
-        g = torch.sigmoid(G + madd)
+        g = torch.sigmoid(Gm)
     else:
         g = torch.ones_like(S)
     A_tild = S * g

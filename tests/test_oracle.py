@@ -157,6 +157,26 @@ def test_ffn_oracle_backward_and_identities():
     assert_close(y1, y0, rtol=1e-9, arel=1e-9, name="shift invariance")
 
 
+def test_all_masked_row_ungated_is_uniform_like_fp32_reference():
+    """SURVEY 8(a) a5/a11 (probed fp32 facts): logit + (-1e9) rounds to exactly -1e9, so a row whose
+    keys are all masked attends UNIFORMLY over its least-masked keys in the ungated variant -- the
+    fp64 evaluation of the oracle must reproduce that rounding, not keep the logit differences."""
+    from oracle import egt_oracle as O
+    torch.manual_seed(0)
+    B, N, H, d = 1, 4, 8, 2
+    QKV = torch.randn(B, N, 3 * d * H, dtype=torch.float64)
+    E = torch.randn(B, N, N, H, dtype=torch.float64)
+    mask = torch.ones(B, N, dtype=torch.bool)
+    rm = torch.zeros(B, N, N, H, dtype=torch.bool)
+    rm[0, 1] = True                       # query row 1: every key hit by the random mask
+    rm[0, 2, :3] = True                   # row 2: keys 0..2 masked, key 3 free
+    V_att, _, A = O.egt_forward(QKV, E, None, None, mask, num_heads=H, rand_mask=rm)
+    assert torch.allclose(A[0, 1], torch.full((N, H), 1.0 / N, dtype=torch.float64), atol=1e-12)
+    assert torch.allclose(A[0, 2, 3], torch.ones(H, dtype=torch.float64)) and float(A[0, 2, :3].abs().max()) == 0.0
+    A32 = O.egt_forward(QKV.float(), E.float(), None, None, mask, num_heads=H, rand_mask=rm)[2]
+    assert torch.allclose(A32.double(), A, atol=1e-6)
+
+
 def test_fp32_oracle_close_to_fp64():
     inp, params, attrs, _ = CS.make_block_case("residual_zinc500k")
     o64 = CS.block_oracle(inp, params, attrs, torch.float64)

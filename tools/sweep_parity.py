@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the fused stack (and FFN) against the fp64 oracle over edge-case
+geometries.  Test infrastructure (imports oracle/): run on the GPU box, prints failures."""
+import itertools
+import os
+import random
+import sys
+import traceback
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from util import assert_close, BWD  # noqa: E402
+from test_block_gpu import PMAP  # noqa: E402
+
+
+def one(N, De, d, gated, train, Ly, B, dev, seed):
+    from egt_amd import EGTStack
+    from egt_amd.fused import layer_seed
+    from oracle import egt_oracle as O, rng_ref
+    Dh, p = 8 * d, 0.25
+    torch.manual_seed(seed)
+    st = EGTStack(model_height=Ly, model_width=Dh, edge_width=De, num_heads=8, gate_attention=gated,
+                  random_mask_prob=p if train else 0.0, seed=seed, fused=True).to(dev).train(train)
+    with torch.no_grad():
+        for prm in st.parameters():
+            if prm.dim() == 1:
+                prm.add_(0.2 * torch.randn_like(prm))
+    g = torch.Generator().manual_seed(seed + 1)
+    h = torch.randn(B, N, Dh, generator=g); e = torch.randn(B, N, N, De, generator=g) * 1.3
+    mask = torch.ones(B, N, dtype=torch.bool)
+    if N > 2:
+        mask[B - 1, N - max(1, N // 4):] = False
+    dh = torch.randn(B, N, Dh, generator=g); de = torch.randn(B, N, N, De, generator=g)
+    hg = h.to(dev).requires_grad_(); eg = e.to(dev).requires_grad_()
+    h2, e2 = st(hg, eg, mask.to(dev))
+    assert st.last_path == "fused-stack", st.last_path
+    torch.autograd.backward([h2, e2], [dh.to(dev), de.to(dev)])
+    names = {k: v for k, v in PMAP.items() if gated or not k.startswith("attention_gates")}
+    layers = [{k: getattr(getattr(blk, m), a_).detach().double().cpu().requires_grad_()
+               for k, (m, a_) in names.items()} for blk in st.blocks]
+    rms = None
+    if train:
+        b0 = st.blocks[0].mha
+        sd = (b0.seed * 0x9E3779B97F4A7C15 + b0._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        rms = [torch.from_numpy(rng_ref.random_mask(layer_seed(sd, l), B, N, 8, p)) for l in range(Ly)]
+    h64 = h.double().requires_grad_(); e64 = e.double().requires_grad_()
+    ho, eo = O.stack_forward(h64, e64, mask, layers, num_heads=8, rand_masks=rms, gate_attention=gated)
+    flat = [t for lp in layers for t in lp.values()]
+    gr = torch.autograd.grad([ho, eo], [h64, e64] + flat, [dh.double(), de.double()])
+    assert_close(h2, ho, name="h_out", rtol=2e-4, arel=5e-5)
+    assert_close(e2, eo, name="e_out", rtol=2e-4, arel=5e-5)
+    assert_close(hg.grad, gr[0], name="dh", **BWD)
+    assert_close(eg.grad, gr[1], name="de", **BWD)
+    gi = iter(gr[2:])
+    for li, blk in enumerate(st.blocks):
+        for k, (m, a_) in names.items():
+            assert_close(getattr(getattr(blk, m), a_).grad, next(gi), name=f"L{li}.{k}", **BWD)
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    rnd = random.Random(2024)
+    Ns = [1, 2, 3, 7, 15, 16, 17, 31, 32, 33, 47, 48, 49, 64, 65, 80]
+    combos = []
+    for N in Ns:
+        for _ in range(3):
+            combos.append((N, rnd.choice([8, 16, 32, 48, 64]), rnd.choice([1, 2, 3, 4, 5, 6, 7, 8]),
+                           rnd.random() < 0.8, rnd.random() < 0.5, rnd.choice([1, 2, 3]), rnd.choice([1, 2, 5])))
+    combos += [(64, 64, 8, True, True, 3, 4), (64, 64, 8, False, False, 2, 3), (128, 64, 8, True, True, 1, 2),
+               (16, 64, 8, True, False, 2, 1), (96, 16, 8, True, True, 2, 2)]
+    bad = 0
+    for i, (N, De, d, gated, train, Ly, B) in enumerate(combos):
+        try:
+            one(N, De, d, gated, train, Ly, B, dev, seed=100 + i)
+        except Exception as ex:  # noqa: BLE001
+            bad += 1
+            print("FAIL", dict(N=N, De=De, d=d, gated=gated, train=train, Ly=Ly, B=B), type(ex).__name__, str(ex)[:300])
+            if not isinstance(ex, AssertionError):
+                traceback.print_exc()
+    print(f"sweep: {len(combos) - bad}/{len(combos)} geometries ok")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
