@@ -60,6 +60,35 @@ def one(N, De, d, gated, train, Ly, B, dev, seed):
             assert_close(getattr(getattr(blk, m), a_).grad, next(gi), name=f"L{li}.{k}", **BWD)
 
 
+def one_attn(N, d, opts, B, dev, seed):
+    """inner op through the C-ABI (general kernels, and the MFMA path when d in {16,32,64}) vs the oracle"""
+    import cases as CS
+    from test_attn_gpu import run_hip, compare
+    H = 8
+    g = torch.Generator().manual_seed(seed)
+    QKV = torch.randn(B, N, 3 * d * H, generator=g) * 0.8
+    E = torch.randn(B, N, N, H, generator=g) if opts["edge"] else None
+    G = torch.randn(B, N, N, H, generator=g) if opts["gate"] else None
+    M = None
+    if opts["attn_mask"]:
+        M = (torch.rand(B, N, N, generator=g) > 0.4).float()[..., None].repeat(1, 1, 1, H).contiguous()
+    mask = None
+    if opts["pad"]:
+        mask = torch.ones(B, N, dtype=torch.bool)
+        mask[B - 1, N - max(1, N // 3):] = False
+    rm = (torch.rand(B, N, N, H, generator=g) < 0.3) if opts["rand"] else None
+    pd = 0.2 if opts["drop"] else 0.0
+    dk = (torch.rand(B, N, N, H, generator=g) >= pd) if opts["drop"] else None
+    inp = dict(QKV=QKV, E=E, G=G, M=M, mask=mask, rand_mask=rm, drop_keep=dk,
+               dV=torch.randn(B, N, d * H, generator=g), dH=torch.randn(B, N, N, H, generator=g))
+    attrs = dict(num_heads=H, clip_logits_value=(-5.0, 5.0) if opts["clip"] else None,
+                 scale_degree=opts["deg"] and opts["gate"], scaler_type=opts["scaler"],
+                 num_virtual_nodes=1 if (opts["deg"] and N > 2) else 0, attn_dropout=pd)
+    compare(run_hip(inp, attrs, dev, a_tild=opts["atild"]) if opts["atild"] else
+            {**run_hip(inp, attrs, dev, a_tild=False), "A_tild": CS.attn_oracle(inp, attrs)["A_tild"]},
+            CS.attn_oracle(inp, attrs))
+
+
 def main():
     dev = torch.device("cuda", 0)
     rnd = random.Random(2024)
@@ -81,6 +110,23 @@ def main():
             if not isinstance(ex, AssertionError):
                 traceback.print_exc()
     print(f"sweep: {len(combos) - bad}/{len(combos)} geometries ok")
+    nat = 0
+    for i in range(70):
+        N = rnd.choice([1, 2, 3, 5, 15, 16, 17, 33, 48, 63, 64, 70])
+        d = rnd.choice([1, 2, 3, 5, 8, 8, 16, 32, 64])
+        opts = dict(edge=rnd.random() < 0.8, gate=rnd.random() < 0.7, attn_mask=rnd.random() < 0.3,
+                    pad=rnd.random() < 0.7, rand=rnd.random() < 0.5, drop=rnd.random() < 0.25,
+                    clip=rnd.random() < 0.8, deg=rnd.random() < 0.25, scaler=rnd.choice(["log", "linear"]),
+                    atild=rnd.random() < 0.5)
+        nat += 1
+        try:
+            one_attn(N, d, opts, rnd.choice([1, 2, 3]), dev, seed=500 + i)
+        except Exception as ex:  # noqa: BLE001
+            bad += 1
+            print("FAIL attn", dict(N=N, d=d, **opts), type(ex).__name__, str(ex)[:300])
+            if not isinstance(ex, AssertionError):
+                traceback.print_exc()
+    print(f"sweep: inner op {nat} random configurations done, total failures {bad}")
     return 1 if bad else 0
 
 
