@@ -669,297 +669,6 @@ __global__ void __launch_bounds__(256, 1) k_block_bwd(BlockArgs a) {
 }
 
 
-// ======================================================= backward, DMA-staged ====
-// Same math as k_block_bwd, restructured to fit two wavefronts per SIMD (<= 256 registers,
-// <= 80 KiB LDS per workgroup) for full 16-key tiles and De % 16 == 0:
-//  * e / de' tiles arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction;
-//    the XOR swizzle is applied on the per-lane SOURCE address, the LDS image stays linear),
-//    one row ahead, so no staging registers and no ds_write pass;
-//  * the dH_ext and d(ehat) weight operands are read from LDS instead of living in registers;
-//  * the pair-major xhat operands of the T contraction are lifted into registers right after
-//    LayerNorm, which frees the e tile for the next row's DMA three quarters of a row early;
-//  * dQ partials go to HBM per key tile (summed in k_node_bwd) instead of an LDS slab.
-typedef __attribute__((address_space(3))) void* lds_vptr;
-typedef const __attribute__((address_space(1))) void* gbl_vptr;
-
-template <int DE>
-__device__ __forceinline__ void tile_dma(float* tl, const float* src, int lane) {
-  using G = Geo<DE>;
-  constexpr int NI = G::NF4 / 64;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int f = i * 64 + lane, row = f / G::NSLOT, slot = f % G::NSLOT;
-    const float* g = src + row * DE + ((slot ^ swz<DE>(row)) << 2);
-    __builtin_amdgcn_global_load_lds((gbl_vptr)g, (lds_vptr)(tl + i * 256), 16, 0, 0);
-  }
-}
-
-__device__ __forceinline__ void dma_wait_all() {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
-
-template <int DE, bool ML, int WPS>
-__global__ void __launch_bounds__(256, WPS) k_block_bwd_dma(BlockArgs a) {
-  using G = Geo<DE>;
-  static_assert(DE % 16 == 0, "DMA path needs whole 1 KiB wave-instructions per tile");
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int p = lane & 15, q = lane >> 4;
-  const int N = a.N, TL = a.TL;
-  const int b = blockIdx.x / a.NLR, lr = blockIdx.x % a.NLR;
-  const int l_begin = lr * TL, l_end = min(N, l_begin + TL), nl = l_end - l_begin;
-  const bool gated = (a.flags & EGT_BF_GATE) != 0;
-  const bool clip = (a.flags & EGT_BF_CLIP) != 0;
-  constexpr int PW = 3 * G::TILE_FLOATS + 256 + 192;
-  constexpr int WL = G::DEP + 4;
-  float* et = sm + wave * PW;
-  float* dt0 = et + G::TILE_FLOATS;
-  float* sc1 = dt0 + 2 * G::TILE_FLOATS;
-  float* sc2 = sc1 + 256;
-  float* qd = sm + 4 * PW;            // [TL][QD_LD]
-  float* wrl = qd + TL * QD_LD;       // Wr    [8][WL]
-  float* wpt = wrl + 8 * WL;          // Wp^T  [16][WL]
-  for (int i = threadIdx.x; i < nl * 40; i += 256) {
-    const int r = i / 40, f = i % 40;
-    const size_t rowl = (size_t)b * N + l_begin + r;
-    const float* src = f < 16 ? a.qkvp + rowl * QKVP + f * 4
-                     : f < 32 ? a.dvp + rowl * 64 + (f - 16) * 4
-                              : a.stats + rowl * 32 + (f - 32) * 4;
-    float4 v = *reinterpret_cast<const float4*>(src);
-    if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
-    *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
-  }
-  for (int i = threadIdx.x; i < 8 * DE; i += 256) wrl[(i / DE) * WL + (i % DE)] = a.Wr[i];
-  for (int i = threadIdx.x; i < G::DEP * 16; i += 256) wpt[(i & 15) * WL + (i >> 4)] = a.pw[i];
-
-  float wA[4 * G::TILES], c2r[4];
-#pragma unroll
-  for (int t = 0; t < 4 * G::TILES; ++t) wA[t] = a.pw[(16 * (t >> 2) + 4 * q + (t & 3)) * 16 + p];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) c2r[r] = a.pw[G::DEP * 16 + 4 * q + r];
-  // dH_ext rows: i = 4q'+0 -> head 2q', i = 4q'+1 -> head 2q'+1, rows 4q'+2,3 empty
-  const float* wr_row = wrl + (2 * (p >> 2) + (p & 1)) * WL + 4 * q;
-  const bool wr_live = (p & 2) == 0;
-
-  v4f accT[G::TILES], accR[G::TILES];
-#pragma unroll
-  for (int t = 0; t < G::TILES; ++t) { accT[t] = (v4f){0.f, 0.f, 0.f, 0.f}; accR[t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
-  float ssum[4] = {0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-
-  const int ntile = N / 16;
-  for (int mt = wave; mt < ntile; mt += 4) {
-    const int m0 = mt * 16, m = m0 + p;
-    float Kf[16], Vf[16], dKa[16], dVa[16];
-    const size_t rowm = (size_t)b * N + m;
-    {
-      const float4* kp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 64 + q * 16);
-      const float4* vp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 128 + q * 16);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 kv = kp[i], vv = vp[i];
-        Kf[4*i] = kv.x; Kf[4*i+1] = kv.y; Kf[4*i+2] = kv.z; Kf[4*i+3] = kv.w;
-        Vf[4*i] = vv.x; Vf[4*i+1] = vv.y; Vf[4*i+2] = vv.z; Vf[4*i+3] = vv.w;
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { dKa[i] = 0.f; dVa[i] = 0.f; }
-    }
-    const float kadd = (a.km && a.km[rowm] == 0) ? -EGT_NEG : 0.0f;
-    lds_sync();   // the previous key tile's flush has left the de' buffers
-    {
-      const size_t pair0 = ((size_t)b * N + l_begin) * N + m0;
-      tile_dma<DE>(dt0, a.de_out + pair0 * DE, lane);
-      tile_dma<DE>(et, a.e + pair0 * DE, lane);
-    }
-    for (int l = l_begin; l < l_end; ++l) {
-      const int li = l - l_begin;
-      const size_t rowl = (size_t)b * N + l;
-      const size_t pair0 = rowl * N + m0;
-      float* dt = dt0 + (li & 1) * G::TILE_FLOATS;
-      float* dtp = dt0 + ((li + 1) & 1) * G::TILE_FLOATS;
-      dma_wait_all();                       // e(l), de'(l) have landed (issued a row ago)
-      MaskRegs mr{make_float2(1.f, 1.f), 0};
-      mask_gload<ML>(a, mr, pair0 + p, q);
-      if (li > 0) tile_from_lds<DE>(dtp, a.de + (pair0 - (size_t)N) * DE, lane, 16);   // de(l-1) out
-      lds_sync();
-      if (l + 1 < l_end) tile_dma<DE>(dtp, a.de_out + (pair0 + (size_t)N) * DE, lane);  // de'(l+1) in
-
-      float4 x[G::TILES];
-#pragma unroll
-      for (int t = 0; t < G::TILES; ++t) x[t] = frag_read<DE>(et, p, q, t);
-      const float rstd = ln_frags<DE>(x, q, a.ln_eps);
-#pragma unroll
-      for (int t = 0; t < G::TILES; ++t) frag_write<DE>(et, p, q, t, x[t]);
-      v4f acc = {c2r[0], c2r[1], c2r[2], c2r[3]};
-      acc = project<DE>(x, wA, acc);
-      lds_sync();
-      // pair-major xhat operands of the T contraction, then the e tile is free for row l+1
-      float ax[G::TILES][4];
-#pragma unroll
-      for (int t = 0; t < G::TILES; ++t)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) ax[t][s] = elem_read<DE>(et, q + 4 * s, 16 * t + p);
-      lds_sync();
-      if (l + 1 < l_end) tile_dma<DE>(et, a.e + (pair0 + (size_t)N) * DE, lane);        // e(l+1) in
-
-      // dH_ext = de'.Wr^T (rows 4q, 4q+1 of D = heads 2q, 2q+1); weights from LDS
-      v4f dhx = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < G::TILES; ++t) {
-        const float4 dyv = frag_read<DE>(dt, p, q, t);
-        float4 wv = *reinterpret_cast<const float4*>(wr_row + 16 * t);
-        if (!wr_live) wv = make_float4(0.f, 0.f, 0.f, 0.f);
-        dhx = MFMA(wv.x, dyv.x, dhx);
-        dhx = MFMA(wv.y, dyv.y, dhx);
-        dhx = MFMA(wv.z, dyv.z, dhx);
-        dhx = MFMA(wv.w, dyv.w, dhx);
-      }
-      float Qf[16], dVf[16], st[8];
-      {
-        const float* qr = qd + li * QD_LD;
-        const float4* qp = reinterpret_cast<const float4*>(qr + q * 16);
-        const float4* dp = reinterpret_cast<const float4*>(qr + 64 + q * 16);
-        const float4* sp = reinterpret_cast<const float4*>(qr + 128 + q * 8);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float4 u = qp[i], v = dp[i];
-          Qf[4*i] = u.x; Qf[4*i+1] = u.y; Qf[4*i+2] = u.z; Qf[4*i+3] = u.w;
-          dVf[4*i] = v.x; dVf[4*i+1] = v.y; dVf[4*i+2] = v.z; dVf[4*i+3] = v.w;
-        }
-        const float4 s0 = sp[0], s1 = sp[1];
-        st[0] = s0.x; st[1] = s0.y; st[2] = s0.z; st[4] = s1.x; st[5] = s1.y; st[6] = s1.z;
-      }
-      float hh[2], xl[2], gl[2], inr[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float dot = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dot = fmaf(Qf[2 * k + j], Kf[2 * k + j], dot);
-        const float araw = dot * a.scale;
-        float ah = araw;
-        inr[j] = 1.0f;
-        if (clip) {
-          inr[j] = (araw >= a.clip_lo && araw <= a.clip_hi) ? 1.0f : 0.0f;
-          ah = fminf(fmaxf(araw, a.clip_lo), a.clip_hi);
-        }
-        hh[j] = ah + acc[2 * j + 1];
-        xl[j] = hh[j];
-        gl[j] = acc[2 * j];
-      }
-      apply_masks<ML>(a, kadd, mr, (pair0 + p) * BH, q, xl, gl);
-      float dge[4], dq[16];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float S = __expf(xl[j] - st[4 * j]) * st[4 * j + 1];
-        const float g = gated ? egt_sigmoid(gl[j]) : 1.0f;
-        float dAd = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dAd = fmaf(dVf[2 * k + j], Vf[2 * k + j], dAd);
-        const float dS = dAd * g;
-        const float dGl = gated ? dAd * S * g * (1.0f - g) : 0.f;
-        const float dH = S * (dS - st[4 * j + 2]) + dhx[j];
-        const float dA = dH * inr[j] * a.scale;
-        const float at = S * g;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          dq[2 * k + j] = dA * Kf[2 * k + j];
-          dKa[2 * k + j] = fmaf(dA, Qf[2 * k + j], dKa[2 * k + j]);
-          dVa[2 * k + j] = fmaf(at, dVf[2 * k + j], dVa[2 * k + j]);
-        }
-        dge[2 * j] = dGl;
-        dge[2 * j + 1] = dH;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ssum[r] += dge[r];
-      *reinterpret_cast<float4*>(sc1 + p * 16 + 4 * q) = make_float4(dge[0], dge[1], dge[2], dge[3]);
-      *reinterpret_cast<float2*>(sc2 + p * 12 + 2 * q) = make_float2(hh[0], hh[1]);
-      if (q == 0) sc2[p * 12 + 8] = 1.0f;
-      // dQ[l] partial over this tile's 16 keys -> HBM, summed over key tiles in k_node_pre_bwd
-      a.dqp[(((size_t)b * ntile + mt) * N + l) * 64 + lane] = reduce16_keep_own(dq, p);
-
-      // d(ehat) = Wp . dGE (weights from LDS), LayerNorm backward
-      float4 dxh[G::TILES];
-      float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-      for (int t = 0; t < G::TILES; ++t) {
-        v4f d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) d = MFMA(wpt[(4 * q + s) * WL + 16 * t + p], dge[s], d);
-        dxh[t] = make_float4(d[0], d[1], d[2], d[3]);
-        m1 += (d[0] + d[1]) + (d[2] + d[3]);
-        m2 = fmaf(d[0], x[t].x, m2); m2 = fmaf(d[1], x[t].y, m2);
-        m2 = fmaf(d[2], x[t].z, m2); m2 = fmaf(d[3], x[t].w, m2);
-      }
-      m1 = sum_over_q(m1) * (1.0f / DE);
-      m2 = sum_over_q(m2) * (1.0f / DE);
-      lds_sync();
-      // weight-gradient contractions over the 16 pairs of the tile
-      float bT[4], bR[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        bT[s] = sc1[(q + 4 * s) * 16 + p];
-        bR[s] = (p < 9) ? sc2[(q + 4 * s) * 12 + p] : 0.f;
-      }
-#pragma unroll
-      for (int t = 0; t < G::TILES; ++t)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          accT[t] = MFMA(ax[t][s], bT[s], accT[t]);
-          accR[t] = MFMA(elem_read<DE>(dt, q + 4 * s, 16 * t + p), bR[s], accR[t]);
-        }
-      lds_sync();
-      // de = de' + LN_bwd(d ehat), in place over the de' tile; it leaves with the next row's stores
-#pragma unroll
-      for (int t = 0; t < G::TILES; ++t) {
-        const float4 dyv = frag_read<DE>(dt, p, q, t);
-        float4 o;
-        o.x = dyv.x + rstd * (dxh[t].x - m1 - x[t].x * m2);
-        o.y = dyv.y + rstd * (dxh[t].y - m1 - x[t].y * m2);
-        o.z = dyv.z + rstd * (dxh[t].z - m1 - x[t].z * m2);
-        o.w = dyv.w + rstd * (dxh[t].w - m1 - x[t].w * m2);
-        frag_write<DE>(dt, p, q, t, o);
-      }
-    }
-    {  // flush the last row of this key tile
-      lds_sync();
-      const int li = nl - 1;
-      tile_from_lds<DE>(dt0 + (li & 1) * G::TILE_FLOATS,
-                        a.de + (((size_t)b * N + l_end - 1) * N + m0) * DE, lane, 16);
-    }
-    float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
-    float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
-      vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    ssum[r] = row_sum16(ssum[r]);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  float* ep = sm + wave * G::EP;
-#pragma unroll
-  for (int t = 0; t < G::TILES; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      ep[(16 * t + 4 * q + r) * 16 + p] = accT[t][r];
-      ep[G::DEP * 16 + 16 + (16 * t + 4 * q + r) * 16 + p] = accR[t][r];
-    }
-  if (p == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ep[G::DEP * 16 + 4 * q + r] = ssum[r];
-  }
-  __syncthreads();
-  float* out = a.epart + (size_t)blockIdx.x * G::EP;
-  for (int i = threadIdx.x; i < G::EP; i += 256)
-    out[i] = (sm[i] + sm[G::EP + i]) + (sm[2 * G::EP + i] + sm[3 * G::EP + i]);
-}
-
-
 // ================================================ backward, register-lean ("v4") ====
 // Same math as k_block_bwd for full 16-key tiles, restructured so that two wavefronts fit a
 // SIMD (<= 256 registers, <= 80 KiB LDS per workgroup): the long per-tile dependency chain
@@ -1473,7 +1182,7 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
   const bool ml = a.M != nullptr || a.rm != nullptr;
   const bool full = (a.N % 16) == 0;
   if constexpr (DE % 16 == 0) {
-    if (full && !egt_env_flag("EGT_BWD_V2") && (a.bf16 || !egt_env_flag("EGT_BWD_DMA"))) {   // register-lean, 2 waves/SIMD
+    if (full && !egt_env_flag("EGT_BWD_V2")) {   // register-lean, 2 waves/SIMD
       const size_t lds_v4 = ((size_t)4 * PW + (size_t)BWD_TL * QD_LD + 3 * GG::TILES * 256) * 4;
       a.NQP = a.N / 16;
       { const char* e = getenv("EGT_BWD_ABLATE"); a.guard = e ? atoi(e) : 0; }   // measurement only: drops phases
@@ -1491,22 +1200,6 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
       else if (pf == 1) V4_VARIANT(false, 1, false);
       else V4_VARIANT(false, 2, false);
 #undef V4_VARIANT
-      goto pair_done;
-    }
-    if (full && !a.bf16 && egt_env_flag("EGT_BWD_DMA")) {   // experimental DMA-staged variant (hipcc drains vmcnt after every LDS-DMA)
-      constexpr int WL = GG::DEP + 4;
-      const size_t lds_dma = ((size_t)4 * PW + (size_t)BWD_TL * QD_LD + 24 * WL) * 4;
-      a.NQP = a.N / 16;
-#define DMA_VARIANT(ML_, WPS_)                                                                         \
-  do {                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)k_block_bwd_dma<DE, ML_, WPS_>,                             \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
-    EGT_LAUNCH("k_block_bwd", (k_block_bwd_dma<DE, ML_, WPS_>), dim3(L.nwg_bwd), dim3(256), lds_dma, st, a); \
-  } while (0)
-      const bool one = egt_env_flag("EGT_BWD_WPS1");
-      if (ml) { if (one) DMA_VARIANT(true, 1); else DMA_VARIANT(true, 2); }
-      else { if (one) DMA_VARIANT(false, 1); else DMA_VARIANT(false, 2); }
-#undef DMA_VARIANT
       goto pair_done;
     }
   }
