@@ -20,6 +20,15 @@ struct BlockArgs {
   int NQP;      // backward: dQ partials per row (key tiles) in dqp [B][NQP][N][64]
   int epi;      // forward epilogue in k_block_fwd: 0 none, 1 dense_mha+res, 2 + next block's norm_mha/dense_qkv
   int xcd;      // pair kernels: XCD-aware workgroup order
+  // backward prologue of k_block_bwd_v4 (Dh = 64): the node-side step between two pair kernels is
+  // done per 16-row workgroup inside the lower layer's kernel.  pro = 0: dV_att / delta come from
+  // dvp / stats (k_node_bwd ran); 1: chain top, dh' rows = dh_out; 2: dh' rows are computed here
+  // from the partials of the layer ABOVE (up_*): dQKV gather, d h_ln = dQKV.Wqkv^T, LN backward.
+  int pro;
+  const float *up_h, *up_nm_g, *up_Wqkv, *up_dh_out, *up_dqp, *up_dkvp;
+  float *up_dqkv_sv, *up_spart;
+  float *sbo;    // per-workgroup partials of this layer's dense_mha bias gradient
+  int spart_n, sbo_n;   // how many workgroup partials the reduction finds in spart / sbo
   int guard;    // backward phase guards (always 0 in production, see k_block_bwd_v4)
   int prep;     // node kernels: add the edge-weight preparation workgroup
   const float *nx_nm_g, *nx_nm_b, *nx_Wqkv, *nx_bqkv;   // next block (epi == 2)

@@ -687,6 +687,191 @@ __global__ void __launch_bounds__(256, 1) k_block_bwd(BlockArgs a) {
 //    registers, 116 -> 104 us.  (EGT_BWD_ABLATE sets the bits for phase-cost measurements.)
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// ---- node-side prologue of the backward pair kernel (Dh = 64, 16 rows, 256 threads) -------------
+// What k_node_bwd does between two pair kernels is local to a node row, so the workgroup that
+// owns 16 query rows of layer L does it itself before its tile loop:
+//   [pro == 2] rows of the layer above (L+1): dQKV = packed dQ + dK/dV partial sums (written by the
+//              pair kernel of L+1), d h_ln = dQKV.Wqkv^T (48 MFMA / wave), LayerNorm backward +
+//              residual -> dh(L+1) = dh'(L); dQKV and dh rows go to HBM for the deferred weight-
+//              gradient kernel; bias / LN-parameter column sums -> up_spart
+//   [pro == 1] dh'(L) rows = dh_out (top of the chain)
+//   then       dV_att(L) = dh'.Wo^T (16 MFMA / wave, packed straight into the qd rows in LDS),
+//              delta = sum_k dV_att*V_att into the qd statistics, dbo column sums -> sbo
+// One launch per layer on the dh critical path instead of two; dV_att / delta never touch HBM.
+// `ws`: the (still idle) per-wave tile area; `qd`: the staged [16][QD_LD] rows.
+#define BWD_PRO_WS 8192   // floats of LDS scratch the prologue needs (dQKV, xhat, d h_ln, dh' rows, partials)
+template <int DE>
+__device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg) {
+  constexpr int LD = 68, LD3 = 196;
+  float* dqs = ws;                   // dQKV  [16][196]
+  float* xs = dqs + 16 * LD3;        // xhat  [16][68]
+  float* dls = xs + 16 * LD;         // d h_ln
+  float* dhs = dls + 16 * LD;        // dh'
+  float* rs = dhs + 16 * LD;         // rstd  [16]
+  float* dlp = rs + 16;              // delta partials [4][16][8]
+  static_assert(16 * LD3 + 3 * 16 * LD + 16 + 4 * 16 * 8 <= BWD_PRO_WS, "prologue scratch");
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int p = lane & 15, q = lane >> 4, N = a.N;
+  const size_t row0 = (size_t)b * N + l_begin;
+  const int lnrow = 4 * wave + q;    // LayerNorm mapping: row 4*wave + q, columns p + 16 i
+  if (a.pro == 2) {
+    // ---- every global input in one round trip ----
+    float4 hx = *reinterpret_cast<const float4*>(a.up_h + (row0 + (t >> 4)) * 64 + (t & 15) * 4);
+    float4 gq[3];
+    float dho[4], gmm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dho[i] = a.up_dh_out[(row0 + lnrow) * 64 + p + 16 * i];
+      gmm[i] = a.up_nm_g[p + 16 * i];
+    }
+    const int NP = a.NQP;   // = NLR = N / 16 on this path
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = t + u * 256, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
+      const float* base = sx == 0 ? a.up_dqp + ((size_t)b * NP * N + l_begin + r) * 64 + pos4
+                                  : a.up_dkvp + (((size_t)b * NP * N + l_begin + r) * 2 + (sx - 1)) * 64 + (pos4 & 63);
+      const size_t pstride = sx == 0 ? (size_t)N * 64 : (size_t)N * 128;
+      float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+      for (int pi = 0; pi < NP; ++pi) {
+        const float4 w = *reinterpret_cast<const float4*>(base + pi * pstride);
+        acc4.x += w.x; acc4.y += w.y; acc4.z += w.z; acc4.w += w.w;
+      }
+      gq[u] = acc4;
+    }
+    // B operand of d h_ln = dQKV.Wqkv^T: Wqkv[kk = 16 wave + p][48 q .. 48 q + 47] (contraction order c = 48 q + s)
+    float4 wq[12];
+#pragma unroll
+    for (int s = 0; s < 12; ++s)
+      wq[s] = *reinterpret_cast<const float4*>(a.up_Wqkv + (size_t)(16 * wave + p) * 192 + 48 * q + 4 * s);
+    *reinterpret_cast<float4*>(xs + (t >> 4) * LD + (t & 15) * 4) = hx;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = t + u * 256, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
+      const int qq = (pos4 >> 4) & 3, k0 = (pos4 >> 1) & 7;
+      float* d = dqs + r * LD3 + sx * 64 + k0 * 8 + 2 * qq;
+      d[0] = gq[u].x; d[1] = gq[u].y; d[8] = gq[u].z; d[9] = gq[u].w;
+    }
+    __syncthreads();
+    {   // LN forward statistics -> xhat in place
+      float* xr = xs + lnrow * LD;
+      float v[4], s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = xr[p + 16 * i]; s1 += v[i]; }
+      const float mu = row_sum16(s1) * (1.0f / 64);
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] -= mu; ss = fmaf(v[i], v[i], ss); }
+      const float rstd = rsqrtf(row_sum16(ss) * (1.0f / 64) + a.ln_eps);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xr[p + 16 * i] = v[i] * rstd;
+      if (p == 0) rs[lnrow] = rstd;
+    }
+    {   // d h_ln[row][kk] for kk tile = wave
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
+      const float* ar = dqs + p * LD3 + 48 * q;
+#pragma unroll
+      for (int s = 0; s < 12; ++s) {
+        const float4 av = *reinterpret_cast<const float4*>(ar + 4 * s);
+        acc = MFMA(av.x, wq[s].x, acc);
+        acc = MFMA(av.y, wq[s].y, acc);
+        acc = MFMA(av.z, wq[s].z, acc);
+        acc = MFMA(av.w, wq[s].w, acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dls[(4 * q + r) * LD + 16 * wave + p] = acc[r];
+    }
+    for (int i = t; i < 16 * 48; i += 256) {   // dQKV rows out (natural channel order) for k_node_wgrads
+      const int r = i / 48, c4 = (i % 48) * 4;
+      *reinterpret_cast<float4*>(a.up_dqkv_sv + (row0 + r) * 192 + c4) = *reinterpret_cast<const float4*>(dqs + r * LD3 + c4);
+    }
+    __syncthreads();
+    {   // LayerNorm backward + residual -> dh' rows (HBM + LDS)
+      const float* xr = xs + lnrow * LD;
+      const float* dl = dls + lnrow * LD;
+      float dx[4], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dx[i] = dl[p + 16 * i] * gmm[i];
+        m1 += dx[i];
+        m2 = fmaf(dx[i], xr[p + 16 * i], m2);
+      }
+      m1 = row_sum16(m1) * (1.0f / 64);
+      m2 = row_sum16(m2) * (1.0f / 64);
+      const float rstd = rs[lnrow];
+      float* dh_out_rw = const_cast<float*>(a.dh_out);   // this layer's dh' IS the upper layer's dh
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = p + 16 * i;
+        const float dv = dho[i] + rstd * (dx[i] - m1 - xr[c] * m2);
+        dh_out_rw[(row0 + lnrow) * 64 + c] = dv;
+        dhs[lnrow * LD + c] = dv;
+      }
+    }
+    {   // column sums over the 16 rows: dbqkv | dgamma, dbeta of the layer above
+      float* sp = a.up_spart + (size_t)wg * (192 + 128);
+      if (t < 192) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) { s0 += dqs[r * LD3 + t]; s1 += dqs[(r + 1) * LD3 + t]; }
+        sp[t] = s0 + s1;
+      } else {
+        const int c = t - 192;
+        float g0 = 0.f, b0 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d0 = dls[r * LD + c]; g0 = fmaf(d0, xs[r * LD + c], g0); b0 += d0; }
+        sp[192 + c] = g0;
+        sp[256 + c] = b0;
+      }
+    }
+  } else {
+    *reinterpret_cast<float4*>(dhs + (t >> 4) * LD + (t & 15) * 4) =
+        *reinterpret_cast<const float4*>(a.dh_out + (row0 + (t >> 4)) * 64 + (t & 15) * 4);
+  }
+  // ---- dV_att = dh'.Wo^T for i tile = wave (contraction order c = 16 q + s), delta, dbo ----
+  float4 wo[4];
+  float va[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) wo[s] = *reinterpret_cast<const float4*>(a.Wo + (size_t)(16 * wave + p) * 64 + 16 * q + 4 * s);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) va[r] = a.v_att[(row0 + 4 * q + r) * 64 + 16 * wave + p];
+  __syncthreads();
+  {
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    const float* ar = dhs + p * LD + 16 * q;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float4 av = *reinterpret_cast<const float4*>(ar + 4 * s);
+      acc = MFMA(av.x, wo[s].x, acc);
+      acc = MFMA(av.y, wo[s].y, acc);
+      acc = MFMA(av.z, wo[s].z, acc);
+      acc = MFMA(av.w, wo[s].w, acc);
+    }
+    const int i = 16 * wave + p, k = i >> 3, hh = i & 7;
+    const int pos = (hh >> 1) * 16 + k * 2 + (hh & 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * q + r;
+      qd[row * QD_LD + 64 + pos] = acc[r];
+      float pr = acc[r] * va[r];
+      pr += lane_xor<8>(pr);   // the tile's two k values of head p & 7
+      if (p < 8) dlp[(wave * 16 + row) * 8 + p] = pr;
+    }
+  }
+  if (t < 64) {   // dbo: column sums of dh'
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) { s0 += dhs[r * LD + t]; s1 += dhs[(r + 1) * LD + t]; }
+    a.sbo[(size_t)wg * 64 + t] = s0 + s1;
+  }
+  __syncthreads();
+  if (t < 128) {   // delta of (row, head)
+    const int row = t >> 3, hd = t & 7;
+    qd[row * QD_LD + 128 + hd * 4 + 2] = (dlp[(0 * 16 + row) * 8 + hd] + dlp[(1 * 16 + row) * 8 + hd]) +
+                                         (dlp[(2 * 16 + row) * 8 + hd] + dlp[(3 * 16 + row) * 8 + hd]);
+  }
+}
+
 // PF: how many of the two streamed tiles (e, de') are register-prefetched one row ahead.
 template <int DE, bool ML, int PF, bool BF>
 __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
@@ -712,19 +897,25 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
   float* dt0 = et + G::TILE_FLOATS;
   float* sc1 = dt0 + 2 * G::TILE_FLOATS;
   float* sc2 = sc1 + 256;
-  float* qd = sm + 4 * PW;                   // [TL][QD_LD]
+  constexpr int AREA = 4 * PW > BWD_PRO_WS ? 4 * PW : BWD_PRO_WS;   // per-wave tiles; also the prologue's scratch
+  float* qd = sm + AREA;                     // [TL][QD_LD]
   float* wsA = qd + TL * QD_LD;              // prologue weights   wA[4t+u]
   float* wsB = wsA + WSLAB;                  // dH_ext weights     wrB[4t+u]
   float* wsD = wsB + WSLAB;                  // d(ehat) weights    wD[t][s]
   for (int i = threadIdx.x; i < nl * 40; i += 256) {
     const int r = i / 40, f = i % 40;
     const size_t rowl = (size_t)b * N + l_begin + r;
+    if (a.pro && f >= 16 && f < 32) continue;   // dV_att comes from the prologue below
     const float* src = f < 16 ? a.qkvp + rowl * QKVP + f * 4
                      : f < 32 ? a.dvp + rowl * 64 + (f - 16) * 4
                               : a.stats + rowl * 32 + (f - 32) * 4;
     float4 v = *reinterpret_cast<const float4*>(src);
     if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
     *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
+  }
+  if (a.pro) {
+    __syncthreads();
+    bwd_node_prologue<DE>(a, sm, qd, b, l_begin, wg);
   }
   // weight slabs: element (t, lane, u)
   for (int i = threadIdx.x; i < G::TILES * 256; i += 256) {
@@ -1019,9 +1210,11 @@ static size_t al(size_t x) { return (x + 63) & ~(size_t)63; }  // in floats
 
 struct BlockLayout {
   size_t v_att, stats, qkvp, saved_total;
-  // workspace = [common: dvp dqp dkvp] + per layer [pw epart spart wpart ered dqkv dhbuf]
-  size_t dvp, dqp, dkvp, common_total;
-  size_t pw, epart, spart, wpart, ered, dqkv, dhbuf, layer_total;
+  // workspace = [common: dvp dqp[2] dkvp[2]] + per layer [pw epart spart sbo wpart ered dqkv dhbuf]
+  // (dqp / dkvp alternate by layer parity: the prologue of layer l-1 reads layer l's partials while
+  //  other workgroups of that launch already write their own)
+  size_t dvp, dqp, dkvp, dqp_sz, dkvp_sz, common_total;
+  size_t pw, epart, spart, sbo, wpart, ered, dqkv, dhbuf, layer_total;
   int NLR, nwg_bwd, EP;
 };
 
@@ -1040,13 +1233,20 @@ static BlockLayout layout(const egt_block_desc* d) {
   L.nwg_bwd = d->B * L.NLR;
   o = 0;
   L.dvp = o; o += al(rows * 64);
-  L.dqp = o; o += al(rows * 64 * (size_t)((d->N + 15) / 16));
-  L.dkvp = o; o += al((size_t)d->B * L.NLR * d->N * 128);
+  L.dqp_sz = al(rows * 64 * (size_t)((d->N + 15) / 16));
+  L.dkvp_sz = al((size_t)d->B * L.NLR * d->N * 128);
+  L.dqp = o; o += 2 * L.dqp_sz;
+  L.dkvp = o; o += 2 * L.dkvp_sz;
   L.common_total = o;
   o = 0;
   L.pw = o; o += al((size_t)DEP * 16 + 16);
   L.epart = o; o += al((size_t)L.nwg_bwd * L.EP);
-  L.spart = o; o += al((size_t)d->B * ((d->N + NODE_RC - 1) / NODE_RC) * (6 * Dh));
+  {
+    const size_t nmax = (size_t)(L.nwg_bwd > d->B * ((d->N + NODE_RC - 1) / NODE_RC) ? L.nwg_bwd
+                                                                                        : d->B * ((d->N + NODE_RC - 1) / NODE_RC));
+    L.spart = o; o += al(nmax * (5 * Dh));
+    L.sbo = o; o += al(nmax * Dh);
+  }
   L.wpart = o; o += al((size_t)egt_node_wgrad_chunks((int)rows) * (Dh * 3 * Dh + Dh * Dh));
   L.ered = o; o += al(L.EP);
   L.dqkv = o; o += al(rows * 3 * Dh);
@@ -1056,9 +1256,10 @@ static BlockLayout layout(const egt_block_desc* d) {
 }
 
 // workspace pointers of one layer: `wc` = common region, `wl` = that layer's region
-static void bind_ws(const BlockLayout& L, BlockArgs& a, float* wc, float* wl) {
-  a.dvp = wc + L.dvp; a.dqp = wc + L.dqp; a.dkvp = wc + L.dkvp;
-  a.pw = wl + L.pw; a.epart = wl + L.epart; a.spart = wl + L.spart; a.wpart = wl + L.wpart;
+static void bind_ws(const BlockLayout& L, BlockArgs& a, float* wc, float* wl, int parity = 0) {
+  a.dvp = wc + L.dvp; a.dqp = wc + L.dqp + parity * L.dqp_sz; a.dkvp = wc + L.dkvp + parity * L.dkvp_sz;
+  a.pw = wl + L.pw; a.epart = wl + L.epart; a.spart = wl + L.spart; a.sbo = wl + L.sbo; a.wpart = wl + L.wpart;
+  a.spart_n = a.sbo_n = a.B * ((a.N + NODE_RC - 1) / NODE_RC);   // k_node_bwd's workgroups (prologue path overrides)
   a.ered = wl + L.ered; a.dqkv_sv = wl + L.dqkv;
   a.TL = BWD_TL; a.NLR = L.NLR; a.NQP = 1;
   a.xcd = egt_env_flag("EGT_NO_XCD_REMAP") ? 0 : 1;
@@ -1165,9 +1366,24 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
 // next block of the chain (NULL at the bottom), whose dV_att / delta this block's node kernel
 // produces.  GEMM-shaped weight gradients and all partial reductions are left to the caller.
 template <int DE>
-static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool top, const BlockArgs* below) {
+static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool top, BlockArgs* below, BlockArgs* above) {
   using GG = Geo<DE>;
-  if (top) egt_node_launch_bwd(a, &a, false, st);  // dV_att (packed), delta, dbo sums [+ edge-weight prep]
+  // node-side prologue inside the pair kernel (see bwd_node_prologue): v4 geometry with Dh = 64
+  const bool pro = (DE % 16 == 0) && (a.N % 16) == 0 && a.Dh == 64 && a.DK == 8 && !egt_env_flag("EGT_BWD_V2") &&
+                   !egt_env_flag("EGT_NO_BWD_PROLOGUE");
+  a.pro = 0;
+  if (pro) {
+    a.pro = top ? 1 : 2;
+    a.sbo_n = L.nwg_bwd;
+    if (!top) {
+      a.up_h = above->h; a.up_nm_g = above->nm_g; a.up_Wqkv = above->Wqkv; a.up_dh_out = above->dh_out;
+      a.up_dqp = above->dqp; a.up_dkvp = above->dkvp; a.up_dqkv_sv = above->dqkv_sv; a.up_spart = above->spart;
+      above->spart_n = L.nwg_bwd;
+    }
+    if (a.prep) egt_node_launch_prep(&a, 1, st);   // single-block call: the LN-folded edge weights of this layer
+  } else if (top) {
+    egt_node_launch_bwd(a, &a, false, st);  // dV_att (packed), delta, dbo sums [+ edge-weight prep]
+  }
   constexpr int PW = 3 * GG::TILE_FLOATS + 256 + 192;
   static_assert(4 * GG::EP <= 4 * PW, "edge partial staging must fit the LDS tile area");
   const size_t lds = ((size_t)4 * PW + (size_t)4 * BWD_TL * 64 + (size_t)BWD_TL * QD_LD) * 4;
@@ -1183,7 +1399,7 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
   const bool full = (a.N % 16) == 0;
   if constexpr (DE % 16 == 0) {
     if (full && !egt_env_flag("EGT_BWD_V2")) {   // register-lean, 2 waves/SIMD
-      const size_t lds_v4 = ((size_t)4 * PW + (size_t)BWD_TL * QD_LD + 3 * GG::TILES * 256) * 4;
+      const size_t lds_v4 = ((size_t)(4 * PW > BWD_PRO_WS ? 4 * PW : BWD_PRO_WS) + (size_t)BWD_TL * QD_LD + 3 * GG::TILES * 256) * 4;
       a.NQP = a.N / 16;
       { const char* e = getenv("EGT_BWD_ABLATE"); a.guard = e ? atoi(e) : 0; }   // measurement only: drops phases
 #define V4_VARIANT(ML_, PF_, BF_)                                                                          \
@@ -1209,7 +1425,8 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
 pair_done:
 #undef BWD_VARIANT
 #undef BWD_VARIANT_T
-  egt_node_launch_bwd(a, below, true, st);   // dQKV -> dh, bias/LN sums; dV_att + delta of the block below
+  if (!pro) egt_node_launch_bwd(a, below, true, st);   // dQKV -> dh, bias/LN sums; dV_att + delta of the block below
+  else if (!below) egt_node_launch_bwd(a, nullptr, true, st);   // bottom of the chain: only dQKV -> dh is left
 }
 
 
@@ -1261,7 +1478,7 @@ extern "C" int egt_block_bwd(const egt_block_desc* desc, const egt_block_params*
   a.g_Wo = (float*)grads->dense_mha_kernel; a.g_bo = (float*)grads->dense_mha_bias;
   a.g_Wr = (float*)grads->dense_edge_r_kernel; a.g_br = (float*)grads->dense_edge_r_bias;
   const BlockLayout L = layout(desc);
-  DISPATCH_BDE(desc->De, launch_bwd<DE>(a, L, (hipStream_t)stream, true, nullptr));
+  DISPATCH_BDE(desc->De, launch_bwd<DE>(a, L, (hipStream_t)stream, true, nullptr, nullptr));
   egt_node_launch_wgrads(&a, 1, (hipStream_t)stream);
   egt_node_launch_reduce(&a, 1, L.nwg_bwd, L.EP, (hipStream_t)stream);  // partial sums + edge param grads
   EGT_HIP_LAUNCH_CHECK("egt_block_bwd");
@@ -1312,7 +1529,7 @@ static void bind_layer(const egt_block_desc* d, const StackLayout& S, const Bloc
   a.v_att = bs + L.v_att; a.stats = bs + L.stats; a.qkvp = bs + L.qkvp;
   // per-layer workspace: block l's epilogue must not race block l+1's prepared weights, and the
   // deferred reductions / weight gradients need every layer's partials and dQKV rows at the end
-  bind_ws(L, a, ws, ws + L.common_total + L.layer_total * (size_t)l);
+  bind_ws(L, a, ws, ws + L.common_total + L.layer_total * (size_t)l, l & 1);
   (void)d;
 }
 
@@ -1416,7 +1633,8 @@ extern "C" int egt_stack_bwd(const egt_block_desc* desc, int32_t layers, const e
   egt_node_launch_prep(as, layers, (hipStream_t)stream);
   for (int l = layers - 1; l >= 0; --l) {
     as[l].prep = 0;
-    DISPATCH_BDE(desc->De, launch_bwd<DE>(as[l], L, (hipStream_t)stream, l == layers - 1, l > 0 ? &as[l - 1] : nullptr));
+    DISPATCH_BDE(desc->De, launch_bwd<DE>(as[l], L, (hipStream_t)stream, l == layers - 1, l > 0 ? &as[l - 1] : nullptr,
+                                             l + 1 < layers ? &as[l + 1] : nullptr));
   }
   egt_node_launch_wgrads(as, layers, (hipStream_t)stream);
   egt_node_launch_reduce(as, layers, L.nwg_bwd, L.EP, (hipStream_t)stream);

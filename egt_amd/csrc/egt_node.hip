@@ -307,12 +307,12 @@ __global__ void __launch_bounds__(512) k_node_post(BlockArgs a) {
 //                        dV_att = dh.Wo^T (packed), delta = sum_k dV_att*V_att, dbo column sums
 // The GEMM-shaped weight gradients (dWqkv, dWo) are NOT computed here: k_node_wgrads does them
 // for every layer of the stack in one launch, off the critical path.
-// small per-workgroup partials of a layer: [dbqkv 3Dh | dgamma Dh | dbeta Dh | dbo Dh]
+// small per-workgroup partials of a layer: spart [dbqkv 3Dh | dgamma Dh | dbeta Dh], sbo [dbo Dh]
 struct NodeBwdArgs {
   const float *wq_a, *wo_a;   // Wqkv / dv_Wo rounded down to 16 bytes
   int wq_al, wo_al;           // ... and whether they were aligned to begin with
   const float *dv_Wo, *dv_v_att, *dv_dh_src;   // dv_dh_src: rows of dh' when do_pre == 0
-  float *dv_stats, *dv_dvp, *dv_spart;
+  float *dv_stats, *dv_dvp, *dv_sbo;
 };
 
 template <bool PRE, bool DV, int NP>   // compile-time roles; NP: partials per gathered unit (0: run-time counts)
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(512, 2) k_node_bwd(BlockArgs a, NodeBwdArgs x)
   const int NCH = (a.N + NODE_RC - 1) / NODE_RC;
   if ((int)blockIdx.x == a.B * NCH) { prep_device(a, sm); return; }
   const int Dh = a.Dh, N = a.N, b = blockIdx.x / NCH, chunk = blockIdx.x % NCH, t = threadIdx.x, D3 = 3 * Dh;
-  const int ld = Dh + LDP, ld3 = D3 + LDP, SP = D3 + 3 * Dh;
+  const int ld = Dh + LDP, ld3 = D3 + LDP, SP = D3 + 2 * Dh;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), p = lane & 15, q = lane >> 4, NW = blockDim.x >> 6;
   float* xs = sm;                        // xhat   [NODE_RC][ld]
   float* dls = xs + NODE_RC * ld;        // d h_ln [NODE_RC][ld]
@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(512, 2) k_node_bwd(BlockArgs a, NodeBwdArgs x)
       const int c = t - 256;
       float b0 = 0.f, b1 = 0.f;
       for (int r = 0; r < nrp; r += 2) { b0 += dhs[r * ld + c]; b1 += dhs[(r + 1) * ld + c]; }
-      x.dv_spart[(size_t)blockIdx.x * SP + D3 + 2 * Dh + c] = b0 + b1;
+      x.dv_sbo[(size_t)blockIdx.x * Dh + c] = b0 + b1;
     }
     __syncthreads();
     for (int i = t; i < nr * 8; i += blockDim.x) {
@@ -787,7 +787,7 @@ void egt_node_launch_bwd(BlockArgs& a, const BlockArgs* dv_layer, bool do_pre, h
   if (dv_layer) {
     x.wo_a = down16(dv_layer->Wo); x.wo_al = x.wo_a == dv_layer->Wo;
     x.dv_Wo = dv_layer->Wo; x.dv_v_att = dv_layer->v_att; x.dv_dh_src = a.dh_out;
-    x.dv_stats = dv_layer->stats; x.dv_dvp = dv_layer->dvp; x.dv_spart = dv_layer->spart;
+    x.dv_stats = dv_layer->stats; x.dv_dvp = dv_layer->dvp; x.dv_sbo = dv_layer->sbo;
   }
   const int Dh = a.Dh, ld = Dh + LDP, ld3 = 3 * Dh + LDP;
   size_t lds = ((size_t)4 * NODE_RC * ld + NODE_RC + 4 * NODE_RC * 8 + (size_t)Dh * ld) * 4;
@@ -848,14 +848,14 @@ void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, hipStream
     };
     for (int l = l0; l < l0 + nl; ++l) {
       BlockArgs& a = as[l];
-      const int Dh = a.Dh, D3 = 3 * Dh, nnp = a.B * node_chunks(a), SP = D3 + 3 * Dh;
+      const int Dh = a.Dh, D3 = 3 * Dh, SP = D3 + 2 * Dh;
       const int nwc = egt_node_wgrad_chunks(a.B * a.N), WS = Dh * D3 + Dh * Dh;
       seg(a.wpart, a.g_Wqkv, Dh * D3, nwc, WS);
       seg(a.wpart + Dh * D3, a.g_Wo, Dh * Dh, nwc, WS);
-      seg(a.spart, a.g_bqkv, D3, nnp, SP);
-      seg(a.spart + D3, a.g_nm_g, Dh, nnp, SP);
-      seg(a.spart + D3 + Dh, a.g_nm_b, Dh, nnp, SP);
-      seg(a.spart + D3 + 2 * Dh, a.g_bo, Dh, nnp, SP);
+      seg(a.spart, a.g_bqkv, D3, a.spart_n, SP);          // written by k_node_bwd or by the pair kernel's prologue
+      seg(a.spart + D3, a.g_nm_g, Dh, a.spart_n, SP);
+      seg(a.spart + D3 + Dh, a.g_nm_b, Dh, a.spart_n, SP);
+      seg(a.sbo, a.g_bo, Dh, a.sbo_n, Dh);
       seg(a.epart, a.ered, EP, nwg_bwd, EP);
     }
     EGT_LAUNCH("k_sum_segments", k_sum_segments, dim3(maxblk, k), dim3(256), 0, st, s);
