@@ -22,7 +22,7 @@ F_SCALER_LINEAR, F_TRAINING, F_CLIP = 0x010, 0x020, 0x040
 EP_LAYERNORM, EP_GATES = 0x1, 0x2
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_ELU = 0, 1, 2, 3
 # egt_block_desc.flags
-BF_GATE, BF_ATTN_MASK, BF_TRAINING, BF_CLIP = 0x1, 0x2, 0x4, 0x8
+BF_GATE, BF_ATTN_MASK, BF_TRAINING, BF_CLIP, BF_NO_EDGE_LN = 0x1, 0x2, 0x4, 0x8, 0x10
 
 
 class AttnDesc(C.Structure):

@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256, (DE <= 16 ? 4 : 2)) k_block_fwd(BlockArgs
       }
     }
     // ---- norm_edge + [attention_gates | dense_edge_b] ----
-    ln_frags<DE>(x, q, a.ln_eps);
+    ln_frags<DE>(x, q, a.ln_eps, (a.flags & EGT_BF_NO_EDGE_LN) == 0);
     v4f acc = {c2r[0], c2r[1], c2r[2], c2r[3]};
     acc = project<DE>(x, wA, acc);
     // ---- scaled QK^T, clip, + E (egt_layers.py:79-86) ----
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(256, 1) k_block_bwd(BlockArgs a) {
       float4 x[G::TILES], dy[G::TILES];
 #pragma unroll
       for (int t = 0; t < G::TILES; ++t) { x[t] = frag_read<DE>(et, p, q, t); dy[t] = frag_read<DE>(dt, p, q, t); }
-      const float rstd = ln_frags<DE>(x, q, a.ln_eps);
+      const float rstd = ln_frags<DE>(x, q, a.ln_eps, (a.flags & EGT_BF_NO_EDGE_LN) == 0);
       // xhat back into the tile: the weight-gradient MFMAs read it pair-major
 #pragma unroll
       for (int t = 0; t < G::TILES; ++t) frag_write<DE>(et, p, q, t, x[t]);
@@ -587,6 +587,7 @@ __global__ void __launch_bounds__(256, 1) k_block_bwd(BlockArgs a) {
       }
       m1 = sum_over_q(m1) * (1.0f / DE);
       m2 = sum_over_q(m2) * (1.0f / DE);
+      if (a.flags & EGT_BF_NO_EDGE_LN) { m1 = 0.f; m2 = 0.f; }   // no norm_edge: d e = de' + d(proj input)
 
       lds_sync();
       // ---- weight-gradient contractions over the 16 pairs of the tile ----
@@ -990,7 +991,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
         float4 x[G::TILES];
 #pragma unroll
         for (int t = 0; t < G::TILES; ++t) x[t] = frag_read<DE>(et, p, q, t);
-        rstd = ln_frags<DE>(x, q, a.ln_eps);
+        rstd = ln_frags<DE>(x, q, a.ln_eps, (a.flags & EGT_BF_NO_EDGE_LN) == 0);
 #pragma unroll
         for (int t = 0; t < G::TILES; ++t) {
           frag_write<DE>(et, p, q, t, x[t]);     // xhat stays in the tile for the later phases
@@ -1131,6 +1132,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
         }
         m1 = sum_over_q(m1) * (1.0f / DE);
         m2 = sum_over_q(m2) * (1.0f / DE);
+        if (a.flags & EGT_BF_NO_EDGE_LN) { m1 = 0.f; m2 = 0.f; }   // no norm_edge: d e = de' + d(proj input)
         lds_sync();
 #pragma unroll
         for (int t = 0; t < G::TILES; ++t) {

@@ -159,12 +159,14 @@ __device__ __forceinline__ float sum_over_q(float v) {  // lanes p, p+16, p+32, 
 
 // LayerNorm of the lane's fragments (two-pass moments like tf.nn.moments); returns rstd
 template <int DE>
-__device__ __forceinline__ float ln_frags(float4 (&x)[Geo<DE>::TILES], int q, float eps) {
+__device__ __forceinline__ float ln_frags(float4 (&x)[Geo<DE>::TILES], int q, float eps, bool on = true) {
+  // on == false ('bias' edge channels: projections of the RAW e, graph_xformer_model_base.py:173-190):
+  // mean 0 / rstd 1 are selected instead of the statistics -- branch-free, x passes through
   using G = Geo<DE>;
   float s = 0.f;
 #pragma unroll
   for (int t = 0; t < G::TILES; ++t) s += (x[t].x + x[t].y) + (x[t].z + x[t].w);
-  const float mu = sum_over_q(s) * (1.0f / DE);
+  const float mu = on ? sum_over_q(s) * (1.0f / DE) : 0.0f;
   float v = 0.f;
 #pragma unroll
   for (int t = 0; t < G::TILES; ++t) {
@@ -174,7 +176,7 @@ __device__ __forceinline__ float ln_frags(float4 (&x)[Geo<DE>::TILES], int q, fl
       v = fmaf(x[t].z, x[t].z, v); v = fmaf(x[t].w, x[t].w, v);
     }
   }
-  const float rstd = rsqrtf(sum_over_q(v) * (1.0f / DE) + eps);
+  const float rstd = on ? rsqrtf(sum_over_q(v) * (1.0f / DE) + eps) : 1.0f;
 #pragma unroll
   for (int t = 0; t < G::TILES; ++t) { x[t].x *= rstd; x[t].y *= rstd; x[t].z *= rstd; x[t].w *= rstd; }
   return rstd;

@@ -26,6 +26,8 @@ def _desc(blk, B, N, training, seed, edge_dtype=torch.float32) -> L.BlockDesc:
         flags |= L.BF_ATTN_MASK
     if training:
         flags |= L.BF_TRAINING
+    if blk.edge_channel_type == "bias":
+        flags |= L.BF_NO_EDGE_LN
     lo = hi = 0.0
     if blk.mha.clip_logits_value is not None:
         flags |= L.BF_CLIP
@@ -38,7 +40,7 @@ def _desc(blk, B, N, training, seed, edge_dtype=torch.float32) -> L.BlockDesc:
 
 def block_supported(blk, h, e, attn_mask, rand_mask) -> bool:
     """Configurations the fused kernels cover (everything else composes)."""
-    if blk.edge_channel_type not in ("residual", "constrained"):
+    if blk.edge_channel_type not in ("residual", "constrained", "bias"):
         return False
     if blk.add_n_norm or blk.edge_activation is not None:
         return False
@@ -101,6 +103,7 @@ class _FusedBlock(torch.autograd.Function):
                                   L.ptr(saved), L.ptr(ws), L.current_stream()))
         ctx.desc = desc
         ctx.nparams = len(params)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(h, e, key_mask, attn_mask, rand_mask, saved, *params)
         return h_out, e_out
 
@@ -110,6 +113,10 @@ class _FusedBlock(torch.autograd.Function):
         h, e, key_mask, attn_mask, rand_mask, saved, *params = ctx.saved_tensors
         desc = ctx.desc
         dev = h.device
+        if de_out is None:
+            de_out = torch.zeros_like(e)               # 'bias': the caller continues with e itself
+        if dh_out is None:
+            dh_out = torch.zeros_like(h)
         dh_out = _f32c(dh_out); de_out = _edge_c(de_out, e.dtype)
         dh = torch.empty_like(h)
         de = torch.empty_like(e)
@@ -123,18 +130,31 @@ class _FusedBlock(torch.autograd.Function):
         return (dh, de, None, None, None, None, *grads)
 
 
-def block_fused(blk, h, e, mask, attn_mask, rand_mask=None):
-    training = blk.training and blk.mha.random_mask_prob > 0.0
-    seed = blk.mha.next_seed() if (training and rand_mask is None) else 0
-    desc = _desc(blk, h.shape[0], h.shape[1], training, seed, e.dtype)
+def _block_params(blk, e):
+    """the 14 C-ABI parameters of a block.  'bias' edge channels (EGT-simple) have no norm_edge and no
+    dense_edge_r: identity LN parameters and a zero update are passed instead (EGT_BF_NO_EDGE_LN)."""
     params = []
     for mod, attr in _GRAD_ORDER:
         m = getattr(blk, mod, None)
         params.append(None if m is None else getattr(m, attr))
+    if blk.edge_channel_type == "bias":
+        De, H, dev = blk.edge_width, blk.num_heads, e.device
+        params[0] = torch.ones(De, device=dev); params[1] = torch.zeros(De, device=dev)
+        params[12] = torch.zeros(H, De, device=dev); params[13] = torch.zeros(De, device=dev)
+    return params
+
+
+def block_fused(blk, h, e, mask, attn_mask, rand_mask=None):
+    training = blk.training and blk.mha.random_mask_prob > 0.0
+    seed = blk.mha.next_seed() if (training and rand_mask is None) else 0
+    desc = _desc(blk, h.shape[0], h.shape[1], training, seed, e.dtype)
+    params = _block_params(blk, e)
     if blk.edge_channel_type != "constrained":
         attn_mask = None
     h, hdt = _node_io(h)
     h2, e2 = _FusedBlock.apply(h, e, mask, attn_mask, rand_mask, desc, *params)
+    if blk.edge_channel_type == "bias":
+        e2 = e                                         # :190 returns e0; the kernel's e' equals it (zero update)
     return (h2 if hdt is None else h2.to(hdt)), e2
 
 
@@ -160,6 +180,7 @@ class _FusedStack(torch.autograd.Function):
                                   L.ptr(attn_mask), L.ptr(h_out), L.ptr(e_out), L.ptr(saved), L.ptr(ws),
                                   L.current_stream()))
         ctx.desc, ctx.layers, ctx.holder = desc, layers, holder
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(h, e, key_mask, attn_mask, saved, *params)
         return h_out, e_out
 
@@ -169,6 +190,10 @@ class _FusedStack(torch.autograd.Function):
         h, e, key_mask, attn_mask, saved, *params = ctx.saved_tensors
         desc, layers = ctx.desc, ctx.layers
         dev = h.device
+        if de_out is None:
+            de_out = torch.zeros_like(e)
+        if dh_out is None:
+            dh_out = torch.zeros_like(h)
         dh_out = _f32c(dh_out); de_out = _edge_c(de_out, e.dtype)
         dh, de = torch.empty_like(h), torch.empty_like(e)
         # every parameter gradient is a view of ONE flat buffer: the data-parallel all-reduce
@@ -220,13 +245,13 @@ def stack_fused(stack, h, e, mask, attn_mask):
     desc = _desc(b0, h.shape[0], h.shape[1], training, seed, e.dtype)
     params = []
     for blk in blocks:
-        for mod, attr in _GRAD_ORDER:
-            m = getattr(blk, mod, None)
-            params.append(None if m is None else getattr(m, attr))
+        params += _block_params(blk, e)
     if b0.edge_channel_type != "constrained":
         attn_mask = None
     h, hdt = _node_io(h)
     h2, e2 = _FusedStack.apply(h, e, mask, attn_mask, desc, len(blocks), stack.grad_holder, *params)
+    if b0.edge_channel_type == "bias":
+        e2 = e
     return (h2 if hdt is None else h2.to(hdt)), e2
 
 

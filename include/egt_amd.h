@@ -204,6 +204,10 @@ int egt_edge_update_bwd(const egt_edge_desc* desc, const void* d_e_out,
 #define EGT_BF_ATTN_MASK 0x2u /* 'constrained': attn_mask [B,N,N,H] fp32 present */
 #define EGT_BF_TRAINING 0x4u  /* random attention mask active                    */
 #define EGT_BF_CLIP 0x8u      /* clip_logits_value is not None                   */
+#define EGT_BF_NO_EDGE_LN 0x10u /* 'bias' edge channels (EGT-simple, :173-190): gates / edge bias from
+                                  the RAW e.  The caller passes norm_edge gamma = 1, beta = 0 and
+                                  dense_edge_r kernel = bias = 0 (then e' = e); their gradient
+                                  outputs are scratch */
 
 typedef struct egt_block_desc {
   int32_t B, N, H, d, De;   /* model_width Dh = d*H                             */

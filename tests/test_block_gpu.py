@@ -82,7 +82,7 @@ def test_block_composed_vs_golden(name, gpu, egt_lib):
 
 
 FUSED_CASES = ["residual_zinc500k", "residual_zinc100k", "residual_pattern", "residual_randmask",
-               "constrained", "ungated_residual", "residual_n64"]
+               "constrained", "ungated_residual", "residual_n64", "bias"]
 
 
 @pytest.mark.parametrize("name", FUSED_CASES)
@@ -102,7 +102,7 @@ def test_block_fused_vs_golden(name, gpu, egt_lib):
 
 def test_fused_refuses_uncovered_config(gpu, egt_lib):
     from egt_amd import EGTBlock
-    blk = EGTBlock(model_width=64, edge_width=16, edge_channel_type="bias", fused=True).to(gpu)
+    blk = EGTBlock(model_width=64, edge_width=16, edge_channel_type="bias", edge_activation="lrelu2", fused=True).to(gpu)
     with pytest.raises(RuntimeError, match="not covered"):
         blk(torch.zeros(1, 4, 64, device=gpu), torch.zeros(1, 4, 4, 16, device=gpu))
 
@@ -289,3 +289,48 @@ def test_block_bf16_single_block_and_dtype_errors(gpu, egt_lib):
     hb, eb = blk(h.bfloat16(), e.bfloat16(), mask)
     assert hb.dtype == torch.bfloat16 and eb.dtype == torch.bfloat16
     assert_close(eb.float(), e32, name="e_out(bf16 vs fp32 on rounded input)", rtol=1e-2, arel=5e-3)
+
+
+@pytest.mark.parametrize("N,De,train", [(32, 64, True), (21, 16, False)])
+def test_stack_bias_edge_channels_vs_oracle(N, De, train, gpu, egt_lib):
+    """EGT-simple ('bias' edge channels, graph_xformer_model_base.py:173-190) on the fused stack path:
+    gates / edge bias from the RAW e, e returned unchanged, d e accumulates every layer's projection
+    gradient."""
+    from egt_amd import EGTStack
+    from egt_amd.fused import layer_seed
+    from oracle import egt_oracle as O, rng_ref
+    B, Ly, p, Dh = 2, 3, 0.2, 64
+    torch.manual_seed(31)
+    st = EGTStack(model_height=Ly, model_width=Dh, edge_width=De, num_heads=8, edge_channel_type="bias",
+                  random_mask_prob=p if train else 0.0, seed=4, fused=True).to(gpu).train(train)
+    with torch.no_grad():
+        for prm in st.parameters():
+            if prm.dim() == 1:
+                prm.add_(0.2 * torch.randn_like(prm))
+    g = torch.Generator().manual_seed(N + De)
+    h = torch.randn(B, N, Dh, generator=g); e = torch.randn(B, N, N, De, generator=g)
+    mask = torch.ones(B, N, dtype=torch.bool); mask[1, N - 3:] = False
+    dh = torch.randn(B, N, Dh, generator=g); de = torch.randn(B, N, N, De, generator=g)
+    hg = h.to(gpu).requires_grad_(); eg = e.to(gpu).requires_grad_()
+    h2, e2 = st(hg, eg, mask.to(gpu))
+    assert st.last_path == "fused-stack" and e2 is eg
+    torch.autograd.backward([h2, e2], [dh.to(gpu), de.to(gpu)])
+    names = {k: v for k, v in PMAP.items() if not (k.startswith("norm_edge") or k.startswith("dense_edge_r"))}
+    layers = [{k: getattr(getattr(blk, m), a_).detach().double().cpu().requires_grad_()
+               for k, (m, a_) in names.items()} for blk in st.blocks]
+    rms = None
+    if train:
+        b0 = st.blocks[0].mha
+        seed = (b0.seed * 0x9E3779B97F4A7C15 + b0._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        rms = [torch.from_numpy(rng_ref.random_mask(layer_seed(seed, l), B, N, 8, p)) for l in range(Ly)]
+    h64 = h.double().requires_grad_(); e64 = e.double().requires_grad_()
+    ho, eo = O.stack_forward(h64, e64, mask, layers, num_heads=8, rand_masks=rms, edge_channel_type="bias")
+    flat = [t for lp in layers for t in lp.values()]
+    gr = torch.autograd.grad([ho, eo], [h64, e64] + flat, [dh.double(), de.double()])
+    assert_close(h2, ho, name="h_out", rtol=2e-4, arel=5e-5)
+    assert_close(hg.grad, gr[0], name="dh", **BWD)
+    assert_close(eg.grad, gr[1], name="de", **BWD)
+    gi = iter(gr[2:])
+    for li, blk in enumerate(st.blocks):
+        for k, (m, a_) in names.items():
+            assert_close(getattr(getattr(blk, m), a_).grad, next(gi), name=f"L{li}.{k}", **BWD)
