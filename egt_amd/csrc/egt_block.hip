@@ -20,6 +20,10 @@
 // keeps per-(row,head) softmax statistics + V_att from the forward (flash-style
 // delta), and does every weight gradient as MFMA contractions over the pair
 // axis with deterministic per-workgroup partials.
+// The node side of the block (norm_mha, dense_qkv, dense_mha + residual and their backward) is
+// row-local, so it rides along: the forward's epilogue finishes h' and already produces the next
+// block's packed QKV, the backward's prologue turns the dQ/dK/dV partials of the block above into
+// dh and this block's dV_att / delta -- one launch per layer per direction.
 //
 // Lane roles follow the 16x16x4 f32 MFMA register maps (A: row=lane&15,
 // k=lane>>4; B: k=lane>>4, col=lane&15; D: row=4*(lane>>4)+reg, col=lane&15).
@@ -1090,7 +1094,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) { dq[2 * k] = dA[0] * Kf[2 * k]; dq[2 * k + 1] = dA[1] * Kf[2 * k + 1]; }
-        // dQ[l] partial over this tile's 16 keys -> HBM, summed over key tiles in k_node_pre_bwd
+        // dQ[l] partial over this tile's 16 keys -> HBM, summed over key tiles by the next prologue (or k_node_bwd)
         a.dqp[(((size_t)b * ntile + mt) * N + l) * 64 + lane] = reduce16_keep_own(dq, p);
       }
       SCHED_FENCE();

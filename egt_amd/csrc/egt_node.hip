@@ -4,10 +4,12 @@
 //   k_node_post     : dense_mha + res_mha (:136,140)
 //   k_node_bwd      : [layer l] dQKV -> d(h_ln) -> LN backward -> dh ; bias / LN-parameter sums
 //                     [layer l-1] dV_att = dh.Wo^T (packed), delta = sum_k dV_att*V_att
+//                     (on the headline geometry both run as the prologue of the backward pair
+//                      kernel, egt_block.hip:bwd_node_prologue; this kernel then only closes the chain)
 //   k_node_wgrads   : dWqkv, dWo of every layer in one launch (deferred, off the critical path)
 //   k_sum_segments  : deterministic reduction of all per-workgroup partials
 //   k_edge_param_grads : T,s,R -> grads of norm_edge / attention_gates / dense_edge_b / dense_edge_r
-// One workgroup per graph; every contraction is a 16x16 tile on
+// One workgroup per 32 node rows; every contraction is a 16x16 tile on
 // v_mfma_f32_16x16x4_f32 with the activation rows staged in LDS.
 #include <stdlib.h>
 
@@ -835,7 +837,7 @@ void egt_node_launch_prep(BlockArgs* as, int n, hipStream_t st) {
 }
 
 // Reduce the per-workgroup partials of `n` layers (one BlockArgs each, with their own
-// npart / epart / ered and gradient pointers) and finish the edge-parameter gradients.
+// spart / sbo / wpart / epart / ered and gradient pointers) and finish the edge-parameter gradients.
 void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, hipStream_t st) {
   for (int l0 = 0; l0 < n; l0 += 11) {
     const int nl = (n - l0 < 11) ? (n - l0) : 11;

@@ -7,7 +7,7 @@ import torch
 from egt_amd import egt_attention, AttnConfig, _lib
 
 CONFIGS = {"cfg2": dict(B=128, N=64, H=8, d=8), "cfg5": dict(B=8, N=512, H=8, d=64),
-           "cfg4": dict(B=16, N=120, H=8, d=8)}
+           "cfg4": dict(B=16, N=120, H=8, d=8), "cfg5_b32": dict(B=32, N=512, H=8, d=64)}
 
 
 def main():
