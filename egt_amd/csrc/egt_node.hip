@@ -695,26 +695,30 @@ struct SumSeg { const float* src; float* dst; int n, np, stride, nblk; };
 #define SUM_MAX_SEG 77  // 11 layers x 7 segments: fits the 4 KiB kernel-argument block
 struct SumArgs { SumSeg seg[SUM_MAX_SEG]; };
 
-// 64 outputs per workgroup, the partial axis split over 4 wavefronts
+// 32 outputs per workgroup, the partial axis split over 8 groups of 32 lanes with 8 independent
+// accumulators each: with hundreds of partials per output the loop is latency-bound, so what counts
+// is loads in flight (64 per output), not lanes per output.  Fixed association order: deterministic.
 __global__ void __launch_bounds__(256) k_sum_segments(SumArgs s) {
-  __shared__ float red[4][64];
+  __shared__ float red[8][32];
   const SumSeg sg = s.seg[blockIdx.y];
   if ((int)blockIdx.x >= sg.nblk) return;
-  const int o = blockIdx.x * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
-  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  const int ol = threadIdx.x & 31, pg = threadIdx.x >> 5;
+  const int o = blockIdx.x * 32 + ol;
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = 0.f;
   if (o < sg.n) {
     int pi = pg;
-    for (; pi + 12 < sg.np; pi += 16) {
-      v0 += sg.src[(size_t)pi * sg.stride + o];
-      v1 += sg.src[(size_t)(pi + 4) * sg.stride + o];
-      v2 += sg.src[(size_t)(pi + 8) * sg.stride + o];
-      v3 += sg.src[(size_t)(pi + 12) * sg.stride + o];
+    for (; pi + 56 < sg.np; pi += 64) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += sg.src[(size_t)(pi + 8 * k) * sg.stride + o];
     }
-    for (; pi < sg.np; pi += 4) v0 += sg.src[(size_t)pi * sg.stride + o];
+    for (; pi < sg.np; pi += 8) v[0] += sg.src[(size_t)pi * sg.stride + o];
   }
-  red[pg][threadIdx.x & 63] = (v0 + v1) + (v2 + v3);
+  red[pg][ol] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
   __syncthreads();
-  if (pg == 0 && o < sg.n) sg.dst[o] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (pg == 0 && o < sg.n)
+    sg.dst[o] = ((red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol])) + ((red[4][ol] + red[5][ol]) + (red[6][ol] + red[7][ol]));
 }
 
 // T[c][i], s[i], R[c][h|8] -> grads of norm_edge, attention_gates, dense_edge_b, dense_edge_r.
@@ -844,7 +848,7 @@ void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, hipStream
     SumArgs s{};
     int maxblk = 0, k = 0;
     auto seg = [&](const float* src, float* dst, int cnt, int npart, int stride) {
-      s.seg[k] = SumSeg{src, dst, cnt, npart, stride, (cnt + 63) / 64};
+      s.seg[k] = SumSeg{src, dst, cnt, npart, stride, (cnt + 31) / 32};
       if (s.seg[k].nblk > maxblk) maxblk = s.seg[k].nblk;
       ++k;
     };
