@@ -1375,7 +1375,7 @@ template <int DE>
 static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool top, BlockArgs* below, BlockArgs* above) {
   using GG = Geo<DE>;
   // node-side prologue inside the pair kernel (see bwd_node_prologue): v4 geometry with Dh = 64
-  const bool pro = (DE % 16 == 0) && (a.N % 16) == 0 && a.Dh == 64 && a.DK == 8 && !egt_env_flag("EGT_BWD_V2") &&
+  const bool pro = (DE % 16 == 0 || DE == 8) && (a.N % 16) == 0 && a.Dh == 64 && a.DK == 8 && !egt_env_flag("EGT_BWD_V2") &&
                    !egt_env_flag("EGT_NO_BWD_PROLOGUE");
   a.pro = 0;
   if (pro) {
@@ -1403,7 +1403,7 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
   do { if (a.bf16) BWD_VARIANT_T(ML_, FULL_, true); else BWD_VARIANT_T(ML_, FULL_, false); } while (0)
   const bool ml = a.M != nullptr || a.rm != nullptr;
   const bool full = (a.N % 16) == 0;
-  if constexpr (DE % 16 == 0) {
+  if constexpr (DE % 16 == 0 || DE == 8) {
     if (full && !egt_env_flag("EGT_BWD_V2")) {   // register-lean, 2 waves/SIMD
       const size_t lds_v4 = ((size_t)(4 * PW > BWD_PRO_WS ? 4 * PW : BWD_PRO_WS) + (size_t)BWD_TL * QD_LD + 3 * GG::TILES * 256) * 4;
       a.NQP = a.N / 16;
