@@ -129,8 +129,8 @@ def cpu_baseline(w, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="zinc500k_n64", choices=list(WORKLOADS))
     ap.add_argument("--edge-dtype", default="", choices=["", "f32", "bf16"],
                     help="storage type of the edge tensors (EGT_BF16: bf16 in HBM, fp32 arithmetic); default: the workload's")
