@@ -32,6 +32,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 WORKLOADS = {
     # BASELINE.json configs[1]
     "zinc500k_n64": dict(B=128, N=64, Dh=64, De=64, H=8, Ly=10, nodes=(9, 37), rand_p=0.1),
+    "zinc500k_n64_b1024": dict(B=1024, N=64, Dh=64, De=64, H=8, Ly=10, nodes=(9, 37), rand_p=0.1),   # large-batch sanity
     # the other BASELINE.json configs' shapes, for reference runs -- not bench lines
     "zinc100k_n37": dict(B=128, N=37, Dh=48, De=48, H=8, Ly=4, nodes=(9, 37), rand_p=0.1),
     "cifar10_n150_fp32": dict(B=128, N=150, Dh=64, De=8, H=8, Ly=4, nodes=(85, 150), rand_p=0.1),
