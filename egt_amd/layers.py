@@ -323,6 +323,36 @@ class EGTLayerStack(nn.Module):
         self.ffn_edge = nn.ModuleList([FFN(edge_width, activation=activation) for _ in range(model_height)]) \
             if ect in ('residual', 'constrained') else None
 
+    def keras_named_parameters(self):
+        """every parameter under the reference's Keras variable name: attention sub-layers
+        '<layer>_<ii>/<var>' (graph_xformer_model_base.py:337 tags), FFN sub-layers
+        'norm_fnn_node_<ii>/gamma', 'fnn_lr1_edge_<ii>/kernel', ... (:310,314)."""
+        out = {}
+        for i, blk in enumerate(self.blocks):
+            tag = f"{i:0>2d}"
+            out.update(blk.keras_named_parameters(tag))
+            out.update(self.ffn_node[i].keras_named_parameters(f"node_{tag}"))
+            if self.ffn_edge is not None:
+                out.update(self.ffn_edge[i].keras_named_parameters(f"edge_{tag}"))
+        return out
+
+    @torch.no_grad()
+    def load_keras_weights(self, weights, strict=True):
+        """weights: mapping Keras variable name -> array (e.g. read from the reference's .h5 / an .npz
+        export).  Shapes are Keras' ([in,out] Dense kernels), so arrays are copied as they are."""
+        named = self.keras_named_parameters()
+        missing = [k for k in named if k not in weights]
+        unexpected = [k for k in weights if k not in named]
+        if strict and (missing or unexpected):
+            raise KeyError(f"missing {missing[:4]}... unexpected {unexpected[:4]}...")
+        for k, prm in named.items():
+            if k in weights:
+                w = torch.as_tensor(weights[k], dtype=prm.dtype)
+                if tuple(w.shape) != tuple(prm.shape):
+                    raise ValueError(f"{k}: shape {tuple(w.shape)} vs {tuple(prm.shape)}")
+                prm.copy_(w.to(prm.device))
+        return missing, unexpected
+
     def forward(self, h, e, mask=None, attn_mask=None):
         for i, blk in enumerate(self.blocks):
             h, e = blk(h, e, mask, attn_mask)                  # layer/{i}/attention
