@@ -127,6 +127,24 @@ def main():
             if not isinstance(ex, AssertionError):
                 traceback.print_exc()
     print(f"sweep: inner op {nat} random configurations done, total failures {bad}")
+    # channel FFN: random row counts / widths / activations
+    from test_ffn_gpu import _run as ffn_run
+    nf = 0
+    for i in range(24):
+        W = rnd.choice([16, 32, 48, 64])
+        shape = rnd.choice([(1,), (rnd.randint(1, 70),), (rnd.randint(1, 5), rnd.randint(1, 40)),
+                            (rnd.randint(1, 3), rnd.randint(2, 33), rnd.randint(2, 33))])
+        if len(shape) == 3:
+            shape = (shape[0], shape[1], shape[1])
+        nf += 1
+        try:
+            ffn_run(shape, rnd.choice(["elu", "relu"]), dev, seed=900 + i, W=W)
+        except Exception as ex:  # noqa: BLE001
+            bad += 1
+            print("FAIL ffn", dict(W=W, shape=shape), type(ex).__name__, str(ex)[:300])
+            if not isinstance(ex, AssertionError):
+                traceback.print_exc()
+    print(f"sweep: FFN {nf} random shapes done, total failures {bad}")
     return 1 if bad else 0
 
 
