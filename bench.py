@@ -112,19 +112,33 @@ def cpu_baseline(w, seconds=12.0):
         h2, e2 = O.stack_forward(h, e, mask, layers, num_heads=w["H"], rand_masks=rms)
         torch.autograd.grad([h2, e2], [h, e] + flat, [dh, de])
 
-    step()  # warm
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        step()
-        reps += 1
-        if time.perf_counter() - t0 >= seconds:
-            break
-    dt = time.perf_counter() - t0
-    return dict(value=Bs * reps / dt, unit="graphs/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{reps} fwd+bwd steps of the Ly={w['Ly']} block stack on B={Bs} graphs "
-                       f"(N={w['N']}, fp32, torch-CPU restatement of the TF op sequence, "
-                       f"{dt:.1f}s, host has {os.cpu_count()} cpus)")
+    def timed(sec):
+        step()  # warm
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            step()
+            reps += 1
+            if time.perf_counter() - t0 >= sec:
+                break
+        return reps, time.perf_counter() - t0
+
+    nthr = torch.get_num_threads()
+    runs = []                                            # (threads, graphs/s, reps, seconds)
+    for thr, sec in ((nthr, seconds * 0.5), (8, seconds * 0.5)) if nthr > 8 else ((nthr, seconds),):
+        torch.set_num_threads(thr)
+        try:
+            reps, dt = timed(sec)
+        finally:
+            torch.set_num_threads(nthr)
+        runs.append((thr, Bs * reps / dt, reps, dt))
+    best = max(runs, key=lambda r: r[1])                 # the baseline is the FASTER thread count
+    out = dict(value=best[1], unit="graphs/s", cores=best[0], kind="port",
+               sample=f"{best[2]} fwd+bwd steps of the Ly={w['Ly']} block stack on B={Bs} graphs "
+                      f"(N={w['N']}, fp32, torch-CPU restatement of the TF op sequence, "
+                      f"{best[3]:.1f}s, host has {os.cpu_count()} cpus; "
+                      + ", ".join(f"{t} threads: {v:.1f} graphs/s" for t, v, _, _ in runs) + ")")
+    return out
 
 
 def main():
@@ -140,7 +154,7 @@ def main():
                          "(graph_xformer_model_base.py:336-341); NOT the headline workload")
     ap.add_argument("--layers", type=int, default=0, help="override the workload's layer count (1 = single-block scope)")
     ap.add_argument("--fused", default="auto", choices=["auto", "on", "off"])
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=18.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--dominant", default="k_block_bwd",
