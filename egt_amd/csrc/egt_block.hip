@@ -1215,7 +1215,7 @@ extern "C" int egt_block_supported(const egt_block_desc* d) { return block_check
 static size_t al(size_t x) { return (x + 63) & ~(size_t)63; }  // in floats
 
 struct BlockLayout {
-  size_t v_att, stats, qkvp, saved_total;
+  size_t v_att, stats, qkvp, pw_sv, saved_total;   // pw_sv: LN-folded edge weights, prepared by the forward, reused by the backward
   // workspace = [common: dvp dqp[2] dkvp[2]] + per layer [pw epart spart sbo wpart ered dqkv dhbuf]
   // (dqp / dkvp alternate by layer parity: the prologue of layer l-1 reads layer l's partials while
   //  other workgroups of that launch already write their own)
@@ -1234,6 +1234,7 @@ static BlockLayout layout(const egt_block_desc* d) {
   L.v_att = o; o += al(rows * Dh);
   L.stats = o; o += al(rows * BH * 4);
   L.qkvp = o; o += al(rows * QKVP);
+  L.pw_sv = o; o += al((size_t)DEP * 16 + 16);
   L.saved_total = o;
   L.NLR = (d->N + BWD_TL - 1) / BWD_TL;
   L.nwg_bwd = d->B * L.NLR;
@@ -1264,7 +1265,7 @@ static BlockLayout layout(const egt_block_desc* d) {
 // workspace pointers of one layer: `wc` = common region, `wl` = that layer's region
 static void bind_ws(const BlockLayout& L, BlockArgs& a, float* wc, float* wl, int parity = 0) {
   a.dvp = wc + L.dvp; a.dqp = wc + L.dqp + parity * L.dqp_sz; a.dkvp = wc + L.dkvp + parity * L.dkvp_sz;
-  a.pw = wl + L.pw; a.epart = wl + L.epart; a.spart = wl + L.spart; a.sbo = wl + L.sbo; a.wpart = wl + L.wpart;
+  a.epart = wl + L.epart; a.spart = wl + L.spart; a.sbo = wl + L.sbo; a.wpart = wl + L.wpart;
   a.spart_n = a.sbo_n = a.B * ((a.N + NODE_RC - 1) / NODE_RC);   // k_node_bwd's workgroups (prologue path overrides)
   a.ered = wl + L.ered; a.dqkv_sv = wl + L.dqkv;
   a.TL = BWD_TL; a.NLR = L.NLR; a.NQP = 1;
@@ -1322,6 +1323,7 @@ static void bind_common(const egt_block_desc* d, BlockArgs& a, const void* h, co
   }
   a.v_att = saved + L.v_att; a.stats = saved + L.stats; a.qkvp = saved + L.qkvp;
   bind_ws(L, a, ws, ws + L.common_total);
+  a.pw = saved + L.pw_sv;
   a.prep = 1;
 }
 
@@ -1474,6 +1476,7 @@ extern "C" int egt_block_bwd(const egt_block_desc* desc, const egt_block_params*
     }
   }
   bind_common(desc, a, h, e, key_mask, attn_mask, rand_mask, (float*)saved, (float*)workspace);
+  a.prep = 0;   // prepared by the forward, kept in `saved`
   a.dh_out = (const float*)d_h_out; a.de_out = (const float*)d_e_out;
   a.dh = (float*)d_h; a.de = (float*)d_e;
   a.g_ne_g = (float*)grads->norm_edge_gamma; a.g_ne_b = (float*)grads->norm_edge_beta;
@@ -1536,6 +1539,7 @@ static void bind_layer(const egt_block_desc* d, const StackLayout& S, const Bloc
   // per-layer workspace: block l's epilogue must not race block l+1's prepared weights, and the
   // deferred reductions / weight gradients need every layer's partials and dQKV rows at the end
   bind_ws(L, a, ws, ws + L.common_total + L.layer_total * (size_t)l, l & 1);
+  a.pw = bs + L.pw_sv;
   (void)d;
 }
 
@@ -1636,9 +1640,8 @@ extern "C" int egt_stack_bwd(const egt_block_desc* desc, int32_t layers, const e
     a.g_Wo = (float*)g->dense_mha_kernel; a.g_bo = (float*)g->dense_mha_bias;
     a.g_Wr = (float*)g->dense_edge_r_kernel; a.g_br = (float*)g->dense_edge_r_bias;
   }
-  egt_node_launch_prep(as, layers, (hipStream_t)stream);
   for (int l = layers - 1; l >= 0; --l) {
-    as[l].prep = 0;
+    as[l].prep = 0;   // the LN-folded edge weights were prepared by the forward and live in `saved`
     DISPATCH_BDE(desc->De, launch_bwd<DE>(as[l], L, (hipStream_t)stream, l == layers - 1, l > 0 ? &as[l - 1] : nullptr,
                                              l + 1 < layers ? &as[l + 1] : nullptr));
   }

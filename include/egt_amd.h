@@ -240,7 +240,7 @@ typedef struct egt_block_params {
 /* 1 when the fused kernels cover `desc`, else 0 (caller composes instead). */
 int egt_block_supported(const egt_block_desc* desc);
 /* bytes of the forward->backward buffer (V_att, softmax row statistics, packed
- * Q/K/V) and of the scratch workspace (max of forward and backward needs). */
+ * Q/K/V, the LN-folded edge weights) and of the scratch workspace (max of forward and backward needs). */
 size_t egt_block_saved_bytes(const egt_block_desc* desc);
 size_t egt_block_workspace_bytes(const egt_block_desc* desc);
 
