@@ -84,3 +84,28 @@ def test_keras_parameter_names():
         dense_qkv=("kernel", "bias"), dense_mha=("kernel", "bias"),
         dense_edge_r=("kernel", "bias")).items() for p in ps}
     assert names == want
+
+
+def test_ffn_and_mfma_argument_validation_without_gpu(egt_lib):
+    """the newer entry points validate before they launch: no GPU needed"""
+    from egt_amd import _lib as L
+    f = L.FfnDesc(rows=100, width=40, dtype=L.EGT_F32, activation=L.ACT_ELU, ln_eps=1e-3)
+    assert egt_lib.egt_ffn_supported(C.byref(f)) == 0 and egt_lib.egt_ffn_workspace_bytes(C.byref(f)) == 0
+    p = L.FfnParams()
+    assert egt_lib.egt_ffn_fwd(C.byref(f), C.byref(p), None, None, None, None) == L.EGT_E_NULL   # workspace NULL first
+    f = L.FfnDesc(rows=100, width=64, dtype=L.EGT_F32, activation=L.ACT_LRELU, ln_eps=1e-3)
+    assert egt_lib.egt_ffn_supported(C.byref(f)) == 0
+    f = L.FfnDesc(rows=100, width=48, dtype=L.EGT_F32, activation=L.ACT_RELU, ln_eps=1e-3)
+    assert egt_lib.egt_ffn_supported(C.byref(f)) == 1
+    W = 48
+    assert egt_lib.egt_ffn_workspace_bytes(C.byref(f)) >= 4 * (4 * 2 * W * W)
+    a = L.AttnDesc(B=1, N=40, H=8, d=24, dtype=L.EGT_F32, flags=0)
+    assert egt_lib.egt_attn_mfma_supported(C.byref(a), 0) == 0          # d not in {16,32,64}
+    a = L.AttnDesc(B=1, N=40, H=8, d=32, dtype=L.EGT_F32, flags=0)
+    assert egt_lib.egt_attn_mfma_supported(C.byref(a), 0) == 1 and egt_lib.egt_attn_mfma_supported(C.byref(a), 1) == 0
+    assert egt_lib.egt_attn_mfma_workspace_bytes(C.byref(a)) > egt_lib.egt_attn_mfma_fwd_workspace_bytes(C.byref(a)) > 0
+    b = L.BlockDesc(B=2, N=16, H=8, d=8, De=64, dtype=L.EGT_BF16, flags=0, clip_lo=0, clip_hi=0,
+                    random_mask_prob=0, ln_eps=1e-3, reserved=0, seed=0)
+    assert egt_lib.egt_block_supported(C.byref(b)) == 1                 # bf16 edge tensors are covered
+    b.dtype = 5
+    assert egt_lib.egt_block_supported(C.byref(b)) == 0
