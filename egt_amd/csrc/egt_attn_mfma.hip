@@ -145,27 +145,41 @@ __device__ __forceinline__ float mask_add(const AttnMfmaArgs& a, const Feat<V>& 
 
 // ---- cooperative pair-tile transfers: a [16 rows][16 cols x 8 heads] tile of a [B,N,N,8]
 // tensor is 16 contiguous 512-byte runs; the workgroup's 512 threads move it with one 16-byte
-// access each (thread -> row tid>>5, floats 4*(tid&31)...), through an LDS tile of row stride
-// PT_LD.  Rows / columns past N read a valid address and are zeroed (component-wise selects).
-#define PT_LD 132
-#define PT_SZ (16 * PT_LD)
+// global access each (thread -> row tid>>5, column (tid&31)>>1, heads 4*(tid&1)..+3).  In LDS
+// the tile is HEAD-MAJOR: eight [16][16] planes of stride PT_PL, so the wave that owns head h
+// reads its four consecutive columns with one ds_read_b128 (forward / bwd_q lanes) or walks a
+// column with ds_read_b32 (bwd_kv lanes).  Inside a plane rows 4..7 and 12..15 are pair-swapped
+// and the 4-column chunks are XORed with (row>>1)&3: every access pattern of the three kernels
+// and the 4 x b32 cooperative scatter is bank-conflict free (enumerated against the gfx950
+// lane-group tables; the [row][col][head] layout it replaces was 4- to 8-way conflicted).
+// Rows / columns past N read a valid address and are zeroed (component-wise selects).
+#define PT_PL 260
+#define PT_SZ (8 * PT_PL)
 
+__device__ __forceinline__ int pt_off(int row, int m) {   // offset inside one head's plane
+  return ((row ^ ((row >> 2) & 1)) << 4) + ((((m >> 2) ^ (row >> 1)) & 3) << 2) + (m & 3);
+}
 __device__ __forceinline__ float4 ptile_gload(const float* src, int b, int N, int row0, int col0, int tid) {
   const int row = tid >> 5, c4 = (tid & 31) * 4;
   const int rr = min(row0 + row, N - 1), cc = min(col0 + (c4 >> 3), N - 1);
   return *reinterpret_cast<const float4*>(src + (((size_t)b * N + rr) * N + cc) * AH + (c4 & 7));
 }
 __device__ __forceinline__ void ptile_lds_put(float* tl, float4 v, int N, int row0, int col0, int tid) {
-  const int row = tid >> 5, c4 = (tid & 31) * 4;
-  const bool ok = row0 + row < N && col0 + (c4 >> 3) < N;
-  *reinterpret_cast<float4*>(tl + row * PT_LD + c4) =
-      make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+  const int row = tid >> 5, m = (tid & 31) >> 1;
+  const bool ok = row0 + row < N && col0 + m < N;
+  float* p = tl + (tid & 1) * 4 * PT_PL + pt_off(row, m);
+  p[0] = ok ? v.x : 0.f;
+  p[PT_PL] = ok ? v.y : 0.f;
+  p[2 * PT_PL] = ok ? v.z : 0.f;
+  p[3 * PT_PL] = ok ? v.w : 0.f;
 }
 __device__ __forceinline__ void ptile_gstore(float* dst, const float* tl, int b, int N, int row0, int col0, int tid) {
-  const int row = tid >> 5, c4 = (tid & 31) * 4;
-  if (row0 + row < N && col0 + (c4 >> 3) < N)
-    *reinterpret_cast<float4*>(dst + (((size_t)b * N + row0 + row) * N + col0 + (c4 >> 3)) * AH + (c4 & 7)) =
-        *reinterpret_cast<const float4*>(tl + row * PT_LD + c4);
+  const int row = tid >> 5, m = (tid & 31) >> 1;
+  if (row0 + row < N && col0 + m < N) {
+    const float* p = tl + (tid & 1) * 4 * PT_PL + pt_off(row, m);
+    *reinterpret_cast<float4*>(dst + (((size_t)b * N + row0 + row) * N + col0 + m) * AH + (tid & 1) * 4) =
+        make_float4(p[0], p[PT_PL], p[2 * PT_PL], p[3 * PT_PL]);
+  }
 }
 
 // key-mask bytes of keys m .. m+3 (clamped).  Kept as four separate registers: packing them
@@ -216,35 +230,49 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
   for (int kt = 0; kt < KT; ++kt) oacc[kt] = (v4f){0.f, 0.f, 0.f, 0.f};
   float mrun = -3.0e38f, lrun = 0.f;
 
-  float4 kc[KT], vc[KT], kn[KT], vn[KT];   // current / next key tile operands
-  float4 pe4 = make_float4(0.f, 0.f, 0.f, 0.f), pg4 = pe4, pm4 = pe4;
+  // Two register sets (A, B) alternate roles tile by tile: one feeds this tile's MFMAs while the
+  // other receives the next tile's K / V^T operands, and likewise for the pair tiles, which travel
+  // TWO key tiles ahead (HBM latency under load is about one tile's worth of work).  Alternating
+  // instead of copying matters: a register copy waits for the load it copies.  All prefetches are
+  // unconditional (clamped to the last tile) so each tile is straight-line code with exact waits.
+  float4 kA[KT], vA[KT], kB[KT], vB[KT];
+  float4 eA = make_float4(0.f, 0.f, 0.f, 0.f), gA = eA, mA = eA, eB = eA, gB = eA, mB = eA;
+  Km4 kmA{{1u, 1u, 1u, 1u}}, kmB{{1u, 1u, 1u, 1u}};
+  const int mlast = NP - 16;
 #pragma unroll
   for (int T = 0; T < KT; ++T) {
-    kc[T] = *reinterpret_cast<const float4*>(Kh + (size_t)ll * D + 16 * T + 4 * q);
-    vc[T] = *reinterpret_cast<const float4*>(VT + (size_t)(16 * T + ll) * NP + 4 * q);
-    kn[T] = kc[T]; vn[T] = vc[T];
+    kA[T] = *reinterpret_cast<const float4*>(Kh + (size_t)ll * D + 16 * T + 4 * q);
+    vA[T] = *reinterpret_cast<const float4*>(VT + (size_t)(16 * T + ll) * NP + 4 * q);
   }
-  Km4 kmc{{1u, 1u, 1u, 1u}};
-  if (f.km) kmc = km_load4(a.km + (size_t)b * N, N, 4 * q);
-  Km4 kmn = kmc;
+  if (f.km) kmA = km_load4(a.km + (size_t)b * N, N, 4 * q);
   if (f.E) ptile_lds_put(In + 0 * PT_SZ, ptile_gload(a.E, b, N, l0, 0, tid), N, l0, 0, tid);
   if (f.G) ptile_lds_put(In + 1 * PT_SZ, ptile_gload(a.G, b, N, l0, 0, tid), N, l0, 0, tid);
   if (f.M) ptile_lds_put(In + 2 * PT_SZ, ptile_gload(a.M, b, N, l0, 0, tid), N, l0, 0, tid);
+  {
+    const int m1 = min(16, mlast);
+    if (f.E) eA = ptile_gload(a.E, b, N, l0, m1, tid);
+    if (f.G) gA = ptile_gload(a.G, b, N, l0, m1, tid);
+    if (f.M) mA = ptile_gload(a.M, b, N, l0, m1, tid);
+  }
+  __builtin_amdgcn_s_waitcnt(0);   // nothing pending at the loop header: its waits then reflect the loop alone
   __syncthreads();
 
-  for (int m0 = 0, it = 0; m0 < NP; m0 += 16, ++it) {
-    const bool more = m0 + 16 < NP;
-    if (more) {   // next tile's loads fly during this tile's arithmetic
+  // one key tile: (kc, vc, kmc) feed it, (kn, vn, kmn) receive tile it+1; (pe, pg, pm) hold the pair
+  // tiles of it+1 and go to LDS at the bottom, (qe, qg, qm) receive those of it+2
+  auto tile = [&](const int m0, const int it, float4 (&kc)[KT], float4 (&vc)[KT], Km4& kmc, float4 (&kn)[KT],
+                  float4 (&vn)[KT], Km4& kmn, float4& pe4, float4& pg4, float4& pm4, float4& qe4, float4& qg4,
+                  float4& qm4) __attribute__((always_inline)) {
+    const int m1 = min(m0 + 16, mlast), m2 = min(m0 + 32, mlast);
 #pragma unroll
-      for (int T = 0; T < KT; ++T) {
-        kn[T] = *reinterpret_cast<const float4*>(Kh + (size_t)(m0 + 16 + ll) * D + 16 * T + 4 * q);
-        vn[T] = *reinterpret_cast<const float4*>(VT + (size_t)(16 * T + ll) * NP + m0 + 16 + 4 * q);
-      }
-      if (f.E) pe4 = ptile_gload(a.E, b, N, l0, m0 + 16, tid);
-      if (f.G) pg4 = ptile_gload(a.G, b, N, l0, m0 + 16, tid);
-      if (f.M) pm4 = ptile_gload(a.M, b, N, l0, m0 + 16, tid);
-      if (f.km) kmn = km_load4(a.km + (size_t)b * N, N, m0 + 16 + 4 * q);
+    for (int T = 0; T < KT; ++T) {
+      kn[T] = *reinterpret_cast<const float4*>(Kh + (size_t)(m1 + ll) * D + 16 * T + 4 * q);
+      vn[T] = *reinterpret_cast<const float4*>(VT + (size_t)(16 * T + ll) * NP + m1 + 4 * q);
     }
+    if (f.km) kmn = km_load4(a.km + (size_t)b * N, N, m1 + 4 * q);
+    if (f.E) qe4 = ptile_gload(a.E, b, N, l0, m2, tid);
+    if (f.G) qg4 = ptile_gload(a.G, b, N, l0, m2, tid);
+    if (f.M) qm4 = ptile_gload(a.M, b, N, l0, m2, tid);
+    __builtin_amdgcn_sched_barrier(0);   // keep the prefetches up here: hipcc otherwise sinks them past the MFMAs
     const float* Et = In + (it & 1) * 3 * PT_SZ;
     const float* Gt = Et + PT_SZ;
     const float* Mt = Gt + PT_SZ;
@@ -260,22 +288,29 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
     }
     float x[4], pa[4];
     float tmax = -3.0e38f;
+    const int po4 = h * PT_PL + pt_off(ll, 4 * q);   // this lane's keys 4q..4q+3 of row ll: one 16-byte access
+    float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = e4, m4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (f.E) e4 = *reinterpret_cast<const float4*>(Et + po4);
+    if (f.G) g4 = *reinterpret_cast<const float4*>(Gt + po4);
+    if (f.M) m4 = *reinterpret_cast<const float4*>(Mt + po4);
+    const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w};
+    float hv4[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = m0 + 4 * q + r;
       const bool valid = m < N;
       float ah = s[r] * a.scale;
       if (clip) ah = fminf(fmaxf(ah, a.clip_lo), a.clip_hi);
-      const int po = ll * PT_LD + (4 * q + r) * AH + h;
       const size_t gi = (((size_t)b * N + lc) * N + min(m, N - 1)) * AH + h;
-      const float hv = ah + (f.E ? Et[po] : 0.f);
-      Ht[po] = hv;                                         // H_hat: post-clip, pre-mask (egt_layers.py:85-86)
+      const float hv = ah + ev[r];
+      hv4[r] = hv;                                         // H_hat: post-clip, pre-mask (egt_layers.py:85-86)
       const float kadd = kmc.v[r] ? 0.0f : -EGT_NEG;
-      const float add = mask_add(a, f, kadd, f.M ? Mt[po] : 1.f, gi);
+      const float add = mask_add(a, f, kadd, mv[r], gi);
       x[r] = valid ? hv + add : -3.0e38f;
-      pa[r] = gated ? egt_sigmoid(Gt[po] + add) : 1.0f;    // gate (multiplied into p below)
+      pa[r] = gated ? egt_sigmoid(gv[r] + add) : 1.0f;    // gate (multiplied into p below)
       tmax = fmaxf(tmax, x[r]);
     }
+    *reinterpret_cast<float4*>(Ht + po4) = make_float4(hv4[0], hv4[1], hv4[2], hv4[3]);
     // ---- online softmax over the key axis: in-lane over r, then across q ----
     tmax = pair_max_q(tmax);
     const float mnew = fmaxf(mrun, tmax);
@@ -301,18 +336,24 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
       o = MFMA(vc[kt].w, pa[3], o);
       oacc[kt] = o;
     }
-    if (more) {
+    {   // tile it+1 into the other LDS buffer (its last readers passed the previous barrier)
       float* nx = In + ((it + 1) & 1) * 3 * PT_SZ;
-      if (f.E) ptile_lds_put(nx, pe4, N, l0, m0 + 16, tid);
-      if (f.G) ptile_lds_put(nx + PT_SZ, pg4, N, l0, m0 + 16, tid);
-      if (f.M) ptile_lds_put(nx + 2 * PT_SZ, pm4, N, l0, m0 + 16, tid);
+      if (f.E) ptile_lds_put(nx, pe4, N, l0, m1, tid);
+      if (f.G) ptile_lds_put(nx + PT_SZ, pg4, N, l0, m1, tid);
+      if (f.M) ptile_lds_put(nx + 2 * PT_SZ, pm4, N, l0, m1, tid);
     }
     __syncthreads();
     ptile_gstore(a.h_hat, Ht, b, N, l0, m0, tid);   // whole 512-byte runs
-#pragma unroll
-    for (int T = 0; T < KT; ++T) { kc[T] = kn[T]; vc[T] = vn[T]; }
-    kmc = kmn;
+  };
+  // pairs of tiles in the loop, an odd last tile outside it: a conditional second tile inside the
+  // loop would put the first tile's pending loads on a (never taken) path to the loop header and
+  // make hipcc drain every prefetch there
+  int m0 = 0;
+  for (; m0 + 16 < NP; m0 += 32) {
+    tile(m0, 0, kA, vA, kmA, kB, vB, kmB, eA, gA, mA, eB, gB, mB);
+    tile(m0 + 16, 1, kB, vB, kmB, kA, vA, kmA, eB, gB, mB, eA, gA, mA);
   }
+  if (m0 < NP) tile(m0, 0, kA, vA, kmA, kB, vB, kmB, eA, gA, mA, eB, gB, mB);
   // ---- finalize: V_att[l][k*8+h] = O[l][k] / l_run ; row statistics for the backward ----
   if (l < N) {
     const float inv = 1.0f / lrun;
@@ -465,10 +506,10 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
         inr = (araw >= a.clip_lo && araw <= a.clip_hi) ? 1.0f : 0.0f;
         ah = fminf(fmaxf(araw, a.clip_lo), a.clip_hi);
       }
-      const int po = (4 * q + r) * PT_LD + mm * AH + h;
+      const int po = h * PT_PL + pt_off(4 * q + r, mm);
       const float add = mask_add(a, f, kadd, f.M ? Mt[po] : 1.f, gi[r]);
       const float xv = ah + (f.E ? Et[po] : 0.f) + add;
-      const float S = valid ? __expf(xv - st[r].x) / st[r].y : 0.f;
+      const float S = valid ? __expf(xv - st[r].x) * __builtin_amdgcn_rcpf(st[r].y) : 0.f;
       const float g = gated ? egt_sigmoid(Gt[po] + add) : 1.0f;
       const float dAt_ = dp[r];
       float dH = S * (dAt_ * g - st[r].w) + (f.X ? Xt[po] : 0.f);
@@ -549,9 +590,8 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_q(AttnMfmaArgs a) {
       pa4 = ptile_gload(a.ws_dA, b, N, l0, m0 + 16, tid);
     }
     const float* At = sm + (it & 1) * PT_SZ;
-    float da[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) da[t] = At[ll * PT_LD + (4 * q + t) * AH + h];   // dA[l][m = 4q + t] (zero past N)
+    const float4 da4 = *reinterpret_cast<const float4*>(At + h * PT_PL + pt_off(ll, 4 * q));   // dA[l][m = 4q + t] (zero past N)
+    const float da[4] = {da4.x, da4.y, da4.z, da4.w};
     // dQ^T[k][l] += sum_m K^T[k][m] dA[l][m]
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
