@@ -25,6 +25,8 @@ ARCH = "gfx950"
 EXTRA_FLAGS = {"egt_ffn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 if os.environ.get("EGT_BLOCK_FLAGS"):   # experiments: extra hipcc flags for egt_block.hip
     EXTRA_FLAGS["egt_block.hip"] = os.environ["EGT_BLOCK_FLAGS"].split()
+if os.environ.get("EGT_ATTN_FLAGS"):    # e.g. -DEGT_ATTN_ABLATION (timing ablations of the MFMA inner op)
+    EXTRA_FLAGS["egt_attn_mfma.hip"] = os.environ["EGT_ATTN_FLAGS"].split()
 
 
 def _hipcc() -> str:

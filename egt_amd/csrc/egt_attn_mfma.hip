@@ -32,6 +32,16 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // packed operand arrays, each B*H*NP*d floats, in this order inside the workspace
 enum { PK_KH = 0, PK_VT, PK_QH, PK_QT, PK_KT, PK_VH, PK_OH, PK_OT, PK_COUNT };
 
+// Timing ablations of the forward (which term costs what): build with -DEGT_ATTN_ABLATION
+// (EGT_ATTN_FLAGS, build.py) and set EGT_ATTN_ABLATE=<bits> (1 K/V loads, 2 H_hat stores,
+// 4 pair-tile loads, 8 MFMAs, 16 barrier).  Compiled out otherwise: the always-taken branches
+// split basic blocks and cost 2-3 %.
+#ifdef EGT_ATTN_ABLATION
+#define ABL_ON(a, bit) (!((a).guard & (bit)))
+#else
+#define ABL_ON(a, bit) true
+#endif
+
 struct AttnMfmaArgs {
   int B, N, NP, d;
   uint32_t flags;
@@ -46,6 +56,7 @@ struct AttnMfmaArgs {
   const float *v_att_in, *d_v_att, *d_h_ext;
   float *d_qkv, *d_E, *d_G, *ws_dA;
   int pack_bwd;
+  int guard;   // timing ablations (EGT_ATTN_ABLATE), 0 in production
 };
 
 __device__ __forceinline__ float pair_max_q(float v) {   // max over lanes l, l+16, l+32, l+48
@@ -182,6 +193,19 @@ __device__ __forceinline__ void ptile_gstore(float* dst, const float* tl, int b,
   }
 }
 
+// Same transfers with the address split into a workgroup-uniform base (tensor + graph + first row,
+// scalar registers) and a 32-bit lane offset: rowoff = ptile_rowoff() is fixed for the kernel, the
+// column part is two VALU ops per tile, and one offset serves every [B,N,N,8] tensor.
+__device__ __forceinline__ uint32_t ptile_rowoff(int N, int row0, int tid) {
+  return (uint32_t)(min(row0 + (tid >> 5), N - 1) - row0) * N * AH + (tid & 1) * 4;
+}
+__device__ __forceinline__ uint32_t ptile_off(uint32_t rowoff, int N, int col0, int tid) {
+  return rowoff + (uint32_t)min(col0 + ((tid & 31) >> 1), N - 1) * AH;
+}
+__device__ __forceinline__ const float* ptile_base(const float* src, int b, int N, int row0) {
+  return src + ((size_t)b * N + row0) * N * AH;
+}
+
 // key-mask bytes of keys m .. m+3 (clamped).  Kept as four separate registers: packing them
 // would consume the loads at once, and a wait on these (the youngest loads of the prefetch
 // group) would drain the whole group.
@@ -200,7 +224,7 @@ __device__ __forceinline__ Km4 km_load4(const uint8_t* km, int N, int m) {
 // coalesced by the whole workgroup one tile ahead into double-buffered LDS tiles, H_hat leaves
 // through one: ONE barrier per key tile.
 template <int D, int V>
-__global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
+__global__ void __launch_bounds__(512, 4) k_attn_mfma_fwd(AttnMfmaArgs a) {
   constexpr int KT = D / 16, DH = D * AH;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* In = sm;                    // [2][E | G | M][PT_SZ]
@@ -217,6 +241,16 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
   const size_t arr = (size_t)a.B * AH * NP * D;
   const float* Kh = a.pk + PK_KH * arr + ((size_t)b * AH + h) * NP * D;   // [NP][D]
   const float* VT = a.pk + PK_VT * arr + ((size_t)b * AH + h) * D * NP;   // [D][NP]
+  // uniform bases + 32-bit lane offsets: scalar address arithmetic, one VGPR per access stream
+  const uint32_t koff = ll * D + 4 * q, voff = ll * NP + 4 * q;
+  const uint32_t prow = ptile_rowoff(N, l0, tid);
+  const float* Eb = ptile_base(a.E, b, N, l0);
+  const float* Gb = ptile_base(a.G, b, N, l0);
+  const float* Mb = ptile_base(a.M, b, N, l0);
+  float* Hb = const_cast<float*>(ptile_base(a.h_hat, b, N, l0));
+  auto pload = [&](const float* base, int col0) __attribute__((always_inline)) {
+    return *reinterpret_cast<const float4*>(base + ptile_off(prow, N, col0, tid));
+  };
 
   // Q fragments (B operand of S^T = K.Q^T): Q[l][16T + 4q + u]
   float Qr[4 * KT];
@@ -230,48 +264,44 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
   for (int kt = 0; kt < KT; ++kt) oacc[kt] = (v4f){0.f, 0.f, 0.f, 0.f};
   float mrun = -3.0e38f, lrun = 0.f;
 
-  // Two register sets (A, B) alternate roles tile by tile: one feeds this tile's MFMAs while the
-  // other receives the next tile's K / V^T operands, and likewise for the pair tiles, which travel
-  // TWO key tiles ahead (HBM latency under load is about one tile's worth of work).  Alternating
+  // K / V^T operands are single-buffered: the next tile's K is requested right after this tile's
+  // S MFMAs have consumed the registers, V^T right after the P.V MFMAs -- a full tile ahead of its
+  // use either way.  The pair tiles travel TWO key tiles ahead (HBM latency under load is about one
+  // tile's worth of work) in two register sets (A, B) that alternate roles tile by tile; alternating
   // instead of copying matters: a register copy waits for the load it copies.  All prefetches are
   // unconditional (clamped to the last tile) so each tile is straight-line code with exact waits.
-  float4 kA[KT], vA[KT], kB[KT], vB[KT];
+  float4 kc[KT], vc[KT];
   float4 eA = make_float4(0.f, 0.f, 0.f, 0.f), gA = eA, mA = eA, eB = eA, gB = eA, mB = eA;
-  Km4 kmA{{1u, 1u, 1u, 1u}}, kmB{{1u, 1u, 1u, 1u}};
+  Km4 kmc{{1u, 1u, 1u, 1u}};
   const int mlast = NP - 16;
 #pragma unroll
   for (int T = 0; T < KT; ++T) {
-    kA[T] = *reinterpret_cast<const float4*>(Kh + (size_t)ll * D + 16 * T + 4 * q);
-    vA[T] = *reinterpret_cast<const float4*>(VT + (size_t)(16 * T + ll) * NP + 4 * q);
+    kc[T] = *reinterpret_cast<const float4*>(Kh + koff + 16 * T);
+    vc[T] = *reinterpret_cast<const float4*>(VT + (size_t)16 * T * NP + voff);
   }
-  if (f.km) kmA = km_load4(a.km + (size_t)b * N, N, 4 * q);
-  if (f.E) ptile_lds_put(In + 0 * PT_SZ, ptile_gload(a.E, b, N, l0, 0, tid), N, l0, 0, tid);
-  if (f.G) ptile_lds_put(In + 1 * PT_SZ, ptile_gload(a.G, b, N, l0, 0, tid), N, l0, 0, tid);
-  if (f.M) ptile_lds_put(In + 2 * PT_SZ, ptile_gload(a.M, b, N, l0, 0, tid), N, l0, 0, tid);
+  if (f.km) kmc = km_load4(a.km + (size_t)b * N, N, 4 * q);
+  if (f.E) ptile_lds_put(In + 0 * PT_SZ, pload(Eb, 0), N, l0, 0, tid);
+  if (f.G) ptile_lds_put(In + 1 * PT_SZ, pload(Gb, 0), N, l0, 0, tid);
+  if (f.M) ptile_lds_put(In + 2 * PT_SZ, pload(Mb, 0), N, l0, 0, tid);
   {
     const int m1 = min(16, mlast);
-    if (f.E) eA = ptile_gload(a.E, b, N, l0, m1, tid);
-    if (f.G) gA = ptile_gload(a.G, b, N, l0, m1, tid);
-    if (f.M) mA = ptile_gload(a.M, b, N, l0, m1, tid);
+    if (f.E) eA = pload(Eb, m1);
+    if (f.G) gA = pload(Gb, m1);
+    if (f.M) mA = pload(Mb, m1);
   }
   __builtin_amdgcn_s_waitcnt(0);   // nothing pending at the loop header: its waits then reflect the loop alone
   __syncthreads();
 
-  // one key tile: (kc, vc, kmc) feed it, (kn, vn, kmn) receive tile it+1; (pe, pg, pm) hold the pair
-  // tiles of it+1 and go to LDS at the bottom, (qe, qg, qm) receive those of it+2
-  auto tile = [&](const int m0, const int it, float4 (&kc)[KT], float4 (&vc)[KT], Km4& kmc, float4 (&kn)[KT],
-                  float4 (&vn)[KT], Km4& kmn, float4& pe4, float4& pg4, float4& pm4, float4& qe4, float4& qg4,
+  // one key tile: (pe, pg, pm) hold the pair tiles of it+1 and go to LDS at the bottom,
+  // (qe, qg, qm) receive those of it+2
+  auto tile = [&](const int m0, const int it, float4& pe4, float4& pg4, float4& pm4, float4& qe4, float4& qg4,
                   float4& qm4) __attribute__((always_inline)) {
     const int m1 = min(m0 + 16, mlast), m2 = min(m0 + 32, mlast);
-#pragma unroll
-    for (int T = 0; T < KT; ++T) {
-      kn[T] = *reinterpret_cast<const float4*>(Kh + (size_t)(m1 + ll) * D + 16 * T + 4 * q);
-      vn[T] = *reinterpret_cast<const float4*>(VT + (size_t)(16 * T + ll) * NP + m1 + 4 * q);
+    if (ABL_ON(a, 4)) {
+    if (f.E) qe4 = pload(Eb, m2);
+    if (f.G) qg4 = pload(Gb, m2);
+    if (f.M) qm4 = pload(Mb, m2);
     }
-    if (f.km) kmn = km_load4(a.km + (size_t)b * N, N, m1 + 4 * q);
-    if (f.E) qe4 = ptile_gload(a.E, b, N, l0, m2, tid);
-    if (f.G) qg4 = ptile_gload(a.G, b, N, l0, m2, tid);
-    if (f.M) qm4 = ptile_gload(a.M, b, N, l0, m2, tid);
     __builtin_amdgcn_sched_barrier(0);   // keep the prefetches up here: hipcc otherwise sinks them past the MFMAs
     const float* Et = In + (it & 1) * 3 * PT_SZ;
     const float* Gt = Et + PT_SZ;
@@ -279,6 +309,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
     float* Ht = Hout + (it & 1) * PT_SZ;
     // ---- S^T[m][l] = sum_k K[m][k] Q[l][k] ----
     v4f s = {0.f, 0.f, 0.f, 0.f};
+    if (ABL_ON(a, 8))
 #pragma unroll
     for (int T = 0; T < KT; ++T) {
       s = MFMA(kc[T].x, Qr[4 * T + 0], s);
@@ -286,6 +317,11 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
       s = MFMA(kc[T].z, Qr[4 * T + 2], s);
       s = MFMA(kc[T].w, Qr[4 * T + 3], s);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL_ON(a, 1))
+#pragma unroll
+    for (int T = 0; T < KT; ++T) kc[T] = *reinterpret_cast<const float4*>(Kh + (size_t)m1 * D + koff + 16 * T);
+    __builtin_amdgcn_sched_barrier(0);
     float x[4], pa[4];
     float tmax = -3.0e38f;
     const int po4 = h * PT_PL + pt_off(ll, 4 * q);   // this lane's keys 4q..4q+3 of row ll: one 16-byte access
@@ -311,6 +347,11 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
       tmax = fmaxf(tmax, x[r]);
     }
     *reinterpret_cast<float4*>(Ht + po4) = make_float4(hv4[0], hv4[1], hv4[2], hv4[3]);
+    if (f.km) {   // key mask of the next tile, into the registers this tile just finished with
+      __builtin_amdgcn_sched_barrier(0);
+      kmc = km_load4(a.km + (size_t)b * N, N, m1 + 4 * q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- online softmax over the key axis: in-lane over r, then across q ----
     tmax = pair_max_q(tmax);
     const float mnew = fmaxf(mrun, tmax);
@@ -330,30 +371,43 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
     for (int kt = 0; kt < KT; ++kt) {
       v4f o = oacc[kt];
       o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+      if (ABL_ON(a, 8)) {
       o = MFMA(vc[kt].x, pa[0], o);
       o = MFMA(vc[kt].y, pa[1], o);
       o = MFMA(vc[kt].z, pa[2], o);
       o = MFMA(vc[kt].w, pa[3], o);
+      }
       oacc[kt] = o;
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL_ON(a, 1))
+#pragma unroll
+    for (int T = 0; T < KT; ++T) vc[T] = *reinterpret_cast<const float4*>(VT + (size_t)16 * T * NP + m1 + voff);
+    __builtin_amdgcn_sched_barrier(0);
     {   // tile it+1 into the other LDS buffer (its last readers passed the previous barrier)
       float* nx = In + ((it + 1) & 1) * 3 * PT_SZ;
       if (f.E) ptile_lds_put(nx, pe4, N, l0, m1, tid);
       if (f.G) ptile_lds_put(nx + PT_SZ, pg4, N, l0, m1, tid);
       if (f.M) ptile_lds_put(nx + 2 * PT_SZ, pm4, N, l0, m1, tid);
     }
-    __syncthreads();
-    ptile_gstore(a.h_hat, Ht, b, N, l0, m0, tid);   // whole 512-byte runs
+    if (ABL_ON(a, 16)) __syncthreads();
+    {   // H_hat tile out: whole 512-byte runs
+      const int row = tid >> 5, m = (tid & 31) >> 1;
+      if (l0 + row < N && m0 + m < N && ABL_ON(a, 2)) {
+        const float* p = Ht + (tid & 1) * 4 * PT_PL + pt_off(row, m);
+        *reinterpret_cast<float4*>(Hb + ptile_off(prow, N, m0, tid)) = make_float4(p[0], p[PT_PL], p[2 * PT_PL], p[3 * PT_PL]);
+      }
+    }
   };
   // pairs of tiles in the loop, an odd last tile outside it: a conditional second tile inside the
   // loop would put the first tile's pending loads on a (never taken) path to the loop header and
   // make hipcc drain every prefetch there
   int m0 = 0;
   for (; m0 + 16 < NP; m0 += 32) {
-    tile(m0, 0, kA, vA, kmA, kB, vB, kmB, eA, gA, mA, eB, gB, mB);
-    tile(m0 + 16, 1, kB, vB, kmB, kA, vA, kmA, eB, gB, mB, eA, gA, mA);
+    tile(m0, 0, eA, gA, mA, eB, gB, mB);
+    tile(m0 + 16, 1, eB, gB, mB, eA, gA, mA);
   }
-  if (m0 < NP) tile(m0, 0, kA, vA, kmA, kB, vB, kmB, eA, gA, mA, eB, gB, mB);
+  if (m0 < NP) tile(m0, 0, eA, gA, mA, eB, gB, mB);
   // ---- finalize: V_att[l][k*8+h] = O[l][k] / l_run ; row statistics for the backward ----
   if (l < N) {
     const float inv = 1.0f / lrun;
@@ -653,6 +707,7 @@ static int fill(const egt_attn_desc* desc, const void* qkv, const void* E, const
   a.B = desc->B; a.N = desc->N; a.NP = np_of(desc->N); a.d = desc->d; a.flags = desc->flags;
   a.clip_lo = desc->clip_lo; a.clip_hi = desc->clip_hi;
   a.scale = 1.0f / sqrtf((float)desc->d);
+  { const char* g = getenv("EGT_ATTN_ABLATE"); a.guard = g ? atoi(g) : 0; }
   a.rm_thr = egt_threshold24(desc->random_mask_prob);
   a.s0 = (uint32_t)(desc->seed & 0xFFFFFFFFull); a.s1 = (uint32_t)(desc->seed >> 32);
   a.qkv = (const float*)qkv;
