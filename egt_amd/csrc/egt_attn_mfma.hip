@@ -6,7 +6,7 @@
 // probabilities never exist outside registers.
 //
 // Layout decision: a pack kernel first rewrites Q/K/V (and dV_att) head-major, both row-major
-// [B,H,NP,d] and transposed [B,H,d,NP] (NP = N rounded up to 16, zero padded).  With that,
+// [B,H,NP/16,d/16,16,16] and transposed [B,H,NP/16,d,16], both tile-major (NP = N rounded up to 16, zero padded).  With that,
 // EVERY MFMA operand that comes from Q/K/V/dO is one aligned 16-byte global load per four
 // contraction steps, straight into the lane that feeds the matrix core:
 //   operand "rows x contraction":  lane (row = lane&15, q = lane>>4) holds X[row][16T + 4q + u]
@@ -90,25 +90,28 @@ __global__ void __launch_bounds__(256) k_attn_pack(AttnMfmaArgs a) {
   }
   __syncthreads();
   const size_t arr = (size_t)a.B * AH * NP * D;
-  // section s of the source rows -> row-major [b,h,n,k] array `which`
+  // section s of the source rows -> [b,h,n/16,k/16,16 nodes,16 channels] array `which`: a wave's
+  // operand fetch (16 nodes x 16 channels of one k-tile) is ONE contiguous 1 KB block
 #define PUT_ROWS(s, which)                                                                       \
   do {                                                                                           \
     float* dst = a.pk + (size_t)(which) * arr;                                                   \
     for (int i = tid; i < AH * 16 * (D / 4); i += 256) {                                         \
-      const int k4 = i % (D / 4), r = (i / (D / 4)) % 16, h = i / (16 * (D / 4));                \
+      const int k4 = ((i >> 6) % (D / 16)) * 4 + (i & 3), r = (i >> 2) & 15, h = i / (4 * D);     \
       const float* src = sm + r * LD + (s) * DH + (k4 * 4) * AH + h;                             \
-      *reinterpret_cast<float4*>(dst + (((size_t)b * AH + h) * NP + n0 + r) * D + k4 * 4) =      \
+      *reinterpret_cast<float4*>(dst + ((size_t)b * AH + h) * NP * D + (size_t)n0 * D + (k4 >> 2) * 256 + r * 16 + (k4 & 3) * 4) = \
           make_float4(src[0], src[AH], src[2 * AH], src[3 * AH]);                                \
     }                                                                                            \
   } while (0)
-  // ... -> transposed [b,h,k,n] array
+  // ... -> transposed, tile-major [b,h,n/16,k,16] array: the 16 nodes of a tile are contiguous per
+  // channel and a tile is one 64*D-byte block, so a wave's operand fetch uses whole cache lines
+  // (with [b,h,k,n] rows a 16-node access touches half of each 128-byte line)
 #define PUT_COLS(s, which)                                                                       \
   do {                                                                                           \
     float* dst = a.pk + (size_t)(which) * arr;                                                   \
     for (int i = tid; i < AH * D * 4; i += 256) {                                                \
       const int r4 = i & 3, k = (i >> 2) % D, h = i / (4 * D);                                   \
       const float* src = sm + (r4 * 4) * LD + (s) * DH + k * AH + h;                             \
-      *reinterpret_cast<float4*>(dst + (((size_t)b * AH + h) * D + k) * NP + n0 + r4 * 4) =      \
+      *reinterpret_cast<float4*>(dst + ((size_t)b * AH + h) * D * NP + (size_t)n0 * D + k * 16 + r4 * 4) = \
           make_float4(src[0], src[LD], src[2 * LD], src[3 * LD]);                                \
     }                                                                                            \
   } while (0)
@@ -239,10 +242,10 @@ __global__ void __launch_bounds__(512, 4) k_attn_mfma_fwd(AttnMfmaArgs a) {
   const Feat<V> f(a);
   const bool gated = f.G, clip = f.clip;
   const size_t arr = (size_t)a.B * AH * NP * D;
-  const float* Kh = a.pk + PK_KH * arr + ((size_t)b * AH + h) * NP * D;   // [NP][D]
-  const float* VT = a.pk + PK_VT * arr + ((size_t)b * AH + h) * D * NP;   // [D][NP]
+  const float* Kh = a.pk + PK_KH * arr + ((size_t)b * AH + h) * NP * D;   // [NP/16][D/16][16][16]
+  const float* VT = a.pk + PK_VT * arr + ((size_t)b * AH + h) * D * NP;   // [NP/16][D][16]
   // uniform bases + 32-bit lane offsets: scalar address arithmetic, one VGPR per access stream
-  const uint32_t koff = ll * D + 4 * q, voff = ll * NP + 4 * q;
+  const uint32_t koff = ll * 16 + 4 * q, voff = koff;
   const uint32_t prow = ptile_rowoff(N, l0, tid);
   const float* Eb = ptile_base(a.E, b, N, l0);
   const float* Gb = ptile_base(a.G, b, N, l0);
@@ -276,8 +279,8 @@ __global__ void __launch_bounds__(512, 4) k_attn_mfma_fwd(AttnMfmaArgs a) {
   const int mlast = NP - 16;
 #pragma unroll
   for (int T = 0; T < KT; ++T) {
-    kc[T] = *reinterpret_cast<const float4*>(Kh + koff + 16 * T);
-    vc[T] = *reinterpret_cast<const float4*>(VT + (size_t)16 * T * NP + voff);
+    kc[T] = *reinterpret_cast<const float4*>(Kh + koff + 256 * T);
+    vc[T] = *reinterpret_cast<const float4*>(VT + voff + 256 * T);
   }
   if (f.km) kmc = km_load4(a.km + (size_t)b * N, N, 4 * q);
   if (f.E) ptile_lds_put(In + 0 * PT_SZ, pload(Eb, 0), N, l0, 0, tid);
@@ -320,7 +323,7 @@ __global__ void __launch_bounds__(512, 4) k_attn_mfma_fwd(AttnMfmaArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     if (ABL_ON(a, 1))
 #pragma unroll
-    for (int T = 0; T < KT; ++T) kc[T] = *reinterpret_cast<const float4*>(Kh + (size_t)m1 * D + koff + 16 * T);
+    for (int T = 0; T < KT; ++T) kc[T] = *reinterpret_cast<const float4*>(Kh + (size_t)m1 * D + koff + 256 * T);
     __builtin_amdgcn_sched_barrier(0);
     float x[4], pa[4];
     float tmax = -3.0e38f;
@@ -382,7 +385,7 @@ __global__ void __launch_bounds__(512, 4) k_attn_mfma_fwd(AttnMfmaArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     if (ABL_ON(a, 1))
 #pragma unroll
-    for (int T = 0; T < KT; ++T) vc[T] = *reinterpret_cast<const float4*>(VT + (size_t)16 * T * NP + m1 + voff);
+    for (int T = 0; T < KT; ++T) vc[T] = *reinterpret_cast<const float4*>(VT + (size_t)m1 * D + voff + 256 * T);
     __builtin_amdgcn_sched_barrier(0);
     {   // tile it+1 into the other LDS buffer (its last readers passed the previous barrier)
       float* nx = In + ((it + 1) & 1) * 3 * PT_SZ;
@@ -473,8 +476,8 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
   float4 Kr[KT], Vr[KT];
 #pragma unroll
   for (int T = 0; T < KT; ++T) {
-    Kr[T] = *reinterpret_cast<const float4*>(Kh + (size_t)m * D + 16 * T + 4 * q);
-    Vr[T] = *reinterpret_cast<const float4*>(Vh + (size_t)m * D + 16 * T + 4 * q);
+    Kr[T] = *reinterpret_cast<const float4*>(Kh + (size_t)m0 * D + 256 * T + mm * 16 + 4 * q);
+    Vr[T] = *reinterpret_cast<const float4*>(Vh + (size_t)m0 * D + 256 * T + mm * 16 + 4 * q);
   }
   const float kadd = (f.km && a.km[(size_t)b * N + mc] == 0) ? -EGT_NEG : 0.0f;
   v4f dKacc[KT], dVacc[KT];
@@ -493,8 +496,8 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
   float4 qan[KT], oan[KT], stn[4];   // row operands / statistics of the next query tile
 #pragma unroll
   for (int T = 0; T < KT; ++T) {
-    qan[T] = *reinterpret_cast<const float4*>(Qh + (size_t)mm * D + 16 * T + 4 * q);
-    oan[T] = *reinterpret_cast<const float4*>(Oh + (size_t)mm * D + 16 * T + 4 * q);
+    qan[T] = *reinterpret_cast<const float4*>(Qh + 256 * T + mm * 16 + 4 * q);
+    oan[T] = *reinterpret_cast<const float4*>(Oh + 256 * T + mm * 16 + 4 * q);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r)
@@ -508,8 +511,8 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
     float4 qt[KT], ot[KT];
 #pragma unroll
     for (int T = 0; T < KT; ++T) {
-      qt[T] = *reinterpret_cast<const float4*>(QT + (size_t)(16 * T + mm) * NP + l0 + 4 * q);  // A rows are channels
-      ot[T] = *reinterpret_cast<const float4*>(OT + (size_t)(16 * T + mm) * NP + l0 + 4 * q);
+      qt[T] = *reinterpret_cast<const float4*>(QT + (size_t)l0 * D + (16 * T + mm) * 16 + 4 * q);  // A rows are channels
+      ot[T] = *reinterpret_cast<const float4*>(OT + (size_t)l0 * D + (16 * T + mm) * 16 + 4 * q);
     }
     float4 qa[KT], oa[KT], st[4];
 #pragma unroll
@@ -522,8 +525,8 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
     if (more) {
 #pragma unroll
       for (int T = 0; T < KT; ++T) {
-        qan[T] = *reinterpret_cast<const float4*>(Qh + (size_t)(l0 + 16 + mm) * D + 16 * T + 4 * q);   // A rows are query rows
-        oan[T] = *reinterpret_cast<const float4*>(Oh + (size_t)(l0 + 16 + mm) * D + 16 * T + 4 * q);
+        qan[T] = *reinterpret_cast<const float4*>(Qh + (size_t)(l0 + 16) * D + 256 * T + mm * 16 + 4 * q);   // A rows are query rows
+        oan[T] = *reinterpret_cast<const float4*>(Oh + (size_t)(l0 + 16) * D + 256 * T + mm * 16 + 4 * q);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -630,7 +633,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_q(AttnMfmaArgs a) {
   float4 kc[KT], kn[KT], pa4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
-    kc[kt] = *reinterpret_cast<const float4*>(KTp + (size_t)(16 * kt + ll) * NP + 4 * q);
+    kc[kt] = *reinterpret_cast<const float4*>(KTp + (16 * kt + ll) * 16 + 4 * q);
     kn[kt] = kc[kt];
   }
   ptile_lds_put(sm, ptile_gload(a.ws_dA, b, N, l0, 0, tid), N, l0, 0, tid);
@@ -640,7 +643,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_q(AttnMfmaArgs a) {
     if (more) {
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
-        kn[kt] = *reinterpret_cast<const float4*>(KTp + (size_t)(16 * kt + ll) * NP + m0 + 16 + 4 * q);
+        kn[kt] = *reinterpret_cast<const float4*>(KTp + (size_t)(m0 + 16) * D + (16 * kt + ll) * 16 + 4 * q);
       pa4 = ptile_gload(a.ws_dA, b, N, l0, m0 + 16, tid);
     }
     const float* At = sm + (it & 1) * PT_SZ;
