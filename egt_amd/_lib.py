@@ -98,6 +98,7 @@ _PROTOS = {
     "egt_edge_proj_fwd": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 10),
     "egt_edge_proj_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(EdgeDesc)]),
     "egt_edge_proj_bwd": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 17),
+    "egt_edge_proj_bwd_acc": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 18),
     "egt_edge_update_fwd": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 6),
     "egt_edge_update_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(EdgeDesc)]),
     "egt_edge_update_bwd": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 8),

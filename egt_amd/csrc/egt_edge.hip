@@ -2,15 +2,13 @@
 //   egt_edge_proj_*   : [norm_edge] -> attention_gates (De->H) , dense_edge_b (De->H)
 //                       graph_xformer_model_base.py:195,201-204,149-162
 //   egt_edge_update_* : e' = e + H_hat·Wr + br   (dense_edge_r + res_edge, :214-218)
-// Tile machinery: a 256-thread workgroup stages 256 edge rows (256 x De fp32,
-// coalesced 16-byte loads) in LDS with a +1 padded stride, then one thread owns
-// one row (bank-conflict-free column walk) with the weights broadcast from
-// scalar loads.  Weight gradients are per-workgroup register partials reduced by
-// a deterministic second kernel (no float atomics).
+// The projections and their backward contractions run on the matrix cores (see "MFMA tiles"
+// below); edge_update forward is a pure streaming kernel.  Weight gradients are per-workgroup
+// partials reduced by a deterministic second kernel (no float atomics).
 #include "egt_common.h"
+#include "egt_tile.h"
 
 #define EDGE_H 8
-#define TILE_ROWS 256
 
 struct EdgeArgs {
   long rows;
@@ -23,22 +21,6 @@ struct EdgeArgs {
   float *d_gamma, *d_beta, *d_Wg, *d_bg, *d_We, *d_be, *d_Wr, *d_br;
   int n_partials;
 };
-
-template <int DE>
-__device__ __forceinline__ void load_tile(float* tile, const float* src, long row0, long rows) {
-  // 256 rows x DE floats, coalesced float4 loads -> LDS stride DE+1
-  constexpr int F4_PER_ROW = DE / 4;
-  constexpr int ITERS = F4_PER_ROW;  // 256*DE/4 float4s over 256 threads
-#pragma unroll 4
-  for (int i = 0; i < ITERS; ++i) {
-    const int f = i * TILE_ROWS + threadIdx.x;
-    const int r = f / F4_PER_ROW, c = (f % F4_PER_ROW) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row0 + r < rows) v = *reinterpret_cast<const float4*>(src + (size_t)(row0 + r) * DE + c);
-    float* t = tile + r * (DE + 1) + c;
-    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
-  }
-}
 
 __device__ __forceinline__ float act_fwd(int act, float alpha, float x) {
   switch (act) {
@@ -58,175 +40,203 @@ __device__ __forceinline__ float act_grad_from_out(int act, float alpha, float y
   }
 }
 
+// ---------------------------------------------------------------- MFMA tiles ---
+// The three heavy kernels (proj forward, proj backward, update backward) run on
+// v_mfma_f32_16x16x4_f32 in the transposed formulation of the fused block kernels: the 16 edge
+// rows of a tile sit on the MFMA column axis, lane (p = lane&15, q = lane>>4) owns row p and
+// channels 16t + 4q + {0..3} -- one aligned 16-byte global load per fragment, straight into the
+// register that feeds the matrix core.  LayerNorm statistics are two cross-lane sums over q.
+// The weight-gradient contractions run over the ROW axis, so that one operand needs the rows on
+// the contraction (q) axis: the tile takes one round trip through a wave-private LDS tile
+// (row stride = 16 mod 32 floats: the transposed ds_read_b32 are conflict-free).
+#define EDGE_WAVES 8   // waves per workgroup in the backward kernels
+
+template <int DE> struct EdgeGeo {
+  static constexpr int T = (DE + 15) / 16;
+  static constexpr int LD = (T * 16) % 32 == 16 ? T * 16 : T * 16 + 16;   // 16 mod 32
+};
+
+// fragments of row `rc` (already clamped); channels >= DE (only DE = 8) read as zero
+template <int DE>
+__device__ __forceinline__ void frag_gload(float4 (&x)[EdgeGeo<DE>::T], const float* src, long rc, int q) {
+#pragma unroll
+  for (int t = 0; t < EdgeGeo<DE>::T; ++t) {
+    const int c = 16 * t + 4 * q;
+    const bool ok = c < DE;
+    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)rc * DE + (ok ? c : 0));
+    x[t] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+  }
+}
+__device__ __forceinline__ float f4c(const float4& v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; }
+
+// column i of the concatenated projection [attention_gates | dense_edge_b] for channel c
+__device__ __forceinline__ float wcat(const EdgeArgs& a, bool gates, int c, int i) {
+  return i < EDGE_H ? (gates ? a.Wg[c * EDGE_H + i] : 0.f) : a.We[c * EDGE_H + (i - EDGE_H)];
+}
+
 // ------------------------------------------------------------- proj forward ---
+// out[i][row] = sum_c (gamma_c Wcat[c][i]) xhat[row][c] + (b_i + sum_c beta_c Wcat[c][i]):
+// the folded weights are the A operand (4*T registers per lane, loaded once per wave).
 template <int DE>
 __global__ void __launch_bounds__(256) k_edge_proj_fwd(EdgeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];
-  const long ntiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
-  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const long row0 = t * TILE_ROWS;
-    __syncthreads();
-    load_tile<DE>(tile, a.e, row0, a.rows);
-    __syncthreads();
-    const long row = row0 + threadIdx.x;
-    float x[DE];
-    const float* tr = tile + threadIdx.x * (DE + 1);
+  constexpr int T = EdgeGeo<DE>::T;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+  const bool ln = (a.flags & EGT_EP_LAYERNORM) != 0, gates = (a.flags & EGT_EP_GATES) != 0;
+  float wA[T][4];
 #pragma unroll
-    for (int k = 0; k < DE; ++k) x[k] = tr[k];
-    if (a.flags & EGT_EP_LAYERNORM) {
-      float mu = 0.f;
+  for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int k = 0; k < DE; ++k) mu += x[k];
-      mu *= (1.0f / DE);
-      float var = 0.f;
-#pragma unroll
-      for (int k = 0; k < DE; ++k) { const float c = x[k] - mu; var = fmaf(c, c, var); }
-      var *= (1.0f / DE);
-      const float rstd = rsqrtf(var + a.ln_eps);
-#pragma unroll
-      for (int k = 0; k < DE; ++k) x[k] = fmaf((x[k] - mu) * rstd, a.gamma[k], a.beta[k]);
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * t + 4 * q + r;
+      wA[t][r] = c < DE ? wcat(a, gates, c, p) * (ln ? a.gamma[c] : 1.0f) : 0.f;
     }
-    float g[EDGE_H], eb[EDGE_H];
+  float bias[4];
 #pragma unroll
-    for (int j = 0; j < EDGE_H; ++j) { g[j] = (a.flags & EGT_EP_GATES) ? a.bg[j] : 0.f; eb[j] = a.be[j]; }
-    if (a.flags & EGT_EP_GATES) {
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * q + r;
+    float b = i < EDGE_H ? (gates ? a.bg[i] : 0.f) : a.be[i - EDGE_H];
+    if (ln)
+      for (int c = 0; c < DE; ++c) b = fmaf(a.beta[c], wcat(a, gates, c, i), b);
+    bias[r] = b;
+  }
+  const long ntiles = (a.rows + 15) / 16;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    const long row = tile * 16 + p;
+    float4 x[T];
+    frag_gload<DE>(x, a.e, row < a.rows ? row : a.rows - 1, q);
+    ln_frags<DE>(x, q, a.ln_eps, ln);
+    v4f acc = {bias[0], bias[1], bias[2], bias[3]};
 #pragma unroll
-      for (int k = 0; k < DE; ++k)
-#pragma unroll
-        for (int j = 0; j < EDGE_H; ++j) g[j] = fmaf(x[k], a.Wg[k * EDGE_H + j], g[j]);
+    for (int t = 0; t < T; ++t) {
+      acc = MFMA(wA[t][0], x[t].x, acc);
+      acc = MFMA(wA[t][1], x[t].y, acc);
+      acc = MFMA(wA[t][2], x[t].z, acc);
+      acc = MFMA(wA[t][3], x[t].w, acc);
     }
-#pragma unroll
-    for (int k = 0; k < DE; ++k)
-#pragma unroll
-      for (int j = 0; j < EDGE_H; ++j) eb[j] = fmaf(x[k], a.We[k * EDGE_H + j], eb[j]);
-    if (row < a.rows) {
-      if (a.flags & EGT_EP_GATES) {
-        float4* go = reinterpret_cast<float4*>(a.G_out + (size_t)row * EDGE_H);
-        go[0] = make_float4(g[0], g[1], g[2], g[3]);
-        go[1] = make_float4(g[4], g[5], g[6], g[7]);
+    if (row < a.rows) {   // lane holds outputs 4q..4q+3 of its row: q < 2 gates, q >= 2 edge bias
+      if (q < 2) {
+        if (gates) *reinterpret_cast<float4*>(a.G_out + (size_t)row * EDGE_H + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      } else {
+        *reinterpret_cast<float4*>(a.E_o + (size_t)row * EDGE_H + 4 * (q - 2)) =
+            make_float4(act_fwd(a.act, a.act_alpha, acc[0]), act_fwd(a.act, a.act_alpha, acc[1]),
+                        act_fwd(a.act, a.act_alpha, acc[2]), act_fwd(a.act, a.act_alpha, acc[3]));
       }
-#pragma unroll
-      for (int j = 0; j < EDGE_H; ++j) eb[j] = act_fwd(a.act, a.act_alpha, eb[j]);
-      float4* eo = reinterpret_cast<float4*>(a.E_o + (size_t)row * EDGE_H);
-      eo[0] = make_float4(eb[0], eb[1], eb[2], eb[3]);
-      eo[1] = make_float4(eb[4], eb[5], eb[6], eb[7]);
     }
   }
 }
 
 // ------------------------------------------------------------ proj backward ---
 // partial layout per workgroup: That[DE][16] then s[16]
+//   dxh[c][row]  = gamma_c sum_i Wcat[c][i] dpre[row][i]      (A = folded weights, B = dpre in place)
+//   de           = LayerNorm backward of dxh, in the lane's fragments
+//   That[c][i]  += sum_row xhat[row][c] dpre[row][i]          (both operands transposed through LDS)
 template <int DE>
-__global__ void __launch_bounds__(256) k_edge_proj_bwd(EdgeArgs a) {
+__global__ void __launch_bounds__(64 * EDGE_WAVES) k_edge_proj_bwd(EdgeArgs a) {
+  constexpr int T = EdgeGeo<DE>::T, LD = EdgeGeo<DE>::LD, PSZ = DE * 16 + 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* tile = smem;                              // xhat [256][DE+1]
-  float* dt = smem + TILE_ROWS * (DE + 1);         // dpre [256][17]
-  const bool ln = (a.flags & EGT_EP_LAYERNORM) != 0;
-  const bool gates = (a.flags & EGT_EP_GATES) != 0;
-  const int kq = threadIdx.x >> 2, jq = threadIdx.x & 3;
-  float accT[4] = {0.f, 0.f, 0.f, 0.f}, accS[4] = {0.f, 0.f, 0.f, 0.f};
-  const long ntiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
-  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const long row0 = t * TILE_ROWS;
-    __syncthreads();
-    load_tile<DE>(tile, a.e, row0, a.rows);
-    __syncthreads();
-    const long row = row0 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+  float* xs = smem + wave * (16 * LD + 256);   // xhat tile [16][LD]
+  float* ds = xs + 16 * LD;                    // dpre tile [16][16]
+  const bool ln = (a.flags & EGT_EP_LAYERNORM) != 0, gates = (a.flags & EGT_EP_GATES) != 0;
+  float wB[T][4];   // A operand of the dxh GEMM: row = channel 16t + p, contraction index i = 4q + s
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int c = 16 * t + p;
+      wB[t][s] = c < DE ? wcat(a, gates, c, 4 * q + s) * (ln ? a.gamma[c] : 1.0f) : 0.f;
+    }
+  v4f accT[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) accT[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+  float4 accS = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long ntiles = (a.rows + 15) / 16;
+  for (long tile = (long)blockIdx.x * EDGE_WAVES + wave; tile < ntiles; tile += (long)gridDim.x * EDGE_WAVES) {
+    const long row = tile * 16 + p;
     const bool valid = row < a.rows;
-    float x[DE];
-    float* tr = tile + threadIdx.x * (DE + 1);
-#pragma unroll
-    for (int k = 0; k < DE; ++k) x[k] = tr[k];
-    float rstd = 1.0f;
-    if (ln) {
-      float mu = 0.f;
-#pragma unroll
-      for (int k = 0; k < DE; ++k) mu += x[k];
-      mu *= (1.0f / DE);
-      float var = 0.f;
-#pragma unroll
-      for (int k = 0; k < DE; ++k) { const float c = x[k] - mu; var = fmaf(c, c, var); }
-      var *= (1.0f / DE);
-      rstd = rsqrtf(var + a.ln_eps);
-#pragma unroll
-      for (int k = 0; k < DE; ++k) { x[k] = (x[k] - mu) * rstd; tr[k] = x[k]; }
-    }
-    float dp[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) dp[j] = 0.f;
-    if (valid) {
-      if (gates) {
-        const float4* gp = reinterpret_cast<const float4*>(a.dG + (size_t)row * EDGE_H);
-        float4 u = gp[0], v = gp[1];
-        dp[0] = u.x; dp[1] = u.y; dp[2] = u.z; dp[3] = u.w;
-        dp[4] = v.x; dp[5] = v.y; dp[6] = v.z; dp[7] = v.w;
-      }
-      const float4* ep = reinterpret_cast<const float4*>(a.dE + (size_t)row * EDGE_H);
-      float4 u = ep[0], v = ep[1];
-      dp[8] = u.x; dp[9] = u.y; dp[10] = u.z; dp[11] = u.w;
-      dp[12] = v.x; dp[13] = v.y; dp[14] = v.z; dp[15] = v.w;
+    const long rc = valid ? row : a.rows - 1;
+    float4 x[T], base[T];
+    frag_gload<DE>(x, a.e, rc, q);
+    if (a.de_out) frag_gload<DE>(base, a.de_out, rc, q);   // gradient e already carries (residual branch)
+    // dpre[row][4q..4q+3]: q < 2 from dG, q >= 2 from dE (through the activation derivative)
+    float4 dp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < 2) {
+      if (gates) dp = *reinterpret_cast<const float4*>(a.dG + (size_t)rc * EDGE_H + 4 * q);
+    } else {
+      dp = *reinterpret_cast<const float4*>(a.dE + (size_t)rc * EDGE_H + 4 * (q - 2));
       if (a.act != EGT_ACT_NONE) {
-        const float* yo = a.E_out + (size_t)row * EDGE_H;
-#pragma unroll
-        for (int j = 0; j < EDGE_H; ++j) dp[8 + j] *= act_grad_from_out(a.act, a.act_alpha, yo[j]);
+        const float4 y = *reinterpret_cast<const float4*>(a.E_out + (size_t)rc * EDGE_H + 4 * (q - 2));
+        dp.x *= act_grad_from_out(a.act, a.act_alpha, y.x); dp.y *= act_grad_from_out(a.act, a.act_alpha, y.y);
+        dp.z *= act_grad_from_out(a.act, a.act_alpha, y.z); dp.w *= act_grad_from_out(a.act, a.act_alpha, y.w);
       }
     }
-    float* dr = dt + threadIdx.x * 17;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) dr[j] = dp[j];
-    // d(e_ln)_k = sum_j dpre_j * Wcat[k][j]
-    float dx[DE];
+    if (!valid) dp = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float rstd = ln_frags<DE>(x, q, a.ln_eps, ln);
+    float4 dx[T];
     float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < DE; ++k) {
-      float v = 0.f;
-      if (gates) {
-#pragma unroll
-        for (int j = 0; j < EDGE_H; ++j) v = fmaf(dp[j], a.Wg[k * EDGE_H + j], v);
-      }
-#pragma unroll
-      for (int j = 0; j < EDGE_H; ++j) v = fmaf(dp[8 + j], a.We[k * EDGE_H + j], v);
-      if (ln) {
-        v *= a.gamma[k];
-        m1 += v;
-        m2 = fmaf(v, x[k], m2);
-      }
-      dx[k] = v;
+    for (int t = 0; t < T; ++t) {
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
+      acc = MFMA(wB[t][0], dp.x, acc);
+      acc = MFMA(wB[t][1], dp.y, acc);
+      acc = MFMA(wB[t][2], dp.z, acc);
+      acc = MFMA(wB[t][3], dp.w, acc);
+      dx[t] = make_float4(acc[0], acc[1], acc[2], acc[3]);   // channels 16t + 4q + r of row p (zero past DE)
+      m1 += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+      m2 = fmaf(acc[0], x[t].x, m2); m2 = fmaf(acc[1], x[t].y, m2);
+      m2 = fmaf(acc[2], x[t].z, m2); m2 = fmaf(acc[3], x[t].w, m2);
     }
     if (ln) {
-      m1 *= (1.0f / DE);
-      m2 *= (1.0f / DE);
+      m1 = sum_over_q(m1) * (1.0f / DE);
+      m2 = sum_over_q(m2) * (1.0f / DE);
 #pragma unroll
-      for (int k = 0; k < DE; ++k) dx[k] = rstd * (dx[k] - m1 - x[k] * m2);
-    }
-    if (valid) {
-      float4* o = reinterpret_cast<float4*>(a.d_e + (size_t)row * DE);
-#pragma unroll
-      for (int k = 0; k < DE; k += 4) o[k / 4] = make_float4(dx[k], dx[k + 1], dx[k + 2], dx[k + 3]);
-    }
-    __syncthreads();
-    // That[k][j] += sum_r xhat[r][k] * dpre[r][j]
-    if (kq < DE) {
-      for (int r = 0; r < TILE_ROWS; ++r) {
-        const float xv = tile[r * (DE + 1) + kq];
-        const float* d4 = dt + r * 17 + jq * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) accT[i] = fmaf(xv, d4[i], accT[i]);
-        if (kq == 0) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) accS[i] += d4[i];
-        }
+      for (int t = 0; t < T; ++t) {
+        dx[t].x = rstd * (dx[t].x - m1 - x[t].x * m2); dx[t].y = rstd * (dx[t].y - m1 - x[t].y * m2);
+        dx[t].z = rstd * (dx[t].z - m1 - x[t].z * m2); dx[t].w = rstd * (dx[t].w - m1 - x[t].w * m2);
       }
     }
-  }
-  float* part = a.ws + (size_t)blockIdx.x * (DE * 16 + 16);
-  if (kq < DE) {
+    if (a.de_out) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) part[kq * 16 + jq * 4 + i] = accT[i];
-    if (kq == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) part[DE * 16 + jq * 4 + i] = accS[i];
+      for (int t = 0; t < T; ++t) { dx[t].x += base[t].x; dx[t].y += base[t].y; dx[t].z += base[t].z; dx[t].w += base[t].w; }
     }
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        if (16 * t + 4 * q < DE) *reinterpret_cast<float4*>(a.d_e + (size_t)row * DE + 16 * t + 4 * q) = dx[t];
+    }
+    // transposed operands of the weight-gradient contraction
+#pragma unroll
+    for (int t = 0; t < T; ++t) *reinterpret_cast<float4*>(xs + p * LD + 16 * t + 4 * q) = x[t];
+    *reinterpret_cast<float4*>(ds + p * 16 + 4 * q) = dp;
+    lds_sync();
+    float aD[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) aD[s] = ds[(4 * s + q) * 16 + p];        // A[i = p][row = 4s + q]
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        accT[t] = MFMA(aD[s], xs[(4 * s + q) * LD + 16 * t + p], accT[t]);   // B[row = 4s + q][c = 16t + p]
+    accS.x += dp.x; accS.y += dp.y; accS.z += dp.z; accS.w += dp.w;
+    lds_sync();
+  }
+  // accT[t][r] = That[c = 16t + p][i = 4q + r]; s[4q + r] = sum over the 16 lanes p
+  __syncthreads();
+  float* red = smem + wave * PSZ;   // the tiles are dead: reuse the space, one image per wave
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+    if (16 * t + p < DE)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(16 * t + p) * 16 + 4 * q + r] = accT[t][r];
+  const float s0 = row_sum16(accS.x), s1 = row_sum16(accS.y), s2 = row_sum16(accS.z), s3 = row_sum16(accS.w);
+  if (p == 0) { red[DE * 16 + 4 * q] = s0; red[DE * 16 + 4 * q + 1] = s1; red[DE * 16 + 4 * q + 2] = s2; red[DE * 16 + 4 * q + 3] = s3; }
+  __syncthreads();
+  float* part = a.ws + (size_t)blockIdx.x * PSZ;
+  for (int i = threadIdx.x; i < PSZ; i += 64 * EDGE_WAVES) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < EDGE_WAVES; ++w) v += smem[w * PSZ + i];
+    part[i] = v;
   }
 }
 
@@ -302,63 +312,88 @@ __global__ void __launch_bounds__(256) k_edge_update_fwd(EdgeArgs a) {
 
 // ---------------------------------------------------------- update backward ---
 // partial layout per workgroup: dWr[8][DE] then dbr[DE]
+//   d_h_hat[h][row] = sum_c Wr[h][c] de'[row][c]             (A = Wr rows, B = de' fragments in place)
+//   dWr[h][c]      += sum_row h_hat[row][h] de'[row][c]      (A = h_hat straight from global, rows on
+//                                                            the contraction axis; B = de' through LDS)
 template <int DE>
-__global__ void __launch_bounds__(256) k_edge_update_bwd(EdgeArgs a) {
+__global__ void __launch_bounds__(64 * EDGE_WAVES) k_edge_update_bwd(EdgeArgs a) {
+  constexpr int T = EdgeGeo<DE>::T, LD = EdgeGeo<DE>::LD, PSZ = EDGE_H * DE + DE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* tile = smem;                          // d_e_out [256][DE+1]
-  float* ht = smem + TILE_ROWS * (DE + 1);     // h_hat   [256][9]
-  const int c = threadIdx.x & 63, hq = threadIdx.x >> 6;
-  float accW0 = 0.f, accW1 = 0.f, accB = 0.f;
-  const long ntiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
-  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const long row0 = t * TILE_ROWS;
-    __syncthreads();
-    load_tile<DE>(tile, a.de_out, row0, a.rows);
-    const long row = row0 + threadIdx.x;
-    {
-      float* hr = ht + threadIdx.x * 9;
-      if (row < a.rows) {
-        const float4* hp = reinterpret_cast<const float4*>(a.h_hat + (size_t)row * EDGE_H);
-        const float4 u = hp[0], v = hp[1];
-        hr[0] = u.x; hr[1] = u.y; hr[2] = u.z; hr[3] = u.w;
-        hr[4] = v.x; hr[5] = v.y; hr[6] = v.z; hr[7] = v.w;
-      } else {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+  float* xs = smem + wave * (16 * LD);
+  float wR[T][4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) hr[j] = 0.f;
-      }
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * t + 4 * q + r;
+      wR[t][r] = (p < EDGE_H && c < DE) ? a.Wr[p * DE + c] : 0.f;
     }
-    __syncthreads();
-    // d_h_hat[row][h] = sum_c de'[row][c] * Wr[h][c]
-    float dh[EDGE_H];
+  v4f accW[T];
+  float4 accB[T];
 #pragma unroll
-    for (int h = 0; h < EDGE_H; ++h) dh[h] = 0.f;
-    const float* tr = tile + threadIdx.x * (DE + 1);
+  for (int t = 0; t < T; ++t) { accW[t] = (v4f){0.f, 0.f, 0.f, 0.f}; accB[t] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  const long ntiles = (a.rows + 15) / 16;
+  for (long tile = (long)blockIdx.x * EDGE_WAVES + wave; tile < ntiles; tile += (long)gridDim.x * EDGE_WAVES) {
+    const long row0 = tile * 16, row = row0 + p;
+    const bool valid = row < a.rows;
+    float4 df[T];
+    frag_gload<DE>(df, a.de_out, valid ? row : a.rows - 1, q);
+    float hA[4];   // A[h = p][row = 4s + q]
 #pragma unroll
-    for (int k = 0; k < DE; ++k) {
-      const float v = tr[k];
-#pragma unroll
-      for (int h = 0; h < EDGE_H; ++h) dh[h] = fmaf(v, a.Wr[h * DE + k], dh[h]);
+    for (int s = 0; s < 4; ++s) {
+      const long rr = row0 + 4 * s + q;
+      const bool ok = p < EDGE_H && rr < a.rows;
+      const float v = a.h_hat[(size_t)(rr < a.rows ? rr : a.rows - 1) * EDGE_H + (p & 7)];
+      hA[s] = ok ? v : 0.f;
     }
-    if (row < a.rows) {
-      float4* o = reinterpret_cast<float4*>(a.d_h_hat + (size_t)row * EDGE_H);
-      o[0] = make_float4(dh[0], dh[1], dh[2], dh[3]);
-      o[1] = make_float4(dh[4], dh[5], dh[6], dh[7]);
+    if (!valid) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) df[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // dWr[h][c] += sum_r h_hat[r][h] * de'[r][c]
-    if (c < DE) {
-      for (int r = 0; r < TILE_ROWS; ++r) {
-        const float dv = tile[r * (DE + 1) + c];
-        accW0 = fmaf(ht[r * 9 + 2 * hq], dv, accW0);
-        accW1 = fmaf(ht[r * 9 + 2 * hq + 1], dv, accW1);
-        if (hq == 0) accB += dv;
-      }
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      acc = MFMA(wR[t][0], df[t].x, acc);
+      acc = MFMA(wR[t][1], df[t].y, acc);
+      acc = MFMA(wR[t][2], df[t].z, acc);
+      acc = MFMA(wR[t][3], df[t].w, acc);
+    }
+    if (valid && q < 2)
+      *reinterpret_cast<float4*>(a.d_h_hat + (size_t)row * EDGE_H + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+    for (int t = 0; t < T; ++t) *reinterpret_cast<float4*>(xs + p * LD + 16 * t + 4 * q) = df[t];
+    lds_sync();
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        accW[t] = MFMA(hA[s], xs[(4 * s + q) * LD + 16 * t + p], accW[t]);   // B[row = 4s + q][c = 16t + p]
+      accB[t].x += df[t].x; accB[t].y += df[t].y; accB[t].z += df[t].z; accB[t].w += df[t].w;
+    }
+    lds_sync();
+  }
+  // accW[t][r] = dWr[h = 4q + r][c = 16t + p] (q < 2); dbr[16t + 4q + r] = sum over the 16 lanes p
+  __syncthreads();
+  float* red = smem + wave * PSZ;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (q < 2 && 16 * t + p < DE)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(4 * q + r) * DE + 16 * t + p] = accW[t][r];
+    const float b0 = row_sum16(accB[t].x), b1 = row_sum16(accB[t].y), b2 = row_sum16(accB[t].z), b3 = row_sum16(accB[t].w);
+    if (p == 0 && 16 * t + 4 * q < DE) {
+      float* o = red + EDGE_H * DE + 16 * t + 4 * q;
+      o[0] = b0; o[1] = b1; o[2] = b2; o[3] = b3;
     }
   }
-  float* part = a.ws + (size_t)blockIdx.x * (EDGE_H * DE + DE);
-  if (c < DE) {
-    part[(2 * hq) * DE + c] = accW0;
-    part[(2 * hq + 1) * DE + c] = accW1;
-    if (hq == 0) part[EDGE_H * DE + c] = accB;
+  __syncthreads();
+  float* part = a.ws + (size_t)blockIdx.x * PSZ;
+  for (int i = threadIdx.x; i < PSZ; i += 64 * EDGE_WAVES) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < EDGE_WAVES; ++w) v += smem[w * PSZ + i];
+    part[i] = v;
   }
 }
 
@@ -372,16 +407,31 @@ __global__ void __launch_bounds__(256) k_edge_update_bwd_final(EdgeArgs a) {
   }
 }
 
-// out[i] = sum_p part[p][i]: 64 outputs per workgroup, the partial axis split over 4 wavefronts
+// out[i] = sum_p part[p][i]: 16 outputs per workgroup (64-byte runs), the partial axis split over
+// 16 thread groups with four independent accumulators each; fixed order -> bit-reproducible
 __global__ void __launch_bounds__(256) k_edge_reduce_partials(const float* part, int n, int np, float* out) {
-  __shared__ float red[4][64];
-  const int o = blockIdx.x * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
-  float v = 0.f;
-  if (o < n)
-    for (int pi = pg; pi < np; pi += 4) v += part[(size_t)pi * n + o];
-  red[pg][threadIdx.x & 63] = v;
+  __shared__ float red[16][17];
+  const int oi = threadIdx.x & 15, pg = threadIdx.x >> 4;
+  const int o = blockIdx.x * 16 + oi;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  if (o < n) {
+    int pi = pg;
+    for (; pi + 48 < np; pi += 64) {
+      v0 += part[(size_t)pi * n + o];
+      v1 += part[(size_t)(pi + 16) * n + o];
+      v2 += part[(size_t)(pi + 32) * n + o];
+      v3 += part[(size_t)(pi + 48) * n + o];
+    }
+    for (; pi < np; pi += 16) v0 += part[(size_t)pi * n + o];
+  }
+  red[pg][oi] = (v0 + v1) + (v2 + v3);
   __syncthreads();
-  if (pg == 0 && o < n) out[o] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (pg == 0 && o < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += red[g][oi];
+    out[o] = s;
+  }
 }
 
 // ------------------------------------------------------------------ host glue --
@@ -399,9 +449,15 @@ static int check_edge(const egt_edge_desc* d) {
   return EGT_OK;
 }
 
-static int edge_grid(const egt_edge_desc* d, int cap) {
-  long ntiles = (d->rows + TILE_ROWS - 1) / TILE_ROWS;
-  return (int)(ntiles < cap ? ntiles : cap);
+// workgroups for a kernel whose workgroup walks `waves` 16-row tiles at a time
+static int edge_grid(const egt_edge_desc* d, int waves, int cap) {
+  const long ntiles = (d->rows + 15) / 16;
+  const long wgs = (ntiles + waves - 1) / waves;
+  return (int)(wgs < cap ? wgs : cap);
+}
+template <int DE> static size_t edge_bwd_lds(int tile_floats, int psz) {
+  const size_t tiles = (size_t)EDGE_WAVES * tile_floats, red = (size_t)EDGE_WAVES * psz;
+  return (tiles > red ? tiles : red) * sizeof(float);
 }
 
 #define DISPATCH_DE(De, CALL)                 \
@@ -432,11 +488,9 @@ extern "C" int egt_edge_proj_fwd(const egt_edge_desc* desc, const void* e, const
   a.e = (const float*)e; a.gamma = (const float*)ln_gamma; a.beta = (const float*)ln_beta;
   a.Wg = (const float*)Wg; a.bg = (const float*)bg; a.We = (const float*)We; a.be = (const float*)be;
   a.G_out = (float*)G_out; a.E_o = (float*)E_out;
-  const int grid = edge_grid(desc, 4096);
+  const int grid = edge_grid(desc, 4, 4096);
   DISPATCH_DE(desc->De, {
-    const size_t lds = (size_t)TILE_ROWS * (DE + 1) * 4;
-    (void)hipFuncSetAttribute((const void*)k_edge_proj_fwd<DE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    EGT_LAUNCH("k_edge_proj_fwd", k_edge_proj_fwd<DE>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    EGT_LAUNCH("k_edge_proj_fwd", k_edge_proj_fwd<DE>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   });
   EGT_HIP_LAUNCH_CHECK("egt_edge_proj_fwd");
   return EGT_OK;
@@ -447,11 +501,11 @@ extern "C" size_t egt_edge_proj_bwd_workspace_bytes(const egt_edge_desc* d) {
   return (size_t)(EDGE_MAX_PARTIALS + 1) * (d->De * 16 + 16) * sizeof(float);
 }
 
-extern "C" int egt_edge_proj_bwd(const egt_edge_desc* desc, const void* e, const void* ln_gamma,
-                                 const void* ln_beta, const void* Wg, const void* We,
-                                 const void* E_out, const void* d_G, const void* d_E, void* d_e,
-                                 void* d_ln_gamma, void* d_ln_beta, void* d_Wg, void* d_bg,
-                                 void* d_We, void* d_be, void* workspace, void* stream) {
+static int edge_proj_bwd_impl(const egt_edge_desc* desc, const void* e, const void* ln_gamma,
+                              const void* ln_beta, const void* Wg, const void* We,
+                              const void* E_out, const void* d_G, const void* d_E, const void* d_e_base,
+                              void* d_e, void* d_ln_gamma, void* d_ln_beta, void* d_Wg, void* d_bg,
+                              void* d_We, void* d_be, void* workspace, void* stream) {
   int rc = check_edge(desc);
   if (rc) return rc;
   if (!e || !We || !d_E || !d_e || !d_We || !d_be || !workspace)
@@ -463,24 +517,43 @@ extern "C" int egt_edge_proj_bwd(const egt_edge_desc* desc, const void* e, const
   EdgeArgs a; fill_edge(desc, a);
   a.e = (const float*)e; a.gamma = (const float*)ln_gamma; a.beta = (const float*)ln_beta;
   a.Wg = (const float*)Wg; a.We = (const float*)We; a.E_out = (const float*)E_out;
-  a.dG = (const float*)d_G; a.dE = (const float*)d_E; a.d_e = (float*)d_e;
+  a.dG = (const float*)d_G; a.dE = (const float*)d_E; a.d_e = (float*)d_e; a.de_out = (const float*)d_e_base;
   a.d_gamma = (float*)d_ln_gamma; a.d_beta = (float*)d_ln_beta; a.d_Wg = (float*)d_Wg;
   a.d_bg = (float*)d_bg; a.d_We = (float*)d_We; a.d_be = (float*)d_be; a.ws = (float*)workspace;
-  const int grid = edge_grid(desc, EDGE_MAX_PARTIALS);
+  const int grid = edge_grid(desc, EDGE_WAVES, EDGE_MAX_PARTIALS);
   a.n_partials = grid;
   DISPATCH_DE(desc->De, {
-    const size_t lds = (size_t)TILE_ROWS * (DE + 1 + 17) * 4;
-    (void)hipFuncSetAttribute((const void*)k_edge_proj_bwd<DE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    EGT_LAUNCH("k_edge_proj_bwd", k_edge_proj_bwd<DE>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
     constexpr int PSZ = DE * 16 + 16;
+    const size_t lds = edge_bwd_lds<DE>(16 * EdgeGeo<DE>::LD + 256, PSZ);
+    (void)hipFuncSetAttribute((const void*)k_edge_proj_bwd<DE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_LAUNCH("k_edge_proj_bwd", k_edge_proj_bwd<DE>, dim3(grid), dim3(64 * EDGE_WAVES), lds, (hipStream_t)stream, a);
     float* red = a.ws + (size_t)EDGE_MAX_PARTIALS * PSZ;
-    EGT_LAUNCH("k_edge_reduce_partials", k_edge_reduce_partials, dim3((PSZ + 63) / 64), dim3(256), 0,
+    EGT_LAUNCH("k_edge_reduce_partials", k_edge_reduce_partials, dim3((PSZ + 15) / 16), dim3(256), 0,
                (hipStream_t)stream, (const float*)a.ws, PSZ, grid, red);
     a.ws = red; a.n_partials = 1;
     EGT_LAUNCH("k_edge_proj_bwd_final", k_edge_proj_bwd_final<DE>, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   });
   EGT_HIP_LAUNCH_CHECK("egt_edge_proj_bwd");
   return EGT_OK;
+}
+
+extern "C" int egt_edge_proj_bwd(const egt_edge_desc* desc, const void* e, const void* ln_gamma,
+                                 const void* ln_beta, const void* Wg, const void* We,
+                                 const void* E_out, const void* d_G, const void* d_E, void* d_e,
+                                 void* d_ln_gamma, void* d_ln_beta, void* d_Wg, void* d_bg,
+                                 void* d_We, void* d_be, void* workspace, void* stream) {
+  return edge_proj_bwd_impl(desc, e, ln_gamma, ln_beta, Wg, We, E_out, d_G, d_E, nullptr, d_e, d_ln_gamma,
+                            d_ln_beta, d_Wg, d_bg, d_We, d_be, workspace, stream);
+}
+
+extern "C" int egt_edge_proj_bwd_acc(const egt_edge_desc* desc, const void* e, const void* ln_gamma,
+                                     const void* ln_beta, const void* Wg, const void* We,
+                                     const void* E_out, const void* d_G, const void* d_E,
+                                     const void* d_e_base, void* d_e, void* d_ln_gamma, void* d_ln_beta,
+                                     void* d_Wg, void* d_bg, void* d_We, void* d_be, void* workspace,
+                                     void* stream) {
+  return edge_proj_bwd_impl(desc, e, ln_gamma, ln_beta, Wg, We, E_out, d_G, d_E, d_e_base, d_e, d_ln_gamma,
+                            d_ln_beta, d_Wg, d_bg, d_We, d_be, workspace, stream);
 }
 
 extern "C" int egt_edge_update_fwd(const egt_edge_desc* desc, const void* e, const void* h_hat,
@@ -516,15 +589,15 @@ extern "C" int egt_edge_update_bwd(const egt_edge_desc* desc, const void* d_e_ou
   EdgeArgs a; fill_edge(desc, a);
   a.de_out = (const float*)d_e_out; a.h_hat = (const float*)h_hat; a.Wr = (const float*)Wr;
   a.d_h_hat = (float*)d_h_hat; a.d_Wr = (float*)d_Wr; a.d_br = (float*)d_br; a.ws = (float*)workspace;
-  const int grid = edge_grid(desc, EDGE_MAX_PARTIALS);
+  const int grid = edge_grid(desc, EDGE_WAVES, EDGE_MAX_PARTIALS);
   a.n_partials = grid;
   DISPATCH_DE(desc->De, {
-    const size_t lds = (size_t)TILE_ROWS * (DE + 1 + 9) * 4;
-    (void)hipFuncSetAttribute((const void*)k_edge_update_bwd<DE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    EGT_LAUNCH("k_edge_update_bwd", k_edge_update_bwd<DE>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
     constexpr int PSZ = EDGE_H * DE + DE;
+    const size_t lds = edge_bwd_lds<DE>(16 * EdgeGeo<DE>::LD, PSZ);
+    (void)hipFuncSetAttribute((const void*)k_edge_update_bwd<DE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_LAUNCH("k_edge_update_bwd", k_edge_update_bwd<DE>, dim3(grid), dim3(64 * EDGE_WAVES), lds, (hipStream_t)stream, a);
     float* red = a.ws + (size_t)EDGE_MAX_PARTIALS * PSZ;
-    EGT_LAUNCH("k_edge_reduce_partials", k_edge_reduce_partials, dim3((PSZ + 63) / 64), dim3(256), 0,
+    EGT_LAUNCH("k_edge_reduce_partials", k_edge_reduce_partials, dim3((PSZ + 15) / 16), dim3(256), 0,
                (hipStream_t)stream, (const float*)a.ws, PSZ, grid, red);
     a.ws = red; a.n_partials = 1;
     EGT_LAUNCH("k_edge_update_bwd_final", k_edge_update_bwd_final<DE>, dim3(1), dim3(256), 0, (hipStream_t)stream, a);

@@ -188,9 +188,10 @@ def _edge_desc(e, use_ln, gates, act, alpha, eps) -> L.EdgeDesc:
 
 class _EdgeProj(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, e, gamma, beta, Wg, bg, We, be, use_ln, edge_activation, eps):
+    def forward(ctx, e, gamma, beta, Wg, bg, We, be, use_ln, edge_activation, eps, passthrough):
         _need_gpu(e)
         lib = L.load()
+        e_in = e
         e = _f32c(e)
         gates = Wg is not None
         act, alpha = _act_code(edge_activation)
@@ -212,10 +213,17 @@ class _EdgeProj(torch.autograd.Function):
         if G is None:
             G = torch.empty(0, device=e.device)
             ctx.mark_non_differentiable(G)
-        return G, E
+        if passthrough:
+            # e handed on to the residual update: its gradient comes back into THIS backward and is
+            # folded into d_e by the kernel (egt_edge_proj_bwd_acc) instead of a separate e-sized add
+            thru = e_in.view_as(e_in)
+        else:
+            thru = torch.empty(0, device=e.device)
+            ctx.mark_non_differentiable(thru)
+        return G, E, thru
 
     @staticmethod
-    def backward(ctx, dG, dE):
+    def backward(ctx, dG, dE, d_thru):
         lib = L.load()
         e, gamma, beta, Wg, We, E_out = ctx.saved_tensors
         desc = ctx.desc
@@ -234,18 +242,24 @@ class _EdgeProj(torch.autograd.Function):
         d_We, d_be = mk(De, 8), mk(8)
         ws = torch.empty(lib.egt_edge_proj_bwd_workspace_bytes(C.byref(desc)), device=e.device,
                          dtype=torch.uint8)
-        L.check(lib.egt_edge_proj_bwd(C.byref(desc), L.ptr(e), L.ptr(gamma), L.ptr(beta), L.ptr(Wg),
-                                      L.ptr(We), L.ptr(E_out), L.ptr(dG), L.ptr(dE), L.ptr(d_e),
-                                      L.ptr(d_gamma), L.ptr(d_beta), L.ptr(d_Wg), L.ptr(d_bg),
-                                      L.ptr(d_We), L.ptr(d_be), L.ptr(ws), L.current_stream()))
-        return d_e, d_gamma, d_beta, d_Wg, d_bg, d_We, d_be, None, None, None
+        base = _f32c(d_thru) if d_thru is not None else None
+        L.check(lib.egt_edge_proj_bwd_acc(C.byref(desc), L.ptr(e), L.ptr(gamma), L.ptr(beta), L.ptr(Wg),
+                                          L.ptr(We), L.ptr(E_out), L.ptr(dG), L.ptr(dE), L.ptr(base), L.ptr(d_e),
+                                          L.ptr(d_gamma), L.ptr(d_beta), L.ptr(d_Wg), L.ptr(d_bg),
+                                          L.ptr(d_We), L.ptr(d_be), L.ptr(ws), L.current_stream()))
+        return d_e, d_gamma, d_beta, d_Wg, d_bg, d_We, d_be, None, None, None, None
 
 
-def edge_proj(e, gamma, beta, Wg, bg, We, be, *, use_ln=True, edge_activation=None, eps=1e-3):
+def edge_proj(e, gamma, beta, Wg, bg, We, be, *, use_ln=True, edge_activation=None, eps=1e-3,
+              passthrough=False):
     """(G, E): [norm_edge] -> attention_gates, dense_edge_b
-    (graph_xformer_model_base.py:195,201-204,149-162).  Wg/bg None => no gates."""
-    G, E = _EdgeProj.apply(e, gamma, beta, Wg, bg, We, be, use_ln, edge_activation, eps)
-    return (G if Wg is not None else None), E
+    (graph_xformer_model_base.py:195,201-204,149-162).  Wg/bg None => no gates.
+    passthrough=True returns (G, E, e_thru): e_thru is `e` itself, to be used by the residual
+    update that follows (:218) so that the two gradient branches of e are summed inside the
+    projection-backward kernel rather than by a separate elementwise add over [B,N,N,De]."""
+    G, E, thru = _EdgeProj.apply(e, gamma, beta, Wg, bg, We, be, use_ln, edge_activation, eps, passthrough)
+    G = G if Wg is not None else None
+    return (G, E, thru) if passthrough else (G, E)
 
 
 class _EdgeUpdate(torch.autograd.Function):

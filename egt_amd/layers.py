@@ -225,11 +225,12 @@ class EGTBlock(nn.Module):
         use_ln = ect in ('residual', 'constrained') and not self.add_n_norm
         ne = getattr(self, 'norm_edge', None)
         ag = getattr(self, 'attention_gates', None)
-        gates, e_b = EF.edge_proj(
+        gates, e_b, e = EF.edge_proj(
             e, ne.gamma if use_ln else None, ne.beta if use_ln else None,
             ag.kernel if ag is not None else None, ag.bias if ag is not None else None,
             self.dense_edge_b.kernel, self.dense_edge_b.bias,
-            use_ln=use_ln, edge_activation=self.edge_activation, eps=LN_EPS)   # :195-208
+            use_ln=use_ln, edge_activation=self.edge_activation, eps=LN_EPS,
+            passthrough=True)                                                  # :195-208
         h, h_hat = self._mha_block(h, e_b, gates, mask, attn_mask, rand_mask)  # :212
         if ect == 'bias':
             return h, e                                             # :190 (returns e0)

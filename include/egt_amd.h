@@ -175,6 +175,16 @@ int egt_edge_proj_bwd(const egt_edge_desc* desc, const void* e,
                       const void* d_E, void* d_e, void* d_ln_gamma,
                       void* d_ln_beta, void* d_Wg, void* d_bg, void* d_We,
                       void* d_be, void* workspace, void* stream);
+/* Same, with d_e = d_e_base + (projection backward): d_e_base [rows,De] is the gradient e already
+ * carries from the residual branch e' = e + ... (graph_xformer_model_base.py:218), so the sum the
+ * autodiff of the reference forms with a separate add costs no extra pass.  d_e_base may be NULL
+ * (then identical to egt_edge_proj_bwd) and may alias d_e. */
+int egt_edge_proj_bwd_acc(const egt_edge_desc* desc, const void* e,
+                          const void* ln_gamma, const void* ln_beta, const void* Wg,
+                          const void* We, const void* E_out, const void* d_G,
+                          const void* d_E, const void* d_e_base, void* d_e,
+                          void* d_ln_gamma, void* d_ln_beta, void* d_Wg, void* d_bg,
+                          void* d_We, void* d_be, void* workspace, void* stream);
 
 /* e' = e + H_hat·Wr + br   (dense_edge_r + res_edge,
  * graph_xformer_model_base.py:214-218).  Wr [H,De], br [De]. */

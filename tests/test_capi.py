@@ -17,7 +17,7 @@ def declared_symbols():
 
 def test_header_declares_expected_entry_points():
     syms = declared_symbols()
-    for s in ("egt_attn_fwd", "egt_attn_bwd", "egt_edge_proj_fwd", "egt_edge_proj_bwd",
+    for s in ("egt_attn_fwd", "egt_attn_bwd", "egt_edge_proj_fwd", "egt_edge_proj_bwd", "egt_edge_proj_bwd_acc",
               "egt_edge_update_fwd", "egt_edge_update_bwd", "egt_block_fwd", "egt_block_bwd",
               "egt_last_error_string"):
         assert s in syms

@@ -56,6 +56,31 @@ def test_edge_proj(De, rows_shape, use_ln, gates, act, gpu, egt_lib):
         assert_close(a, b, name=n, **BWD)
 
 
+@pytest.mark.parametrize("De,rows_shape", [(32, (2, 13, 13)), (64, (1, 21, 21)), (8, (1, 10, 10))])
+def test_edge_proj_passthrough_accumulates(De, rows_shape, gpu, egt_lib):
+    """edge_proj(passthrough=True): the gradient arriving on the handed-on e is summed into d_e by
+    the kernel (egt_edge_proj_bwd_acc) -- same result as autograd's separate add."""
+    from egt_amd import edge_proj
+    g = torch.Generator().manual_seed(De + 5)
+    r = lambda *s: torch.randn(*s, generator=g)
+    e = r(*rows_shape, De)
+    gamma, beta = 1 + 0.2 * r(De), 0.2 * r(De)
+    Wg, bg, We, be = 0.3 * r(De, 8), 0.1 * r(8), 0.3 * r(De, 8), 0.1 * r(8)
+    dG, dE, dres = r(*rows_shape, 8), r(*rows_shape, 8), r(*rows_shape, De)
+    t64 = [x.double().requires_grad_() for x in (e, gamma, beta, Wg, bg, We, be)]
+    en = O.layer_norm(t64[0], t64[1], t64[2])
+    loss = (O.dense(en, t64[3], t64[4]) * dG.double()).sum() + (O.dense(en, t64[5], t64[6]) * dE.double()).sum() \
+        + (t64[0] * dres.double()).sum()
+    gref = torch.autograd.grad(loss, t64)
+    t = [x.to(gpu).requires_grad_() for x in (e, gamma, beta, Wg, bg, We, be)]
+    G, E, thru = edge_proj(*t, use_ln=True, passthrough=True)
+    assert thru.data_ptr() == t[0].data_ptr()
+    loss = (G * dG.to(gpu)).sum() + (E * dE.to(gpu)).sum() + (thru * dres.to(gpu)).sum()
+    grads = torch.autograd.grad(loss, t)
+    for n, a, b in zip(["de", "dgamma", "dbeta", "dWg", "dbg", "dWe", "dbe"], grads, gref):
+        assert_close(a, b, name=n, **BWD)
+
+
 @pytest.mark.parametrize("De,rows_shape", [(64, (2, 9, 9)), (64, (3, 37, 37)), (48, (2, 11, 11)),
                                            (32, (1, 8, 8)), (16, (1, 7, 7)), (8, (1, 20, 20))])
 def test_edge_update(De, rows_shape, gpu, egt_lib):
