@@ -72,57 +72,54 @@ __device__ __forceinline__ float pair_sum_q(float v) { return sum_xor32(sum_xor1
 // and leave head-major.  Channel index of the source: c = s*d*H + k*H + h (egt_layers.py:70-76).
 template <int D>
 __global__ void __launch_bounds__(256) k_attn_pack(AttnMfmaArgs a) {
-  constexpr int DH = D * AH, SRC = 4 * DH, LD = SRC + 4;   // [q | k | v | dO] per row
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+  // workgroup = (graph, 16 node rows, ONE section of [q | k | v | dO]): forward packs k and v only
+  constexpr int DH = D * AH, LD = DH + 4;
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [16][LD]
   const int N = a.N, NP = a.NP, tid = threadIdx.x;
   const int tiles = NP / 16;
-  const int b = blockIdx.x / tiles, n0 = (blockIdx.x % tiles) * 16;
   const bool bwd = a.pack_bwd != 0;
-  for (int i = tid; i < 16 * (SRC / 4); i += 256) {
-    const int r = i / (SRC / 4), c = (i % (SRC / 4)) * 4;
+  const int nsec = bwd ? 4 : 2;
+  const int sec = bwd ? (int)(blockIdx.x % nsec) : (int)(blockIdx.x % nsec) + 1;
+  const int tile = blockIdx.x / nsec;
+  const int b = tile / tiles, n0 = (tile % tiles) * 16;
+  for (int i = tid; i < 16 * (DH / 4); i += 256) {
+    const int r = i / (DH / 4), c = (i % (DH / 4)) * 4;
     const int n = n0 + r;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < N) {
-      if (c < 3 * DH) v = *reinterpret_cast<const float4*>(a.qkv + ((size_t)b * N + n) * 3 * DH + c);
-      else if (bwd) v = *reinterpret_cast<const float4*>(a.d_v_att + ((size_t)b * N + n) * DH + (c - 3 * DH));
-    }
+    if (n < N)
+      v = sec < 3 ? *reinterpret_cast<const float4*>(a.qkv + ((size_t)b * N + n) * 3 * DH + sec * DH + c)
+                  : *reinterpret_cast<const float4*>(a.d_v_att + ((size_t)b * N + n) * DH + c);
     *reinterpret_cast<float4*>(sm + r * LD + c) = v;
   }
   __syncthreads();
   const size_t arr = (size_t)a.B * AH * NP * D;
-  // section s of the source rows -> [b,h,n/16,k/16,16 nodes,16 channels] array `which`: a wave's
+  // the staged rows -> [b,h,n/16,k/16,16 nodes,16 channels] array `which`: a wave's
   // operand fetch (16 nodes x 16 channels of one k-tile) is ONE contiguous 1 KB block
-#define PUT_ROWS(s, which)                                                                       \
-  do {                                                                                           \
-    float* dst = a.pk + (size_t)(which) * arr;                                                   \
-    for (int i = tid; i < AH * 16 * (D / 4); i += 256) {                                         \
-      const int k4 = ((i >> 6) % (D / 16)) * 4 + (i & 3), r = (i >> 2) & 15, h = i / (4 * D);     \
-      const float* src = sm + r * LD + (s) * DH + (k4 * 4) * AH + h;                             \
-      *reinterpret_cast<float4*>(dst + ((size_t)b * AH + h) * NP * D + (size_t)n0 * D + (k4 >> 2) * 256 + r * 16 + (k4 & 3) * 4) = \
-          make_float4(src[0], src[AH], src[2 * AH], src[3 * AH]);                                \
-    }                                                                                            \
-  } while (0)
+  auto put_rows = [&](int which) {
+    float* dst = a.pk + (size_t)which * arr;
+    for (int i = tid; i < AH * 16 * (D / 4); i += 256) {
+      const int k4 = ((i >> 6) % (D / 16)) * 4 + (i & 3), r = (i >> 2) & 15, h = i / (4 * D);
+      const float* src = sm + r * LD + (k4 * 4) * AH + h;
+      *reinterpret_cast<float4*>(dst + ((size_t)b * AH + h) * NP * D + (size_t)n0 * D + (k4 >> 2) * 256 + r * 16 + (k4 & 3) * 4) =
+          make_float4(src[0], src[AH], src[2 * AH], src[3 * AH]);
+    }
+  };
   // ... -> transposed, tile-major [b,h,n/16,k,16] array: the 16 nodes of a tile are contiguous per
   // channel and a tile is one 64*D-byte block, so a wave's operand fetch uses whole cache lines
   // (with [b,h,k,n] rows a 16-node access touches half of each 128-byte line)
-#define PUT_COLS(s, which)                                                                       \
-  do {                                                                                           \
-    float* dst = a.pk + (size_t)(which) * arr;                                                   \
-    for (int i = tid; i < AH * D * 4; i += 256) {                                                \
-      const int r4 = i & 3, k = (i >> 2) % D, h = i / (4 * D);                                   \
-      const float* src = sm + (r4 * 4) * LD + (s) * DH + k * AH + h;                             \
-      *reinterpret_cast<float4*>(dst + ((size_t)b * AH + h) * D * NP + (size_t)n0 * D + k * 16 + r4 * 4) = \
-          make_float4(src[0], src[LD], src[2 * LD], src[3 * LD]);                                \
-    }                                                                                            \
-  } while (0)
-  PUT_ROWS(1, PK_KH);
-  PUT_COLS(2, PK_VT);
-  if (bwd) {
-    PUT_ROWS(0, PK_QH); PUT_COLS(0, PK_QT); PUT_COLS(1, PK_KT);
-    PUT_ROWS(2, PK_VH); PUT_ROWS(3, PK_OH); PUT_COLS(3, PK_OT);
-  }
-#undef PUT_ROWS
-#undef PUT_COLS
+  auto put_cols = [&](int which) {
+    float* dst = a.pk + (size_t)which * arr;
+    for (int i = tid; i < AH * D * 4; i += 256) {
+      const int r4 = i & 3, k = (i >> 2) % D, h = i / (4 * D);
+      const float* src = sm + (r4 * 4) * LD + k * AH + h;
+      *reinterpret_cast<float4*>(dst + ((size_t)b * AH + h) * D * NP + (size_t)n0 * D + k * 16 + r4 * 4) =
+          make_float4(src[0], src[LD], src[2 * LD], src[3 * LD]);
+    }
+  };
+  if (sec == 0) { put_rows(PK_QH); put_cols(PK_QT); }
+  else if (sec == 1) { put_rows(PK_KH); if (bwd) put_cols(PK_KT); }
+  else if (sec == 2) { put_cols(PK_VT); if (bwd) put_rows(PK_VH); }
+  else { put_rows(PK_OH); put_cols(PK_OT); }
 }
 
 // Feature set of a kernel instance.  V = 0 reads every switch at run time (any combination);
@@ -727,9 +724,9 @@ static int fill(const egt_attn_desc* desc, const void* qkv, const void* E, const
 
 template <int D>
 static void launch_pack(const AttnMfmaArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)16 * (4 * D * AH + 4) * 4;
+  const size_t lds = (size_t)16 * (D * AH + 4) * 4;
   (void)hipFuncSetAttribute((const void*)k_attn_pack<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  EGT_LAUNCH("k_attn_pack", k_attn_pack<D>, dim3(a.B * (a.NP / 16)), dim3(256), lds, st, a);
+  EGT_LAUNCH("k_attn_pack", k_attn_pack<D>, dim3(a.B * (a.NP / 16) * (a.pack_bwd ? 4 : 2)), dim3(256), lds, st, a);
 }
 
 // 1 / 2: the straight-line instances (see Feat), 0: the run-time-switched one
