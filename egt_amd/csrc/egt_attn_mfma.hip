@@ -506,6 +506,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
     // ---- loads, oldest first: transposed operands of THIS tile (consumed after the elementwise
     //      phase), then the row operands / statistics / pair tiles of the NEXT tile ----
     float4 qt[KT], ot[KT];
+    if (ABL_ON(a, 1))
 #pragma unroll
     for (int T = 0; T < KT; ++T) {
       qt[T] = *reinterpret_cast<const float4*>(QT + (size_t)l0 * D + (16 * T + mm) * 16 + 4 * q);  // A rows are channels
@@ -519,7 +520,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
     size_t gi[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) gi[r] = (((size_t)b * N + min(l0 + 4 * q + r, N - 1)) * N + mc) * AH + h;
-    if (more) {
+    if (more && ABL_ON(a, 1)) {
 #pragma unroll
       for (int T = 0; T < KT; ++T) {
         qan[T] = *reinterpret_cast<const float4*>(Qh + (size_t)(l0 + 16) * D + 256 * T + mm * 16 + 4 * q);   // A rows are query rows
@@ -528,6 +529,8 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         stn[r] = *reinterpret_cast<const float4*>(a.rowstats + (((size_t)b * N + min(l0 + 16 + 4 * q + r, N - 1)) * AH + h) * 4);
+    }
+    if (more && ABL_ON(a, 4)) {
       if (f.E) pe4 = ptile_gload(a.E, b, N, l0 + 16, m0, tid);
       if (f.G) pg4 = ptile_gload(a.G, b, N, l0 + 16, m0, tid);
       if (f.M) pm4 = ptile_gload(a.M, b, N, l0 + 16, m0, tid);
@@ -542,6 +545,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
     float* dAt = dGt + PT_SZ;
     // ---- S[l][m] = sum_k Q[l][k] K[m][k] ; dP[l][m] = sum_k dO[l][k] V[m][k] ----
     v4f s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+    if (ABL_ON(a, 8))
 #pragma unroll
     for (int T = 0; T < KT; ++T) {
       s = MFMA(qa[T].x, Kr[T].x, s);   dp = MFMA(oa[T].x, Vr[T].x, dp);
@@ -575,6 +579,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
       dAt[po] = da[r];
     }
     // ---- dV^T[k][m] += sum_l dO[l][k] A[l][m] ; dK^T[k][m] += sum_l Q[l][k] dA[l][m] ----
+    if (ABL_ON(a, 8))
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
       v4f dv = dVacc[kt], dk = dKacc[kt];
@@ -591,10 +596,12 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
       if (f.M) ptile_lds_put(nx + 2 * PT_SZ, pm4, N, l0 + 16, m0, tid);
       if (f.X) ptile_lds_put(nx + 3 * PT_SZ, px4, N, l0 + 16, m0, tid);
     }
-    __syncthreads();
+    if (ABL_ON(a, 16)) __syncthreads();
+    if (ABL_ON(a, 2)) {
     if (f.E) ptile_gstore(a.d_E, dEt, b, N, l0, m0, tid);
     if (f.G) ptile_gstore(a.d_G, dGt, b, N, l0, m0, tid);
     ptile_gstore(a.ws_dA, dAt, b, N, l0, m0, tid);
+    }
   }
   if (mvalid) {
     float* o = a.d_qkv + ((size_t)b * N + m) * 3 * DH + h;
