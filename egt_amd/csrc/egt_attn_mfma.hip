@@ -116,10 +116,11 @@ __global__ void __launch_bounds__(256) k_attn_pack(AttnMfmaArgs a) {
           make_float4(src[0], src[LD], src[2 * LD], src[3 * LD]);
     }
   };
-  if (sec == 0) { put_rows(PK_QH); put_cols(PK_QT); }
+  // forward: K rows + V^T; backward: Q, K, V, dO rows + K^T (bwd_kv transposes Q / dO in registers)
+  if (sec == 0) put_rows(PK_QH);
   else if (sec == 1) { put_rows(PK_KH); if (bwd) put_cols(PK_KT); }
-  else if (sec == 2) { put_cols(PK_VT); if (bwd) put_rows(PK_VH); }
-  else { put_rows(PK_OH); put_cols(PK_OT); }
+  else if (sec == 2) { if (bwd) put_rows(PK_VH); else put_cols(PK_VT); }
+  else put_rows(PK_OH);
 }
 
 // Feature set of a kernel instance.  V = 0 reads every switch at run time (any combination);
@@ -466,8 +467,9 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
   const float* Vh = a.pk + PK_VH * arr + hb;
   const float* Qh = a.pk + PK_QH * arr + hb;
   const float* Oh = a.pk + PK_OH * arr + hb;
-  const float* QT = a.pk + PK_QT * arr + hb;
-  const float* OT = a.pk + PK_OT * arr + hb;
+  float id4[4];   // identity slices for the in-register transposes
+#pragma unroll
+  for (int u = 0; u < 4; ++u) id4[u] = (mm == 4 * q + u) ? 1.0f : 0.0f;
 
   // K / V fragments of this lane's key (B operands of S = Q.K^T and dP = dO.V^T); padded keys are zero
   float4 Kr[KT], Vr[KT];
@@ -505,16 +507,25 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
     const bool more = l0 + 16 < NP;
     // ---- loads, oldest first: transposed operands of THIS tile (consumed after the elementwise
     //      phase), then the row operands / statistics / pair tiles of the NEXT tile ----
-    float4 qt[KT], ot[KT];
-    if (ABL_ON(a, 1))
-#pragma unroll
-    for (int T = 0; T < KT; ++T) {
-      qt[T] = *reinterpret_cast<const float4*>(QT + (size_t)l0 * D + (16 * T + mm) * 16 + 4 * q);  // A rows are channels
-      ot[T] = *reinterpret_cast<const float4*>(OT + (size_t)l0 * D + (16 * T + mm) * 16 + 4 * q);
-    }
     float4 qa[KT], oa[KT], st[4];
 #pragma unroll
     for (int T = 0; T < KT; ++T) { qa[T] = qan[T]; oa[T] = oan[T]; }
+    // The transposed operands (A rows are channels: Q^T, dO^T of this tile) come from the row
+    // operands through the matrix core itself: D = X . I with the identity split over the four
+    // contraction steps (step u, B[k = q][j] = [j == 4q + u]) leaves lane (mm, q) with
+    // X[l0 + 4q + r][16T + mm] -- exact (one non-zero product per output), 32 extra MFMAs on a
+    // pipe that is 30 % busy instead of a second 8 KB operand fetch per wave and tile.
+    float4 qt[KT], ot[KT];
+#pragma unroll
+    for (int T = 0; T < KT; ++T) {
+      v4f tq = {0.f, 0.f, 0.f, 0.f}, to = {0.f, 0.f, 0.f, 0.f};
+      tq = MFMA(qa[T].x, id4[0], tq);   to = MFMA(oa[T].x, id4[0], to);
+      tq = MFMA(qa[T].y, id4[1], tq);   to = MFMA(oa[T].y, id4[1], to);
+      tq = MFMA(qa[T].z, id4[2], tq);   to = MFMA(oa[T].z, id4[2], to);
+      tq = MFMA(qa[T].w, id4[3], tq);   to = MFMA(oa[T].w, id4[3], to);
+      qt[T] = make_float4(tq[0], tq[1], tq[2], tq[3]);
+      ot[T] = make_float4(to[0], to[1], to[2], to[3]);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) st[r] = stn[r];
     size_t gi[4];
