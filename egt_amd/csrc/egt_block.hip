@@ -118,7 +118,7 @@ __device__ __forceinline__ float reduce16_keep_own(const float (&v)[16], int p) 
 // compiled out of the headline kernel).
 // FULL: N is a multiple of 16 (no ragged key tile): validity selects and address clamps fold away.
 template <int DE, bool KVL, bool ML, bool FULL, bool BF>
-__global__ void __launch_bounds__(256, (DE <= 16 ? 4 : 2)) k_block_fwd(BlockArgs a) {   // narrow edge channels: small tiles, more resident waves
+__global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd(BlockArgs a) {   // narrow tiles without K/V in LDS: more resident waves (with K/V in LDS the LDS footprint caps a CU at two workgroups anyway)
   using G = Geo<DE>;
   typedef typename EdgeT<BF>::type ET;   // element type of the edge tensors in HBM
   const ET* e_in = reinterpret_cast<const ET*>(a.e);
@@ -179,16 +179,27 @@ __global__ void __launch_bounds__(256, (DE <= 16 ? 4 : 2)) k_block_fwd(BlockArgs
   for (int li = 0; li < 4; ++li) nrows += (lg * 16 + wave + 4 * li < N) ? 1 : 0;
   const int total = nrows * ntile;
 
-  TileRegs<DE> tr;
-  auto prefetch = [&](int it) {
+  // e tiles in flight per wave.  A De <= 16 tile is 0.5 - 1 KB, so narrow tiles travel PFD
+  // iterations ahead in a ring of register sets (more bytes in flight per CU).  The ring is indexed
+  // statically (loop unrolled by PFD); the iterations that pad the last group re-run the last tile
+  // with every global write predicated off, which keeps the body straight-line (exact waits).
+  constexpr int PFD = (DE <= 16 && KVL) ? 4 : 1;   // measured: +3.5 % at De = 8, N = 120; without K/V in LDS the extra registers spill
+  TileRegs<DE> ring[PFD];
+  auto prefetch = [&](TileRegs<DE>& tr, int it) {
+    if (PFD > 1) it = min(it, total - 1);
     const int l = lg * 16 + wave + 4 * (it / ntile), m0 = (it % ntile) * 16;
     const size_t pair0 = ((size_t)b * N + l) * N + m0;
     tile_gload<DE>(tr, e_in + pair0 * DE, lane, FULL ? 16 : min(16, N - m0));
   };
-  if (total > 0) prefetch(0);
+  if (total > 0) {
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) prefetch(ring[k], k);
+  }
 
   float Qf[16], mx[2], sum[2], O[16];
-  for (int it = 0; it < total; ++it) {
+  auto step = [&](const int it_, TileRegs<DE>& tr) __attribute__((always_inline)) {
+    const bool live = PFD == 1 || it_ < total;
+    const int it = PFD == 1 ? it_ : min(it_, total - 1);
     const int li = it / ntile, mt = it % ntile;
     const int l = lg * 16 + wave + 4 * li, m0 = mt * 16, m = m0 + p;
     const bool valid = FULL ? true : (m < N);
@@ -209,15 +220,16 @@ __global__ void __launch_bounds__(256, (DE <= 16 ? 4 : 2)) k_block_fwd(BlockArgs
     mask_gload<ML>(a, mr, pair0 + (valid ? p : 0), q);
     // Memory order per step: [stores of tile it-1] then [loads of tile it+1]; the wait in front
     // of the next LDS staging therefore never covers a store younger than the loads it needs.
-    float* tl = tl0 + (it & 1) * G::TILE_FLOATS;
+    float* tl = tl0 + (it_ & 1) * G::TILE_FLOATS;
     lds_sync();
-    if (it > 0) {   // stream out e' of the previous tile from the other buffer
+    if (it_ > 0 && live) {   // stream out e' of the previous tile from the other buffer
       const int itp = it - 1, lp = lg * 16 + wave + 4 * (itp / ntile), m0p = (itp % ntile) * 16;
       tile_from_lds<DE>(tl0 + (itp & 1) * G::TILE_FLOATS, e_o + (((size_t)b * N + lp) * N + m0p) * DE,
                         lane, FULL ? 16 : min(16, N - m0p));
     }
     tile_lds_put<DE>(tl, tr, lane, rows_valid);
-    if (it + 1 < total) prefetch(it + 1);
+    if (PFD == 1) { if (it + 1 < total) prefetch(tr, it + 1); }
+    else prefetch(tr, it_ + PFD);   // this slot's next tile (clamped past the end)
     lds_sync();
     float4 x[G::TILES];
 #pragma unroll
@@ -286,12 +298,12 @@ __global__ void __launch_bounds__(256, (DE <= 16 ? 4 : 2)) k_block_fwd(BlockArgs
       const float4 ev = frag_read<DE>(tl, p, q, t);
       frag_write<DE>(tl, p, q, t, make_float4(ev.x + d[0], ev.y + d[1], ev.z + d[2], ev.w + d[3]));
     }
-    if (it + 1 == total) {   // last tile of the wave: flush
+    if (it_ + 1 == total) {   // last tile of the wave: flush
       lds_sync();
       tile_from_lds<DE>(tl, e_o + pair0 * DE, lane, rows_valid);
     }
 
-    if (mt == ntile - 1) {
+    if (mt == ntile - 1 && live) {
       // ---- merge the 16 key lanes (same q): max, then sums ----
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -315,6 +327,14 @@ __global__ void __launch_bounds__(256, (DE <= 16 ? 4 : 2)) k_block_fwd(BlockArgs
         st[0] = p ? mx[1] : mx[0];
         st[1] = sj;
       }
+    }
+  };
+  if (PFD == 1) {
+    for (int it = 0; it < total; ++it) step(it, ring[0]);
+  } else {
+    for (int it0 = 0; it0 < total; it0 += PFD) {
+#pragma unroll
+      for (int k = 0; k < PFD; ++k) step(it0 + k, ring[k]);
     }
   }
 
@@ -1346,7 +1366,7 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   if (!skip_pre) egt_node_launch_pre(a, st);   // norm_mha + dense_qkv (packed) [+ edge-weight prep]
   const size_t lds_tiles = (size_t)8 * Geo<DE>::TILE_FLOATS * 4;
   const size_t lds_kv = ((size_t)a.N * KV_LD + 16 * QS_LD + a.N) * 4;
-  const bool kvl = lds_tiles + lds_kv <= 80 * 1024 - 512;   // two workgroups per CU keep their K/V in LDS
+  const bool kvl = lds_tiles + lds_kv <= 80 * 1024 - 512 && !egt_env_flag("EGT_NO_KVL");   // two workgroups per CU keep their K/V in LDS
   if (!(kvl && a.Dh == 64 && a.DK == 8) || egt_env_flag("EGT_NO_EPILOGUE")) a.epi = 0;
   const bool ml = a.M != nullptr || a.rm != nullptr;
   const dim3 grid(a.B * lgroups), block(256);
