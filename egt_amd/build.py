@@ -40,8 +40,9 @@ def _digest(paths) -> str:
     h = hashlib.sha256()
     for p in sorted(paths):
         with open(p, "rb") as f:
-            h.update(p.encode())
+            h.update(os.path.basename(p).encode())   # not the absolute path: the tree may be relocated
             h.update(f.read())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())   # experiment flags change the binary
     return h.hexdigest()
 
 

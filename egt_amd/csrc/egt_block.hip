@@ -117,6 +117,15 @@ __device__ __forceinline__ float reduce16_keep_own(const float (&v)[16], int p) 
 // ML: attention-mask / injected-random-mask byte streams are present (their loads are
 // compiled out of the headline kernel).
 // FULL: N is a multiple of 16 (no ragged key tile): validity selects and address clamps fold away.
+// Timing ablations of the forward (EGT_BLOCK_FLAGS=-DEGT_BLOCK_ABLATION at build time, EGT_FWD_ABLATE=<bits>
+// at run time): 1 K/V fragments + QK^T + softmax + A.V, 2 random-mask hash, 4 LN + projections,
+// 8 dense_edge_r + e' tile, 16 e' stores, 32 K/V/Q staging, 64 node-side epilogue, 128 e-tile loads.
+// Compiled out otherwise.
+#ifdef EGT_BLOCK_ABLATION
+#define FABL(a, bit) (!((a).guard & (bit)))
+#else
+#define FABL(a, bit) true
+#endif
 template <int DE, bool KVL, bool ML, bool FULL, bool BF>
 __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd(BlockArgs a) {   // narrow tiles without K/V in LDS: more resident waves (with K/V in LDS the LDS footprint caps a CU at two workgroups anyway)
   using G = Geo<DE>;
@@ -140,7 +149,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
   const bool gated = (a.flags & EGT_BF_GATE) != 0;
   const bool clip = (a.flags & EGT_BF_CLIP) != 0;
 
-  if (KVL) {
+  if (KVL && FABL(a, 32)) {
     const float* src = a.qkvp + (size_t)b * N * QKVP;
     for (int i = threadIdx.x; i < N * 32; i += 256) {
       const int row = i >> 5, f = i & 31;
@@ -186,6 +195,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
   constexpr int PFD = (DE <= 16 && KVL) ? 4 : 1;   // measured: +3.5 % at De = 8, N = 120; without K/V in LDS the extra registers spill
   TileRegs<DE> ring[PFD];
   auto prefetch = [&](TileRegs<DE>& tr, int it) {
+    if (!FABL(a, 128)) return;
     if (PFD > 1) it = min(it, total - 1);
     const int l = lg * 16 + wave + 4 * (it / ntile), m0 = (it % ntile) * 16;
     const size_t pair0 = ((size_t)b * N + l) * N + m0;
@@ -222,7 +232,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
     // of the next LDS staging therefore never covers a store younger than the loads it needs.
     float* tl = tl0 + (it_ & 1) * G::TILE_FLOATS;
     lds_sync();
-    if (it_ > 0 && live) {   // stream out e' of the previous tile from the other buffer
+    if (it_ > 0 && live && FABL(a, 16)) {   // stream out e' of the previous tile from the other buffer
       const int itp = it - 1, lp = lg * 16 + wave + 4 * (itp / ntile), m0p = (itp % ntile) * 16;
       tile_from_lds<DE>(tl0 + (itp & 1) * G::TILE_FLOATS, e_o + (((size_t)b * N + lp) * N + m0p) * DE,
                         lane, FULL ? 16 : min(16, N - m0p));
@@ -235,8 +245,11 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
 #pragma unroll
     for (int t = 0; t < G::TILES; ++t) x[t] = frag_read<DE>(tl, p, q, t);
     // ---- K/V fragments of key m ----
-    float Kf[16], Vf[16], kadd;
-    {
+    float Kf[16], Vf[16], kadd = 0.f;
+    if (!FABL(a, 1)) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { Kf[i] = 1.f; Vf[i] = 1.f; }
+    } else {
       const int mc = valid ? m : 0;
       const float4* kp;
       const float4* vp;
@@ -258,11 +271,14 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
       }
     }
     // ---- norm_edge + [attention_gates | dense_edge_b] ----
-    ln_frags<DE>(x, q, a.ln_eps, (a.flags & EGT_BF_NO_EDGE_LN) == 0);
     v4f acc = {c2r[0], c2r[1], c2r[2], c2r[3]};
-    acc = project<DE>(x, wA, acc);
+    if (FABL(a, 4)) {
+      ln_frags<DE>(x, q, a.ln_eps, (a.flags & EGT_BF_NO_EDGE_LN) == 0);
+      acc = project<DE>(x, wA, acc);
+    }
     // ---- scaled QK^T, clip, + E (egt_layers.py:79-86) ----
-    float hh[2], xl[2], gl[2];
+    float hh[2] = {0.f, 0.f}, xl[2] = {0.f, 0.f}, gl[2] = {0.f, 0.f};
+    if (FABL(a, 1)) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float dot = 0.f;
@@ -274,8 +290,10 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
       xl[j] = hh[j];
       gl[j] = acc[2 * j];
     }
-    apply_masks<ML>(a, kadd, mr, (pair0 + p) * BH, q, xl, gl);
+    }
+    if (FABL(a, 2)) apply_masks<ML>(a, kadd, mr, (pair0 + p) * BH, q, xl, gl);
     // ---- online softmax x gate, A.V (per lane) ----
+    if (FABL(a, 1))
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const float xv = xl[j];
@@ -290,6 +308,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
     }
     // ---- dense_edge_r + res_edge: e' = e + H_hat.Wr + br ----
     const float h0 = valid ? hh[0] : 0.f, h1 = valid ? hh[1] : 0.f;
+    if (FABL(a, 8))
 #pragma unroll
     for (int t = 0; t < G::TILES; ++t) {
       v4f d = {brv[t].x, brv[t].y, brv[t].z, brv[t].w};
@@ -342,7 +361,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
   //   epi >= 1: h' = V_att.Wo + bo + h                      (dense_mha + res_mha, :136,140)
   //   epi == 2: qkv of the NEXT block = LN(h').Wqkv' + bqkv' (norm_mha + dense_qkv, :109,113), packed
   // Contraction order k = 4s + q on both MFMA operands; weights come straight from L2.
-  if (KVL && a.epi) {
+  if (KVL && a.epi && FABL(a, 64)) {
     float wo[16], wq[3][16];
     const int c = wave * 16 + p;
 #pragma unroll
@@ -1369,6 +1388,13 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   const bool kvl = lds_tiles + lds_kv <= 80 * 1024 - 512 && !egt_env_flag("EGT_NO_KVL");   // two workgroups per CU keep their K/V in LDS
   if (!(kvl && a.Dh == 64 && a.DK == 8) || egt_env_flag("EGT_NO_EPILOGUE")) a.epi = 0;
   const bool ml = a.M != nullptr || a.rm != nullptr;
+  { const char* g = getenv("EGT_FWD_ABLATE"); if (g) { a.guard = atoi(g);
+#ifdef EGT_BLOCK_ABLATION
+      static int once = 0; if (!once++) fprintf(stderr, "[egt] forward ablation guard = %d (compiled in)\n", a.guard);
+#else
+      static int once = 0; if (!once++) fprintf(stderr, "[egt] EGT_FWD_ABLATE ignored: build with EGT_BLOCK_FLAGS=-DEGT_BLOCK_ABLATION\n");
+#endif
+  } }
   const dim3 grid(a.B * lgroups), block(256);
   const size_t lds = lds_tiles + (kvl ? lds_kv : 0);
 #define FWD_VARIANT_T(KVL_, ML_, FULL_, BF_)                                                           \
