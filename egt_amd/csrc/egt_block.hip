@@ -111,6 +111,73 @@ __device__ __forceinline__ float reduce16_keep_own(const float (&v)[16], int p) 
 #define KV_LD 132  // LDS row stride (floats) of the staged [K|V] rows
 #define QS_LD 68   // LDS row stride of the staged Q rows (reused for the V_att rows of the epilogue)
 
+// ---- node-side epilogue (Dh = 64): the workgroup holds V_att of its 16 rows in qs ----
+//   epi >= 1: h' = V_att.Wo + bo + h                      (dense_mha + res_mha, :136,140)
+//   epi == 2: qkv of the NEXT block = LN(h').Wqkv' + bqkv' (norm_mha + dense_qkv, :109,113), packed
+// Contraction order k = 4s + q on both MFMA operands; weights come straight from L2.
+__device__ __forceinline__ void fwd_node_epilogue(const BlockArgs& a, float* sm, float* qs, int b, int lg, int N,
+                                                  int wave, int p, int q) {
+
+    float wo[16], wq[3][16];
+    const int c = wave * 16 + p;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) wo[s] = a.Wo[(4 * s + q) * 64 + c];
+    if (a.epi == 2) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) wq[j][s] = a.nx_Wqkv[(4 * s + q) * 192 + (wave + 4 * j) * 16 + p];
+    }
+    const float bo = a.bo[c];
+    float hres[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hres[r] = a.h[((size_t)b * N + min(lg * 16 + 4 * q + r, N - 1)) * 64 + c];
+    __syncthreads();   // every row's V_att is in qs; the tile area is idle from here on
+    float* hs = sm;    // [16][QS_LD]
+    v4f acc = {bo, bo, bo, bo};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = MFMA(qs[p * QS_LD + 4 * s + q], wo[s], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * q + r, l = lg * 16 + row;
+      const float hv = acc[r] + hres[r];
+      if (l < N) a.h_out[((size_t)b * N + l) * 64 + c] = hv;
+      hs[row * QS_LD + c] = hv;
+    }
+    if (a.epi == 2) {
+      __syncthreads();
+      {   // LayerNorm of row 4*wave + q: 16 lanes x 4 columns
+        float* x = hs + (4 * wave + q) * QS_LD;
+        float v[4], sm1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = x[p + 16 * i]; sm1 += v[i]; }
+        const float mu = row_sum16(sm1) * (1.0f / 64);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] -= mu; ss = fmaf(v[i], v[i], ss); }
+        const float rstd = rsqrtf(row_sum16(ss) * (1.0f / 64) + a.ln_eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[p + 16 * i] = fmaf(v[i] * rstd, a.nx_nm_g[p + 16 * i], a.nx_nm_b[p + 16 * i]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int cq = (wave + 4 * j) * 16 + p;
+        const float bq = a.nx_bqkv[cq];
+        v4f aq = {bq, bq, bq, bq};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) aq = MFMA(hs[p * QS_LD + 4 * s + q], wq[j][s], aq);
+        const int sx = cq >> 6, cc = cq & 63, kk = cc >> 3, hh = cc & 7;
+        const int pos = sx * 64 + (hh >> 1) * 16 + kk * 2 + (hh & 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int l = lg * 16 + 4 * q + r;
+          if (l < N) a.nx_qkvp[((size_t)b * N + l) * QKVP + pos] = aq[r];
+        }
+      }
+    }
+  }
+
 // ================================================================= forward =====
 // Workgroup = (graph b, 16 query rows); wave w owns rows l = 16*lg + w + 4*i.
 // KVL: K/V of the graph, Q of the 16 rows and the key-mask adds are staged in LDS.
@@ -361,66 +428,206 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
   //   epi >= 1: h' = V_att.Wo + bo + h                      (dense_mha + res_mha, :136,140)
   //   epi == 2: qkv of the NEXT block = LN(h').Wqkv' + bqkv' (norm_mha + dense_qkv, :109,113), packed
   // Contraction order k = 4s + q on both MFMA operands; weights come straight from L2.
-  if (KVL && a.epi && FABL(a, 64)) {
-    float wo[16], wq[3][16];
-    const int c = wave * 16 + p;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) wo[s] = a.Wo[(4 * s + q) * 64 + c];
-    if (a.epi == 2) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int s = 0; s < 16; ++s) wq[j][s] = a.nx_Wqkv[(4 * s + q) * 192 + (wave + 4 * j) * 16 + p];
+  if (KVL && a.epi && FABL(a, 64)) fwd_node_epilogue(a, sm, qs, b, lg, N, wave, p, q);
+}
+
+// ---------------------------------------------------------------- forward, narrow edge channels ---
+// k_block_fwd walks (row, key tile) pairs one 16-pair tile at a time; for De <= 16 such a tile is
+// 0.5 - 1 KB and a third of the time is the per-iteration skeleton (staging, LDS hand-offs, index
+// arithmetic), the rest a chain of short dependent phases (see the ablation in DESIGN.md).  This
+// variant turns the loop inside out: one iteration = ONE key tile for all FOUR rows of the wave.
+// The K / V fragments and the key-mask add are fetched once per iteration and shared by the four
+// rows, the four e tiles are staged with one pair of LDS hand-offs, and the four rows' LN ->
+// projection -> softmax -> A.V -> dense_edge_r chains are independent, so the scheduler interleaves
+// them (ILP x4 instead of one latency-bound chain).  Q stays in LDS (re-read per key tile), the
+// running softmax state of the four rows lives in registers.  K/V of the graph in LDS (KVL) only;
+// no mask tensors (the ML variants stay on k_block_fwd).
+template <int DE, bool FULL>
+__global__ void __launch_bounds__(256, 2) k_block_fwd_r4(BlockArgs a) {
+  using G = Geo<DE>;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = lane & 15, q = lane >> 4;
+  const int N = a.N;
+  const int lgroups = (N + 15) / 16;
+  const int wg = a.xcd ? egt_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int b = wg / lgroups, lg = wg % lgroups;
+  float* tl = sm + wave * 4 * G::TILE_FLOATS;    // the wave's four tiles (one per row)
+  float* kvs = sm + 16 * G::TILE_FLOATS;         // [N][KV_LD]
+  float* qs = kvs + N * KV_LD;                   // [16][QS_LD]
+  float* kms = qs + 16 * QS_LD;                  // [N]
+  const bool gated = (a.flags & EGT_BF_GATE) != 0;
+  const bool clip = (a.flags & EGT_BF_CLIP) != 0;
+  {
+    const float* src = a.qkvp + (size_t)b * N * QKVP;
+    for (int i = threadIdx.x; i < N * 32; i += 256) {
+      const int row = i >> 5, f = i & 31;
+      *reinterpret_cast<float4*>(kvs + row * KV_LD + f * 4) =
+          *reinterpret_cast<const float4*>(src + (size_t)row * QKVP + 64 + f * 4);
     }
-    const float bo = a.bo[c];
-    float hres[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) hres[r] = a.h[((size_t)b * N + min(lg * 16 + 4 * q + r, N - 1)) * 64 + c];
-    __syncthreads();   // every row's V_att is in qs; the tile area is idle from here on
-    float* hs = sm;    // [16][QS_LD]
-    v4f acc = {bo, bo, bo, bo};
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc = MFMA(qs[p * QS_LD + 4 * s + q], wo[s], acc);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 4 * q + r, l = lg * 16 + row;
-      const float hv = acc[r] + hres[r];
-      if (l < N) a.h_out[((size_t)b * N + l) * 64 + c] = hv;
-      hs[row * QS_LD + c] = hv;
+    for (int i = threadIdx.x; i < 16 * 16; i += 256) {
+      const int row = i >> 4, f = i & 15, l = min(lg * 16 + row, N - 1);
+      *reinterpret_cast<float4*>(qs + row * QS_LD + f * 4) =
+          *reinterpret_cast<const float4*>(src + (size_t)l * QKVP + f * 4);
     }
-    if (a.epi == 2) {
-      __syncthreads();
-      {   // LayerNorm of row 4*wave + q: 16 lanes x 4 columns
-        float* x = hs + (4 * wave + q) * QS_LD;
-        float v[4], sm1 = 0.f;
+    for (int i = threadIdx.x; i < N; i += 256)
+      kms[i] = (a.km && a.km[(size_t)b * N + i] == 0) ? -EGT_NEG : 0.0f;
+  }
+  float wA[4 * G::TILES], wrA[G::TILES][2], c2r[4];
+  float4 brv[G::TILES];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] = x[p + 16 * i]; sm1 += v[i]; }
-        const float mu = row_sum16(sm1) * (1.0f / 64);
-        float ss = 0.f;
+  for (int t = 0; t < 4 * G::TILES; ++t) wA[t] = a.pw[(16 * (t >> 2) + 4 * q + (t & 3)) * 16 + p];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] -= mu; ss = fmaf(v[i], v[i], ss); }
-        const float rstd = rsqrtf(row_sum16(ss) * (1.0f / 64) + a.ln_eps);
+  for (int r = 0; r < 4; ++r) c2r[r] = a.pw[G::DEP * 16 + 4 * q + r];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) x[p + 16 * i] = fmaf(v[i] * rstd, a.nx_nm_g[p + 16 * i], a.nx_nm_b[p + 16 * i]);
+  for (int t = 0; t < G::TILES; ++t) {
+    const int c = 16 * t + p;
+    wrA[t][0] = c < DE ? a.Wr[(2 * q + 0) * DE + c] : 0.f;
+    wrA[t][1] = c < DE ? a.Wr[(2 * q + 1) * DE + c] : 0.f;
+    const int cb = 16 * t + 4 * q;
+    brv[t] = (cb < DE) ? make_float4(a.br[cb], a.br[cb + 1], a.br[cb + 2], a.br[cb + 3])
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+
+  const int ntile = (N + 15) / 16;
+  int nrows = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) nrows += (lg * 16 + wave + 4 * i < N) ? 1 : 0;   // rows i < nrows exist
+  if (nrows > 0) {
+    const float* e_in = a.e;
+    float* e_o = a.e_out;
+    size_t rowl[4];   // rows past the end alias the last real row: loaded, never computed or stored
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rowl[i] = (size_t)b * N + lg * 16 + wave + 4 * min(i, nrows - 1);
+    TileRegs<DE> tr[4];
+    auto prefetch = [&](int mt) {
+      const int m0 = mt * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        tile_gload<DE>(tr[i], e_in + (rowl[i] * N + m0) * DE, lane, FULL ? 16 : min(16, N - m0));
+    };
+    prefetch(0);
+    float mx[4][2], sum[4][2], O[4][16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      mx[i][0] = mx[i][1] = -3.0e38f; sum[i][0] = sum[i][1] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) O[i][k] = 0.f;
+    }
+    for (int mt = 0; mt < ntile; ++mt) {
+      const int m0 = mt * 16, m = m0 + p;
+      const bool valid = FULL ? true : (m < N);
+      const int rows_valid = FULL ? 16 : min(16, N - m0);
+      lds_sync();   // the e' tiles of the previous key tile have left the LDS tiles
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tile_lds_put<DE>(tl + i * G::TILE_FLOATS, tr[i], lane, rows_valid);
+      if (mt + 1 < ntile) prefetch(mt + 1);
+      lds_sync();
+      // ---- K/V fragments of key m: shared by the four rows ----
+      float Kf[16], Vf[16];
+      const int mc = valid ? m : 0;
+      {
+        const float4* kp = reinterpret_cast<const float4*>(kvs + mc * KV_LD + q * 16);
+        const float4* vp = reinterpret_cast<const float4*>(kvs + mc * KV_LD + 64 + q * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 kv = kp[i], vv = vp[i];
+          Kf[4*i] = kv.x; Kf[4*i+1] = kv.y; Kf[4*i+2] = kv.z; Kf[4*i+3] = kv.w;
+          Vf[4*i] = vv.x; Vf[4*i+1] = vv.y; Vf[4*i+2] = vv.z; Vf[4*i+3] = vv.w;
+        }
       }
-      __syncthreads();
+      const float kadd = kms[mc];
+      const MaskRegs mr{make_float2(1.f, 1.f), 0};
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int cq = (wave + 4 * j) * 16 + p;
-        const float bq = a.nx_bqkv[cq];
-        v4f aq = {bq, bq, bq, bq};
+      for (int i = 0; i < 4; ++i) {
+        if (i < nrows) {
+          float* tli = tl + i * G::TILE_FLOATS;
+          float4 x[G::TILES];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) aq = MFMA(hs[p * QS_LD + 4 * s + q], wq[j][s], aq);
-        const int sx = cq >> 6, cc = cq & 63, kk = cc >> 3, hh = cc & 7;
-        const int pos = sx * 64 + (hh >> 1) * 16 + kk * 2 + (hh & 1);
+          for (int t = 0; t < G::TILES; ++t) x[t] = frag_read<DE>(tli, p, q, t);
+          // ---- norm_edge + [attention_gates | dense_edge_b] ----
+          ln_frags<DE>(x, q, a.ln_eps, (a.flags & EGT_BF_NO_EDGE_LN) == 0);
+          v4f acc = {c2r[0], c2r[1], c2r[2], c2r[3]};
+          acc = project<DE>(x, wA, acc);
+          // ---- scaled QK^T, clip, + E (egt_layers.py:79-86); Q of the row from LDS ----
+          float Qf[16];
+          {
+            const float4* qp = reinterpret_cast<const float4*>(qs + (wave + 4 * i) * QS_LD + q * 16);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int l = lg * 16 + 4 * q + r;
-          if (l < N) a.nx_qkvp[((size_t)b * N + l) * QKVP + pos] = aq[r];
+            for (int u = 0; u < 4; ++u) { const float4 v = qp[u]; Qf[4*u] = v.x; Qf[4*u+1] = v.y; Qf[4*u+2] = v.z; Qf[4*u+3] = v.w; }
+          }
+          float hh[2], xl[2], gl[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dot = fmaf(Qf[2 * k + j], Kf[2 * k + j], dot);
+            float ah = dot * a.scale;
+            if (clip) ah = fminf(fmaxf(ah, a.clip_lo), a.clip_hi);
+            hh[j] = ah + acc[2 * j + 1];
+            xl[j] = hh[j];
+            gl[j] = acc[2 * j];
+          }
+          apply_masks<false>(a, kadd, mr, (rowl[i] * N + m0 + p) * BH, q, xl, gl);
+          // ---- online softmax x gate, A.V (per lane) ----
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float xv = xl[j];
+            const float mn = valid ? fmaxf(mx[i][j], xv) : mx[i][j];
+            const float alpha = __expf(mx[i][j] - mn);
+            const float pe = valid ? __expf(xv - mn) : 0.f;
+            mx[i][j] = mn;
+            sum[i][j] = fmaf(sum[i][j], alpha, pe);
+            const float av = gated ? pe * egt_sigmoid(gl[j]) : pe;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) O[i][2 * k + j] = fmaf(O[i][2 * k + j], alpha, av * Vf[2 * k + j]);
+          }
+          // ---- dense_edge_r + res_edge: e' = e + H_hat.Wr + br ----
+          const float h0 = valid ? hh[0] : 0.f, h1 = valid ? hh[1] : 0.f;
+#pragma unroll
+          for (int t = 0; t < G::TILES; ++t) {
+            v4f d = {brv[t].x, brv[t].y, brv[t].z, brv[t].w};
+            d = MFMA(wrA[t][0], h0, d);
+            d = MFMA(wrA[t][1], h1, d);
+            const float4 ev = frag_read<DE>(tli, p, q, t);
+            frag_write<DE>(tli, p, q, t, make_float4(ev.x + d[0], ev.y + d[1], ev.z + d[2], ev.w + d[3]));
+          }
+        }
+      }
+      lds_sync();   // stream out the four e' tiles
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < nrows) tile_from_lds<DE>(tl + i * G::TILE_FLOATS, e_o + (rowl[i] * N + m0) * DE, lane, rows_valid);
+    }
+    // ---- per row: merge the 16 key lanes (same q): max, then sums ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < nrows) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float mr2 = row_max16(mx[i][j]);
+          const float f = __expf(mx[i][j] - mr2);
+          mx[i][j] = mr2;
+          sum[i][j] = row_sum16(sum[i][j] * f);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) O[i][2 * k + j] *= f;
+        }
+        const float o = reduce16_keep_own(O[i], p);
+        const int k = p >> 1, j = p & 1;   // element p: k = p>>1, j = p&1 -> head 2q + j
+        const float sj = j ? sum[i][1] : sum[i][0];
+        const float vo = o / sj;
+        if (k < a.DK) a.v_att[rowl[i] * a.Dh + k * BH + 2 * q + j] = vo;
+        if (a.epi) qs[(wave + 4 * i) * QS_LD + k * BH + 2 * q + j] = vo;   // the row's Q is dead from here on
+        if (p < 2) {
+          float* st = a.stats + (rowl[i] * BH + 2 * q + p) * 4;
+          st[0] = p ? mx[i][1] : mx[i][0];
+          st[1] = sj;
         }
       }
     }
   }
+  if (a.epi) fwd_node_epilogue(a, sm, qs, b, lg, N, wave, p, q);
 }
 
 // ================================================================ backward =====
@@ -1386,6 +1593,7 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   const size_t lds_tiles = (size_t)8 * Geo<DE>::TILE_FLOATS * 4;
   const size_t lds_kv = ((size_t)a.N * KV_LD + 16 * QS_LD + a.N) * 4;
   const bool kvl = lds_tiles + lds_kv <= 80 * 1024 - 512 && !egt_env_flag("EGT_NO_KVL");   // two workgroups per CU keep their K/V in LDS
+  const int epi_req = a.epi;
   if (!(kvl && a.Dh == 64 && a.DK == 8) || egt_env_flag("EGT_NO_EPILOGUE")) a.epi = 0;
   const bool ml = a.M != nullptr || a.rm != nullptr;
   { const char* g = getenv("EGT_FWD_ABLATE"); if (g) { a.guard = atoi(g);
@@ -1406,6 +1614,18 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
 #define FWD_VARIANT(KVL_, ML_, FULL_)                                                                  \
   do { if (a.bf16) FWD_VARIANT_T(KVL_, ML_, FULL_, true); else FWD_VARIANT_T(KVL_, ML_, FULL_, false); } while (0)
   const bool full = (a.N % 16) == 0;
+  // narrow edge channels: four rows per iteration (k_block_fwd_r4) when K/V + its tiles fit twice in a CU
+  const size_t lds_r4 = (size_t)16 * Geo<DE>::TILE_FLOATS * 4 + lds_kv;
+  if (DE <= 16 && !ml && !a.bf16 && lds_r4 <= 80 * 1024 - 512 && !egt_env_flag("EGT_NO_KVL") && !egt_env_flag("EGT_NO_FWD_R4")) {
+    if (!(a.Dh == 64 && a.DK == 8) || egt_env_flag("EGT_NO_EPILOGUE")) a.epi = 0; else a.epi = epi_req;
+    if (full) {
+      (void)hipFuncSetAttribute((const void*)k_block_fwd_r4<DE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      EGT_LAUNCH("k_block_fwd", (k_block_fwd_r4<DE, true>), grid, block, lds_r4, st, a);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_block_fwd_r4<DE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      EGT_LAUNCH("k_block_fwd", (k_block_fwd_r4<DE, false>), grid, block, lds_r4, st, a);
+    }
+  } else
   if (full && kvl && !ml) FWD_VARIANT(true, false, true);      // the headline variant
   else if (kvl) { if (ml) FWD_VARIANT(true, true, false); else FWD_VARIANT(true, false, false); }
   else { if (ml) FWD_VARIANT(false, true, false); else FWD_VARIANT(false, false, false); }
