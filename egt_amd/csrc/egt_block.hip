@@ -442,35 +442,40 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
 // them (ILP x4 instead of one latency-bound chain).  Q stays in LDS (re-read per key tile), the
 // running softmax state of the four rows lives in registers.  K/V of the graph in LDS (KVL) only;
 // no mask tensors (the ML variants stay on k_block_fwd).
-template <int DE, bool FULL>
-__global__ void __launch_bounds__(256, 2) k_block_fwd_r4(BlockArgs a) {
+// NW = 4: 16 rows per workgroup, two workgroups per CU; NW = 8: 32 rows (two 16-row halves), ONE
+// workgroup per CU -- same occupancy, but K/V of a graph up to N ~ 250 still fits in LDS and is staged
+// once per 32 rows.
+template <int DE, bool FULL, int NW>
+__global__ void __launch_bounds__(64 * NW, 2) k_block_fwd_r4(BlockArgs a) {
+  constexpr int RW = 4 * NW, NT = 64 * NW;   // rows / threads per workgroup
   using G = Geo<DE>;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 15, q = lane >> 4;
+  const int hf = wave >> 2, wv = wave & 3;   // 16-row half of the workgroup, wave inside it
   const int N = a.N;
-  const int lgroups = (N + 15) / 16;
+  const int lgroups = (N + RW - 1) / RW;
   const int wg = a.xcd ? egt_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int b = wg / lgroups, lg = wg % lgroups;
   float* tl = sm + wave * 4 * G::TILE_FLOATS;    // the wave's four tiles (one per row)
-  float* kvs = sm + 16 * G::TILE_FLOATS;         // [N][KV_LD]
-  float* qs = kvs + N * KV_LD;                   // [16][QS_LD]
-  float* kms = qs + 16 * QS_LD;                  // [N]
+  float* kvs = sm + 4 * NW * G::TILE_FLOATS;     // [N][KV_LD]
+  float* qs = kvs + N * KV_LD;                   // [RW][QS_LD]
+  float* kms = qs + RW * QS_LD;                  // [N]
   const bool gated = (a.flags & EGT_BF_GATE) != 0;
   const bool clip = (a.flags & EGT_BF_CLIP) != 0;
   {
     const float* src = a.qkvp + (size_t)b * N * QKVP;
-    for (int i = threadIdx.x; i < N * 32; i += 256) {
+    for (int i = threadIdx.x; i < N * 32; i += NT) {
       const int row = i >> 5, f = i & 31;
       *reinterpret_cast<float4*>(kvs + row * KV_LD + f * 4) =
           *reinterpret_cast<const float4*>(src + (size_t)row * QKVP + 64 + f * 4);
     }
-    for (int i = threadIdx.x; i < 16 * 16; i += 256) {
-      const int row = i >> 4, f = i & 15, l = min(lg * 16 + row, N - 1);
+    for (int i = threadIdx.x; i < RW * 16; i += NT) {
+      const int row = i >> 4, f = i & 15, l = min(lg * RW + row, N - 1);
       *reinterpret_cast<float4*>(qs + row * QS_LD + f * 4) =
           *reinterpret_cast<const float4*>(src + (size_t)l * QKVP + f * 4);
     }
-    for (int i = threadIdx.x; i < N; i += 256)
+    for (int i = threadIdx.x; i < N; i += NT)
       kms[i] = (a.km && a.km[(size_t)b * N + i] == 0) ? -EGT_NEG : 0.0f;
   }
   float wA[4 * G::TILES], wrA[G::TILES][2], c2r[4];
@@ -492,14 +497,15 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd_r4(BlockArgs a) {
 
   const int ntile = (N + 15) / 16;
   int nrows = 0;
+  const int row0 = hf * 16 + wv;   // the wave's rows inside the workgroup: row0 + 4i
 #pragma unroll
-  for (int i = 0; i < 4; ++i) nrows += (lg * 16 + wave + 4 * i < N) ? 1 : 0;   // rows i < nrows exist
+  for (int i = 0; i < 4; ++i) nrows += (lg * RW + row0 + 4 * i < N) ? 1 : 0;   // rows i < nrows exist
   if (nrows > 0) {
     const float* e_in = a.e;
     float* e_o = a.e_out;
     size_t rowl[4];   // rows past the end alias the last real row: loaded, never computed or stored
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rowl[i] = (size_t)b * N + lg * 16 + wave + 4 * min(i, nrows - 1);
+    for (int i = 0; i < 4; ++i) rowl[i] = (size_t)b * N + lg * RW + row0 + 4 * min(i, nrows - 1);
     TileRegs<DE> tr[4];
     auto prefetch = [&](int mt) {
       const int m0 = mt * 16;
@@ -553,7 +559,7 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd_r4(BlockArgs a) {
           // ---- scaled QK^T, clip, + E (egt_layers.py:79-86); Q of the row from LDS ----
           float Qf[16];
           {
-            const float4* qp = reinterpret_cast<const float4*>(qs + (wave + 4 * i) * QS_LD + q * 16);
+            const float4* qp = reinterpret_cast<const float4*>(qs + (row0 + 4 * i) * QS_LD + q * 16);
 #pragma unroll
             for (int u = 0; u < 4; ++u) { const float4 v = qp[u]; Qf[4*u] = v.x; Qf[4*u+1] = v.y; Qf[4*u+2] = v.z; Qf[4*u+3] = v.w; }
           }
@@ -618,7 +624,7 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd_r4(BlockArgs a) {
         const float sj = j ? sum[i][1] : sum[i][0];
         const float vo = o / sj;
         if (k < a.DK) a.v_att[rowl[i] * a.Dh + k * BH + 2 * q + j] = vo;
-        if (a.epi) qs[(wave + 4 * i) * QS_LD + k * BH + 2 * q + j] = vo;   // the row's Q is dead from here on
+        if (a.epi) qs[(row0 + 4 * i) * QS_LD + k * BH + 2 * q + j] = vo;   // the row's Q is dead from here on
         if (p < 2) {
           float* st = a.stats + (rowl[i] * BH + 2 * q + p) * 4;
           st[0] = p ? mx[i][1] : mx[i][0];
@@ -627,7 +633,8 @@ __global__ void __launch_bounds__(256, 2) k_block_fwd_r4(BlockArgs a) {
       }
     }
   }
-  if (a.epi) fwd_node_epilogue(a, sm, qs, b, lg, N, wave, p, q);
+  // each 16-row half runs the 4-wave epilogue on its own rows (staging area hs = its own tiles)
+  if (a.epi) fwd_node_epilogue(a, sm + hf * 16 * QS_LD, qs + hf * 16 * QS_LD, b, lg * (RW / 16) + hf, N, wv, p, q);
 }
 
 // ================================================================ backward =====
@@ -1614,17 +1621,22 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
 #define FWD_VARIANT(KVL_, ML_, FULL_)                                                                  \
   do { if (a.bf16) FWD_VARIANT_T(KVL_, ML_, FULL_, true); else FWD_VARIANT_T(KVL_, ML_, FULL_, false); } while (0)
   const bool full = (a.N % 16) == 0;
-  // narrow edge channels: four rows per iteration (k_block_fwd_r4) when K/V + its tiles fit twice in a CU
+  // narrow edge channels: four rows per iteration (k_block_fwd_r4).  16-row workgroups when K/V + tiles fit
+  // twice in a CU, else 32-row workgroups (one per CU) as long as K/V fits at all
   const size_t lds_r4 = (size_t)16 * Geo<DE>::TILE_FLOATS * 4 + lds_kv;
-  if (DE <= 16 && !ml && !a.bf16 && lds_r4 <= 80 * 1024 - 512 && !egt_env_flag("EGT_NO_KVL") && !egt_env_flag("EGT_NO_FWD_R4")) {
+  const size_t lds_r8 = (size_t)32 * Geo<DE>::TILE_FLOATS * 4 + ((size_t)a.N * KV_LD + 32 * QS_LD + a.N) * 4;
+  const bool r4 = lds_r4 <= 80 * 1024 - 512, r8 = !r4 && lds_r8 <= 156 * 1024;
+  if (DE <= 16 && !ml && !a.bf16 && (r4 || r8) && !egt_env_flag("EGT_NO_KVL") && !egt_env_flag("EGT_NO_FWD_R4")) {
     if (!(a.Dh == 64 && a.DK == 8) || egt_env_flag("EGT_NO_EPILOGUE")) a.epi = 0; else a.epi = epi_req;
-    if (full) {
-      (void)hipFuncSetAttribute((const void*)k_block_fwd_r4<DE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      EGT_LAUNCH("k_block_fwd", (k_block_fwd_r4<DE, true>), grid, block, lds_r4, st, a);
-    } else {
-      (void)hipFuncSetAttribute((const void*)k_block_fwd_r4<DE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      EGT_LAUNCH("k_block_fwd", (k_block_fwd_r4<DE, false>), grid, block, lds_r4, st, a);
-    }
+#define R4_LAUNCH(FULL_, NW_)                                                                                     \
+  do {                                                                                                            \
+    (void)hipFuncSetAttribute((const void*)k_block_fwd_r4<DE, FULL_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    EGT_LAUNCH("k_block_fwd", (k_block_fwd_r4<DE, FULL_, NW_>), dim3(a.B * ((a.N + 4 * NW_ - 1) / (4 * NW_))), dim3(64 * NW_), \
+               NW_ == 4 ? lds_r4 : lds_r8, st, a);                                                                \
+  } while (0)
+    if (r4) { if (full) R4_LAUNCH(true, 4); else R4_LAUNCH(false, 4); }
+    else { if (full) R4_LAUNCH(true, 8); else R4_LAUNCH(false, 8); }
+#undef R4_LAUNCH
   } else
   if (full && kvl && !ml) FWD_VARIANT(true, false, true);      // the headline variant
   else if (kvl) { if (ml) FWD_VARIANT(true, true, false); else FWD_VARIANT(true, false, false); }

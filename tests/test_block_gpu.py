@@ -147,7 +147,8 @@ def test_fused_stack_matches_composed(gpu, egt_lib):
 
 @pytest.mark.parametrize("N,De,Dh,train", [(24, 64, 64, False), (32, 64, 64, True), (11, 48, 48, False),
                                            (20, 8, 64, True), (80, 16, 64, True), (32, 32, 64, False), (48, 48, 64, True),
-                                           (32, 8, 64, True), (128, 8, 64, False)])
+                                           (32, 8, 64, True), (128, 8, 64, False),
+                                           (150, 8, 64, True), (144, 16, 64, False)])   # 32-row workgroups of k_block_fwd_r4
 def test_stack_call_vs_oracle(N, De, Dh, train, gpu, egt_lib):
     """egt_stack_fwd/bwd (one C call per direction, deferred partial reduction) vs the fp64 oracle,
     including the per-layer in-kernel random masks."""
