@@ -445,8 +445,9 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
 // NW = 4: 16 rows per workgroup, two workgroups per CU; NW = 8: 32 rows (two 16-row halves), ONE
 // workgroup per CU -- same occupancy, but K/V of a graph up to N ~ 250 still fits in LDS and is staged
 // once per 32 rows.
-template <int DE, bool FULL, int NW>
+template <int DE, bool FULL, int NW, bool BF>
 __global__ void __launch_bounds__(64 * NW, 2) k_block_fwd_r4(BlockArgs a) {
+  typedef typename EdgeT<BF>::type ET;   // element type of the edge tensors in HBM
   constexpr int RW = 4 * NW, NT = 64 * NW;   // rows / threads per workgroup
   using G = Geo<DE>;
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -501,8 +502,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_fwd_r4(BlockArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) nrows += (lg * RW + row0 + 4 * i < N) ? 1 : 0;   // rows i < nrows exist
   if (nrows > 0) {
-    const float* e_in = a.e;
-    float* e_o = a.e_out;
+    const ET* e_in = reinterpret_cast<const ET*>(a.e);
+    ET* e_o = reinterpret_cast<ET*>(a.e_out);
     size_t rowl[4];   // rows past the end alias the last real row: loaded, never computed or stored
 #pragma unroll
     for (int i = 0; i < 4; ++i) rowl[i] = (size_t)b * N + lg * RW + row0 + 4 * min(i, nrows - 1);
@@ -1626,17 +1627,19 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   const size_t lds_r4 = (size_t)16 * Geo<DE>::TILE_FLOATS * 4 + lds_kv;
   const size_t lds_r8 = (size_t)32 * Geo<DE>::TILE_FLOATS * 4 + ((size_t)a.N * KV_LD + 32 * QS_LD + a.N) * 4;
   const bool r4 = lds_r4 <= 80 * 1024 - 512, r8 = !r4 && lds_r8 <= 156 * 1024;
-  if (DE <= 16 && !ml && !a.bf16 && (r4 || r8) && !egt_env_flag("EGT_NO_KVL") && !egt_env_flag("EGT_NO_FWD_R4")) {
+  if (DE <= 16 && !ml && (r4 || r8) && !egt_env_flag("EGT_NO_KVL") && !egt_env_flag("EGT_NO_FWD_R4")) {
     if (!(a.Dh == 64 && a.DK == 8) || egt_env_flag("EGT_NO_EPILOGUE")) a.epi = 0; else a.epi = epi_req;
-#define R4_LAUNCH(FULL_, NW_)                                                                                     \
+#define R4_LAUNCH_T(FULL_, NW_, BF_)                                                                              \
   do {                                                                                                            \
-    (void)hipFuncSetAttribute((const void*)k_block_fwd_r4<DE, FULL_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    EGT_LAUNCH("k_block_fwd", (k_block_fwd_r4<DE, FULL_, NW_>), dim3(a.B * ((a.N + 4 * NW_ - 1) / (4 * NW_))), dim3(64 * NW_), \
+    (void)hipFuncSetAttribute((const void*)k_block_fwd_r4<DE, FULL_, NW_, BF_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    EGT_LAUNCH("k_block_fwd", (k_block_fwd_r4<DE, FULL_, NW_, BF_>), dim3(a.B * ((a.N + 4 * NW_ - 1) / (4 * NW_))), dim3(64 * NW_), \
                NW_ == 4 ? lds_r4 : lds_r8, st, a);                                                                \
   } while (0)
+#define R4_LAUNCH(FULL_, NW_) do { if (a.bf16) R4_LAUNCH_T(FULL_, NW_, true); else R4_LAUNCH_T(FULL_, NW_, false); } while (0)
     if (r4) { if (full) R4_LAUNCH(true, 4); else R4_LAUNCH(false, 4); }
     else { if (full) R4_LAUNCH(true, 8); else R4_LAUNCH(false, 8); }
 #undef R4_LAUNCH
+#undef R4_LAUNCH_T
   } else
   if (full && kvl && !ml) FWD_VARIANT(true, false, true);      // the headline variant
   else if (kvl) { if (ml) FWD_VARIANT(true, true, false); else FWD_VARIANT(true, false, false); }
