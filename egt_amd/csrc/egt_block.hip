@@ -1440,6 +1440,316 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
     out[i] = (sm[i] + sm[G::EP + i]) + (sm[2 * G::EP + i] + sm[3 * G::EP + i]);
 }
 
+// ---------------------------------------------------------------- backward, narrow edge channels ---
+// k_block_bwd_v4 with the row loop unrolled by R (De <= 16, N % 16 == 0, no mask tensors): one
+// iteration = the wave's key tile x R query rows.  The rows' P1..P5 chains are independent, the LDS
+// hand-offs are shared (5 per R rows instead of 5 per row), the e / de' tiles of the next R rows are
+// in flight during the arithmetic.  Same arguments, partial layouts and prologue as v4.
+template <int DE, bool BF, int R>
+__global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R rows per iteration
+  using G = Geo<DE>;
+  typedef typename EdgeT<BF>::type ET;
+  const ET* e_in = reinterpret_cast<const ET*>(a.e);
+  const ET* dey_in = reinterpret_cast<const ET*>(a.de_out);
+  ET* dex_o = reinterpret_cast<ET*>(a.de);
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = lane & 15, q = lane >> 4;
+  const int N = a.N, TL = a.TL;   // TL == 16
+  const int wg = a.xcd ? egt_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int b = wg / a.NLR, lr = wg % a.NLR;
+  const int l_begin = lr * TL, l_end = min(N, l_begin + TL), nl = l_end - l_begin;
+  const bool gated = (a.flags & EGT_BF_GATE) != 0;
+  const bool clip = (a.flags & EGT_BF_CLIP) != 0;
+  constexpr int TF = G::TILE_FLOATS;
+  constexpr int PWR = R * (2 * TF + 256 + 192);   // per wave: R rows x (xhat tile, de' tile, dGE, H_hat)
+  constexpr int WSLAB = G::TILES * 256;
+  float* et0 = sm + wave * PWR;        // [R][TF]
+  float* dt0 = et0 + R * TF;           // [R][TF]
+  float* sc10 = dt0 + R * TF;          // [R][256]
+  float* sc20 = sc10 + R * 256;        // [R][192]
+  constexpr int AREA = 4 * PWR > BWD_PRO_WS ? 4 * PWR : BWD_PRO_WS;
+  static_assert(4 * G::EP <= AREA, "edge partial staging must fit the LDS tile area");
+  float* qd = sm + AREA;               // [TL][QD_LD]
+  float* wsA = qd + TL * QD_LD;
+  float* wsB = wsA + WSLAB;
+  float* wsD = wsB + WSLAB;
+  for (int i = threadIdx.x; i < nl * 40; i += 256) {
+    const int r = i / 40, f = i % 40;
+    const size_t rowl = (size_t)b * N + l_begin + r;
+    if (a.pro && f >= 16 && f < 32) continue;   // dV_att comes from the prologue below
+    const float* src = f < 16 ? a.qkvp + rowl * QKVP + f * 4
+                     : f < 32 ? a.dvp + rowl * 64 + (f - 16) * 4
+                              : a.stats + rowl * 32 + (f - 32) * 4;
+    float4 v = *reinterpret_cast<const float4*>(src);
+    if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
+    *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
+  }
+  if (a.pro) {
+    __syncthreads();
+    bwd_node_prologue<DE>(a, sm, qd, b, l_begin, wg);
+  }
+  for (int i = threadIdx.x; i < G::TILES * 256; i += 256) {
+    const int t = i >> 8, ln = (i >> 2) & 63, u = i & 3, pp = ln & 15, qq = ln >> 4;
+    const int c = 16 * t + 4 * qq + u;
+    wsA[i] = a.pw[c * 16 + pp];
+    const int hd = 2 * (pp >> 2) + (pp & 1);
+    wsB[i] = ((pp & 2) == 0 && c < DE) ? a.Wr[hd * DE + c] : 0.f;
+    wsD[i] = a.pw[(16 * t + pp) * 16 + 4 * qq + u];
+  }
+  float c2r[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c2r[r] = a.pw[G::DEP * 16 + 4 * q + r];
+  v4f accT[G::TILES], accR[G::TILES];
+#pragma unroll
+  for (int t = 0; t < G::TILES; ++t) { accT[t] = (v4f){0.f, 0.f, 0.f, 0.f}; accR[t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  const int ntile = N / 16;
+  for (int mt = wave; mt < ntile; mt += 4) {
+    const int m0 = mt * 16, m = m0 + p;
+    float Kf[16], Vf[16], dKa[16], dVa[16];
+    const size_t rowm = (size_t)b * N + m;
+    {
+      const float4* kp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 64 + q * 16);
+      const float4* vp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 128 + q * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 kv = kp[i], vv = vp[i];
+        Kf[4*i] = kv.x; Kf[4*i+1] = kv.y; Kf[4*i+2] = kv.z; Kf[4*i+3] = kv.w;
+        Vf[4*i] = vv.x; Vf[4*i+1] = vv.y; Vf[4*i+2] = vv.z; Vf[4*i+3] = vv.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { dKa[i] = 0.f; dVa[i] = 0.f; }
+    }
+    const float kadd = (a.km && a.km[rowm] == 0) ? -EGT_NEG : 0.0f;
+    const MaskRegs mr{make_float2(1.f, 1.f), 0};
+    TileRegs<DE> te[R], td[R];
+    auto prefetch = [&](int lq) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const size_t pair0 = ((size_t)b * N + l_begin + R * lq + i) * N + m0;
+        tile_gload<DE>(te[i], e_in + pair0 * DE, lane, 16);
+        tile_gload<DE>(td[i], dey_in + pair0 * DE, lane, 16);
+      }
+    };
+    prefetch(0);
+    for (int lq = 0; lq < nl / R; ++lq) {
+      const int lb = l_begin + R * lq;
+      size_t pair0[R];
+#pragma unroll
+      for (int i = 0; i < R; ++i) pair0[i] = ((size_t)b * N + lb + i) * N + m0;
+      lds_sync();   // the de tiles of the previous four rows have left the LDS tiles
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        tile_lds_put<DE>(et0 + i * TF, te[i], lane, 16);
+        tile_lds_put<DE>(dt0 + i * TF, td[i], lane, 16);
+      }
+      if (R * (lq + 1) < nl) prefetch(lq + 1);
+      lds_sync();
+      // ---- P1: norm_edge, projections (recompute) ; P2: dH_ext = de'.Wr^T ----
+      float rstd[R];
+      v4f acc[R], dhx[R];
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        float* et = et0 + i * TF;
+        const float* dt = dt0 + i * TF;
+        acc[i] = (v4f){c2r[0], c2r[1], c2r[2], c2r[3]};
+        dhx[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+        float4 x[G::TILES];
+#pragma unroll
+        for (int t = 0; t < G::TILES; ++t) x[t] = frag_read<DE>(et, p, q, t);
+        rstd[i] = ln_frags<DE>(x, q, a.ln_eps, (a.flags & EGT_BF_NO_EDGE_LN) == 0);
+#pragma unroll
+        for (int t = 0; t < G::TILES; ++t) {
+          frag_write<DE>(et, p, q, t, x[t]);     // xhat stays in the tile for the later phases
+          const float4 w = *reinterpret_cast<const float4*>(wsA + (t * 64 + lane) * 4);
+          acc[i] = MFMA(w.x, x[t].x, acc[i]);
+          acc[i] = MFMA(w.y, x[t].y, acc[i]);
+          acc[i] = MFMA(w.z, x[t].z, acc[i]);
+          acc[i] = MFMA(w.w, x[t].w, acc[i]);
+          const float4 dyv = frag_read<DE>(dt, p, q, t);
+          const float4 wb = *reinterpret_cast<const float4*>(wsB + (t * 64 + lane) * 4);
+          dhx[i] = MFMA(wb.x, dyv.x, dhx[i]);
+          dhx[i] = MFMA(wb.y, dyv.y, dhx[i]);
+          dhx[i] = MFMA(wb.z, dyv.z, dhx[i]);
+          dhx[i] = MFMA(wb.w, dyv.w, dhx[i]);
+        }
+      }
+      // ---- P3: logits, softmax/gate backward ----
+      float dge[R][4], dA[R][2], at[R][2];
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const float* qr = qd + (R * lq + i) * QD_LD;
+        float dots[2], dAd[2], hh[2];
+        {
+          const float4* qp = reinterpret_cast<const float4*>(qr + q * 16);
+          const float4* dp = reinterpret_cast<const float4*>(qr + 64 + q * 16);
+          float d0 = 0.f, d1 = 0.f, e0 = 0.f, e1 = 0.f;
+#pragma unroll
+          for (int u4 = 0; u4 < 4; ++u4) {
+            const float4 u = qp[u4], v = dp[u4];
+            d0 = fmaf(u.x, Kf[4*u4], d0);   d1 = fmaf(u.y, Kf[4*u4+1], d1);
+            d0 = fmaf(u.z, Kf[4*u4+2], d0); d1 = fmaf(u.w, Kf[4*u4+3], d1);
+            e0 = fmaf(v.x, Vf[4*u4], e0);   e1 = fmaf(v.y, Vf[4*u4+1], e1);
+            e0 = fmaf(v.z, Vf[4*u4+2], e0); e1 = fmaf(v.w, Vf[4*u4+3], e1);
+          }
+          dots[0] = d0; dots[1] = d1; dAd[0] = e0; dAd[1] = e1;
+        }
+        const float4* sp = reinterpret_cast<const float4*>(qr + 128 + q * 8);
+        const float4 s0 = sp[0], s1 = sp[1];
+        const float st[8] = {s0.x, s0.y, s0.z, 0.f, s1.x, s1.y, s1.z, 0.f};
+        float xl[2], gl[2], inr[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float araw = dots[j] * a.scale;
+          float ah = araw;
+          inr[j] = 1.0f;
+          if (clip) {
+            inr[j] = (araw >= a.clip_lo && araw <= a.clip_hi) ? 1.0f : 0.0f;
+            ah = fminf(fmaxf(araw, a.clip_lo), a.clip_hi);
+          }
+          hh[j] = ah + acc[i][2 * j + 1];
+          xl[j] = hh[j];
+          gl[j] = acc[i][2 * j];
+        }
+        apply_masks<false>(a, kadd, mr, (pair0[i] + p) * BH, q, xl, gl);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float S = __expf(xl[j] - st[4 * j]) * st[4 * j + 1];
+          const float g = gated ? egt_sigmoid(gl[j]) : 1.0f;
+          const float dS = dAd[j] * g;
+          const float dGl = gated ? dAd[j] * S * g * (1.0f - g) : 0.f;
+          const float dH = S * (dS - st[4 * j + 2]) + dhx[i][j];
+          dA[i][j] = dH * inr[j] * a.scale;
+          at[i][j] = S * g;
+          dge[i][2 * j] = dGl;
+          dge[i][2 * j + 1] = dH;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ssum[r] += dge[i][r];
+        float* sc1 = sc10 + i * 256;
+        float* sc2 = sc20 + i * 192;
+        *reinterpret_cast<float4*>(sc1 + p * 16 + 4 * q) = make_float4(dge[i][0], dge[i][1], dge[i][2], dge[i][3]);
+        *reinterpret_cast<float2*>(sc2 + p * 12 + 2 * q) = make_float2(hh[0], hh[1]);
+        if (q == 0) sc2[p * 12 + 8] = 1.0f;
+        SCHED_FENCE();   // one row's Q / dV_att fragments (32 registers) at a time
+      }
+      lds_sync();
+      // ---- dK / dV accumulation, dQ partials ; P4: weight-gradient contractions ----
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const float* qr = qd + (R * lq + i) * QD_LD;
+        const float4* qp = reinterpret_cast<const float4*>(qr + q * 16);
+        const float4* dp = reinterpret_cast<const float4*>(qr + 64 + q * 16);
+        float dq[16];
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) {
+          const float4 u = qp[u4], v = dp[u4];
+          dKa[4*u4]   = fmaf(dA[i][0], u.x, dKa[4*u4]);   dKa[4*u4+1] = fmaf(dA[i][1], u.y, dKa[4*u4+1]);
+          dKa[4*u4+2] = fmaf(dA[i][0], u.z, dKa[4*u4+2]); dKa[4*u4+3] = fmaf(dA[i][1], u.w, dKa[4*u4+3]);
+          dVa[4*u4]   = fmaf(at[i][0], v.x, dVa[4*u4]);   dVa[4*u4+1] = fmaf(at[i][1], v.y, dVa[4*u4+1]);
+          dVa[4*u4+2] = fmaf(at[i][0], v.z, dVa[4*u4+2]); dVa[4*u4+3] = fmaf(at[i][1], v.w, dVa[4*u4+3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { dq[2 * k] = dA[i][0] * Kf[2 * k]; dq[2 * k + 1] = dA[i][1] * Kf[2 * k + 1]; }
+        a.dqp[(((size_t)b * ntile + mt) * N + lb + i) * 64 + lane] = reduce16_keep_own(dq, p);
+        const float* et = et0 + i * TF;
+        const float* dt = dt0 + i * TF;
+        const float* sc1 = sc10 + i * 256;
+        const float* sc2 = sc20 + i * 192;
+        float bT[4], bR[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          bT[s4] = sc1[(q + 4 * s4) * 16 + p];
+          bR[s4] = (p < 9) ? sc2[(q + 4 * s4) * 12 + p] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < G::TILES; ++t)
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            accT[t] = MFMA(elem_read<DE>(et, q + 4 * s4, 16 * t + p), bT[s4], accT[t]);
+            accR[t] = MFMA(elem_read<DE>(dt, q + 4 * s4, 16 * t + p), bR[s4], accR[t]);
+          }
+        SCHED_FENCE();
+      }
+      lds_sync();
+      // ---- P5: d(ehat) = Wp . dGE, LayerNorm backward, de = de' + ... in place over the de' tiles ----
+      float4 dxh[R][G::TILES];
+      float m1[R], m2[R];
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const float* et = et0 + i * TF;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < G::TILES; ++t) {
+          const float4 w = *reinterpret_cast<const float4*>(wsD + (t * 64 + lane) * 4);
+          const float4 xh = frag_read<DE>(et, p, q, t);
+          v4f d = {0.f, 0.f, 0.f, 0.f};
+          d = MFMA(w.x, dge[i][0], d);
+          d = MFMA(w.y, dge[i][1], d);
+          d = MFMA(w.z, dge[i][2], d);
+          d = MFMA(w.w, dge[i][3], d);
+          dxh[i][t] = make_float4(d[0], d[1], d[2], d[3]);
+          s1 += (d[0] + d[1]) + (d[2] + d[3]);
+          s2 = fmaf(d[0], xh.x, s2); s2 = fmaf(d[1], xh.y, s2);
+          s2 = fmaf(d[2], xh.z, s2); s2 = fmaf(d[3], xh.w, s2);
+        }
+        m1[i] = sum_over_q(s1) * (1.0f / DE);
+        m2[i] = sum_over_q(s2) * (1.0f / DE);
+        if (a.flags & EGT_BF_NO_EDGE_LN) { m1[i] = 0.f; m2[i] = 0.f; }   // no norm_edge: d e = de' + d(proj input)
+      }
+      lds_sync();
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const float* et = et0 + i * TF;
+        float* dt = dt0 + i * TF;
+#pragma unroll
+        for (int t = 0; t < G::TILES; ++t) {
+          const float4 dyv = frag_read<DE>(dt, p, q, t);
+          const float4 xh = frag_read<DE>(et, p, q, t);
+          float4 o;
+          o.x = dyv.x + rstd[i] * (dxh[i][t].x - m1[i] - xh.x * m2[i]);
+          o.y = dyv.y + rstd[i] * (dxh[i][t].y - m1[i] - xh.y * m2[i]);
+          o.z = dyv.z + rstd[i] * (dxh[i][t].z - m1[i] - xh.z * m2[i]);
+          o.w = dyv.w + rstd[i] * (dxh[i][t].w - m1[i] - xh.w * m2[i]);
+          frag_write<DE>(dt, p, q, t, o);
+        }
+      }
+      lds_sync();   // stream out the four de tiles
+#pragma unroll
+      for (int i = 0; i < R; ++i) tile_from_lds<DE>(dt0 + i * TF, dex_o + pair0[i] * DE, lane, 16);
+    }
+    float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
+    float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
+      vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ssum[r] = row_sum16(ssum[r]);
+  __syncthreads();
+  float* ep = sm + wave * G::EP;
+#pragma unroll
+  for (int t = 0; t < G::TILES; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ep[(16 * t + 4 * q + r) * 16 + p] = accT[t][r];
+      ep[G::DEP * 16 + 16 + (16 * t + 4 * q + r) * 16 + p] = accR[t][r];
+    }
+  if (p == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ep[G::DEP * 16 + 4 * q + r] = ssum[r];
+  }
+  __syncthreads();
+  float* out = a.epart + (size_t)wg * G::EP;
+  for (int i = threadIdx.x; i < G::EP; i += 256)
+    out[i] = (sm[i] + sm[G::EP + i]) + (sm[2 * G::EP + i] + sm[3 * G::EP + i]);
+}
+
 // ================================================================ host glue ====
 
 
@@ -1699,6 +2009,21 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
   } while (0)
       const char* pfe = getenv("EGT_BWD_PF");
       const int pf = pfe ? atoi(pfe) : 0;   // two resident waves hide the HBM latency; prefetch registers only spill
+      if constexpr (DE <= 16) {
+        if (!ml && !egt_env_flag("EGT_NO_BWD_R4")) {   // narrow edge channels: four rows per iteration
+          constexpr int RR = 2;   // rows per iteration: four spill (the rows' carried state + prefetch exceed 256 VGPRs)
+          constexpr int PWR = RR * (2 * GG::TILE_FLOATS + 256 + 192);
+          const size_t lds_r = ((size_t)(4 * PWR > BWD_PRO_WS ? 4 * PWR : BWD_PRO_WS) + (size_t)BWD_TL * QD_LD + 3 * GG::TILES * 256) * 4;
+          if (a.bf16) {
+            (void)hipFuncSetAttribute((const void*)k_block_bwd_v4r<DE, true, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            EGT_LAUNCH("k_block_bwd", (k_block_bwd_v4r<DE, true, RR>), dim3(L.nwg_bwd), dim3(256), lds_r, st, a);
+          } else {
+            (void)hipFuncSetAttribute((const void*)k_block_bwd_v4r<DE, false, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            EGT_LAUNCH("k_block_bwd", (k_block_bwd_v4r<DE, false, RR>), dim3(L.nwg_bwd), dim3(256), lds_r, st, a);
+          }
+          goto pair_done;
+        }
+      }
       if (a.bf16) { if (ml) V4_VARIANT(true, 0, true); else V4_VARIANT(false, 0, true); }
       else if (ml) V4_VARIANT(true, 0, false);
       else if (pf == 0) V4_VARIANT(false, 0, false);
