@@ -973,22 +973,27 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
   const int p = lane & 15, q = lane >> 4, N = a.N;
   const size_t row0 = (size_t)b * N + l_begin;
   const int lnrow = 4 * wave + q;    // LayerNorm mapping: row 4*wave + q, columns p + 16 i
+  // ragged last row group (N not a multiple of 16): loads are clamped to the graph's last row, the
+  // rows past the end contribute zeros to every sum and are never stored
+  const int nv = min(16, N - l_begin);                     // valid rows of this workgroup
+  auto rc = [&](int r) { return row0 + min(r, nv - 1); };   // clamped global row
   if (a.pro == 2) {
     // ---- every global input in one round trip ----
-    float4 hx = *reinterpret_cast<const float4*>(a.up_h + (row0 + (t >> 4)) * 64 + (t & 15) * 4);
+    float4 hx = *reinterpret_cast<const float4*>(a.up_h + rc(t >> 4) * 64 + (t & 15) * 4);
     float4 gq[3];
     float dho[4], gmm[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      dho[i] = a.up_dh_out[(row0 + lnrow) * 64 + p + 16 * i];
+      dho[i] = a.up_dh_out[rc(lnrow) * 64 + p + 16 * i];
       gmm[i] = a.up_nm_g[p + 16 * i];
     }
-    const int NP = a.NQP;   // = NLR = N / 16 on this path
+    const int NP = a.NQP;   // key tiles = ceil(N / 16)
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int i = t + u * 256, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
-      const float* base = sx == 0 ? a.up_dqp + ((size_t)b * NP * N + l_begin + r) * 64 + pos4
-                                  : a.up_dkvp + (((size_t)b * NP * N + l_begin + r) * 2 + (sx - 1)) * 64 + (pos4 & 63);
+      const int rr = min(r, nv - 1);
+      const float* base = sx == 0 ? a.up_dqp + ((size_t)b * NP * N + l_begin + rr) * 64 + pos4
+                                  : a.up_dkvp + (((size_t)b * NP * N + l_begin + rr) * 2 + (sx - 1)) * 64 + (pos4 & 63);
       const size_t pstride = sx == 0 ? (size_t)N * 64 : (size_t)N * 128;
       float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
@@ -996,6 +1001,7 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
         const float4 w = *reinterpret_cast<const float4*>(base + pi * pstride);
         acc4.x += w.x; acc4.y += w.y; acc4.z += w.z; acc4.w += w.w;
       }
+      if (r >= nv) acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
       gq[u] = acc4;
     }
     // B operand of d h_ln = dQKV.Wqkv^T: Wqkv[kk = 16 wave + p][48 q .. 48 q + 47] (contraction order c = 48 q + s)
@@ -1040,7 +1046,7 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
 #pragma unroll
       for (int r = 0; r < 4; ++r) dls[(4 * q + r) * LD + 16 * wave + p] = acc[r];
     }
-    for (int i = t; i < 16 * 48; i += 256) {   // dQKV rows out (natural channel order) for k_node_wgrads
+    for (int i = t; i < nv * 48; i += 256) {   // dQKV rows out (natural channel order) for k_node_wgrads
       const int r = i / 48, c4 = (i % 48) * 4;
       *reinterpret_cast<float4*>(a.up_dqkv_sv + (row0 + r) * 192 + c4) = *reinterpret_cast<const float4*>(dqs + r * LD3 + c4);
     }
@@ -1062,8 +1068,8 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c = p + 16 * i;
-        const float dv = dho[i] + rstd * (dx[i] - m1 - xr[c] * m2);
-        dh_out_rw[(row0 + lnrow) * 64 + c] = dv;
+        const float dv = lnrow < nv ? dho[i] + rstd * (dx[i] - m1 - xr[c] * m2) : 0.f;
+        if (lnrow < nv) dh_out_rw[(row0 + lnrow) * 64 + c] = dv;
         dhs[lnrow * LD + c] = dv;
       }
     }
@@ -1084,8 +1090,10 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
       }
     }
   } else {
+    const float4 dv4 = *reinterpret_cast<const float4*>(a.dh_out + rc(t >> 4) * 64 + (t & 15) * 4);
+    const bool ok = (t >> 4) < nv;
     *reinterpret_cast<float4*>(dhs + (t >> 4) * LD + (t & 15) * 4) =
-        *reinterpret_cast<const float4*>(a.dh_out + (row0 + (t >> 4)) * 64 + (t & 15) * 4);
+        make_float4(ok ? dv4.x : 0.f, ok ? dv4.y : 0.f, ok ? dv4.z : 0.f, ok ? dv4.w : 0.f);
   }
   // ---- dV_att = dh'.Wo^T for i tile = wave (contraction order c = 16 q + s), delta, dbo ----
   float4 wo[4];
@@ -1093,7 +1101,7 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
 #pragma unroll
   for (int s = 0; s < 4; ++s) wo[s] = *reinterpret_cast<const float4*>(a.Wo + (size_t)(16 * wave + p) * 64 + 16 * q + 4 * s);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) va[r] = a.v_att[(row0 + 4 * q + r) * 64 + 16 * wave + p];
+  for (int r = 0; r < 4; ++r) va[r] = a.v_att[rc(4 * q + r) * 64 + 16 * wave + p];
   __syncthreads();
   {
     v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -1506,11 +1514,14 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
   float ssum[4] = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
-  const int ntile = N / 16;
+  // Ragged N: the last key tile has kv < 16 valid keys (loads clamped / zero-filled, the lanes of the
+  // missing keys get probability and gate exactly 0), the last row group has nl < 16 rows (skipped).
+  const int ntile = (N + 15) / 16;
   for (int mt = wave; mt < ntile; mt += 4) {
-    const int m0 = mt * 16, m = m0 + p;
+    const int m0 = mt * 16, m = m0 + p, kv = min(16, N - m0);
+    const bool kvalid = m < N;
     float Kf[16], Vf[16], dKa[16], dVa[16];
-    const size_t rowm = (size_t)b * N + m;
+    const size_t rowm = (size_t)b * N + (kvalid ? m : N - 1);
     {
       const float4* kp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 64 + q * 16);
       const float4* vp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 128 + q * 16);
@@ -1529,22 +1540,23 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
     auto prefetch = [&](int lq) {
 #pragma unroll
       for (int i = 0; i < R; ++i) {
-        const size_t pair0 = ((size_t)b * N + l_begin + R * lq + i) * N + m0;
-        tile_gload<DE>(te[i], e_in + pair0 * DE, lane, 16);
-        tile_gload<DE>(td[i], dey_in + pair0 * DE, lane, 16);
+        const size_t pair0 = ((size_t)b * N + l_begin + min(R * lq + i, nl - 1)) * N + m0;
+        tile_gload<DE>(te[i], e_in + pair0 * DE, lane, kv);
+        tile_gload<DE>(td[i], dey_in + pair0 * DE, lane, kv);
       }
     };
     prefetch(0);
-    for (int lq = 0; lq < nl / R; ++lq) {
+    for (int lq = 0; R * lq < nl; ++lq) {
       const int lb = l_begin + R * lq;
+      const int nr = min(R, nl - R * lq);   // rows of this step that exist
       size_t pair0[R];
 #pragma unroll
-      for (int i = 0; i < R; ++i) pair0[i] = ((size_t)b * N + lb + i) * N + m0;
+      for (int i = 0; i < R; ++i) pair0[i] = ((size_t)b * N + min(lb + i, l_end - 1)) * N + m0;
       lds_sync();   // the de tiles of the previous four rows have left the LDS tiles
 #pragma unroll
       for (int i = 0; i < R; ++i) {
-        tile_lds_put<DE>(et0 + i * TF, te[i], lane, 16);
-        tile_lds_put<DE>(dt0 + i * TF, td[i], lane, 16);
+        tile_lds_put<DE>(et0 + i * TF, te[i], lane, kv);
+        tile_lds_put<DE>(dt0 + i * TF, td[i], lane, kv);
       }
       if (R * (lq + 1) < nl) prefetch(lq + 1);
       lds_sync();
@@ -1553,6 +1565,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
       v4f acc[R], dhx[R];
 #pragma unroll
       for (int i = 0; i < R; ++i) {
+        if (i >= nr) continue;
         float* et = et0 + i * TF;
         const float* dt = dt0 + i * TF;
         acc[i] = (v4f){c2r[0], c2r[1], c2r[2], c2r[3]};
@@ -1581,6 +1594,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
       float dge[R][4], dA[R][2], at[R][2];
 #pragma unroll
       for (int i = 0; i < R; ++i) {
+        if (i >= nr) continue;
         const float* qr = qd + (R * lq + i) * QD_LD;
         float dots[2], dAd[2], hh[2];
         {
@@ -1615,6 +1629,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
           gl[j] = acc[i][2 * j];
         }
         apply_masks<false>(a, kadd, mr, (pair0[i] + p) * BH, q, xl, gl);
+        if (!kvalid) { xl[0] = xl[1] = -3.0e38f; gl[0] = gl[1] = -3.0e38f; }   // a key past N: S = 0, gate = 0
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float S = __expf(xl[j] - st[4 * j]) * st[4 * j + 1];
@@ -1640,6 +1655,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
       // ---- dK / dV accumulation, dQ partials ; P4: weight-gradient contractions ----
 #pragma unroll
       for (int i = 0; i < R; ++i) {
+        if (i >= nr) continue;
         const float* qr = qd + (R * lq + i) * QD_LD;
         const float4* qp = reinterpret_cast<const float4*>(qr + q * 16);
         const float4* dp = reinterpret_cast<const float4*>(qr + 64 + q * 16);
@@ -1680,6 +1696,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
       float m1[R], m2[R];
 #pragma unroll
       for (int i = 0; i < R; ++i) {
+        if (i >= nr) continue;
         const float* et = et0 + i * TF;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -1703,6 +1720,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
       lds_sync();
 #pragma unroll
       for (int i = 0; i < R; ++i) {
+        if (i >= nr) continue;
         const float* et = et0 + i * TF;
         float* dt = dt0 + i * TF;
 #pragma unroll
@@ -1719,14 +1737,17 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
       }
       lds_sync();   // stream out the four de tiles
 #pragma unroll
-      for (int i = 0; i < R; ++i) tile_from_lds<DE>(dt0 + i * TF, dex_o + pair0[i] * DE, lane, 16);
+      for (int i = 0; i < R; ++i)
+        if (i < nr) tile_from_lds<DE>(dt0 + i * TF, dex_o + pair0[i] * DE, lane, kv);
     }
     float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
     float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
+    if (kvalid) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
-      vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
+      for (int i = 0; i < 4; ++i) {
+        ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
+        vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
+      }
     }
   }
 #pragma unroll
@@ -1968,7 +1989,10 @@ template <int DE>
 static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool top, BlockArgs* below, BlockArgs* above) {
   using GG = Geo<DE>;
   // node-side prologue inside the pair kernel (see bwd_node_prologue): v4 geometry with Dh = 64
-  const bool pro = (DE % 16 == 0 || DE == 8) && (a.N % 16) == 0 && a.Dh == 64 && a.DK == 8 && !egt_env_flag("EGT_BWD_V2") &&
+  const bool ml = a.M != nullptr || a.rm != nullptr;
+  // narrow edge channels without mask tensors run k_block_bwd_v4r, which (with the prologue) also covers ragged N
+  const bool narrow_r = DE <= 16 && !ml && !egt_env_flag("EGT_NO_BWD_R4") && !egt_env_flag("EGT_BWD_V2");
+  const bool pro = (DE % 16 == 0 || DE == 8) && ((a.N % 16) == 0 || narrow_r) && a.Dh == 64 && a.DK == 8 && !egt_env_flag("EGT_BWD_V2") &&
                    !egt_env_flag("EGT_NO_BWD_PROLOGUE");
   a.pro = 0;
   if (pro) {
@@ -1994,12 +2018,11 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
   } while (0)
 #define BWD_VARIANT(ML_, FULL_)                                                                        \
   do { if (a.bf16) BWD_VARIANT_T(ML_, FULL_, true); else BWD_VARIANT_T(ML_, FULL_, false); } while (0)
-  const bool ml = a.M != nullptr || a.rm != nullptr;
   const bool full = (a.N % 16) == 0;
   if constexpr (DE % 16 == 0 || DE == 8) {
-    if (full && !egt_env_flag("EGT_BWD_V2")) {   // register-lean, 2 waves/SIMD
+    if ((full || narrow_r) && !egt_env_flag("EGT_BWD_V2")) {   // register-lean, 2 waves/SIMD
       const size_t lds_v4 = ((size_t)(4 * PW > BWD_PRO_WS ? 4 * PW : BWD_PRO_WS) + (size_t)BWD_TL * QD_LD + 3 * GG::TILES * 256) * 4;
-      a.NQP = a.N / 16;
+      a.NQP = (a.N + 15) / 16;
       { const char* e = getenv("EGT_BWD_ABLATE"); a.guard = e ? atoi(e) : 0; }   // measurement only: drops phases
 #define V4_VARIANT(ML_, PF_, BF_)                                                                          \
   do {                                                                                                 \
@@ -2010,7 +2033,7 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
       const char* pfe = getenv("EGT_BWD_PF");
       const int pf = pfe ? atoi(pfe) : 0;   // two resident waves hide the HBM latency; prefetch registers only spill
       if constexpr (DE <= 16) {
-        if (!ml && !egt_env_flag("EGT_NO_BWD_R4")) {   // narrow edge channels: four rows per iteration
+        if (narrow_r) {   // narrow edge channels: R rows per iteration, ragged N included
           constexpr int RR = 2;   // rows per iteration: four spill (the rows' carried state + prefetch exceed 256 VGPRs)
           constexpr int PWR = RR * (2 * GG::TILE_FLOATS + 256 + 192);
           const size_t lds_r = ((size_t)(4 * PWR > BWD_PRO_WS ? 4 * PWR : BWD_PRO_WS) + (size_t)BWD_TL * QD_LD + 3 * GG::TILES * 256) * 4;
