@@ -1140,7 +1140,9 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
 }
 
 // PF: how many of the two streamed tiles (e, de') are register-prefetched one row ahead.
-template <int DE, bool ML, int PF, bool BF>
+// RAG: N is not a multiple of 16 -- the last key tile is zero-filled past N and its lanes get probability and
+// gate exactly 0, the last row group is short (the row loop and the prologue already take nl < 16).
+template <int DE, bool ML, int PF, bool BF, bool RAG>
 __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
   using G = Geo<DE>;
   typedef typename EdgeT<BF>::type ET;   // element type of the edge tensors in HBM
@@ -1203,11 +1205,13 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
   float ssum[4] = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
-  const int ntile = N / 16;
+  const int ntile = RAG ? (N + 15) / 16 : N / 16;
   for (int mt = wave; mt < ntile; mt += 4) {
     const int m0 = mt * 16, m = m0 + p;
+    const int kv = RAG ? min(16, N - m0) : 16;
+    const bool kvalid = RAG ? (m < N) : true;
     float Kf[16], Vf[16], dKa[16], dVa[16];
-    const size_t rowm = (size_t)b * N + m;
+    const size_t rowm = (size_t)b * N + (kvalid ? m : N - 1);
     {
       const float4* kp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 64 + q * 16);
       const float4* vp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 128 + q * 16);
@@ -1225,8 +1229,8 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
     TileRegs<DE> te, td;
     {
       const size_t pair0 = ((size_t)b * N + l_begin) * N + m0;
-      if (PF >= 1) tile_gload<DE>(te, e_in + pair0 * DE, lane, 16);
-      if (PF >= 2) tile_gload<DE>(td, dey_in + pair0 * DE, lane, 16);
+      if (PF >= 1) tile_gload<DE>(te, e_in + pair0 * DE, lane, kv);
+      if (PF >= 2) tile_gload<DE>(td, dey_in + pair0 * DE, lane, kv);
     }
     for (int l = l_begin; l < l_end; ++l) {
       const int li = l - l_begin;
@@ -1234,19 +1238,19 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
       const size_t pair0 = rowl * N + m0;
       float* dt = dt0 + (li & 1) * G::TILE_FLOATS;
       MaskRegs mr{make_float2(1.f, 1.f), 0};
-      mask_gload<ML>(a, mr, pair0 + p, q);
+      mask_gload<ML>(a, mr, pair0 + (kvalid ? p : 0), q);
       // memory order per step: [stores of row l-1] then [loads of row l+1] (see k_block_fwd)
       lds_sync();
       if (li > 0)
-        tile_from_lds<DE>(dt0 + ((li - 1) & 1) * G::TILE_FLOATS, dex_o + (pair0 - (size_t)N) * DE, lane, 16);
+        tile_from_lds<DE>(dt0 + ((li - 1) & 1) * G::TILE_FLOATS, dex_o + (pair0 - (size_t)N) * DE, lane, kv);
       const size_t lp0 = (a.guard & 16) ? (size_t)wave * 16 : pair0;
-      if (PF < 2) tile_gload<DE>(td, dey_in + lp0 * DE, lane, 16);
-      if (PF < 1) tile_gload<DE>(te, e_in + lp0 * DE, lane, 16);
-      tile_lds_put<DE>(et, te, lane, 16);
-      tile_lds_put<DE>(dt, td, lane, 16);
+      if (PF < 2) tile_gload<DE>(td, dey_in + lp0 * DE, lane, kv);
+      if (PF < 1) tile_gload<DE>(te, e_in + lp0 * DE, lane, kv);
+      tile_lds_put<DE>(et, te, lane, kv);
+      tile_lds_put<DE>(dt, td, lane, kv);
       if (l + 1 < l_end) {
-        if (PF >= 1) tile_gload<DE>(te, e_in + (pair0 + (size_t)N) * DE, lane, 16);
-        if (PF >= 2) tile_gload<DE>(td, dey_in + (pair0 + (size_t)N) * DE, lane, 16);
+        if (PF >= 1) tile_gload<DE>(te, e_in + (pair0 + (size_t)N) * DE, lane, kv);
+        if (PF >= 2) tile_gload<DE>(td, dey_in + (pair0 + (size_t)N) * DE, lane, kv);
       }
       lds_sync();
       SCHED_FENCE();
@@ -1321,6 +1325,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
           gl[j] = acc[2 * j];
         }
         apply_masks<ML>(a, kadd, mr, (pair0 + p) * BH, q, xl, gl);
+        if (RAG && !kvalid) { xl[0] = xl[1] = -3.0e38f; gl[0] = gl[1] = -3.0e38f; }   // a key past N: S = 0, gate = 0
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float S = __expf(xl[j] - st[4 * j]) * st[4 * j + 1];
@@ -1417,14 +1422,16 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
     {  // flush the last row of this key tile
       lds_sync();
       tile_from_lds<DE>(dt0 + ((nl - 1) & 1) * G::TILE_FLOATS,
-                        dex_o + (((size_t)b * N + l_end - 1) * N + m0) * DE, lane, 16);
+                        dex_o + (((size_t)b * N + l_end - 1) * N + m0) * DE, lane, kv);
     }
     float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
     float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
+    if (kvalid) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
-      vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
+      for (int i = 0; i < 4; ++i) {
+        ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
+        vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
+      }
     }
   }
 #pragma unroll
@@ -1992,7 +1999,8 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
   const bool ml = a.M != nullptr || a.rm != nullptr;
   // narrow edge channels without mask tensors run k_block_bwd_v4r, which (with the prologue) also covers ragged N
   const bool narrow_r = DE <= 16 && !ml && !egt_env_flag("EGT_NO_BWD_R4") && !egt_env_flag("EGT_BWD_V2");
-  const bool pro = (DE % 16 == 0 || DE == 8) && ((a.N % 16) == 0 || narrow_r) && a.Dh == 64 && a.DK == 8 && !egt_env_flag("EGT_BWD_V2") &&
+  const bool rag_ok = !egt_env_flag("EGT_NO_BWD_RAGGED");   // v4 / v4r and the prologue take N that is not a multiple of 16
+  const bool pro = (DE % 16 == 0 || DE == 8) && ((a.N % 16) == 0 || rag_ok) && a.Dh == 64 && a.DK == 8 && !egt_env_flag("EGT_BWD_V2") &&
                    !egt_env_flag("EGT_NO_BWD_PROLOGUE");
   a.pro = 0;
   if (pro) {
@@ -2020,16 +2028,17 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
   do { if (a.bf16) BWD_VARIANT_T(ML_, FULL_, true); else BWD_VARIANT_T(ML_, FULL_, false); } while (0)
   const bool full = (a.N % 16) == 0;
   if constexpr (DE % 16 == 0 || DE == 8) {
-    if ((full || narrow_r) && !egt_env_flag("EGT_BWD_V2")) {   // register-lean, 2 waves/SIMD
+    if ((full || rag_ok) && !egt_env_flag("EGT_BWD_V2")) {   // register-lean, 2 waves/SIMD
       const size_t lds_v4 = ((size_t)(4 * PW > BWD_PRO_WS ? 4 * PW : BWD_PRO_WS) + (size_t)BWD_TL * QD_LD + 3 * GG::TILES * 256) * 4;
       a.NQP = (a.N + 15) / 16;
       { const char* e = getenv("EGT_BWD_ABLATE"); a.guard = e ? atoi(e) : 0; }   // measurement only: drops phases
-#define V4_VARIANT(ML_, PF_, BF_)                                                                          \
+#define V4_VARIANT_R(ML_, PF_, BF_, RAG_)                                                                  \
   do {                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)k_block_bwd_v4<DE, ML_, PF_, BF_>,                          \
+    (void)hipFuncSetAttribute((const void*)k_block_bwd_v4<DE, ML_, PF_, BF_, RAG_>,                    \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
-    EGT_LAUNCH("k_block_bwd", (k_block_bwd_v4<DE, ML_, PF_, BF_>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a); \
+    EGT_LAUNCH("k_block_bwd", (k_block_bwd_v4<DE, ML_, PF_, BF_, RAG_>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a); \
   } while (0)
+#define V4_VARIANT(ML_, PF_, BF_) do { if (full) V4_VARIANT_R(ML_, PF_, BF_, false); else V4_VARIANT_R(ML_, 0, BF_, true); } while (0)
       const char* pfe = getenv("EGT_BWD_PF");
       const int pf = pfe ? atoi(pfe) : 0;   // two resident waves hide the HBM latency; prefetch registers only spill
       if constexpr (DE <= 16) {
@@ -2053,6 +2062,7 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
       else if (pf == 1) V4_VARIANT(false, 1, false);
       else V4_VARIANT(false, 2, false);
 #undef V4_VARIANT
+#undef V4_VARIANT_R
       goto pair_done;
     }
   }
