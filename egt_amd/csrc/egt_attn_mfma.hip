@@ -424,6 +424,206 @@ __global__ void __launch_bounds__(512, 4) k_attn_mfma_fwd(AttnMfmaArgs a) {
   }
 }
 
+// ---- forward, two key tiles per iteration ------------------------------------------------------
+// Same decomposition as k_attn_mfma_fwd, but one iteration covers 32 keys: two independent
+// S^T / softmax chains per wave (the scheduler interleaves them), one barrier and one online-softmax
+// rescale per 32 keys, pair tiles one iteration (= two tiles) ahead in registers -- no role swap
+// needed.  ~190 VGPRs, so ONE workgroup per CU: the variant for grids that cannot give a CU two
+// workgroups anyway (B * N/16 <= 2 x 256 on MI355X).
+template <int D, int V>
+__global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd2(AttnMfmaArgs a) {
+  constexpr int KT = D / 16, DH = D * AH;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* In = sm;                        // [2][2 sub-tiles][E | G | M][PT_SZ]
+  float* Hout = sm + 2 * 2 * 3 * PT_SZ;  // [2][2][PT_SZ]
+  const int tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ll = lane & 15, q = lane >> 4;
+  const int N = a.N, NP = a.NP;
+  const int ltiles = NP / 16;
+  const int wg = egt_xcd_remap(blockIdx.x, gridDim.x);
+  const int b = wg / ltiles, l0 = (wg % ltiles) * 16;
+  const int l = l0 + ll, lc = min(l, N - 1);
+  const Feat<V> f(a);
+  const bool gated = f.G, clip = f.clip;
+  const size_t arr = (size_t)a.B * AH * NP * D;
+  const float* Kh = a.pk + PK_KH * arr + ((size_t)b * AH + h) * NP * D;
+  const float* VT = a.pk + PK_VT * arr + ((size_t)b * AH + h) * D * NP;
+  const uint32_t koff = ll * 16 + 4 * q;
+  const uint32_t prow = ptile_rowoff(N, l0, tid);
+  const float* Eb = ptile_base(a.E, b, N, l0);
+  const float* Gb = ptile_base(a.G, b, N, l0);
+  const float* Mb = ptile_base(a.M, b, N, l0);
+  float* Hb = const_cast<float*>(ptile_base(a.h_hat, b, N, l0));
+  auto pload = [&](const float* base, int col0) __attribute__((always_inline)) {
+    return *reinterpret_cast<const float4*>(base + ptile_off(prow, N, col0, tid));
+  };
+  float Qr[4 * KT];
+  {
+    const float* qrow = a.qkv + ((size_t)b * N + lc) * 3 * DH + h;
+#pragma unroll
+    for (int t = 0; t < 4 * KT; ++t) Qr[t] = qrow[(16 * (t >> 2) + 4 * q + (t & 3)) * AH];
+  }
+  v4f oacc[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) oacc[kt] = (v4f){0.f, 0.f, 0.f, 0.f};
+  float mrun = -3.0e38f, lrun = 0.f;
+  const int mlast = NP - 16;
+  auto clampm = [&](int m) { return min(m, mlast); };   // tiles past the end re-read the last one and are masked off
+  float4 kc[2][KT], vc[2][KT];
+  float4 pe[2], pg[2], pm[2];
+  Km4 kmc[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int mk = clampm(16 * kb);
+#pragma unroll
+    for (int T = 0; T < KT; ++T) {
+      kc[kb][T] = *reinterpret_cast<const float4*>(Kh + (size_t)mk * D + koff + 256 * T);
+      vc[kb][T] = *reinterpret_cast<const float4*>(VT + (size_t)mk * D + koff + 256 * T);
+    }
+    kmc[kb] = Km4{{1u, 1u, 1u, 1u}};
+    if (f.km) kmc[kb] = km_load4(a.km + (size_t)b * N, N, mk + 4 * q);
+    pe[kb] = pg[kb] = pm[kb] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f.E) ptile_lds_put(In + (kb * 3 + 0) * PT_SZ, pload(Eb, mk), N, l0, mk, tid);
+    if (f.G) ptile_lds_put(In + (kb * 3 + 1) * PT_SZ, pload(Gb, mk), N, l0, mk, tid);
+    if (f.M) ptile_lds_put(In + (kb * 3 + 2) * PT_SZ, pload(Mb, mk), N, l0, mk, tid);
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+
+  for (int m0 = 0, it = 0; m0 < NP; m0 += 32, ++it) {
+    int mn[2];   // the two key tiles of the NEXT iteration
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      mn[kb] = clampm(m0 + 32 + 16 * kb);
+      if (f.E) pe[kb] = pload(Eb, mn[kb]);
+      if (f.G) pg[kb] = pload(Gb, mn[kb]);
+      if (f.M) pm[kb] = pload(Mb, mn[kb]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float* Inb = In + (it & 1) * 6 * PT_SZ;
+    float* Hb2 = Hout + (it & 1) * 2 * PT_SZ;
+    // ---- S^T of both key tiles ----
+    v4f s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      s[kb] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int T = 0; T < KT; ++T) {
+        s[kb] = MFMA(kc[kb][T].x, Qr[4 * T + 0], s[kb]);
+        s[kb] = MFMA(kc[kb][T].y, Qr[4 * T + 1], s[kb]);
+        s[kb] = MFMA(kc[kb][T].z, Qr[4 * T + 2], s[kb]);
+        s[kb] = MFMA(kc[kb][T].w, Qr[4 * T + 3], s[kb]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int T = 0; T < KT; ++T) kc[kb][T] = *reinterpret_cast<const float4*>(Kh + (size_t)mn[kb] * D + koff + 256 * T);
+    __builtin_amdgcn_sched_barrier(0);
+    float x[2][4], pa[2][4];
+    float tmax = -3.0e38f;
+    const int po4 = h * PT_PL + pt_off(ll, 4 * q);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int mt0 = m0 + 16 * kb;   // may lie past NP on the last iteration: every key then fails `valid`
+      float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = e4, m4 = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (f.E) e4 = *reinterpret_cast<const float4*>(Inb + (kb * 3 + 0) * PT_SZ + po4);
+      if (f.G) g4 = *reinterpret_cast<const float4*>(Inb + (kb * 3 + 1) * PT_SZ + po4);
+      if (f.M) m4 = *reinterpret_cast<const float4*>(Inb + (kb * 3 + 2) * PT_SZ + po4);
+      const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w};
+      float hv4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mt0 + 4 * q + r;
+        const bool valid = m < N;
+        float ah = s[kb][r] * a.scale;
+        if (clip) ah = fminf(fmaxf(ah, a.clip_lo), a.clip_hi);
+        const size_t gi = (((size_t)b * N + lc) * N + min(m, N - 1)) * AH + h;
+        const float hv = ah + ev[r];
+        hv4[r] = hv;
+        const float kadd = kmc[kb].v[r] ? 0.0f : -EGT_NEG;
+        const float add = mask_add(a, f, kadd, mv[r], gi);
+        x[kb][r] = valid ? hv + add : -3.0e38f;
+        pa[kb][r] = gated ? egt_sigmoid(gv[r] + add) : 1.0f;
+        tmax = fmaxf(tmax, x[kb][r]);
+      }
+      *reinterpret_cast<float4*>(Hb2 + kb * PT_SZ + po4) = make_float4(hv4[0], hv4[1], hv4[2], hv4[3]);
+    }
+    if (f.km) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) kmc[kb] = km_load4(a.km + (size_t)b * N, N, mn[kb] + 4 * q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- online softmax over the 32 keys ----
+    tmax = pair_max_q(tmax);
+    const float mnew = fmaxf(mrun, tmax);
+    const float alpha = __expf(mrun - mnew);
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pexp = (x[kb][r] > -2.9e38f) ? __expf(x[kb][r] - mnew) : 0.f;
+        psum += pexp;
+        pa[kb][r] *= pexp;
+      }
+    psum = pair_sum_q(psum);
+    lrun = fmaf(lrun, alpha, psum);
+    mrun = mnew;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      v4f o = oacc[kt];
+      o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        o = MFMA(vc[kb][kt].x, pa[kb][0], o);
+        o = MFMA(vc[kb][kt].y, pa[kb][1], o);
+        o = MFMA(vc[kb][kt].z, pa[kb][2], o);
+        o = MFMA(vc[kb][kt].w, pa[kb][3], o);
+      }
+      oacc[kt] = o;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int T = 0; T < KT; ++T) vc[kb][T] = *reinterpret_cast<const float4*>(VT + (size_t)mn[kb] * D + koff + 256 * T);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      float* nx = In + ((it + 1) & 1) * 6 * PT_SZ;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        if (f.E) ptile_lds_put(nx + (kb * 3 + 0) * PT_SZ, pe[kb], N, l0, mn[kb], tid);
+        if (f.G) ptile_lds_put(nx + (kb * 3 + 1) * PT_SZ, pg[kb], N, l0, mn[kb], tid);
+        if (f.M) ptile_lds_put(nx + (kb * 3 + 2) * PT_SZ, pm[kb], N, l0, mn[kb], tid);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {   // H_hat tiles out: whole 512-byte runs
+      const int row = tid >> 5, m = (tid & 31) >> 1, mt0 = m0 + 16 * kb;
+      if (l0 + row < N && mt0 + m < N) {
+        const float* p = Hb2 + kb * PT_SZ + (tid & 1) * 4 * PT_PL + pt_off(row, m);
+        *reinterpret_cast<float4*>(Hb + ptile_off(prow, N, mt0, tid)) = make_float4(p[0], p[PT_PL], p[2 * PT_PL], p[3 * PT_PL]);
+      }
+    }
+  }
+  if (l < N) {
+    const float inv = 1.0f / lrun;
+    float* vo = a.v_att + ((size_t)b * N + l) * DH + h;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vo[(16 * kt + 4 * q + r) * AH] = oacc[kt][r] * inv;
+    if (q == 0) {
+      float* rs = a.rowstats + (((size_t)b * N + l) * AH + h) * 4;
+      rs[0] = mrun; rs[1] = lrun; rs[2] = 0.f; rs[3] = 0.f;
+    }
+  }
+}
+
 // ================================================================= backward =====
 // Launches (flash-attention style, the [N,N,H] probabilities are recomputed):
 //   k_attn_pack        : head-major operand arrays of Q, K, V, dV_att
@@ -757,6 +957,14 @@ static int variant_of(const AttnMfmaArgs& a, bool bwd) {
 
 template <int D, int V>
 static void launch_fwd_v(const AttnMfmaArgs& a, hipStream_t st) {
+  // small grids (no CU would get two workgroups anyway): two key tiles per iteration
+  const char* f2 = getenv("EGT_ATTN_FWD2");
+  const bool two = f2 ? atoi(f2) != 0 : (a.B * (a.NP / 16) <= 512);
+  if (two) {
+    (void)hipFuncSetAttribute((const void*)k_attn_mfma_fwd2<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_LAUNCH("k_attn_mfma_fwd", (k_attn_mfma_fwd2<D, V>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)16 * PT_SZ * 4, st, a);
+    return;
+  }
   (void)hipFuncSetAttribute((const void*)k_attn_mfma_fwd<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   EGT_LAUNCH("k_attn_mfma_fwd", (k_attn_mfma_fwd<D, V>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)8 * PT_SZ * 4, st, a);
 }
