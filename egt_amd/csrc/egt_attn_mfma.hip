@@ -828,7 +828,10 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
 }
 
 // Lane (ll = lane&15, q): query row l0 + ll; keys m0 + 4q + t as the contraction index.
-template <int D>
+// TB key tiles per iteration (one barrier per 16*TB keys; K^T operands single-buffered: the next
+// block's are requested right after the MFMAs have read the registers).  TB = 4 for grids that
+// cannot give a CU two workgroups, TB = 1 (76 VGPRs, several workgroups per CU) otherwise.
+template <int D, int TB>
 __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_q(AttnMfmaArgs a) {
   constexpr int KT = D / 16, DH = D * AH;
   const int lane = threadIdx.x & 63, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -840,44 +843,57 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_q(AttnMfmaArgs a) {
   const int l = l0 + ll;
   const size_t arr = (size_t)a.B * AH * NP * D;
   const float* KTp = a.pk + PK_KT * arr + ((size_t)b * AH + h) * D * NP;
+  const uint32_t koff = ll * 16 + 4 * q;
   v4f dQacc[KT];
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) dQacc[kt] = (v4f){0.f, 0.f, 0.f, 0.f};
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // dA tiles [2][PT_SZ]
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // dA tiles [2][TB][PT_SZ]
   const int tid = threadIdx.x;
-  float4 kc[KT], kn[KT], pa4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int mlast = NP - 16;
+  float4 kc[TB][KT], pa4[TB];
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) {
-    kc[kt] = *reinterpret_cast<const float4*>(KTp + (16 * kt + ll) * 16 + 4 * q);
-    kn[kt] = kc[kt];
+  for (int tb = 0; tb < TB; ++tb) {
+    const int mk = min(16 * tb, mlast);   // tiles past the end: K^T of the last tile against dA columns that are zero
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) kc[tb][kt] = *reinterpret_cast<const float4*>(KTp + (size_t)mk * D + koff + 256 * kt);
+    ptile_lds_put(sm + tb * PT_SZ, ptile_gload(a.ws_dA, b, N, l0, 16 * tb, tid), N, l0, 16 * tb, tid);
+    pa4[tb] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  ptile_lds_put(sm, ptile_gload(a.ws_dA, b, N, l0, 0, tid), N, l0, 0, tid);
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  for (int m0 = 0, it = 0; m0 < NP; m0 += 16, ++it) {
-    const bool more = m0 + 16 < NP;
-    if (more) {
+  for (int m0 = 0, it = 0; m0 < NP; m0 += 16 * TB, ++it) {
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-        kn[kt] = *reinterpret_cast<const float4*>(KTp + (size_t)(m0 + 16) * D + (16 * kt + ll) * 16 + 4 * q);
-      pa4 = ptile_gload(a.ws_dA, b, N, l0, m0 + 16, tid);
-    }
-    const float* At = sm + (it & 1) * PT_SZ;
-    const float4 da4 = *reinterpret_cast<const float4*>(At + h * PT_PL + pt_off(ll, 4 * q));   // dA[l][m = 4q + t] (zero past N)
-    const float da[4] = {da4.x, da4.y, da4.z, da4.w};
+    for (int tb = 0; tb < TB; ++tb) pa4[tb] = ptile_gload(a.ws_dA, b, N, l0, m0 + 16 * (TB + tb), tid);   // clamped, zeroed at the LDS store
+    __builtin_amdgcn_sched_barrier(0);
+    const float* At = sm + (it & 1) * TB * PT_SZ;
+    float4 da4[TB];
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) da4[tb] = *reinterpret_cast<const float4*>(At + tb * PT_SZ + h * PT_PL + pt_off(ll, 4 * q));
     // dQ^T[k][l] += sum_m K^T[k][m] dA[l][m]
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
       v4f dq = dQacc[kt];
-      dq = MFMA(kc[kt].x, da[0], dq);
-      dq = MFMA(kc[kt].y, da[1], dq);
-      dq = MFMA(kc[kt].z, da[2], dq);
-      dq = MFMA(kc[kt].w, da[3], dq);
+#pragma unroll
+      for (int tb = 0; tb < TB; ++tb) {
+        dq = MFMA(kc[tb][kt].x, da4[tb].x, dq);
+        dq = MFMA(kc[tb][kt].y, da4[tb].y, dq);
+        dq = MFMA(kc[tb][kt].z, da4[tb].z, dq);
+        dq = MFMA(kc[tb][kt].w, da4[tb].w, dq);
+      }
       dQacc[kt] = dq;
     }
-    if (more) ptile_lds_put(sm + ((it + 1) & 1) * PT_SZ, pa4, N, l0, m0 + 16, tid);
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) kc[kt] = kn[kt];
+    for (int tb = 0; tb < TB; ++tb) {
+      const int mk = min(m0 + 16 * (TB + tb), mlast);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) kc[tb][kt] = *reinterpret_cast<const float4*>(KTp + (size_t)mk * D + koff + 256 * kt);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+      ptile_lds_put(sm + (((it + 1) & 1) * TB + tb) * PT_SZ, pa4[tb], N, l0, m0 + 16 * (TB + tb), tid);
+    __syncthreads();
   }
   if (l < N) {
     float* o = a.d_qkv + ((size_t)b * N + l) * 3 * DH + h;
@@ -1012,7 +1028,16 @@ static void launch_bwd(const AttnMfmaArgs& a, hipStream_t st) {
     case 2: launch_bwd_kv_v<D, 2>(a, st); break;
     default: launch_bwd_kv_v<D, 0>(a, st); break;
   }
-  EGT_LAUNCH("k_attn_mfma_bwd_q", k_attn_mfma_bwd_q<D>, dim3(a.B * (a.NP / 16)), dim3(512), (size_t)2 * PT_SZ * 4, st, a);
+  {
+    const char* e4 = getenv("EGT_ATTN_BWDQ4");
+    const bool four = e4 ? atoi(e4) != 0 : false;   // four key tiles per iteration: measured equal to one (49 vs 50 us at B = 8, slower at B = 32), kept as an experiment switch
+    if (four) {
+      (void)hipFuncSetAttribute((const void*)k_attn_mfma_bwd_q<D, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      EGT_LAUNCH("k_attn_mfma_bwd_q", (k_attn_mfma_bwd_q<D, 4>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)8 * PT_SZ * 4, st, a);
+    } else {
+      EGT_LAUNCH("k_attn_mfma_bwd_q", (k_attn_mfma_bwd_q<D, 1>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)2 * PT_SZ * 4, st, a);
+    }
+  }
 }
 
 // rowstats is read AND written (slot 3 receives delta); workspace: egt_attn_mfma_workspace_bytes()
