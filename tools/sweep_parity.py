@@ -91,8 +91,12 @@ def one_attn(N, d, opts, B, dev, seed):
 
 def main():
     dev = torch.device("cuda", 0)
-    rnd = random.Random(2024)
+    import os
+    seed = int(os.environ.get("EGT_SWEEP_SEED", "2024"))   # other seeds: other geometries / feature mixes
+    rnd = random.Random(seed)
     Ns = [1, 2, 3, 7, 15, 16, 17, 31, 32, 33, 47, 48, 49, 64, 65, 80]
+    if seed != 2024:
+        Ns = sorted(rnd.sample(range(1, 161), 16))
     combos = []
     for N in Ns:
         for _ in range(3):
