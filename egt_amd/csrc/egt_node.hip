@@ -691,19 +691,25 @@ __global__ void __launch_bounds__(512, 4) k_node_wgrads(WGradArgs wa) {
 }
 
 // ------------------------------------------------------------ final reduce -----
-struct SumSeg { const float* src; float* dst; int n, np, stride, nblk; };
+struct SumSeg { const float* src; float* dst; int n, np, stride, blk0; };   // blk0: first workgroup of the segment in the flat grid
 #define SUM_MAX_SEG 77  // 11 layers x 7 segments: fits the 4 KiB kernel-argument block
-struct SumArgs { SumSeg seg[SUM_MAX_SEG]; };
+struct SumArgs { SumSeg seg[SUM_MAX_SEG]; int nseg; };
 
 // 32 outputs per workgroup, the partial axis split over 8 groups of 32 lanes with 8 independent
 // accumulators each: with hundreds of partials per output the loop is latency-bound, so what counts
 // is loads in flight (64 per output), not lanes per output.  Fixed association order: deterministic.
 __global__ void __launch_bounds__(256) k_sum_segments(SumArgs s) {
   __shared__ float red[8][32];
-  const SumSeg sg = s.seg[blockIdx.y];
-  if ((int)blockIdx.x >= sg.nblk) return;
+  // flat grid: one workgroup per 32 outputs of some segment (a (max blocks) x (segments) grid launched
+  // four empty workgroups for every working one); the segment is found by a scalar binary search
+  int lo = 0, hi = s.nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (s.seg[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SumSeg sg = s.seg[lo];
   const int ol = threadIdx.x & 31, pg = threadIdx.x >> 5;
-  const int o = blockIdx.x * 32 + ol;
+  const int o = ((int)blockIdx.x - sg.blk0) * 32 + ol;
   float v[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) v[k] = 0.f;
@@ -846,10 +852,10 @@ void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, hipStream
   for (int l0 = 0; l0 < n; l0 += 11) {
     const int nl = (n - l0 < 11) ? (n - l0) : 11;
     SumArgs s{};
-    int maxblk = 0, k = 0;
+    int nblk = 0, k = 0;
     auto seg = [&](const float* src, float* dst, int cnt, int npart, int stride) {
-      s.seg[k] = SumSeg{src, dst, cnt, npart, stride, (cnt + 31) / 32};
-      if (s.seg[k].nblk > maxblk) maxblk = s.seg[k].nblk;
+      s.seg[k] = SumSeg{src, dst, cnt, npart, stride, nblk};
+      nblk += (cnt + 31) / 32;
       ++k;
     };
     for (int l = l0; l < l0 + nl; ++l) {
@@ -864,7 +870,8 @@ void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, hipStream
       seg(a.sbo, a.g_bo, Dh, a.sbo_n, Dh);
       seg(a.epart, a.ered, EP, nwg_bwd, EP);
     }
-    EGT_LAUNCH("k_sum_segments", k_sum_segments, dim3(maxblk, k), dim3(256), 0, st, s);
+    s.nseg = k;
+    EGT_LAUNCH("k_sum_segments", k_sum_segments, dim3(nblk), dim3(256), 0, st, s);
   }
   for (int l0 = 0; l0 < n; l0 += EPG_MAX_LAYERS) {
     const int nl = (n - l0 < EPG_MAX_LAYERS) ? (n - l0) : EPG_MAX_LAYERS;
