@@ -105,3 +105,33 @@ def test_unsupported_width_raises(gpu, egt_lib):
     with pytest.raises(AssertionError):
         edge_update(torch.zeros(1, 2, 2, 24, device=gpu), torch.zeros(1, 2, 2, 8, device=gpu),
                     torch.zeros(8, 24, device=gpu), torch.zeros(24, device=gpu))
+
+
+def test_edge_proj_bwd_acc_in_place(gpu, egt_lib):
+    """egt_edge_proj_bwd_acc with d_e_base aliasing d_e (documented in include/egt_amd.h): the
+    residual-branch gradient buffer is updated in place and equals base + egt_edge_proj_bwd's d_e."""
+    import ctypes as C
+    from egt_amd import _lib as L
+    from egt_amd.functional import _edge_desc
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=g).to(gpu)
+    De, rows = 32, 1000   # ragged last tile
+    e, gamma, beta = r(rows, De), 1 + 0.1 * r(De), 0.1 * r(De)
+    Wg, We, dG, dE, base = 0.3 * r(De, 8), 0.3 * r(De, 8), r(rows, 8), r(rows, 8), r(rows, De)
+    desc = _edge_desc(e, True, True, L.ACT_NONE, 0.0, 1e-3)
+    mk = lambda *s: torch.empty(*s, device=gpu)
+    ws = torch.empty(egt_lib.egt_edge_proj_bwd_workspace_bytes(C.byref(desc)), device=gpu, dtype=torch.uint8)
+    grads = [mk(De), mk(De), mk(De, 8), mk(8), mk(De, 8), mk(8)]
+    d_ref = mk(rows, De)
+    L.check(egt_lib.egt_edge_proj_bwd(C.byref(desc), L.ptr(e), L.ptr(gamma), L.ptr(beta), L.ptr(Wg), L.ptr(We), None,
+                                      L.ptr(dG), L.ptr(dE), L.ptr(d_ref), *[L.ptr(t) for t in grads], L.ptr(ws),
+                                      L.current_stream()))
+    grads_ref = [t.clone() for t in grads]
+    inout = base.clone()
+    L.check(egt_lib.egt_edge_proj_bwd_acc(C.byref(desc), L.ptr(e), L.ptr(gamma), L.ptr(beta), L.ptr(Wg), L.ptr(We), None,
+                                          L.ptr(dG), L.ptr(dE), L.ptr(inout), L.ptr(inout), *[L.ptr(t) for t in grads],
+                                          L.ptr(ws), L.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(inout, base + d_ref)          # same arithmetic, one extra add per element
+    for a, b in zip(grads, grads_ref):
+        assert torch.equal(a, b)                     # parameter gradients: bit-identical (deterministic partials)
