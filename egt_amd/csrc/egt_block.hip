@@ -1965,7 +1965,10 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   const size_t lds_r4 = (size_t)16 * Geo<DE>::TILE_FLOATS * 4 + lds_kv;
   const size_t lds_r8 = (size_t)32 * Geo<DE>::TILE_FLOATS * 4 + ((size_t)a.N * KV_LD + 32 * QS_LD + a.N) * 4;
   const bool r4 = lds_r4 <= 80 * 1024 - 512, r8 = !r4 && lds_r8 <= 156 * 1024;
-  if (DE <= 16 && !ml && (r4 || r8) && !egt_env_flag("EGT_NO_KVL") && !egt_env_flag("EGT_NO_FWD_R4")) {
+  bool narrow = false;
+  if constexpr (DE <= 16) {   // (wider channels would not fit the four rows' state in 256 VGPRs: not instantiated)
+    narrow = !ml && (r4 || r8) && !egt_env_flag("EGT_NO_KVL") && !egt_env_flag("EGT_NO_FWD_R4");
+    if (narrow) {
     if (!(a.Dh == 64 && a.DK == 8) || egt_env_flag("EGT_NO_EPILOGUE")) a.epi = 0; else a.epi = epi_req;
 #define R4_LAUNCH_T(FULL_, NW_, BF_)                                                                              \
   do {                                                                                                            \
@@ -1978,8 +1981,10 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
     else { if (full) R4_LAUNCH(true, 8); else R4_LAUNCH(false, 8); }
 #undef R4_LAUNCH
 #undef R4_LAUNCH_T
-  } else
-  if (full && kvl && !ml) FWD_VARIANT(true, false, true);      // the headline variant
+    }
+  }
+  if (narrow) {}
+  else if (full && kvl && !ml) FWD_VARIANT(true, false, true);      // the headline variant
   else if (kvl) { if (ml) FWD_VARIANT(true, true, false); else FWD_VARIANT(true, false, false); }
   else { if (ml) FWD_VARIANT(false, true, false); else FWD_VARIANT(false, false, false); }
 #undef FWD_VARIANT_T
