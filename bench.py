@@ -10,7 +10,13 @@ ZINC-500K shapes (Dh=64, De=64, H=8, d=8, Ly=10), padded N=64, fp32, B=128
 graphs per GPU (weak scaling), node counts ~U[9,37], random_mask_prob=0.1.
 
 Usage: python bench.py --gpus N --steps K --warmup W
-(N>1: launched by torch.distributed.run, one rank per GPU).
+N>1 runs one rank per GPU over RCCL.  Either launch it under torch.distributed.run
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+--master-port P bench.py --gpus N ...`) or just run `python bench.py --gpus N`: without a
+launcher in the environment the script re-executes itself under torch.distributed.run.  A
+world size that differs from --gpus, or fewer visible GPUs than ranks, is an ERROR (never a
+silent 1-rank run).  --scaling weak (default): 128 graphs per GPU; strong: 128 graphs split
+over the ranks (lib/training/training_base.py:230-247: Keras splits the global batch).
 """
 from __future__ import annotations
 
@@ -145,6 +151,29 @@ def cpu_baseline(w, seconds=12.0):
     return out
 
 
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n: int):
+    """`python bench.py --gpus N` with no launcher in the environment: become
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` (one rank per GPU)."""
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py: --gpus {n} but only {have} GPU(s) visible; refusing to run fewer ranks")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+    print("[bench] launching: " + " ".join(cmd), file=sys.stderr, flush=True)
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,22 +192,32 @@ def main():
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--dominant", default="k_block_bwd",
                     help="kernel timed with hipEvents inside the timed region")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the workload's B graphs per GPU; strong: B graphs split over the ranks")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        self_launch(args.gpus)           # does not return
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if env_world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks; "
+                         "pass matching values (the line must report the GPUs that really ran)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or "RANK" in os.environ   # under torch.distributed.run even a 1-rank job goes through RCCL init
+    use_dist = launched                  # under torch.distributed.run even a 1-rank job goes through RCCL init
+    world = 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=env_world)  # "nccl" is RCCL on ROCm
+        world = dist.get_world_size()    # what RCCL really connected -- this is what the line reports
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: RCCL world size {world} != --gpus {args.gpus}")
 
     from egt_amd import build as _build
     if local_rank == 0:
@@ -195,25 +234,37 @@ def main():
     if args.edge_dtype:
         w["edge_dtype"] = args.edge_dtype
     bf16 = w.get("edge_dtype", "f32") == "bf16"
+    global_B = w["B"] * world
+    if args.scaling == "strong":
+        from egt_amd.dp import shard_batch
+        global_B = w["B"]
+        lo, hi = shard_batch(global_B, world, rank)
+        w["B"] = hi - lo                 # this rank's contiguous slice of the global batch
+        if w["B"] < 1:
+            raise SystemExit("bench.py: strong scaling needs at least one graph per rank")
     torch.manual_seed(1234)  # same weights on every rank (replicated parameters)
+    mask_seed = 1 * world + rank  # the replicas draw independent random attention masks
     fused = {"auto": "auto", "on": True, "off": False}[args.fused]
     if args.with_ffn:
         from egt_amd import EGTLayerStack
         model = EGTLayerStack(model_height=w["Ly"], model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"],
-                              random_mask_prob=w["rand_p"], seed=1, fused=fused).to(dev).train()
+                              random_mask_prob=w["rand_p"], seed=mask_seed, fused=fused).to(dev).train()
         model.fused_parameters = lambda: list(model.parameters())
         from types import SimpleNamespace
         model.grad_holder = SimpleNamespace(flat=None)   # per-block calls: classic flat buffer bound to .grad
     else:
         model = EGTStack(model_height=w["Ly"], model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"],
-                         random_mask_prob=w["rand_p"], seed=1, fused=fused).to(dev).train()
+                         random_mask_prob=w["rand_p"], seed=mask_seed, fused=fused).to(dev).train()
     h, e, mask, dh, de = make_inputs(w, dev, seed=1234 + rank)  # each rank its own graphs
     if bf16:
         e, de = e.bfloat16(), de.bfloat16()
     h.requires_grad_(); e.requires_grad_()
     params = model.fused_parameters()
     nbytes = sum(p.numel() for p in params) * 4
-    state = {"flat_ok": None, "fa": None}
+    state = {"flat_ok": None, "fa": None, "ar_events": None}
+    # uneven strong-scaling shards: weight the local-mean gradients by local/global graphs
+    ar_kw = dict(local_count=w["B"], global_count=global_B) if args.scaling == "strong" else {}
+    ar_kw["force"] = use_dist            # a launched 1-rank job still issues the RCCL collective
 
     def step():
         # fused stack: the backward writes every parameter gradient into one flat buffer whose
@@ -233,10 +284,17 @@ def main():
             if not state["flat_ok"]:
                 state["fa"] = FlatGradAllReduce(params)   # takes effect from the next step
                 return
+        evs = state["ar_events"]
+        if evs is not None:              # hipEvents around the collective (untimed pass only)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         if state["flat_ok"]:
-            all_reduce_flat(model.grad_holder.flat, average=True)
+            all_reduce_flat(model.grad_holder.flat, average=True, **ar_kw)
         else:
-            fa.all_reduce(average=True)
+            fa.all_reduce(average=True, **ar_kw)
+        if evs is not None:
+            e1.record()
+            evs.append((e0, e1))
 
     def fence():
         torch.cuda.synchronize()
@@ -259,10 +317,16 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     lib.egt_prof_enable(0)
-    if world > 1:
+    graphs_step = w["B"]
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        gs = torch.tensor([w["B"]], device=dev, dtype=torch.int64)
+        dist.all_reduce(gs)              # graphs all ranks processed per step
+        graphs_step = int(gs.item())
+    else:
+        graphs_step = w["B"]
     dom_prof = prof_read_all(lib) if not args.no_prof else {}
     all_prof = {}
     if not args.no_prof:   # every rank runs it (the step contains the collective)
@@ -273,6 +337,16 @@ def main():
         fence()
         lib.egt_prof_enable(0)
         all_prof = prof_read_all(lib)
+    # the one exchange step, timed on its own: hipEvents around the flat-buffer collective
+    ar_us = None
+    if use_dist:
+        state["ar_events"] = []
+        for _ in range(min(args.steps, 10)):
+            step()
+        fence()
+        ts = sorted(a.elapsed_time(b) * 1e3 for a, b in state["ar_events"])
+        state["ar_events"] = None
+        ar_us = ts[len(ts) // 2] if ts else None
 
     prof = all_prof
     if rank == 0:
@@ -301,7 +375,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(w, args.cpu_seconds)
-        graphs = world * w["B"] * args.steps
+        graphs = graphs_step * args.steps
         path = "fused-stack" if state["flat_ok"] else ("fused" if any(k.startswith("k_block") for k in prof) else "composed")
         if args.with_ffn:
             path += "+ffn"
@@ -309,15 +383,16 @@ def main():
             "metric": "graphs/sec EGT fwd+bwd, ZINC-500K padded N=64",
             "value": graphs / elapsed, "unit": "graphs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32 (edge tensors stored bf16)" if bf16 else "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: attention-block stack (h,e,mask)->(h',e') x Ly, fwd+bwd "
                                    f"+ param grads" + (" + flat RCCL grad all-reduce" if world > 1 else ""),
-                       "graphs_per_gpu": w["B"], "global_batch": w["B"] * world, "N": w["N"],
+                       "graphs_per_gpu": w["B"], "global_batch": graphs_step, "N": w["N"],
                        "Dh": w["Dh"], "De": w["De"], "H": w["H"], "d": w["Dh"] // w["H"], "Ly": w["Ly"],
                        "random_mask_prob": w["rand_p"], "nodes": list(w["nodes"]), "path": path,
                        "parallelism": f"dp{world}", "grad_allreduce_bytes": nbytes,
+                       "grad_allreduce_us": ar_us, "backend": "rccl" if use_dist else "none (single process)",
                        "flat_grad_adopted": bool(state["flat_ok"])},
             "roofline": roof, "cpu_baseline": cpu,
         }

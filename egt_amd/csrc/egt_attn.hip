@@ -150,8 +150,8 @@ __global__ void __launch_bounds__(256) k_attn_fwd(AttnArgs a) {
           const size_t idx = rowbase + (size_t)m * H + h;
           float at = xs[m * H + h] * inv;
           if (gated) at *= gs[m * H + h];
-          if (a.a_tild) a.a_tild[idx] = at;
           ad = at * drop_factor(a, idx);
+          if (a.a_tild) a.a_tild[idx] = ad;   // the reference REASSIGNS A_tild = dropout(A_tild) (:116-117) and returns that
           xs[m * H + h] = ad;
         } else {
           ad = xs[m * H + h];

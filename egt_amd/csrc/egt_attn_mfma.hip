@@ -929,6 +929,26 @@ extern "C" size_t egt_attn_mfma_fwd_workspace_bytes(const egt_attn_desc* d) {
   return (size_t)2 * d->B * AH * np_of(d->N) * d->d * sizeof(float);
 }
 
+// experiment switches, read once per process (no getenv on the launch path)
+struct EgtAttnEnv { int ablate, generic, fwd2 /* -1: auto */, bwdq4; };
+static const EgtAttnEnv& attn_env() {
+  static const EgtAttnEnv e = [] {
+    EgtAttnEnv v{};
+    const char* g = getenv("EGT_ATTN_ABLATE");
+    v.ablate = g ? atoi(g) : 0;
+#ifndef EGT_ATTN_ABLATION
+    if (v.ablate) { fprintf(stderr, "[egt] EGT_ATTN_ABLATE ignored: build with EGT_ATTN_FLAGS=-DEGT_ATTN_ABLATION\n"); v.ablate = 0; }
+#endif
+    v.generic = getenv("EGT_ATTN_GENERIC") != nullptr;
+    const char* f2 = getenv("EGT_ATTN_FWD2");
+    v.fwd2 = f2 ? (atoi(f2) != 0) : -1;
+    const char* e4 = getenv("EGT_ATTN_BWDQ4");
+    v.bwdq4 = e4 ? (atoi(e4) != 0) : 0;
+    return v;
+  }();
+  return e;
+}
+
 static int fill(const egt_attn_desc* desc, const void* qkv, const void* E, const void* G,
                 const uint8_t* key_mask, const void* attn_mask, const uint8_t* rand_mask, void* workspace,
                 AttnMfmaArgs& a) {
@@ -941,7 +961,7 @@ static int fill(const egt_attn_desc* desc, const void* qkv, const void* E, const
   a.B = desc->B; a.N = desc->N; a.NP = np_of(desc->N); a.d = desc->d; a.flags = desc->flags;
   a.clip_lo = desc->clip_lo; a.clip_hi = desc->clip_hi;
   a.scale = 1.0f / sqrtf((float)desc->d);
-  { const char* g = getenv("EGT_ATTN_ABLATE"); a.guard = g ? atoi(g) : 0; }
+  a.guard = attn_env().ablate;
   a.rm_thr = egt_threshold24(desc->random_mask_prob);
   a.s0 = (uint32_t)(desc->seed & 0xFFFFFFFFull); a.s1 = (uint32_t)(desc->seed >> 32);
   a.qkv = (const float*)qkv;
@@ -967,15 +987,15 @@ static void launch_pack(const AttnMfmaArgs& a, hipStream_t st) {
 static int variant_of(const AttnMfmaArgs& a, bool bwd) {
   const bool main_cfg = a.E && (a.flags & EGT_F_GATE_INPUT) && a.G && !a.M && a.km && (a.flags & EGT_F_CLIP) && !a.rm &&
                         (!bwd || (a.d_h_ext && a.d_E && a.d_G));
-  if (!main_cfg || getenv("EGT_ATTN_GENERIC")) return 0;
+  if (!main_cfg || attn_env().generic) return 0;
   return a.rng_rm ? 2 : 1;
 }
 
 template <int D, int V>
 static void launch_fwd_v(const AttnMfmaArgs& a, hipStream_t st) {
   // small grids (no CU would get two workgroups anyway): two key tiles per iteration
-  const char* f2 = getenv("EGT_ATTN_FWD2");
-  const bool two = f2 ? atoi(f2) != 0 : (a.B * (a.NP / 16) <= 512);
+  const int f2 = attn_env().fwd2;
+  const bool two = f2 >= 0 ? f2 != 0 : (a.B * (a.NP / 16) <= 512);
   if (two) {
     (void)hipFuncSetAttribute((const void*)k_attn_mfma_fwd2<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     EGT_LAUNCH("k_attn_mfma_fwd", (k_attn_mfma_fwd2<D, V>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)16 * PT_SZ * 4, st, a);
@@ -1029,8 +1049,7 @@ static void launch_bwd(const AttnMfmaArgs& a, hipStream_t st) {
     default: launch_bwd_kv_v<D, 0>(a, st); break;
   }
   {
-    const char* e4 = getenv("EGT_ATTN_BWDQ4");
-    const bool four = e4 ? atoi(e4) != 0 : false;   // four key tiles per iteration: measured equal to one (49 vs 50 us at B = 8, slower at B = 32), kept as an experiment switch
+    const bool four = attn_env().bwdq4 != 0;   // four key tiles per iteration: measured equal to one (49 vs 50 us at B = 8, slower at B = 32), kept as an experiment switch
     if (four) {
       (void)hipFuncSetAttribute((const void*)k_attn_mfma_bwd_q<D, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       EGT_LAUNCH("k_attn_mfma_bwd_q", (k_attn_mfma_bwd_q<D, 4>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)8 * PT_SZ * 4, st, a);

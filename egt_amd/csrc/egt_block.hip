@@ -1781,9 +1781,49 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
 // ================================================================ host glue ====
 
 
-static bool egt_env_flag(const char* name) {
+// Experiment switches (EGT_* environment variables) are read ONCE per process: the launch path
+// does no getenv().  The phase-ablation guards of the pair kernels are measurement-only and are
+// honoured only by a library built with EGT_BLOCK_FLAGS=-DEGT_BLOCK_ABLATION; a release build
+// forces them to 0 (a stray variable can then not drop gradient phases) and says so once.
+struct EgtBlockEnv {
+  bool no_xcd_remap, no_kvl, no_epilogue, no_fwd_r4, no_bwd_r4, bwd_v2, no_bwd_ragged, no_bwd_prologue;
+  int fwd_ablate, bwd_ablate, bwd_pf;
+};
+static bool env_flag_raw(const char* name) {
   const char* v = getenv(name);
   return v && v[0] && v[0] != '0';
+}
+static int env_guard_raw(const char* name) {
+  const char* v = getenv(name);
+  const int g = v ? atoi(v) : 0;
+#ifndef EGT_BLOCK_ABLATION
+  if (g) {
+    fprintf(stderr, "[egt] %s=%d ignored: phase ablation needs a build with EGT_BLOCK_FLAGS=-DEGT_BLOCK_ABLATION\n", name, g);
+    return 0;
+  }
+#else
+  if (g) fprintf(stderr, "[egt] %s = %d (ablation build: results are WRONG by design)\n", name, g);
+#endif
+  return g;
+}
+static const EgtBlockEnv& block_env() {
+  static const EgtBlockEnv e = [] {
+    EgtBlockEnv v{};
+    v.no_xcd_remap = env_flag_raw("EGT_NO_XCD_REMAP");
+    v.no_kvl = env_flag_raw("EGT_NO_KVL");
+    v.no_epilogue = env_flag_raw("EGT_NO_EPILOGUE");
+    v.no_fwd_r4 = env_flag_raw("EGT_NO_FWD_R4");
+    v.no_bwd_r4 = env_flag_raw("EGT_NO_BWD_R4");
+    v.bwd_v2 = env_flag_raw("EGT_BWD_V2");
+    v.no_bwd_ragged = env_flag_raw("EGT_NO_BWD_RAGGED");
+    v.no_bwd_prologue = env_flag_raw("EGT_NO_BWD_PROLOGUE");
+    v.fwd_ablate = env_guard_raw("EGT_FWD_ABLATE");
+    v.bwd_ablate = env_guard_raw("EGT_BWD_ABLATE");
+    const char* pf = getenv("EGT_BWD_PF");
+    v.bwd_pf = pf ? atoi(pf) : 0;
+    return v;
+  }();
+  return e;
 }
 
 static int block_check(const egt_block_desc* d, bool report) {
@@ -1861,7 +1901,7 @@ static void bind_ws(const BlockLayout& L, BlockArgs& a, float* wc, float* wl, in
   a.spart_n = a.sbo_n = a.B * ((a.N + NODE_RC - 1) / NODE_RC);   // k_node_bwd's workgroups (prologue path overrides)
   a.ered = wl + L.ered; a.dqkv_sv = wl + L.dqkv;
   a.TL = BWD_TL; a.NLR = L.NLR; a.NQP = 1;
-  a.xcd = egt_env_flag("EGT_NO_XCD_REMAP") ? 0 : 1;
+  a.xcd = block_env().no_xcd_remap ? 0 : 1;
 }
 
 extern "C" size_t egt_block_saved_bytes(const egt_block_desc* d) {
@@ -1938,17 +1978,11 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   if (!skip_pre) egt_node_launch_pre(a, st);   // norm_mha + dense_qkv (packed) [+ edge-weight prep]
   const size_t lds_tiles = (size_t)8 * Geo<DE>::TILE_FLOATS * 4;
   const size_t lds_kv = ((size_t)a.N * KV_LD + 16 * QS_LD + a.N) * 4;
-  const bool kvl = lds_tiles + lds_kv <= 80 * 1024 - 512 && !egt_env_flag("EGT_NO_KVL");   // two workgroups per CU keep their K/V in LDS
+  const bool kvl = lds_tiles + lds_kv <= 80 * 1024 - 512 && !block_env().no_kvl;   // two workgroups per CU keep their K/V in LDS
   const int epi_req = a.epi;
-  if (!(kvl && a.Dh == 64 && a.DK == 8) || egt_env_flag("EGT_NO_EPILOGUE")) a.epi = 0;
+  if (!(kvl && a.Dh == 64 && a.DK == 8) || block_env().no_epilogue) a.epi = 0;
   const bool ml = a.M != nullptr || a.rm != nullptr;
-  { const char* g = getenv("EGT_FWD_ABLATE"); if (g) { a.guard = atoi(g);
-#ifdef EGT_BLOCK_ABLATION
-      static int once = 0; if (!once++) fprintf(stderr, "[egt] forward ablation guard = %d (compiled in)\n", a.guard);
-#else
-      static int once = 0; if (!once++) fprintf(stderr, "[egt] EGT_FWD_ABLATE ignored: build with EGT_BLOCK_FLAGS=-DEGT_BLOCK_ABLATION\n");
-#endif
-  } }
+  a.guard = block_env().fwd_ablate;
   const dim3 grid(a.B * lgroups), block(256);
   const size_t lds = lds_tiles + (kvl ? lds_kv : 0);
 #define FWD_VARIANT_T(KVL_, ML_, FULL_, BF_)                                                           \
@@ -1967,9 +2001,9 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   const bool r4 = lds_r4 <= 80 * 1024 - 512, r8 = !r4 && lds_r8 <= 156 * 1024;
   bool narrow = false;
   if constexpr (DE <= 16) {   // (wider channels would not fit the four rows' state in 256 VGPRs: not instantiated)
-    narrow = !ml && (r4 || r8) && !egt_env_flag("EGT_NO_KVL") && !egt_env_flag("EGT_NO_FWD_R4");
+    narrow = !ml && (r4 || r8) && !block_env().no_kvl && !block_env().no_fwd_r4;
     if (narrow) {
-    if (!(a.Dh == 64 && a.DK == 8) || egt_env_flag("EGT_NO_EPILOGUE")) a.epi = 0; else a.epi = epi_req;
+    if (!(a.Dh == 64 && a.DK == 8) || block_env().no_epilogue) a.epi = 0; else a.epi = epi_req;
 #define R4_LAUNCH_T(FULL_, NW_, BF_)                                                                              \
   do {                                                                                                            \
     (void)hipFuncSetAttribute((const void*)k_block_fwd_r4<DE, FULL_, NW_, BF_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -2003,10 +2037,10 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
   // node-side prologue inside the pair kernel (see bwd_node_prologue): v4 geometry with Dh = 64
   const bool ml = a.M != nullptr || a.rm != nullptr;
   // narrow edge channels without mask tensors run k_block_bwd_v4r, which (with the prologue) also covers ragged N
-  const bool narrow_r = DE <= 16 && !ml && !egt_env_flag("EGT_NO_BWD_R4") && !egt_env_flag("EGT_BWD_V2");
-  const bool rag_ok = !egt_env_flag("EGT_NO_BWD_RAGGED");   // v4 / v4r and the prologue take N that is not a multiple of 16
-  const bool pro = (DE % 16 == 0 || DE == 8) && ((a.N % 16) == 0 || rag_ok) && a.Dh == 64 && a.DK == 8 && !egt_env_flag("EGT_BWD_V2") &&
-                   !egt_env_flag("EGT_NO_BWD_PROLOGUE");
+  const bool narrow_r = DE <= 16 && !ml && !block_env().no_bwd_r4 && !block_env().bwd_v2;
+  const bool rag_ok = !block_env().no_bwd_ragged;   // v4 / v4r and the prologue take N that is not a multiple of 16
+  const bool pro = (DE % 16 == 0 || DE == 8) && ((a.N % 16) == 0 || rag_ok) && a.Dh == 64 && a.DK == 8 && !block_env().bwd_v2 &&
+                   !block_env().no_bwd_prologue;
   a.pro = 0;
   if (pro) {
     a.pro = top ? 1 : 2;
@@ -2033,10 +2067,10 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
   do { if (a.bf16) BWD_VARIANT_T(ML_, FULL_, true); else BWD_VARIANT_T(ML_, FULL_, false); } while (0)
   const bool full = (a.N % 16) == 0;
   if constexpr (DE % 16 == 0 || DE == 8) {
-    if ((full || rag_ok) && !egt_env_flag("EGT_BWD_V2")) {   // register-lean, 2 waves/SIMD
+    if ((full || rag_ok) && !block_env().bwd_v2) {   // register-lean, 2 waves/SIMD
       const size_t lds_v4 = ((size_t)(4 * PW > BWD_PRO_WS ? 4 * PW : BWD_PRO_WS) + (size_t)BWD_TL * QD_LD + 3 * GG::TILES * 256) * 4;
       a.NQP = (a.N + 15) / 16;
-      { const char* e = getenv("EGT_BWD_ABLATE"); a.guard = e ? atoi(e) : 0; }   // measurement only: drops phases
+      a.guard = block_env().bwd_ablate;   // 0 unless this is an ablation build (measurement only: drops phases)
 #define V4_VARIANT_R(ML_, PF_, BF_, RAG_)                                                                  \
   do {                                                                                                 \
     (void)hipFuncSetAttribute((const void*)k_block_bwd_v4<DE, ML_, PF_, BF_, RAG_>,                    \
@@ -2044,8 +2078,7 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
     EGT_LAUNCH("k_block_bwd", (k_block_bwd_v4<DE, ML_, PF_, BF_, RAG_>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a); \
   } while (0)
 #define V4_VARIANT(ML_, PF_, BF_) do { if (full) V4_VARIANT_R(ML_, PF_, BF_, false); else V4_VARIANT_R(ML_, 0, BF_, true); } while (0)
-      const char* pfe = getenv("EGT_BWD_PF");
-      const int pf = pfe ? atoi(pfe) : 0;   // two resident waves hide the HBM latency; prefetch registers only spill
+      const int pf = block_env().bwd_pf;   // two resident waves hide the HBM latency; prefetch registers only spill
       if constexpr (DE <= 16) {
         if (narrow_r) {   // narrow edge channels: R rows per iteration, ragged N included
           constexpr int RR = 2;   // rows per iteration: four spill (the rows' carried state + prefetch exceed 256 VGPRs)
@@ -2111,6 +2144,8 @@ extern "C" int egt_block_bwd(const egt_block_desc* desc, const egt_block_params*
   if (!h || !e || !saved || !d_h_out || !d_e_out || !d_h || !d_e || !grads || !workspace)
     EGT_FAIL(EGT_E_NULL, "h/e/saved/d_h_out/d_e_out/d_h/d_e/grads/workspace is NULL");
   if ((desc->flags & EGT_BF_ATTN_MASK) && !attn_mask) EGT_FAIL(EGT_E_NULL, "ATTN_MASK set but attn_mask is NULL");
+  // every layer's dh' is read again after dh was written (deferred dWo contraction): no in-place dh
+  if (d_h == d_h_out) EGT_FAIL(EGT_E_FLAGS, "d_h must not alias d_h_out (d_e may alias d_e_out)");
   const bool gated = (desc->flags & EGT_BF_GATE) != 0;
   {
     const void* const* gp = reinterpret_cast<const void* const*>(grads);
@@ -2246,6 +2281,7 @@ extern "C" int egt_stack_bwd(const egt_block_desc* desc, int32_t layers, const e
     EGT_FAIL(EGT_E_NULL, "params/grads/h/e/saved/d_h_out/d_e_out/d_h/d_e/workspace is NULL");
   if (block_check(desc, true)) return block_check(desc, true);
   if ((desc->flags & EGT_BF_ATTN_MASK) && !attn_mask) EGT_FAIL(EGT_E_NULL, "ATTN_MASK set but attn_mask is NULL");
+  if (d_h == d_h_out) EGT_FAIL(EGT_E_FLAGS, "d_h must not alias d_h_out (d_e may alias d_e_out)");
   const StackLayout S = stack_layout(desc, layers);
   const BlockLayout L = layout(desc);
   float* sv = (float*)saved;

@@ -56,18 +56,10 @@ class FlatGradAllReduce:
                 p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
 
-    def all_reduce(self, average: bool = True):
+    def all_reduce(self, average: bool = True, local_count=None, global_count=None, force=False):
         """Sum over ranks, then /world: the loss is a mean over the GLOBAL batch
-        (MirroredStrategy semantics)."""
-        if not (dist.is_available() and dist.is_initialized()):
-            return self.flat
-        ws = dist.get_world_size(self.group)
-        if ws == 1:
-            return self.flat
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        if average:
-            self.flat.div_(ws)
-        return self.flat
+        (MirroredStrategy semantics).  See all_reduce_flat for uneven shards."""
+        return all_reduce_flat(self.flat, self.group, average, local_count, global_count, force)
 
 
 def flat_grad_view(params, flat) -> bool:
@@ -84,14 +76,28 @@ def flat_grad_view(params, flat) -> bool:
     return off == flat.numel()
 
 
-def all_reduce_flat(flat, process_group=None, average=True):
-    """The single per-step collective: sum over ranks, then /world."""
+def all_reduce_flat(flat, process_group=None, average=True, local_count=None, global_count=None, force=False):
+    """The single per-step collective.
+
+    average=True, counts omitted: SUM over ranks, then /world — the mean over the GLOBAL batch when
+    every rank holds a gradient of its LOCAL-mean loss and the shards are equal (what
+    MirroredStrategy does with a batch the replica count divides, training_base.py:230-247).
+    local_count / global_count given (shard_batch hands out shards that differ by one graph when
+    world does not divide the batch): each rank's local-mean gradient is weighted by
+    local_count / global_count before the SUM and nothing is divided afterwards, so every graph of
+    the global batch carries the same weight.
+    average=False: plain SUM (the per-rank loss is already scaled by 1 / global batch).
+    force: issue the collective even in a 1-rank group (bench.py / tests: exercises the RCCL call)."""
+    if (local_count is None) != (global_count is None):
+        raise ValueError("local_count and global_count go together")
     if not (dist.is_available() and dist.is_initialized()):
         return flat
     ws = dist.get_world_size(process_group)
-    if ws == 1:
+    if ws == 1 and not force:
         return flat
+    if local_count is not None and average:
+        flat.mul_(float(local_count) / float(global_count))
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
-    if average:
+    if average and local_count is None:
         flat.div_(ws)
     return flat

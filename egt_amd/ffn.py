@@ -78,6 +78,12 @@ class FFN(nn.Module):
         hid = round(width * ffn_multiplier)
         if hid != 2 * width:
             raise ValueError("fused FFN is built for ffn_multiplier = 2")
+        if activation not in _ACT:
+            raise ValueError(f"fused FFN activation must be one of {sorted(_ACT)} (got {activation!r})")
+        # fail at construction for a width the kernels do not cover (there is no composed fallback);
+        # the C library decides (egt_ffn_supported), so the Python side never drifts from it
+        if not L.load().egt_ffn_supported(C.byref(_desc(16, width, activation, 1e-3))):
+            raise ValueError(f"fused FFN does not cover width {width} (fp32)")
         self.width, self.activation = width, activation
         self.norm_gamma = nn.Parameter(torch.ones(width))
         self.norm_beta = nn.Parameter(torch.zeros(width))

@@ -138,9 +138,8 @@ def _block_params(blk, e):
         m = getattr(blk, mod, None)
         params.append(None if m is None else getattr(m, attr))
     if blk.edge_channel_type == "bias":
-        De, H, dev = blk.edge_width, blk.num_heads, e.device
-        params[0] = torch.ones(De, device=dev); params[1] = torch.zeros(De, device=dev)
-        params[12] = torch.zeros(H, De, device=dev); params[13] = torch.zeros(De, device=dev)
+        params[0], params[1] = blk._id_gamma, blk._id_beta       # constants owned by the block (no per-call allocation)
+        params[12], params[13] = blk._zero_Wr, blk._zero_br
     return params
 
 

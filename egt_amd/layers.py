@@ -189,6 +189,14 @@ class EGTBlock(nn.Module):
         self.dense_mha = KerasDense(model_width, model_width)
         if edge_channel_type in ('residual', 'constrained'):
             self.dense_edge_r = KerasDense(num_heads, edge_width)
+        if edge_channel_type == 'bias':
+            # EGT-simple has no norm_edge / dense_edge_r (:173-190); the fused kernel takes identity LN
+            # parameters and a zero update instead (EGT_BF_NO_EDGE_LN).  Constants, not parameters:
+            # non-persistent buffers that follow .to(device) -- nothing is allocated per call.
+            self.register_buffer('_id_gamma', torch.ones(edge_width), persistent=False)
+            self.register_buffer('_id_beta', torch.zeros(edge_width), persistent=False)
+            self.register_buffer('_zero_Wr', torch.zeros(num_heads, edge_width), persistent=False)
+            self.register_buffer('_zero_br', torch.zeros(edge_width), persistent=False)
 
     # ---- composed path: HIP edge/attention kernels + torch node-side Dense ----
     def _mha_block(self, h, e_b, gates, mask, attn_mask, rand_mask):
@@ -320,6 +328,8 @@ class EGTLayerStack(nn.Module):
             [EGTBlock(seed=seed * 1000 + i, model_width=model_width, edge_width=edge_width, **block_kwargs)
              for i in range(model_height)])
         ect = block_kwargs.get('edge_channel_type', 'residual')
+        # FFN.__init__ raises ValueError for a width the fused FFN kernels do not cover (at
+        # construction, not at the first forward: ADVICE r1)
         self.ffn_node = nn.ModuleList([FFN(model_width, activation=activation) for _ in range(model_height)])
         self.ffn_edge = nn.ModuleList([FFN(edge_width, activation=activation) for _ in range(model_height)]) \
             if ect in ('residual', 'constrained') else None

@@ -135,7 +135,9 @@ def egt_forward(QKV: torch.Tensor,
         V_att = V_att * degree_scalers
 
     V_att = V_att.reshape(B, N, d * H)                        # :139-141
-    return V_att, H_hat, A_tild
+    # :116-117 / :202-203 REASSIGN A_tild = tf.nn.dropout(A_tild, ...): the third output is the
+    # post-dropout matrix (identical to A_tild when attention dropout is off)
+    return V_att, H_hat, A_drop
 
 
 def egt_backward(QKV, E, G, M, mask, dV_att, dH_ext, *, num_heads=8,

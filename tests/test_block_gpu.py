@@ -226,7 +226,7 @@ def test_fused_accepts_unaligned_parameter_views(gpu, egt_lib):
         (h2.sum() + (e2 * e2).sum()).backward()
         outs.append((h2.detach(), e2.detach(), hh.grad, ee.grad, blk.dense_qkv.kernel.grad, blk.dense_edge_r.bias.grad))
     for n, u, v in zip(("h", "e", "dh", "de", "dWqkv", "dbr"), *outs):
-        assert_close(u, v, name=n, rtol=1e-3, arel=2e-4, floor=0.1)
+        assert_close(u, v, name=n, rtol=1e-3, arel=2e-4, l2=2e-3)
 
 
 @pytest.mark.parametrize("N,De,Dh,train,Ly", [(32, 64, 64, True, 3), (20, 8, 64, False, 2), (37, 48, 48, True, 2),
@@ -276,7 +276,7 @@ def test_stack_bf16_edge_tensors_vs_oracle(N, De, Dh, train, Ly, gpu, egt_lib):
     gi = iter(gr[2:])
     for li, blk in enumerate(st.blocks):
         for k, (m, a_) in PMAP.items():
-            assert_close(getattr(getattr(blk, m), a_).grad, next(gi), name=f"L{li}.{k}", rtol=3e-2, arel=2e-2, floor=0.1)
+            assert_close(getattr(getattr(blk, m), a_).grad, next(gi), name=f"L{li}.{k}", rtol=3e-2, arel=2e-2, l2=3e-2)
 
 
 def test_block_bf16_single_block_and_dtype_errors(gpu, egt_lib):

@@ -135,3 +135,48 @@ def test_all_reduce_flat_adopted_views_gloo_ws2():
     for r in res:
         assert r[1] is True and r[2] is False
         assert r[3] == want and r[4] == want[6:]   # the .grad views see the reduced values
+
+
+def _worker_uneven(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from egt_amd.dp import FlatGradAllReduce, shard_batch
+        Bg = 7                                           # world does not divide the global batch
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(Bg, 4, generator=g, dtype=torch.float64)
+        w0 = torch.randn(4, 3, generator=g, dtype=torch.float64)
+        lo, hi = shard_batch(Bg, world, rank)
+        w = torch.nn.Parameter(w0.clone())
+        fa = FlatGradAllReduce([w])
+        (x[lo:hi] @ w).pow(2).sum(1).mean().backward()   # LOCAL-mean loss, as a replica computes it
+        naive = fa.flat.clone()
+        fa.all_reduce(average=True, local_count=hi - lo, global_count=Bg)
+        wf = torch.nn.Parameter(w0.clone())
+        (x @ wf).pow(2).sum(1).mean().backward()         # the global-batch mean
+        err = float((fa.flat.view_as(wf) - wf.grad).abs().max())
+        # the unweighted SUM / world differs whenever the shards differ in size
+        t = naive.clone(); dist.all_reduce(t); t /= world
+        err_naive = float((t.view_as(wf) - wf.grad).abs().max())
+        q.put((rank, hi - lo, err, err_naive))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_uneven_shards_weighted_allreduce_gloo_ws2():
+    """shards that differ by one graph must not over-weight the smaller shard."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [4, 3]
+    for r in res:
+        assert r[2] < 1e-12, f"weighted all-reduce is not the global mean: {r[2]}"
+        assert r[3] > 1e-6, "control: the unweighted mean should differ for uneven shards"
