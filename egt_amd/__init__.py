@@ -5,10 +5,13 @@ Public surface (mirrors the reference's operator interface for this path):
     egt_attention, edge_proj, edge_update        (egt_amd.functional)
     FlatGradAllReduce, shard_batch               (egt_amd.dp)
     FFN, ffn                                     (egt_amd.ffn: the ffn_block step after the attention block)
+    node_mask_from_features, node_mask_from_masking, constrained_edge_mask   (egt_amd.masks: mask producers)
 """
 from .layers import EGT, EGTBlock, EGTStack, EGTLayerStack, custom_layers, KerasDense, KerasLayerNorm  # noqa: F401
 from .functional import AttnConfig, egt_attention, edge_proj, edge_update, mask_sample  # noqa: F401
 from .ffn import FFN, ffn  # noqa: F401
+from .masks import node_mask_from_features, node_mask_from_masking, constrained_edge_mask  # noqa: F401
 
 __all__ = ["EGT", "EGTBlock", "EGTStack", "EGTLayerStack", "custom_layers", "AttnConfig", "egt_attention",
-           "edge_proj", "edge_update", "mask_sample", "FFN", "ffn"]
+           "edge_proj", "edge_update", "mask_sample", "FFN", "ffn", "node_mask_from_features",
+           "node_mask_from_masking", "constrained_edge_mask"]

@@ -102,6 +102,9 @@ _PROTOS = {
     "egt_edge_update_fwd": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 6),
     "egt_edge_update_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(EdgeDesc)]),
     "egt_edge_update_bwd": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 8),
+    "egt_node_mask_from_features": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP]),
+    "egt_node_mask_from_float_features": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _VP, _VP]),
+    "egt_constrained_edge_mask": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, _VP]),
     "egt_prof_enable": (C.c_int, [C.c_int]),
     "egt_prof_filter": (C.c_int, [C.c_char_p]),
     "egt_prof_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

@@ -199,7 +199,17 @@ class EGTBlock(nn.Module):
             self.register_buffer('_zero_br', torch.zeros(edge_width), persistent=False)
 
     # ---- composed path: HIP edge/attention kernels + torch node-side Dense ----
-    def _mha_block(self, h, e_b, gates, mask, attn_mask, rand_mask):
+    @staticmethod
+    def _dropout(x, rate, training, keep):
+        """keras.layers.Dropout: inverted scaling on the kept elements, training only.  `keep`
+        injects the sample (parity tests); otherwise torch's device RNG draws it."""
+        if rate <= 0 or not training:
+            return x
+        if keep is not None:
+            return x * (keep.to(x.dtype) / (1.0 - rate))
+        return F.dropout(x, rate, True)
+
+    def _mha_block(self, h, e_b, gates, mask, attn_mask, rand_mask, node_keep=None):
         y = h                                                       # :107
         if not self.add_n_norm:
             h = self.norm_mha(h)                                    # :109
@@ -215,17 +225,16 @@ class EGTBlock(nn.Module):
             inputs.append(attn_mask)
         v_att, h_hat, _ = self.mha(inputs, mask=mask, rand_mask=rand_mask)   # :117-131
         h = self.dense_mha(v_att)                                   # :136
-        if self.node_dropout > 0:
-            h = F.dropout(h, self.node_dropout, self.training)      # :138-139
+        h = self._dropout(h, self.node_dropout, self.training, node_keep)   # :138-139
         h = h + y                                                   # :140
         if self.add_n_norm:
             h = self.norm_mha(h)                                    # :142-143
         return h, h_hat
 
-    def forward(self, h, e, mask=None, attn_mask=None, rand_mask=None):
+    def forward(self, h, e, mask=None, attn_mask=None, rand_mask=None, node_keep=None, edge_keep=None):
         ect = self.edge_channel_type
         if ect == 'none':                                           # :164-171
-            h, _ = self._mha_block(h, None, None, mask, attn_mask, rand_mask)
+            h, _ = self._mha_block(h, None, None, mask, attn_mask, rand_mask, node_keep)
             return h, e
         if self._use_fused(h, e, attn_mask, rand_mask):
             from .fused import block_fused
@@ -239,13 +248,13 @@ class EGTBlock(nn.Module):
             self.dense_edge_b.kernel, self.dense_edge_b.bias,
             use_ln=use_ln, edge_activation=self.edge_activation, eps=LN_EPS,
             passthrough=True)                                                  # :195-208
-        h, h_hat = self._mha_block(h, e_b, gates, mask, attn_mask, rand_mask)  # :212
+        h, h_hat = self._mha_block(h, e_b, gates, mask, attn_mask, rand_mask, node_keep)  # :212
         if ect == 'bias':
             return h, e                                             # :190 (returns e0)
-        if self.edge_dropout > 0:
+        if self.edge_dropout > 0 and self.training:
             # dropout sits between dense_edge_r and the residual add (:214-218)
             y = h_hat @ self.dense_edge_r.kernel + self.dense_edge_r.bias
-            e = F.dropout(y, self.edge_dropout, self.training) + e
+            e = self._dropout(y, self.edge_dropout, True, edge_keep) + e
         else:
             e = EF.edge_update(e, h_hat, self.dense_edge_r.kernel, self.dense_edge_r.bias)
         if self.add_n_norm:

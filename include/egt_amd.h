@@ -333,6 +333,25 @@ int egt_ffn_bwd(const egt_ffn_desc* desc, const egt_ffn_params* params, const vo
                 const void* dy, void* dx, const egt_ffn_params* grads, void* workspace,
                 void* stream);
 
+/* ---- mask producers (integer / boolean work: bit-exact) ---------
+ * The masks the path consumes are produced by the model around it; these entry points replace
+ *   Neg1MaskedEmbedding.compute_mask   lib/base/xformer_layers/masking.py:35-43   (x + 1) != 0
+ *   keras.layers.Masking(mask_value)   lib/models/cifar10/dc.py:69               any(x != v, -1)
+ *   VirtualNodeEmbedding.compute_mask  lib/base/graph_layers/virtual_nodes.py:47-50
+ *   AdjMatModel.get_edge_mask          lib/models/graph_model_base.py:131-142     tile(adj, H)
+ *   VNModel.get_edge_mask              lib/models/graph_model_base.py:248-268     ones for VN rows/cols
+ * features [B,N] int32 (padding value -1)  ->  mask [B, num_virtual_nodes + N] uint8 (1 = real node) */
+int egt_node_mask_from_features(const int32_t* features, int32_t B, int32_t N, int32_t num_virtual_nodes,
+                                uint8_t* mask, void* stream);
+/* features [B,N,width] fp32 -> mask [B, num_virtual_nodes + N] uint8: some feature != mask_value */
+int egt_node_mask_from_float_features(const float* features, int32_t B, int32_t N, int32_t width,
+                                      float mask_value, int32_t num_virtual_nodes, uint8_t* mask,
+                                      void* stream);
+/* adj [B,N,N] fp32 -> M [B, nv+N, nv+N, H] fp32 (nv = num_virtual_nodes): the attention mask of
+ * edge_channel_type 'constrained' as the inner op / fused block take it */
+int egt_constrained_edge_mask(const float* adj, int32_t B, int32_t N, int32_t H, int32_t num_virtual_nodes,
+                              float* M, void* stream);
+
 /* ---- per-kernel timing (measurement only) ------------------------------------
  * egt_prof_enable(1) makes every launch site bracket its kernel with hipEvents
  * on the launch stream (2 = reset counters and enable, 0 = off).  After the

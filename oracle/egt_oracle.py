@@ -300,13 +300,20 @@ def block_forward(h, e, mask, params, *, num_heads=8,
                   clip_logits_value=(-5.0, 5.0), scale_degree=False,
                   scaler_type="log", num_virtual_nodes=0, edge_activation=None,
                   attn_mask=None, rand_mask=None, drop_keep=None,
-                  attn_dropout=0.0, add_n_norm=False, return_inner=False):
+                  attn_dropout=0.0, add_n_norm=False, return_inner=False,
+                  node_keep=None, node_dropout=0.0, edge_keep=None, edge_dropout=0.0):
     """(h, e, mask) -> (h', e'): graph_xformer_model_base.py:192-223 (residual /
     constrained), :173-190 (bias), :164-171 (none), with mha_block :106-145.
-    Node/edge dropout (:138-139, :216-217) are identity here (rate 0 in every
-    shipped config; scheme_base.py:22)."""
+    Node/edge dropout (drp_mha :138-139, drp_edge :216-217; rate 0 in every shipped
+    config, scheme_base.py:22) take an INJECTED keep mask (Keras Dropout = inverted
+    scaling 1/(1-rate) on the kept elements); identity when no mask is given."""
     p = params
     H = num_heads
+
+    def drop(x, keep, rate):
+        if keep is None or rate <= 0.0:
+            return x
+        return x * keep.to(x.dtype) / (1.0 - rate)
 
     def mha_block(h, e_b, gates):
         y = h                                                       # :107
@@ -320,6 +327,7 @@ def block_forward(h, e, mask, params, *, num_heads=8,
             scaler_type=scaler_type, num_virtual_nodes=num_virtual_nodes,
             rand_mask=rand_mask, drop_keep=drop_keep, attn_dropout=attn_dropout)
         ho = dense(v_att, p["dense_mha.kernel"], p["dense_mha.bias"])  # :136
+        ho = drop(ho, node_keep, node_dropout)                      # :138-139
         ho = ho + y                                                 # :140
         if add_n_norm:                                              # :142-143
             ho = layer_norm(ho, p["norm_mha.gamma"], p["norm_mha.beta"])
@@ -348,6 +356,7 @@ def block_forward(h, e, mask, params, *, num_heads=8,
             dense(en, p["dense_edge_b.kernel"], p["dense_edge_b.bias"]), edge_activation)
         h2, h_hat, a_tild = mha_block(h, e_b, gates)
         e2 = dense(h_hat, p["dense_edge_r.kernel"], p["dense_edge_r.bias"])  # :214
+        e2 = drop(e2, edge_keep, edge_dropout)                      # :216-217
         e2 = e2 + y                                                 # :218
         if add_n_norm:
             e2 = layer_norm(e2, p["norm_edge.gamma"], p["norm_edge.beta"])
@@ -389,12 +398,33 @@ def stack_forward(h, e, mask, layer_params, **kw):
 # --------------------------------------------------------------------------
 # mask producers
 # --------------------------------------------------------------------------
-def node_mask_from_features(node_features: torch.Tensor) -> torch.Tensor:
-    """Neg1MaskedEmbedding.compute_mask (masking.py:35-43): (x+1) != 0."""
-    return (node_features + 1) != 0
+def node_mask_from_features(node_features: torch.Tensor, num_virtual_nodes: int = 0) -> torch.Tensor:
+    """Neg1MaskedEmbedding.compute_mask (masking.py:35-43): Embedding(mask_zero=True) on
+    inputs+1, i.e. (x+1) != 0.  VirtualNodeEmbedding.compute_mask (virtual_nodes.py:47-50)
+    prepends num_virtual_nodes True entries."""
+    m = (node_features + 1) != 0
+    if num_virtual_nodes > 0:
+        m = torch.cat([torch.ones(m.shape[0], num_virtual_nodes, dtype=torch.bool), m], dim=1)
+    return m
 
 
-def constrained_edge_mask(adj: torch.Tensor, num_heads: int) -> torch.Tensor:
-    """AdjMatModel.get_edge_mask (graph_model_base.py:131-142): tile adjacency
-    over heads."""
-    return adj[..., None].repeat(1, 1, 1, num_heads)
+def node_mask_from_masking(node_features: torch.Tensor, mask_value: float = -1.0,
+                           num_virtual_nodes: int = 0) -> torch.Tensor:
+    """keras.layers.Masking(mask_value) (cifar10/dc.py:69): a step is kept when any of its
+    features differs from mask_value."""
+    m = (node_features != mask_value).any(dim=-1)
+    if num_virtual_nodes > 0:
+        m = torch.cat([torch.ones(m.shape[0], num_virtual_nodes, dtype=torch.bool), m], dim=1)
+    return m
+
+
+def constrained_edge_mask(adj: torch.Tensor, num_heads: int, num_virtual_nodes: int = 0) -> torch.Tensor:
+    """AdjMatModel.get_edge_mask (graph_model_base.py:131-142): tile adjacency over heads;
+    VNModel.get_edge_mask (:248-268): concat ones rows (axis 1), then ones columns (axis 2)."""
+    M = adj[..., None].repeat(1, 1, 1, num_heads)
+    nv = num_virtual_nodes
+    if nv > 0:
+        B, N1, N2, H = M.shape
+        M = torch.cat([torch.ones(B, nv, N2, H, dtype=M.dtype), M], dim=1)
+        M = torch.cat([torch.ones(B, N1 + nv, nv, H, dtype=M.dtype), M], dim=2)
+    return M

@@ -230,7 +230,11 @@ def test_fused_accepts_unaligned_parameter_views(gpu, egt_lib):
 
 
 @pytest.mark.parametrize("N,De,Dh,train,Ly", [(32, 64, 64, True, 3), (20, 8, 64, False, 2), (37, 48, 48, True, 2),
-                                              (64, 64, 64, False, 1)])
+                                              (64, 64, 64, False, 1),
+                                              # BASELINE config 3 as specified (CIFAR10 shapes, bf16): N = 150 selects the
+                                              # 32-row / 8-wave forward k_block_fwd_r4<8,false,8,true> and the ragged
+                                              # two-row backward k_block_bwd_v4r<8,true,2>; N = 160 their 16-row-exact forms
+                                              (150, 8, 64, True, 2), (160, 8, 64, False, 2), (120, 8, 64, True, 2)])
 def test_stack_bf16_edge_tensors_vs_oracle(N, De, Dh, train, Ly, gpu, egt_lib):
     """EGT_BF16 (BASELINE config 3's dtype): e / e' / de' / de are bfloat16 in HBM, arithmetic fp32.
     The fp64 oracle gets the SAME bf16-rounded inputs; tolerance is SURVEY §8(c)'s bf16 figure

@@ -89,10 +89,11 @@ def one_attn(N, d, opts, B, dev, seed):
             CS.attn_oracle(inp, attrs))
 
 
-def main():
+def main(seed=None, n_stack=None, n_attn=70, n_ffn=24):
     dev = torch.device("cuda", 0)
     import os
-    seed = int(os.environ.get("EGT_SWEEP_SEED", "2024"))   # other seeds: other geometries / feature mixes
+    if seed is None:
+        seed = int(os.environ.get("EGT_SWEEP_SEED", "2024"))   # other seeds: other geometries / feature mixes
     rnd = random.Random(seed)
     Ns = [1, 2, 3, 7, 15, 16, 17, 31, 32, 33, 47, 48, 49, 64, 65, 80]
     if seed != 2024:
@@ -104,6 +105,8 @@ def main():
                            rnd.random() < 0.8, rnd.random() < 0.5, rnd.choice([1, 2, 3]), rnd.choice([1, 2, 5])))
     combos += [(64, 64, 8, True, True, 3, 4), (64, 64, 8, False, False, 2, 3), (128, 64, 8, True, True, 1, 2),
                (16, 64, 8, True, False, 2, 1), (96, 16, 8, True, True, 2, 2)]
+    if n_stack is not None:
+        combos = combos[:n_stack]
     bad = 0
     for i, (N, De, d, gated, train, Ly, B) in enumerate(combos):
         try:
@@ -115,7 +118,7 @@ def main():
                 traceback.print_exc()
     print(f"sweep: {len(combos) - bad}/{len(combos)} geometries ok")
     nat = 0
-    for i in range(70):
+    for i in range(n_attn):
         N = rnd.choice([1, 2, 3, 5, 15, 16, 17, 33, 48, 63, 64, 70])
         d = rnd.choice([1, 2, 3, 5, 8, 8, 16, 32, 64])
         opts = dict(edge=rnd.random() < 0.8, gate=rnd.random() < 0.7, attn_mask=rnd.random() < 0.3,
@@ -134,7 +137,7 @@ def main():
     # channel FFN: random row counts / widths / activations
     from test_ffn_gpu import _run as ffn_run
     nf = 0
-    for i in range(24):
+    for i in range(n_ffn):
         W = rnd.choice([16, 32, 48, 64])
         shape = rnd.choice([(1,), (rnd.randint(1, 70),), (rnd.randint(1, 5), rnd.randint(1, 40)),
                             (rnd.randint(1, 3), rnd.randint(2, 33), rnd.randint(2, 33))])
