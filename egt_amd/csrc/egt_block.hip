@@ -1455,6 +1455,367 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
     out[i] = (sm[i] + sm[G::EP + i]) + (sm[2 * G::EP + i] + sm[3 * G::EP + i]);
 }
 
+// ================================================ backward, LDS-DMA staged ("v5") ====
+// k_block_bwd_v4 with the HBM latency of the two streamed tiles taken off the wave's critical path
+// WITHOUT spending registers (v4's register prefetch spills at two waves per SIMD):
+//  * the e tile of row l+1 is fetched by LDS-DMA (global_load_lds_dwordx4: HBM -> LDS, no VGPR
+//    destination) into the second e-tile buffer while row l is being computed; the wave counts its
+//    own vmcnt for it (hipcc does not see inline-asm memory operations).  The DMA writes lane-linear
+//    1 KiB chunks, so the XOR swizzle of the De = 64 tile goes on the SOURCE address (lane L of
+//    chunk i fetches slot (L & 15) ^ row of row 4i + (L >> 4)); reads stay swizzled as before.
+//    It is issued after the wave's only compiler-counted loads of the iteration (de') have been
+//    waited for, so no compiler wait ever covers a DMA in flight;
+//  * the de' tile of row l is requested at the top of the iteration and consumed after P1 (LayerNorm +
+//    projections need only e): its latency hides under P1 and the partner wave;
+//  * de leaves from the registers that hold it (64-byte row segments, the four stores of a tile fill
+//    whole lines) instead of making an LDS round trip through a second de' buffer.
+// Same LDS footprint as v4 (two e buffers + one de' buffer instead of one + two): two workgroups per CU.
+// fp32 edge tensors, no mask tensors, N a multiple of 16, De a multiple of 16.
+template <int DE>
+__device__ __forceinline__ unsigned dma_lane_offset(int lane) {
+  // byte offset (inside the tile) of the 16-byte piece lane `lane` fetches for chunk 0
+  if (DE == 64) return (unsigned)((lane >> 4) * 256 + (((lane & 15) ^ (lane >> 4)) << 4));
+  return (unsigned)(lane * 16);
+}
+// one 16-pair tile HBM -> LDS; `lds` = byte address of the tile in LDS (wave-uniform), `src` = the
+// tile's first byte in HBM (wave-uniform), off0 = dma_lane_offset.  Chunk i (rows 4i .. 4i+3 at
+// De = 64) differs from chunk 0 by +1024 i bytes and, for the swizzle, by flipping slot bits 2..3
+// with i: one XOR with 1088 i (the offsets of chunk 0 are < 1024, so the add is an OR is an XOR).
+template <int DE>
+__device__ __forceinline__ void tile_dma(unsigned lds, const float* src, unsigned off0) {
+  constexpr int NI = Geo<DE>::NF4 / 64;
+  static_assert(Geo<DE>::NF4 % 64 == 0 && NI >= 1 && NI <= 4, "whole 1 KiB chunks");
+  unsigned keep, t;
+  constexpr unsigned X = DE == 64 ? 1088u : 1024u;
+  if (NI == 4)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
+        "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+        "v_xor_b32 %1, %6, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+        "v_xor_b32 %1, %7, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X), "i"(2 * X), "i"(3 * X) : "memory", "scc");
+  else if (NI == 3)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
+        "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+        "v_xor_b32 %1, %6, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X), "i"(2 * X) : "memory", "scc");
+  else if (NI == 2)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
+        "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X) : "memory", "scc");
+  else
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep) : "s"(src), "v"(off0), "s"(lds) : "memory");
+  (void)t;
+}
+// wait until at most N of the wave's vector-memory operations are outstanding (they retire in order)
+template <int N_>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N_) : "memory"); }
+
+template <int DE>
+__global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
+  using G = Geo<DE>;
+  const float* e_in = a.e;
+  const float* dey_in = a.de_out;
+  float* dex_o = a.de;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = lane & 15, q = lane >> 4;
+  const int N = a.N, TL = a.TL;
+  const int wg = a.xcd ? egt_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int b = wg / a.NLR, lr = wg % a.NLR;
+  const int l_begin = lr * TL, l_end = min(N, l_begin + TL), nl = l_end - l_begin;
+  const bool gated = (a.flags & EGT_BF_GATE) != 0;
+  const bool clip = (a.flags & EGT_BF_CLIP) != 0;
+  constexpr int PW = 3 * G::TILE_FLOATS + 256 + 192;
+  constexpr int WSLAB = G::TILES * 256;      // one weight slab: [TILES][64 lanes] float4
+  float* et0 = sm + wave * PW;               // e / xhat tile, two buffers (row parity)
+  float* dt = et0 + 2 * G::TILE_FLOATS;      // de' tile
+  float* sc1 = dt + G::TILE_FLOATS;
+  float* sc2 = sc1 + 256;
+  constexpr int AREA = 4 * PW > BWD_PRO_WS ? 4 * PW : BWD_PRO_WS;   // per-wave tiles; also the prologue's scratch
+  float* qd = sm + AREA;                     // [TL][QD_LD]
+  float* wsA = qd + TL * QD_LD;              // prologue weights   wA[4t+u]
+  float* wsB = wsA + WSLAB;                  // dH_ext weights     wrB[4t+u]
+  float* wsD = wsB + WSLAB;                  // d(ehat) weights    wD[t][s]
+  // LDS byte address of the wave's e buffers (the kernel's only LDS object is the dynamic array: offset 0)
+  const unsigned et_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)et0);
+  const unsigned off0 = dma_lane_offset<DE>(lane);
+  for (int i = threadIdx.x; i < nl * 40; i += 256) {
+    const int r = i / 40, f = i % 40;
+    const size_t rowl = (size_t)b * N + l_begin + r;
+    if (a.pro && f >= 16 && f < 32) continue;   // dV_att comes from the prologue below
+    const float* src = f < 16 ? a.qkvp + rowl * QKVP + f * 4
+                     : f < 32 ? a.dvp + rowl * 64 + (f - 16) * 4
+                              : a.stats + rowl * 32 + (f - 32) * 4;
+    float4 v = *reinterpret_cast<const float4*>(src);
+    if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
+    *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
+  }
+  if (a.pro) {
+    __syncthreads();
+    bwd_node_prologue<DE>(a, sm, qd, b, l_begin, wg);
+  }
+  // weight slabs: element (t, lane, u)
+  for (int i = threadIdx.x; i < G::TILES * 256; i += 256) {
+    const int t = i >> 8, ln = (i >> 2) & 63, u = i & 3, pp = ln & 15, qq = ln >> 4;
+    const int c = 16 * t + 4 * qq + u;
+    wsA[i] = a.pw[c * 16 + pp];
+    const int hd = 2 * (pp >> 2) + (pp & 1);
+    wsB[i] = ((pp & 2) == 0 && c < DE) ? a.Wr[hd * DE + c] : 0.f;
+    wsD[i] = a.pw[(16 * t + pp) * 16 + 4 * qq + u];
+  }
+  float c2r[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c2r[r] = a.pw[G::DEP * 16 + 4 * q + r];
+
+  v4f accT[G::TILES], accR[G::TILES];
+#pragma unroll
+  for (int t = 0; t < G::TILES; ++t) { accT[t] = (v4f){0.f, 0.f, 0.f, 0.f}; accR[t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();   // the prologue's scratch (= the tile area) is dead from here: DMA may land in it
+
+  const int ntile = N / 16;
+  for (int mt = wave; mt < ntile; mt += 4) {
+    const int m0 = mt * 16, m = m0 + p;
+    // first e tile of this key tile: in flight while K / V are fetched
+    tile_dma<DE>(et_lds, e_in + (((size_t)b * N + l_begin) * N + m0) * DE, off0);
+    float Kf[16], Vf[16], dKa[16], dVa[16];
+    const size_t rowm = (size_t)b * N + m;
+    {
+      const float4* kp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 64 + q * 16);
+      const float4* vp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 128 + q * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 kv = kp[i], vv = vp[i];
+        Kf[4*i] = kv.x; Kf[4*i+1] = kv.y; Kf[4*i+2] = kv.z; Kf[4*i+3] = kv.w;
+        Vf[4*i] = vv.x; Vf[4*i+1] = vv.y; Vf[4*i+2] = vv.z; Vf[4*i+3] = vv.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { dKa[i] = 0.f; dVa[i] = 0.f; }
+    }
+    const float kadd = (a.km && a.km[rowm] == 0) ? -EGT_NEG : 0.0f;
+
+    for (int l = l_begin; l < l_end; ++l) {
+      const int li = l - l_begin;
+      const size_t rowl = (size_t)b * N + l;
+      const size_t pair0 = rowl * N + m0;
+      float* et = et0 + (li & 1) * G::TILE_FLOATS;
+      MaskRegs mr{make_float2(1.f, 1.f), 0};
+      // ---- de'(l): requested now, consumed after P1 ----
+      TileRegs<DE> td;
+      tile_gload<DE>(td, dey_in + pair0 * DE, lane, 16);
+      // ---- e(l) has been in flight for a whole iteration: retire it.  Younger operations of this wave:
+      // row l-1's dQ-partial store and its NI de stores, then the NI de' loads just issued ----
+      if (li == 0) vm_wait<0>(); else vm_wait<2 * ((G::NF4 + 63) / 64) + 1>();
+      SCHED_FENCE();
+      // ---- P1: norm_edge, projections (recompute) ----
+      float rstd;
+      v4f acc = {c2r[0], c2r[1], c2r[2], c2r[3]};
+      {
+        float4 x[G::TILES];
+#pragma unroll
+        for (int t = 0; t < G::TILES; ++t) x[t] = frag_read<DE>(et, p, q, t);
+        rstd = ln_frags<DE>(x, q, a.ln_eps, (a.flags & EGT_BF_NO_EDGE_LN) == 0);
+#pragma unroll
+        for (int t = 0; t < G::TILES; ++t) {
+          frag_write<DE>(et, p, q, t, x[t]);     // xhat stays in the tile for the later phases
+          const float4 w = *reinterpret_cast<const float4*>(wsA + (t * 64 + lane) * 4);
+          acc = MFMA(w.x, x[t].x, acc);
+          acc = MFMA(w.y, x[t].y, acc);
+          acc = MFMA(w.z, x[t].z, acc);
+          acc = MFMA(w.w, x[t].w, acc);
+        }
+      }
+      SCHED_FENCE();
+      tile_lds_put<DE>(dt, td, lane, 16);   // (the compiler's own vmcnt wait for de' sits here)
+      lds_sync();
+      // ---- e(l+1) -> the other e buffer (its last reader, row l-1's P5, retired its LDS reads) ----
+      if (l + 1 < l_end)
+        tile_dma<DE>(et_lds + (unsigned)(((li + 1) & 1) * G::TILE_FLOATS * 4), e_in + (pair0 + (size_t)N) * DE, off0);
+      SCHED_FENCE();
+      // ---- P2: dH_ext = de'.Wr^T ----
+      v4f dhx = {0.f, 0.f, 0.f, 0.f};
+      if (!(a.guard & 8))
+#pragma unroll
+      for (int t = 0; t < G::TILES; ++t) {
+        const float4 dyv = frag_read<DE>(dt, p, q, t);
+        const float4 w = *reinterpret_cast<const float4*>(wsB + (t * 64 + lane) * 4);
+        dhx = MFMA(w.x, dyv.x, dhx);
+        dhx = MFMA(w.y, dyv.y, dhx);
+        dhx = MFMA(w.z, dyv.z, dhx);
+        dhx = MFMA(w.w, dyv.w, dhx);
+      }
+      SCHED_FENCE();
+      // ---- P3: logits, softmax/gate backward, dQ/dK/dV ----
+      float dge[4], hh[2], dA[2], at[2];
+      {
+        const float* qr = qd + li * QD_LD;
+        float dots[2], dAd[2];
+        {
+          const float4* qp = reinterpret_cast<const float4*>(qr + q * 16);
+          const float4* dp = reinterpret_cast<const float4*>(qr + 64 + q * 16);
+          float d0 = 0.f, d1 = 0.f, e0 = 0.f, e1 = 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float4 u = qp[i], v = dp[i];
+            d0 = fmaf(u.x, Kf[4*i], d0);   d1 = fmaf(u.y, Kf[4*i+1], d1);
+            d0 = fmaf(u.z, Kf[4*i+2], d0); d1 = fmaf(u.w, Kf[4*i+3], d1);
+            e0 = fmaf(v.x, Vf[4*i], e0);   e1 = fmaf(v.y, Vf[4*i+1], e1);
+            e0 = fmaf(v.z, Vf[4*i+2], e0); e1 = fmaf(v.w, Vf[4*i+3], e1);
+          }
+          dots[0] = d0; dots[1] = d1; dAd[0] = e0; dAd[1] = e1;
+        }
+        const float4* sp = reinterpret_cast<const float4*>(qr + 128 + q * 8);
+        const float4 s0 = sp[0], s1 = sp[1];
+        const float st[8] = {s0.x, s0.y, s0.z, 0.f, s1.x, s1.y, s1.z, 0.f};
+        float xl[2], gl[2], inr[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float araw = dots[j] * a.scale;
+          float ah = araw;
+          inr[j] = 1.0f;
+          if (clip) {
+            inr[j] = (araw >= a.clip_lo && araw <= a.clip_hi) ? 1.0f : 0.0f;
+            ah = fminf(fmaxf(araw, a.clip_lo), a.clip_hi);
+          }
+          hh[j] = ah + acc[2 * j + 1];
+          xl[j] = hh[j];
+          gl[j] = acc[2 * j];
+        }
+        apply_masks<false>(a, kadd, mr, (pair0 + p) * BH, q, xl, gl);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float S = __expf(xl[j] - st[4 * j]) * st[4 * j + 1];
+          const float g = gated ? egt_sigmoid(gl[j]) : 1.0f;
+          const float dS = dAd[j] * g;
+          const float dGl = gated ? dAd[j] * S * g * (1.0f - g) : 0.f;
+          const float dH = S * (dS - st[4 * j + 2]) + dhx[j];
+          dA[j] = dH * inr[j] * a.scale;
+          at[j] = S * g;
+          dge[2 * j] = dGl;
+          dge[2 * j + 1] = dH;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ssum[r] += dge[r];
+      *reinterpret_cast<float4*>(sc1 + p * 16 + 4 * q) = make_float4(dge[0], dge[1], dge[2], dge[3]);
+      *reinterpret_cast<float2*>(sc2 + p * 12 + 2 * q) = make_float2(hh[0], hh[1]);
+      if (q == 0) sc2[p * 12 + 8] = 1.0f;
+      lds_sync();
+      SCHED_FENCE();
+      if (!(a.guard & 4)) {
+        const float* qr = qd + li * QD_LD;
+        const float4* qp = reinterpret_cast<const float4*>(qr + q * 16);
+        const float4* dp = reinterpret_cast<const float4*>(qr + 64 + q * 16);
+        float dq[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 u = qp[i], v = dp[i];
+          dKa[4*i]   = fmaf(dA[0], u.x, dKa[4*i]);   dKa[4*i+1] = fmaf(dA[1], u.y, dKa[4*i+1]);
+          dKa[4*i+2] = fmaf(dA[0], u.z, dKa[4*i+2]); dKa[4*i+3] = fmaf(dA[1], u.w, dKa[4*i+3]);
+          dVa[4*i]   = fmaf(at[0], v.x, dVa[4*i]);   dVa[4*i+1] = fmaf(at[1], v.y, dVa[4*i+1]);
+          dVa[4*i+2] = fmaf(at[0], v.z, dVa[4*i+2]); dVa[4*i+3] = fmaf(at[1], v.w, dVa[4*i+3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { dq[2 * k] = dA[0] * Kf[2 * k]; dq[2 * k + 1] = dA[1] * Kf[2 * k + 1]; }
+        // dQ[l] partial over this tile's 16 keys -> HBM, summed over key tiles by the next prologue (or k_node_bwd)
+        a.dqp[(((size_t)b * ntile + mt) * N + l) * 64 + lane] = reduce16_keep_own(dq, p);
+      }
+      SCHED_FENCE();
+      // ---- P4: weight-gradient contractions over the 16 pairs of the tile ----
+      if (!(a.guard & 1)) {
+        float bT[4], bR[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          bT[s] = sc1[(q + 4 * s) * 16 + p];
+          bR[s] = (p < 9) ? sc2[(q + 4 * s) * 12 + p] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < G::TILES; ++t)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            accT[t] = MFMA(elem_read<DE>(et, q + 4 * s, 16 * t + p), bT[s], accT[t]);
+            accR[t] = MFMA(elem_read<DE>(dt, q + 4 * s, 16 * t + p), bR[s], accR[t]);
+          }
+      }
+      lds_sync();
+      SCHED_FENCE();
+      // ---- P5: d(ehat) = Wp . dGE, LayerNorm backward, de = de' + ... straight to HBM ----
+      if (!(a.guard & 2)) {
+        float4 dxh[G::TILES];
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < G::TILES; ++t) {
+          const float4 w = *reinterpret_cast<const float4*>(wsD + (t * 64 + lane) * 4);
+          const float4 xh = frag_read<DE>(et, p, q, t);
+          v4f d = {0.f, 0.f, 0.f, 0.f};
+          d = MFMA(w.x, dge[0], d);
+          d = MFMA(w.y, dge[1], d);
+          d = MFMA(w.z, dge[2], d);
+          d = MFMA(w.w, dge[3], d);
+          dxh[t] = make_float4(d[0], d[1], d[2], d[3]);
+          m1 += (d[0] + d[1]) + (d[2] + d[3]);
+          m2 = fmaf(d[0], xh.x, m2); m2 = fmaf(d[1], xh.y, m2);
+          m2 = fmaf(d[2], xh.z, m2); m2 = fmaf(d[3], xh.w, m2);
+        }
+        m1 = sum_over_q(m1) * (1.0f / DE);
+        m2 = sum_over_q(m2) * (1.0f / DE);
+        if (a.flags & EGT_BF_NO_EDGE_LN) { m1 = 0.f; m2 = 0.f; }   // no norm_edge: d e = de' + d(proj input)
+        float* orow = dex_o + (pair0 + p) * DE + 4 * q;
+#pragma unroll
+        for (int t = 0; t < G::TILES; ++t) {
+          if (16 * t + 4 * q < DE) {
+            const float4 dyv = frag_read<DE>(dt, p, q, t);
+            const float4 xh = frag_read<DE>(et, p, q, t);
+            float4 o;
+            o.x = dyv.x + rstd * (dxh[t].x - m1 - xh.x * m2);
+            o.y = dyv.y + rstd * (dxh[t].y - m1 - xh.y * m2);
+            o.z = dyv.z + rstd * (dxh[t].z - m1 - xh.z * m2);
+            o.w = dyv.w + rstd * (dxh[t].w - m1 - xh.w * m2);
+            *reinterpret_cast<float4*>(orow + 16 * t) = o;
+          }
+        }
+        lds_sync();   // the tile reads above retire before the next iteration overwrites dt / DMAs into et
+      }
+      SCHED_FENCE();
+    }
+    float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
+    float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
+      vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ssum[r] = row_sum16(ssum[r]);
+  __syncthreads();
+  float* ep = sm + wave * G::EP;
+#pragma unroll
+  for (int t = 0; t < G::TILES; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ep[(16 * t + 4 * q + r) * 16 + p] = accT[t][r];
+      ep[G::DEP * 16 + 16 + (16 * t + 4 * q + r) * 16 + p] = accR[t][r];
+    }
+  if (p == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ep[G::DEP * 16 + 4 * q + r] = ssum[r];
+  }
+  __syncthreads();
+  float* out = a.epart + (size_t)wg * G::EP;
+  for (int i = threadIdx.x; i < G::EP; i += 256)
+    out[i] = (sm[i] + sm[G::EP + i]) + (sm[2 * G::EP + i] + sm[3 * G::EP + i]);
+}
+
 // ---------------------------------------------------------------- backward, narrow edge channels ---
 // k_block_bwd_v4 with the row loop unrolled by R (De <= 16, N % 16 == 0, no mask tensors): one
 // iteration = the wave's key tile x R query rows.  The rows' P1..P5 chains are independent, the LDS
@@ -1788,6 +2149,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
 struct EgtBlockEnv {
   bool no_xcd_remap, no_kvl, no_epilogue, no_fwd_r4, no_bwd_r4, bwd_v2, no_bwd_ragged, no_bwd_prologue;
   int fwd_ablate, bwd_ablate, bwd_pf;
+  int bwd_v5;   // LDS-DMA staged backward (default on; EGT_BWD_V5=0 selects k_block_bwd_v4)
 };
 static bool env_flag_raw(const char* name) {
   const char* v = getenv(name);
@@ -1821,6 +2183,8 @@ static const EgtBlockEnv& block_env() {
     v.bwd_ablate = env_guard_raw("EGT_BWD_ABLATE");
     const char* pf = getenv("EGT_BWD_PF");
     v.bwd_pf = pf ? atoi(pf) : 0;
+    const char* v5 = getenv("EGT_BWD_V5");
+    v.bwd_v5 = v5 ? atoi(v5) : 1;
     return v;
   }();
   return e;
@@ -2091,6 +2455,13 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
             (void)hipFuncSetAttribute((const void*)k_block_bwd_v4r<DE, false, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             EGT_LAUNCH("k_block_bwd", (k_block_bwd_v4r<DE, false, RR>), dim3(L.nwg_bwd), dim3(256), lds_r, st, a);
           }
+          goto pair_done;
+        }
+      }
+      if constexpr (DE >= 32) {
+        if (full && !ml && !a.bf16 && block_env().bwd_v5) {   // LDS-DMA staged e tiles (k_block_bwd_v5)
+          (void)hipFuncSetAttribute((const void*)k_block_bwd_v5<DE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a);
           goto pair_done;
         }
       }
