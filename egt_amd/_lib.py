@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libegt_amd.so")
+LIB_PATH = os.environ.get("EGT_AMD_LIB") or os.path.join(_HERE, "lib", "libegt_amd.so")   # EGT_AMD_LIB: A/B experiments with variant builds
 
 # --- constants mirrored from include/egt_amd.h ---------------------------------
 EGT_OK = 0

@@ -30,6 +30,7 @@ struct BlockArgs {
   float *sbo;    // per-workgroup partials of this layer's dense_mha bias gradient
   int spart_n, sbo_n;   // how many workgroup partials the reduction finds in spart / sbo
   int guard;    // backward phase guards (always 0 in production, see k_block_bwd_v4)
+  unsigned* dbg; unsigned dbg_t0;   // EGT_BWD_TIMING builds: per-wave phase cycle sums
   int prep;     // node kernels: add the edge-weight preparation workgroup
   const float *nx_nm_g, *nx_nm_b, *nx_Wqkv, *nx_bqkv;   // next block (epi == 2)
   float* nx_qkvp;

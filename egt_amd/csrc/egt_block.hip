@@ -30,6 +30,7 @@
 #include "egt_common.h"
 
 #include <stdlib.h>
+#include <vector>
 
 #include "egt_block.h"
 #include "egt_tile.h"
@@ -1519,6 +1520,22 @@ __device__ __forceinline__ void tile_dma(unsigned lds, const float* src, unsigne
 template <int N_>
 __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N_) : "memory"); }
 
+// Phase timing of k_block_bwd_v5 (EGT_BLOCK_FLAGS=-DEGT_BWD_TIMING, measurement builds only): the wave
+// stamps s_memtime at the phase boundaries and sums the deltas in SGPRs; every wave of the grid writes its
+// sums to a.dbg [wg][4 waves][16] at the end, the host averages and prints them at exit.
+#ifdef EGT_BWD_TIMING
+#define TSTAMP(i) do { const unsigned tn__ = (unsigned)__builtin_amdgcn_s_memtime(); tacc[i] += tn__ - tlast; tlast = tn__; } while (0)
+#else
+#define TSTAMP(i) do {} while (0)
+#endif
+// transposed element (row q + 4s, channel 16t + p) of a swizzled De = 64 tile: the XOR swizzle splits into a
+// per-lane part and a part that depends only on (s, t), so ONE address register + compile-time offsets
+// replace 32 per-(s,t) address registers:  floats = [64 q + 4 ((p >> 2) ^ q) + (p & 3)] + 256 s + 16 (t ^ s)
+template <int DE>
+__device__ __forceinline__ float elem_read_st(const float* lane_base, const float* tl, int p, int q, int s, int t) {
+  if (DE == 64) return lane_base[256 * s + 16 * (t ^ s)];
+  return elem_read<DE>(tl, q + 4 * s, 16 * t + p);
+}
 template <int DE>
 __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   using G = Geo<DE>;
@@ -1582,6 +1599,11 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   float ssum[4] = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();   // the prologue's scratch (= the tile area) is dead from here: DMA may land in it
 
+#ifdef EGT_BWD_TIMING
+  unsigned tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned tlast = (unsigned)__builtin_amdgcn_s_memtime();
+  const unsigned tstart = tlast;
+#endif
   const int ntile = N / 16;
   for (int mt = wave; mt < ntile; mt += 4) {
     const int m0 = mt * 16, m = m0 + p;
@@ -1602,6 +1624,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       for (int i = 0; i < 16; ++i) { dKa[i] = 0.f; dVa[i] = 0.f; }
     }
     const float kadd = (a.km && a.km[rowm] == 0) ? -EGT_NEG : 0.0f;
+    TSTAMP(10);
 
     for (int l = l_begin; l < l_end; ++l) {
       const int li = l - l_begin;
@@ -1612,10 +1635,12 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       // ---- de'(l): requested now, consumed after P1 ----
       TileRegs<DE> td;
       tile_gload<DE>(td, dey_in + pair0 * DE, lane, 16);
+      TSTAMP(0);
       // ---- e(l) has been in flight for a whole iteration: retire it.  Younger operations of this wave:
       // row l-1's dQ-partial store and its NI de stores, then the NI de' loads just issued ----
       if (li == 0) vm_wait<0>(); else vm_wait<2 * ((G::NF4 + 63) / 64) + 1>();
       SCHED_FENCE();
+      TSTAMP(1);
       // ---- P1: norm_edge, projections (recompute) ----
       float rstd;
       v4f acc = {c2r[0], c2r[1], c2r[2], c2r[3]};
@@ -1635,12 +1660,14 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
         }
       }
       SCHED_FENCE();
+      TSTAMP(2);
       tile_lds_put<DE>(dt, td, lane, 16);   // (the compiler's own vmcnt wait for de' sits here)
       lds_sync();
       // ---- e(l+1) -> the other e buffer (its last reader, row l-1's P5, retired its LDS reads) ----
       if (l + 1 < l_end)
         tile_dma<DE>(et_lds + (unsigned)(((li + 1) & 1) * G::TILE_FLOATS * 4), e_in + (pair0 + (size_t)N) * DE, off0);
       SCHED_FENCE();
+      TSTAMP(3);
       // ---- P2: dH_ext = de'.Wr^T ----
       v4f dhx = {0.f, 0.f, 0.f, 0.f};
       if (!(a.guard & 8))
@@ -1654,6 +1681,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
         dhx = MFMA(w.w, dyv.w, dhx);
       }
       SCHED_FENCE();
+      TSTAMP(4);
       // ---- P3: logits, softmax/gate backward, dQ/dK/dV ----
       float dge[4], hh[2], dA[2], at[2];
       {
@@ -1711,7 +1739,9 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       if (q == 0) sc2[p * 12 + 8] = 1.0f;
       lds_sync();
       SCHED_FENCE();
-      if (!(a.guard & 4)) {
+      TSTAMP(5);
+      if (!(a.guard & 4))
+      {
         const float* qr = qd + li * QD_LD;
         const float4* qp = reinterpret_cast<const float4*>(qr + q * 16);
         const float4* dp = reinterpret_cast<const float4*>(qr + 64 + q * 16);
@@ -1730,32 +1760,40 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
         a.dqp[(((size_t)b * ntile + mt) * N + l) * 64 + lane] = reduce16_keep_own(dq, p);
       }
       SCHED_FENCE();
+      TSTAMP(6);
       // ---- P4: weight-gradient contractions over the 16 pairs of the tile ----
-      if (!(a.guard & 1)) {
+      if (!(a.guard & 1))
+      {
         float bT[4], bR[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           bT[s] = sc1[(q + 4 * s) * 16 + p];
           bR[s] = (p < 9) ? sc2[(q + 4 * s) * 12 + p] : 0.f;
         }
+        {
+          const int lb = 64 * q + 4 * ((p >> 2) ^ q) + (p & 3);
+          const float* eb = et + lb;
+          const float* db = dt + lb;
 #pragma unroll
-        for (int t = 0; t < G::TILES; ++t)
+          for (int t = 0; t < G::TILES; ++t)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            accT[t] = MFMA(elem_read<DE>(et, q + 4 * s, 16 * t + p), bT[s], accT[t]);
-            accR[t] = MFMA(elem_read<DE>(dt, q + 4 * s, 16 * t + p), bR[s], accR[t]);
-          }
+            for (int s = 0; s < 4; ++s) {
+              accT[t] = MFMA(elem_read_st<DE>(eb, et, p, q, s, t), bT[s], accT[t]);
+              accR[t] = MFMA(elem_read_st<DE>(db, dt, p, q, s, t), bR[s], accR[t]);
+            }
+        }
       }
       lds_sync();
       SCHED_FENCE();
+      TSTAMP(7);
       // ---- P5: d(ehat) = Wp . dGE, LayerNorm backward, de = de' + ... straight to HBM ----
       if (!(a.guard & 2)) {
         float4 dxh[G::TILES];
         float m1 = 0.f, m2 = 0.f;
 #pragma unroll
         for (int t = 0; t < G::TILES; ++t) {
-          const float4 w = *reinterpret_cast<const float4*>(wsD + (t * 64 + lane) * 4);
           const float4 xh = frag_read<DE>(et, p, q, t);
+          const float4 w = *reinterpret_cast<const float4*>(wsD + (t * 64 + lane) * 4);
           v4f d = {0.f, 0.f, 0.f, 0.f};
           d = MFMA(w.x, dge[0], d);
           d = MFMA(w.y, dge[1], d);
@@ -1786,6 +1824,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
         lds_sync();   // the tile reads above retire before the next iteration overwrites dt / DMAs into et
       }
       SCHED_FENCE();
+      TSTAMP(8);
     }
     float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
     float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
@@ -1794,7 +1833,16 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
       vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
     }
+    TSTAMP(9);
   }
+#ifdef EGT_BWD_TIMING
+  if (a.dbg && lane == 0) {
+    unsigned* o = a.dbg + ((size_t)wg * 4 + wave) * 16;
+    for (int i = 0; i < 12; ++i) o[i] = tacc[i];
+    o[12] = tstart - a.dbg_t0;      // (unused: absolute start)
+    o[13] = tlast - tstart;         // loop total
+  }
+#endif
 #pragma unroll
   for (int r = 0; r < 4; ++r) ssum[r] = row_sum16(ssum[r]);
   __syncthreads();
@@ -2332,6 +2380,42 @@ static void bind_common(const egt_block_desc* d, BlockArgs& a, const void* h, co
     default: { constexpr int DE = 64; CALL; } break;  \
   }
 
+#ifdef EGT_BWD_TIMING
+// measurement builds only: per-phase cycle sums of k_block_bwd_v5 (synchronises after every launch)
+static unsigned* g_bt_dev = nullptr;
+static int g_bt_n = 0;
+static double g_bt_sum[16];
+static long g_bt_launch = 0, g_bt_waves = 0;
+static void bwd_timing_report() {
+  static const char* nm[] = {"top+de'issue", "wait e(DMA)", "P1 LN+proj", "wait de'+put+DMA issue", "P2 dHext", "P3 softmax bwd",
+                             "dQ/dK/dV", "P4 wgrad MFMA", "P5 dehat+LNbwd+store", "dkv store", "KV load", "-", "-", "loop total"};
+  if (!g_bt_waves) return;
+  fprintf(stderr, "[egt] k_block_bwd_v5 phase cycles per wave (mean over %ld waves, %ld launches):\n", g_bt_waves, g_bt_launch);
+  for (int i = 0; i < 14; ++i)
+    if (nm[i][0] != '-') fprintf(stderr, "    %-26s %10.0f  (%.1f %%)\n", nm[i], g_bt_sum[i] / g_bt_waves, 100.0 * g_bt_sum[i] / g_bt_sum[13]);
+}
+static void bwd_timing_attach(BlockArgs& a, int nwg) {
+  if (g_bt_n < nwg) {
+    if (g_bt_dev) (void)hipFree(g_bt_dev);
+    (void)hipMalloc(&g_bt_dev, (size_t)nwg * 64 * sizeof(unsigned));
+    if (!g_bt_n) atexit(bwd_timing_report);
+    g_bt_n = nwg;
+  }
+  a.dbg = g_bt_dev; a.dbg_t0 = 0;
+}
+static void bwd_timing_collect(const BlockArgs& a, int nwg, hipStream_t st) {
+  (void)hipStreamSynchronize(st);
+  static std::vector<unsigned> h;
+  h.resize((size_t)nwg * 64);
+  (void)hipMemcpy(h.data(), a.dbg, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
+  if (++g_bt_launch <= 20) return;   // warm-up launches
+  for (size_t w = 0; w < (size_t)nwg * 4; ++w) {
+    for (int i = 0; i < 14; ++i) g_bt_sum[i] += h[w * 16 + i];
+    ++g_bt_waves;
+  }
+}
+#endif
+
 // Forward of one block.  `skip_pre`: qkvp (and pw) of this block were already produced (by the
 // previous block's epilogue / k_edge_prep).  a.epi is the epilogue the caller would like; the
 // value actually used is returned (0 when the geometry is outside the epilogue's cover, in
@@ -2461,7 +2545,19 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
       if constexpr (DE >= 32) {
         if (full && !ml && !a.bf16 && block_env().bwd_v5) {   // LDS-DMA staged e tiles (k_block_bwd_v5)
           (void)hipFuncSetAttribute((const void*)k_block_bwd_v5<DE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#ifdef EGT_BWD_TIMING
+          bwd_timing_attach(a, L.nwg_bwd);
+#endif
+#ifdef EGT_BWD_TIMING
+          { static const char* padv = getenv("EGT_BWD_LDS_PAD");   // occupancy experiments: extra LDS bytes per workgroup
+            const size_t pad = padv ? (size_t)atoi(padv) : 0;
+            EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE>), dim3(L.nwg_bwd), dim3(256), lds_v4 + pad, st, a); }
+#else
           EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a);
+#endif
+#ifdef EGT_BWD_TIMING
+          bwd_timing_collect(a, L.nwg_bwd, st);
+#endif
           goto pair_done;
         }
       }
