@@ -90,6 +90,39 @@ def make_inputs(w, dev, seed=1234):
     return [t.to(dev) for t in (h, e, mask, dh, de)]
 
 
+def make_zinc_inputs(w, dev, seed=1234):
+    """synthetic molecules in the reference's input format (lib/data/datasets/zinc.py): node_features [B,N] int
+    (28 atom types, padding -1), feature_matrix [B,N,N] int (bond type on edges, -1 elsewhere), graph_matrix
+    [B,N,N] 0/1 symmetric adjacency (random sparse, average degree ~2.2 like ZINC), target [B,1]."""
+    g = torch.Generator().manual_seed(seed)
+    B, N = w["B"], w["N"]
+    lo, hi = w["nodes"]
+    n = torch.randint(lo, hi + 1, (B,), generator=g)
+    real = torch.arange(N)[None, :] < n[:, None]
+    nf = torch.randint(0, 28, (B, N), generator=g)
+    nf[~real] = -1
+    pr = (1.1 / n.float().clamp(min=2))[:, None, None]
+    adj = (torch.rand(B, N, N, generator=g) < pr).float()
+    adj = ((adj + adj.transpose(1, 2)) > 0).float() * (real[:, :, None] & real[:, None, :]).float()
+    adj = adj * (1 - torch.eye(N))[None]
+    bond = torch.randint(0, 4, (B, N, N), generator=g)
+    bond = torch.triu(bond, 1); bond = bond + bond.transpose(1, 2)
+    fm = torch.where(adj > 0, bond, torch.tensor(-1))
+    tgt = torch.randn(B, 1, generator=g)
+    return [t.to(dev) for t in (nf.int(), fm.int(), adj, tgt)]
+
+
+def algorithmic_flops(kernel: str, w: dict, scope: str) -> float:
+    """ALGORITHMIC flops of ONE STEP's launches of an MFMA-bound kernel (the channel FFN costs
+    24 W^2 flop per row fwd+bwd = 8 W^2 forward + 16 W^2 backward)."""
+    B, N, Dh, De, Ly = w["B"], w["N"], w["Dh"], w["De"], w["Ly"]
+    n_edge = Ly - 1 if scope == "model" else Ly        # the model's last edge FFN is not on a path to the output
+    per_row = {"k_ffn_fwd": 8.0, "k_ffn_bwd": 16.0}.get(kernel)
+    if per_row is None:
+        return 0.0
+    return per_row * (n_edge * B * N * N * De * De + Ly * B * N * Dh * Dh)
+
+
 def prof_read_all(lib):
     buf = C.create_string_buffer(4096)
     lib.egt_prof_names(buf, 4096)
@@ -100,6 +133,36 @@ def prof_read_all(lib):
         if cnt.value:
             out[name] = (cnt.value, ms.value)
     return out
+
+
+def cpu_baseline_model(w, seconds=12.0):
+    """whole-model scope: the torch-CPU restatement of the ZINC model (oracle/egt_model_oracle.py), fwd + MAE + bwd."""
+    from oracle import egt_model_oracle as MO
+    Bs = 8
+    cfg = dict(model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"], model_height=w["Ly"], upto_hop=16)
+    nf, fm, adj, tgt = make_zinc_inputs(dict(w, B=Bs), "cpu", seed=77)
+    g = torch.Generator().manual_seed(3)
+    p = {k: v.requires_grad_() for k, v in MO.init_zinc_params(cfg, generator=g).items()}
+    rms = [torch.rand(Bs, w["N"], w["N"], w["H"], generator=g) < w["rand_p"] for _ in range(w["Ly"])]
+
+    def step():
+        y = MO.zinc_forward(nf, fm, adj, p, cfg, rand_masks=rms)
+        torch.autograd.grad(MO.mae_loss(y, tgt), [v for k, v in p.items()], allow_unused=True)
+
+    nthr = torch.get_num_threads()
+    thr = min(nthr, 8)
+    torch.set_num_threads(thr)
+    try:
+        step()
+        t0 = time.perf_counter(); reps = 0
+        while time.perf_counter() - t0 < seconds:
+            step(); reps += 1
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(nthr)
+    return dict(value=Bs * reps / dt, unit="graphs/s", cores=thr, kind="port",
+                sample=f"{reps} fwd+MAE+bwd steps of the whole ZINC model (Ly={w['Ly']}) on B={Bs} graphs "
+                       f"(N={w['N']}, fp32, torch-CPU restatement, {dt:.1f}s, host has {os.cpu_count()} cpus)")
 
 
 def cpu_baseline(w, seconds=12.0):
@@ -185,6 +248,10 @@ def main():
     ap.add_argument("--with-ffn", action="store_true",
                     help="whole-layer scope: every attention block is followed by the fused node + edge FFN "
                          "(graph_xformer_model_base.py:336-341); NOT the headline workload")
+    ap.add_argument("--scope", default="", choices=["", "stack", "layers", "model"],
+                    help="stack (default, the headline): the attention-block stack; layers (= --with-ffn): attention block + "
+                         "node/edge FFN per layer; model: the whole ZINC model (embeddings, hop stacking, layers, final norm, "
+                         "masked mean pooling, MLP head, MAE loss), SURVEY 8(f)-2 -- NOT the headline workload")
     ap.add_argument("--layers", type=int, default=0, help="override the workload's layer count (1 = single-block scope)")
     ap.add_argument("--fused", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--cpu-seconds", type=float, default=18.0)
@@ -195,6 +262,10 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's B graphs per GPU; strong: B graphs split over the ranks")
     args = ap.parse_args()
+    if args.scope == "layers":
+        args.with_ffn = True
+    if args.scope == "model" and args.dominant == "k_block_bwd":
+        args.dominant = "k_ffn_bwd"
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -245,7 +316,16 @@ def main():
     torch.manual_seed(1234)  # same weights on every rank (replicated parameters)
     mask_seed = 1 * world + rank  # the replicas draw independent random attention masks
     fused = {"auto": "auto", "on": True, "off": False}[args.fused]
-    if args.with_ffn:
+    zinc = None
+    if args.scope == "model":
+        from egt_amd import ZincDCTransformer, mae_loss
+        from types import SimpleNamespace
+        model = ZincDCTransformer(model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"], model_height=w["Ly"],
+                                  upto_hop=16, random_mask_prob=w["rand_p"], seed=mask_seed).to(dev).train()
+        model.fused_parameters = model.trainable_parameters
+        model.grad_holder = SimpleNamespace(flat=None)
+        zinc = make_zinc_inputs(w, dev, seed=1234 + rank)
+    elif args.with_ffn:
         from egt_amd import EGTLayerStack
         model = EGTLayerStack(model_height=w["Ly"], model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"],
                               random_mask_prob=w["rand_p"], seed=mask_seed, fused=fused).to(dev).train()
@@ -276,9 +356,13 @@ def main():
         else:
             for p in params:
                 p.grad = None
-        h.grad = None; e.grad = None
-        h2, e2 = model(h, e, mask)
-        torch.autograd.backward([h2, e2], [dh, de])
+        if zinc is not None:             # whole model: prediction -> MAE -> backward
+            nf, fm, adj, tgt = zinc
+            mae_loss(model(nf, fm, adj), tgt).backward()
+        else:
+            h.grad = None; e.grad = None
+            h2, e2 = model(h, e, mask)
+            torch.autograd.backward([h2, e2], [dh, de])
         if state["flat_ok"] is None:
             state["flat_ok"] = flat_grad_view(params, model.grad_holder.flat)
             if not state["flat_ok"]:
@@ -366,7 +450,18 @@ def main():
                     traffic = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json"))).get(dom)
             except Exception:
                 traffic = None
-            roof = dict(bound="hbm", kernel=dom, timed_in_region=dom in dom_prof, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+            nprof = min(args.steps, 10)
+            fl = algorithmic_flops(dom, w, args.scope)
+            if fl > 0:    # MFMA-bound dominant kernel (whole-layer / whole-model scopes): fp32 matrix peak
+                tot_s = prof[dom][1] / 1e3 / nprof        # this kernel's time per step (all its launches)
+                roof = dict(bound="mfma", kernel=dom, timed_in_region=False, achieved=fl / tot_s / 1e12, peak=157.3,
+                            unit="TFLOP/s", frac=fl / tot_s / 1e12 / 157.3, traffic=None,
+                            avg_launch_us=avg_s * 1e6, launches=cnt, algorithmic_flops_per_step=fl,
+                            kernels={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3,
+                                             share=v[1] / sum(x[1] for x in prof.values()))
+                                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
+            else:
+              roof = dict(bound="hbm", kernel=dom, timed_in_region=dom in dom_prof, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=(ach / HBM_PEAK_GBS) if ach else None, traffic=traffic,
                         avg_launch_us=avg_s * 1e6, launches=cnt, algorithmic_bytes_per_launch=ab,
                         kernels={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3,
@@ -374,11 +469,13 @@ def main():
                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
         cpu = None
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline(w, args.cpu_seconds)
+            cpu = cpu_baseline_model(w, args.cpu_seconds) if args.scope == "model" else cpu_baseline(w, args.cpu_seconds)
         graphs = graphs_step * args.steps
         path = "fused-stack" if state["flat_ok"] else ("fused" if any(k.startswith("k_block") for k in prof) else "composed")
         if args.with_ffn:
             path += "+ffn"
+        if args.scope == "model":
+            path = "zinc-model (HIP edge embedding + fused blocks + fused FFNs, torch node-side head)"
         line = {
             "metric": "graphs/sec EGT fwd+bwd, ZINC-500K padded N=64",
             "value": graphs / elapsed, "unit": "graphs/s", "n_gpus": world,
@@ -386,8 +483,13 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32 (edge tensors stored bf16)" if bf16 else "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: attention-block stack (h,e,mask)->(h',e') x Ly, fwd+bwd "
-                                   f"+ param grads" + (" + flat RCCL grad all-reduce" if world > 1 else ""),
+            "config": {"workload": (f"{args.workload}: " + {"model": "WHOLE ZINC MODEL (embeddings, 16-hop stacking, Ly x [attention block + node/edge FFN], "
+                                                             "final norm, masked mean pool, MLP head, MAE) fwd+bwd",
+                                                             "layers": "Ly x [attention block + node/edge FFN] fwd+bwd"}.get(
+                                        args.scope or ("layers" if args.with_ffn else "stack"),
+                                        "attention-block stack (h,e,mask)->(h',e') x Ly, fwd+bwd")
+                                    + " + param grads" + (" + flat RCCL grad all-reduce" if world > 1 else "")),
+                       "scope": args.scope or ("layers" if args.with_ffn else "stack"),
                        "graphs_per_gpu": w["B"], "global_batch": graphs_step, "N": w["N"],
                        "Dh": w["Dh"], "De": w["De"], "H": w["H"], "d": w["Dh"] // w["H"], "Ly": w["Ly"],
                        "random_mask_prob": w["rand_p"], "nodes": list(w["nodes"]), "path": path,

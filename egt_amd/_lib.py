@@ -75,6 +75,12 @@ class BlockParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in BLOCK_PARAM_FIELDS]
 
 
+class EmbedDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("De", C.c_int32), ("upto_hop", C.c_int32),
+                ("clip_hops", C.c_int32), ("num_edge_features", C.c_int32), ("dtype", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class EGTLibraryError(RuntimeError):
     pass
 
@@ -105,6 +111,11 @@ _PROTOS = {
     "egt_node_mask_from_features": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP]),
     "egt_node_mask_from_float_features": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _VP, _VP]),
     "egt_constrained_edge_mask": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, _VP]),
+    "egt_edge_embed_supported": (C.c_int, [C.POINTER(EmbedDesc)]),
+    "egt_edge_embed_hops_bytes": (C.c_size_t, [C.POINTER(EmbedDesc)]),
+    "egt_edge_embed_workspace_bytes": (C.c_size_t, [C.POINTER(EmbedDesc)]),
+    "egt_edge_embed_fwd": (C.c_int, [C.POINTER(EmbedDesc)] + [_VP] * 8),
+    "egt_edge_embed_bwd": (C.c_int, [C.POINTER(EmbedDesc)] + [_VP] * 8),
     "egt_prof_enable": (C.c_int, [C.c_int]),
     "egt_prof_filter": (C.c_int, [C.c_char_p]),
     "egt_prof_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

@@ -16,7 +16,7 @@ REPO = os.path.dirname(ROOT)
 CSRC = os.path.join(ROOT, "csrc")
 LIBDIR = os.path.join(ROOT, "lib")
 LIB = os.path.join(LIBDIR, "libegt_amd.so")
-SOURCES = ["egt_capi.hip", "egt_attn.hip", "egt_attn_mfma.hip", "egt_edge.hip", "egt_block.hip", "egt_node.hip", "egt_ffn.hip", "egt_masks.hip"]
+SOURCES = ["egt_capi.hip", "egt_attn.hip", "egt_attn_mfma.hip", "egt_edge.hip", "egt_block.hip", "egt_node.hip", "egt_ffn.hip", "egt_masks.hip", "egt_embed.hip"]
 ARCH = "gfx950"
 # per-source compiler flags.  egt_ffn.hip: the backward keeps 256 weight-gradient accumulator
 # registers per wave; with hipcc's default (AGPR-form MFMA everywhere) the short-lived GEMM

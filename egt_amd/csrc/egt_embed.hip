@@ -1,0 +1,247 @@
+// Edge-channel input embedding of the EGT model -- the producer of the e tensor the
+// attention path consumes:   e0 = Embedding(fmat + 1) + Dense(stack_hops(adj))
+//   stack_hops   lib/models/graph_model_base.py:101-119  hops[...,0] = A, hops[...,k] = clip(A . hops[...,k-1], 0, 1)
+//   adj_emb      :125-126                                Dense(upto_hop -> De)
+//   fm_emb       lib/models/zinc/dc.py:70-73             Neg1MaskedEmbedding(num_edge_features + 1, De)
+//   edge_emb_add lib/models/graph_xformer_model_base.py:401-404
+// Once per batch (not per layer).  The hop products are batched N x N x N fp32 contractions on MFMA
+// tiles (one wave per 16 x 16 output tile, operands straight from L2: 1 GFLOP per batch at config 2);
+// the embedding itself is a write-bound streaming kernel (256 B per pair at De = 64); its backward is a
+// read-bound contraction over the pair axis with deterministic per-workgroup partials.
+#include "egt_common.h"
+
+typedef float v4f_e __attribute__((ext_vector_type(4)));
+
+// hops[b,l,m,k] = clip( sum_j adj[b,l,j] * hops[b,j,m,k-1] ); grid = B * T * T waves (T = ceil(N/16))
+__global__ void __launch_bounds__(64) k_hop_step(const float* __restrict__ adj, float* __restrict__ hops, int B, int N,
+                                                 int K, int k, int clip) {
+  const int T = (N + 15) / 16;
+  const int tile = blockIdx.x % (T * T), b = blockIdx.x / (T * T);
+  const int l0 = (tile / T) * 16, m0 = (tile % T) * 16;
+  const int lane = threadIdx.x, i = lane & 15, kk = lane >> 4;
+  const float* A = adj + (size_t)b * N * N;
+  const float* P = hops + (size_t)b * N * N * K + (k - 1);
+  v4f_e acc = {0.f, 0.f, 0.f, 0.f};
+  const int la = min(l0 + i, N - 1), mb = min(m0 + i, N - 1);
+  for (int j0 = 0; j0 < N; j0 += 4) {
+    const int j = j0 + kk;
+    const float av = j < N ? A[(size_t)la * N + j] : 0.f;                 // A operand: row l0 + i, contraction index j
+    const float bv = j < N ? P[((size_t)j * N + mb) * K] : 0.f;           // B operand: contraction index j, column m0 + i
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+  }
+  // D: row 4 * (lane >> 4) + r, column lane & 15
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int l = l0 + 4 * kk + r, m = m0 + i;
+    float v = acc[r];
+    if (clip) v = fminf(fmaxf(v, 0.f), 1.f);
+    if (l < N && m < N) hops[(((size_t)b * N + l) * N + m) * K + k] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_hop_first(const float* __restrict__ adj, float* __restrict__ hops, long pairs, int K) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < pairs) hops[i * K] = adj[i];
+}
+
+// e0[pair, c] = fm_table[fmat[pair] + 1, c] + bias[c] + sum_k hops[pair, k] * W[k, c]
+// thread = (pair, 4 channels); W / bias / table staged in LDS
+template <int KMAX>
+__global__ void __launch_bounds__(256) k_edge_embed_fwd(const int32_t* __restrict__ fmat, const float* __restrict__ hops,
+                                                        const float* __restrict__ table, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ e, long pairs,
+                                                        int De, int K, int V) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Ws = sm;                 // [K][De]
+  float* Ts = Ws + K * De;        // [V][De] (+ bias folded in)
+  for (int i = threadIdx.x; i < K * De; i += 256) Ws[i] = W[i];
+  for (int i = threadIdx.x; i < V * De; i += 256) Ts[i] = table[i] + bias[i % De];
+  __syncthreads();
+  const int C4 = De / 4;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long pair = gid / C4;
+  const int c4 = (int)(gid % C4);
+  if (pair >= pairs) return;
+  int f = fmat[pair] + 1;
+  f = min(max(f, 0), V - 1);
+  float4 acc = *reinterpret_cast<const float4*>(Ts + f * De + 4 * c4);
+  const float* hp = hops + pair * K;
+#pragma unroll 4
+  for (int k = 0; k < K; ++k) {
+    const float hv = hp[k];
+    const float4 w = *reinterpret_cast<const float4*>(Ws + k * De + 4 * c4);
+    acc.x = fmaf(hv, w.x, acc.x); acc.y = fmaf(hv, w.y, acc.y);
+    acc.z = fmaf(hv, w.z, acc.z); acc.w = fmaf(hv, w.w, acc.w);
+  }
+  *reinterpret_cast<float4*>(e + pair * De + 4 * c4) = acc;
+}
+
+// backward: dW[k,c] = sum_pairs hops[pair,k] de[pair,c];  dtable[v,c] = sum_{fmat+1 == v} de[pair,c];  dbias = sum de
+// block = 16 pair lanes x (De/4 <= 16) channel quads; each thread owns 4 channels and walks its pairs; the
+// (K + V) x 4 accumulators per thread are reduced over the 16 pair lanes in LDS; one partial per workgroup
+#define EMB_PPB 2048   // pairs per workgroup
+template <int K_, int V_>
+__global__ void __launch_bounds__(256) k_edge_embed_bwd(const int32_t* __restrict__ fmat, const float* __restrict__ hops,
+                                                        const float* __restrict__ de, float* __restrict__ part, long pairs,
+                                                        int De) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [16 pair lanes][(K+V)][De]
+  const int C4 = De / 4;
+  const int c4 = threadIdx.x % 16, pl = threadIdx.x / 16;
+  float4 aw[K_], at[V_];
+#pragma unroll
+  for (int k = 0; k < K_; ++k) aw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int v = 0; v < V_; ++v) at[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long p0 = (long)blockIdx.x * EMB_PPB;
+  const long p1 = min(pairs, p0 + EMB_PPB);
+  if (c4 < C4) {
+    for (long pair = p0 + pl; pair < p1; pair += 16) {
+      const float4 d = *reinterpret_cast<const float4*>(de + pair * De + 4 * c4);
+      const float* hp = hops + pair * K_;
+      int f = fmat[pair] + 1;
+      f = min(max(f, 0), V_ - 1);
+#pragma unroll
+      for (int k = 0; k < K_; ++k) {
+        const float hv = hp[k];
+        aw[k].x = fmaf(hv, d.x, aw[k].x); aw[k].y = fmaf(hv, d.y, aw[k].y);
+        aw[k].z = fmaf(hv, d.z, aw[k].z); aw[k].w = fmaf(hv, d.w, aw[k].w);
+      }
+#pragma unroll
+      for (int v = 0; v < V_; ++v) {   // branch-free one-hot accumulate (static register indexing)
+        const float s = (f == v) ? 1.0f : 0.0f;
+        at[v].x = fmaf(s, d.x, at[v].x); at[v].y = fmaf(s, d.y, at[v].y);
+        at[v].z = fmaf(s, d.z, at[v].z); at[v].w = fmaf(s, d.w, at[v].w);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K_; ++k) *reinterpret_cast<float4*>(sm + ((size_t)pl * (K_ + V_) + k) * De + 4 * c4) = aw[k];
+#pragma unroll
+    for (int v = 0; v < V_; ++v) *reinterpret_cast<float4*>(sm + ((size_t)pl * (K_ + V_) + K_ + v) * De + 4 * c4) = at[v];
+  }
+  __syncthreads();
+  const int R = (K_ + V_) * De;
+  float* out = part + (size_t)blockIdx.x * R;
+  for (int i = threadIdx.x; i < R; i += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += sm[(size_t)j * R + i];   // fixed order: bit-reproducible
+    out[i] = s;
+  }
+}
+
+// deterministic reduction of the workgroup partials + split into the three gradients
+__global__ void __launch_bounds__(256) k_edge_embed_bwd_reduce(const float* __restrict__ part, int nparts, int K, int V, int De,
+                                                               float* __restrict__ dW, float* __restrict__ dtable,
+                                                               float* __restrict__ dbias) {
+  const int R = (K + V) * De;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= R) return;
+  double s = 0.0;
+  for (int j = 0; j < nparts; ++j) s += (double)part[(size_t)j * R + i];
+  if (i < K * De) dW[i] = (float)s;
+  else dtable[i - K * De] = (float)s;
+  if (i >= K * De && dbias) {
+    // bias gradient = column sums of the table gradient (every pair selects exactly one row)
+    // done by the thread of row 0: walk the V rows
+    if (i < (K + 1) * De) {
+      const int c = i - K * De;
+      double b = 0.0;
+      for (int v = 0; v < V; ++v)
+        for (int j = 0; j < nparts; ++j) b += (double)part[(size_t)j * R + (K + v) * De + c];
+      dbias[c] = (float)b;
+    }
+  }
+}
+
+static int embed_check(const egt_embed_desc* d) {
+  if (!d) EGT_FAIL(EGT_E_NULL, "desc is NULL");
+  if (d->B <= 0 || d->N <= 0) EGT_FAIL(EGT_E_SHAPE, "B and N must be positive");
+  if (d->De < 4 || d->De > 64 || d->De % 4) EGT_FAIL(EGT_E_SHAPE, "edge embedding covers edge_width in 4..64, multiple of 4 (got %d)", d->De);
+  if (d->upto_hop < 1 || d->upto_hop > 16) EGT_FAIL(EGT_E_SHAPE, "upto_hop must be in 1..16 (got %d)", d->upto_hop);
+  if (d->num_edge_features < 0 || d->num_edge_features > 7) EGT_FAIL(EGT_E_SHAPE, "num_edge_features must be in 0..7 (got %d)", d->num_edge_features);
+  if (d->dtype != EGT_F32) EGT_FAIL(EGT_E_DTYPE, "edge embedding is fp32");
+  return EGT_OK;
+}
+extern "C" int egt_edge_embed_supported(const egt_embed_desc* d) {
+  if (!d) return 0;
+  return d->B > 0 && d->N > 0 && d->De >= 4 && d->De <= 64 && d->De % 4 == 0 && d->upto_hop >= 1 && d->upto_hop <= 16 &&
+         d->num_edge_features >= 0 && d->num_edge_features <= 7 && d->dtype == EGT_F32;
+}
+extern "C" size_t egt_edge_embed_hops_bytes(const egt_embed_desc* d) {
+  if (!egt_edge_embed_supported(d)) return 0;
+  return (size_t)d->B * d->N * d->N * d->upto_hop * sizeof(float);
+}
+static int embed_nparts(const egt_embed_desc* d) {
+  const long pairs = (long)d->B * d->N * d->N;
+  return (int)((pairs + EMB_PPB - 1) / EMB_PPB);
+}
+extern "C" size_t egt_edge_embed_workspace_bytes(const egt_embed_desc* d) {
+  if (!egt_edge_embed_supported(d)) return 0;
+  return (size_t)embed_nparts(d) * (d->upto_hop + d->num_edge_features + 1) * d->De * sizeof(float);
+}
+
+extern "C" int egt_edge_embed_fwd(const egt_embed_desc* d, const int32_t* feature_matrix, const void* graph_matrix,
+                                  const void* fm_table, const void* adj_kernel, const void* adj_bias, void* hops,
+                                  void* e_out, void* stream) {
+  int rc = embed_check(d);
+  if (rc) return rc;
+  if (!feature_matrix || !graph_matrix || !fm_table || !adj_kernel || !adj_bias || !hops || !e_out)
+    EGT_FAIL(EGT_E_NULL, "feature_matrix/graph_matrix/fm_table/adj_kernel/adj_bias/hops/e_out is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  const long pairs = (long)d->B * d->N * d->N;
+  const int K = d->upto_hop, V = d->num_edge_features + 1, T = (d->N + 15) / 16;
+  EGT_LAUNCH("k_hop_first", k_hop_first, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, (const float*)graph_matrix,
+             (float*)hops, pairs, K);
+  for (int k = 1; k < K; ++k)
+    EGT_LAUNCH("k_hop_step", k_hop_step, dim3((unsigned)(d->B * T * T)), dim3(64), 0, st, (const float*)graph_matrix,
+               (float*)hops, d->B, d->N, K, k, d->clip_hops ? 1 : 0);
+  const long threads = pairs * (d->De / 4);
+  const size_t lds = (size_t)(K + V) * d->De * sizeof(float);
+  EGT_LAUNCH("k_edge_embed_fwd", k_edge_embed_fwd<16>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, st,
+             feature_matrix, (const float*)hops, (const float*)fm_table, (const float*)adj_kernel, (const float*)adj_bias,
+             (float*)e_out, pairs, d->De, K, V);
+  EGT_HIP_LAUNCH_CHECK("egt_edge_embed_fwd");
+  return EGT_OK;
+}
+
+template <int K_>
+static void launch_embed_bwd(const egt_embed_desc* d, const int32_t* fmat, const float* hops, const float* de, float* part,
+                             hipStream_t st) {
+  const long pairs = (long)d->B * d->N * d->N;
+  const int nparts = embed_nparts(d);
+#define EB(V_)                                                                                                      \
+  do {                                                                                                              \
+    const size_t lds = (size_t)16 * (K_ + V_) * d->De * sizeof(float);                                              \
+    (void)hipFuncSetAttribute((const void*)k_edge_embed_bwd<K_, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    EGT_LAUNCH("k_edge_embed_bwd", (k_edge_embed_bwd<K_, V_>), dim3(nparts), dim3(256), lds, st, fmat, hops, de, part, pairs, d->De); \
+  } while (0)
+  switch (d->num_edge_features + 1) {
+    case 1: EB(1); break; case 2: EB(2); break; case 3: EB(3); break; case 4: EB(4); break;
+    case 5: EB(5); break; case 6: EB(6); break; case 7: EB(7); break; default: EB(8); break;
+  }
+#undef EB
+}
+
+extern "C" int egt_edge_embed_bwd(const egt_embed_desc* d, const int32_t* feature_matrix, const void* hops,
+                                  const void* d_e, void* d_fm_table, void* d_adj_kernel, void* d_adj_bias,
+                                  void* workspace, void* stream) {
+  int rc = embed_check(d);
+  if (rc) return rc;
+  if (!feature_matrix || !hops || !d_e || !d_fm_table || !d_adj_kernel || !d_adj_bias || !workspace)
+    EGT_FAIL(EGT_E_NULL, "feature_matrix/hops/d_e/d_fm_table/d_adj_kernel/d_adj_bias/workspace is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  const float* h = (const float*)hops;
+  const float* de = (const float*)d_e;
+  float* part = (float*)workspace;
+  switch (d->upto_hop) {
+#define C(K_) case K_: launch_embed_bwd<K_>(d, feature_matrix, h, de, part, st); break;
+    C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16)
+#undef C
+  }
+  const int R = (d->upto_hop + d->num_edge_features + 1) * d->De;
+  EGT_LAUNCH("k_edge_embed_bwd_reduce", k_edge_embed_bwd_reduce, dim3((R + 255) / 256), dim3(256), 0, st, (const float*)part,
+             embed_nparts(d), d->upto_hop, d->num_edge_features + 1, d->De, (float*)d_adj_kernel, (float*)d_fm_table,
+             (float*)d_adj_bias);
+  EGT_HIP_LAUNCH_CHECK("egt_edge_embed_bwd");
+  return EGT_OK;
+}

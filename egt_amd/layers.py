@@ -373,10 +373,14 @@ class EGTLayerStack(nn.Module):
                 prm.copy_(w.to(prm.device))
         return missing, unexpected
 
-    def forward(self, h, e, mask=None, attn_mask=None):
+    def forward(self, h, e, mask=None, attn_mask=None, skip_last_edge_ffn=False):
+        """skip_last_edge_ffn: a model whose readout ignores the edge channels (e.g. ZINC, readout_edges=False)
+        does not contain the last layer's edge FFN in the reference either (a Keras functional model keeps only
+        layers on a path to its outputs)."""
+        last = len(self.blocks) - 1
         for i, blk in enumerate(self.blocks):
             h, e = blk(h, e, mask, attn_mask)                  # layer/{i}/attention
-            if self.ffn_edge is not None:                      # layer/{i}/ffn
+            if self.ffn_edge is not None and not (skip_last_edge_ffn and i == last):   # layer/{i}/ffn
                 e = self.ffn_edge[i](e)
             h = self.ffn_node[i](h)
         return h, e

@@ -1,0 +1,163 @@
+"""The ZINC model around the attention path: what the reference's
+``lib.models.zinc.dc.DCSVDTransformer`` builds for scheme ``zinc.svd`` with the shipped configs
+(``use_svd: false``, ``configs/main/zinc/*/egt.json``), as one torch module
+
+    ZincDCTransformer(**model_config)(node_features, feature_matrix, graph_matrix) -> [B, num_targets]
+
+Pair-sized work runs in the HIP kernels through the C-ABI: the edge-channel input embedding
+(egt_edge_embed_fwd/bwd: hop stacking + adj_emb + fm_emb), every attention block (egt_block_*) and
+every channel FFN (egt_ffn_*), the node mask producer (egt_node_mask_from_features).  Node-sized
+[B,N,Dh] pieces (embedding lookup, final LayerNorm, masked mean pooling, the MLP head, the loss) are
+torch ops.  Parameters carry the reference's Keras variable names (keras_named_parameters) so a
+weight file of the reference loads unchanged.
+
+Reference (relative to /root/reference/): lib/models/zinc/dc.py:17-120,
+lib/models/graph_model_base.py:97-129, lib/models/graph_xformer_model_base.py:336-372,377-466,
+lib/training/schemes/zinc/svd.py:27-42, lib/training/schemes/scheme_base.py:37-60.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from .functional import _f32c, _need_gpu
+from .layers import EGTLayerStack, KerasDense, KerasLayerNorm, LN_EPS
+from .masks import node_mask_from_features
+
+
+def _embed_desc(B, N, De, upto_hop, clip_hops, num_edge_features) -> L.EmbedDesc:
+    return L.EmbedDesc(B=B, N=N, De=De, upto_hop=upto_hop, clip_hops=1 if clip_hops else 0,
+                       num_edge_features=num_edge_features, dtype=L.EGT_F32, reserved=0)
+
+
+class _EdgeEmbed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fmat, adj, table, kernel, bias, clip_hops):
+        _need_gpu(fmat, adj, table)
+        lib = L.load()
+        fmat = fmat.to(torch.int32).contiguous()
+        adj = _f32c(adj.to(torch.float32))
+        table, kernel, bias = _f32c(table), _f32c(kernel), _f32c(bias)
+        B, N, _ = adj.shape
+        K, De = kernel.shape
+        desc = _embed_desc(B, N, De, K, clip_hops, table.shape[0] - 1)
+        if not lib.egt_edge_embed_supported(C.byref(desc)):
+            raise ValueError(f"edge embedding kernel does not cover upto_hop={K}, edge_width={De}, "
+                             f"num_edge_features={table.shape[0] - 1}")
+        hops = torch.empty(B, N, N, K, dtype=torch.float32, device=adj.device)
+        e = torch.empty(B, N, N, De, dtype=torch.float32, device=adj.device)
+        L.check(lib.egt_edge_embed_fwd(C.byref(desc), L.ptr(fmat), L.ptr(adj), L.ptr(table), L.ptr(kernel),
+                                       L.ptr(bias), L.ptr(hops), L.ptr(e), L.current_stream()))
+        ctx.desc = desc
+        ctx.save_for_backward(fmat, hops, table, kernel, bias)
+        ctx.mark_non_differentiable(hops)
+        return e, hops
+
+    @staticmethod
+    def backward(ctx, de, _dhops):
+        lib = L.load()
+        fmat, hops, table, kernel, bias = ctx.saved_tensors
+        desc = ctx.desc
+        de = _f32c(de)
+        dt, dk, db = torch.empty_like(table), torch.empty_like(kernel), torch.empty_like(bias)
+        ws = torch.empty(lib.egt_edge_embed_workspace_bytes(C.byref(desc)), dtype=torch.uint8, device=de.device)
+        L.check(lib.egt_edge_embed_bwd(C.byref(desc), L.ptr(fmat), L.ptr(hops), L.ptr(de), L.ptr(dt), L.ptr(dk),
+                                       L.ptr(db), L.ptr(ws), L.current_stream()))
+        return None, None, dt, dk, db, None
+
+
+def edge_embed(feature_matrix, graph_matrix, fm_table, adj_kernel, adj_bias, clip_hops=True, return_hops=False):
+    """e0 = fm_table[feature_matrix + 1] + stack_hops(graph_matrix) @ adj_kernel + adj_bias  ->  [B,N,N,De]."""
+    e, hops = _EdgeEmbed.apply(feature_matrix, graph_matrix, fm_table, adj_kernel, adj_bias, clip_hops)
+    return (e, hops) if return_hops else e
+
+
+class ZincDCTransformer(nn.Module):
+    """DCSVDTransformer for zinc.svd without SVD features; constructor kwargs are the reference's
+    model_config keys (scheme_base.py:37-60, zinc/svd.py:27-35) with its defaults."""
+
+    def __init__(self, model_width=64, edge_width=64, num_heads=8, model_height=10, gate_attention=True,
+                 edge_channel_type='residual', upto_hop=16, clip_hops=True, random_mask_prob=0.1,
+                 clip_logits_value=[-5, 5], mlp_layers=[.5, .25], activation='elu', do_final_norm=True,
+                 ffn_multiplier=2., num_node_features=28, num_edge_features=4, num_targets=1,
+                 readout_edges=False, num_virtual_nodes=0, use_svd=False, node_dropout=0., edge_dropout=0.,
+                 seed=0, **unused):
+        super().__init__()
+        if readout_edges or num_virtual_nodes or use_svd or node_dropout or edge_dropout:
+            raise NotImplementedError("ZincDCTransformer covers the shipped ZINC configs: readout_edges=False, "
+                                      "num_virtual_nodes=0, use_svd=False, dropout=0")
+        if edge_channel_type not in ('residual', 'constrained'):
+            raise NotImplementedError("edge_channel_type must be residual or constrained")
+        self.cfg = dict(model_width=model_width, edge_width=edge_width, num_heads=num_heads, model_height=model_height,
+                        upto_hop=upto_hop, clip_hops=clip_hops, mlp_layers=list(mlp_layers), activation=activation,
+                        do_final_norm=do_final_norm, num_node_features=num_node_features,
+                        num_edge_features=num_edge_features, num_targets=num_targets, ffn_multiplier=ffn_multiplier,
+                        edge_channel_type=edge_channel_type)
+        self.node_emb = nn.Parameter(torch.empty(num_node_features + 1, model_width).uniform_(-0.05, 0.05))   # keras 'uniform'
+        self.fm_emb = nn.Parameter(torch.empty(num_edge_features + 1, edge_width).uniform_(-0.05, 0.05))
+        self.adj_emb = KerasDense(upto_hop, edge_width)
+        self.layers = EGTLayerStack(model_height=model_height, model_width=model_width, edge_width=edge_width,
+                                    activation=activation, num_heads=num_heads, gate_attention=gate_attention,
+                                    edge_channel_type=edge_channel_type, clip_logits_value=clip_logits_value,
+                                    random_mask_prob=random_mask_prob, seed=seed)
+        self.node_norm_final = KerasLayerNorm(model_width) if do_final_norm else None
+        self.mlp_out = nn.ModuleList()
+        w = model_width
+        for f in mlp_layers:
+            self.mlp_out.append(KerasDense(w, round(f * model_width)))
+            w = round(f * model_width)
+        self.target = KerasDense(w, num_targets)
+
+    # the Keras functional model contains only layers on a path to the outputs: with readout_edges=False the last
+    # layer's dense_edge_r / edge FFN and edge_norm_final are NOT part of the reference model
+    def _dead_edge_params(self):
+        last = self.layers.blocks[-1]
+        dead = [last.dense_edge_r.kernel, last.dense_edge_r.bias]
+        if self.layers.ffn_edge is not None:
+            dead += list(self.layers.ffn_edge[-1].parameters())
+        return dead
+
+    def keras_named_parameters(self):
+        dead = {id(p) for p in self._dead_edge_params()}
+        out = {"node_emb/embeddings": self.node_emb, "fm_emb/embeddings": self.fm_emb,
+               "adj_emb/kernel": self.adj_emb.kernel, "adj_emb/bias": self.adj_emb.bias}
+        out.update({k: v for k, v in self.layers.keras_named_parameters().items() if id(v) not in dead})
+        if self.node_norm_final is not None:
+            out["node_norm_final/gamma"] = self.node_norm_final.gamma
+            out["node_norm_final/beta"] = self.node_norm_final.beta
+        for i, m in enumerate(self.mlp_out):
+            out[f"mlp_out_{i}/kernel"], out[f"mlp_out_{i}/bias"] = m.kernel, m.bias
+        out["target/kernel"], out["target/bias"] = self.target.kernel, self.target.bias
+        return out
+
+    def trainable_parameters(self):
+        """the parameters the reference model owns (the dead last-layer edge parameters excluded)"""
+        return list(self.keras_named_parameters().values())
+
+    def embeddings(self, node_features, feature_matrix, graph_matrix):
+        mask = node_mask_from_features(node_features)                                  # masking.py:42-43
+        h = F.embedding((node_features + 1).long(), self.node_emb)                      # zinc/dc.py:66-69
+        e = edge_embed(feature_matrix, graph_matrix, self.fm_emb, self.adj_emb.kernel, self.adj_emb.bias,
+                       clip_hops=self.cfg["clip_hops"])                                 # :70-73 + graph_model_base.py:97-127
+        return h, e, mask
+
+    def forward(self, node_features, feature_matrix, graph_matrix, attn_mask=None):
+        h, e, mask = self.embeddings(node_features, feature_matrix, graph_matrix)
+        h, e = self.layers(h, e, mask, attn_mask, skip_last_edge_ffn=True)              # :336-341
+        if self.node_norm_final is not None:
+            h = self.node_norm_final(h)                                                 # :343-345
+        m = mask.to(h.dtype)[..., None]
+        x = (h * m).sum(dim=1) / m.sum(dim=1)                                           # node_glob_avg_pool, zinc/dc.py:109
+        for lyr in self.mlp_out:                                                        # mlp_out, :354-372
+            x = lyr(x)
+            x = F.elu(x) if self.cfg["activation"] == 'elu' else torch.relu(x)
+        return self.target(x)                                                           # zinc/dc.py:116-117
+
+
+def mae_loss(y_pred, y_true):
+    """keras.losses.MeanAbsoluteError (schemes/zinc/svd.py:37-39)."""
+    return (y_pred - y_true).abs().mean()

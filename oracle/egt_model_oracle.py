@@ -1,0 +1,160 @@
+"""CPU oracle of the whole ZINC model around the hot path — TEST INFRASTRUCTURE.
+
+A torch-CPU restatement (any dtype; tests evaluate it in fp64) of what `DCSVDTransformer`
+builds for scheme `zinc.svd` with the shipped ZINC configs (`use_svd: false`), composed from
+oracle/egt_oracle.py for the layer stack.  Parity is UNPINNED by the reference (TensorFlow cannot
+run here; the reference ships no vectors): correctness is by construction from the cited lines.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this module.
+
+Model (all citations relative to /root/reference/):
+  inputs   node_features [B,N] int (padding -1), feature_matrix [B,N,N] int (-1 = no edge / padding),
+           graph_matrix [B,N,N] float adjacency           lib/models/zinc/dc.py:37-59, graph_model_base.py:42-52
+  h0       Neg1MaskedEmbedding(num_node_features+1, Dh)(nodef)           zinc/dc.py:66-69, masking.py:5-43
+  e0       Neg1MaskedEmbedding(num_edge_features+1, De)(fmat)            zinc/dc.py:70-73
+           + Dense(De)(stack_hops(adj, upto_hop, clip))                  graph_model_base.py:97-127
+           (Add of the edge embeddings)                                  graph_xformer_model_base.py:401-409
+  mask     node_features != -1 (Embedding(mask_zero) on inputs+1)        masking.py:35-43
+  layers   for ii: edge_update_residual; ffn_block                       graph_xformer_model_base.py:336-341
+  final    node_norm_final / edge_norm_final                             :343-347
+  readout  masked GlobalAveragePooling1D -> mlp_out (elu) -> Dense(1)    zinc/dc.py:100-120, :354-372
+  loss     MeanAbsoluteError                                             lib/training/schemes/zinc/svd.py:37-39
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import egt_oracle as O
+
+
+def neg1_masked_embedding(x, table):
+    """Neg1MaskedEmbedding.call (masking.py:31-40): Embedding lookup of inputs+1 (padding -1 -> row 0,
+    which is an ordinary trainable row: mask_zero only produces the mask)."""
+    return table[(x + 1).long()]
+
+
+def stack_hops(adj, upto_hop, clip_hops=True):
+    """AdjMatModel.create_embedding('adj') (graph_model_base.py:101-119): [A, clip(A.A), clip(A.clip(A.A)), ...]
+    stacked on a new last axis; upto_hop == 1 is A[..., None]."""
+    if upto_hop < 1:
+        raise ValueError
+    hops = [adj]
+    hop = adj
+    for _ in range(upto_hop - 1):
+        hop = torch.matmul(adj, hop)
+        if clip_hops:
+            hop = hop.clamp(0.0, 1.0)
+        hops.append(hop)
+    return torch.stack(hops, dim=-1)
+
+
+def masked_global_avg_pool_1d(h, mask):
+    """keras GlobalAveragePooling1D with a mask: sum(h * m) / sum(m) over the node axis (zinc/dc.py:109)."""
+    m = mask.to(h.dtype)[..., None]
+    return (h * m).sum(dim=1) / m.sum(dim=1)
+
+
+def activation_fn(x, name):
+    if name == "elu":
+        return torch.nn.functional.elu(x)
+    if name == "relu":
+        return torch.relu(x)
+    raise ValueError(name)
+
+
+def mlp_out(x, params, n_layers, activation="elu"):
+    """GraphTransformerBase.mlp_out (graph_xformer_model_base.py:354-372)."""
+    for ii in range(n_layers):
+        x = activation_fn(O.dense(x, params[f"mlp_out_{ii}.kernel"], params[f"mlp_out_{ii}.bias"]), activation)
+    return x
+
+
+def init_zinc_params(cfg, *, dtype=torch.float32, generator=None, randomize=True):
+    """Keras defaults: Embedding 'uniform' U(-0.05, 0.05), Dense glorot_uniform / zeros, LN ones / zeros.
+    randomize: perturb biases and LN parameters so the parity tests exercise them."""
+    Dh, De, H, Ly = cfg["model_width"], cfg["edge_width"], cfg.get("num_heads", 8), cfg["model_height"]
+    g = generator
+
+    def glorot(fi, fo):
+        lim = math.sqrt(6.0 / (fi + fo))
+        return (torch.rand(fi, fo, generator=g, dtype=torch.float64) * 2 - 1) * lim
+
+    def vec(n, base):
+        if randomize:
+            return base + 0.2 * torch.randn(n, generator=g, dtype=torch.float64)
+        return torch.full((n,), float(base), dtype=torch.float64)
+
+    p = {
+        "node_emb.embeddings": torch.rand(cfg.get("num_node_features", 28) + 1, Dh, generator=g, dtype=torch.float64) * 0.1 - 0.05,
+        "fm_emb.embeddings": torch.rand(cfg.get("num_edge_features", 4) + 1, De, generator=g, dtype=torch.float64) * 0.1 - 0.05,
+        "adj_emb.kernel": glorot(cfg["upto_hop"], De), "adj_emb.bias": vec(De, 0.0),
+        "node_norm_final.gamma": vec(Dh, 1.0), "node_norm_final.beta": vec(Dh, 0.0),
+        "edge_norm_final.gamma": vec(De, 1.0), "edge_norm_final.beta": vec(De, 0.0),
+    }
+    if randomize:   # embeddings of O(1) so the layer norms see real signal
+        p["node_emb.embeddings"] = p["node_emb.embeddings"] * 20
+        p["fm_emb.embeddings"] = p["fm_emb.embeddings"] * 20
+    w = Dh
+    for ii, f in enumerate(cfg.get("mlp_layers", [0.5, 0.25])):
+        wo = round(f * Dh)
+        p[f"mlp_out_{ii}.kernel"] = glorot(w, wo)
+        p[f"mlp_out_{ii}.bias"] = vec(wo, 0.0)
+        w = wo
+    p["target.kernel"] = glorot(w, cfg.get("num_targets", 1))
+    p["target.bias"] = vec(cfg.get("num_targets", 1), 0.0)
+    for ii in range(Ly):
+        for k, v in O.init_block_params(Dh, De, H, dtype=torch.float64, generator=g, randomize_norm=randomize).items():
+            p[f"layer{ii}.{k}"] = v
+        for tag, W in (("node", Dh), ("edge", De)):
+            hid = round(W * cfg.get("ffn_multiplier", 2.0))
+            p[f"layer{ii}.ffn_{tag}.norm_gamma"] = vec(W, 1.0)
+            p[f"layer{ii}.ffn_{tag}.norm_beta"] = vec(W, 0.0)
+            p[f"layer{ii}.ffn_{tag}.lr1_kernel"] = glorot(W, hid)
+            p[f"layer{ii}.ffn_{tag}.lr1_bias"] = vec(hid, 0.0)
+            p[f"layer{ii}.ffn_{tag}.lr2_kernel"] = glorot(hid, W)
+            p[f"layer{ii}.ffn_{tag}.lr2_bias"] = vec(W, 0.0)
+    return {k: v.to(dtype) for k, v in p.items()}
+
+
+def zinc_embeddings(node_features, feature_matrix, graph_matrix, p, cfg):
+    """get_embeddings (graph_xformer_model_base.py:411-431) for the zinc.svd model without SVD features."""
+    dt = p["node_emb.embeddings"].dtype
+    h = neg1_masked_embedding(node_features, p["node_emb.embeddings"])                      # zinc/dc.py:66-69
+    e_fm = neg1_masked_embedding(feature_matrix, p["fm_emb.embeddings"])                    # zinc/dc.py:70-73
+    hops = stack_hops(graph_matrix.to(dt), cfg["upto_hop"], cfg.get("clip_hops", True))     # graph_model_base.py:101-119
+    e_adj = O.dense(hops, p["adj_emb.kernel"], p["adj_emb.bias"])                           # :125-126
+    e = e_adj + e_fm                                                                        # edge_emb_add, :403-404
+    mask = O.node_mask_from_features(node_features)                                         # masking.py:42-43
+    return h, e, mask
+
+
+def zinc_forward(node_features, feature_matrix, graph_matrix, p, cfg, rand_masks=None, return_hidden=False):
+    """DCSVDTransformer.call -> prediction [B, num_targets] (graph_xformer_model_base.py:447-466).
+    rand_masks: per-layer injected random attention masks (training with random_mask_prob > 0)."""
+    H, Ly = cfg.get("num_heads", 8), cfg["model_height"]
+    act = cfg.get("activation", "elu")
+    h, e, mask = zinc_embeddings(node_features, feature_matrix, graph_matrix, p, cfg)
+    for ii in range(Ly):
+        bp = {k[len(f"layer{ii}."):]: v for k, v in p.items()
+              if k.startswith(f"layer{ii}.") and ".ffn_" not in k}
+        rm = None if rand_masks is None else rand_masks[ii]
+        h, e = O.block_forward(h, e, mask, bp, num_heads=H, rand_mask=rm)                   # layer/ii/attention, :338-339
+        fn = {k.split(".", 2)[2]: v for k, v in p.items() if k.startswith(f"layer{ii}.ffn_node.")}
+        fe = {k.split(".", 2)[2]: v for k, v in p.items() if k.startswith(f"layer{ii}.ffn_edge.")}
+        e = O.ffn_forward(e, fe, activation=act)                                            # layer/ii/ffn, :309-324
+        h = O.ffn_forward(h, fn, activation=act)
+    if cfg.get("do_final_norm", True):                                                      # :343-347
+        h = O.layer_norm(h, p["node_norm_final.gamma"], p["node_norm_final.beta"])
+        e = O.layer_norm(e, p["edge_norm_final.gamma"], p["edge_norm_final.beta"])
+    x = masked_global_avg_pool_1d(h, mask)                                                  # zinc/dc.py:109
+    x = mlp_out(x, p, len(cfg.get("mlp_layers", [0.5, 0.25])), act)                         # :115
+    y = O.dense(x, p["target.kernel"], p["target.bias"])                                    # :116-117
+    if return_hidden:
+        return y, h, e, mask
+    return y
+
+
+def mae_loss(y_pred, y_true):
+    """keras.losses.MeanAbsoluteError (schemes/zinc/svd.py:37-39): mean |y - y'| over the batch."""
+    return (y_pred - y_true).abs().mean()

@@ -195,3 +195,41 @@ def ffn_oracle(inp, params, c, dtype=torch.float64):
     y = O.ffn_forward(x, p, activation=c["act"])
     gr = torch.autograd.grad(y, [x] + [p[k] for k in FFN_NAMES], inp["dy"].to(dtype))
     return {"y": y.detach(), "dx": gr[0], "dparams": dict(zip(FFN_NAMES, gr[1:]))}
+
+
+# ----------------------------------------------------------------- whole ZINC model -----
+MODEL_CASES = {
+    # name: model config (reference model_config keys) + batch geometry
+    "zinc_small": dict(cfg=dict(model_width=16, edge_width=16, model_height=2, upto_hop=4), B=3, N=11, nodes=(4, 11)),
+    "zinc_w64": dict(cfg=dict(model_width=64, edge_width=64, model_height=2, upto_hop=16), B=2, N=21, nodes=(9, 21)),
+}
+
+
+def make_model_case(name, seed=99):
+    from oracle import egt_model_oracle as MO
+    c = MODEL_CASES[name]
+    g = torch.Generator().manual_seed(seed + sum(map(ord, name)))
+    B, N = c["B"], c["N"]
+    lo, hi = c["nodes"]
+    n = torch.randint(lo, hi + 1, (B,), generator=g); n[0] = N
+    real = torch.arange(N)[None, :] < n[:, None]
+    nf = torch.randint(0, 28, (B, N), generator=g)
+    nf[~real] = -1
+    adj = (torch.rand(B, N, N, generator=g) > 0.7).float()
+    adj = ((adj + adj.transpose(1, 2)) > 0).float() * (real[:, :, None] & real[:, None, :]).float()
+    adj = adj * (1 - torch.eye(N))[None]
+    fm = torch.where(adj > 0, torch.randint(0, 4, (B, N, N), generator=g), torch.tensor(-1))
+    fm = torch.minimum(fm, fm.transpose(1, 2)) if False else fm
+    y = torch.randn(B, 1, generator=g)
+    params = MO.init_zinc_params(c["cfg"], dtype=torch.float32, generator=g)
+    return dict(node_features=nf, feature_matrix=fm, graph_matrix=adj, target=y), params, c
+
+
+def model_oracle(inp, params, c, dtype=torch.float64, rand_masks=None):
+    from oracle import egt_model_oracle as MO
+    p = {k: v.to(dtype).requires_grad_() for k, v in params.items()}
+    y = MO.zinc_forward(inp["node_features"], inp["feature_matrix"], inp["graph_matrix"], p, c["cfg"], rand_masks=rand_masks)
+    loss = MO.mae_loss(y, inp["target"].to(dtype))
+    names = list(p.keys())
+    grads = torch.autograd.grad(loss, [p[k] for k in names], allow_unused=True)
+    return dict(y=y.detach(), loss=loss.detach().reshape(1)), {k: g for k, g in zip(names, grads)}

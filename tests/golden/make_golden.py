@@ -38,6 +38,14 @@ def main():
         tree = {"in": inp, "params": params, "out": {"y": out["y"].float(), "dx": out["dx"].float()},
                 "dparams": {k: v.float() for k, v in out["dparams"].items()}}
         CS.save_npz(os.path.join(CS.GOLDEN_DIR, f"ffn_{name}.npz"), tree)
+    for name in CS.MODEL_CASES:
+        inp, params, c = CS.make_model_case(name)
+        out, dparams = CS.model_oracle(inp, params, c)
+        keep = [k for k in dparams if dparams[k] is not None and
+                (not k.startswith("layer") or k.startswith("layer0.") or "dense_qkv" in k)]   # a subset keeps the fixture small
+        tree = {"in": inp, "out": {k: v.float() for k, v in out.items()},
+                "dparams": {k: dparams[k].float() for k in keep}}
+        CS.save_npz(os.path.join(CS.GOLDEN_DIR, f"model_{name}.npz"), tree)
     print("wrote", len(os.listdir(CS.GOLDEN_DIR)) - 1, "fixtures to", CS.GOLDEN_DIR)
 
 

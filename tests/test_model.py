@@ -1,0 +1,183 @@
+"""Whole ZINC model: oracle vs committed fixtures and its own invariants on CPU; the
+product model (HIP edge embedding + attention blocks + FFNs behind the C-ABI, torch node-side head)
+against the fp64 oracle on the GPU: prediction, loss and every parameter gradient."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases as CS
+from util import assert_close, load_golden, FWD, BWD
+
+
+@pytest.mark.parametrize("name", list(CS.MODEL_CASES))
+def test_model_oracle_matches_golden(name):
+    g = load_golden(os.path.join(CS.GOLDEN_DIR, f"model_{name}.npz"))
+    inp, params, c = CS.make_model_case(name)
+    for k, v in g["in"].items():
+        assert np.array_equal(inp[k].numpy(), v), k
+    out, dparams = CS.model_oracle(inp, params, c)
+    assert_close(out["y"].float(), g["out"]["y"], rtol=1e-6, arel=1e-6, name="y")
+    assert_close(out["loss"].float(), g["out"]["loss"], rtol=1e-6, arel=1e-6, name="loss")
+    for k, v in g["dparams"].items():
+        assert_close(dparams[k].float(), v, rtol=1e-5, arel=1e-6, name=k)
+
+
+def test_model_oracle_invariants():
+    """padding invariance: scrambling padded node features' edges / adding padded nodes leaves the
+    prediction unchanged; the dead last-layer edge parameters get no gradient (they are not part of the
+    reference's Keras model); hop stacking is idempotent once every reachable pair is 1."""
+    from oracle import egt_model_oracle as MO
+    inp, params, c = CS.make_model_case("zinc_small")
+    out, dparams = CS.model_oracle(inp, params, c)
+    Ly = c["cfg"]["model_height"]
+    for k, g in dparams.items():
+        dead = k.startswith(f"layer{Ly - 1}.dense_edge_r") or k.startswith(f"layer{Ly - 1}.ffn_edge") or k.startswith("edge_norm_final")
+        if dead:
+            assert g is None or float(g.abs().max()) == 0.0, k
+        else:
+            assert g is not None and float(g.abs().max()) > 0.0, k
+    # grow the padding: same graphs padded to N + 3
+    B, N = inp["node_features"].shape
+    pad = lambda t, v: torch.nn.functional.pad(t, (0, 3) if t.dim() == 2 else (0, 3, 0, 3), value=v)
+    inp2 = dict(node_features=pad(inp["node_features"], -1), feature_matrix=pad(inp["feature_matrix"], -1),
+                graph_matrix=pad(inp["graph_matrix"], 0.0), target=inp["target"])
+    out2, _ = CS.model_oracle(inp2, params, c)
+    assert_close(out2["y"], out["y"], rtol=1e-9, arel=1e-9, name="padding invariance")
+    hops = MO.stack_hops(inp["graph_matrix"].double(), 12)
+    assert set(hops.unique().tolist()) <= {0.0, 1.0}
+    assert torch.equal(hops[..., 11], MO.stack_hops(inp["graph_matrix"].double(), 13)[..., 11])
+
+
+# ------------------------------------------------------------------------------------ GPU -----
+def _load_params(model, params, dev):
+    named = model.keras_named_parameters()
+    Ly = len(model.layers.blocks)
+    with torch.no_grad():
+        model.node_emb.copy_(params["node_emb.embeddings"]); model.fm_emb.copy_(params["fm_emb.embeddings"])
+        model.adj_emb.kernel.copy_(params["adj_emb.kernel"]); model.adj_emb.bias.copy_(params["adj_emb.bias"])
+        model.node_norm_final.gamma.copy_(params["node_norm_final.gamma"]); model.node_norm_final.beta.copy_(params["node_norm_final.beta"])
+        for i, m in enumerate(model.mlp_out):
+            m.kernel.copy_(params[f"mlp_out_{i}.kernel"]); m.bias.copy_(params[f"mlp_out_{i}.bias"])
+        model.target.kernel.copy_(params["target.kernel"]); model.target.bias.copy_(params["target.bias"])
+        for ii in range(Ly):
+            blk = model.layers.blocks[ii]
+            for k in ("norm_edge.gamma", "norm_edge.beta", "attention_gates.kernel", "attention_gates.bias",
+                      "dense_edge_b.kernel", "dense_edge_b.bias", "norm_mha.gamma", "norm_mha.beta", "dense_qkv.kernel",
+                      "dense_qkv.bias", "dense_mha.kernel", "dense_mha.bias", "dense_edge_r.kernel", "dense_edge_r.bias"):
+                m, a = k.split(".")
+                getattr(getattr(blk, m), a).copy_(params[f"layer{ii}.{k}"])
+            for tag, lst in (("node", model.layers.ffn_node), ("edge", model.layers.ffn_edge)):
+                for a in ("norm_gamma", "norm_beta", "lr1_kernel", "lr1_bias", "lr2_kernel", "lr2_bias"):
+                    getattr(lst[ii], a).copy_(params[f"layer{ii}.ffn_{tag}.{a}"])
+    return named
+
+
+def _grad_of(model, key):
+    """oracle parameter name -> the module parameter"""
+    if key == "node_emb.embeddings":
+        return model.node_emb
+    if key == "fm_emb.embeddings":
+        return model.fm_emb
+    parts = key.split(".")
+    if parts[0].startswith("layer"):
+        ii = int(parts[0][5:])
+        if parts[1].startswith("ffn_"):
+            lst = model.layers.ffn_node if parts[1] == "ffn_node" else model.layers.ffn_edge
+            return getattr(lst[ii], parts[2])
+        return getattr(getattr(model.layers.blocks[ii], parts[1]), parts[2])
+    if parts[0].startswith("mlp_out_"):
+        return getattr(model.mlp_out[int(parts[0][8:])], parts[1])
+    if parts[0] == "edge_norm_final":
+        return None
+    return getattr(getattr(model, parts[0]), parts[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,De,K,V", [(2, 9, 16, 4, 5), (3, 37, 64, 16, 5), (2, 64, 64, 16, 5), (1, 21, 48, 1, 3), (2, 70, 8, 7, 5)])
+def test_edge_embed_vs_oracle(B, N, De, K, V, gpu, egt_lib):
+    from egt_amd import edge_embed
+    from oracle import egt_model_oracle as MO, egt_oracle as O
+    g = torch.Generator().manual_seed(B * 100 + N)
+    adj = (torch.rand(B, N, N, generator=g) > 0.8).float()
+    adj = ((adj + adj.transpose(1, 2)) > 0).float()
+    fm = torch.where(adj > 0, torch.randint(0, V - 1, (B, N, N), generator=g), torch.tensor(-1))
+    table = torch.randn(V, De, generator=g); W = torch.randn(K, De, generator=g) * 0.3; b = torch.randn(De, generator=g) * 0.2
+    de = torch.randn(B, N, N, De, generator=g)
+    t64, W64, b64 = (x.double().requires_grad_() for x in (table, W, b))
+    hops_o = MO.stack_hops(adj.double(), K)
+    e_o = O.dense(hops_o, W64, b64) + MO.neg1_masked_embedding(fm, t64)
+    gr = torch.autograd.grad(e_o, [t64, W64, b64], de.double())
+    tg, Wg, bg = (x.to(gpu).requires_grad_() for x in (table, W, b))
+    e, hops = edge_embed(fm.to(gpu), adj.to(gpu), tg, Wg, bg, return_hops=True)
+    assert torch.equal(hops.cpu(), hops_o.float()), "hop matrices of a 0/1 adjacency are exact"
+    assert_close(e, e_o, name="e0", **FWD)
+    e.backward(de.to(gpu))
+    assert_close(tg.grad, gr[0], name="d fm_emb", **BWD)
+    assert_close(Wg.grad, gr[1], name="d adj_emb.kernel", **BWD)
+    assert_close(bg.grad, gr[2], name="d adj_emb.bias", **BWD)
+    # weighted (non-binary) adjacency without clipping: fp32 contraction within tolerance
+    adjw = adj * torch.rand(B, N, N, generator=g)
+    _, hw = edge_embed(fm.to(gpu), adjw.to(gpu), tg, Wg, bg, clip_hops=False, return_hops=True)
+    assert_close(hw, MO.stack_hops(adjw.double(), K, clip_hops=False), name="weighted hops", rtol=1e-4, arel=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CS.MODEL_CASES))
+def test_zinc_model_vs_oracle_and_golden(name, gpu, egt_lib):
+    from egt_amd import ZincDCTransformer, mae_loss
+    inp, params, c = CS.make_model_case(name)
+    model = ZincDCTransformer(random_mask_prob=0.0, **c["cfg"]).to(gpu).eval()
+    _load_params(model, params, gpu)
+    out, dparams = CS.model_oracle(inp, params, c)
+    y = model(inp["node_features"].to(gpu), inp["feature_matrix"].to(gpu), inp["graph_matrix"].to(gpu))
+    loss = mae_loss(y, inp["target"].to(gpu))
+    loss.backward()
+    assert_close(y, out["y"], name="prediction", rtol=2e-4, arel=5e-5)
+    assert_close(loss.reshape(1), out["loss"], name="MAE", rtol=2e-4, arel=5e-5)
+    gold = load_golden(os.path.join(CS.GOLDEN_DIR, f"model_{name}.npz"))
+    assert_close(y, gold["out"]["y"], name="prediction vs golden", rtol=2e-4, arel=5e-5)
+    dead = {id(p) for p in model._dead_edge_params()}
+    for k, gref in dparams.items():
+        prm = _grad_of(model, k)
+        if prm is None:
+            continue
+        if gref is None or id(prm) in dead:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, k
+            continue
+        assert_close(prm.grad, gref, name=k, **BWD)
+    for k, v in gold["dparams"].items():
+        prm = _grad_of(model, k)
+        if prm is not None and id(prm) not in dead:
+            assert_close(prm.grad, v, name=f"{k} vs golden", **BWD)
+
+
+@pytest.mark.gpu
+def test_zinc_model_training_masks_and_names(gpu, egt_lib):
+    """training mode: every block draws its random attention mask from the counter hash; the oracle gets the
+    same sample (oracle/rng_ref.py).  Also: parameter names are the reference's Keras variable names."""
+    from egt_amd import ZincDCTransformer, mae_loss
+    from oracle import rng_ref
+    inp, params, c = CS.make_model_case("zinc_small")
+    p_rm = 0.3
+    model = ZincDCTransformer(random_mask_prob=p_rm, seed=5, **c["cfg"]).to(gpu).train()
+    _load_params(model, params, gpu)
+    B, N = inp["node_features"].shape
+    rms = []
+    for blk in model.layers.blocks:
+        m = blk.mha
+        sd = (m.seed * 0x9E3779B97F4A7C15 + (m._calls + 1) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        rms.append(torch.from_numpy(rng_ref.random_mask(sd, B, N, 8, p_rm)))
+    out, dparams = CS.model_oracle(inp, params, c, rand_masks=rms)
+    y = model(inp["node_features"].to(gpu), inp["feature_matrix"].to(gpu), inp["graph_matrix"].to(gpu))
+    mae_loss(y, inp["target"].to(gpu)).backward()
+    assert_close(y, out["y"], name="prediction (training)", rtol=2e-4, arel=5e-5)
+    assert_close(model.layers.blocks[0].dense_qkv.kernel.grad, dparams["layer0.dense_qkv.kernel"], name="dWqkv0", **BWD)
+    assert_close(model.fm_emb.grad, dparams["fm_emb.embeddings"], name="d fm_emb", **BWD)
+    names = model.keras_named_parameters()
+    for k in ("node_emb/embeddings", "fm_emb/embeddings", "adj_emb/kernel", "dense_qkv_00/kernel", "norm_edge_01/gamma",
+              "fnn_lr1_edge_00/kernel", "norm_fnn_node_01/beta", "node_norm_final/gamma", "mlp_out_0/kernel", "target/bias"):
+        assert k in names, k
+    Ly = c["cfg"]["model_height"]
+    assert f"dense_edge_r_{Ly - 1:0>2d}/kernel" not in names and f"fnn_lr1_edge_{Ly - 1:0>2d}/kernel" not in names
