@@ -252,6 +252,10 @@ def main():
                     help="stack (default, the headline): the attention-block stack; layers (= --with-ffn): attention block + "
                          "node/edge FFN per layer; model: the whole ZINC model (embeddings, hop stacking, layers, final norm, "
                          "masked mean pooling, MLP head, MAE loss), SURVEY 8(f)-2 -- NOT the headline workload")
+    ap.add_argument("--ffn-matmul", default="f32", choices=["f32", "bf16x3", "bf16"],
+                    help="layers / model scopes: how the channel FFN evaluates its matrix products (egt_ffn_desc.matmul): "
+                         "f32 exact (default); bf16x3 3-term bfloat16 split on the bf16 matrix pipe, fp32 accumulate, "
+                         "per-product error 2^-16 (holds the fp32 parity tolerances); bf16 plain bfloat16 products")
     ap.add_argument("--layers", type=int, default=0, help="override the workload's layer count (1 = single-block scope)")
     ap.add_argument("--fused", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--cpu-seconds", type=float, default=18.0)
@@ -321,14 +325,16 @@ def main():
         from egt_amd import ZincDCTransformer, mae_loss
         from types import SimpleNamespace
         model = ZincDCTransformer(model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"], model_height=w["Ly"],
-                                  upto_hop=16, random_mask_prob=w["rand_p"], seed=mask_seed).to(dev).train()
+                                  upto_hop=16, random_mask_prob=w["rand_p"], seed=mask_seed,
+                                  ffn_matmul=args.ffn_matmul).to(dev).train()
         model.fused_parameters = model.trainable_parameters
         model.grad_holder = SimpleNamespace(flat=None)
         zinc = make_zinc_inputs(w, dev, seed=1234 + rank)
     elif args.with_ffn:
         from egt_amd import EGTLayerStack
         model = EGTLayerStack(model_height=w["Ly"], model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"],
-                              random_mask_prob=w["rand_p"], seed=mask_seed, fused=fused).to(dev).train()
+                              random_mask_prob=w["rand_p"], seed=mask_seed, fused=fused,
+                              ffn_matmul=args.ffn_matmul).to(dev).train()
         model.fused_parameters = lambda: list(model.parameters())
         from types import SimpleNamespace
         model.grad_holder = SimpleNamespace(flat=None)   # per-block calls: classic flat buffer bound to .grad
@@ -490,6 +496,7 @@ def main():
                                         "attention-block stack (h,e,mask)->(h',e') x Ly, fwd+bwd")
                                     + " + param grads" + (" + flat RCCL grad all-reduce" if world > 1 else "")),
                        "scope": args.scope or ("layers" if args.with_ffn else "stack"),
+                       "ffn_matmul": args.ffn_matmul if (args.with_ffn or args.scope == "model") else None,
                        "graphs_per_gpu": w["B"], "global_batch": graphs_step, "N": w["N"],
                        "Dh": w["Dh"], "De": w["De"], "H": w["H"], "d": w["Dh"] // w["H"], "Ly": w["Ly"],
                        "random_mask_prob": w["rand_p"], "nodes": list(w["nodes"]), "path": path,

@@ -50,7 +50,10 @@ class BlockDesc(C.Structure):
 
 class FfnDesc(C.Structure):
     _fields_ = [("rows", C.c_int64), ("width", C.c_int32), ("dtype", C.c_int32),
-                ("activation", C.c_int32), ("ln_eps", C.c_float)]
+                ("activation", C.c_int32), ("ln_eps", C.c_float), ("matmul", C.c_int32), ("reserved", C.c_int32)]
+
+
+MM_F32, MM_BF16X3, MM_BF16 = 0, 1, 2   # egt_ffn_desc.matmul
 
 
 FFN_PARAM_FIELDS = ("norm_gamma", "norm_beta", "lr1_kernel", "lr1_bias", "lr2_kernel", "lr2_bias")
@@ -161,7 +164,7 @@ def load():
         if hasattr(lib, name):
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-    if lib.egt_abi_version() != 1:
+    if lib.egt_abi_version() != 2:
         raise EGTLibraryError("ABI version mismatch")
     _lib = lib
     return lib

@@ -129,28 +129,33 @@ __global__ void __launch_bounds__(256) k_edge_embed_bwd(const int32_t* __restric
   }
 }
 
-// deterministic reduction of the workgroup partials + split into the three gradients
+// deterministic reduction of the workgroup partials + split into the three gradients.
+// block = 64 outputs x 4 partial groups (group g sums partials j = g, g+4, ... in order; the four group sums
+// are added in a fixed order: bit-reproducible); the bias gradient is the column sum of the table gradient
+// (every pair selects exactly one table row)
 __global__ void __launch_bounds__(256) k_edge_embed_bwd_reduce(const float* __restrict__ part, int nparts, int K, int V, int De,
                                                                float* __restrict__ dW, float* __restrict__ dtable,
                                                                float* __restrict__ dbias) {
+  __shared__ float red[4][64];
   const int R = (K + V) * De;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= R) return;
-  double s = 0.0;
-  for (int j = 0; j < nparts; ++j) s += (double)part[(size_t)j * R + i];
-  if (i < K * De) dW[i] = (float)s;
-  else dtable[i - K * De] = (float)s;
-  if (i >= K * De && dbias) {
-    // bias gradient = column sums of the table gradient (every pair selects exactly one row)
-    // done by the thread of row 0: walk the V rows
-    if (i < (K + 1) * De) {
-      const int c = i - K * De;
-      double b = 0.0;
-      for (int v = 0; v < V; ++v)
-        for (int j = 0; j < nparts; ++j) b += (double)part[(size_t)j * R + (K + v) * De + c];
-      dbias[c] = (float)b;
-    }
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  float s = 0.f;
+  if (i < R)
+    for (int j = g; j < nparts; j += 4) s += part[(size_t)j * R + i];
+  red[g][o] = s;
+  __syncthreads();
+  if (g == 0 && i < R) {
+    const float v = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    if (i < K * De) dW[i] = v; else dtable[i - K * De] = v;
   }
+}
+__global__ void __launch_bounds__(64) k_edge_embed_bias_grad(const float* __restrict__ dtable, int V, int De, float* __restrict__ dbias) {
+  const int c = threadIdx.x;
+  if (c >= De) return;
+  float b = 0.f;
+  for (int v = 0; v < V; ++v) b += dtable[v * De + c];
+  dbias[c] = b;
 }
 
 static int embed_check(const egt_embed_desc* d) {
@@ -239,9 +244,11 @@ extern "C" int egt_edge_embed_bwd(const egt_embed_desc* d, const int32_t* featur
 #undef C
   }
   const int R = (d->upto_hop + d->num_edge_features + 1) * d->De;
-  EGT_LAUNCH("k_edge_embed_bwd_reduce", k_edge_embed_bwd_reduce, dim3((R + 255) / 256), dim3(256), 0, st, (const float*)part,
+  EGT_LAUNCH("k_edge_embed_bwd_reduce", k_edge_embed_bwd_reduce, dim3((R + 63) / 64), dim3(256), 0, st, (const float*)part,
              embed_nparts(d), d->upto_hop, d->num_edge_features + 1, d->De, (float*)d_adj_kernel, (float*)d_fm_table,
              (float*)d_adj_bias);
+  EGT_LAUNCH("k_edge_embed_bwd_reduce", k_edge_embed_bias_grad, dim3(1), dim3(64), 0, st, (const float*)d_fm_table,
+             d->num_edge_features + 1, d->De, (float*)d_adj_bias);
   EGT_HIP_LAUNCH_CHECK("egt_edge_embed_bwd");
   return EGT_OK;
 }

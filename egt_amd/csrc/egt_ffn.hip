@@ -36,6 +36,9 @@ struct FfnArgs {
   const float *gamma, *beta, *W1, *b1, *W2, *b2;
   // prepared operands (workspace)
   float *slab1, *slab2, *slab3, *slab4, *b1p;
+  uint16_t *sA1, *sA2;   // EGT_MM_BF16X3 / EGT_MM_BF16: bf16 (hi | lo) A-operand slabs of the two forward GEMMs
+  uint16_t *sA3, *sA4;   // ... and of the backward's dhid = W2 . dy and dxhat = W1p . dpre
+  int mm;                // egt_ffn_desc.matmul
   float *part, *red;   // backward: per-workgroup partials, reduced sums
   float *g_gamma, *g_beta, *g_W1, *g_b1, *g_W2, *g_b2;
   int nwg;
@@ -216,21 +219,251 @@ __global__ void __launch_bounds__(512, 2) k_ffn_fwd(FfnArgs a) {
   }
 }
 
-// ================================================================= backward =====
-template <int W, int ACT>
-__global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
+// ================================================= forward on the bf16 matrix pipe =====
+// egt_ffn_desc.matmul = EGT_MM_BF16X3: every fp32 operand v is split into two bfloat16 terms,
+// v = hi + lo (hi = bf16(v), lo = bf16(v - hi): 16 mantissa bits survive), and a product a.b is
+// evaluated as a_hi.b_hi + a_lo.b_hi + a_hi.b_lo on v_mfma_f32_16x16x32_bf16 with fp32 accumulation
+// (the dropped a_lo.b_lo term is 2^-18 relative; every bf16 x bf16 product is exact in fp32).  Per-product
+// error <= 2^-16 instead of fp32's 2^-24 -- the outputs stay inside the fp32 parity tolerances of the
+// test-suite (tests/test_ffn_gpu.py runs the SAME tolerances on this mode) -- at 3/16 of the fp32 MFMA
+// cost: 96 bf16 MFMAs of 16 cycles per 16-row tile instead of 256 fp32 MFMAs of 32 cycles, which turns
+// the FFN from MFMA-bound (0.46 of the fp32 matrix peak) into an HBM-bound streaming kernel.
+// EGT_MM_BF16 keeps only the hi terms (plain bf16 products, fp32 accumulate; tolerance rtol 2e-2).
+// Same tile flow and fragment layout as k_ffn_fwd: lane (p, q) holds row p's channels 16t + 4q + {0..3};
+// one 16x16x32 step contracts the 8 values a lane holds of channel tiles 2s and 2s+1 (slot i <-> tile
+// 2s + (i >> 2), offset i & 3) -- both operands use that order, so the accumulators of GEMM 1 are again
+// the B operand of GEMM 2 without leaving the lane.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+union Bf8 { bf16x8_t v; uint32_t u[4]; uint4 q; };
+#define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  const bf16x2_t r = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);   // v_cvt_pk_bf16_f32 (RNE)
+  return *reinterpret_cast<const uint32_t*>(&r);
+}
+// 8 fp32 values -> hi / lo bf16x8 (lo only when SPLIT)
+template <bool SPLIT>
+__device__ __forceinline__ void split8(const float (&v)[8], Bf8& hi, Bf8& lo) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t h = pk_bf16(v[2 * k], v[2 * k + 1]);
+    hi.u[k] = h;
+    if (SPLIT) {
+      const float f0 = __uint_as_float(h << 16), f1 = __uint_as_float(h & 0xFFFF0000u);
+      lo.u[k] = pk_bf16(v[2 * k] - f0, v[2 * k + 1] - f1);
+    } else {
+      lo.u[k] = 0u;
+    }
+  }
+}
+
+// sA1[j][s][part][lane][i] = bf16_part( gamma[c] W1[c][16j + pl] ),  c = 16 (2s + (i >> 2)) + 4q + (i & 3)   (0 past W)
+// sA2[o][s][part][lane][i] = bf16_part( W2[hc][16o + pl] ),         hc = 16 (2s + (i >> 2)) + 4q + (i & 3)
+// part 0 = hi, 1 = lo; NS1 = ceil(TW / 2) steps for GEMM 1, TW steps for GEMM 2 (hidden = 2W = TW x 32)
+template <int W>
+__global__ void __launch_bounds__(256) k_ffn_prep_bf(FfnArgs a) {
   FFN_GEO(W);
+  constexpr int NS1 = (TW + 1) / 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // one thread per (block, lane, i)
+  auto parts = [](float v, uint16_t& hi, uint16_t& lo) {
+    const uint32_t h = pk_bf16(v, 0.f) & 0xFFFFu;
+    hi = (uint16_t)h;
+    lo = (uint16_t)(pk_bf16(v - __uint_as_float(h << 16), 0.f) & 0xFFFFu);
+  };
+  if (idx < TH * NS1 * 512) {
+    const int i = idx & 7, lane = (idx >> 3) & 63, blk = idx >> 9, s = blk % NS1, j = blk / NS1;
+    const int pl = lane & 15, q = lane >> 4, t = 2 * s + (i >> 2);
+    const int c = 16 * t + 4 * q + (i & 3);
+    const float v = t < TW ? a.gamma[c] * a.W1[c * FH + 16 * j + pl] : 0.f;
+    uint16_t hi, lo;
+    parts(v, hi, lo);
+    a.sA1[((size_t)(blk * 2 + 0) * 64 + lane) * 8 + i] = hi;
+    a.sA1[((size_t)(blk * 2 + 1) * 64 + lane) * 8 + i] = lo;
+  }
+  if (idx < TW * TW * 512) {
+    const int i = idx & 7, lane = (idx >> 3) & 63, blk = idx >> 9, s = blk % TW, o = blk / TW;
+    const int pl = lane & 15, q = lane >> 4;
+    const int hc = 16 * (2 * s + (i >> 2)) + 4 * q + (i & 3);
+    uint16_t hi, lo;
+    parts(a.W2[hc * FW + 16 * o + pl], hi, lo);
+    a.sA2[((size_t)(blk * 2 + 0) * 64 + lane) * 8 + i] = hi;
+    a.sA2[((size_t)(blk * 2 + 1) * 64 + lane) * 8 + i] = lo;
+    // sA4[o][s][part][lane][i] = gamma[16o + pl] W1[16o + pl][hc]      (A operand of dxhat = W1p . dpre)
+    parts(a.gamma[16 * o + pl] * a.W1[(16 * o + pl) * FH + hc], hi, lo);
+    a.sA4[((size_t)(blk * 2 + 0) * 64 + lane) * 8 + i] = hi;
+    a.sA4[((size_t)(blk * 2 + 1) * 64 + lane) * 8 + i] = lo;
+  }
+  if (idx < TH * NS1 * 512) {   // sA3[j][s][part][lane][i] = W2[16j + pl][c]   (A operand of dhid = W2 . dy)
+    const int i = idx & 7, lane = (idx >> 3) & 63, blk = idx >> 9, s = blk % NS1, j = blk / NS1;
+    const int pl = lane & 15, q = lane >> 4, t = 2 * s + (i >> 2);
+    const int c = 16 * t + 4 * q + (i & 3);
+    uint16_t hi, lo;
+    parts(t < TW ? a.W2[(16 * j + pl) * FW + c] : 0.f, hi, lo);
+    a.sA3[((size_t)(blk * 2 + 0) * 64 + lane) * 8 + i] = hi;
+    a.sA3[((size_t)(blk * 2 + 1) * 64 + lane) * 8 + i] = lo;
+  }
+  if (idx < FH) {
+    float s = a.b1[idx];
+    for (int c = 0; c < FW; ++c) s = fmaf(a.beta[c], a.W1[c * FH + idx], s);
+    a.b1p[idx] = s;
+  }
+}
+
+// acc += sum_s A[blk0 + s] . B[s] with the 3-term split (or the hi term only); slab blocks are [part][lane] uint4
+template <int NS, bool SPLIT>
+__device__ __forceinline__ v4f bf_gemm(const float* slab, int blk0, int lane, const Bf8 (&bh)[NS], const Bf8 (&bl)[NS], v4f acc) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    Bf8 ah, al;
+    ah.q = *reinterpret_cast<const uint4*>(slab + ((size_t)((blk0 + s) * 2 + 0) * 64 + lane) * 4);
+    acc = MFMA_BF(ah.v, bh[s].v, acc);
+    if (SPLIT) {
+      al.q = *reinterpret_cast<const uint4*>(slab + ((size_t)((blk0 + s) * 2 + 1) * 64 + lane) * 4);
+      acc = MFMA_BF(al.v, bh[s].v, acc);
+      acc = MFMA_BF(ah.v, bl[s].v, acc);
+    }
+  }
+  return acc;
+}
+// the lane's 4 NT values (channel tiles 0 .. NT-1) -> ceil(NT / 2) split B operands
+template <int NT, bool SPLIT>
+__device__ __forceinline__ void split_tiles(const v4f (&v)[NT], Bf8 (&hi)[(NT + 1) / 2], Bf8 (&lo)[(NT + 1) / 2]) {
+#pragma unroll
+  for (int s = 0; s < (NT + 1) / 2; ++s) {
+    const v4f a0 = v[2 * s];
+    const v4f a1 = (2 * s + 1 < NT) ? v[(2 * s + 1 < NT) ? 2 * s + 1 : 0] : (v4f){0.f, 0.f, 0.f, 0.f};
+    const float f[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    split8<SPLIT>(f, hi[s], lo[s]);
+  }
+}
+
+template <int W, int ACT, bool SPLIT>
+__global__ void __launch_bounds__(512, 2) k_ffn_fwd_bf(FfnArgs a) {
+  FFN_GEO(W);
+  constexpr int NS1 = (TW + 1) / 2;
+  constexpr int A1F = TH * NS1 * 2 * 256, A2F = TW * TW * 2 * 256;   // slab sizes in floats (1 KiB = 256 floats per [part][lane] block)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s1 = sm;
-  float* s3 = s1 + SLABF;
-  float* s4 = s3 + SLABF;
-  float* b1s = s4 + SLABF;          // [128]
+  float* s2 = s1 + A1F;
+  float* b1s = s2 + A2F;            // [2W]
+  float* b2s = b1s + FH;            // [W]
+  float* tiles = b2s + FW;          // [8 waves][2][16 W]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = lane & 15, q = lane >> 4;
+  slab_to_lds(s1, reinterpret_cast<const float*>(a.sA1), A1F, 512);
+  slab_to_lds(s2, reinterpret_cast<const float*>(a.sA2), A2F, 512);
+  if (threadIdx.x < FH) b1s[threadIdx.x] = a.b1p[threadIdx.x];
+  if (threadIdx.x < FW) b2s[threadIdx.x] = a.b2[threadIdx.x];
+  __syncthreads();
+  float* tl0 = tiles + wave * 2 * TILEF;
+  const long ntiles = (a.rows + 15) / 16;
+  const long stride = (long)gridDim.x * 8;
+  long tile = (long)blockIdx.x * 8 + wave;
+  TileRegs<FW> tr;
+  if (tile < ntiles) tile_gload<FW>(tr, a.x + tile * TILEF, lane, (int)min(16L, a.rows - tile * 16));
+  long prev = -1;
+  for (int it = 0; tile < ntiles; tile += stride, ++it) {
+    const int rows_valid = (int)min(16L, a.rows - tile * 16);
+    float* tl = tl0 + (it & 1) * TILEF;
+    lds_sync();
+    if (prev >= 0)   // stream out the previous tile's y from the other buffer
+      tile_from_lds<FW>(tl0 + ((it - 1) & 1) * TILEF, a.y + prev * TILEF, lane, (int)min(16L, a.rows - prev * 16));
+    tile_lds_put<FW>(tl, tr, lane, rows_valid);
+    const long nxt = tile + stride;
+    if (nxt < ntiles) tile_gload<FW>(tr, a.x + nxt * TILEF, lane, (int)min(16L, a.rows - nxt * 16));
+    lds_sync();
+    float4 x[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) x[t] = frag_read<FW>(tl, p, q, t);
+    ln_frags<FW>(x, q, a.ln_eps);                                   // norm_fnn (gamma/beta folded into the weights)
+    Bf8 xh[NS1], xl[NS1];
+#pragma unroll
+    for (int s = 0; s < NS1; ++s) {
+      const float4 x0 = x[2 * s];
+      const float4 x1 = (2 * s + 1 < TW) ? x[(2 * s + 1 < TW) ? 2 * s + 1 : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      split8<SPLIT>(v, xh[s], xl[s]);
+    }
+    v4f h[TH];
+#pragma unroll
+    for (int j = 0; j < TH; ++j) {                                    // fnn_lr1 + activation
+      const float4 bj = *reinterpret_cast<const float4*>(b1s + 16 * j + 4 * q);
+      v4f acc = {bj.x, bj.y, bj.z, bj.w};
+#pragma unroll
+      for (int s = 0; s < NS1; ++s) {
+        Bf8 ah, al;
+        ah.q = *reinterpret_cast<const uint4*>(s1 + ((size_t)((j * NS1 + s) * 2 + 0) * 64 + lane) * 4);
+        acc = MFMA_BF(ah.v, xh[s].v, acc);
+        if (SPLIT) {
+          al.q = *reinterpret_cast<const uint4*>(s1 + ((size_t)((j * NS1 + s) * 2 + 1) * 64 + lane) * 4);
+          acc = MFMA_BF(al.v, xh[s].v, acc);
+          acc = MFMA_BF(ah.v, xl[s].v, acc);
+        }
+      }
+      h[j] = (v4f){ffn_act<ACT>(acc[0]), ffn_act<ACT>(acc[1]), ffn_act<ACT>(acc[2]), ffn_act<ACT>(acc[3])};
+    }
+    Bf8 hh[TW], hl[TW];
+#pragma unroll
+    for (int s = 0; s < TW; ++s) {
+      const float v[8] = {h[2 * s][0], h[2 * s][1], h[2 * s][2], h[2 * s][3], h[2 * s + 1][0], h[2 * s + 1][1], h[2 * s + 1][2], h[2 * s + 1][3]};
+      split8<SPLIT>(v, hh[s], hl[s]);
+    }
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {                                    // fnn_lr2 + res_fnn
+      const float4 xr = frag_read<FW>(tl, p, q, i);
+      const float4 b = *reinterpret_cast<const float4*>(b2s + 16 * i + 4 * q);
+      v4f acc = {xr.x + b.x, xr.y + b.y, xr.z + b.z, xr.w + b.w};
+#pragma unroll
+      for (int s = 0; s < TW; ++s) {
+        Bf8 ah, al;
+        ah.q = *reinterpret_cast<const uint4*>(s2 + ((size_t)((i * TW + s) * 2 + 0) * 64 + lane) * 4);
+        acc = MFMA_BF(ah.v, hh[s].v, acc);
+        if (SPLIT) {
+          al.q = *reinterpret_cast<const uint4*>(s2 + ((size_t)((i * TW + s) * 2 + 1) * 64 + lane) * 4);
+          acc = MFMA_BF(al.v, hh[s].v, acc);
+          acc = MFMA_BF(ah.v, hl[s].v, acc);
+        }
+      }
+      frag_write<FW>(tl, p, q, i, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    }
+    prev = tile;
+    if (nxt >= ntiles) {   // last tile of this wave: flush
+      lds_sync();
+      tile_from_lds<FW>(tl, a.y + tile * TILEF, lane, rows_valid);
+    }
+  }
+}
+
+// ================================================================= backward =====
+// MM: egt_ffn_desc.matmul.  EGT_MM_BF16X3 / EGT_MM_BF16 move the three channel contractions (recompute,
+// dhid = W2 . dy, dxhat = W1p . dpre: 384 of the 640 fp32 MFMAs of a tile) to the bf16 matrix pipe (144 / 48
+// MFMAs of 16 cycles); the weight-gradient contractions over the ROW axis stay exact fp32 (their operands are
+// read transposed out of the fp32 LDS tiles).
+template <int W, int ACT, int MM>
+__global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
+  FFN_GEO(W);
+  constexpr int NS1 = (TW + 1) / 2;
+  constexpr bool SPLIT = MM == EGT_MM_BF16X3;
+  constexpr int S1F = MM ? TH * NS1 * 2 * 256 : SLABF, S4F = MM ? TW * TW * 2 * 256 : SLABF;   // slab sizes in floats
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s1 = sm;
+  float* s3 = s1 + S1F;
+  float* s4 = s3 + S1F;
+  float* b1s = s4 + S4F;            // [128]
   float* tiles = b1s + FH;          // [4 waves][x | dy | hid/dpre half][TILEF]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p0 = lane & 15, q0 = lane >> 4;
-  slab_to_lds(s1, a.slab1, SLABF, 256);
-  slab_to_lds(s3, a.slab3, SLABF, 256);
-  slab_to_lds(s4, a.slab4, SLABF, 256);
+  if constexpr (MM != 0) {
+    slab_to_lds(s1, reinterpret_cast<const float*>(a.sA1), S1F, 256);
+    slab_to_lds(s3, reinterpret_cast<const float*>(a.sA3), S1F, 256);
+    slab_to_lds(s4, reinterpret_cast<const float*>(a.sA4), S4F, 256);
+  } else {
+    slab_to_lds(s1, a.slab1, SLABF, 256);
+    slab_to_lds(s3, a.slab3, SLABF, 256);
+    slab_to_lds(s4, a.slab4, SLABF, 256);
+  }
   if (threadIdx.x < FH) b1s[threadIdx.x] = a.b1p[threadIdx.x];
   __syncthreads();
   float* et = tiles + wave * 3 * TILEF;
@@ -285,10 +518,24 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
       rstd = ln_frags<FW>(x, q, a.ln_eps);
 #pragma unroll
       for (int t = 0; t < TW; ++t) frag_write<FW>(et, p, q, t, x[t]);   // xhat: A operand of T1 (other rows) + LN backward
+      if constexpr (MM != 0) {
+        v4f xv[TW];
+        Bf8 xh[NS1], xl[NS1];
 #pragma unroll
-      for (int j = 0; j < TH; ++j) {
-        const v4f pre = ffn_gemm1<W>(s1, b1s, x, j, lane, q);
-        h[j] = (v4f){ffn_act<ACT>(pre[0]), ffn_act<ACT>(pre[1]), ffn_act<ACT>(pre[2]), ffn_act<ACT>(pre[3])};
+        for (int t = 0; t < TW; ++t) xv[t] = (v4f){x[t].x, x[t].y, x[t].z, x[t].w};
+        split_tiles<TW, SPLIT>(xv, xh, xl);
+#pragma unroll
+        for (int j = 0; j < TH; ++j) {
+          const float4 bj = *reinterpret_cast<const float4*>(b1s + 16 * j + 4 * q);
+          const v4f pre = bf_gemm<NS1, SPLIT>(s1, j * NS1, lane, xh, xl, (v4f){bj.x, bj.y, bj.z, bj.w});
+          h[j] = (v4f){ffn_act<ACT>(pre[0]), ffn_act<ACT>(pre[1]), ffn_act<ACT>(pre[2]), ffn_act<ACT>(pre[3])};
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TH; ++j) {
+          const v4f pre = ffn_gemm1<W>(s1, b1s, x, j, lane, q);
+          h[j] = (v4f){ffn_act<ACT>(pre[0]), ffn_act<ACT>(pre[1]), ffn_act<ACT>(pre[2]), ffn_act<ACT>(pre[3])};
+        }
       }
     }
     lds_sync();
@@ -302,17 +549,28 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
         dyf[t] = frag_read<FW>(dt, p, q, t);
         sd[t].x += dyf[t].x; sd[t].y += dyf[t].y; sd[t].z += dyf[t].z; sd[t].w += dyf[t].w;
       }
+      Bf8 dyh[NS1], dyl[NS1];
+      if constexpr (MM != 0) {
+        v4f dv[TW];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) dv[t] = (v4f){dyf[t].x, dyf[t].y, dyf[t].z, dyf[t].w};
+        split_tiles<TW, SPLIT>(dv, dyh, dyl);
+      }
 #pragma unroll
       for (int j = 0; j < TH; ++j) {
         v4f acc = {0.f, 0.f, 0.f, 0.f};
-        v4f w[TW];
-        slab_read<TW>(w, s3 + (j * TW * 64 + lane) * 4);
+        if constexpr (MM != 0) {
+          acc = bf_gemm<NS1, SPLIT>(s3, j * NS1, lane, dyh, dyl, acc);
+        } else {
+          v4f w[TW];
+          slab_read<TW>(w, s3 + (j * TW * 64 + lane) * 4);
 #pragma unroll
-        for (int t = 0; t < TW; ++t) {
-          acc = MFMA(w[t][0], dyf[t].x, acc);
-          acc = MFMA(w[t][1], dyf[t].y, acc);
-          acc = MFMA(w[t][2], dyf[t].z, acc);
-          acc = MFMA(w[t][3], dyf[t].w, acc);
+          for (int t = 0; t < TW; ++t) {
+            acc = MFMA(w[t][0], dyf[t].x, acc);
+            acc = MFMA(w[t][1], dyf[t].y, acc);
+            acc = MFMA(w[t][2], dyf[t].z, acc);
+            acc = MFMA(w[t][3], dyf[t].w, acc);
+          }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] *= ffn_dact<ACT>(h[j][r]);
@@ -377,18 +635,24 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
       asm volatile("" : "+v"(p), "+v"(q));   // keep this phase's LDS address math inside the phase (no hoisting out of the tile loop)
       float4 dxh[TW], x[TW];
       float m1 = 0.f, m2 = 0.f;
+      Bf8 dph[TW], dpl[TW];
+      if constexpr (MM != 0) split_tiles<TH, SPLIT>(dp, dph, dpl);
 #pragma unroll
       for (int i = 0; i < TW; ++i) {
         x[i] = frag_read<FW>(et, p, q, i);          // xhat
         v4f acc = {0.f, 0.f, 0.f, 0.f};
-        v4f w[TH];
-        slab_read<TH>(w, s4 + (i * TH * 64 + lane) * 4);
+        if constexpr (MM != 0) {
+          acc = bf_gemm<TW, SPLIT>(s4, i * TW, lane, dph, dpl, acc);
+        } else {
+          v4f w[TH];
+          slab_read<TH>(w, s4 + (i * TH * 64 + lane) * 4);
 #pragma unroll
-        for (int j = 0; j < TH; ++j) {
-          acc = MFMA(w[j][0], dp[j][0], acc);
-          acc = MFMA(w[j][1], dp[j][1], acc);
-          acc = MFMA(w[j][2], dp[j][2], acc);
-          acc = MFMA(w[j][3], dp[j][3], acc);
+          for (int j = 0; j < TH; ++j) {
+            acc = MFMA(w[j][0], dp[j][0], acc);
+            acc = MFMA(w[j][1], dp[j][1], acc);
+            acc = MFMA(w[j][2], dp[j][2], acc);
+            acc = MFMA(w[j][3], dp[j][3], acc);
+          }
         }
         dxh[i] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         m1 += (acc[0] + acc[1]) + (acc[2] + acc[3]);
@@ -521,15 +785,25 @@ static size_t ffn_al(size_t x) { return (x + 63) & ~(size_t)63; }
 
 extern "C" int egt_ffn_supported(const egt_ffn_desc* d) {
   if (!d || d->dtype != EGT_F32 || d->rows <= 0) return 0;
+  if (d->matmul != EGT_MM_F32 && d->matmul != EGT_MM_BF16X3 && d->matmul != EGT_MM_BF16) return 0;
   if (d->width != 16 && d->width != 32 && d->width != 48 && d->width != 64) return 0;
   return d->activation == EGT_ACT_RELU || d->activation == EGT_ACT_ELU;
 }
 
-// [slab1 slab2 slab3 slab4 b1p | red | part x FFN_NWG]
+// [slab1 slab2 slab3 slab4 b1p | red | part x FFN_NWG | sA1 sA2 (bf16 modes)]
+static size_t ffn_bf_slab_floats(size_t W) {   // sA1, sA3: [TH][NS1][2][256] floats each; sA2, sA4: [TW][TW][2][256]
+  const size_t TW = W / 16, NS1 = (TW + 1) / 2;
+  return 2 * (2 * TW * NS1 * 2 * 256) + 2 * (TW * TW * 2 * 256);
+}
+static int ffn_bf_prep_blocks(int W) {
+  const int TW = W / 16, NS1 = (TW + 1) / 2;
+  const int n1 = 2 * TW * NS1 * 512, n2 = TW * TW * 512;
+  return ((n1 > n2 ? n1 : n2) + 255) / 256;
+}
 extern "C" size_t egt_ffn_workspace_bytes(const egt_ffn_desc* d) {
   if (!egt_ffn_supported(d)) return 0;
   const size_t W = d->width, slab = 2 * W * W, part = 2 * slab + 3 * W;
-  return (4 * slab + ffn_al(2 * W) + ffn_al(part) + (size_t)FFN_NWG * part) * sizeof(float);
+  return (4 * slab + ffn_al(2 * W) + ffn_al(part) + (size_t)FFN_NWG * part + ffn_bf_slab_floats(W)) * sizeof(float);
 }
 
 static int ffn_fill(const egt_ffn_desc* d, const egt_ffn_params* p, void* ws, FfnArgs& a) {
@@ -549,6 +823,16 @@ static int ffn_fill(const egt_ffn_desc* d, const egt_ffn_params* p, void* ws, Ff
   a.b1p = w + 4 * slab;
   a.red = a.b1p + ffn_al(2 * W);
   a.part = a.red + ffn_al(part);
+  a.mm = d->matmul;
+  {
+    const size_t TW = W / 16, NS1 = (TW + 1) / 2;
+    float* bf = a.part + (size_t)FFN_NWG * part;
+    const size_t a1 = 2 * TW * NS1 * 2 * 256, a2 = TW * TW * 2 * 256;
+    a.sA1 = reinterpret_cast<uint16_t*>(bf);
+    a.sA2 = reinterpret_cast<uint16_t*>(bf + a1);
+    a.sA3 = reinterpret_cast<uint16_t*>(bf + a1 + a2);
+    a.sA4 = reinterpret_cast<uint16_t*>(bf + 2 * a1 + a2);
+  }
   {   // backward workgroups: one per CU for large inputs; small inputs (node channels) one tile
       // per wave (a tile is ~16 us of dependent work: spreading beats amortising the slab staging)
     const long ntiles = (a.rows + 15) / 16;
@@ -574,15 +858,44 @@ static void ffn_launch_fwd(const FfnArgs& a, int act, hipStream_t st) {
 }
 
 template <int W>
-static void ffn_launch_bwd(const FfnArgs& a, int act, hipStream_t st) {
-  const size_t lds = (3 * (size_t)(2 * W * W) + 2 * W + 4 * 3 * 16 * W) * 4;
+static void ffn_launch_fwd_bf(const FfnArgs& a, int act, hipStream_t st) {
+  constexpr int TW = W / 16, NS1 = (TW + 1) / 2;
+  const size_t lds = ((size_t)(2 * TW * NS1 * 2 * 256 + TW * TW * 2 * 256) + 3 * W + 8 * 2 * 16 * W) * 4;
+  const long ntiles = (a.rows + 15) / 16;
+  const long wantf = (ntiles + 7) / 8;
+  const int grid = (int)(wantf < 1 ? 1 : (wantf > 512 ? 512 : wantf));
+  EGT_LAUNCH("k_ffn_prep", k_ffn_prep_bf<W>, dim3(ffn_bf_prep_blocks(W)), dim3(256), 0, st, a);
+#define FBF(ACT_, SPLIT_)                                                                                             \
+  do {                                                                                                                \
+    (void)hipFuncSetAttribute((const void*)k_ffn_fwd_bf<W, ACT_, SPLIT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    EGT_LAUNCH("k_ffn_fwd", (k_ffn_fwd_bf<W, ACT_, SPLIT_>), dim3(grid), dim3(512), lds, st, a);                       \
+  } while (0)
+  const bool split = a.mm == EGT_MM_BF16X3;
+  if (act == EGT_ACT_RELU) { if (split) FBF(EGT_ACT_RELU, true); else FBF(EGT_ACT_RELU, false); }
+  else { if (split) FBF(EGT_ACT_ELU, true); else FBF(EGT_ACT_ELU, false); }
+#undef FBF
+}
+
+template <int W, int MM>
+static void ffn_launch_bwd_mm(const FfnArgs& a, int act, hipStream_t st) {
+  constexpr int TW = W / 16, NS1 = (TW + 1) / 2;
+  constexpr size_t slabs = MM ? (size_t)(2 * (2 * TW * NS1 * 2 * 256) + TW * TW * 2 * 256) : 3 * (size_t)(2 * W * W);
+  // the per-workgroup partial (2 * 2W*W + 3W floats) is staged over the slab area at the end
+  constexpr size_t part = 2 * (size_t)(2 * W * W) + 3 * W;
+  const size_t lds = ((slabs > part ? slabs : part) + 2 * W + 4 * 3 * 16 * W) * 4;
   if (act == EGT_ACT_RELU) {
-    (void)hipFuncSetAttribute((const void*)k_ffn_bwd<W, EGT_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    EGT_LAUNCH("k_ffn_bwd", (k_ffn_bwd<W, EGT_ACT_RELU>), dim3(a.nwg), dim3(256), lds, st, a);
+    (void)hipFuncSetAttribute((const void*)k_ffn_bwd<W, EGT_ACT_RELU, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_LAUNCH("k_ffn_bwd", (k_ffn_bwd<W, EGT_ACT_RELU, MM>), dim3(a.nwg), dim3(256), lds, st, a);
   } else {
-    (void)hipFuncSetAttribute((const void*)k_ffn_bwd<W, EGT_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    EGT_LAUNCH("k_ffn_bwd", (k_ffn_bwd<W, EGT_ACT_ELU>), dim3(a.nwg), dim3(256), lds, st, a);
+    (void)hipFuncSetAttribute((const void*)k_ffn_bwd<W, EGT_ACT_ELU, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_LAUNCH("k_ffn_bwd", (k_ffn_bwd<W, EGT_ACT_ELU, MM>), dim3(a.nwg), dim3(256), lds, st, a);
   }
+}
+template <int W>
+static void ffn_launch_bwd(const FfnArgs& a, int act, hipStream_t st) {
+  if (a.mm == EGT_MM_BF16X3) ffn_launch_bwd_mm<W, EGT_MM_BF16X3>(a, act, st);
+  else if (a.mm == EGT_MM_BF16) ffn_launch_bwd_mm<W, EGT_MM_BF16>(a, act, st);
+  else ffn_launch_bwd_mm<W, EGT_MM_F32>(a, act, st);
 }
 
 #define FFN_DISPATCH_W(width, CALL)               \
@@ -601,8 +914,12 @@ extern "C" int egt_ffn_fwd(const egt_ffn_desc* desc, const egt_ffn_params* param
   if (!x || !y) EGT_FAIL(EGT_E_NULL, "x/y is NULL");
   a.x = (const float*)x; a.y = (float*)y;
   hipStream_t st = (hipStream_t)stream;
-  FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep<W>, dim3((2 * W * W + 255) / 256), dim3(256), 0, st, a));
-  FFN_DISPATCH_W(desc->width, ffn_launch_fwd<W>(a, desc->activation, st));
+  if (desc->matmul != EGT_MM_F32) {
+    FFN_DISPATCH_W(desc->width, ffn_launch_fwd_bf<W>(a, desc->activation, st));
+  } else {
+    FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep<W>, dim3((2 * W * W + 255) / 256), dim3(256), 0, st, a));
+    FFN_DISPATCH_W(desc->width, ffn_launch_fwd<W>(a, desc->activation, st));
+  }
   EGT_HIP_LAUNCH_CHECK("egt_ffn_fwd");
   return EGT_OK;
 }
@@ -621,6 +938,8 @@ extern "C" int egt_ffn_bwd(const egt_ffn_desc* desc, const egt_ffn_params* param
   a.g_W2 = (float*)grads->lr2_kernel; a.g_b2 = (float*)grads->lr2_bias;
   hipStream_t st = (hipStream_t)stream;
   FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep<W>, dim3((2 * W * W + 255) / 256), dim3(256), 0, st, a));
+  if (desc->matmul != EGT_MM_F32)
+    FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep_bf<W>, dim3(ffn_bf_prep_blocks(W)), dim3(256), 0, st, a));
   FFN_DISPATCH_W(desc->width, ffn_launch_bwd<W>(a, desc->activation, st));
   const int part = 4 * a.W * a.W + 3 * a.W;
   EGT_LAUNCH("k_ffn_sum", k_ffn_sum, dim3((part + 63) / 64), dim3(256), 0, st, a);

@@ -15,12 +15,19 @@ from . import _lib as L
 from .functional import _f32c, _need_gpu
 
 _ACT = {"relu": L.ACT_RELU, "elu": L.ACT_ELU}
+# how the matrix products are evaluated (include/egt_amd.h EGT_MM_*): "f32" exact fp32 MFMA; "bf16x3" 3-term
+# bfloat16 split on the bf16 matrix pipe (per-product error 2^-16, same parity tolerances as fp32);
+# "bf16" plain bfloat16 products (rtol 2e-2).  Tensors and accumulation are fp32 in every mode.
+_MM = {"f32": L.MM_F32, "bf16x3": L.MM_BF16X3, "bf16": L.MM_BF16}
 
 
-def _desc(rows: int, width: int, activation: str, eps: float) -> L.FfnDesc:
+def _desc(rows: int, width: int, activation: str, eps: float, matmul: str = "f32") -> L.FfnDesc:
     if activation not in _ACT:
         raise ValueError(f"fused FFN activation must be one of {sorted(_ACT)} (got {activation!r})")
-    return L.FfnDesc(rows=rows, width=width, dtype=L.EGT_F32, activation=_ACT[activation], ln_eps=eps)
+    if matmul not in _MM:
+        raise ValueError(f"matmul must be one of {sorted(_MM)} (got {matmul!r})")
+    return L.FfnDesc(rows=rows, width=width, dtype=L.EGT_F32, activation=_ACT[activation], ln_eps=eps,
+                     matmul=_MM[matmul], reserved=0)
 
 
 def _pstruct(tensors) -> L.FfnParams:
@@ -60,10 +67,10 @@ class _FusedFFN(torch.autograd.Function):
         return (dx, None, *grads)
 
 
-def ffn(x, norm_gamma, norm_beta, lr1_kernel, lr1_bias, lr2_kernel, lr2_bias, activation="elu", eps=1e-3):
+def ffn(x, norm_gamma, norm_beta, lr1_kernel, lr1_bias, lr2_kernel, lr2_bias, activation="elu", eps=1e-3, matmul="f32"):
     """x: [..., W] -> [..., W]; kernels in Keras layout [in, out]."""
     W = x.shape[-1]
-    desc = _desc(x.numel() // W, W, activation, eps)
+    desc = _desc(x.numel() // W, W, activation, eps, matmul)
     if not L.load().egt_ffn_supported(C.byref(desc)):
         raise ValueError(f"fused FFN covers widths 16/32/48/64 in fp32 (got width {W}, dtype {x.dtype})")
     return _FusedFFN.apply(x, desc, norm_gamma, norm_beta, lr1_kernel, lr1_bias, lr2_kernel, lr2_bias)
@@ -73,7 +80,7 @@ class FFN(nn.Module):
     """ffnlr1 -> ffnact -> ffnlr2 of one channel type; parameters under the Keras layer names
     (norm_fnn_<tag>, fnn_lr1_<tag>, fnn_lr2_<tag>: keras_named_parameters)."""
 
-    def __init__(self, width: int, ffn_multiplier: float = 2.0, activation: str = "elu"):
+    def __init__(self, width: int, ffn_multiplier: float = 2.0, activation: str = "elu", matmul: str = "f32"):
         super().__init__()
         hid = round(width * ffn_multiplier)
         if hid != 2 * width:
@@ -84,7 +91,9 @@ class FFN(nn.Module):
         # the C library decides (egt_ffn_supported), so the Python side never drifts from it
         if not L.load().egt_ffn_supported(C.byref(_desc(16, width, activation, 1e-3))):
             raise ValueError(f"fused FFN does not cover width {width} (fp32)")
-        self.width, self.activation = width, activation
+        if matmul not in _MM:
+            raise ValueError(f"matmul must be one of {sorted(_MM)} (got {matmul!r})")
+        self.width, self.activation, self.matmul = width, activation, matmul
         self.norm_gamma = nn.Parameter(torch.ones(width))
         self.norm_beta = nn.Parameter(torch.zeros(width))
         lim1 = math.sqrt(6.0 / (width + hid))            # Keras Dense default: glorot_uniform
@@ -100,4 +109,4 @@ class FFN(nn.Module):
 
     def forward(self, x):
         return ffn(x, self.norm_gamma, self.norm_beta, self.lr1_kernel, self.lr1_bias, self.lr2_kernel,
-                   self.lr2_bias, activation=self.activation)
+                   self.lr2_bias, activation=self.activation, matmul=self.matmul)

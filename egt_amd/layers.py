@@ -329,9 +329,11 @@ class EGTLayerStack(nn.Module):
     (egt_amd.ffn.FFN; widths 64).  `edge_channel_type` in ('residual', 'constrained') updates
     both channels in ffn_block (:312-320); otherwise only the node channels (:322-323)."""
 
-    def __init__(self, model_height=4, model_width=64, edge_width=64, activation='elu', **block_kwargs):
+    def __init__(self, model_height=4, model_width=64, edge_width=64, activation='elu', ffn_matmul='f32', **block_kwargs):
         super().__init__()
-        from .ffn import FFN
+        from .ffn import FFN as _FFN
+        from functools import partial
+        FFN = partial(_FFN, matmul=ffn_matmul)   # "f32" exact | "bf16x3" split products (fp32 tolerances) | "bf16"
         seed = block_kwargs.pop('seed', 0)
         self.blocks = nn.ModuleList(
             [EGTBlock(seed=seed * 1000 + i, model_width=model_width, edge_width=edge_width, **block_kwargs)

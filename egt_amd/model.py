@@ -85,7 +85,7 @@ class ZincDCTransformer(nn.Module):
                  clip_logits_value=[-5, 5], mlp_layers=[.5, .25], activation='elu', do_final_norm=True,
                  ffn_multiplier=2., num_node_features=28, num_edge_features=4, num_targets=1,
                  readout_edges=False, num_virtual_nodes=0, use_svd=False, node_dropout=0., edge_dropout=0.,
-                 seed=0, **unused):
+                 seed=0, ffn_matmul='f32', **unused):
         super().__init__()
         if readout_edges or num_virtual_nodes or use_svd or node_dropout or edge_dropout:
             raise NotImplementedError("ZincDCTransformer covers the shipped ZINC configs: readout_edges=False, "
@@ -103,7 +103,7 @@ class ZincDCTransformer(nn.Module):
         self.layers = EGTLayerStack(model_height=model_height, model_width=model_width, edge_width=edge_width,
                                     activation=activation, num_heads=num_heads, gate_attention=gate_attention,
                                     edge_channel_type=edge_channel_type, clip_logits_value=clip_logits_value,
-                                    random_mask_prob=random_mask_prob, seed=seed)
+                                    random_mask_prob=random_mask_prob, seed=seed, ffn_matmul=ffn_matmul)
         self.node_norm_final = KerasLayerNorm(model_width) if do_final_norm else None
         self.mlp_out = nn.ModuleList()
         w = model_width

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EGT_ABI_VERSION 1
+#define EGT_ABI_VERSION 2
 
 /* error codes */
 #define EGT_OK 0
@@ -306,12 +306,24 @@ int egt_stack_bwd(const egt_block_desc* desc, int32_t layers,
  * [B*N, Dh].  Keras layouts: kernels are [in,out]; LayerNormalization epsilon = ln_eps.
  * Fused MFMA kernels for width in {16,32,48,64}, fp32, activation EGT_ACT_ELU (config default) or
  * EGT_ACT_RELU; egt_ffn_supported says whether a desc is covered. */
+/* how the matrix products are evaluated (tensors stay fp32 in HBM, accumulation is always fp32):
+ *   EGT_MM_F32     exact fp32 products (v_mfma_f32_16x16x4_f32)
+ *   EGT_MM_BF16X3  every operand split into two bfloat16 terms, a.b = a_hi.b_hi + a_lo.b_hi + a_hi.b_lo on the
+ *                  bf16 matrix pipe: per-product error <= 2^-16 (fp32: 2^-24); stays inside the fp32 parity
+ *                  tolerances of the test-suite at 3/16 of the fp32 MFMA cost
+ *   EGT_MM_BF16    plain bfloat16 products (hi terms only): tolerance rtol 2e-2 (SURVEY 8(c) bf16 figure) */
+#define EGT_MM_F32 0
+#define EGT_MM_BF16X3 1
+#define EGT_MM_BF16 2
+
 typedef struct egt_ffn_desc {
   int64_t rows;
   int32_t width;
   int32_t dtype;      /* EGT_F32 */
   int32_t activation; /* EGT_ACT_* (config.activation) */
   float ln_eps;       /* 1e-3 */
+  int32_t matmul;     /* EGT_MM_* */
+  int32_t reserved;
 } egt_ffn_desc;
 
 typedef struct egt_ffn_params {

@@ -9,11 +9,11 @@ pytestmark = pytest.mark.gpu
 NAMES = ("norm_gamma", "norm_beta", "lr1_kernel", "lr1_bias", "lr2_kernel", "lr2_bias")
 
 
-def _run(shape, act, gpu, seed=0, W=64):
+def _run(shape, act, gpu, seed=0, W=64, matmul="f32", fwd_tol=FWD, bwd_tol=BWD):
     from egt_amd import FFN
     from oracle import egt_oracle as O
     torch.manual_seed(seed)
-    m = FFN(W, activation=act).to(gpu)
+    m = FFN(W, activation=act, matmul=matmul).to(gpu)
     with torch.no_grad():
         for n in ("norm_gamma", "norm_beta", "lr1_bias", "lr2_bias"):
             getattr(m, n).add_(0.3 * torch.randn_like(getattr(m, n)))
@@ -27,10 +27,25 @@ def _run(shape, act, gpu, seed=0, W=64):
     x64 = x.double().requires_grad_()
     yo = O.ffn_forward(x64, p64, activation=act)
     gr = torch.autograd.grad(yo, [x64] + [p64[n] for n in NAMES], dy.double())
-    assert_close(y, yo, name="y", **FWD)
-    assert_close(xg.grad, gr[0], name="dx", **BWD)
+    assert_close(y, yo, name="y", **fwd_tol)
+    assert_close(xg.grad, gr[0], name="dx", **bwd_tol)
     for n, gref in zip(NAMES, gr[1:]):
-        assert_close(getattr(m, n).grad, gref, name="d" + n, **BWD)
+        assert_close(getattr(m, n).grad, gref, name="d" + n, **bwd_tol)
+
+
+@pytest.mark.parametrize("W,shape,act", [(64, (2, 24, 24), "elu"), (64, (3, 17, 17), "relu"), (64, (4, 64, 64), "elu"), (64, (1, 5), "elu"),
+                                          (48, (2, 37, 37), "elu"), (32, (2, 19, 19), "elu"), (16, (2, 23, 23), "relu")])
+def test_ffn_bf16x3_matmul_holds_the_fp32_tolerances(W, shape, act, gpu, egt_lib):
+    """matmul="bf16x3": 3-term bfloat16 split products on the bf16 matrix pipe (per-product error 2^-16).
+    SAME tolerances as the exact-fp32 kernels."""
+    _run(shape, act, gpu, seed=W + 1, W=W, matmul="bf16x3")
+
+
+@pytest.mark.parametrize("W,shape", [(64, (2, 24, 24)), (48, (2, 21, 21)), (16, (3, 9))])
+def test_ffn_plain_bf16_matmul(W, shape, gpu, egt_lib):
+    """matmul="bf16": plain bfloat16 products, fp32 accumulate -- SURVEY 8(c)'s bf16 tolerance (rtol 2e-2)."""
+    tol = dict(rtol=2e-2, arel=1e-2, l2=2e-2)
+    _run(shape, "elu", gpu, seed=W + 2, W=W, matmul="bf16", fwd_tol=tol, bwd_tol=tol)
 
 
 @pytest.mark.parametrize("shape,act", [((2, 24, 24), "elu"), ((3, 17, 17), "elu"), ((2, 37), "relu"),

@@ -18,9 +18,10 @@ def main():
         shape = (B, N, W)
     else:
         shape = (B, N, N, W)
+    mm = os.environ.get("EGT_FFN_MATMUL", "f32")
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    m = FFN(W).to(dev)
+    m = FFN(W, matmul=mm).to(dev)
     x = torch.randn(*shape, device=dev, requires_grad=True)
     dy = torch.randn(*shape, device=dev)
     lib = L.load()
@@ -60,7 +61,7 @@ def main():
     flop_alg = 24 * W * W * rows            # fwd+bwd without recompute
     mfma_issued = (256 + 640) * 1024 * 2 * (rows / 16)   # MFMA flops actually issued (incl. recompute)
     bytes_alg = rows * W * 4 * 5            # fwd: r x, w y; bwd: r x, r dy, w dx
-    print(json.dumps({"scope": "ffn", "shape": list(shape), "ms_per_step": ms, "graphs_per_s": B / ms * 1e3,
+    print(json.dumps({"scope": "ffn", "matmul": mm, "shape": list(shape), "ms_per_step": ms, "graphs_per_s": B / ms * 1e3,
                       "TFLOPs_algorithmic": flop_alg / ms / 1e9, "TFLOPs_issued": mfma_issued / ms / 1e9,
                       "frac_of_157.3": flop_alg / ms / 1e9 / 157.3, "algorithmic_GBps": bytes_alg / ms / 1e6,
                       "kernels_us": ks}))
