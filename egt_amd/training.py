@@ -1,0 +1,489 @@
+"""Scheme / config driver for the ZINC model: consumes the reference's
+``configs/**/zinc/*.json`` unchanged — same keys, same defaults, unknown key -> KeyError — and runs the
+same training protocol around egt_amd.model.ZincDCTransformer:
+
+    python -m egt_amd.training cfg.json            (the reference: python run_training.py cfg.json)
+
+Reference (relative to /root/reference/):
+  config keys / lazily evaluated defaults   lib/training/training_base.py:80-112, lib/base/dotdict/dotdict.py:23-105
+  scheme defaults and config -> model_config lib/training/schemes/scheme_base.py:6-60,92-111,116-160,
+                                            lib/training/schemes/zinc/svd.py:12-42
+  optimizer (Adam / RMSprop / SGD, clipvalue) lib/training/training_base.py:59-72
+  state, save-best, reduce-LR-on-plateau, min_lr_factor, stopping_lr   :114-181
+  per-epoch checkpoint + restore at train begin, max_to_keep=1         lib/base/callbacks/checkpoint.py:8-83
+  ``save_when`` mini-DSL (event;cond;format) weight snapshots           :86-138
+  warm-up + cosine schedule                   lib/base/genutil/warmup.py:41-75
+  fit loop, finalize (final weight file)      lib/training/training_base.py:293-327
+  data-parallel training                      :230-247 (MirroredStrategy) -> egt_amd.dp, one process per GPU
+
+What is NOT here: the HDF5 dataset reader (h5py and the datasets are absent); ``load_data``
+takes any iterable of batches in the reference's input format, and ``SyntheticZinc`` generates molecules of
+that format.  Weight files are ``.npz`` keyed by the reference's Keras variable names instead of ``.h5``.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import sys
+from typing import Callable, Dict, Iterable, Optional
+
+import numpy as np
+import torch
+
+# ----------------------------------------------------------------------------------------- config --
+
+
+class Config(dict):
+    """HDict (dotdict.py:87-105): attribute access; a value that is a callable ``f(c)`` is a lazily evaluated
+    default (the reference's ``HDict.L('c: expr')`` string lambdas) resolved against the final config."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        return v(self) if callable(v) else v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def get_dict(self):
+        return {k: self[k] for k in self.keys()}
+
+
+def read_config_from_file(config_file):          # training_base.py:15-17
+    with open(config_file, "r") as fp:
+        return json.load(fp)
+
+
+def save_config_to_file(config, config_file):    # :19-21
+    with open(config_file, "w") as fp:
+        return json.dump(config, fp, indent="\t")
+
+
+def default_config() -> Config:
+    """TrainingBase.get_default_config (:80-112) + BaseDCModelScheme (scheme_base.py:7-35) + BaseAdjModelScheme
+    (:93-101) + BaseSVDModelScheme (:117-126) + ZincDCSVD (zinc/svd.py:13-21), later ones overriding."""
+    path = os.path
+    c = Config(
+        scheme=None, model_name="unnamed_model", distributed=False,
+        batch_size=lambda c: 32 if c.distributed else 128,
+        initial_lr=5e-4, gradient_clipval=None, num_epochs=1000,
+        dataset_path="datasets/gnn_benchmark.h5",
+        save_path=lambda c: path.join("models", c.model_name),
+        checkpoint_path=lambda c: path.join(c.save_path, "checkpoint"),
+        log_path=lambda c: path.join(c.save_path, "logs"),
+        config_path=lambda c: path.join(c.save_path, "config"),
+        summary_path=lambda c: path.join(c.save_path, "summary"),
+        saved_model_path=lambda c: path.join(c.save_path, "saved", c.model_name),
+        rlr_factor=0.5, rlr_patience=10, rlr_monitor=lambda c: c.save_best_monitor,
+        min_lr_factor=0.01, stopping_lr=0., steps_per_epoch=None, validation_steps=None,
+        save_best=True,
+        save_when=lambda c: "" if not c.save_best else "epoch;" + c.save_best_monitor + "<=save_best_value;epoch{epoch:0>4d}",
+        save_best_monitor="val_loss", stopping_patience=0,
+        predictions_path=lambda c: path.join(c.save_path, "predictions"),
+        weight_file=":", prediction_bmult=2, optimizer="adam",
+    )
+    c.update(  # BaseDCModelScheme
+        model_name="dc", dataset_name="dataset",
+        dataset_path=lambda c: f"datasets/{c.dataset_name.upper()}/{c.dataset_name.upper()}.h5",
+        cache_dir=lambda c: f"data_cache/{c.dataset_name.upper()}/data",
+        save_path=lambda c: path.join(f"models/{c.dataset_name.lower()}", c.model_name),
+        model_width=48, model_height=4, edge_width=48, num_heads=8, gate_attention=True, scale_degree=False,
+        l2_reg=0, dropout=0, attn_dropout=0.0, edge_dropout=None, mlp_layers=[.5, .25], edge_activation=None,
+        edge_channel_type="residual", combine_layer_repr=False, max_shuffle_len=10000, ffn_multiplier=2.,
+        warmup_steps=0, total_steps=None, random_mask_prob=0.,
+    )
+    c.update(  # BaseAdjModelScheme
+        model_name="dc_mat", cache_dir=lambda c: f"data_cache/{c.dataset_name.upper()}/mat",
+        upto_hop=1, distance_loss=0., distance_target=8,
+    )
+    c.update(  # BaseSVDModelScheme
+        model_name="dc_svd", cache_dir=lambda c: f"data_cache/{c.dataset_name.upper()}/svd_{c.num_svd_features}",
+        num_svd_features=16, sel_svd_features=8, use_svd=True, random_neg=True,
+    )
+    c.update(  # ZincDCSVD
+        dataset_name="zinc", num_virtual_nodes=0, rlr_monitor="val_mae", save_best_monitor="val_mae",
+    )
+    return c
+
+
+SCHEMES = ("zinc.svd",)
+
+
+def make_config(user: Optional[dict]) -> Config:
+    """TrainingBase.__init__ (:24-32): defaults, then the user's keys; an unknown key is an error."""
+    c = default_config()
+    if user is not None:
+        for k in user.keys():
+            if k not in c:
+                raise KeyError(f'Unknown config "{k}"')
+        c.update(user)
+    return c
+
+
+def model_config(c: Config) -> dict:
+    """config -> model_config (scheme_base.py:37-60, :103-111, :151-160; zinc/svd.py:27-35)."""
+    return dict(
+        model_width=c.model_width, edge_width=c.edge_width, num_heads=c.num_heads, gate_attention=c.gate_attention,
+        scale_degree=c.scale_degree, random_mask_prob=c.random_mask_prob, attn_dropout=c.attn_dropout,
+        model_height=c.model_height, l2_reg=c.l2_reg, node_dropout=c.dropout,
+        edge_dropout=c.dropout if c.edge_dropout is None else c.edge_dropout,
+        mlp_layers=c.mlp_layers, edge_channel_type=c.edge_channel_type, edge_activation=c.edge_activation,
+        ffn_multiplier=c.ffn_multiplier, global_step_layer=True,
+        upto_hop=c.upto_hop, distance_loss=c.distance_loss, distance_target=c.distance_target,
+        use_svd=c.use_svd, transform_svd=True, random_neg=c.random_neg, num_svd_features=c.num_svd_features,
+        sel_svd_features=c.sel_svd_features,
+        readout_edges=False, num_virtual_nodes=c.num_virtual_nodes,
+    )
+
+
+# ------------------------------------------------------------------------------------------ state --
+class TrainingState:
+    """get_default_state (:114-131): counters + save-best + reduce-LR bookkeeping (checkpointed)."""
+
+    def __init__(self, config: Config):
+        self.current_epoch = 0
+        self.global_step = 0
+        self.has_best = bool(config.save_best)
+        self.has_rlr = config.rlr_factor < 1.0
+        self.save_best_value = math.inf
+        self.save_best_epoch = 0
+        self.last_reduce_lr = 0
+
+    def items(self):
+        d = dict(current_epoch=self.current_epoch, global_step=self.global_step)
+        if self.has_best:
+            d.update(save_best_value=self.save_best_value, save_best_epoch=self.save_best_epoch)
+        if self.has_rlr:
+            d.update(last_reduce_lr=self.last_reduce_lr)
+        return d
+
+    def load(self, d):
+        for k, v in d.items():
+            setattr(self, k, v)
+
+
+def save_best_update(config: Config, state: TrainingState, get_lr: Callable[[], float], set_lr: Callable[[float], None],
+                     logs: dict, print_fn=print) -> bool:
+    """get_state_updates.save_best_update (:145-178), called at epoch end BEFORE current_epoch is advanced...
+    the reference appends it after the counter update, so it sees the advanced epoch.  Returns stop_training."""
+    monitor = config.save_best_monitor
+    new_value = logs.get(monitor, math.inf)
+    old_value, old_epoch, new_epoch = state.save_best_value, state.save_best_epoch, state.current_epoch
+    if new_value < old_value:
+        state.save_best_value, state.save_best_epoch = float(new_value), new_epoch
+        print_fn(f"\nSAVE BEST: {monitor} improved from (epoch:{old_epoch},value:{old_value:0.5f}) to (epoch:{new_epoch},value:{new_value:0.5f})")
+    else:
+        print_fn(f"\nSAVE BEST: {monitor} did NOT improve from (epoch:{old_epoch},value:{old_value:0.5f})")
+        if config.rlr_factor < 1.0:
+            epoch_gap = new_epoch - max(old_epoch, state.last_reduce_lr)
+            if epoch_gap >= config.rlr_patience:
+                set_lr(max(get_lr() * config.rlr_factor, config.initial_lr * config.min_lr_factor))
+                state.last_reduce_lr = new_epoch
+                print_fn(f"\nRLR: {monitor} did NOT improve for {epoch_gap} epochs, new lr = {get_lr()}")
+    if get_lr() < config.stopping_lr:
+        print_fn(f"\nSTOP: lr fell below {config.stopping_lr}, STOPPING TRAINING!")
+        return True
+    return False
+
+
+class SaveWhen:
+    """SaveWhenCallback (checkpoint.py:86-138): '#'-separated 'event;condition;name-format' rules evaluated against
+    the epoch logs + state; a rule that fires snapshots the weights."""
+
+    def __init__(self, when: str):
+        self.criterions = []
+        for item in (when.split("#") if when else []):
+            ev, cond, fmt = (e.strip() for e in item.split(";"))
+            self.criterions.append((ev.lower(), cond, fmt))
+
+    def fire(self, event: str, scope: dict):
+        out = []
+        for e, c, f in self.criterions:
+            if e == event:
+                try:
+                    if eval(c, {"__builtins__": {}}, dict(scope)):   # noqa: S307 - the reference evals the config string
+                        out.append(f.format(**scope))
+                except NameError:
+                    pass                                           # ':125-126: did not find log, IGNORING'
+        return out
+
+
+def warmup_cosine_lr(global_step: int, warmup_steps: int, max_lr: float, total_steps: Optional[int], min_lr: float = 0.):
+    """WarmUpAndCosine.on_train_batch_begin (warmup.py:56-67): (lr or None = leave unchanged, stop_training)."""
+    span = max_lr - min_lr
+    if global_step < warmup_steps:
+        return min_lr + span / warmup_steps * (global_step + 1), False
+    if total_steps is not None:
+        if global_step <= total_steps:
+            return min_lr + span * math.cos(0.5 * math.pi / (total_steps - warmup_steps) * (global_step - warmup_steps)), False
+        return None, True
+    return None, False
+
+
+# --------------------------------------------------------------------------------------------- data --
+class SyntheticZinc:
+    """Batches in the reference's input format (lib/data/datasets/zinc.py:9-142 after MatrixDataset + padded_batch):
+    node_features [B,N] int (28 atom types, padding -1), feature_matrix [B,N,N] int (bond type, -1 elsewhere),
+    graph_matrix [B,N,N] 0/1, target [B,1]; N = the batch's longest molecule (padded_batch pads to the batch max,
+    lib/data/dataset_base.py:106-111), optionally rounded up to a multiple of `pad_multiple`."""
+
+    def __init__(self, n_graphs=1024, batch_size=128, nodes=(9, 37), seed=0, pad_multiple=1, device="cpu"):
+        g = torch.Generator().manual_seed(seed)
+        self.n = torch.randint(nodes[0], nodes[1] + 1, (n_graphs,), generator=g)
+        self.seed, self.batch_size, self.pad_multiple, self.device = seed, batch_size, pad_multiple, device
+        # a learnable target: a fixed random function of the atom-type histogram and the bond count
+        self.w = torch.randn(28, generator=g) * 0.3
+
+    def __len__(self):
+        return (len(self.n) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        for b in range(len(self)):
+            ns = self.n[b * self.batch_size:(b + 1) * self.batch_size]
+            g = torch.Generator().manual_seed(self.seed * 100003 + b)
+            B, N = len(ns), int(ns.max())
+            N = (N + self.pad_multiple - 1) // self.pad_multiple * self.pad_multiple
+            real = torch.arange(N)[None, :] < ns[:, None]
+            nf = torch.randint(0, 28, (B, N), generator=g)
+            nf[~real] = -1
+            pr = (1.1 / ns.float().clamp(min=2))[:, None, None]
+            adj = (torch.rand(B, N, N, generator=g) < pr).float()
+            adj = ((adj + adj.transpose(1, 2)) > 0).float() * (real[:, :, None] & real[:, None, :]).float()
+            adj = adj * (1 - torch.eye(N))[None]
+            bond = torch.randint(0, 4, (B, N, N), generator=g)
+            bond = torch.triu(bond, 1); bond = bond + bond.transpose(1, 2)
+            fm = torch.where(adj > 0, bond, torch.tensor(-1))
+            hist = torch.stack([(nf == t).sum(1) for t in range(28)], 1).float()
+            tgt = (hist @ self.w / 10 + adj.sum((1, 2)) / 40)[:, None]
+            yield dict(node_features=nf.int().to(self.device), feature_matrix=fm.int().to(self.device),
+                       graph_matrix=adj.to(self.device), target=tgt.to(self.device))
+
+
+# ------------------------------------------------------------------------------------------ scheme --
+class ZincSVDScheme:
+    """lib.training.schemes.zinc.svd.SCHEME: TrainingBase protocol around the ZINC model."""
+
+    def __init__(self, config: Optional[dict] = None, model_factory=None, device=None, print_fn=print):
+        self.config_input = config
+        self.config = make_config(config)
+        if self.config.scheme not in (None,) + SCHEMES:
+            raise KeyError(f"scheme {self.config.scheme!r}: only {SCHEMES} are built (SURVEY 8(f)-2: ZINC first)")
+        self.state = TrainingState(self.config)
+        self.model_factory = model_factory
+        self.device = device
+        self.print = print_fn
+        self.stop_training = False
+        self.history = []
+
+    # ---- model / optimizer (:59-72, :227-247) ----
+    def get_model_config(self):
+        return model_config(self.config)
+
+    def get_model(self):
+        if self.model_factory is not None:
+            return self.model_factory(self.get_model_config())
+        from .model import ZincDCTransformer
+        mc = self.get_model_config()
+        if mc["use_svd"]:
+            raise NotImplementedError("use_svd=True (SVD positional encodings) needs the data pipeline's features; "
+                                      "the shipped ZINC configs set use_svd=false")
+        return ZincDCTransformer(**mc)
+
+    def get_optimizer(self, params):
+        c = self.config
+        opt = dict(adam=lambda p: torch.optim.Adam(p, lr=c.initial_lr, betas=(0.9, 0.999), eps=1e-7),     # Keras Adam epsilon
+                   rmsprop=lambda p: torch.optim.RMSprop(p, lr=c.initial_lr, alpha=0.9, eps=1e-7),        # Keras rho=0.9
+                   sgd=lambda p: torch.optim.SGD(p, lr=c.initial_lr))[c.optimizer]
+        return opt(params)
+
+    def get_loss(self):                              # zinc/svd.py:37-39
+        from .model import mae_loss
+        return mae_loss
+
+    def get_metrics(self):                           # :41-42
+        return ["mae"]
+
+    def load_model(self):
+        self.model = self.get_model()
+        if self.device is not None:
+            self.model = self.model.to(self.device)
+        params = self.model.trainable_parameters() if hasattr(self.model, "trainable_parameters") else list(self.model.parameters())
+        self.params = params
+        self.optimizer = self.get_optimizer(params)
+        self.loss_fn = self.get_loss()
+        self.flat = None
+        if self.config.distributed and torch.distributed.is_available() and torch.distributed.is_initialized():
+            from .dp import FlatGradAllReduce
+            self.flat = FlatGradAllReduce(params)     # one flat-buffer all-reduce per step (MirroredStrategy, :230-247)
+
+    # ---- lr ----
+    def get_lr(self):
+        return self.optimizer.param_groups[0]["lr"]
+
+    def set_lr(self, v):
+        for g in self.optimizer.param_groups:
+            g["lr"] = float(v)
+
+    # ---- checkpoint (checkpoint.py:8-83: model + optimizer + state, max_to_keep = 1, restored at train begin) ----
+    def _ckpt_file(self):
+        return os.path.join(self.config.checkpoint_path, "ckpt.pt")
+
+    def save_checkpoint(self):
+        os.makedirs(self.config.checkpoint_path, exist_ok=True)
+        tmp = self._ckpt_file() + ".tmp"
+        torch.save(dict(model=self.model.state_dict(), optimizer=self.optimizer.state_dict(), state=self.state.items()), tmp)
+        os.replace(tmp, self._ckpt_file())
+        self.print(f"Checkpoint saved to {self.config.checkpoint_path}")
+
+    def load_checkpoint(self):
+        f = self._ckpt_file()
+        if not os.path.exists(f):
+            return False
+        ck = torch.load(f, map_location=self.device or "cpu")
+        self.model.load_state_dict(ck["model"])
+        self.optimizer.load_state_dict(ck["optimizer"])
+        self.state.load(ck["state"])
+        self.print(f"Checkpoint loaded from {self.config.checkpoint_path}")
+        return True
+
+    def load_state(self):                            # :249-260
+        os.makedirs(self.config.checkpoint_path, exist_ok=True)
+        self.save_when = SaveWhen(self.config.save_when)
+        self.load_checkpoint()
+
+    # ---- weight files (Keras variable names; .npz instead of .h5) ----
+    def save_weights(self, path):
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        named = self.model.keras_named_parameters() if hasattr(self.model, "keras_named_parameters") else dict(self.model.named_parameters())
+        np.savez(path, **{k: v.detach().cpu().numpy() for k, v in named.items()})
+        self.print(f"Saved model to {path}")
+
+    def config_summary(self):
+        for k, v in self.config.get_dict().items():
+            self.print(f"{k} : {v}")
+
+    def save_config_file(self):                      # :187-190
+        os.makedirs(os.path.dirname(self.config.config_path), exist_ok=True)
+        save_config_to_file(self.config.get_dict(), self.config.config_path + ".json")
+        save_config_to_file(self.config_input, self.config.config_path + "_input.json")
+
+    # ---- data ----
+    def load_data(self, trainset: Iterable = None, valset: Iterable = None):
+        if trainset is None:
+            raise NotImplementedError("the HDF5 reader (SURVEY 8(f)-4) is not built: pass iterables of batches "
+                                      "(see SyntheticZinc for the format)")
+        self.trainset, self.valset = trainset, valset
+
+    # ---- one step / one epoch ----
+    def _batch(self, b):
+        dev = self.device
+        mv = (lambda t: t.to(dev)) if dev is not None else (lambda t: t)
+        return mv(b["node_features"]), mv(b["feature_matrix"]), mv(b["graph_matrix"]), mv(b["target"])
+
+    def train_step(self, batch):
+        c = self.config
+        if c.warmup_steps > 0:
+            lr, stop = warmup_cosine_lr(self.state.global_step, c.warmup_steps, c.initial_lr, c.total_steps)
+            if lr is not None:
+                self.set_lr(lr)
+            self.stop_training |= stop
+        nf, fm, adj, tgt = self._batch(batch)
+        if self.flat is not None:
+            self.flat.zero(); self.flat.rebind()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+        self.model.train()
+        y = self.model(nf, fm, adj)
+        loss = self.loss_fn(y, tgt)
+        loss.backward()
+        if self.flat is not None:
+            self.flat.all_reduce(average=True)
+        if c.gradient_clipval is not None:           # Keras clipvalue: elementwise clip of every gradient
+            torch.nn.utils.clip_grad_value_(self.params, c.gradient_clipval)
+        self.optimizer.step()
+        self.state.global_step += 1                  # on_batch_end (:136)
+        return float(loss.detach())
+
+    @torch.no_grad()
+    def evaluate(self, dataset, max_steps=None):
+        self.model.eval()
+        tot, n = 0.0, 0
+        for i, b in enumerate(dataset):
+            if max_steps is not None and i >= max_steps:
+                break
+            nf, fm, adj, tgt = self._batch(b)
+            y = self.model(nf, fm, adj)
+            tot += float((y - tgt).abs().sum()); n += tgt.numel()
+        return tot / max(n, 1)
+
+    def train_model(self):                           # model.fit (:293-302) with the callbacks' behaviour inlined
+        c = self.config
+        for epoch in range(self.state.current_epoch, c.num_epochs):
+            if self.stop_training:
+                break
+            losses = []
+            for i, b in enumerate(self.trainset):
+                if c.steps_per_epoch is not None and i >= c.steps_per_epoch:
+                    break
+                losses.append(self.train_step(b))
+                if self.stop_training:
+                    break
+            logs = dict(loss=float(np.mean(losses)) if losses else math.nan)
+            logs["mae"] = logs["loss"]               # the loss IS the MAE metric for this scheme
+            if self.valset is not None:
+                v = self.evaluate(self.valset, c.validation_steps)
+                logs.update(val_loss=v, val_mae=v)
+            # epoch-end order of the reference's callback list: training callbacks (SaveWhen) first, then the
+            # checkpoint callback, whose on_epoch_end runs the state updates and saves (:249-256, checkpoint.py:66-83)
+            scope = dict(logs); scope["epoch"] = epoch + 1; scope.update(self.state.items())
+            for name in self.save_when.fire("epoch", scope):
+                self.save_weights(os.path.join(os.path.dirname(c.saved_model_path), name + ".npz"))
+            self.state.current_epoch += 1            # on_epoch_end[0] (:137)
+            if c.save_best:
+                self.stop_training |= save_best_update(c, self.state, self.get_lr, self.set_lr, logs, self.print)
+            self.print(f"\nCHECKPOINT Epoch: {epoch + 1}  " + "  ".join(f"{k}={v:.5f}" for k, v in logs.items()) + f"  lr={self.get_lr():.3g}")
+            self.save_checkpoint()
+            self.history.append(dict(epoch=epoch + 1, lr=self.get_lr(), **logs))
+
+    def finalize_training(self):                     # :321-327
+        self.save_weights(self.config.saved_model_path + ".npz")
+        self.print("DONE!!!")
+
+    def execute_training(self, trainset=None, valset=None):   # :305-312
+        self.config_summary()
+        self.save_config_file()
+        self.load_data(trainset, valset)
+        self.load_model()
+        self.load_state()
+        self.train_model()
+        self.finalize_training()
+
+
+def import_scheme(name: str):
+    """lib/training/importer.py:3-11."""
+    if name != "zinc.svd":
+        raise KeyError(f"scheme {name!r}: only {SCHEMES} are built")
+    return ZincSVDScheme
+
+
+def main(argv=None):
+    """python -m egt_amd.training cfg.json [--synthetic N_GRAPHS]  (run_training.py:5-10; the dataset reader is not
+    built, so the run trains on SyntheticZinc molecules in the reference's batch format)."""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv:
+        raise SystemExit("usage: python -m egt_amd.training cfg.json [--synthetic N_GRAPHS]")
+    config = read_config_from_file(argv[0])
+    n_graphs = int(argv[argv.index("--synthetic") + 1]) if "--synthetic" in argv else 2048
+    scheme = import_scheme(config["scheme"])(config, device=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+    bs = scheme.config.batch_size
+    scheme.execute_training(SyntheticZinc(n_graphs, bs, seed=1), SyntheticZinc(max(bs, n_graphs // 8), bs, seed=2))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+"""Scheme / config driver: config semantics, model_config mapping, save-best + reduce-LR-on-
+plateau + stopping logic, the save_when DSL, warm-up/cosine, checkpoint + resume -- on CPU with a stub model;
+a real (small) ZINC model trained for a few epochs on the GPU."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from egt_amd import training as T
+
+# configs/main/zinc/500k/egt.json of the reference (a config file is data: the keys the driver must accept)
+ZINC_500K = {"scheme": "zinc.svd", "distributed": True, "batch_size": 128, "initial_lr": 0.0005, "num_epochs": 600,
+             "rlr_factor": 0.5, "rlr_patience": 20, "min_lr_factor": 0.01, "model_width": 64, "edge_width": 64,
+             "model_height": 10, "num_heads": 8, "ffn_multiplier": 2.0, "use_svd": False, "random_mask_prob": 0.1,
+             "upto_hop": 16, "model_name": "egt_500k"}
+
+
+def test_config_defaults_lazy_values_and_unknown_key():
+    c = T.make_config(ZINC_500K)
+    assert c.batch_size == 128 and c.model_height == 10 and c.upto_hop == 16 and c.use_svd is False
+    # lazily evaluated defaults resolve against the FINAL config (HDict.L)
+    assert c.save_path == os.path.join("models/zinc", "egt_500k")
+    assert c.checkpoint_path == os.path.join("models/zinc", "egt_500k", "checkpoint")
+    assert c.saved_model_path == os.path.join("models/zinc", "egt_500k", "saved", "egt_500k")
+    assert c.save_best_monitor == "val_mae" and c.rlr_monitor == "val_mae"
+    assert c.save_when == "epoch;val_mae<=save_best_value;epoch{epoch:0>4d}"
+    assert c.dataset_path == "datasets/ZINC/ZINC.h5" and c.cache_dir == "data_cache/ZINC/svd_16"
+    d = T.make_config(None)
+    assert d.batch_size == 128 and T.make_config({"distributed": True}).batch_size == 32      # 'c:32 if c.distributed else 128'
+    assert d.model_width == 48 and d.edge_width == 48 and d.model_height == 4 and d.upto_hop == 1 and d.use_svd is True
+    with pytest.raises(KeyError, match='Unknown config "modle_width"'):
+        T.make_config({"modle_width": 64})
+    json.dumps(c.get_dict())                                                                  # save_config_file needs plain values
+
+
+def test_model_config_mapping_of_the_shipped_zinc_config():
+    mc = T.model_config(T.make_config(ZINC_500K))
+    want = dict(model_width=64, edge_width=64, num_heads=8, gate_attention=True, scale_degree=False, random_mask_prob=0.1,
+                attn_dropout=0.0, model_height=10, l2_reg=0, node_dropout=0, edge_dropout=0, mlp_layers=[.5, .25],
+                edge_channel_type="residual", edge_activation=None, ffn_multiplier=2.0, global_step_layer=True, upto_hop=16,
+                distance_loss=0., distance_target=8, use_svd=False, transform_svd=True, random_neg=True, num_svd_features=16,
+                sel_svd_features=8, readout_edges=False, num_virtual_nodes=0)
+    assert mc == want
+    assert T.model_config(T.make_config({"dropout": 0.1, "edge_dropout": 0.3}))["edge_dropout"] == 0.3
+    assert T.model_config(T.make_config({"dropout": 0.1}))["edge_dropout"] == 0.1             # edge_dropout None -> dropout
+
+
+def test_save_best_reduce_lr_and_stopping_logic():
+    c = T.make_config(dict(initial_lr=1e-3, rlr_factor=0.5, rlr_patience=2, min_lr_factor=0.2, stopping_lr=3e-4))
+    st = T.TrainingState(c)
+    lr = [1e-3]
+    log = []
+    vals = [1.0, 0.9, 0.95, 0.93, 0.97, 0.96, 0.99, 0.98]       # best at epoch 2, then a plateau
+    stops = []
+    for v in vals:
+        st.current_epoch += 1
+        stops.append(T.save_best_update(c, st, lambda: lr[0], lambda x: lr.__setitem__(0, x), {"val_mae": v}, log.append))
+    assert st.save_best_value == 0.9 and st.save_best_epoch == 2
+    # no improvement at epochs 3,4 -> gap 2 at epoch 4 -> lr 5e-4; again at 6 -> 2.5e-4, floored... min lr = 2e-4
+    # epochs 3,4 without improvement: gap 2 at epoch 4 -> 5e-4; gap 2 again at 6 -> 2.5e-4 (< stopping_lr: STOP from here on);
+    # at 8 -> max(1.25e-4, initial_lr * min_lr_factor = 2e-4)
+    assert lr[0] == pytest.approx(2e-4) and st.last_reduce_lr == 8
+    assert stops == [False, False, False, False, False, True, True, True]
+    # a missing monitor counts as +inf (no improvement), as in the reference (logs.get(monitor, np.inf))
+    st2 = T.TrainingState(c); st2.current_epoch = 1
+    T.save_best_update(c, st2, lambda: 1e-3, lambda x: None, {}, log.append)
+    assert st2.save_best_value == math.inf
+
+
+def test_save_when_dsl_and_warmup_cosine():
+    sw = T.SaveWhen("epoch;val_mae<=save_best_value;epoch{epoch:0>4d}#batch;True;b{batch}")
+    assert sw.fire("epoch", dict(val_mae=0.5, save_best_value=0.7, epoch=12)) == ["epoch0012"]
+    assert sw.fire("epoch", dict(val_mae=0.8, save_best_value=0.7, epoch=13)) == []
+    assert sw.fire("epoch", dict(epoch=3)) == []                 # monitor missing: NameError -> ignored
+    assert sw.fire("batch", dict(batch=7)) == ["b7"]
+    assert T.SaveWhen("").fire("epoch", {}) == []
+    lr, stop = T.warmup_cosine_lr(0, 10, 1.0, 110)
+    assert lr == pytest.approx(0.1) and not stop
+    assert T.warmup_cosine_lr(9, 10, 1.0, 110)[0] == pytest.approx(1.0)
+    assert T.warmup_cosine_lr(60, 10, 1.0, 110)[0] == pytest.approx(math.cos(0.25 * math.pi))
+    assert T.warmup_cosine_lr(111, 10, 1.0, 110) == (None, True)
+    assert T.warmup_cosine_lr(50, 10, 1.0, None) == (None, False)
+
+
+class _Stub(torch.nn.Module):
+    """same call convention as ZincDCTransformer, runs on CPU: target ~ linear in the atom histogram"""
+    def __init__(self, mc):
+        super().__init__()
+        self.mc = mc
+        self.emb = torch.nn.Parameter(torch.zeros(29))
+        self.b = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, nf, fm, adj):
+        return (self.emb[(nf + 1).long()] * (nf >= 0)).sum(1, keepdim=True) + self.b + adj.sum((1, 2))[:, None] / 40
+
+
+def test_training_loop_checkpoint_resume_and_snapshots(tmp_path):
+    cfg = dict(scheme="zinc.svd", model_name="t", num_epochs=3, initial_lr=0.02, batch_size=32, use_svd=False,
+               save_path=str(tmp_path / "run"), rlr_patience=1, gradient_clipval=1.0)
+    logs = []
+    tr = T.SyntheticZinc(128, 32, seed=1); va = T.SyntheticZinc(64, 32, seed=2)
+    s = T.ZincSVDScheme(cfg, model_factory=_Stub, print_fn=logs.append)
+    s.execute_training(tr, va)
+    assert s.state.current_epoch == 3 and s.state.global_step == 12
+    assert s.history[-1]["val_mae"] < s.history[0]["val_mae"]
+    assert os.path.exists(tmp_path / "run" / "checkpoint" / "ckpt.pt")
+    assert os.path.exists(tmp_path / "run" / "saved" / "t.npz")
+    snaps = sorted(f for f in os.listdir(tmp_path / "run" / "saved") if f.startswith("epoch"))
+    assert snaps and snaps[0] == "epoch0001.npz"                                   # first epoch always improves on +inf
+    assert json.load(open(tmp_path / "run" / "config_input.json"))["model_name"] == "t"
+    assert json.load(open(tmp_path / "run" / "config.json"))["checkpoint_path"].endswith("checkpoint")
+    # resume: a new process with more epochs continues from the checkpoint (restore at train begin)
+    cfg2 = dict(cfg, num_epochs=5)
+    s2 = T.ZincSVDScheme(cfg2, model_factory=_Stub, print_fn=logs.append)
+    s2.load_data(tr, va); s2.load_model(); s2.load_state()
+    assert s2.state.current_epoch == 3 and s2.state.global_step == 12 and s2.state.save_best_value == s.state.save_best_value
+    assert torch.equal(s2.model.emb, s.model.emb) and s2.get_lr() == s.get_lr()
+    s2.train_model()
+    assert s2.state.current_epoch == 5 and [h["epoch"] for h in s2.history] == [4, 5]
+    w = np.load(tmp_path / "run" / "saved" / "t.npz")
+    assert "emb" in w.files
+    with pytest.raises(KeyError):
+        T.import_scheme("pattern.svd")
+    with pytest.raises(NotImplementedError):
+        T.ZincSVDScheme(dict(cfg, use_svd=True)).get_model()
+
+
+def test_synthetic_zinc_batches_have_the_reference_format():
+    ds = T.SyntheticZinc(70, 32, nodes=(9, 37), seed=3, pad_multiple=16)
+    bs = list(ds)
+    assert len(bs) == 3 and bs[-1]["node_features"].shape[0] == 6
+    for b in bs:
+        nf, fm, adj = b["node_features"], b["feature_matrix"], b["graph_matrix"]
+        B, N = nf.shape
+        assert N % 16 == 0 and fm.shape == (B, N, N) and adj.shape == (B, N, N) and b["target"].shape == (B, 1)
+        assert nf.dtype == torch.int32 and int(nf.min()) == -1 and int(nf.max()) < 28
+        assert torch.equal(adj, adj.transpose(1, 2)) and set(adj.unique().tolist()) <= {0.0, 1.0}
+        assert ((fm >= 0) == (adj > 0)).all()                                       # bond types on edges, -1 elsewhere
+        pad = nf < 0
+        assert (adj[pad] == 0).all()                                                # padded nodes have no edges
+
+
+@pytest.mark.gpu
+def test_zinc_scheme_trains_the_real_model_and_resumes(tmp_path, gpu, egt_lib):
+    cfg = dict(scheme="zinc.svd", model_name="g", num_epochs=3, initial_lr=2e-3, batch_size=32, use_svd=False,
+               model_width=32, edge_width=32, model_height=2, upto_hop=4, random_mask_prob=0.1,
+               save_path=str(tmp_path / "run"))
+    logs = []
+    tr = T.SyntheticZinc(256, 32, seed=1, pad_multiple=16); va = T.SyntheticZinc(64, 32, seed=2, pad_multiple=16)
+    s = T.ZincSVDScheme(cfg, device=gpu, print_fn=logs.append)
+    s.execute_training(tr, va)
+    assert s.state.current_epoch == 3 and s.state.global_step == 24
+    assert s.history[-1]["loss"] < s.history[0]["loss"], s.history
+    w = np.load(tmp_path / "run" / "saved" / "g.npz")
+    assert "dense_qkv_00/kernel" in w.files and "node_emb/embeddings" in w.files and "fnn_lr1_edge_00/kernel" in w.files
+    assert "dense_edge_r_01/kernel" not in w.files                                  # not part of the reference's Keras model
+    s2 = T.ZincSVDScheme(dict(cfg, num_epochs=4), device=gpu, print_fn=logs.append)
+    s2.load_data(tr, va); s2.load_model(); s2.load_state()
+    assert s2.state.current_epoch == 3
+    assert torch.equal(s2.model.layers.blocks[0].dense_qkv.kernel, s.model.layers.blocks[0].dense_qkv.kernel)
+    s2.train_model()
+    assert s2.state.current_epoch == 4
