@@ -30,6 +30,7 @@
 #include "egt_common.h"
 
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #include "egt_block.h"
@@ -1536,8 +1537,16 @@ __device__ __forceinline__ float elem_read_st(const float* lane_base, const floa
   if (DE == 64) return lane_base[256 * s + 16 * (t ^ s)];
   return elem_read<DE>(tl, q + 4 * s, 16 * t + p);
 }
-template <int DE>
+// MM = EGT_MM_BF16X3 (opt-in: EGT_BWD_MATMUL=bf16x3): the three channel contractions of a tile (P1 projections,
+// P2 dH_ext, P5 d ehat: 48 of the 80 fp32 MFMAs) run as 3-term bfloat16 split products on the bf16 matrix pipe
+// (20 MFMAs of 16 cycles; per-product error 2^-16, fp32 accumulate); the weight-gradient contractions over the
+// pair axis (P4) and everything else stay exact fp32.  Same LDS footprint: a bf16 hi + lo pair is as large as the
+// fp32 value it replaces.
+template <int DE, int MM>
 __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
+  constexpr bool SPLIT = MM == EGT_MM_BF16X3;
+  constexpr int NS = (Geo<DE>::TILES + 1) / 2;   // 16x16x32 steps over the channel axis
+  (void)SPLIT; (void)NS;
   using G = Geo<DE>;
   const float* e_in = a.e;
   const float* dey_in = a.de_out;
@@ -1552,7 +1561,8 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   const bool gated = (a.flags & EGT_BF_GATE) != 0;
   const bool clip = (a.flags & EGT_BF_CLIP) != 0;
   constexpr int PW = 3 * G::TILE_FLOATS + 256 + 192;
-  constexpr int WSLAB = G::TILES * 256;      // one weight slab: [TILES][64 lanes] float4
+  // one weight slab: [TILES][64 lanes] float4; the bf16 slabs of an odd tile count are padded to whole 32-channel steps
+  constexpr int WSLAB = (MM != 0 && NS * 512 > G::TILES * 256) ? NS * 512 : G::TILES * 256;
   float* et0 = sm + wave * PW;               // e / xhat tile, two buffers (row parity)
   float* dt = et0 + 2 * G::TILE_FLOATS;      // de' tile
   float* sc1 = dt + G::TILE_FLOATS;
@@ -1581,6 +1591,35 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
     bwd_node_prologue<DE>(a, sm, qd, b, l_begin, wg);
   }
   // weight slabs: element (t, lane, u)
+  if constexpr (MM != 0) {
+    // bf16 operands.  wsA / wsB: [step s][part hi|lo][lane][8 slots], slot i <-> channel 16 (2s + (i >> 2)) + 4q + (i & 3);
+    // wsD: [tile t][lane][hi(4) | lo(4)] of the lane's 4 dGE columns 4q + u
+    uint16_t* A16 = reinterpret_cast<uint16_t*>(wsA);
+    uint16_t* B16 = reinterpret_cast<uint16_t*>(wsB);
+    uint16_t* D16 = reinterpret_cast<uint16_t*>(wsD);
+    auto parts = [](float v, uint16_t& hi, uint16_t& lo) {
+      const uint32_t h = pk_bf16(v, 0.f) & 0xFFFFu;
+      hi = (uint16_t)h;
+      lo = (uint16_t)(pk_bf16(v - __uint_as_float(h << 16), 0.f) & 0xFFFFu);
+    };
+    for (int idx = threadIdx.x; idx < NS * 512; idx += 256) {
+      const int i = idx & 7, ln = (idx >> 3) & 63, s_ = idx >> 9, pp = ln & 15, qq = ln >> 4, t = 2 * s_ + (i >> 2);
+      const int c = 16 * t + 4 * qq + (i & 3);
+      const bool in = t < G::TILES && c < DE;
+      const int hd = 2 * (pp >> 2) + (pp & 1);
+      uint16_t hi, lo;
+      parts(in ? a.pw[c * 16 + pp] : 0.f, hi, lo);
+      A16[((s_ * 2 + 0) * 64 + ln) * 8 + i] = hi; A16[((s_ * 2 + 1) * 64 + ln) * 8 + i] = lo;
+      parts((in && (pp & 2) == 0) ? a.Wr[hd * DE + c] : 0.f, hi, lo);
+      B16[((s_ * 2 + 0) * 64 + ln) * 8 + i] = hi; B16[((s_ * 2 + 1) * 64 + ln) * 8 + i] = lo;
+    }
+    for (int idx = threadIdx.x; idx < G::TILES * 256; idx += 256) {
+      const int u = idx & 3, ln = (idx >> 2) & 63, t = idx >> 8, pp = ln & 15, qq = ln >> 4;
+      uint16_t hi, lo;
+      parts(a.pw[(16 * t + pp) * 16 + 4 * qq + u], hi, lo);
+      D16[(t * 64 + ln) * 8 + u] = hi; D16[(t * 64 + ln) * 8 + 4 + u] = lo;
+    }
+  } else
   for (int i = threadIdx.x; i < G::TILES * 256; i += 256) {
     const int t = i >> 8, ln = (i >> 2) & 63, u = i & 3, pp = ln & 15, qq = ln >> 4;
     const int c = 16 * t + 4 * qq + u;
@@ -1649,6 +1688,16 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
 #pragma unroll
         for (int t = 0; t < G::TILES; ++t) x[t] = frag_read<DE>(et, p, q, t);
         rstd = ln_frags<DE>(x, q, a.ln_eps, (a.flags & EGT_BF_NO_EDGE_LN) == 0);
+        if constexpr (MM != 0) {
+#pragma unroll
+          for (int t = 0; t < G::TILES; ++t) frag_write<DE>(et, p, q, t, x[t]);     // xhat stays in the tile for the later phases
+          v4f xv[G::TILES];
+          Bf8 xh[NS], xl[NS];
+#pragma unroll
+          for (int t = 0; t < G::TILES; ++t) xv[t] = (v4f){x[t].x, x[t].y, x[t].z, x[t].w};
+          split_tiles<G::TILES, SPLIT>(xv, xh, xl);
+          acc = bf_gemm<NS, SPLIT>(wsA, 0, lane, xh, xl, acc);
+        } else {
 #pragma unroll
         for (int t = 0; t < G::TILES; ++t) {
           frag_write<DE>(et, p, q, t, x[t]);     // xhat stays in the tile for the later phases
@@ -1657,6 +1706,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
           acc = MFMA(w.y, x[t].y, acc);
           acc = MFMA(w.z, x[t].z, acc);
           acc = MFMA(w.w, x[t].w, acc);
+        }
         }
       }
       SCHED_FENCE();
@@ -1670,7 +1720,15 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       TSTAMP(3);
       // ---- P2: dH_ext = de'.Wr^T ----
       v4f dhx = {0.f, 0.f, 0.f, 0.f};
-      if (!(a.guard & 8))
+      if (!(a.guard & 8)) {
+      if constexpr (MM != 0) {
+        v4f dv[G::TILES];
+        Bf8 dh_[NS], dl_[NS];
+#pragma unroll
+        for (int t = 0; t < G::TILES; ++t) { const float4 d4 = frag_read<DE>(dt, p, q, t); dv[t] = (v4f){d4.x, d4.y, d4.z, d4.w}; }
+        split_tiles<G::TILES, SPLIT>(dv, dh_, dl_);
+        dhx = bf_gemm<NS, SPLIT>(wsB, 0, lane, dh_, dl_, dhx);
+      } else {
 #pragma unroll
       for (int t = 0; t < G::TILES; ++t) {
         const float4 dyv = frag_read<DE>(dt, p, q, t);
@@ -1679,6 +1737,8 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
         dhx = MFMA(w.y, dyv.y, dhx);
         dhx = MFMA(w.z, dyv.z, dhx);
         dhx = MFMA(w.w, dyv.w, dhx);
+      }
+      }
       }
       SCHED_FENCE();
       TSTAMP(4);
@@ -1790,15 +1850,33 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       if (!(a.guard & 2)) {
         float4 dxh[G::TILES];
         float m1 = 0.f, m2 = 0.f;
+        Bf8 gB1, gB2;   // B operands of the stacked K = 16 product: [dGE_hi | dGE_hi] and [dGE_lo | 0]
+        if constexpr (MM != 0) {
+          const uint32_t h0 = pk_bf16(dge[0], dge[1]), h1 = pk_bf16(dge[2], dge[3]);
+          gB1.u[0] = h0; gB1.u[1] = h1; gB1.u[2] = h0; gB1.u[3] = h1;
+          gB2.u[0] = pk_bf16(dge[0] - __uint_as_float(h0 << 16), dge[1] - __uint_as_float(h0 & 0xFFFF0000u));
+          gB2.u[1] = pk_bf16(dge[2] - __uint_as_float(h1 << 16), dge[3] - __uint_as_float(h1 & 0xFFFF0000u));
+          gB2.u[2] = 0u; gB2.u[3] = 0u;
+        }
 #pragma unroll
         for (int t = 0; t < G::TILES; ++t) {
           const float4 xh = frag_read<DE>(et, p, q, t);
-          const float4 w = *reinterpret_cast<const float4*>(wsD + (t * 64 + lane) * 4);
           v4f d = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (MM != 0) {
+            Bf8 wa, wb;   // [W_hi(4) | W_lo(4)] . [d_hi | d_hi] = W_hi.d_hi + W_lo.d_hi ;  [W_hi(4) | 0] . [d_lo | 0]
+            wa.q = *reinterpret_cast<const uint4*>(wsD + (t * 64 + lane) * 4);
+            d = MFMA_BF(wa.v, gB1.v, d);
+            if (SPLIT) {
+              wb.u[0] = wa.u[0]; wb.u[1] = wa.u[1]; wb.u[2] = 0u; wb.u[3] = 0u;
+              d = MFMA_BF(wb.v, gB2.v, d);
+            }
+          } else {
+          const float4 w = *reinterpret_cast<const float4*>(wsD + (t * 64 + lane) * 4);
           d = MFMA(w.x, dge[0], d);
           d = MFMA(w.y, dge[1], d);
           d = MFMA(w.z, dge[2], d);
           d = MFMA(w.w, dge[3], d);
+          }
           dxh[t] = make_float4(d[0], d[1], d[2], d[3]);
           m1 += (d[0] + d[1]) + (d[2] + d[3]);
           m2 = fmaf(d[0], xh.x, m2); m2 = fmaf(d[1], xh.y, m2);
@@ -2198,6 +2276,7 @@ struct EgtBlockEnv {
   bool no_xcd_remap, no_kvl, no_epilogue, no_fwd_r4, no_bwd_r4, bwd_v2, no_bwd_ragged, no_bwd_prologue;
   int fwd_ablate, bwd_ablate, bwd_pf;
   int bwd_v5;   // LDS-DMA staged backward (default on; EGT_BWD_V5=0 selects k_block_bwd_v4)
+  int bwd_mm;   // EGT_BWD_MATMUL=bf16x3: the backward's channel contractions as 3-term bf16 split products (opt-in; default exact fp32)
 };
 static bool env_flag_raw(const char* name) {
   const char* v = getenv(name);
@@ -2233,6 +2312,8 @@ static const EgtBlockEnv& block_env() {
     v.bwd_pf = pf ? atoi(pf) : 0;
     const char* v5 = getenv("EGT_BWD_V5");
     v.bwd_v5 = v5 ? atoi(v5) : 1;
+    const char* mm = getenv("EGT_BWD_MATMUL");
+    v.bwd_mm = (mm && !strcmp(mm, "bf16x3")) ? EGT_MM_BF16X3 : EGT_MM_F32;
     return v;
   }();
   return e;
@@ -2516,7 +2597,7 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
   const bool full = (a.N % 16) == 0;
   if constexpr (DE % 16 == 0 || DE == 8) {
     if ((full || rag_ok) && !block_env().bwd_v2) {   // register-lean, 2 waves/SIMD
-      const size_t lds_v4 = ((size_t)(4 * PW > BWD_PRO_WS ? 4 * PW : BWD_PRO_WS) + (size_t)BWD_TL * QD_LD + 3 * GG::TILES * 256) * 4;
+      const size_t lds_v4 = ((size_t)(4 * PW > BWD_PRO_WS ? 4 * PW : BWD_PRO_WS) + (size_t)BWD_TL * QD_LD + 3 * ((GG::TILES + 1) / 2) * 512) * 4;   // slabs padded to whole 32-channel steps (bf16 operands)
       a.NQP = (a.N + 15) / 16;
       a.guard = block_env().bwd_ablate;   // 0 unless this is an ablation build (measurement only: drops phases)
 #define V4_VARIANT_R(ML_, PF_, BF_, RAG_)                                                                  \
@@ -2544,16 +2625,20 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
       }
       if constexpr (DE >= 32) {
         if (full && !ml && !a.bf16 && block_env().bwd_v5) {   // LDS-DMA staged e tiles (k_block_bwd_v5)
-          (void)hipFuncSetAttribute((const void*)k_block_bwd_v5<DE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          const bool x3 = block_env().bwd_mm == EGT_MM_BF16X3;
+          (void)hipFuncSetAttribute((const void*)k_block_bwd_v5<DE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          (void)hipFuncSetAttribute((const void*)k_block_bwd_v5<DE, EGT_MM_BF16X3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #ifdef EGT_BWD_TIMING
           bwd_timing_attach(a, L.nwg_bwd);
 #endif
 #ifdef EGT_BWD_TIMING
           { static const char* padv = getenv("EGT_BWD_LDS_PAD");   // occupancy experiments: extra LDS bytes per workgroup
             const size_t pad = padv ? (size_t)atoi(padv) : 0;
-            EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE>), dim3(L.nwg_bwd), dim3(256), lds_v4 + pad, st, a); }
+            if (x3) EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE, EGT_MM_BF16X3>), dim3(L.nwg_bwd), dim3(256), lds_v4 + pad, st, a);
+            else EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE, 0>), dim3(L.nwg_bwd), dim3(256), lds_v4 + pad, st, a); }
 #else
-          EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a);
+          if (x3) EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE, EGT_MM_BF16X3>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a);
+          else EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE, 0>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a);
 #endif
 #ifdef EGT_BWD_TIMING
           bwd_timing_collect(a, L.nwg_bwd, st);

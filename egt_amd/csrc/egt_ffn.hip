@@ -233,32 +233,6 @@ __global__ void __launch_bounds__(512, 2) k_ffn_fwd(FfnArgs a) {
 // one 16x16x32 step contracts the 8 values a lane holds of channel tiles 2s and 2s+1 (slot i <-> tile
 // 2s + (i >> 2), offset i & 3) -- both operands use that order, so the accumulators of GEMM 1 are again
 // the B operand of GEMM 2 without leaving the lane.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-union Bf8 { bf16x8_t v; uint32_t u[4]; uint4 q; };
-#define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
-
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
-  const bf16x2_t r = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);   // v_cvt_pk_bf16_f32 (RNE)
-  return *reinterpret_cast<const uint32_t*>(&r);
-}
-// 8 fp32 values -> hi / lo bf16x8 (lo only when SPLIT)
-template <bool SPLIT>
-__device__ __forceinline__ void split8(const float (&v)[8], Bf8& hi, Bf8& lo) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint32_t h = pk_bf16(v[2 * k], v[2 * k + 1]);
-    hi.u[k] = h;
-    if (SPLIT) {
-      const float f0 = __uint_as_float(h << 16), f1 = __uint_as_float(h & 0xFFFF0000u);
-      lo.u[k] = pk_bf16(v[2 * k] - f0, v[2 * k + 1] - f1);
-    } else {
-      lo.u[k] = 0u;
-    }
-  }
-}
-
 // sA1[j][s][part][lane][i] = bf16_part( gamma[c] W1[c][16j + pl] ),  c = 16 (2s + (i >> 2)) + 4q + (i & 3)   (0 past W)
 // sA2[o][s][part][lane][i] = bf16_part( W2[hc][16o + pl] ),         hc = 16 (2s + (i >> 2)) + 4q + (i & 3)
 // part 0 = hi, 1 = lo; NS1 = ceil(TW / 2) steps for GEMM 1, TW steps for GEMM 2 (hidden = 2W = TW x 32)
@@ -308,34 +282,6 @@ __global__ void __launch_bounds__(256) k_ffn_prep_bf(FfnArgs a) {
     float s = a.b1[idx];
     for (int c = 0; c < FW; ++c) s = fmaf(a.beta[c], a.W1[c * FH + idx], s);
     a.b1p[idx] = s;
-  }
-}
-
-// acc += sum_s A[blk0 + s] . B[s] with the 3-term split (or the hi term only); slab blocks are [part][lane] uint4
-template <int NS, bool SPLIT>
-__device__ __forceinline__ v4f bf_gemm(const float* slab, int blk0, int lane, const Bf8 (&bh)[NS], const Bf8 (&bl)[NS], v4f acc) {
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    Bf8 ah, al;
-    ah.q = *reinterpret_cast<const uint4*>(slab + ((size_t)((blk0 + s) * 2 + 0) * 64 + lane) * 4);
-    acc = MFMA_BF(ah.v, bh[s].v, acc);
-    if (SPLIT) {
-      al.q = *reinterpret_cast<const uint4*>(slab + ((size_t)((blk0 + s) * 2 + 1) * 64 + lane) * 4);
-      acc = MFMA_BF(al.v, bh[s].v, acc);
-      acc = MFMA_BF(ah.v, bl[s].v, acc);
-    }
-  }
-  return acc;
-}
-// the lane's 4 NT values (channel tiles 0 .. NT-1) -> ceil(NT / 2) split B operands
-template <int NT, bool SPLIT>
-__device__ __forceinline__ void split_tiles(const v4f (&v)[NT], Bf8 (&hi)[(NT + 1) / 2], Bf8 (&lo)[(NT + 1) / 2]) {
-#pragma unroll
-  for (int s = 0; s < (NT + 1) / 2; ++s) {
-    const v4f a0 = v[2 * s];
-    const v4f a1 = (2 * s + 1 < NT) ? v[(2 * s + 1 < NT) ? 2 * s + 1 : 0] : (v4f){0.f, 0.f, 0.f, 0.f};
-    const float f[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-    split8<SPLIT>(f, hi[s], lo[s]);
   }
 }
 

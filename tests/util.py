@@ -1,3 +1,5 @@
+import os
+
 import numpy as np
 import torch
 
@@ -12,7 +14,9 @@ import torch
 # `floor` (a lower bound on the magnitude the absolute term is relative to) is 0 by default; the few
 # GPU-vs-GPU comparisons of tensors known to be analytically zero pass it explicitly.
 FWD = dict(rtol=1e-4, arel=2e-5, l2=1e-4)
-BWD = dict(rtol=1e-3, arel=1e-4, l2=1e-3, zero_atol=2e-5)
+BWD = dict(rtol=1e-3, arel=1e-4, l2=1e-3, zero_atol=float(os.environ.get("EGT_TEST_ZERO_ATOL", "2e-5")))
+# (EGT_TEST_ZERO_ATOL: tests/test_bwd_modes_gpu.py re-runs the block suite with the backward's opt-in bf16x3 matrix
+#  products, whose rounding noise on an analytically-zero sum is ~2^-16 instead of ~2^-24 of the summands)
 
 
 def assert_close(actual, ref, *, rtol, arel, name="", floor=0.0, l2=None, zero_atol=None):
