@@ -195,6 +195,12 @@ __device__ __forceinline__ void fwd_node_epilogue(const BlockArgs& a, float* sm,
 #else
 #define FABL(a, bit) true
 #endif
+// Phase timing of k_block_fwd (EGT_BLOCK_FLAGS=-DEGT_FWD_TIMING, measurement builds only; see EGT_BWD_TIMING)
+#ifdef EGT_FWD_TIMING
+#define FSTAMP(i) do { const unsigned tn__ = (unsigned)__builtin_amdgcn_s_memtime(); facc[i] += tn__ - flast; flast = tn__; } while (0)
+#else
+#define FSTAMP(i) do {} while (0)
+#endif
 template <int DE, bool KVL, bool ML, bool FULL, bool BF>
 __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd(BlockArgs a) {   // narrow tiles without K/V in LDS: more resident waves (with K/V in LDS the LDS footprint caps a CU at two workgroups anyway)
   using G = Geo<DE>;
@@ -276,7 +282,13 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
   }
 
   float Qf[16], mx[2], sum[2], O[16];
+#ifdef EGT_FWD_TIMING
+  unsigned facc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned flast = (unsigned)__builtin_amdgcn_s_memtime();
+  const unsigned fstart = flast;
+#endif
   auto step = [&](const int it_, TileRegs<DE>& tr) __attribute__((always_inline)) {
+    FSTAMP(0);
     const bool live = PFD == 1 || it_ < total;
     const int it = PFD == 1 ? it_ : min(it_, total - 1);
     const int li = it / ntile, mt = it % ntile;
@@ -310,6 +322,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
     if (PFD == 1) { if (it + 1 < total) prefetch(tr, it + 1); }
     else prefetch(tr, it_ + PFD);   // this slot's next tile (clamped past the end)
     lds_sync();
+    FSTAMP(1);
     float4 x[G::TILES];
 #pragma unroll
     for (int t = 0; t < G::TILES; ++t) x[t] = frag_read<DE>(tl, p, q, t);
@@ -345,6 +358,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
       ln_frags<DE>(x, q, a.ln_eps, (a.flags & EGT_BF_NO_EDGE_LN) == 0);
       acc = project<DE>(x, wA, acc);
     }
+    FSTAMP(2);
     // ---- scaled QK^T, clip, + E (egt_layers.py:79-86) ----
     float hh[2] = {0.f, 0.f}, xl[2] = {0.f, 0.f}, gl[2] = {0.f, 0.f};
     if (FABL(a, 1)) {
@@ -375,6 +389,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
 #pragma unroll
       for (int k = 0; k < 8; ++k) O[2 * k + j] = fmaf(O[2 * k + j], alpha, av * Vf[2 * k + j]);
     }
+    FSTAMP(3);
     // ---- dense_edge_r + res_edge: e' = e + H_hat.Wr + br ----
     const float h0 = valid ? hh[0] : 0.f, h1 = valid ? hh[1] : 0.f;
     if (FABL(a, 8))
@@ -390,6 +405,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
       lds_sync();
       tile_from_lds<DE>(tl, e_o + pair0 * DE, lane, rows_valid);
     }
+    FSTAMP(4);
 
     if (mt == ntile - 1 && live) {
       // ---- merge the 16 key lanes (same q): max, then sums ----
@@ -416,6 +432,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
         st[1] = sj;
       }
     }
+    FSTAMP(5);
   };
   if (PFD == 1) {
     for (int it = 0; it < total; ++it) step(it, ring[0]);
@@ -430,7 +447,18 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
   //   epi >= 1: h' = V_att.Wo + bo + h                      (dense_mha + res_mha, :136,140)
   //   epi == 2: qkv of the NEXT block = LN(h').Wqkv' + bqkv' (norm_mha + dense_qkv, :109,113), packed
   // Contraction order k = 4s + q on both MFMA operands; weights come straight from L2.
+#ifdef EGT_FWD_TIMING
+  FSTAMP(6);
+#endif
   if (KVL && a.epi && FABL(a, 64)) fwd_node_epilogue(a, sm, qs, b, lg, N, wave, p, q);
+#ifdef EGT_FWD_TIMING
+  FSTAMP(7);
+  if (a.dbg && lane == 0) {
+    unsigned* o = a.dbg + ((size_t)wg * 4 + wave) * 16;
+    for (int i = 0; i < 8; ++i) o[i] = facc[i];
+    o[13] = flast - fstart;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- forward, narrow edge channels ---
@@ -2497,6 +2525,28 @@ static void bwd_timing_collect(const BlockArgs& a, int nwg, hipStream_t st) {
 }
 #endif
 
+#ifdef EGT_FWD_TIMING
+static unsigned* g_ft_dev = nullptr;
+static int g_ft_n = 0;
+static double g_ft_sum[16];
+static long g_ft_launch = 0, g_ft_waves = 0;
+static void fwd_timing_report() {
+  static const char* nm[] = {"loop top (between tiles)", "store-out prev + LDS put + prefetch issue", "frag/KV read + LN + projections",
+                             "QK^T softmax A.V", "dense_edge_r + write-back", "row merge / stats", "(after loop)", "node epilogue"};
+  if (!g_ft_waves) return;
+  fprintf(stderr, "[egt] k_block_fwd phase cycles per wave (mean over %ld waves, %ld launches):\n", g_ft_waves, g_ft_launch);
+  for (int i = 0; i < 8; ++i) fprintf(stderr, "    %-44s %10.0f  (%.1f %%)\n", nm[i], g_ft_sum[i] / g_ft_waves, 100.0 * g_ft_sum[i] / g_ft_sum[13]);
+  fprintf(stderr, "    %-44s %10.0f\n", "total", g_ft_sum[13] / g_ft_waves);
+}
+static size_t fwd_lds_pad() { static const char* v = getenv("EGT_FWD_LDS_PAD"); return v ? (size_t)atoi(v) : 0; }
+#define FWD_TIMING_ATTACH() do { const int nwg__ = (int)grid.x; if (g_ft_n < nwg__) { if (g_ft_dev) (void)hipFree(g_ft_dev); (void)hipMalloc(&g_ft_dev, (size_t)nwg__ * 64 * sizeof(unsigned)); if (!g_ft_n) atexit(fwd_timing_report); g_ft_n = nwg__; } a.dbg = g_ft_dev; } while (0)
+#define FWD_TIMING_COLLECT() do { (void)hipStreamSynchronize(st); static std::vector<unsigned> h__; h__.resize((size_t)grid.x * 64); (void)hipMemcpy(h__.data(), a.dbg, h__.size() * 4, hipMemcpyDeviceToHost); if (++g_ft_launch > 20) for (size_t w__ = 0; w__ < (size_t)grid.x * 4; ++w__) { for (int i = 0; i < 14; ++i) g_ft_sum[i] += h__[w__ * 16 + i]; ++g_ft_waves; } } while (0)
+#else
+static size_t fwd_lds_pad() { return 0; }
+#define FWD_TIMING_ATTACH() do {} while (0)
+#define FWD_TIMING_COLLECT() do {} while (0)
+#endif
+
 // Forward of one block.  `skip_pre`: qkvp (and pw) of this block were already produced (by the
 // previous block's epilogue / k_edge_prep).  a.epi is the epilogue the caller would like; the
 // value actually used is returned (0 when the geometry is outside the epilogue's cover, in
@@ -2518,7 +2568,9 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   do {                                                                                                 \
     (void)hipFuncSetAttribute((const void*)k_block_fwd<DE, KVL_, ML_, FULL_, BF_>,                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
-    EGT_LAUNCH("k_block_fwd", (k_block_fwd<DE, KVL_, ML_, FULL_, BF_>), grid, block, lds, st, a);      \
+    FWD_TIMING_ATTACH();                                                                                \
+    EGT_LAUNCH("k_block_fwd", (k_block_fwd<DE, KVL_, ML_, FULL_, BF_>), grid, block, lds + fwd_lds_pad(), st, a); \
+    FWD_TIMING_COLLECT();                                                                               \
   } while (0)
 #define FWD_VARIANT(KVL_, ML_, FULL_)                                                                  \
   do { if (a.bf16) FWD_VARIANT_T(KVL_, ML_, FULL_, true); else FWD_VARIANT_T(KVL_, ML_, FULL_, false); } while (0)
