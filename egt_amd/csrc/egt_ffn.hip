@@ -39,6 +39,11 @@ struct FfnArgs {
   uint16_t *sA1, *sA2;   // EGT_MM_BF16X3 / EGT_MM_BF16: bf16 (hi | lo) A-operand slabs of the two forward GEMMs
   uint16_t *sA3, *sA4;   // ... and of the backward's dhid = W2 . dy and dxhat = W1p . dpre
   int mm;                // egt_ffn_desc.matmul
+  int group8;            // width 8 (De = 8 of configs 3/4): two 8-wide rows ride in one 16-wide row of the W = 16 kernels
+                         // (block-diagonal weights, LayerNorm statistics per group of 8 channels); p8_* are the caller's
+                         // 8-wide parameters, gamma/beta/W1/b1/W2/b2 then point at the expanded copies in the workspace
+  const float *p8_gamma, *p8_beta, *p8_W1, *p8_b1, *p8_W2, *p8_b2;
+  float *x16;            // workspace: expanded parameters [gamma 16 | beta 16 | W1 16x32 | b1 32 | W2 32x16 | b2 16]
   float *part, *red;   // backward: per-workgroup partials, reduced sums
   float *g_gamma, *g_beta, *g_W1, *g_b1, *g_W2, *g_b2;
   int nwg;
@@ -86,6 +91,61 @@ template <int ACT>   // derivative from the activation's OUTPUT (hid > 0 <=> pre
 __device__ __forceinline__ float ffn_dact(float hid) {
   if (ACT == EGT_ACT_RELU) return hid > 0.f ? 1.f : 0.f;
   return hid > 0.f ? 1.f : hid + 1.0f;
+}
+
+// LayerNorm of a 16-wide row that carries TWO 8-wide logical rows (channels 0-7: lanes q = 0,1; channels 8-15: q = 2,3):
+// two-pass moments over each group of 8 (one cross-lane add between the lanes q and q ^ 1)
+__device__ __forceinline__ float ln_frags_g8(float4 (&x)[1], float eps) {
+  const float mu = sum_xor16((x[0].x + x[0].y) + (x[0].z + x[0].w)) * (1.0f / 8);
+  x[0].x -= mu; x[0].y -= mu; x[0].z -= mu; x[0].w -= mu;
+  float v = fmaf(x[0].x, x[0].x, 0.f); v = fmaf(x[0].y, x[0].y, v); v = fmaf(x[0].z, x[0].z, v); v = fmaf(x[0].w, x[0].w, v);
+  const float rstd = rsqrtf(sum_xor16(v) * (1.0f / 8) + eps);
+  x[0].x *= rstd; x[0].y *= rstd; x[0].z *= rstd; x[0].w *= rstd;
+  return rstd;
+}
+template <int W>
+__device__ __forceinline__ float ffn_ln(float4 (&x)[W / 16], int q, float eps, int group8) {
+  if constexpr (W == 16) { if (group8) return ln_frags_g8(x, eps); }
+  return ln_frags<W>(x, q, eps);
+}
+
+// width 8: expand the caller's 8-wide parameters to the block-diagonal 16-wide ones the W = 16 kernels consume
+//   gamma'[c] = gamma[c & 7]   W1'[c][h] = (c >> 3 == h >> 4) ? W1[c & 7][h & 15] : 0     b1'[h] = b1[h & 15]
+//   W2'[h][o] = (h >> 4 == o >> 3) ? W2[h & 15][o & 7] : 0                                  b2'[o] = b2[o & 7]
+__global__ void __launch_bounds__(256) k_ffn_expand8(FfnArgs a) {
+  float* g = a.x16; float* bt = g + 16; float* w1 = bt + 16; float* b1 = w1 + 512; float* w2 = b1 + 32; float* b2 = w2 + 512;
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    { const int c = i >> 5, h = i & 31; w1[i] = ((c >> 3) == (h >> 4)) ? a.p8_W1[(c & 7) * 16 + (h & 15)] : 0.f; }
+    { const int h = i >> 4, o = i & 15; w2[i] = ((h >> 4) == (o >> 3)) ? a.p8_W2[(h & 15) * 8 + (o & 7)] : 0.f; }
+  }
+  if (threadIdx.x < 16) { g[threadIdx.x] = a.p8_gamma[threadIdx.x & 7]; bt[threadIdx.x] = a.p8_beta[threadIdx.x & 7]; b2[threadIdx.x] = a.p8_b2[threadIdx.x & 7]; }
+  if (threadIdx.x < 32) b1[threadIdx.x] = a.p8_b1[threadIdx.x & 15];
+}
+// width 8: fold the 16-wide sums back: T1'[16x32], T2'[32x16], s1'[32], s2'[16] (a.red) -> the 8-wide gradients
+//   T1[c][h] = T1'[c][h] + T1'[8+c][16+h] (the two diagonal blocks), likewise T2, s1, s2; then the formulas of k_ffn_param_grads
+__global__ void __launch_bounds__(256) k_ffn_param_grads8(FfnArgs a) {
+  __shared__ float T1[128], T2[128], s1[16], s2[8];
+  const float* R1 = a.red; const float* R2 = a.red + 512; const float* r1 = a.red + 1024; const float* r2 = r1 + 32;
+  const int t = threadIdx.x;
+  if (t < 128) {
+    { const int c = t >> 4, h = t & 15; T1[t] = R1[c * 32 + h] + R1[(8 + c) * 32 + 16 + h]; }
+    { const int h = t >> 3, o = t & 7; T2[t] = R2[h * 16 + o] + R2[(16 + h) * 16 + 8 + o]; }
+  }
+  if (t < 16) s1[t] = r1[t] + r1[16 + t];
+  if (t < 8) s2[t] = r2[t] + r2[8 + t];
+  __syncthreads();
+  if (t < 128) {
+    const int c = t >> 4, h = t & 15;
+    a.g_W1[t] = fmaf(a.p8_gamma[c], T1[t], a.p8_beta[c] * s1[h]);
+    a.g_W2[t] = T2[t];
+  }
+  if (t < 16) a.g_b1[t] = s1[t];
+  if (t < 8) {
+    a.g_b2[t] = s2[t];
+    float dg = 0.f, db = 0.f;
+    for (int h = 0; h < 16; ++h) { const float w = a.p8_W1[t * 16 + h]; dg = fmaf(w, T1[t * 16 + h], dg); db = fmaf(w, s1[h], db); }
+    a.g_gamma[t] = dg; a.g_beta[t] = db;
+  }
 }
 
 __device__ __forceinline__ void slab_to_lds(float* dst, const float* src, int nfloats, int nthreads) {
@@ -188,7 +248,7 @@ __global__ void __launch_bounds__(512, 2) k_ffn_fwd(FfnArgs a) {
     float4 x[TW];
 #pragma unroll
     for (int t = 0; t < TW; ++t) x[t] = frag_read<FW>(tl, p, q, t);
-    ln_frags<FW>(x, q, a.ln_eps);                                   // norm_fnn (gamma/beta folded into the weights)
+    ffn_ln<W>(x, q, a.ln_eps, a.group8);                            // norm_fnn (gamma/beta folded into the weights)
     v4f h[TH];
 #pragma unroll
     for (int j = 0; j < TH; ++j) {                                    // fnn_lr1 + activation
@@ -323,7 +383,7 @@ __global__ void __launch_bounds__(512, 2) k_ffn_fwd_bf(FfnArgs a) {
     float4 x[TW];
 #pragma unroll
     for (int t = 0; t < TW; ++t) x[t] = frag_read<FW>(tl, p, q, t);
-    ln_frags<FW>(x, q, a.ln_eps);                                   // norm_fnn (gamma/beta folded into the weights)
+    ffn_ln<W>(x, q, a.ln_eps, a.group8);                            // norm_fnn (gamma/beta folded into the weights)
     Bf8 xh[NS1], xl[NS1];
 #pragma unroll
     for (int s = 0; s < NS1; ++s) {
@@ -461,7 +521,7 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
       float4 x[TW];
 #pragma unroll
       for (int t = 0; t < TW; ++t) x[t] = frag_read<FW>(et, p, q, t);
-      rstd = ln_frags<FW>(x, q, a.ln_eps);
+      rstd = ffn_ln<W>(x, q, a.ln_eps, a.group8);
 #pragma unroll
       for (int t = 0; t < TW; ++t) frag_write<FW>(et, p, q, t, x[t]);   // xhat: A operand of T1 (other rows) + LN backward
       if constexpr (MM != 0) {
@@ -605,8 +665,8 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
         m2 = fmaf(acc[0], x[i].x, m2); m2 = fmaf(acc[1], x[i].y, m2);
         m2 = fmaf(acc[2], x[i].z, m2); m2 = fmaf(acc[3], x[i].w, m2);
       }
-      m1 = sum_over_q(m1) * (1.0f / FW);
-      m2 = sum_over_q(m2) * (1.0f / FW);
+      if (W == 16 && a.group8) { m1 = sum_xor16(m1) * (1.0f / 8); m2 = sum_xor16(m2) * (1.0f / 8); }   // statistics per 8-channel group
+      else { m1 = sum_over_q(m1) * (1.0f / FW); m2 = sum_over_q(m2) * (1.0f / FW); }
 #pragma unroll
       for (int i = 0; i < TW; ++i) {
         const float4 dyv = frag_read<FW>(dt, p, q, i);
@@ -732,6 +792,8 @@ static size_t ffn_al(size_t x) { return (x + 63) & ~(size_t)63; }
 extern "C" int egt_ffn_supported(const egt_ffn_desc* d) {
   if (!d || d->dtype != EGT_F32 || d->rows <= 0) return 0;
   if (d->matmul != EGT_MM_F32 && d->matmul != EGT_MM_BF16X3 && d->matmul != EGT_MM_BF16) return 0;
+  if (d->width == 8) return (d->rows % 2 == 0) && d->matmul == EGT_MM_F32 &&   // two 8-wide rows per 16-wide kernel row
+                            (d->activation == EGT_ACT_RELU || d->activation == EGT_ACT_ELU);
   if (d->width != 16 && d->width != 32 && d->width != 48 && d->width != 64) return 0;
   return d->activation == EGT_ACT_RELU || d->activation == EGT_ACT_ELU;
 }
@@ -748,14 +810,15 @@ static int ffn_bf_prep_blocks(int W) {
 }
 extern "C" size_t egt_ffn_workspace_bytes(const egt_ffn_desc* d) {
   if (!egt_ffn_supported(d)) return 0;
-  const size_t W = d->width, slab = 2 * W * W, part = 2 * slab + 3 * W;
-  return (4 * slab + ffn_al(2 * W) + ffn_al(part) + (size_t)FFN_NWG * part + ffn_bf_slab_floats(W)) * sizeof(float);
+  const size_t W = d->width == 8 ? 16 : d->width, slab = 2 * W * W, part = 2 * slab + 3 * W;
+  return (4 * slab + ffn_al(2 * W) + ffn_al(part) + (size_t)FFN_NWG * part + ffn_bf_slab_floats(W) + 1280) * sizeof(float);
 }
 
 static int ffn_fill(const egt_ffn_desc* d, const egt_ffn_params* p, void* ws, FfnArgs& a) {
   if (!d || !p || !ws) EGT_FAIL(EGT_E_NULL, "desc/params/workspace is NULL");
   if (!egt_ffn_supported(d))
-    EGT_FAIL(EGT_E_SHAPE, "fused FFN covers widths 16/32/48/64, fp32, relu/elu (got width %d, act %d)", d->width, d->activation);
+    EGT_FAIL(EGT_E_SHAPE, "fused FFN covers widths 16/32/48/64 (and 8 with an even row count, exact fp32 products), fp32, relu/elu "
+                          "(got width %d, rows %lld, act %d, matmul %d)", d->width, (long long)d->rows, d->activation, d->matmul);
   if (!p->norm_gamma || !p->norm_beta || !p->lr1_kernel || !p->lr1_bias || !p->lr2_kernel || !p->lr2_bias)
     EGT_FAIL(EGT_E_NULL, "an FFN parameter pointer is NULL");
   a = FfnArgs{};
@@ -763,7 +826,7 @@ static int ffn_fill(const egt_ffn_desc* d, const egt_ffn_params* p, void* ws, Ff
   a.gamma = (const float*)p->norm_gamma; a.beta = (const float*)p->norm_beta;
   a.W1 = (const float*)p->lr1_kernel; a.b1 = (const float*)p->lr1_bias;
   a.W2 = (const float*)p->lr2_kernel; a.b2 = (const float*)p->lr2_bias;
-  const size_t W = d->width, slab = 2 * W * W, part = 2 * slab + 3 * W;
+  const size_t W = d->width == 8 ? 16 : d->width, slab = 2 * W * W, part = 2 * slab + 3 * W;
   float* w = (float*)ws;
   a.slab1 = w; a.slab2 = w + slab; a.slab3 = w + 2 * slab; a.slab4 = w + 3 * slab;
   a.b1p = w + 4 * slab;
@@ -778,6 +841,12 @@ static int ffn_fill(const egt_ffn_desc* d, const egt_ffn_params* p, void* ws, Ff
     a.sA2 = reinterpret_cast<uint16_t*>(bf + a1);
     a.sA3 = reinterpret_cast<uint16_t*>(bf + a1 + a2);
     a.sA4 = reinterpret_cast<uint16_t*>(bf + 2 * a1 + a2);
+    a.x16 = bf + 2 * a1 + 2 * a2;
+  }
+  if (d->width == 8) {   // ride on the W = 16 kernels: half as many 16-wide rows, expanded parameters
+    a.group8 = 1; a.W = 16; a.rows = d->rows / 2;
+    a.p8_gamma = a.gamma; a.p8_beta = a.beta; a.p8_W1 = a.W1; a.p8_b1 = a.b1; a.p8_W2 = a.W2; a.p8_b2 = a.b2;
+    a.gamma = a.x16; a.beta = a.x16 + 16; a.W1 = a.x16 + 32; a.b1 = a.x16 + 544; a.W2 = a.x16 + 576; a.b2 = a.x16 + 1088;
   }
   {   // backward workgroups: one per CU for large inputs; small inputs (node channels) one tile
       // per wave (a tile is ~16 us of dependent work: spreading beats amortising the slab staging)
@@ -846,6 +915,7 @@ static void ffn_launch_bwd(const FfnArgs& a, int act, hipStream_t st) {
 
 #define FFN_DISPATCH_W(width, CALL)               \
   switch (width) {                                \
+    case 8:                                       \
     case 16: { constexpr int W = 16; CALL; } break; \
     case 32: { constexpr int W = 32; CALL; } break; \
     case 48: { constexpr int W = 48; CALL; } break; \
@@ -860,6 +930,7 @@ extern "C" int egt_ffn_fwd(const egt_ffn_desc* desc, const egt_ffn_params* param
   if (!x || !y) EGT_FAIL(EGT_E_NULL, "x/y is NULL");
   a.x = (const float*)x; a.y = (float*)y;
   hipStream_t st = (hipStream_t)stream;
+  if (a.group8) EGT_LAUNCH("k_ffn_prep", k_ffn_expand8, dim3(1), dim3(256), 0, st, a);
   if (desc->matmul != EGT_MM_F32) {
     FFN_DISPATCH_W(desc->width, ffn_launch_fwd_bf<W>(a, desc->activation, st));
   } else {
@@ -883,13 +954,15 @@ extern "C" int egt_ffn_bwd(const egt_ffn_desc* desc, const egt_ffn_params* param
   a.g_W1 = (float*)grads->lr1_kernel; a.g_b1 = (float*)grads->lr1_bias;
   a.g_W2 = (float*)grads->lr2_kernel; a.g_b2 = (float*)grads->lr2_bias;
   hipStream_t st = (hipStream_t)stream;
+  if (a.group8) EGT_LAUNCH("k_ffn_prep", k_ffn_expand8, dim3(1), dim3(256), 0, st, a);
   FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep<W>, dim3((2 * W * W + 255) / 256), dim3(256), 0, st, a));
   if (desc->matmul != EGT_MM_F32)
     FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep_bf<W>, dim3(ffn_bf_prep_blocks(W)), dim3(256), 0, st, a));
   FFN_DISPATCH_W(desc->width, ffn_launch_bwd<W>(a, desc->activation, st));
   const int part = 4 * a.W * a.W + 3 * a.W;
   EGT_LAUNCH("k_ffn_sum", k_ffn_sum, dim3((part + 63) / 64), dim3(256), 0, st, a);
-  FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_param_grads", k_ffn_param_grads<W>, dim3(16), dim3(256), 0, st, a));
+  if (a.group8) EGT_LAUNCH("k_ffn_param_grads", k_ffn_param_grads8, dim3(1), dim3(256), 0, st, a);
+  else FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_param_grads", k_ffn_param_grads<W>, dim3(16), dim3(256), 0, st, a));
   EGT_HIP_LAUNCH_CHECK("egt_ffn_bwd");
   return EGT_OK;
 }

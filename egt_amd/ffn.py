@@ -70,10 +70,23 @@ class _FusedFFN(torch.autograd.Function):
 def ffn(x, norm_gamma, norm_beta, lr1_kernel, lr1_bias, lr2_kernel, lr2_bias, activation="elu", eps=1e-3, matmul="f32"):
     """x: [..., W] -> [..., W]; kernels in Keras layout [in, out]."""
     W = x.shape[-1]
-    desc = _desc(x.numel() // W, W, activation, eps, matmul)
+    rows = x.numel() // W
+    params = (norm_gamma, norm_beta, lr1_kernel, lr1_bias, lr2_kernel, lr2_bias)
+    if W == 8 and rows % 2 == 1:
+        # width 8 rides two rows per 16-wide kernel row (egt_ffn.hip: group8): an odd row count sends its last row
+        # through a second, 2-row call (padded with a zero row whose output is dropped)
+        flat = x.reshape(rows, W)
+        tail = torch.cat([flat[rows - 1:], torch.zeros_like(flat[:1])], dim=0)
+        y_tail = ffn(tail, *params, activation=activation, eps=eps, matmul=matmul)[:1]
+        if rows == 1:
+            return y_tail.reshape(x.shape)
+        y_main = ffn(flat[:rows - 1], *params, activation=activation, eps=eps, matmul=matmul)
+        return torch.cat([y_main, y_tail], dim=0).reshape(x.shape)
+    desc = _desc(rows, W, activation, eps, matmul)
     if not L.load().egt_ffn_supported(C.byref(desc)):
-        raise ValueError(f"fused FFN covers widths 16/32/48/64 in fp32 (got width {W}, dtype {x.dtype})")
-    return _FusedFFN.apply(x, desc, norm_gamma, norm_beta, lr1_kernel, lr1_bias, lr2_kernel, lr2_bias)
+        raise ValueError(f"fused FFN covers widths 8/16/32/48/64 in fp32 (width 8: exact fp32 products only); "
+                         f"got width {W}, dtype {x.dtype}, matmul {matmul!r}")
+    return _FusedFFN.apply(x, desc, *params)
 
 
 class FFN(nn.Module):
@@ -89,8 +102,8 @@ class FFN(nn.Module):
             raise ValueError(f"fused FFN activation must be one of {sorted(_ACT)} (got {activation!r})")
         # fail at construction for a width the kernels do not cover (there is no composed fallback);
         # the C library decides (egt_ffn_supported), so the Python side never drifts from it
-        if not L.load().egt_ffn_supported(C.byref(_desc(16, width, activation, 1e-3))):
-            raise ValueError(f"fused FFN does not cover width {width} (fp32)")
+        if not L.load().egt_ffn_supported(C.byref(_desc(16, width, activation, 1e-3, matmul if matmul in _MM else "f32"))):
+            raise ValueError(f"fused FFN does not cover width {width} with matmul={matmul!r} (fp32; width 8: exact products only)")
         if matmul not in _MM:
             raise ValueError(f"matmul must be one of {sorted(_MM)} (got {matmul!r})")
         self.width, self.activation, self.matmul = width, activation, matmul

@@ -62,6 +62,14 @@ def test_ffn_other_widths_vs_oracle(W, shape, act, gpu, egt_lib):
     _run(shape, act, gpu, seed=W, W=W)
 
 
+@pytest.mark.parametrize("shape,act", [((2, 20, 20), "elu"), ((3, 15, 15), "relu"), ((1, 7), "elu"), ((1,), "elu"), ((128, 9), "elu"),
+                                        ((2, 120, 120), "elu")])
+def test_ffn_width8_vs_oracle(shape, act, gpu, egt_lib):
+    """edge_width 8 (BASELINE configs 3 / 4: CIFAR10, PATTERN): two 8-wide rows per 16-wide kernel row, LayerNorm per
+    8-channel group, block-diagonal weights; odd row counts take the padded tail call"""
+    _run(shape, act, gpu, seed=8, W=8)
+
+
 def test_ffn_bit_reproducible_and_linear_in_dy(gpu, egt_lib):
     from egt_amd import FFN
     torch.manual_seed(5)
@@ -90,19 +98,21 @@ def test_ffn_rejects_uncovered(gpu, egt_lib):
         ffn(x, z, z, torch.zeros(40, 80, device=gpu), torch.zeros(80, device=gpu), torch.zeros(80, 40, device=gpu), z)
 
 
-def test_layer_stack_attention_plus_ffn_vs_oracle(gpu, egt_lib):
+@pytest.mark.parametrize("N,De", [(32, 64), (23, 8), (40, 8)])
+def test_layer_stack_attention_plus_ffn_vs_oracle(N, De, gpu, egt_lib):
     """EGTLayerStack = the reference's full layer loop (attention block, then ffn_block on both
-    channel types; graph_xformer_model_base.py:336-341) vs the fp64 oracle composition."""
+    channel types; graph_xformer_model_base.py:336-341) vs the fp64 oracle composition.  De = 8 is the
+    edge width of BASELINE configs 3 / 4 (CIFAR10, PATTERN): whole layers run there since the width-8 FFN."""
     from egt_amd import EGTLayerStack
     from oracle import egt_oracle as O
     from test_block_gpu import PMAP
     torch.manual_seed(17)
-    B, N, Ly = 2, 32, 2
-    st = EGTLayerStack(model_height=Ly, model_width=64, edge_width=64, num_heads=8, fused=True).to(gpu).eval()
+    B, Ly = 2, 2
+    st = EGTLayerStack(model_height=Ly, model_width=64, edge_width=De, num_heads=8, fused=True).to(gpu).eval()
     g = torch.Generator().manual_seed(2)
-    h = torch.randn(B, N, 64, generator=g); e = torch.randn(B, N, N, 64, generator=g)
+    h = torch.randn(B, N, 64, generator=g); e = torch.randn(B, N, N, De, generator=g)
     mask = torch.ones(B, N, dtype=torch.bool); mask[0, N - 4:] = False
-    dh = torch.randn(B, N, 64, generator=g); de = torch.randn(B, N, N, 64, generator=g)
+    dh = torch.randn(B, N, 64, generator=g); de = torch.randn(B, N, N, De, generator=g)
     hg = h.to(gpu).requires_grad_(); eg = e.to(gpu).requires_grad_()
     h2, e2 = st(hg, eg, mask.to(gpu))
     torch.autograd.backward([h2, e2], [dh.to(gpu), de.to(gpu)])
