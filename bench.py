@@ -135,19 +135,28 @@ def prof_read_all(lib):
     return out
 
 
-def cpu_baseline_model(w, seconds=12.0):
-    """whole-model scope: the torch-CPU restatement of the ZINC model (oracle/egt_model_oracle.py), fwd + MAE + bwd."""
+def cpu_baseline_model(w, seconds=12.0, pattern=False):
+    """whole-model scope: the torch-CPU restatement of the ZINC / PATTERN model (oracle/egt_model_oracle.py), fwd + loss + bwd."""
     from oracle import egt_model_oracle as MO
     Bs = 8
     cfg = dict(model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"], model_height=w["Ly"], upto_hop=16)
+    if pattern:
+        cfg.update(num_node_features=3, num_edge_features=0, num_targets=2)
     nf, fm, adj, tgt = make_zinc_inputs(dict(w, B=Bs), "cpu", seed=77)
     g = torch.Generator().manual_seed(3)
     p = {k: v.requires_grad_() for k, v in MO.init_zinc_params(cfg, generator=g).items()}
     rms = [torch.rand(Bs, w["N"], w["N"], w["H"], generator=g) < w["rand_p"] for _ in range(w["Ly"])]
+    ycls = torch.randint(0, 2, (Bs, w["N"]), generator=g)
+    cw = MO.class_weights_from_sizes([979220, 209900]).float()
+    nf3 = torch.where(nf >= 0, nf % 3, nf)
 
     def step():
-        y = MO.zinc_forward(nf, fm, adj, p, cfg, rand_masks=rms)
-        torch.autograd.grad(MO.mae_loss(y, tgt), [v for k, v in p.items()], allow_unused=True)
+        if pattern:
+            lo, m = MO.pattern_forward(nf3, adj, p, cfg, rand_masks=rms)
+            loss = MO.weighted_sparse_xent_loss(lo, ycls, m, cw)
+        else:
+            loss = MO.mae_loss(MO.zinc_forward(nf, fm, adj, p, cfg, rand_masks=rms), tgt)
+        torch.autograd.grad(loss, [v for k, v in p.items()], allow_unused=True)
 
     nthr = torch.get_num_threads()
     thr = min(nthr, 8)
@@ -161,7 +170,7 @@ def cpu_baseline_model(w, seconds=12.0):
     finally:
         torch.set_num_threads(nthr)
     return dict(value=Bs * reps / dt, unit="graphs/s", cores=thr, kind="port",
-                sample=f"{reps} fwd+MAE+bwd steps of the whole ZINC model (Ly={w['Ly']}) on B={Bs} graphs "
+                sample=f"{reps} fwd+loss+bwd steps of the whole {'PATTERN' if pattern else 'ZINC'} model (Ly={w['Ly']}) on B={Bs} graphs "
                        f"(N={w['N']}, fp32, torch-CPU restatement, {dt:.1f}s, host has {os.cpu_count()} cpus)")
 
 
@@ -321,15 +330,21 @@ def main():
     mask_seed = 1 * world + rank  # the replicas draw independent random attention masks
     fused = {"auto": "auto", "on": True, "off": False}[args.fused]
     zinc = None
+    pattern = args.workload.startswith("pattern")
     if args.scope == "model":
-        from egt_amd import ZincDCTransformer, mae_loss
+        from egt_amd import ZincDCTransformer, PatternDCTransformer, mae_loss, weighted_sparse_xent_loss, class_weights_from_sizes
         from types import SimpleNamespace
-        model = ZincDCTransformer(model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"], model_height=w["Ly"],
-                                  upto_hop=16, random_mask_prob=w["rand_p"], seed=mask_seed,
-                                  ffn_matmul=args.ffn_matmul).to(dev).train()
+        cls = PatternDCTransformer if pattern else ZincDCTransformer     # PATTERN: lib/models/sbm_pattern/dc.py (BASELINE config 4)
+        model = cls(model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"], model_height=w["Ly"],
+                    upto_hop=16, random_mask_prob=w["rand_p"], seed=mask_seed, ffn_matmul=args.ffn_matmul).to(dev).train()
         model.fused_parameters = model.trainable_parameters
         model.grad_holder = SimpleNamespace(flat=None)
         zinc = make_zinc_inputs(w, dev, seed=1234 + rank)
+        if pattern:
+            gy = torch.Generator().manual_seed(99 + rank)
+            zinc.append(torch.randint(0, 2, (w["B"], w["N"]), generator=gy).to(dev))          # node class targets
+            zinc.append(class_weights_from_sizes([979220, 209900], device=dev))
+            zinc[0] = torch.where(zinc[0] >= 0, zinc[0] % 3, zinc[0])                           # 3 node feature values
     elif args.with_ffn:
         from egt_amd import EGTLayerStack
         model = EGTLayerStack(model_height=w["Ly"], model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"],
@@ -363,8 +378,13 @@ def main():
             for p in params:
                 p.grad = None
         if zinc is not None:             # whole model: prediction -> MAE -> backward
-            nf, fm, adj, tgt = zinc
-            mae_loss(model(nf, fm, adj), tgt).backward()
+            if pattern:
+                nf, fm, adj, tgt, ycls, cw = zinc
+                logits, nmask = model(nf, adj, return_mask=True)
+                weighted_sparse_xent_loss(logits, ycls, nmask, cw).backward()
+            else:
+                nf, fm, adj, tgt = zinc
+                mae_loss(model(nf, fm, adj), tgt).backward()
         else:
             h.grad = None; e.grad = None
             h2, e2 = model(h, e, mask)
@@ -475,13 +495,13 @@ def main():
                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
         cpu = None
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline_model(w, args.cpu_seconds) if args.scope == "model" else cpu_baseline(w, args.cpu_seconds)
+            cpu = cpu_baseline_model(w, args.cpu_seconds, pattern=args.workload.startswith("pattern")) if args.scope == "model" else cpu_baseline(w, args.cpu_seconds)
         graphs = graphs_step * args.steps
         path = "fused-stack" if state["flat_ok"] else ("fused" if any(k.startswith("k_block") for k in prof) else "composed")
         if args.with_ffn:
             path += "+ffn"
         if args.scope == "model":
-            path = "zinc-model (HIP edge embedding + fused blocks + fused FFNs, torch node-side head)"
+            path = ("pattern" if pattern else "zinc") + "-model (HIP edge embedding + fused blocks + fused FFNs, torch node-side head)"
         line = {
             "metric": "graphs/sec EGT fwd+bwd, ZINC-500K padded N=64",
             "value": graphs / elapsed, "unit": "graphs/s", "n_gpus": world,
@@ -489,8 +509,10 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32 (edge tensors stored bf16)" if bf16 else "f32",
             "data": "synthetic",
-            "config": {"workload": (f"{args.workload}: " + {"model": "WHOLE ZINC MODEL (embeddings, 16-hop stacking, Ly x [attention block + node/edge FFN], "
-                                                             "final norm, masked mean pool, MLP head, MAE) fwd+bwd",
+            "config": {"workload": (f"{args.workload}: " + {"model": ("WHOLE PATTERN MODEL (node embedding, 16-hop adjacency embedding, Ly x [attention block + node/edge FFN], "
+                                                                       "final norm, per-node MLP head, class-weighted x-ent) fwd+bwd" if args.workload.startswith("pattern") else
+                                                                       "WHOLE ZINC MODEL (embeddings, 16-hop stacking, Ly x [attention block + node/edge FFN], "
+                                                                       "final norm, masked mean pool, MLP head, MAE) fwd+bwd"),
                                                              "layers": "Ly x [attention block + node/edge FFN] fwd+bwd"}.get(
                                         args.scope or ("layers" if args.with_ffn else "stack"),
                                         "attention-block stack (h,e,mask)->(h',e') x Ly, fwd+bwd")

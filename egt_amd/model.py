@@ -158,6 +158,55 @@ class ZincDCTransformer(nn.Module):
         return self.target(x)                                                           # zinc/dc.py:116-117
 
 
+class PatternDCTransformer(ZincDCTransformer):
+    """lib.models.sbm_pattern.dc.DCSVDTransformer for scheme pattern.svd (use_svd false): integer node features
+    (3 values), the adjacency hop embedding as the ONLY edge-channel input (no feature matrix), per-node readout
+    `mlp_out -> Dense(num_target_labels)` (sbm_pattern/dc.py:51-58).  edge_width 8 in the shipped configs."""
+
+    def __init__(self, num_node_features=3, num_target_labels=2, edge_width=8, model_height=16, **kw):
+        kw.pop("num_edge_features", None); kw.pop("num_targets", None)
+        super().__init__(num_node_features=num_node_features, num_edge_features=0, num_targets=num_target_labels,
+                         edge_width=edge_width, model_height=model_height, **kw)
+        # no fm_emb in this model: the embedding kernel gets a one-row ZERO table (a constant buffer, not a parameter)
+        del self.fm_emb
+        self.register_buffer("fm_emb", torch.zeros(1, edge_width), persistent=False)
+
+    def keras_named_parameters(self):
+        out = super().keras_named_parameters()
+        out.pop("fm_emb/embeddings", None)
+        return out
+
+    def forward(self, node_features, graph_matrix, attn_mask=None, return_mask=False):
+        fmat = torch.full(graph_matrix.shape, -1, dtype=torch.int32, device=graph_matrix.device)
+        h, e, mask = self.embeddings(node_features, fmat, graph_matrix)
+        h, e = self.layers(h, e, mask, attn_mask, skip_last_edge_ffn=True)
+        if self.node_norm_final is not None:
+            h = self.node_norm_final(h)
+        x = h
+        for lyr in self.mlp_out:
+            x = lyr(x)
+            x = F.elu(x) if self.cfg["activation"] == 'elu' else torch.relu(x)
+        y = self.target(x)                                                                # logits [B,N,C]
+        return (y, mask) if return_mask else y
+
+
+def class_weights_from_sizes(class_sizes, device=None):
+    """WeightedSparseXEntropyLoss (lib/base/genutil/losses.py:41-46)."""
+    cs = torch.as_tensor(class_sizes, dtype=torch.float32, device=device)
+    w = cs.sum() - cs
+    return w / w.sum()
+
+
+def weighted_sparse_xent_loss(logits, y_true, mask, class_weights):
+    """schemes/pattern/svd.py:34-39: class-weighted sparse cross-entropy per node, masked by the node mask, divided by
+    the number of (graph, node) slots (Keras SUM_OVER_BATCH_SIZE counts the padded slots too)."""
+    logp = torch.log_softmax(logits, dim=-1)
+    y = y_true.clamp(min=0).long()
+    xent = -logp.gather(-1, y[..., None])[..., 0]
+    per = class_weights[y] * xent * mask.to(logits.dtype)
+    return per.sum() / per.numel()
+
+
 def mae_loss(y_pred, y_true):
     """keras.losses.MeanAbsoluteError (schemes/zinc/svd.py:37-39)."""
     return (y_pred - y_true).abs().mean()

@@ -65,7 +65,7 @@ def save_config_to_file(config, config_file):    # :19-21
         return json.dump(config, fp, indent="\t")
 
 
-def default_config() -> Config:
+def default_config(scheme: str = "zinc.svd") -> Config:
     """TrainingBase.get_default_config (:80-112) + BaseDCModelScheme (scheme_base.py:7-35) + BaseAdjModelScheme
     (:93-101) + BaseSVDModelScheme (:117-126) + ZincDCSVD (zinc/svd.py:13-21), later ones overriding."""
     path = os.path
@@ -106,18 +106,19 @@ def default_config() -> Config:
         model_name="dc_svd", cache_dir=lambda c: f"data_cache/{c.dataset_name.upper()}/svd_{c.num_svd_features}",
         num_svd_features=16, sel_svd_features=8, use_svd=True, random_neg=True,
     )
-    c.update(  # ZincDCSVD
-        dataset_name="zinc", num_virtual_nodes=0, rlr_monitor="val_mae", save_best_monitor="val_mae",
-    )
+    if scheme == "pattern.svd":   # SBMPDCSVD (schemes/pattern/svd.py:16-24)
+        c.update(dataset_name="sbm_pattern", class_sizes=[979220, 209900], rlr_monitor="val_xent", save_best_monitor="val_xent")
+    else:                         # ZincDCSVD (schemes/zinc/svd.py:13-21)
+        c.update(dataset_name="zinc", num_virtual_nodes=0, rlr_monitor="val_mae", save_best_monitor="val_mae")
     return c
 
 
-SCHEMES = ("zinc.svd",)
+SCHEMES = ("zinc.svd", "pattern.svd")
 
 
-def make_config(user: Optional[dict]) -> Config:
+def make_config(user: Optional[dict], scheme: Optional[str] = None) -> Config:
     """TrainingBase.__init__ (:24-32): defaults, then the user's keys; an unknown key is an error."""
-    c = default_config()
+    c = default_config(scheme or (user or {}).get("scheme") or "zinc.svd")
     if user is not None:
         for k in user.keys():
             if k not in c:
@@ -127,7 +128,14 @@ def make_config(user: Optional[dict]) -> Config:
 
 
 def model_config(c: Config) -> dict:
-    """config -> model_config (scheme_base.py:37-60, :103-111, :151-160; zinc/svd.py:27-35)."""
+    """config -> model_config (scheme_base.py:37-60, :103-111, :151-160; zinc/svd.py:27-35; pattern/svd.py:30-32)."""
+    mc = _model_config_common(c)
+    if "num_virtual_nodes" in c:           # the ZINC scheme adds these two (zinc/svd.py:30-34)
+        mc.update(readout_edges=False, num_virtual_nodes=c.num_virtual_nodes)
+    return mc
+
+
+def _model_config_common(c: Config) -> dict:
     return dict(
         model_width=c.model_width, edge_width=c.edge_width, num_heads=c.num_heads, gate_attention=c.gate_attention,
         scale_degree=c.scale_degree, random_mask_prob=c.random_mask_prob, attn_dropout=c.attn_dropout,
@@ -138,7 +146,6 @@ def model_config(c: Config) -> dict:
         upto_hop=c.upto_hop, distance_loss=c.distance_loss, distance_target=c.distance_target,
         use_svd=c.use_svd, transform_svd=True, random_neg=c.random_neg, num_svd_features=c.num_svd_features,
         sel_svd_features=c.sel_svd_features,
-        readout_edges=False, num_virtual_nodes=c.num_virtual_nodes,
     )
 
 
@@ -268,12 +275,13 @@ class SyntheticZinc:
 # ------------------------------------------------------------------------------------------ scheme --
 class ZincSVDScheme:
     """lib.training.schemes.zinc.svd.SCHEME: TrainingBase protocol around the ZINC model."""
+    SCHEME = "zinc.svd"
 
     def __init__(self, config: Optional[dict] = None, model_factory=None, device=None, print_fn=print):
         self.config_input = config
-        self.config = make_config(config)
-        if self.config.scheme not in (None,) + SCHEMES:
-            raise KeyError(f"scheme {self.config.scheme!r}: only {SCHEMES} are built (SURVEY 8(f)-2: ZINC first)")
+        self.config = make_config(config, self.SCHEME)
+        if self.config.scheme not in (None, self.SCHEME):
+            raise KeyError(f"scheme {self.config.scheme!r} given to {type(self).__name__} ({self.SCHEME}); built schemes: {SCHEMES}")
         self.state = TrainingState(self.config)
         self.model_factory = model_factory
         self.device = device
@@ -386,6 +394,12 @@ class ZincSVDScheme:
         mv = (lambda t: t.to(dev)) if dev is not None else (lambda t: t)
         return mv(b["node_features"]), mv(b["feature_matrix"]), mv(b["graph_matrix"]), mv(b["target"])
 
+    def batch_loss(self, batch):
+        """(loss, metric sums) of one batch: scheme-specific"""
+        nf, fm, adj, tgt = self._batch(batch)
+        y = self.model(nf, fm, adj)
+        return self.loss_fn(y, tgt), dict(mae=((y - tgt).abs().sum().detach(), tgt.numel()))
+
     def train_step(self, batch):
         c = self.config
         if c.warmup_steps > 0:
@@ -393,14 +407,12 @@ class ZincSVDScheme:
             if lr is not None:
                 self.set_lr(lr)
             self.stop_training |= stop
-        nf, fm, adj, tgt = self._batch(batch)
         if self.flat is not None:
             self.flat.zero(); self.flat.rebind()
         else:
             self.optimizer.zero_grad(set_to_none=True)
         self.model.train()
-        y = self.model(nf, fm, adj)
-        loss = self.loss_fn(y, tgt)
+        loss, _ = self.batch_loss(batch)
         loss.backward()
         if self.flat is not None:
             self.flat.all_reduce(average=True)
@@ -412,15 +424,16 @@ class ZincSVDScheme:
 
     @torch.no_grad()
     def evaluate(self, dataset, max_steps=None):
+        """validation metrics: {name: weighted mean}"""
         self.model.eval()
-        tot, n = 0.0, 0
+        acc = {}
         for i, b in enumerate(dataset):
             if max_steps is not None and i >= max_steps:
                 break
-            nf, fm, adj, tgt = self._batch(b)
-            y = self.model(nf, fm, adj)
-            tot += float((y - tgt).abs().sum()); n += tgt.numel()
-        return tot / max(n, 1)
+            _, ms = self.batch_loss(b)
+            for k, (sm, cnt) in ms.items():
+                a = acc.setdefault(k, [0.0, 0.0]); a[0] += float(sm); a[1] += float(cnt)
+        return {k: v[0] / max(v[1], 1e-30) for k, v in acc.items()}
 
     def train_model(self):                           # model.fit (:293-302) with the callbacks' behaviour inlined
         c = self.config
@@ -435,10 +448,11 @@ class ZincSVDScheme:
                 if self.stop_training:
                     break
             logs = dict(loss=float(np.mean(losses)) if losses else math.nan)
-            logs["mae"] = logs["loss"]               # the loss IS the MAE metric for this scheme
+            logs[self.get_metrics()[0]] = logs["loss"]   # the loss IS the first metric of these schemes (MAE / weighted x-ent)
             if self.valset is not None:
                 v = self.evaluate(self.valset, c.validation_steps)
-                logs.update(val_loss=v, val_mae=v)
+                logs["val_loss"] = v[self.get_metrics()[0]]
+                logs.update({"val_" + k: x for k, x in v.items()})
             # epoch-end order of the reference's callback list: training callbacks (SaveWhen) first, then the
             # checkpoint callback, whose on_epoch_end runs the state updates and saves (:249-256, checkpoint.py:66-83)
             scope = dict(logs); scope["epoch"] = epoch + 1; scope.update(self.state.items())
@@ -465,11 +479,80 @@ class ZincSVDScheme:
         self.finalize_training()
 
 
+class PatternSVDScheme(ZincSVDScheme):
+    """lib.training.schemes.pattern.svd.SCHEME (SBMPDCSVD): node classification with the class-weighted sparse
+    cross-entropy (lib/base/genutil/losses.py), metrics xent + acc, monitors val_xent."""
+    SCHEME = "pattern.svd"
+
+    def get_model(self):
+        if self.model_factory is not None:
+            return self.model_factory(self.get_model_config())
+        from .model import PatternDCTransformer
+        mc = self.get_model_config()
+        if mc["use_svd"]:
+            raise NotImplementedError("use_svd=True needs the data pipeline's SVD features; the shipped PATTERN configs set use_svd=false")
+        return PatternDCTransformer(**mc)
+
+    def get_loss(self):
+        from .model import weighted_sparse_xent_loss
+        return weighted_sparse_xent_loss
+
+    def get_metrics(self):
+        return ["xent", "acc"]
+
+    def batch_loss(self, batch):
+        from .model import class_weights_from_sizes
+        dev = self.device
+        mv = (lambda t: t.to(dev)) if dev is not None else (lambda t: t)
+        nf, adj, tgt = mv(batch["node_features"]), mv(batch["graph_matrix"]), mv(batch["target"])
+        out = self.model(nf, adj, return_mask=True)
+        logits, mask = out
+        w = class_weights_from_sizes(self.config.class_sizes, device=logits.device)
+        loss = self.loss_fn(logits, tgt, mask, w)
+        m = mask.to(logits.dtype)
+        hit = ((logits.argmax(-1) == tgt).to(logits.dtype) * m).sum().detach()
+        # Keras feeds the mask as sample_weight: the metrics are means over the REAL nodes (losses.py:108-118)
+        logp = torch.log_softmax(logits.detach(), -1).gather(-1, tgt.clamp(min=0).long()[..., None])[..., 0]
+        xs = (-(logp) * w[tgt.clamp(min=0).long()] * m).sum()
+        return loss, dict(xent=(xs, m.sum()), acc=(hit, m.sum()))
+
+
+class SyntheticPattern:
+    """Batches in the PATTERN input format (lib/data/datasets/sbm_pattern.py): node_features [B,N] int in {0,1,2}
+    (padding -1), graph_matrix [B,N,N] 0/1, target [B,N] int class per node (0 on padded slots).  A planted pattern:
+    nodes of class 1 are more densely connected among themselves."""
+
+    def __init__(self, n_graphs=512, batch_size=128, nodes=(44, 188), seed=0, pad_multiple=1, device="cpu"):
+        g = torch.Generator().manual_seed(seed)
+        self.n = torch.randint(nodes[0], nodes[1] + 1, (n_graphs,), generator=g)
+        self.seed, self.batch_size, self.pad_multiple, self.device = seed, batch_size, pad_multiple, device
+
+    def __len__(self):
+        return (len(self.n) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        for b in range(len(self)):
+            ns = self.n[b * self.batch_size:(b + 1) * self.batch_size]
+            g = torch.Generator().manual_seed(self.seed * 100003 + b)
+            B, N = len(ns), int(ns.max())
+            N = (N + self.pad_multiple - 1) // self.pad_multiple * self.pad_multiple
+            real = torch.arange(N)[None, :] < ns[:, None]
+            cls = (torch.rand(B, N, generator=g) < 0.18).long() * real
+            same = (cls[:, :, None] == 1) & (cls[:, None, :] == 1)
+            pr = torch.where(same, torch.tensor(0.5), torch.tensor(0.08))
+            adj = (torch.rand(B, N, N, generator=g) < pr).float()
+            adj = ((adj + adj.transpose(1, 2)) > 0).float() * (real[:, :, None] & real[:, None, :]).float() * (1 - torch.eye(N))[None]
+            nf = torch.randint(0, 3, (B, N), generator=g); nf[~real] = -1
+            yield dict(node_features=nf.int().to(self.device), graph_matrix=adj.to(self.device), target=cls.to(self.device))
+
+
 def import_scheme(name: str):
     """lib/training/importer.py:3-11."""
-    if name != "zinc.svd":
-        raise KeyError(f"scheme {name!r}: only {SCHEMES} are built")
-    return ZincSVDScheme
+    if name == "zinc.svd":
+        return ZincSVDScheme
+    if name == "pattern.svd":
+        return PatternSVDScheme
+    raise KeyError(f"scheme {name!r}: only {SCHEMES} are built")
 
 
 def main(argv=None):
@@ -482,7 +565,8 @@ def main(argv=None):
     n_graphs = int(argv[argv.index("--synthetic") + 1]) if "--synthetic" in argv else 2048
     scheme = import_scheme(config["scheme"])(config, device=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
     bs = scheme.config.batch_size
-    scheme.execute_training(SyntheticZinc(n_graphs, bs, seed=1), SyntheticZinc(max(bs, n_graphs // 8), bs, seed=2))
+    data = SyntheticPattern if config["scheme"] == "pattern.svd" else SyntheticZinc
+    scheme.execute_training(data(n_graphs, bs, seed=1), data(max(bs, n_graphs // 8), bs, seed=2))
 
 
 if __name__ == "__main__":

@@ -117,6 +117,50 @@ def init_zinc_params(cfg, *, dtype=torch.float32, generator=None, randomize=True
     return {k: v.to(dtype) for k, v in p.items()}
 
 
+def class_weights_from_sizes(class_sizes):
+    """WeightedSparseXEntropyLoss.__init__ (lib/base/genutil/losses.py:41-46): w = (sum - sizes) / sum(sum - sizes)."""
+    cs = torch.as_tensor(class_sizes, dtype=torch.float64)
+    w = cs.sum() - cs
+    return w / w.sum()
+
+
+def weighted_sparse_xent_loss(logits, y_true, mask, class_weights):
+    """schemes/pattern/svd.py:34-39 + losses.py:5-23: per-node w[y] * sparse_categorical_crossentropy(from_logits);
+    Keras multiplies the per-node losses by the output's mask (the node mask travels with h) and reduces with
+    SUM_OVER_BATCH_SIZE = sum / number of (batch x node) elements, padded ones included (TF 2.1
+    losses_utils.compute_weighted_loss)."""
+    logp = torch.log_softmax(logits, dim=-1)
+    y = y_true.clamp(min=0).long()
+    xent = -logp.gather(-1, y[..., None])[..., 0]
+    w = class_weights.to(logits.dtype)[y]
+    per = w * xent * mask.to(logits.dtype)
+    return per.sum() / per.numel()
+
+
+def pattern_forward(node_features, graph_matrix, p, cfg, rand_masks=None):
+    """lib/models/sbm_pattern/dc.py:14-61 (DCSVDTransformer, use_svd false): node embedding, adjacency hop embedding as the
+    only edge channel input, the layer loop, final norm, per-node mlp_out + Dense(num_target_labels) -> logits [B,N,C]."""
+    H, Ly = cfg.get("num_heads", 8), cfg["model_height"]
+    act = cfg.get("activation", "elu")
+    dt = p["node_emb.embeddings"].dtype
+    h = neg1_masked_embedding(node_features, p["node_emb.embeddings"])                      # sbm_pattern/dc.py:45-48
+    hops = stack_hops(graph_matrix.to(dt), cfg["upto_hop"], cfg.get("clip_hops", True))
+    e = O.dense(hops, p["adj_emb.kernel"], p["adj_emb.bias"])                               # graph_model_base.py:97-127
+    mask = O.node_mask_from_features(node_features)
+    for ii in range(Ly):
+        bp = {k[len(f"layer{ii}."):]: v for k, v in p.items() if k.startswith(f"layer{ii}.") and ".ffn_" not in k}
+        rm = None if rand_masks is None else rand_masks[ii]
+        h, e = O.block_forward(h, e, mask, bp, num_heads=H, rand_mask=rm)
+        fn = {k.split(".", 2)[2]: v for k, v in p.items() if k.startswith(f"layer{ii}.ffn_node.")}
+        fe = {k.split(".", 2)[2]: v for k, v in p.items() if k.startswith(f"layer{ii}.ffn_edge.")}
+        e = O.ffn_forward(e, fe, activation=act)
+        h = O.ffn_forward(h, fn, activation=act)
+    if cfg.get("do_final_norm", True):
+        h = O.layer_norm(h, p["node_norm_final.gamma"], p["node_norm_final.beta"])
+    x = mlp_out(h, p, len(cfg.get("mlp_layers", [0.5, 0.25])), act)                         # :55 (per node)
+    return O.dense(x, p["target.kernel"], p["target.bias"]), mask                           # :56-58
+
+
 def zinc_embeddings(node_features, feature_matrix, graph_matrix, p, cfg):
     """get_embeddings (graph_xformer_model_base.py:411-431) for the zinc.svd model without SVD features."""
     dt = p["node_emb.embeddings"].dtype

@@ -55,7 +55,9 @@ def _load_params(model, params, dev):
     named = model.keras_named_parameters()
     Ly = len(model.layers.blocks)
     with torch.no_grad():
-        model.node_emb.copy_(params["node_emb.embeddings"]); model.fm_emb.copy_(params["fm_emb.embeddings"])
+        model.node_emb.copy_(params["node_emb.embeddings"])
+        if isinstance(model.fm_emb, torch.nn.Parameter):
+            model.fm_emb.copy_(params["fm_emb.embeddings"])
         model.adj_emb.kernel.copy_(params["adj_emb.kernel"]); model.adj_emb.bias.copy_(params["adj_emb.bias"])
         model.node_norm_final.gamma.copy_(params["node_norm_final.gamma"]); model.node_norm_final.beta.copy_(params["node_norm_final.beta"])
         for i, m in enumerate(model.mlp_out):
@@ -181,3 +183,60 @@ def test_zinc_model_training_masks_and_names(gpu, egt_lib):
         assert k in names, k
     Ly = c["cfg"]["model_height"]
     assert f"dense_edge_r_{Ly - 1:0>2d}/kernel" not in names and f"fnn_lr1_edge_{Ly - 1:0>2d}/kernel" not in names
+
+
+# ------------------------------------------------------------------------------ PATTERN (config 4) -----
+def _pattern_case(B=3, N=13, seed=5):
+    from oracle import egt_model_oracle as MO
+    cfg = dict(model_width=32, edge_width=8, model_height=2, upto_hop=4, num_node_features=3, num_edge_features=0, num_targets=2)
+    g = torch.Generator().manual_seed(seed)
+    n = torch.tensor([N, 7, 10][:B])
+    real = torch.arange(N)[None, :] < n[:, None]
+    nf = torch.randint(0, 3, (B, N), generator=g); nf[~real] = -1
+    adj = (torch.rand(B, N, N, generator=g) > 0.6).float()
+    adj = ((adj + adj.transpose(1, 2)) > 0).float() * (real[:, :, None] & real[:, None, :]).float() * (1 - torch.eye(N))[None]
+    y = torch.randint(0, 2, (B, N), generator=g); y[~real] = 0
+    params = MO.init_zinc_params(cfg, dtype=torch.float32, generator=g)
+    return cfg, nf, adj, y, params
+
+
+def test_pattern_oracle_loss_semantics():
+    from oracle import egt_model_oracle as MO
+    w = MO.class_weights_from_sizes([979220, 209900])               # schemes/pattern/svd.py:20
+    assert torch.allclose(w, torch.tensor([209900 / 1189120, 979220 / 1189120], dtype=torch.float64))
+    logits = torch.zeros(1, 3, 2, dtype=torch.float64); y = torch.tensor([[0, 1, 1]]); mask = torch.tensor([[True, True, False]])
+    loss = MO.weighted_sparse_xent_loss(logits, y, mask, w)          # uniform logits: xent = ln 2; padded slot weighs 0 but counts
+    assert float(loss) == pytest.approx(float((w[0] + w[1]) * torch.log(torch.tensor(2.0, dtype=torch.float64)) / 3))
+
+
+@pytest.mark.gpu
+def test_pattern_model_vs_oracle(gpu, egt_lib):
+    """PATTERN model (BASELINE config 4's dataset): edge_width 8, adjacency-only edge input, per-node logits, class-weighted
+    cross-entropy -- logits, loss and every parameter gradient vs the fp64 oracle.  B * N * N is odd here: the width-8 edge
+    FFN takes its padded-tail path."""
+    from egt_amd import PatternDCTransformer, weighted_sparse_xent_loss, class_weights_from_sizes
+    from oracle import egt_model_oracle as MO
+    cfg, nf, adj, y, params = _pattern_case()
+    model = PatternDCTransformer(model_width=32, model_height=2, upto_hop=4, random_mask_prob=0.0).to(gpu).eval()
+    _load_params(model, params, gpu)
+    p64 = {k: v.double().requires_grad_() for k, v in params.items()}
+    lo, mo = MO.pattern_forward(nf, adj, p64, cfg)
+    w64 = MO.class_weights_from_sizes([979220, 209900])
+    loss_o = MO.weighted_sparse_xent_loss(lo, y, mo, w64)
+    names = [k for k in p64 if k != "fm_emb.embeddings"]
+    gro = torch.autograd.grad(loss_o, [p64[k] for k in names], allow_unused=True)
+    logits, mask = model(nf.to(gpu), adj.to(gpu), return_mask=True)
+    assert torch.equal(mask.cpu(), mo)
+    loss = weighted_sparse_xent_loss(logits, y.to(gpu), mask, class_weights_from_sizes([979220, 209900], device=gpu))
+    loss.backward()
+    assert_close(logits, lo, name="logits", rtol=2e-4, arel=5e-5)
+    assert_close(loss.reshape(1), loss_o.reshape(1), name="xent", rtol=2e-4, arel=5e-5)
+    dead = {id(p) for p in model._dead_edge_params()}
+    checked = 0
+    for k, gref in zip(names, gro):
+        prm = _grad_of(model, k)
+        if prm is None or id(prm) in dead or gref is None:
+            continue
+        assert_close(prm.grad, gref, name=k, **BWD); checked += 1
+    assert checked > 40
+    assert "fm_emb/embeddings" not in model.keras_named_parameters() and not isinstance(model.fm_emb, torch.nn.Parameter)

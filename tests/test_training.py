@@ -123,9 +123,30 @@ def test_training_loop_checkpoint_resume_and_snapshots(tmp_path):
     w = np.load(tmp_path / "run" / "saved" / "t.npz")
     assert "emb" in w.files
     with pytest.raises(KeyError):
-        T.import_scheme("pattern.svd")
+        T.import_scheme("tsp.svd")
     with pytest.raises(NotImplementedError):
         T.ZincSVDScheme(dict(cfg, use_svd=True)).get_model()
+
+
+def test_pattern_scheme_config_and_synthetic_batches():
+    # configs/main/pattern/500k/egt.json of the reference
+    cfg = {"scheme": "pattern.svd", "distributed": True, "batch_size": 128, "initial_lr": 0.0005, "num_epochs": 200, "rlr_factor": 0.5,
+           "rlr_patience": 10, "min_lr_factor": 0.01, "model_width": 64, "edge_width": 8, "model_height": 16, "num_heads": 8,
+           "ffn_multiplier": 2.0, "use_svd": False, "random_mask_prob": 0.1, "upto_hop": 16, "model_name": "egt_500k"}
+    c = T.make_config(cfg)
+    assert c.dataset_name == "sbm_pattern" and c.class_sizes == [979220, 209900]
+    assert c.save_best_monitor == "val_xent" and c.save_when == "epoch;val_xent<=save_best_value;epoch{epoch:0>4d}"
+    assert c.save_path == os.path.join("models/sbm_pattern", "egt_500k")
+    mc = T.model_config(c)
+    assert mc["edge_width"] == 8 and mc["model_height"] == 16 and "readout_edges" not in mc and "num_virtual_nodes" not in mc
+    with pytest.raises(KeyError):
+        T.make_config(dict(cfg, num_virtual_nodes=0))               # not a key of the PATTERN scheme
+    assert T.import_scheme("pattern.svd") is T.PatternSVDScheme
+    b = next(iter(T.SyntheticPattern(40, 16, nodes=(20, 50), seed=1, pad_multiple=16)))
+    nf, adj, y = b["node_features"], b["graph_matrix"], b["target"]
+    assert nf.shape == y.shape and adj.shape == nf.shape + nf.shape[-1:] and nf.shape[1] % 16 == 0
+    assert int(nf.max()) <= 2 and int(nf.min()) == -1 and set(y.unique().tolist()) <= {0, 1}
+    assert (y[nf < 0] == 0).all() and torch.equal(adj, adj.transpose(1, 2))
 
 
 def test_synthetic_zinc_batches_have_the_reference_format():
@@ -163,3 +184,17 @@ def test_zinc_scheme_trains_the_real_model_and_resumes(tmp_path, gpu, egt_lib):
     assert torch.equal(s2.model.layers.blocks[0].dense_qkv.kernel, s.model.layers.blocks[0].dense_qkv.kernel)
     s2.train_model()
     assert s2.state.current_epoch == 4
+
+
+@pytest.mark.gpu
+def test_pattern_scheme_trains_on_the_gpu(tmp_path, gpu, egt_lib):
+    cfg = dict(scheme="pattern.svd", model_name="p", num_epochs=2, initial_lr=2e-3, batch_size=16, use_svd=False,
+               model_width=32, edge_width=8, model_height=2, upto_hop=4, random_mask_prob=0.1, save_path=str(tmp_path / "run"))
+    logs = []
+    tr = T.SyntheticPattern(64, 16, nodes=(20, 44), seed=1, pad_multiple=16); va = T.SyntheticPattern(32, 16, nodes=(20, 44), seed=2, pad_multiple=16)
+    s = T.PatternSVDScheme(cfg, device=gpu, print_fn=logs.append)
+    s.execute_training(tr, va)
+    assert s.state.current_epoch == 2 and s.history[-1]["loss"] < s.history[0]["loss"], s.history
+    assert 0.0 <= s.history[-1]["val_acc"] <= 1.0 and s.history[-1]["val_xent"] > 0
+    w = np.load(tmp_path / "run" / "saved" / "p.npz")
+    assert "adj_emb/kernel" in w.files and "fm_emb/embeddings" not in w.files and "fnn_lr1_edge_00/kernel" in w.files
