@@ -12,36 +12,42 @@
 
 typedef float v4f_e __attribute__((ext_vector_type(4)));
 
-// hops[b,l,m,k] = clip( sum_j adj[b,l,j] * hops[b,j,m,k-1] ); grid = B * T * T waves (T = ceil(N/16))
+// hop-major storage hops[k][b][l][m] (every plane is a contiguous [B,N,N] matrix stack: the B operand of the next
+// product and the embedding kernels read it with unit stride).
+// hops[k] = clip( adj . hops[k-1] ) per graph; grid = B * T * T waves (T = ceil(N/16)), one 16 x 16 output tile per wave
 __global__ void __launch_bounds__(64) k_hop_step(const float* __restrict__ adj, float* __restrict__ hops, int B, int N,
                                                  int K, int k, int clip) {
   const int T = (N + 15) / 16;
   const int tile = blockIdx.x % (T * T), b = blockIdx.x / (T * T);
   const int l0 = (tile / T) * 16, m0 = (tile % T) * 16;
   const int lane = threadIdx.x, i = lane & 15, kk = lane >> 4;
+  const size_t plane = (size_t)B * N * N;
   const float* A = adj + (size_t)b * N * N;
-  const float* P = hops + (size_t)b * N * N * K + (k - 1);
-  v4f_e acc = {0.f, 0.f, 0.f, 0.f};
+  const float* P = hops + (size_t)(k - 1) * plane + (size_t)b * N * N;
+  v4f_e acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const int la = min(l0 + i, N - 1), mb = min(m0 + i, N - 1);
-  for (int j0 = 0; j0 < N; j0 += 4) {
-    const int j = j0 + kk;
-    const float av = j < N ? A[(size_t)la * N + j] : 0.f;                 // A operand: row l0 + i, contraction index j
-    const float bv = j < N ? P[((size_t)j * N + mb) * K] : 0.f;           // B operand: contraction index j, column m0 + i
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+  for (int j0 = 0; j0 < N; j0 += 8) {     // two independent accumulators: the loads of both steps are in flight together
+    const int ja = j0 + kk, jb = j0 + 4 + kk;
+    const float a0 = ja < N ? A[(size_t)la * N + ja] : 0.f;               // A operand: row l0 + i, contraction index j
+    const float b0 = ja < N ? P[(size_t)ja * N + mb] : 0.f;               // B operand: contraction index j, column m0 + i
+    const float a1 = jb < N ? A[(size_t)la * N + jb] : 0.f;
+    const float b1 = jb < N ? P[(size_t)jb * N + mb] : 0.f;
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
   }
   // D: row 4 * (lane >> 4) + r, column lane & 15
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int l = l0 + 4 * kk + r, m = m0 + i;
-    float v = acc[r];
+    float v = acc0[r] + acc1[r];
     if (clip) v = fminf(fmaxf(v, 0.f), 1.f);
-    if (l < N && m < N) hops[(((size_t)b * N + l) * N + m) * K + k] = v;
+    if (l < N && m < N) hops[(size_t)k * plane + ((size_t)b * N + l) * N + m] = v;
   }
 }
 
 __global__ void __launch_bounds__(256) k_hop_first(const float* __restrict__ adj, float* __restrict__ hops, long pairs, int K) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i < pairs) hops[i * K] = adj[i];
+  if (i < pairs) hops[i] = adj[i];   // plane 0
 }
 
 // e0[pair, c] = fm_table[fmat[pair] + 1, c] + bias[c] + sum_k hops[pair, k] * W[k, c]
@@ -65,10 +71,10 @@ __global__ void __launch_bounds__(256) k_edge_embed_fwd(const int32_t* __restric
   int f = fmat[pair] + 1;
   f = min(max(f, 0), V - 1);
   float4 acc = *reinterpret_cast<const float4*>(Ts + f * De + 4 * c4);
-  const float* hp = hops + pair * K;
+  const float* hp = hops + pair;
 #pragma unroll 4
   for (int k = 0; k < K; ++k) {
-    const float hv = hp[k];
+    const float hv = hp[(size_t)k * pairs];
     const float4 w = *reinterpret_cast<const float4*>(Ws + k * De + 4 * c4);
     acc.x = fmaf(hv, w.x, acc.x); acc.y = fmaf(hv, w.y, acc.y);
     acc.z = fmaf(hv, w.z, acc.z); acc.w = fmaf(hv, w.w, acc.w);
@@ -77,16 +83,18 @@ __global__ void __launch_bounds__(256) k_edge_embed_fwd(const int32_t* __restric
 }
 
 // backward: dW[k,c] = sum_pairs hops[pair,k] de[pair,c];  dtable[v,c] = sum_{fmat+1 == v} de[pair,c];  dbias = sum de
-// block = 16 pair lanes x (De/4 <= 16) channel quads; each thread owns 4 channels and walks its pairs; the
-// (K + V) x 4 accumulators per thread are reduced over the 16 pair lanes in LDS; one partial per workgroup
+// block = PL pair lanes x C4P channel quads (C4P = De/4 rounded up to a power of two, PL = 256 / C4P: narrow edge
+// channels get more pair lanes instead of idle threads); each thread owns 4 channels and walks its pairs; the
+// (K + V) x 4 accumulators per thread are reduced over the pair lanes in LDS; one partial per workgroup
 #define EMB_PPB 2048   // pairs per workgroup
 template <int K_, int V_>
 __global__ void __launch_bounds__(256) k_edge_embed_bwd(const int32_t* __restrict__ fmat, const float* __restrict__ hops,
                                                         const float* __restrict__ de, float* __restrict__ part, long pairs,
-                                                        int De) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // [16 pair lanes][(K+V)][De]
+                                                        int De, int C4P) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [PL pair lanes][(K+V)][De]
   const int C4 = De / 4;
-  const int c4 = threadIdx.x % 16, pl = threadIdx.x / 16;
+  const int PL = 256 / C4P;
+  const int c4 = threadIdx.x % C4P, pl = threadIdx.x / C4P;
   float4 aw[K_], at[V_];
 #pragma unroll
   for (int k = 0; k < K_; ++k) aw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -95,14 +103,14 @@ __global__ void __launch_bounds__(256) k_edge_embed_bwd(const int32_t* __restric
   const long p0 = (long)blockIdx.x * EMB_PPB;
   const long p1 = min(pairs, p0 + EMB_PPB);
   if (c4 < C4) {
-    for (long pair = p0 + pl; pair < p1; pair += 16) {
+    for (long pair = p0 + pl; pair < p1; pair += PL) {
       const float4 d = *reinterpret_cast<const float4*>(de + pair * De + 4 * c4);
-      const float* hp = hops + pair * K_;
+      const float* hp = hops + pair;
       int f = fmat[pair] + 1;
       f = min(max(f, 0), V_ - 1);
 #pragma unroll
       for (int k = 0; k < K_; ++k) {
-        const float hv = hp[k];
+        const float hv = hp[(size_t)k * pairs];
         aw[k].x = fmaf(hv, d.x, aw[k].x); aw[k].y = fmaf(hv, d.y, aw[k].y);
         aw[k].z = fmaf(hv, d.z, aw[k].z); aw[k].w = fmaf(hv, d.w, aw[k].w);
       }
@@ -123,8 +131,7 @@ __global__ void __launch_bounds__(256) k_edge_embed_bwd(const int32_t* __restric
   float* out = part + (size_t)blockIdx.x * R;
   for (int i = threadIdx.x; i < R; i += 256) {
     float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) s += sm[(size_t)j * R + i];   // fixed order: bit-reproducible
+    for (int j = 0; j < PL; ++j) s += sm[(size_t)j * R + i];   // fixed order: bit-reproducible
     out[i] = s;
   }
 }
@@ -214,11 +221,14 @@ static void launch_embed_bwd(const egt_embed_desc* d, const int32_t* fmat, const
                              hipStream_t st) {
   const long pairs = (long)d->B * d->N * d->N;
   const int nparts = embed_nparts(d);
+  int c4p = 1;
+  while (c4p < d->De / 4) c4p *= 2;
+  while ((size_t)(256 / c4p) * (K_ + 8) * d->De * sizeof(float) > 150 * 1024) c4p *= 2;   // LDS reduction image must fit
 #define EB(V_)                                                                                                      \
   do {                                                                                                              \
-    const size_t lds = (size_t)16 * (K_ + V_) * d->De * sizeof(float);                                              \
+    const size_t lds = (size_t)(256 / c4p) * (K_ + V_) * d->De * sizeof(float);                                     \
     (void)hipFuncSetAttribute((const void*)k_edge_embed_bwd<K_, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    EGT_LAUNCH("k_edge_embed_bwd", (k_edge_embed_bwd<K_, V_>), dim3(nparts), dim3(256), lds, st, fmat, hops, de, part, pairs, d->De); \
+    EGT_LAUNCH("k_edge_embed_bwd", (k_edge_embed_bwd<K_, V_>), dim3(nparts), dim3(256), lds, st, fmat, hops, de, part, pairs, d->De, c4p); \
   } while (0)
   switch (d->num_edge_features + 1) {
     case 1: EB(1); break; case 2: EB(2); break; case 3: EB(3); break; case 4: EB(4); break;

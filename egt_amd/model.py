@@ -48,7 +48,7 @@ class _EdgeEmbed(torch.autograd.Function):
         if not lib.egt_edge_embed_supported(C.byref(desc)):
             raise ValueError(f"edge embedding kernel does not cover upto_hop={K}, edge_width={De}, "
                              f"num_edge_features={table.shape[0] - 1}")
-        hops = torch.empty(B, N, N, K, dtype=torch.float32, device=adj.device)
+        hops = torch.empty(K, B, N, N, dtype=torch.float32, device=adj.device)   # hop-major (unit-stride planes)
         e = torch.empty(B, N, N, De, dtype=torch.float32, device=adj.device)
         L.check(lib.egt_edge_embed_fwd(C.byref(desc), L.ptr(fmat), L.ptr(adj), L.ptr(table), L.ptr(kernel),
                                        L.ptr(bias), L.ptr(hops), L.ptr(e), L.current_stream()))

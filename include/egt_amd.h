@@ -369,7 +369,7 @@ int egt_constrained_edge_mask(const float* adj, int32_t B, int32_t N, int32_t H,
  *      + Dense(upto_hop -> De)(stack_hops(graph_matrix))                        lib/models/graph_model_base.py:97-127
  * feature_matrix [B,N,N] int32 (-1 = no edge / padding), graph_matrix [B,N,N] fp32, fm_table [V,De]
  * (V = num_edge_features + 1), adj_kernel [upto_hop, De] (Keras layout), adj_bias [De].  `hops`
- * ([B,N,N,upto_hop] fp32, egt_edge_embed_hops_bytes) receives the stacked hop matrices; the backward
+ * ([upto_hop,B,N,N] fp32 -- hop-major --, egt_edge_embed_hops_bytes) receives the hop matrices; the backward
  * reads them again.  Gradients: d_fm_table, d_adj_kernel, d_adj_bias (no gradient flows to the inputs). */
 typedef struct egt_embed_desc {
   int32_t B, N, De;

@@ -113,7 +113,7 @@ def test_edge_embed_vs_oracle(B, N, De, K, V, gpu, egt_lib):
     gr = torch.autograd.grad(e_o, [t64, W64, b64], de.double())
     tg, Wg, bg = (x.to(gpu).requires_grad_() for x in (table, W, b))
     e, hops = edge_embed(fm.to(gpu), adj.to(gpu), tg, Wg, bg, return_hops=True)
-    assert torch.equal(hops.cpu(), hops_o.float()), "hop matrices of a 0/1 adjacency are exact"
+    assert torch.equal(hops.permute(1, 2, 3, 0).cpu(), hops_o.float()), "hop matrices of a 0/1 adjacency are exact"
     assert_close(e, e_o, name="e0", **FWD)
     e.backward(de.to(gpu))
     assert_close(tg.grad, gr[0], name="d fm_emb", **BWD)
@@ -122,7 +122,7 @@ def test_edge_embed_vs_oracle(B, N, De, K, V, gpu, egt_lib):
     # weighted (non-binary) adjacency without clipping: fp32 contraction within tolerance
     adjw = adj * torch.rand(B, N, N, generator=g)
     _, hw = edge_embed(fm.to(gpu), adjw.to(gpu), tg, Wg, bg, clip_hops=False, return_hops=True)
-    assert_close(hw, MO.stack_hops(adjw.double(), K, clip_hops=False), name="weighted hops", rtol=1e-4, arel=1e-5)
+    assert_close(hw.permute(1, 2, 3, 0), MO.stack_hops(adjw.double(), K, clip_hops=False), name="weighted hops", rtol=1e-4, arel=1e-5)
 
 
 @pytest.mark.gpu
