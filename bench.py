@@ -331,10 +331,13 @@ def main():
     fused = {"auto": "auto", "on": True, "off": False}[args.fused]
     zinc = None
     pattern = args.workload.startswith("pattern")
+    cifar = args.workload.startswith("cifar")
     if args.scope == "model":
-        from egt_amd import ZincDCTransformer, PatternDCTransformer, mae_loss, weighted_sparse_xent_loss, class_weights_from_sizes
+        from egt_amd import (ZincDCTransformer, PatternDCTransformer, Cifar10DCTransformer, mae_loss, weighted_sparse_xent_loss,
+                             class_weights_from_sizes, sparse_xent_loss)
         from types import SimpleNamespace
-        cls = PatternDCTransformer if pattern else ZincDCTransformer     # PATTERN: lib/models/sbm_pattern/dc.py (BASELINE config 4)
+        # PATTERN: lib/models/sbm_pattern/dc.py (BASELINE config 4); CIFAR10: lib/models/cifar10/dc.py (config 3)
+        cls = PatternDCTransformer if pattern else (Cifar10DCTransformer if cifar else ZincDCTransformer)
         model = cls(model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"], model_height=w["Ly"],
                     upto_hop=16, random_mask_prob=w["rand_p"], seed=mask_seed, ffn_matmul=args.ffn_matmul).to(dev).train()
         model.fused_parameters = model.trainable_parameters
@@ -345,6 +348,13 @@ def main():
             zinc.append(torch.randint(0, 2, (w["B"], w["N"]), generator=gy).to(dev))          # node class targets
             zinc.append(class_weights_from_sizes([979220, 209900], device=dev))
             zinc[0] = torch.where(zinc[0] >= 0, zinc[0] % 3, zinc[0])                           # 3 node feature values
+        if cifar:     # real-valued superpixel features in the reference's format (padding / non-edges = -1)
+            gy = torch.Generator().manual_seed(99 + rank)
+            nfi, fmi, adj_, _ = zinc
+            real = (nfi >= 0)
+            nff = torch.where(real[..., None], torch.rand(w["B"], w["N"], 5, generator=gy).to(dev), torch.tensor(-1.0, device=dev))
+            fmf = torch.where(adj_ > 0, torch.rand(w["B"], w["N"], w["N"], generator=gy).to(dev), torch.tensor(-1.0, device=dev))[..., None]
+            zinc = [nff, fmf.contiguous(), adj_, torch.randint(0, 10, (w["B"],), generator=gy).to(dev)]
     elif args.with_ffn:
         from egt_amd import EGTLayerStack
         model = EGTLayerStack(model_height=w["Ly"], model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"],
@@ -378,7 +388,10 @@ def main():
             for p in params:
                 p.grad = None
         if zinc is not None:             # whole model: prediction -> MAE -> backward
-            if pattern:
+            if cifar:
+                nf, fm, adj, ycls = zinc
+                sparse_xent_loss(model(nf, fm, adj), ycls).backward()
+            elif pattern:
                 nf, fm, adj, tgt, ycls, cw = zinc
                 logits, nmask = model(nf, adj, return_mask=True)
                 weighted_sparse_xent_loss(logits, ycls, nmask, cw).backward()
@@ -495,13 +508,16 @@ def main():
                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
         cpu = None
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline_model(w, args.cpu_seconds, pattern=args.workload.startswith("pattern")) if args.scope == "model" else cpu_baseline(w, args.cpu_seconds)
+            if args.scope == "model" and cifar:
+                cpu = None      # (no CPU leg for the CIFAR10 model scope: not a bench line of BASELINE.json's metric)
+            else:
+                cpu = cpu_baseline_model(w, args.cpu_seconds, pattern=args.workload.startswith("pattern")) if args.scope == "model" else cpu_baseline(w, args.cpu_seconds)
         graphs = graphs_step * args.steps
         path = "fused-stack" if state["flat_ok"] else ("fused" if any(k.startswith("k_block") for k in prof) else "composed")
         if args.with_ffn:
             path += "+ffn"
         if args.scope == "model":
-            path = ("pattern" if pattern else "zinc") + "-model (HIP edge embedding + fused blocks + fused FFNs, torch node-side head)"
+            path = ("pattern" if pattern else "cifar10" if cifar else "zinc") + "-model (HIP edge embedding + fused blocks + fused FFNs, torch node-side head)"
         line = {
             "metric": "graphs/sec EGT fwd+bwd, ZINC-500K padded N=64",
             "value": graphs / elapsed, "unit": "graphs/s", "n_gpus": world,
@@ -511,6 +527,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": (f"{args.workload}: " + {"model": ("WHOLE PATTERN MODEL (node embedding, 16-hop adjacency embedding, Ly x [attention block + node/edge FFN], "
                                                                        "final norm, per-node MLP head, class-weighted x-ent) fwd+bwd" if args.workload.startswith("pattern") else
+                                                                       "WHOLE CIFAR10 MODEL (Masking+Dense node / edge embeddings, 16-hop adjacency embedding, Ly x [attention block + "
+                                                                       "node/edge FFN], final norm, masked mean pool, MLP head, sparse x-ent) fwd+bwd" if args.workload.startswith("cifar") else
                                                                        "WHOLE ZINC MODEL (embeddings, 16-hop stacking, Ly x [attention block + node/edge FFN], "
                                                                        "final norm, masked mean pool, MLP head, MAE) fwd+bwd"),
                                                              "layers": "Ly x [attention block + node/edge FFN] fwd+bwd"}.get(

@@ -10,11 +10,11 @@ Public surface (mirrors the reference's operator interface for this path):
 from .layers import EGT, EGTBlock, EGTStack, EGTLayerStack, custom_layers, KerasDense, KerasLayerNorm  # noqa: F401
 from .functional import AttnConfig, egt_attention, edge_proj, edge_update, mask_sample  # noqa: F401
 from .ffn import FFN, ffn  # noqa: F401
-from .model import (ZincDCTransformer, PatternDCTransformer, edge_embed, mae_loss, weighted_sparse_xent_loss,  # noqa: F401
+from .model import (ZincDCTransformer, PatternDCTransformer, Cifar10DCTransformer, sparse_xent_loss, edge_embed, mae_loss, weighted_sparse_xent_loss,  # noqa: F401
                     class_weights_from_sizes)
 from .masks import node_mask_from_features, node_mask_from_masking, constrained_edge_mask  # noqa: F401
 
 __all__ = ["EGT", "EGTBlock", "EGTStack", "EGTLayerStack", "custom_layers", "AttnConfig", "egt_attention",
            "edge_proj", "edge_update", "mask_sample", "FFN", "ffn", "node_mask_from_features",
-           "node_mask_from_masking", "constrained_edge_mask", "ZincDCTransformer", "PatternDCTransformer", "edge_embed", "mae_loss",
+           "node_mask_from_masking", "constrained_edge_mask", "ZincDCTransformer", "PatternDCTransformer", "Cifar10DCTransformer", "sparse_xent_loss", "edge_embed", "mae_loss",
            "weighted_sparse_xent_loss", "class_weights_from_sizes"]

@@ -81,7 +81,7 @@ class BlockParams(C.Structure):
 class EmbedDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("De", C.c_int32), ("upto_hop", C.c_int32),
                 ("clip_hops", C.c_int32), ("num_edge_features", C.c_int32), ("dtype", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("num_float_features", C.c_int32), ("mask_value", C.c_float), ("reserved", C.c_int32)]
 
 
 class EGTLibraryError(RuntimeError):
@@ -117,7 +117,7 @@ _PROTOS = {
     "egt_edge_embed_supported": (C.c_int, [C.POINTER(EmbedDesc)]),
     "egt_edge_embed_hops_bytes": (C.c_size_t, [C.POINTER(EmbedDesc)]),
     "egt_edge_embed_workspace_bytes": (C.c_size_t, [C.POINTER(EmbedDesc)]),
-    "egt_edge_embed_fwd": (C.c_int, [C.POINTER(EmbedDesc)] + [_VP] * 8),
+    "egt_edge_embed_fwd": (C.c_int, [C.POINTER(EmbedDesc)] + [_VP] * 9),
     "egt_edge_embed_bwd": (C.c_int, [C.POINTER(EmbedDesc)] + [_VP] * 8),
     "egt_prof_enable": (C.c_int, [C.c_int]),
     "egt_prof_filter": (C.c_int, [C.c_char_p]),

@@ -50,6 +50,18 @@ __global__ void __launch_bounds__(256) k_hop_first(const float* __restrict__ adj
   if (i < pairs) hops[i] = adj[i];   // plane 0
 }
 
+// real-valued edge features (lib/models/cifar10/dc.py:70-73: keras Masking(mask_value) + Dense(edge_emb)): Masking zeroes
+// a pair whose features ALL equal mask_value; the Dense then is F more "planes" behind the hop planes with the rows of its
+// kernel appended to adj_emb's -- plane[K + f][pair] = masked ? 0 : x[pair, f]
+__global__ void __launch_bounds__(256) k_feature_planes(const float* __restrict__ x, float* __restrict__ planes, long pairs, int F,
+                                                       float mask_value) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= pairs) return;
+  bool keep = false;
+  for (int f = 0; f < F; ++f) keep |= x[i * F + f] != mask_value;
+  for (int f = 0; f < F; ++f) planes[(size_t)f * pairs + i] = keep ? x[i * F + f] : 0.f;
+}
+
 // e0[pair, c] = fm_table[fmat[pair] + 1, c] + bias[c] + sum_k hops[pair, k] * W[k, c]
 // thread = (pair, 4 channels); W / bias / table staged in LDS
 template <int KMAX>
@@ -170,6 +182,7 @@ static int embed_check(const egt_embed_desc* d) {
   if (d->B <= 0 || d->N <= 0) EGT_FAIL(EGT_E_SHAPE, "B and N must be positive");
   if (d->De < 4 || d->De > 64 || d->De % 4) EGT_FAIL(EGT_E_SHAPE, "edge embedding covers edge_width in 4..64, multiple of 4 (got %d)", d->De);
   if (d->upto_hop < 1 || d->upto_hop > 16) EGT_FAIL(EGT_E_SHAPE, "upto_hop must be in 1..16 (got %d)", d->upto_hop);
+  if (d->num_float_features < 0 || d->num_float_features > 4) EGT_FAIL(EGT_E_SHAPE, "num_float_features must be in 0..4 (got %d)", d->num_float_features);
   if (d->num_edge_features < 0 || d->num_edge_features > 7) EGT_FAIL(EGT_E_SHAPE, "num_edge_features must be in 0..7 (got %d)", d->num_edge_features);
   if (d->dtype != EGT_F32) EGT_FAIL(EGT_E_DTYPE, "edge embedding is fp32");
   return EGT_OK;
@@ -177,11 +190,12 @@ static int embed_check(const egt_embed_desc* d) {
 extern "C" int egt_edge_embed_supported(const egt_embed_desc* d) {
   if (!d) return 0;
   return d->B > 0 && d->N > 0 && d->De >= 4 && d->De <= 64 && d->De % 4 == 0 && d->upto_hop >= 1 && d->upto_hop <= 16 &&
+         d->num_float_features >= 0 && d->num_float_features <= 4 &&
          d->num_edge_features >= 0 && d->num_edge_features <= 7 && d->dtype == EGT_F32;
 }
 extern "C" size_t egt_edge_embed_hops_bytes(const egt_embed_desc* d) {
   if (!egt_edge_embed_supported(d)) return 0;
-  return (size_t)d->B * d->N * d->N * d->upto_hop * sizeof(float);
+  return (size_t)d->B * d->N * d->N * (d->upto_hop + d->num_float_features) * sizeof(float);
 }
 static int embed_nparts(const egt_embed_desc* d) {
   const long pairs = (long)d->B * d->N * d->N;
@@ -189,24 +203,28 @@ static int embed_nparts(const egt_embed_desc* d) {
 }
 extern "C" size_t egt_edge_embed_workspace_bytes(const egt_embed_desc* d) {
   if (!egt_edge_embed_supported(d)) return 0;
-  return (size_t)embed_nparts(d) * (d->upto_hop + d->num_edge_features + 1) * d->De * sizeof(float);
+  return (size_t)embed_nparts(d) * (d->upto_hop + d->num_float_features + d->num_edge_features + 1) * d->De * sizeof(float);
 }
 
 extern "C" int egt_edge_embed_fwd(const egt_embed_desc* d, const int32_t* feature_matrix, const void* graph_matrix,
-                                  const void* fm_table, const void* adj_kernel, const void* adj_bias, void* hops,
-                                  void* e_out, void* stream) {
+                                  const void* float_features, const void* fm_table, const void* adj_kernel,
+                                  const void* adj_bias, void* hops, void* e_out, void* stream) {
   int rc = embed_check(d);
   if (rc) return rc;
   if (!feature_matrix || !graph_matrix || !fm_table || !adj_kernel || !adj_bias || !hops || !e_out)
     EGT_FAIL(EGT_E_NULL, "feature_matrix/graph_matrix/fm_table/adj_kernel/adj_bias/hops/e_out is NULL");
   hipStream_t st = (hipStream_t)stream;
   const long pairs = (long)d->B * d->N * d->N;
-  const int K = d->upto_hop, V = d->num_edge_features + 1, T = (d->N + 15) / 16;
+  if (d->num_float_features > 0 && !float_features) EGT_FAIL(EGT_E_NULL, "num_float_features set but float_features is NULL");
+  const int KH = d->upto_hop, K = KH + d->num_float_features, V = d->num_edge_features + 1, T = (d->N + 15) / 16;
   EGT_LAUNCH("k_hop_first", k_hop_first, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, (const float*)graph_matrix,
              (float*)hops, pairs, K);
-  for (int k = 1; k < K; ++k)
+  for (int k = 1; k < KH; ++k)
     EGT_LAUNCH("k_hop_step", k_hop_step, dim3((unsigned)(d->B * T * T)), dim3(64), 0, st, (const float*)graph_matrix,
                (float*)hops, d->B, d->N, K, k, d->clip_hops ? 1 : 0);
+  if (d->num_float_features > 0)
+    EGT_LAUNCH("k_feature_planes", k_feature_planes, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st,
+               (const float*)float_features, (float*)hops + (size_t)KH * pairs, pairs, d->num_float_features, d->mask_value);
   const long threads = pairs * (d->De / 4);
   const size_t lds = (size_t)(K + V) * d->De * sizeof(float);
   EGT_LAUNCH("k_edge_embed_fwd", k_edge_embed_fwd<16>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, st,
@@ -248,14 +266,15 @@ extern "C" int egt_edge_embed_bwd(const egt_embed_desc* d, const int32_t* featur
   const float* h = (const float*)hops;
   const float* de = (const float*)d_e;
   float* part = (float*)workspace;
-  switch (d->upto_hop) {
+  const int KT = d->upto_hop + d->num_float_features;   // hop planes + real-valued feature planes
+  switch (KT) {
 #define C(K_) case K_: launch_embed_bwd<K_>(d, feature_matrix, h, de, part, st); break;
-    C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16)
+    C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17) C(18) C(19) C(20)
 #undef C
   }
-  const int R = (d->upto_hop + d->num_edge_features + 1) * d->De;
+  const int R = (KT + d->num_edge_features + 1) * d->De;
   EGT_LAUNCH("k_edge_embed_bwd_reduce", k_edge_embed_bwd_reduce, dim3((R + 63) / 64), dim3(256), 0, st, (const float*)part,
-             embed_nparts(d), d->upto_hop, d->num_edge_features + 1, d->De, (float*)d_adj_kernel, (float*)d_fm_table,
+             embed_nparts(d), KT, d->num_edge_features + 1, d->De, (float*)d_adj_kernel, (float*)d_fm_table,
              (float*)d_adj_bias);
   EGT_LAUNCH("k_edge_embed_bwd_reduce", k_edge_embed_bias_grad, dim3(1), dim3(64), 0, st, (const float*)d_fm_table,
              d->num_edge_features + 1, d->De, (float*)d_adj_bias);

@@ -29,28 +29,32 @@ from .layers import EGTLayerStack, KerasDense, KerasLayerNorm, LN_EPS
 from .masks import node_mask_from_features
 
 
-def _embed_desc(B, N, De, upto_hop, clip_hops, num_edge_features) -> L.EmbedDesc:
+def _embed_desc(B, N, De, upto_hop, clip_hops, num_edge_features, num_float_features=0, mask_value=-1.0) -> L.EmbedDesc:
     return L.EmbedDesc(B=B, N=N, De=De, upto_hop=upto_hop, clip_hops=1 if clip_hops else 0,
-                       num_edge_features=num_edge_features, dtype=L.EGT_F32, reserved=0)
+                       num_edge_features=num_edge_features, dtype=L.EGT_F32, num_float_features=num_float_features,
+                       mask_value=float(mask_value), reserved=0)
 
 
 class _EdgeEmbed(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, fmat, adj, table, kernel, bias, clip_hops):
+    def forward(ctx, fmat, adj, table, kernel, bias, clip_hops, ffeat=None, mask_value=-1.0):
+        """kernel: [upto_hop + F, De] (adj_emb rows, then the rows of the real-valued features' Dense); ffeat [B,N,N,F]"""
         _need_gpu(fmat, adj, table)
         lib = L.load()
         fmat = fmat.to(torch.int32).contiguous()
         adj = _f32c(adj.to(torch.float32))
         table, kernel, bias = _f32c(table), _f32c(kernel), _f32c(bias)
+        ffeat = None if ffeat is None else _f32c(ffeat.to(torch.float32))
         B, N, _ = adj.shape
-        K, De = kernel.shape
-        desc = _embed_desc(B, N, De, K, clip_hops, table.shape[0] - 1)
+        F_ = 0 if ffeat is None else ffeat.shape[-1]
+        K, De = kernel.shape[0] - F_, kernel.shape[1]
+        desc = _embed_desc(B, N, De, K, clip_hops, table.shape[0] - 1, F_, mask_value)
         if not lib.egt_edge_embed_supported(C.byref(desc)):
             raise ValueError(f"edge embedding kernel does not cover upto_hop={K}, edge_width={De}, "
                              f"num_edge_features={table.shape[0] - 1}")
-        hops = torch.empty(K, B, N, N, dtype=torch.float32, device=adj.device)   # hop-major (unit-stride planes)
+        hops = torch.empty(K + F_, B, N, N, dtype=torch.float32, device=adj.device)   # plane-major (unit-stride planes)
         e = torch.empty(B, N, N, De, dtype=torch.float32, device=adj.device)
-        L.check(lib.egt_edge_embed_fwd(C.byref(desc), L.ptr(fmat), L.ptr(adj), L.ptr(table), L.ptr(kernel),
+        L.check(lib.egt_edge_embed_fwd(C.byref(desc), L.ptr(fmat), L.ptr(adj), L.ptr(ffeat), L.ptr(table), L.ptr(kernel),
                                        L.ptr(bias), L.ptr(hops), L.ptr(e), L.current_stream()))
         ctx.desc = desc
         ctx.save_for_backward(fmat, hops, table, kernel, bias)
@@ -67,12 +71,20 @@ class _EdgeEmbed(torch.autograd.Function):
         ws = torch.empty(lib.egt_edge_embed_workspace_bytes(C.byref(desc)), dtype=torch.uint8, device=de.device)
         L.check(lib.egt_edge_embed_bwd(C.byref(desc), L.ptr(fmat), L.ptr(hops), L.ptr(de), L.ptr(dt), L.ptr(dk),
                                        L.ptr(db), L.ptr(ws), L.current_stream()))
-        return None, None, dt, dk, db, None
+        return None, None, dt, dk, db, None, None, None
 
 
-def edge_embed(feature_matrix, graph_matrix, fm_table, adj_kernel, adj_bias, clip_hops=True, return_hops=False):
-    """e0 = fm_table[feature_matrix + 1] + stack_hops(graph_matrix) @ adj_kernel + adj_bias  ->  [B,N,N,De]."""
-    e, hops = _EdgeEmbed.apply(feature_matrix, graph_matrix, fm_table, adj_kernel, adj_bias, clip_hops)
+def edge_embed(feature_matrix, graph_matrix, fm_table, adj_kernel, adj_bias, clip_hops=True, return_hops=False,
+               float_features=None, float_kernel=None, float_bias=None, mask_value=-1.0):
+    """e0 = fm_table[feature_matrix + 1] + stack_hops(graph_matrix) @ adj_kernel + adj_bias
+          [+ Dense(Masking(float_features))]  ->  [B,N,N,De].
+    float_features [B,N,N,F] (F <= 4) with its Dense kernel [F,De] / bias: the real-valued edge features of the
+    CIFAR10 / MNIST models (lib/models/cifar10/dc.py:70-73); they ride as F more planes behind the hop planes."""
+    kernel, bias = adj_kernel, adj_bias
+    if float_features is not None:
+        kernel = torch.cat([adj_kernel, float_kernel], dim=0)        # autograd splits the gradient rows back
+        bias = adj_bias + float_bias
+    e, hops = _EdgeEmbed.apply(feature_matrix, graph_matrix, fm_table, kernel, bias, clip_hops, float_features, mask_value)
     return (e, hops) if return_hops else e
 
 
@@ -123,8 +135,11 @@ class ZincDCTransformer(nn.Module):
 
     def keras_named_parameters(self):
         dead = {id(p) for p in self._dead_edge_params()}
-        out = {"node_emb/embeddings": self.node_emb, "fm_emb/embeddings": self.fm_emb,
-               "adj_emb/kernel": self.adj_emb.kernel, "adj_emb/bias": self.adj_emb.bias}
+        out = {"adj_emb/kernel": self.adj_emb.kernel, "adj_emb/bias": self.adj_emb.bias}
+        if isinstance(self.node_emb, nn.Parameter):
+            out["node_emb/embeddings"] = self.node_emb
+        if isinstance(self.fm_emb, nn.Parameter):
+            out["fm_emb/embeddings"] = self.fm_emb
         out.update({k: v for k, v in self.layers.keras_named_parameters().items() if id(v) not in dead})
         if self.node_norm_final is not None:
             out["node_norm_final/gamma"] = self.node_norm_final.gamma
@@ -188,6 +203,46 @@ class PatternDCTransformer(ZincDCTransformer):
             x = F.elu(x) if self.cfg["activation"] == 'elu' else torch.relu(x)
         y = self.target(x)                                                                # logits [B,N,C]
         return (y, mask) if return_mask else y
+
+
+class Cifar10DCTransformer(ZincDCTransformer):
+    """lib.models.cifar10.dc.DCSVDTransformer for scheme cifar10.svd (use_svd false; the MNIST model has the same
+    structure): real-valued node features [B,N,5] and edge features [B,N,N,1], each through keras Masking(mask_value)
+    + Dense (cifar10/dc.py:66-73); the adjacency hop embedding is added to the edge embedding; graph-level readout
+    (masked mean pool -> mlp_out -> Dense(num_target_labels)).  edge_width 8 / model_height 4 in the shipped config."""
+
+    def __init__(self, num_node_features=5, num_edge_features=1, num_target_labels=10, mask_value=-1., edge_width=8,
+                 model_height=4, **kw):
+        kw.pop("num_targets", None)
+        super().__init__(num_node_features=1, num_edge_features=0, num_targets=num_target_labels,
+                         edge_width=edge_width, model_height=model_height, **kw)
+        del self.node_emb, self.fm_emb
+        self.register_buffer("fm_emb", torch.zeros(1, edge_width), persistent=False)   # no integer feature matrix here
+        self.mask_value = float(mask_value)
+        self.node_emb = KerasDense(num_node_features, self.cfg["model_width"])
+        self.edge_emb = KerasDense(num_edge_features, edge_width)
+
+    def keras_named_parameters(self):
+        out = super().keras_named_parameters()
+        out.pop("fm_emb/embeddings", None); out.pop("node_emb/embeddings", None)
+        out.update({"node_emb/kernel": self.node_emb.kernel, "node_emb/bias": self.node_emb.bias,
+                    "edge_emb/kernel": self.edge_emb.kernel, "edge_emb/bias": self.edge_emb.bias})
+        return out
+
+    def embeddings(self, node_features, feature_matrix, graph_matrix):
+        from .masks import node_mask_from_masking
+        mask = node_mask_from_masking(node_features, self.mask_value)                   # keras Masking, cifar10/dc.py:68
+        h = self.node_emb(node_features * mask[..., None].to(node_features.dtype))      # Masking zeroes the padded rows
+        fmat = torch.full(graph_matrix.shape, -1, dtype=torch.int32, device=graph_matrix.device)
+        e = edge_embed(fmat, graph_matrix, self.fm_emb, self.adj_emb.kernel, self.adj_emb.bias,
+                       clip_hops=self.cfg["clip_hops"], float_features=feature_matrix, float_kernel=self.edge_emb.kernel,
+                       float_bias=self.edge_emb.bias, mask_value=self.mask_value)       # :71-73 + graph_model_base.py:97-127
+        return h, e, mask
+
+
+def sparse_xent_loss(logits, y_true):
+    """keras.losses.SparseCategoricalCrossentropy(from_logits=True) (schemes/cifar10/svd.py:37-40): batch mean."""
+    return F.cross_entropy(logits, y_true.long())
 
 
 def class_weights_from_sizes(class_sizes, device=None):

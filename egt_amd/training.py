@@ -106,14 +106,16 @@ def default_config(scheme: str = "zinc.svd") -> Config:
         model_name="dc_svd", cache_dir=lambda c: f"data_cache/{c.dataset_name.upper()}/svd_{c.num_svd_features}",
         num_svd_features=16, sel_svd_features=8, use_svd=True, random_neg=True,
     )
-    if scheme == "pattern.svd":   # SBMPDCSVD (schemes/pattern/svd.py:16-24)
+    if scheme == "cifar10.svd":   # CIFAR10DCSVD (schemes/cifar10/svd.py:13-20): rlr_monitor follows save_best_monitor
+        c.update(dataset_name="cifar10", num_virtual_nodes=0, save_best_monitor="val_xent")
+    elif scheme == "pattern.svd":   # SBMPDCSVD (schemes/pattern/svd.py:16-24)
         c.update(dataset_name="sbm_pattern", class_sizes=[979220, 209900], rlr_monitor="val_xent", save_best_monitor="val_xent")
     else:                         # ZincDCSVD (schemes/zinc/svd.py:13-21)
         c.update(dataset_name="zinc", num_virtual_nodes=0, rlr_monitor="val_mae", save_best_monitor="val_mae")
     return c
 
 
-SCHEMES = ("zinc.svd", "pattern.svd")
+SCHEMES = ("zinc.svd", "pattern.svd", "cifar10.svd")
 
 
 def make_config(user: Optional[dict], scheme: Optional[str] = None) -> Config:
@@ -546,8 +548,73 @@ class SyntheticPattern:
             yield dict(node_features=nf.int().to(self.device), graph_matrix=adj.to(self.device), target=cls.to(self.device))
 
 
+class Cifar10SVDScheme(ZincSVDScheme):
+    """lib.training.schemes.cifar10.svd.SCHEME (CIFAR10DCSVD): graph classification, SparseCategoricalCrossentropy from
+    logits, metrics acc + xent, monitors val_xent."""
+    SCHEME = "cifar10.svd"
+
+    def get_model(self):
+        if self.model_factory is not None:
+            return self.model_factory(self.get_model_config())
+        from .model import Cifar10DCTransformer
+        mc = self.get_model_config()
+        if mc["use_svd"]:
+            raise NotImplementedError("use_svd=True needs the data pipeline's SVD features; the shipped CIFAR10 configs set use_svd=false")
+        return Cifar10DCTransformer(**mc)
+
+    def get_loss(self):
+        from .model import sparse_xent_loss
+        return sparse_xent_loss
+
+    def get_metrics(self):
+        return ["xent", "acc"]     # (the reference lists ['acc', xent]; the loss is the x-ent)
+
+    def batch_loss(self, batch):
+        nf, fm, adj, tgt = self._batch(batch)
+        logits = self.model(nf, fm, adj)
+        loss = self.loss_fn(logits, tgt)
+        n = tgt.numel()
+        return loss, dict(xent=(loss.detach() * n, n), acc=((logits.argmax(-1) == tgt).sum().detach(), n))
+
+
+class SyntheticCifar10:
+    """Batches in the CIFAR10 superpixel-graph input format (lib/data/datasets/cifar10.py): node_features [B,N,5] float
+    (RGB mean + x,y; padding -1), feature_matrix [B,N,N,1] float (edge feature on edges, -1 elsewhere), graph_matrix
+    [B,N,N] 0/1 (8 nearest neighbours, symmetrised), target [B] int class in 0..9 (a function of the mean colour)."""
+
+    def __init__(self, n_graphs=512, batch_size=128, nodes=(85, 150), seed=0, pad_multiple=1, device="cpu"):
+        g = torch.Generator().manual_seed(seed)
+        self.n = torch.randint(nodes[0], nodes[1] + 1, (n_graphs,), generator=g)
+        self.seed, self.batch_size, self.pad_multiple, self.device = seed, batch_size, pad_multiple, device
+
+    def __len__(self):
+        return (len(self.n) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        for b in range(len(self)):
+            ns = self.n[b * self.batch_size:(b + 1) * self.batch_size]
+            g = torch.Generator().manual_seed(self.seed * 100003 + b)
+            B, N = len(ns), int(ns.max())
+            N = (N + self.pad_multiple - 1) // self.pad_multiple * self.pad_multiple
+            real = torch.arange(N)[None, :] < ns[:, None]
+            cls = torch.randint(0, 10, (B,), generator=g)
+            nf = torch.rand(B, N, 5, generator=g)
+            nf[..., 0] = (nf[..., 0] * 0.5 + cls[:, None].float() / 20).clamp(0, 1)       # class-dependent colour channel
+            pos = nf[..., 3:5]
+            d = (pos[:, :, None, :] - pos[:, None, :, :]).pow(2).sum(-1) + (~real)[:, None, :].float() * 10 + torch.eye(N)[None] * 10
+            knn = d.topk(min(8, N - 1), dim=-1, largest=False).indices
+            adj = torch.zeros(B, N, N).scatter_(2, knn, 1.0)
+            adj = ((adj + adj.transpose(1, 2)) > 0).float() * (real[:, :, None] & real[:, None, :]).float()
+            fm = torch.where(adj > 0, torch.exp(-d).clamp(max=1.0), torch.tensor(-1.0))[..., None]
+            nf = torch.where(real[..., None], nf, torch.tensor(-1.0))
+            yield dict(node_features=nf.to(self.device), feature_matrix=fm.to(self.device), graph_matrix=adj.to(self.device),
+                       target=cls.to(self.device))
+
+
 def import_scheme(name: str):
     """lib/training/importer.py:3-11."""
+    if name == "cifar10.svd":
+        return Cifar10SVDScheme
     if name == "zinc.svd":
         return ZincSVDScheme
     if name == "pattern.svd":
@@ -565,7 +632,7 @@ def main(argv=None):
     n_graphs = int(argv[argv.index("--synthetic") + 1]) if "--synthetic" in argv else 2048
     scheme = import_scheme(config["scheme"])(config, device=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
     bs = scheme.config.batch_size
-    data = SyntheticPattern if config["scheme"] == "pattern.svd" else SyntheticZinc
+    data = {"pattern.svd": SyntheticPattern, "cifar10.svd": SyntheticCifar10}.get(config["scheme"], SyntheticZinc)
     scheme.execute_training(data(n_graphs, bs, seed=1), data(max(bs, n_graphs // 8), bs, seed=2))
 
 

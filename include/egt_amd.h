@@ -369,22 +369,26 @@ int egt_constrained_edge_mask(const float* adj, int32_t B, int32_t N, int32_t H,
  *      + Dense(upto_hop -> De)(stack_hops(graph_matrix))                        lib/models/graph_model_base.py:97-127
  * feature_matrix [B,N,N] int32 (-1 = no edge / padding), graph_matrix [B,N,N] fp32, fm_table [V,De]
  * (V = num_edge_features + 1), adj_kernel [upto_hop, De] (Keras layout), adj_bias [De].  `hops`
- * ([upto_hop,B,N,N] fp32 -- hop-major --, egt_edge_embed_hops_bytes) receives the hop matrices; the backward
+ * ([upto_hop + num_float_features,B,N,N] fp32 -- plane-major --, egt_edge_embed_hops_bytes) receives the hop matrices; the backward
  * reads them again.  Gradients: d_fm_table, d_adj_kernel, d_adj_bias (no gradient flows to the inputs). */
 typedef struct egt_embed_desc {
   int32_t B, N, De;
-  int32_t upto_hop;          /* 1..16 */
-  int32_t clip_hops;         /* clip every hop product to [0,1] (graph_model_base.py:114-115) */
-  int32_t num_edge_features; /* embedding rows - 1 */
-  int32_t dtype;             /* EGT_F32 */
+  int32_t upto_hop;           /* 1..16 */
+  int32_t clip_hops;          /* clip every hop product to [0,1] (graph_model_base.py:114-115) */
+  int32_t num_edge_features;  /* embedding rows - 1 (0: no integer feature matrix; pass a zero one-row table) */
+  int32_t dtype;              /* EGT_F32 */
+  int32_t num_float_features; /* 0..4 real-valued edge features per pair: keras Masking(mask_value) + Dense
+                                 (lib/models/cifar10/dc.py:70-73); the rows of that Dense kernel are appended to
+                                 adj_kernel ([upto_hop + num_float_features, De]) and its bias added to adj_bias */
+  float mask_value;           /* Masking: a pair whose features all equal mask_value contributes 0 */
   int32_t reserved;
 } egt_embed_desc;
 int egt_edge_embed_supported(const egt_embed_desc* desc);
 size_t egt_edge_embed_hops_bytes(const egt_embed_desc* desc);
 size_t egt_edge_embed_workspace_bytes(const egt_embed_desc* desc);
 int egt_edge_embed_fwd(const egt_embed_desc* desc, const int32_t* feature_matrix, const void* graph_matrix,
-                       const void* fm_table, const void* adj_kernel, const void* adj_bias, void* hops,
-                       void* e_out, void* stream);
+                       const void* float_features /* [B,N,N,num_float_features] or NULL */, const void* fm_table,
+                       const void* adj_kernel, const void* adj_bias, void* hops, void* e_out, void* stream);
 int egt_edge_embed_bwd(const egt_embed_desc* desc, const int32_t* feature_matrix, const void* hops,
                        const void* d_e, void* d_fm_table, void* d_adj_kernel, void* d_adj_bias,
                        void* workspace, void* stream);

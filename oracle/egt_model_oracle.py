@@ -92,6 +92,9 @@ def init_zinc_params(cfg, *, dtype=torch.float32, generator=None, randomize=True
         "node_norm_final.gamma": vec(Dh, 1.0), "node_norm_final.beta": vec(Dh, 0.0),
         "edge_norm_final.gamma": vec(De, 1.0), "edge_norm_final.beta": vec(De, 0.0),
     }
+    if cfg.get("float_node_features"):   # CIFAR10 / MNIST: Dense embeddings of real-valued features (cifar10/dc.py:66-73)
+        p["node_emb.kernel"] = glorot(cfg["float_node_features"], Dh); p["node_emb.bias"] = vec(Dh, 0.0)
+        p["edge_emb.kernel"] = glorot(cfg.get("float_edge_features", 1), De); p["edge_emb.bias"] = vec(De, 0.0)
     if randomize:   # embeddings of O(1) so the layer norms see real signal
         p["node_emb.embeddings"] = p["node_emb.embeddings"] * 20
         p["fm_emb.embeddings"] = p["fm_emb.embeddings"] * 20
@@ -159,6 +162,47 @@ def pattern_forward(node_features, graph_matrix, p, cfg, rand_masks=None):
         h = O.layer_norm(h, p["node_norm_final.gamma"], p["node_norm_final.beta"])
     x = mlp_out(h, p, len(cfg.get("mlp_layers", [0.5, 0.25])), act)                         # :55 (per node)
     return O.dense(x, p["target.kernel"], p["target.bias"]), mask                           # :56-58
+
+
+def keras_masking(x, mask_value=-1.0):
+    """keras.layers.Masking: a step whose features ALL equal mask_value is zeroed and masked out
+    (outputs = inputs * any(inputs != mask_value, axis=-1)); returns (masked inputs, boolean mask)."""
+    keep = (x != mask_value).any(dim=-1)
+    return x * keep[..., None].to(x.dtype), keep
+
+
+def cifar10_forward(node_features, feature_matrix, graph_matrix, p, cfg, rand_masks=None):
+    """lib/models/cifar10/dc.py:14-122 (DCSVDTransformer, use_svd false; scheme cifar10.svd): real-valued node features
+    [B,N,5] and edge features [B,N,N,1] through Masking(-1) + Dense (:66-73), the adjacency hop embedding added to the
+    edge embedding, the layer loop, final norm, masked GlobalAveragePooling1D, mlp_out, Dense(num_target_labels) -> logits."""
+    H, Ly = cfg.get("num_heads", 8), cfg["model_height"]
+    act = cfg.get("activation", "elu")
+    dt = p["node_emb.kernel"].dtype
+    mv = cfg.get("mask_value", -1.0)
+    xn, mask = keras_masking(node_features.to(dt), mv)
+    h = O.dense(xn, p["node_emb.kernel"], p["node_emb.bias"])                                # :68-70
+    xe, _ = keras_masking(feature_matrix.to(dt), mv)
+    e = O.dense(xe, p["edge_emb.kernel"], p["edge_emb.bias"])                                # :71-73
+    hops = stack_hops(graph_matrix.to(dt), cfg["upto_hop"], cfg.get("clip_hops", True))
+    e = e + O.dense(hops, p["adj_emb.kernel"], p["adj_emb.bias"])                            # edge_emb_add
+    for ii in range(Ly):
+        bp = {k[len(f"layer{ii}."):]: v for k, v in p.items() if k.startswith(f"layer{ii}.") and ".ffn_" not in k}
+        rm = None if rand_masks is None else rand_masks[ii]
+        h, e = O.block_forward(h, e, mask, bp, num_heads=H, rand_mask=rm)
+        fn = {k.split(".", 2)[2]: v for k, v in p.items() if k.startswith(f"layer{ii}.ffn_node.")}
+        fe = {k.split(".", 2)[2]: v for k, v in p.items() if k.startswith(f"layer{ii}.ffn_edge.")}
+        e = O.ffn_forward(e, fe, activation=act)
+        h = O.ffn_forward(h, fn, activation=act)
+    if cfg.get("do_final_norm", True):
+        h = O.layer_norm(h, p["node_norm_final.gamma"], p["node_norm_final.beta"])
+    x = masked_global_avg_pool_1d(h, mask)                                                   # :107
+    x = mlp_out(x, p, len(cfg.get("mlp_layers", [0.5, 0.25])), act)
+    return O.dense(x, p["target.kernel"], p["target.bias"])                                  # :118-120
+
+
+def sparse_xent_loss(logits, y_true):
+    """keras.losses.SparseCategoricalCrossentropy(from_logits=True) (schemes/cifar10/svd.py:37-40): batch mean."""
+    return -torch.log_softmax(logits, dim=-1).gather(-1, y_true.long()[..., None])[..., 0].mean()
 
 
 def zinc_embeddings(node_features, feature_matrix, graph_matrix, p, cfg):

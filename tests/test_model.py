@@ -55,7 +55,11 @@ def _load_params(model, params, dev):
     named = model.keras_named_parameters()
     Ly = len(model.layers.blocks)
     with torch.no_grad():
-        model.node_emb.copy_(params["node_emb.embeddings"])
+        if isinstance(model.node_emb, torch.nn.Parameter):
+            model.node_emb.copy_(params["node_emb.embeddings"])
+        else:
+            model.node_emb.kernel.copy_(params["node_emb.kernel"]); model.node_emb.bias.copy_(params["node_emb.bias"])
+            model.edge_emb.kernel.copy_(params["edge_emb.kernel"]); model.edge_emb.bias.copy_(params["edge_emb.bias"])
         if isinstance(model.fm_emb, torch.nn.Parameter):
             model.fm_emb.copy_(params["fm_emb.embeddings"])
         model.adj_emb.kernel.copy_(params["adj_emb.kernel"]); model.adj_emb.bias.copy_(params["adj_emb.bias"])
@@ -79,7 +83,7 @@ def _load_params(model, params, dev):
 def _grad_of(model, key):
     """oracle parameter name -> the module parameter"""
     if key == "node_emb.embeddings":
-        return model.node_emb
+        return model.node_emb if isinstance(model.node_emb, torch.nn.Parameter) else None
     if key == "fm_emb.embeddings":
         return model.fm_emb
     parts = key.split(".")
@@ -240,3 +244,76 @@ def test_pattern_model_vs_oracle(gpu, egt_lib):
         assert_close(prm.grad, gref, name=k, **BWD); checked += 1
     assert checked > 40
     assert "fm_emb/embeddings" not in model.keras_named_parameters() and not isinstance(model.fm_emb, torch.nn.Parameter)
+
+
+# ------------------------------------------------------------------------------ CIFAR10 (config 3) -----
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,De,K,F", [(2, 19, 8, 16, 1), (3, 30, 16, 4, 3), (1, 64, 64, 16, 4)])
+def test_edge_embed_float_features_vs_oracle(B, N, De, K, F, gpu, egt_lib):
+    """real-valued edge features: Masking(-1) + Dense ride as F planes behind the hop planes (cifar10/dc.py:70-73)"""
+    from egt_amd import edge_embed
+    from oracle import egt_model_oracle as MO, egt_oracle as O
+    g = torch.Generator().manual_seed(B * 7 + N)
+    adj = (torch.rand(B, N, N, generator=g) > 0.7).float(); adj = ((adj + adj.transpose(1, 2)) > 0).float()
+    ff = torch.rand(B, N, N, F, generator=g)
+    ff[adj == 0] = -1.0                                             # non-edges carry the mask value in every feature
+    ff[0, 0, 1] = -1.0; ff[0, 0, 1, F - 1] = 0.5                    # a single differing feature keeps the pair (F > 1) / is the value (F = 1)
+    Wa = torch.randn(K, De, generator=g) * 0.3; ba = torch.randn(De, generator=g) * 0.2
+    We = torch.randn(F, De, generator=g); be = torch.randn(De, generator=g) * 0.2
+    de = torch.randn(B, N, N, De, generator=g)
+    p64 = [x.double().requires_grad_() for x in (Wa, ba, We, be)]
+    xe, _ = MO.keras_masking(ff.double(), -1.0)
+    e_o = O.dense(MO.stack_hops(adj.double(), K), p64[0], p64[1]) + O.dense(xe, p64[2], p64[3])
+    gr = torch.autograd.grad(e_o, p64, de.double())
+    pg = [x.to(gpu).requires_grad_() for x in (Wa, ba, We, be)]
+    fm = torch.full((B, N, N), -1, dtype=torch.int32, device=gpu)
+    e = edge_embed(fm, adj.to(gpu), torch.zeros(1, De, device=gpu), pg[0], pg[1], float_features=ff.to(gpu),
+                   float_kernel=pg[2], float_bias=pg[3])
+    e.backward(de.to(gpu))
+    assert_close(e, e_o, name="e0", **FWD)
+    for n, a, b in zip(("d adj_emb.kernel", "d adj_emb.bias", "d edge_emb.kernel", "d edge_emb.bias"), pg, gr):
+        assert_close(a.grad, b, name=n, **BWD)
+
+
+@pytest.mark.gpu
+def test_cifar10_model_vs_oracle(gpu, egt_lib):
+    """CIFAR10 model (BASELINE config 3's dataset): Masking + Dense embeddings of real-valued node / edge features,
+    edge_width 8, graph-level logits, sparse categorical cross-entropy -- logits, loss, every parameter gradient."""
+    from egt_amd import Cifar10DCTransformer, sparse_xent_loss
+    from oracle import egt_model_oracle as MO
+    cfg = dict(model_width=32, edge_width=8, model_height=2, upto_hop=4, num_node_features=1, num_edge_features=0, num_targets=10,
+               float_node_features=5, float_edge_features=1)
+    g = torch.Generator().manual_seed(21)
+    B, N = 4, 18
+    n = torch.tensor([18, 11, 15, 9]); real = torch.arange(N)[None, :] < n[:, None]
+    nf = torch.rand(B, N, 5, generator=g); nf[~real] = -1.0
+    adj = (torch.rand(B, N, N, generator=g) > 0.6).float()
+    adj = ((adj + adj.transpose(1, 2)) > 0).float() * (real[:, :, None] & real[:, None, :]).float() * (1 - torch.eye(N))[None]
+    fm = torch.rand(B, N, N, 1, generator=g); fm[adj == 0] = -1.0
+    y = torch.randint(0, 10, (B,), generator=g)
+    params = MO.init_zinc_params(cfg, dtype=torch.float32, generator=g)
+    model = Cifar10DCTransformer(model_width=32, model_height=2, upto_hop=4, random_mask_prob=0.0).to(gpu).eval()
+    _load_params(model, params, gpu)
+    p64 = {k: v.double().requires_grad_() for k, v in params.items()}
+    lo = MO.cifar10_forward(nf, fm, adj, p64, cfg)
+    loss_o = MO.sparse_xent_loss(lo, y)
+    names = [k for k in p64 if k not in ("fm_emb.embeddings", "node_emb.embeddings")]
+    gro = torch.autograd.grad(loss_o, [p64[k] for k in names], allow_unused=True)
+    logits = model(nf.to(gpu), fm.to(gpu), adj.to(gpu))
+    loss = sparse_xent_loss(logits, y.to(gpu))
+    loss.backward()
+    assert_close(logits, lo, name="logits", rtol=2e-4, arel=5e-5)
+    assert_close(loss.reshape(1), loss_o.reshape(1), name="xent", rtol=2e-4, arel=5e-5)
+    dead = {id(p) for p in model._dead_edge_params()}
+    checked = 0
+    for k, gref in zip(names, gro):
+        if k.startswith("node_emb.") or k.startswith("edge_emb."):
+            prm = getattr(getattr(model, k.split(".")[0]), k.split(".")[1])
+        else:
+            prm = _grad_of(model, k)
+        if prm is None or id(prm) in dead or gref is None:
+            continue
+        assert_close(prm.grad, gref, name=k, **BWD); checked += 1
+    assert checked > 44
+    names_k = model.keras_named_parameters()
+    assert "node_emb/kernel" in names_k and "edge_emb/kernel" in names_k and "node_emb/embeddings" not in names_k

@@ -149,6 +149,25 @@ def test_pattern_scheme_config_and_synthetic_batches():
     assert (y[nf < 0] == 0).all() and torch.equal(adj, adj.transpose(1, 2))
 
 
+def test_cifar10_scheme_config_and_synthetic_batches():
+    # configs/main/cifar10/100k/egt.json of the reference
+    cfg = {"scheme": "cifar10.svd", "distributed": True, "batch_size": 128, "initial_lr": 0.0005, "num_epochs": 200, "rlr_factor": 0.5,
+           "rlr_patience": 10, "min_lr_factor": 0.01, "model_width": 64, "edge_width": 8, "model_height": 4, "num_heads": 8,
+           "ffn_multiplier": 2.0, "use_svd": False, "random_mask_prob": 0.1, "upto_hop": 16, "model_name": "egt_100k"}
+    c = T.make_config(cfg)
+    assert c.dataset_name == "cifar10" and c.save_best_monitor == "val_xent" and c.rlr_monitor == "val_xent"
+    mc = T.model_config(c)
+    assert mc["edge_width"] == 8 and mc["model_height"] == 4 and mc["readout_edges"] is False and mc["num_virtual_nodes"] == 0
+    assert T.import_scheme("cifar10.svd") is T.Cifar10SVDScheme
+    b = next(iter(T.SyntheticCifar10(20, 8, nodes=(20, 40), seed=1, pad_multiple=16)))
+    nf, fm, adj, y = b["node_features"], b["feature_matrix"], b["graph_matrix"], b["target"]
+    B, N, _ = nf.shape
+    assert nf.shape == (B, N, 5) and fm.shape == (B, N, N, 1) and adj.shape == (B, N, N) and y.shape == (B,)
+    pad = (nf == -1).all(-1)
+    assert pad.any() and (adj[pad] == 0).all() and ((fm[..., 0] == -1) == (adj == 0)).all()
+    assert torch.equal(adj, adj.transpose(1, 2)) and int(y.max()) <= 9
+
+
 def test_synthetic_zinc_batches_have_the_reference_format():
     ds = T.SyntheticZinc(70, 32, nodes=(9, 37), seed=3, pad_multiple=16)
     bs = list(ds)
@@ -198,3 +217,17 @@ def test_pattern_scheme_trains_on_the_gpu(tmp_path, gpu, egt_lib):
     assert 0.0 <= s.history[-1]["val_acc"] <= 1.0 and s.history[-1]["val_xent"] > 0
     w = np.load(tmp_path / "run" / "saved" / "p.npz")
     assert "adj_emb/kernel" in w.files and "fm_emb/embeddings" not in w.files and "fnn_lr1_edge_00/kernel" in w.files
+
+
+@pytest.mark.gpu
+def test_cifar10_scheme_trains_on_the_gpu(tmp_path, gpu, egt_lib):
+    cfg = dict(scheme="cifar10.svd", model_name="c", num_epochs=2, initial_lr=2e-3, batch_size=16, use_svd=False,
+               model_width=32, edge_width=8, model_height=2, upto_hop=4, random_mask_prob=0.1, save_path=str(tmp_path / "run"))
+    logs = []
+    tr = T.SyntheticCifar10(64, 16, nodes=(20, 44), seed=1, pad_multiple=16); va = T.SyntheticCifar10(32, 16, nodes=(20, 44), seed=2, pad_multiple=16)
+    s = T.Cifar10SVDScheme(cfg, device=gpu, print_fn=logs.append)
+    s.execute_training(tr, va)
+    assert s.state.current_epoch == 2 and s.history[-1]["loss"] < s.history[0]["loss"], s.history
+    assert 0.0 <= s.history[-1]["val_acc"] <= 1.0
+    w = np.load(tmp_path / "run" / "saved" / "c.npz")
+    assert "node_emb/kernel" in w.files and "edge_emb/kernel" in w.files and "adj_emb/kernel" in w.files
