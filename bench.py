@@ -502,6 +502,9 @@ def main():
             else:
               roof = dict(bound="hbm", kernel=dom, timed_in_region=dom in dom_prof, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=(ach / HBM_PEAK_GBS) if ach else None, traffic=traffic,
+                        traffic_source=("static: profiles/pmc_traffic.json = HBM bytes per launch from the committed rocprofv3 --pmc "
+                                        "FETCH_SIZE / WRITE_SIZE passes of this command (FETCH doubled per the gfx950 note); not re-measured in this run"
+                                        if traffic is not None else None),
                         avg_launch_us=avg_s * 1e6, launches=cnt, algorithmic_bytes_per_launch=ab,
                         kernels={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3,
                                          share=v[1] / sum(x[1] for x in prof.values()))

@@ -97,6 +97,9 @@ def all_reduce_flat(flat, process_group=None, average=True, local_count=None, gl
         return flat
     if local_count is not None and average:
         flat.mul_(float(local_count) / float(global_count))
+    if average and local_count is None and dist.get_backend(process_group) == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=process_group)   # RCCL averages in the collective: no extra pass over the buffer
+        return flat
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
     if average and local_count is None:
         flat.div_(ws)
