@@ -385,9 +385,22 @@ class ZincSVDScheme:
 
     # ---- data ----
     def load_data(self, trainset: Iterable = None, valset: Iterable = None):
+        """:207-218.  Iterables of batches in the reference's input format are used as they are (SyntheticZinc ...);
+        otherwise the scheme's dataset is opened from ``config.dataset_path`` through egt_amd.data (a PackedStore
+        ``.npz`` or, where h5py exists, the reference's ``.h5``): record maps, excluded features, per-epoch shuffle,
+        padded batches of ``batch_size``; under DP every rank takes its contiguous slice of each global batch."""
         if trainset is None:
-            raise NotImplementedError("the HDF5 reader (SURVEY 8(f)-4) is not built: pass iterables of batches "
-                                      "(see SyntheticZinc for the format)")
+            from .data import dataset_for_scheme
+            c = self.config
+            if not os.path.exists(c.dataset_path):
+                raise FileNotFoundError(f"dataset_path {c.dataset_path!r} does not exist (pass iterables of batches, "
+                                        "or a PackedStore .npz / reference .h5)")
+            self.dataset = dataset_for_scheme(self.SCHEME, c.dataset_path, max_shuffle_len=c.max_shuffle_len,
+                                              num_svd_features=c.num_svd_features, use_svd=c.use_svd)
+            shard = None
+            if c.distributed and torch.distributed.is_available() and torch.distributed.is_initialized():
+                shard = (torch.distributed.get_rank(), torch.distributed.get_world_size())
+            trainset, valset = self.dataset.get_batched_data(c.batch_size, shard=shard)
         self.trainset, self.valset = trainset, valset
 
     # ---- one step / one epoch ----
