@@ -274,6 +274,8 @@ def main():
                     help="kernel timed with hipEvents inside the timed region")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's B graphs per GPU; strong: B graphs split over the ranks")
+    ap.add_argument("--dp-backend", default="torch", choices=["torch", "capi"],
+                    help="gradient all-reduce through torch.distributed (RCCL) or the library's own egt_dp_* entry points (RCCL)")
     args = ap.parse_args()
     if args.scope == "layers":
         args.with_ffn = True
@@ -311,6 +313,12 @@ def main():
     from egt_amd import EGTStack, _lib
     from egt_amd.dp import FlatGradAllReduce, flat_grad_view, all_reduce_flat
     lib = _lib.load()
+    comm = None
+    if use_dist and args.dp_backend == "capi":
+        from egt_amd.dp import CapiComm
+        comm = CapiComm()                # ncclCommInitRank behind the C-ABI; the id travels over the process group once
+        if comm.world != world:
+            raise SystemExit(f"bench.py: egt_dp world {comm.world} != {world}")
 
     w = dict(WORKLOADS[args.workload])
     if args.layers > 0:
@@ -411,7 +419,10 @@ def main():
         if evs is not None:              # hipEvents around the collective (untimed pass only)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if state["flat_ok"]:
+        if comm is not None:
+            comm.all_reduce_flat(model.grad_holder.flat if state["flat_ok"] else fa.flat, True,
+                                 ar_kw.get("local_count"), ar_kw.get("global_count"))
+        elif state["flat_ok"]:
             all_reduce_flat(model.grad_holder.flat, average=True, **ar_kw)
         else:
             fa.all_reduce(average=True, **ar_kw)
@@ -544,13 +555,15 @@ def main():
                        "Dh": w["Dh"], "De": w["De"], "H": w["H"], "d": w["Dh"] // w["H"], "Ly": w["Ly"],
                        "random_mask_prob": w["rand_p"], "nodes": list(w["nodes"]), "path": path,
                        "parallelism": f"dp{world}", "grad_allreduce_bytes": nbytes,
-                       "grad_allreduce_us": ar_us, "backend": "rccl" if use_dist else "none (single process)",
+                       "grad_allreduce_us": ar_us, "backend": ("rccl (egt_dp_* C-ABI)" if comm is not None else "rccl") if use_dist else "none (single process)",
                        "flat_grad_adopted": bool(state["flat_ok"])},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if use_dist:
         dist.barrier()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

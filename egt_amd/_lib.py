@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("EGT_AMD_LIB") or os.path.join(_HERE, "lib", "libegt_a
 
 # --- constants mirrored from include/egt_amd.h ---------------------------------
 EGT_OK = 0
-EGT_E_NULL, EGT_E_SHAPE, EGT_E_DTYPE, EGT_E_FLAGS, EGT_E_HIP, EGT_E_WORKSPACE = -1, -2, -3, -4, -5, -6
+EGT_E_NULL, EGT_E_SHAPE, EGT_E_DTYPE, EGT_E_FLAGS, EGT_E_HIP, EGT_E_WORKSPACE, EGT_E_RCCL = -1, -2, -3, -4, -5, -6, -7
 EGT_F32 = 0
 EGT_BF16 = 1   # fused block/stack: edge tensors bf16 in HBM, everything else fp32
 F_EDGE_INPUT, F_GATE_INPUT, F_ATTN_MASK, F_SCALE_DEGREE = 0x001, 0x002, 0x004, 0x008
@@ -119,6 +119,12 @@ _PROTOS = {
     "egt_edge_embed_workspace_bytes": (C.c_size_t, [C.POINTER(EmbedDesc)]),
     "egt_edge_embed_fwd": (C.c_int, [C.POINTER(EmbedDesc)] + [_VP] * 9),
     "egt_edge_embed_bwd": (C.c_int, [C.POINTER(EmbedDesc)] + [_VP] * 8),
+    "egt_dp_unique_id": (C.c_int, [_VP]),
+    "egt_dp_init": (C.c_int, [_VP, C.c_int32, C.c_int32]),
+    "egt_dp_allreduce": (C.c_int, [_VP, C.c_size_t, C.c_int32, _VP]),
+    "egt_dp_world": (C.c_int, []),
+    "egt_dp_rank": (C.c_int, []),
+    "egt_dp_finalize": (C.c_int, []),
     "egt_prof_enable": (C.c_int, [C.c_int]),
     "egt_prof_filter": (C.c_int, [C.c_char_p]),
     "egt_prof_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -171,7 +177,7 @@ def load():
 
 
 _EXC = {EGT_E_NULL: ValueError, EGT_E_SHAPE: AssertionError, EGT_E_DTYPE: TypeError,
-        EGT_E_FLAGS: ValueError, EGT_E_HIP: RuntimeError, EGT_E_WORKSPACE: RuntimeError}
+        EGT_E_FLAGS: ValueError, EGT_E_HIP: RuntimeError, EGT_E_WORKSPACE: RuntimeError, EGT_E_RCCL: RuntimeError}
 
 
 def check(rc: int):

@@ -16,7 +16,7 @@ REPO = os.path.dirname(ROOT)
 CSRC = os.path.join(ROOT, "csrc")
 LIBDIR = os.path.join(ROOT, "lib")
 LIB = os.path.join(LIBDIR, "libegt_amd.so")
-SOURCES = ["egt_capi.hip", "egt_attn.hip", "egt_attn_mfma.hip", "egt_edge.hip", "egt_block.hip", "egt_node.hip", "egt_ffn.hip", "egt_masks.hip", "egt_embed.hip"]
+SOURCES = ["egt_capi.hip", "egt_attn.hip", "egt_attn_mfma.hip", "egt_edge.hip", "egt_block.hip", "egt_node.hip", "egt_ffn.hip", "egt_masks.hip", "egt_embed.hip", "egt_dp.hip"]
 ARCH = "gfx950"
 # per-source compiler flags.  egt_ffn.hip: the backward keeps 256 weight-gradient accumulator
 # registers per wave; with hipcc's default (AGPR-form MFMA everywhere) the short-lived GEMM
@@ -80,7 +80,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {s}")
         if verbose and out:
             print(out.decode(errors="replace"))
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         sys.stderr.write(r.stdout.decode(errors="replace"))

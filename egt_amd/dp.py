@@ -8,6 +8,11 @@ data-path collective) and the gradients of all parameters live in ONE flat
 contiguous fp32 buffer that is all-reduced once per step over RCCL/xGMI
 (torch.distributed backend "nccl" on ROCm; "gloo" in the CPU tests).  The
 payload is <= ~2.2 MB, i.e. latency-bound — a single collective, no bucketing.
+
+Two transports for that one collective: ``torch.distributed`` (default) and ``CapiComm`` — the library's own
+``egt_dp_init / egt_dp_allreduce / egt_dp_finalize`` (include/egt_amd.h), which put ncclAllReduce
+on the stream the backward ran on with nothing of torch.distributed in the step (it is used once, to hand the
+RCCL unique id from rank 0 to the other ranks).
 """
 from __future__ import annotations
 
@@ -28,7 +33,8 @@ def shard_batch(n_graphs: int, world_size: int, rank: int):
 class FlatGradAllReduce:
     """Owns one flat gradient buffer aliasing every parameter's .grad."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, comm: "CapiComm" = None):
+        self.comm = comm
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -59,6 +65,8 @@ class FlatGradAllReduce:
     def all_reduce(self, average: bool = True, local_count=None, global_count=None, force=False):
         """Sum over ranks, then /world: the loss is a mean over the GLOBAL batch
         (MirroredStrategy semantics).  See all_reduce_flat for uneven shards."""
+        if self.comm is not None:
+            return self.comm.all_reduce_flat(self.flat, average, local_count, global_count)
         return all_reduce_flat(self.flat, self.group, average, local_count, global_count, force)
 
 
@@ -104,3 +112,55 @@ def all_reduce_flat(flat, process_group=None, average=True, local_count=None, gl
     if average and local_count is None:
         flat.div_(ws)
     return flat
+
+
+class CapiComm:
+    """The per-process RCCL communicator behind the C-ABI (egt_dp_*).  Bootstrap: rank 0 draws the unique id,
+    every rank receives it through ``store`` (a torch.distributed Store, default: the default process group's)
+    or through ``broadcast`` (callable: bytes-or-None -> bytes), then joins on its current HIP device."""
+
+    KEY = "egt_dp_unique_id"
+
+    def __init__(self, rank: int = None, world: int = None, store=None, broadcast=None):
+        import ctypes as C
+        from . import _lib
+        self._lib = _lib.load()
+        self._check = _lib.check
+        if rank is None or world is None:
+            rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            self._check(self._lib.egt_dp_unique_id(buf))
+        ident = bytes(buf.raw)
+        if world > 1:
+            if broadcast is not None:
+                ident = broadcast(ident if rank == 0 else None)
+            else:
+                if store is None:
+                    if not dist.is_initialized():
+                        raise RuntimeError("CapiComm: world > 1 needs a store, a broadcast callable or an initialised process group")
+                    box = [ident if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    ident = box[0]
+                elif rank == 0:
+                    store.set(self.KEY, ident)
+                else:
+                    ident = bytes(store.get(self.KEY))
+        self._check(self._lib.egt_dp_init(C.create_string_buffer(ident, 128), world, rank))
+        self.rank, self.world = rank, world
+
+    def all_reduce_flat(self, flat: torch.Tensor, average=True, local_count=None, global_count=None):
+        """same contract as dp.all_reduce_flat, on the current stream"""
+        if (local_count is None) != (global_count is None):
+            raise ValueError("local_count and global_count go together")
+        if flat.dtype != torch.float32 or not flat.is_cuda or not flat.is_contiguous():
+            raise TypeError("egt_dp_allreduce takes a contiguous fp32 device buffer")
+        from ._lib import ptr, current_stream
+        weighted = local_count is not None and average
+        if weighted:
+            flat.mul_(float(local_count) / float(global_count))
+        self._check(self._lib.egt_dp_allreduce(ptr(flat), flat.numel(), int(average and not weighted), current_stream()))
+        return flat
+
+    def close(self):
+        self._check(self._lib.egt_dp_finalize())

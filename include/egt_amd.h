@@ -45,6 +45,7 @@ extern "C" {
 #define EGT_E_FLAGS (-4)     /* inconsistent flags (egt_layers.py:20-24)        */
 #define EGT_E_HIP (-5)       /* a HIP runtime call failed                       */
 #define EGT_E_WORKSPACE (-6) /* workspace too small                             */
+#define EGT_E_RCCL (-7)      /* RCCL missing or a collective call failed        */
 
 /* dtype */
 #define EGT_F32 0
@@ -392,6 +393,25 @@ int egt_edge_embed_fwd(const egt_embed_desc* desc, const int32_t* feature_matrix
 int egt_edge_embed_bwd(const egt_embed_desc* desc, const int32_t* feature_matrix, const void* hops,
                        const void* d_e, void* d_fm_table, void* d_adj_kernel, void* d_adj_bias,
                        void* workspace, void* stream);
+
+/* ---- batch data parallelism: the gradient all-reduce on RCCL -------------------
+ * Replaces what tf.distribute.MirroredStrategy does for the reference
+ * (lib/training/training_base.py:230-247): one synchronous all-reduce of every
+ * parameter gradient per step.  One process per GPU and ONE communicator per process
+ * (the library's only global state).  Bootstrap: rank 0 calls egt_dp_unique_id and
+ * hands the 128 bytes to every rank out of band (the launcher's TCP store); every
+ * rank then calls egt_dp_init with its HIP device current.  egt_dp_allreduce reduces
+ * `count` fp32 values in place on `stream` (the stream the backward ran on; no host
+ * synchronisation) -- SUM, or the mean over ranks when average != 0.  RCCL is resolved
+ * at run time (the copy already mapped into the process, else librccl.so.1); its
+ * absence is EGT_E_RCCL, not a load failure of this library. */
+#define EGT_DP_ID_BYTES 128
+int egt_dp_unique_id(void* id_out /* host, EGT_DP_ID_BYTES */);
+int egt_dp_init(const void* id /* host, EGT_DP_ID_BYTES */, int32_t world, int32_t rank);
+int egt_dp_allreduce(void* buf, size_t count, int32_t average, void* stream);
+int egt_dp_world(void); /* 0 before init */
+int egt_dp_rank(void);  /* -1 before init */
+int egt_dp_finalize(void);
 
 /* ---- per-kernel timing (measurement only) ------------------------------------
  * egt_prof_enable(1) makes every launch site bracket its kernel with hipEvents

@@ -41,6 +41,53 @@ def test_bench_one_rank_under_launcher_uses_rccl():
     assert line["value"] > 0 and line["scaling"] == "weak"
 
 
+def test_bench_one_rank_through_the_capi_communicator():
+    """--dp-backend capi: the step's collective is egt_dp_allreduce (ncclAllReduce on the compute stream)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", "29633", os.path.join(REPO, "bench.py"),
+           "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--layers", "2", "--dp-backend", "capi"]
+    r = subprocess.run(cmd, cwd=REPO, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 1 and line["config"]["backend"] == "rccl (egt_dp_* C-ABI)"
+    assert line["config"]["grad_allreduce_us"] is not None and line["config"]["grad_allreduce_us"] > 0
+    assert line["value"] > 0
+
+
+def test_capi_communicator_one_rank_allreduce():
+    """egt_dp_unique_id / init / allreduce / finalize on a 1-rank RCCL communicator: SUM and AVG leave the buffer
+    unchanged, the weighted form scales by local/global, a second init is refused, finalize allows a new one."""
+    code = r"""
+import torch, ctypes as C
+from egt_amd import _lib as L
+from egt_amd.dp import CapiComm, FlatGradAllReduce
+torch.cuda.set_device(0)
+c = CapiComm(rank=0, world=1)
+lib = L.load()
+assert lib.egt_dp_world() == 1 and lib.egt_dp_rank() == 0
+x = torch.randn(100003, device="cuda"); ref = x.clone()
+c.all_reduce_flat(x, average=False); c.all_reduce_flat(x, average=True)
+torch.cuda.synchronize(); assert torch.equal(x, ref)
+c.all_reduce_flat(x, True, local_count=3, global_count=4)
+torch.cuda.synchronize(); assert torch.allclose(x, ref * 0.75)
+ident = C.create_string_buffer(128)
+assert lib.egt_dp_init(ident, 1, 0) == L.EGT_E_FLAGS
+try:
+    c.all_reduce_flat(x.double())
+    raise SystemExit("dtype check missing")
+except TypeError:
+    pass
+p = torch.nn.Parameter(torch.ones(5, device="cuda"))
+fa = FlatGradAllReduce([p], comm=c); fa.flat.fill_(2.0); fa.all_reduce()
+torch.cuda.synchronize(); assert torch.equal(p.grad, torch.full((5,), 2.0, device="cuda"))
+c.close(); assert lib.egt_dp_world() == 0
+c2 = CapiComm(rank=0, world=1); c2.close()
+print("CAPI_DP_OK")
+"""
+    r = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CAPI_DP_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     n = torch.cuda.device_count() + 1
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--steps", "1",

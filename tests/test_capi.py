@@ -52,6 +52,21 @@ def test_argument_validation_without_gpu(egt_lib):
     assert egt_lib.egt_edge_update_fwd(C.byref(e), *([None] * 6)) == L.EGT_E_SHAPE
 
 
+def test_dp_entry_points_validate_without_a_communicator(egt_lib):
+    """egt_dp_* (SURVEY 8(b)): state queries and argument errors before any communicator exists (no RCCL call)."""
+    from egt_amd import _lib as L
+    assert egt_lib.egt_dp_world() == 0 and egt_lib.egt_dp_rank() == -1
+    assert egt_lib.egt_dp_allreduce(None, 16, 1, None) == L.EGT_E_FLAGS
+    assert b"before egt_dp_init" in egt_lib.egt_last_error_string()
+    assert egt_lib.egt_dp_init(None, 1, 0) == L.EGT_E_NULL
+    ident = C.create_string_buffer(128)
+    assert egt_lib.egt_dp_init(ident, 2, 2) == L.EGT_E_SHAPE and egt_lib.egt_dp_init(ident, 0, 0) == L.EGT_E_SHAPE
+    assert egt_lib.egt_dp_unique_id(None) == L.EGT_E_NULL
+    assert egt_lib.egt_dp_finalize() == L.EGT_OK          # nothing to destroy
+    with pytest.raises(RuntimeError):
+        L.check(L.EGT_E_RCCL)
+
+
 def test_layer_constructor_errors_match_reference():
     from egt_amd import EGT, EGTBlock
     with pytest.raises(ValueError):           # egt_layers.py:20-21
