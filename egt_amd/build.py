@@ -16,15 +16,19 @@ REPO = os.path.dirname(ROOT)
 CSRC = os.path.join(ROOT, "csrc")
 LIBDIR = os.path.join(ROOT, "lib")
 LIB = os.path.join(LIBDIR, "libegt_amd.so")
-SOURCES = ["egt_capi.hip", "egt_attn.hip", "egt_attn_mfma.hip", "egt_edge.hip", "egt_block.hip", "egt_node.hip", "egt_ffn.hip", "egt_masks.hip", "egt_embed.hip", "egt_dp.hip"]
+SOURCES = ["egt_capi.hip", "egt_attn.hip", "egt_attn_mfma.hip", "egt_edge.hip", "egt_block.hip", "egt_narrow.hip", "egt_node.hip", "egt_ffn.hip", "egt_masks.hip", "egt_embed.hip", "egt_dp.hip"]
 ARCH = "gfx950"
 # per-source compiler flags.  egt_ffn.hip: the backward keeps 256 weight-gradient accumulator
 # registers per wave; with hipcc's default (AGPR-form MFMA everywhere) the short-lived GEMM
 # accumulators compete for the same 256 AccVGPRs and 300+ registers spill; VGPR-form MFMA lets
 # the allocator park the long-lived tiles in AccVGPRs instead (0 spills).
-EXTRA_FLAGS = {"egt_ffn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA_FLAGS = {"egt_ffn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               # egt_narrow.hip: SLP-packed v_pk_add_f32 cannot take the DPP operand of the quad exchanges
+               "egt_narrow.hip": ["-fno-slp-vectorize"]}
 if os.environ.get("EGT_BLOCK_FLAGS"):   # experiments: extra hipcc flags for egt_block.hip
     EXTRA_FLAGS["egt_block.hip"] = os.environ["EGT_BLOCK_FLAGS"].split()
+if os.environ.get("EGT_NARROW_FLAGS"):  # e.g. -DNRW_ABL=<bits> (timing ablations of the De = 8 kernels)
+    EXTRA_FLAGS["egt_narrow.hip"] = EXTRA_FLAGS["egt_narrow.hip"] + os.environ["EGT_NARROW_FLAGS"].split()
 if os.environ.get("EGT_ATTN_FLAGS"):    # e.g. -DEGT_ATTN_ABLATION (timing ablations of the MFMA inner op)
     EXTRA_FLAGS["egt_attn_mfma.hip"] = os.environ["EGT_ATTN_FLAGS"].split()
 

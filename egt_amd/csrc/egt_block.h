@@ -73,6 +73,9 @@ __host__ __device__ inline int col_head(int i) { return 2 * (i >> 2) + ((i >> 1)
 #define BWD_TL 16   // backward: query rows per workgroup
 #define NODE_RC 32  // node rows per workgroup in the node kernels
 
+// De = 8 VALU pair kernels (egt_narrow.hip)
+void egt_narrow_launch_fwd(BlockArgs& a, hipStream_t st);
+
 // launchers implemented in egt_node.hip
 void egt_node_launch_pre(BlockArgs& a, hipStream_t st);
 void egt_node_launch_post(BlockArgs& a, hipStream_t st);

@@ -1,0 +1,347 @@
+// Device helpers shared by the pair kernels of the fused attention block (egt_block.hip: MFMA-tile kernels;
+// egt_narrow.hip: De = 8 VALU kernels): mask application in the reference order, the node-side epilogue of the
+// forward and the node-side prologue of the backward.
+#pragma once
+#include "egt_block.h"
+#include "egt_tile.h"
+
+// 16 projection columns of the lane's pair: acc[r] = column 4q+r
+template <int DE>
+__device__ __forceinline__ v4f project(const float4 (&x)[Geo<DE>::TILES],
+                                       const float (&wA)[4 * Geo<DE>::TILES], v4f acc) {
+  using G = Geo<DE>;
+#pragma unroll
+  for (int t = 0; t < G::TILES; ++t) {
+    acc = MFMA(wA[4 * t + 0], x[t].x, acc);
+    acc = MFMA(wA[4 * t + 1], x[t].y, acc);
+    acc = MFMA(wA[4 * t + 2], x[t].z, acc);
+    acc = MFMA(wA[4 * t + 3], x[t].w, acc);
+  }
+  return acc;
+}
+
+// Per-pair mask inputs, fetched with the tile prefetch (unconditional, clamped).
+struct MaskRegs { float2 mv; unsigned short rb; };
+
+template <bool ML>
+__device__ __forceinline__ void mask_gload(const BlockArgs& a, MaskRegs& mr, size_t pairc, int q) {
+  // pairc: linear pair index of a VALID pair (clamped by the caller)
+  if (!ML) return;
+  if (a.M) mr.mv = *reinterpret_cast<const float2*>(a.M + pairc * BH + 2 * q);
+  if (a.rm) mr.rb = *reinterpret_cast<const unsigned short*>(a.rm + pairc * BH + 2 * q);
+}
+
+// logits x and gate-logits gl of the lane's pair, heads 2q+j; masks ADDED in the
+// reference's order (egt_layers.py:91-108): key padding, attention mask, random mask
+template <bool ML>
+__device__ __forceinline__ void apply_masks(const BlockArgs& a, float kadd, const MaskRegs& mr,
+                                            size_t idx8, int q, float (&x)[2], float (&gl)[2]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float xv = x[j], gv = gl[j];
+    if (a.km) { xv += kadd; gv += kadd; }
+    if (ML && a.M) {
+      const float mm = ((j ? mr.mv.y : mr.mv.x) - 1.0f) * EGT_NEG;
+      xv += mm; gv += mm;
+    }
+    if ((ML && a.rm) || a.rng_rm) {
+      bool hit;
+      if (ML && a.rm) hit = ((mr.rb >> (8 * j)) & 0xFF) != 0;
+      else hit = (egt_hash32((uint32_t)(idx8 + 2 * q + j), a.s0, a.s1) >> 8) < a.rm_thr;
+      const float mrv = hit ? -EGT_NEG : 0.0f;
+      xv += mrv; gv += mrv;
+    }
+    x[j] = xv; gl[j] = gv;
+  }
+}
+
+// transpose-reduce 16 per-lane values over the 16 key lanes (same q): lane p returns the
+// sum of element p
+__device__ __forceinline__ float reduce16_keep_own(const float (&v)[16], int p) {
+  float w8[8], w4[4], w2[2];
+  const bool b3 = (p & 8) != 0, b2 = (p & 4) != 0, b1 = (p & 2) != 0, b0 = (p & 1) != 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float snd = b3 ? v[i] : v[i + 8], kp = b3 ? v[i + 8] : v[i];
+    w8[i] = kp + lane_xor<8>(snd);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float snd = b2 ? w8[i] : w8[i + 4], kp = b2 ? w8[i + 4] : w8[i];
+    w4[i] = kp + lane_xor<4>(snd);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float snd = b1 ? w4[i] : w4[i + 2], kp = b1 ? w4[i + 2] : w4[i];
+    w2[i] = kp + lane_xor<2>(snd);
+  }
+  const float snd = b0 ? w2[0] : w2[1], kp = b0 ? w2[1] : w2[0];
+  return kp + lane_xor<1>(snd);
+}
+
+#define KV_LD 132  // LDS row stride (floats) of the staged [K|V] rows
+#define QS_LD 68   // LDS row stride of the staged Q rows (reused for the V_att rows of the epilogue)
+
+// ---- node-side epilogue (Dh = 64): the workgroup holds V_att of its 16 rows in qs ----
+//   epi >= 1: h' = V_att.Wo + bo + h                      (dense_mha + res_mha, :136,140)
+//   epi == 2: qkv of the NEXT block = LN(h').Wqkv' + bqkv' (norm_mha + dense_qkv, :109,113), packed
+// Contraction order k = 4s + q on both MFMA operands; weights come straight from L2.
+__device__ __forceinline__ void fwd_node_epilogue(const BlockArgs& a, float* sm, float* qs, int b, int lg, int N,
+                                                  int wave, int p, int q) {
+
+    float wo[16], wq[3][16];
+    const int c = wave * 16 + p;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) wo[s] = a.Wo[(4 * s + q) * 64 + c];
+    if (a.epi == 2) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) wq[j][s] = a.nx_Wqkv[(4 * s + q) * 192 + (wave + 4 * j) * 16 + p];
+    }
+    const float bo = a.bo[c];
+    float hres[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hres[r] = a.h[((size_t)b * N + min(lg * 16 + 4 * q + r, N - 1)) * 64 + c];
+    __syncthreads();   // every row's V_att is in qs; the tile area is idle from here on
+    float* hs = sm;    // [16][QS_LD]
+    v4f acc = {bo, bo, bo, bo};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = MFMA(qs[p * QS_LD + 4 * s + q], wo[s], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * q + r, l = lg * 16 + row;
+      const float hv = acc[r] + hres[r];
+      if (l < N) a.h_out[((size_t)b * N + l) * 64 + c] = hv;
+      hs[row * QS_LD + c] = hv;
+    }
+    if (a.epi == 2) {
+      __syncthreads();
+      {   // LayerNorm of row 4*wave + q: 16 lanes x 4 columns
+        float* x = hs + (4 * wave + q) * QS_LD;
+        float v[4], sm1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = x[p + 16 * i]; sm1 += v[i]; }
+        const float mu = row_sum16(sm1) * (1.0f / 64);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] -= mu; ss = fmaf(v[i], v[i], ss); }
+        const float rstd = rsqrtf(row_sum16(ss) * (1.0f / 64) + a.ln_eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[p + 16 * i] = fmaf(v[i] * rstd, a.nx_nm_g[p + 16 * i], a.nx_nm_b[p + 16 * i]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int cq = (wave + 4 * j) * 16 + p;
+        const float bq = a.nx_bqkv[cq];
+        v4f aq = {bq, bq, bq, bq};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) aq = MFMA(hs[p * QS_LD + 4 * s + q], wq[j][s], aq);
+        const int sx = cq >> 6, cc = cq & 63, kk = cc >> 3, hh = cc & 7;
+        const int pos = sx * 64 + (hh >> 1) * 16 + kk * 2 + (hh & 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int l = lg * 16 + 4 * q + r;
+          if (l < N) a.nx_qkvp[((size_t)b * N + l) * QKVP + pos] = aq[r];
+        }
+      }
+    }
+  }
+
+#define QD_LD 160  // per row: Q[64] | dV_att[64] | stats[32]
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// ---- node-side prologue of the backward pair kernel (Dh = 64, 16 rows, 256 threads) -------------
+// What k_node_bwd does between two pair kernels is local to a node row, so the workgroup that
+// owns 16 query rows of layer L does it itself before its tile loop:
+//   [pro == 2] rows of the layer above (L+1): dQKV = packed dQ + dK/dV partial sums (written by the
+//              pair kernel of L+1), d h_ln = dQKV.Wqkv^T (48 MFMA / wave), LayerNorm backward +
+//              residual -> dh(L+1) = dh'(L); dQKV and dh rows go to HBM for the deferred weight-
+//              gradient kernel; bias / LN-parameter column sums -> up_spart
+//   [pro == 1] dh'(L) rows = dh_out (top of the chain)
+//   then       dV_att(L) = dh'.Wo^T (16 MFMA / wave, packed straight into the qd rows in LDS),
+//              delta = sum_k dV_att*V_att into the qd statistics, dbo column sums -> sbo
+// One launch per layer on the dh critical path instead of two; dV_att / delta never touch HBM.
+// `ws`: the (still idle) per-wave tile area; `qd`: the staged [16][QD_LD] rows.
+#define BWD_PRO_WS 8192   // floats of LDS scratch the prologue needs (dQKV, xhat, d h_ln, dh' rows, partials)
+template <int DE>
+__device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg) {
+  constexpr int LD = 68, LD3 = 196;
+  float* dqs = ws;                   // dQKV  [16][196]
+  float* xs = dqs + 16 * LD3;        // xhat  [16][68]
+  float* dls = xs + 16 * LD;         // d h_ln
+  float* dhs = dls + 16 * LD;        // dh'
+  float* rs = dhs + 16 * LD;         // rstd  [16]
+  float* dlp = rs + 16;              // delta partials [4][16][8]
+  static_assert(16 * LD3 + 3 * 16 * LD + 16 + 4 * 16 * 8 <= BWD_PRO_WS, "prologue scratch");
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int p = lane & 15, q = lane >> 4, N = a.N;
+  const size_t row0 = (size_t)b * N + l_begin;
+  const int lnrow = 4 * wave + q;    // LayerNorm mapping: row 4*wave + q, columns p + 16 i
+  // ragged last row group (N not a multiple of 16): loads are clamped to the graph's last row, the
+  // rows past the end contribute zeros to every sum and are never stored
+  const int nv = min(16, N - l_begin);                     // valid rows of this workgroup
+  auto rc = [&](int r) { return row0 + min(r, nv - 1); };   // clamped global row
+  if (a.pro == 2) {
+    // ---- every global input in one round trip ----
+    float4 hx = *reinterpret_cast<const float4*>(a.up_h + rc(t >> 4) * 64 + (t & 15) * 4);
+    float4 gq[3];
+    float dho[4], gmm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dho[i] = a.up_dh_out[rc(lnrow) * 64 + p + 16 * i];
+      gmm[i] = a.up_nm_g[p + 16 * i];
+    }
+    const int NP = a.NQP;   // key tiles = ceil(N / 16)
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = t + u * 256, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
+      const int rr = min(r, nv - 1);
+      const float* base = sx == 0 ? a.up_dqp + ((size_t)b * NP * N + l_begin + rr) * 64 + pos4
+                                  : a.up_dkvp + (((size_t)b * NP * N + l_begin + rr) * 2 + (sx - 1)) * 64 + (pos4 & 63);
+      const size_t pstride = sx == 0 ? (size_t)N * 64 : (size_t)N * 128;
+      float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+      for (int pi = 0; pi < NP; ++pi) {
+        const float4 w = *reinterpret_cast<const float4*>(base + pi * pstride);
+        acc4.x += w.x; acc4.y += w.y; acc4.z += w.z; acc4.w += w.w;
+      }
+      if (r >= nv) acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      gq[u] = acc4;
+    }
+    // B operand of d h_ln = dQKV.Wqkv^T: Wqkv[kk = 16 wave + p][48 q .. 48 q + 47] (contraction order c = 48 q + s)
+    float4 wq[12];
+#pragma unroll
+    for (int s = 0; s < 12; ++s)
+      wq[s] = *reinterpret_cast<const float4*>(a.up_Wqkv + (size_t)(16 * wave + p) * 192 + 48 * q + 4 * s);
+    *reinterpret_cast<float4*>(xs + (t >> 4) * LD + (t & 15) * 4) = hx;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = t + u * 256, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
+      const int qq = (pos4 >> 4) & 3, k0 = (pos4 >> 1) & 7;
+      float* d = dqs + r * LD3 + sx * 64 + k0 * 8 + 2 * qq;
+      d[0] = gq[u].x; d[1] = gq[u].y; d[8] = gq[u].z; d[9] = gq[u].w;
+    }
+    __syncthreads();
+    {   // LN forward statistics -> xhat in place
+      float* xr = xs + lnrow * LD;
+      float v[4], s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = xr[p + 16 * i]; s1 += v[i]; }
+      const float mu = row_sum16(s1) * (1.0f / 64);
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] -= mu; ss = fmaf(v[i], v[i], ss); }
+      const float rstd = rsqrtf(row_sum16(ss) * (1.0f / 64) + a.ln_eps);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xr[p + 16 * i] = v[i] * rstd;
+      if (p == 0) rs[lnrow] = rstd;
+    }
+    {   // d h_ln[row][kk] for kk tile = wave
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
+      const float* ar = dqs + p * LD3 + 48 * q;
+#pragma unroll
+      for (int s = 0; s < 12; ++s) {
+        const float4 av = *reinterpret_cast<const float4*>(ar + 4 * s);
+        acc = MFMA(av.x, wq[s].x, acc);
+        acc = MFMA(av.y, wq[s].y, acc);
+        acc = MFMA(av.z, wq[s].z, acc);
+        acc = MFMA(av.w, wq[s].w, acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dls[(4 * q + r) * LD + 16 * wave + p] = acc[r];
+    }
+    for (int i = t; i < nv * 48; i += 256) {   // dQKV rows out (natural channel order) for k_node_wgrads
+      const int r = i / 48, c4 = (i % 48) * 4;
+      *reinterpret_cast<float4*>(a.up_dqkv_sv + (row0 + r) * 192 + c4) = *reinterpret_cast<const float4*>(dqs + r * LD3 + c4);
+    }
+    __syncthreads();
+    {   // LayerNorm backward + residual -> dh' rows (HBM + LDS)
+      const float* xr = xs + lnrow * LD;
+      const float* dl = dls + lnrow * LD;
+      float dx[4], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dx[i] = dl[p + 16 * i] * gmm[i];
+        m1 += dx[i];
+        m2 = fmaf(dx[i], xr[p + 16 * i], m2);
+      }
+      m1 = row_sum16(m1) * (1.0f / 64);
+      m2 = row_sum16(m2) * (1.0f / 64);
+      const float rstd = rs[lnrow];
+      float* dh_out_rw = const_cast<float*>(a.dh_out);   // this layer's dh' IS the upper layer's dh
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = p + 16 * i;
+        const float dv = lnrow < nv ? dho[i] + rstd * (dx[i] - m1 - xr[c] * m2) : 0.f;
+        if (lnrow < nv) dh_out_rw[(row0 + lnrow) * 64 + c] = dv;
+        dhs[lnrow * LD + c] = dv;
+      }
+    }
+    {   // column sums over the 16 rows: dbqkv | dgamma, dbeta of the layer above
+      float* sp = a.up_spart + (size_t)wg * (192 + 128);
+      if (t < 192) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) { s0 += dqs[r * LD3 + t]; s1 += dqs[(r + 1) * LD3 + t]; }
+        sp[t] = s0 + s1;
+      } else {
+        const int c = t - 192;
+        float g0 = 0.f, b0 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d0 = dls[r * LD + c]; g0 = fmaf(d0, xs[r * LD + c], g0); b0 += d0; }
+        sp[192 + c] = g0;
+        sp[256 + c] = b0;
+      }
+    }
+  } else {
+    const float4 dv4 = *reinterpret_cast<const float4*>(a.dh_out + rc(t >> 4) * 64 + (t & 15) * 4);
+    const bool ok = (t >> 4) < nv;
+    *reinterpret_cast<float4*>(dhs + (t >> 4) * LD + (t & 15) * 4) =
+        make_float4(ok ? dv4.x : 0.f, ok ? dv4.y : 0.f, ok ? dv4.z : 0.f, ok ? dv4.w : 0.f);
+  }
+  // ---- dV_att = dh'.Wo^T for i tile = wave (contraction order c = 16 q + s), delta, dbo ----
+  float4 wo[4];
+  float va[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) wo[s] = *reinterpret_cast<const float4*>(a.Wo + (size_t)(16 * wave + p) * 64 + 16 * q + 4 * s);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) va[r] = a.v_att[rc(4 * q + r) * 64 + 16 * wave + p];
+  __syncthreads();
+  {
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    const float* ar = dhs + p * LD + 16 * q;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float4 av = *reinterpret_cast<const float4*>(ar + 4 * s);
+      acc = MFMA(av.x, wo[s].x, acc);
+      acc = MFMA(av.y, wo[s].y, acc);
+      acc = MFMA(av.z, wo[s].z, acc);
+      acc = MFMA(av.w, wo[s].w, acc);
+    }
+    const int i = 16 * wave + p, k = i >> 3, hh = i & 7;
+    const int pos = (hh >> 1) * 16 + k * 2 + (hh & 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * q + r;
+      qd[row * QD_LD + 64 + pos] = acc[r];
+      float pr = acc[r] * va[r];
+      pr += lane_xor<8>(pr);   // the tile's two k values of head p & 7
+      if (p < 8) dlp[(wave * 16 + row) * 8 + p] = pr;
+    }
+  }
+  if (t < 64) {   // dbo: column sums of dh'
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) { s0 += dhs[r * LD + t]; s1 += dhs[(r + 1) * LD + t]; }
+    a.sbo[(size_t)wg * 64 + t] = s0 + s1;
+  }
+  __syncthreads();
+  if (t < 128) {   // delta of (row, head)
+    const int row = t >> 3, hd = t & 7;
+    qd[row * QD_LD + 128 + hd * 4 + 2] = (dlp[(0 * 16 + row) * 8 + hd] + dlp[(1 * 16 + row) * 8 + hd]) +
+                                         (dlp[(2 * 16 + row) * 8 + hd] + dlp[(3 * 16 + row) * 8 + hd]);
+  }
+}
+
