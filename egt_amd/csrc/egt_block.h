@@ -75,6 +75,7 @@ __host__ __device__ inline int col_head(int i) { return 2 * (i >> 2) + ((i >> 1)
 
 // De = 8 VALU pair kernels (egt_narrow.hip)
 void egt_narrow_launch_fwd(BlockArgs& a, hipStream_t st);
+void egt_narrow_launch_bwd(BlockArgs& a, int nwg, hipStream_t st);   // same a.pro / partial-buffer contract as k_block_bwd_v4r
 
 // launchers implemented in egt_node.hip
 void egt_node_launch_pre(BlockArgs& a, hipStream_t st);

@@ -54,6 +54,8 @@ __device__ __forceinline__ float nrw_quad_sum(float v) {
 __device__ __forceinline__ float nrw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float nrw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+// Wave-uniform base pointer + 32-bit lane offset (in elements): hipcc then uses the SGPR-base addressing mode and
+// keeps ONE offset register per lane instead of a 64-bit address per tensor.
 template <bool BF> struct NrwLd;
 template <> struct NrwLd<false> {
   typedef float2 raw;
@@ -64,6 +66,12 @@ template <> struct NrwLd<false> {
   static __device__ __forceinline__ void store(void* base, size_t pair, int q, float2 v) {
     *reinterpret_cast<float2*>(reinterpret_cast<float*>(base) + pair * NRW_DE + 2 * q) = v;
   }
+  static __device__ __forceinline__ raw uload(const void* base, size_t upair, int off) {   // upair: wave-uniform pair index
+    return *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(base) + upair * NRW_DE + off);
+  }
+  static __device__ __forceinline__ void ustore(void* base, size_t upair, int off, float2 v) {
+    *reinterpret_cast<float2*>(reinterpret_cast<float*>(base) + upair * NRW_DE + off) = v;
+  }
 };
 template <> struct NrwLd<true> {
   typedef uint32_t raw;
@@ -73,6 +81,12 @@ template <> struct NrwLd<true> {
   static __device__ __forceinline__ float2 cvt(raw r) { return make_float2(__uint_as_float(r << 16), __uint_as_float(r & 0xFFFF0000u)); }
   static __device__ __forceinline__ void store(void* base, size_t pair, int q, float2 v) {
     *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(base) + pair * NRW_DE + 2 * q) = f2_to_bf2(v.x, v.y);
+  }
+  static __device__ __forceinline__ raw uload(const void* base, size_t upair, int off) {
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(base) + upair * NRW_DE + off);
+  }
+  static __device__ __forceinline__ void ustore(void* base, size_t upair, int off, float2 v) {
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(base) + upair * NRW_DE + off) = f2_to_bf2(v.x, v.y);
   }
 };
 
@@ -138,20 +152,24 @@ __global__ void __launch_bounds__(256, 3) k_narrow_fwd(BlockArgs a) {
 #pragma unroll
   for (int k = 0; k < 16; ++k) O[k] = 0.f;
 
-  const size_t pair_row = rowl * N;
+  const size_t pair_row = rowl * N;              // (mask-RNG counter)
+  const size_t ugraph = (size_t)b * N * N;       // wave-uniform: first pair of the graph
+  const int loff = min(l, N - 1) * N * NRW_DE + 2 * q;   // the lane's element offset from the pair (row 0, key m)
   typename LD::raw eb[NRW_KB];
   float4 kvr[2];
   float kmr = 0.f;
   auto fetch = [&](int blk) {
     const int m0 = blk * NRW_KB;
 #pragma unroll
-    for (int kk = 0; kk < NRW_KB; ++kk) eb[kk] = LD::load(a.e, (NRW_ABL & 2) ? (size_t)(q + kk) : pair_row + min(m0 + kk, N - 1), q);
+    for (int kk = 0; kk < NRW_KB; ++kk) eb[kk] = LD::uload(a.e, (NRW_ABL & 2) ? (size_t)kk : ugraph + min(m0 + kk, N - 1), loff);
+    const int kmax = N - 1 - m0;   // keys of the block past the graph's last one are clamped to it
+    const float* kvb = a.qkvp + ((size_t)b * N + m0) * QKVP;   // wave-uniform
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int f = lane + 64 * u, key = f >> 5, piece = f & 31;
-      if (!(NRW_ABL & 4) || blk == blk0) kvr[u] = *reinterpret_cast<const float4*>(a.qkvp + ((size_t)b * N + min(m0 + key, N - 1)) * QKVP + 64 + piece * 4);
+      const int f = lane + 64 * u, key = min(f >> 5, kmax), piece = f & 31;
+      if (!(NRW_ABL & 4) || blk == blk0) kvr[u] = *reinterpret_cast<const float4*>(kvb + key * QKVP + 64 + piece * 4);
     }
-    if (a.km) kmr = (a.km[(size_t)b * N + min(m0 + (lane & 3), N - 1)] == 0) ? -EGT_NEG : 0.0f;
+    if (a.km) kmr = (a.km[(size_t)b * N + m0 + min(lane & 3, kmax)] == 0) ? -EGT_NEG : 0.0f;
   };
   if (blk0 < blk1) fetch(blk0);
 
@@ -212,7 +230,7 @@ __global__ void __launch_bounds__(256, 3) k_narrow_fwd(BlockArgs a) {
         gl[kk][j] = acc[2 * j];
       }
       const MaskRegs mr{make_float2(1.f, 1.f), 0};
-      if (!(NRW_ABL & 8)) apply_masks<false>(a, kmw[kk], mr, (pair_row + m) * BH, q, xl[kk], gl[kk]);
+      if (!(NRW_ABL & 8)) apply_masks<false>(a, kmw[kk], mr, (size_t)(((uint32_t)pair_row + (uint32_t)m) * (uint32_t)BH), q, xl[kk], gl[kk]);   // (counter mod 2^32)
       if (kk >= nv) { xl[kk][0] = -3.0e38f; xl[kk][1] = -3.0e38f; }   // past the graph's last key: probability exactly 0
       // ---- dense_edge_r + res_edge: e' = e + H_hat.Wr + br, the lane's two channels ----
       float2 eo;
@@ -224,8 +242,8 @@ __global__ void __launch_bounds__(256, 3) k_narrow_fwd(BlockArgs a) {
         eo.x = ev[kk].x + t0;
         eo.y = ev[kk].y + t1;
       }
-      if (row_ok && kk < nv && !(NRW_ABL & 1)) LD::store(a.e_out, pair_row + m, q, eo);
-      if ((NRW_ABL & 1) && eo.x == 123.456f) LD::store(a.e_out, pair_row + m, q, eo);
+      if (row_ok && kk < nv && !(NRW_ABL & 1)) LD::ustore(a.e_out, ugraph + m, loff, eo);
+      if ((NRW_ABL & 1) && eo.x == 123.456f) LD::ustore(a.e_out, ugraph + m, loff, eo);
     }
     // ---- one online-softmax step for the block, x gate, A.V: the row's state never leaves the lane ----
 #pragma unroll
@@ -316,4 +334,343 @@ void egt_narrow_launch_fwd(BlockArgs& a, hipStream_t st) {
   if (a.bf16) { if (feat == full) NRW_FWD(true, NRW_F_GATED | NRW_F_CLIP); else NRW_FWD(true, NRW_F_RUNTIME); }
   else { if (feat == full) NRW_FWD(false, NRW_F_GATED | NRW_F_CLIP); else NRW_FWD(false, NRW_F_RUNTIME); }
 #undef NRW_FWD
+}
+
+// ----------------------------------------------------------------------------------- backward ---
+// Workgroup = (graph b, 16 query rows), 4 waves; a wave owns key tiles w, w+4, ... and walks the rows:
+// lane (p, q) = key m0 + p, heads / channels 2q, 2q+1.  K / V of the key and the dK / dV accumulators live in
+// the lane; e and de' arrive by coalesced 8-byte loads two rows ahead; Q / dV_att / softmax statistics of the
+// rows are the staged qd rows of the wide kernels (same node-side prologue).
+//   per step (16 pairs): LayerNorm + projections (recompute), dH_ext = de'.Wr^T, softmax / gate backward,
+//   d ehat = Wp.dGE, LayerNorm backward -- 2-channel / 2-head partial sums combined across the quad by DPP adds
+//   (quad-relative weight tables in LDS);
+//   weight gradients: [xhat | de']^T . dGE and [xhat | de']^T . [H_hat | 1] over the step's 16 pairs on the matrix
+//   pipe (operands through three lane-linear LDS tiles: 8 MFMAs per step, two accumulators);
+//   dQ: dA of eight rows is parked in LDS, then dQ[row][k] = sum_keys dA . K is 32 MFMAs per eight rows
+//   (no cross-lane reduction on the VALU); dK / dV partials as in the wide kernels.
+// Partial buffers (dqp, dkvp, epart) have the wide kernels' layouts.
+#define NRW_NB 6                                     // rows per dQ batch (16 rows = 6 + 6 + 4)
+#define NRW_BWD_WAVE (NRW_NB * 128 + 3 * 256 + 1024)   // floats per wave: dA of NRW_NB rows [NB][64][2] | XS | DG | HH [16][16] each | K tile [16 keys][64]
+#define NRW_TAB_WP 0                     // [4 q][36]: wp[c][g][r]
+#define NRW_TAB_WR 144                   // [4 q][20]: wr[c][g][j]
+#define NRW_TAB_WD 224                   // [4 q][36]: wd[r][g][c]
+#define NRW_TAB_FLOATS 368
+template <bool BF, int FEAT>
+__global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
+  typedef NrwLd<BF> LD;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = lane >> 2, q = lane & 3;
+  const int N = a.N, TL = a.TL;   // TL == 16
+  const int wg = a.xcd ? egt_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int b = wg / a.NLR, lr = wg % a.NLR;
+  const int l_begin = lr * TL, l_end = min(N, l_begin + TL), nl = l_end - l_begin;
+  const bool gated = FEAT >= 0 ? (FEAT & NRW_F_GATED) != 0 : (a.flags & EGT_BF_GATE) != 0;
+  const bool clip = FEAT >= 0 ? (FEAT & NRW_F_CLIP) != 0 : (a.flags & EGT_BF_CLIP) != 0;
+  const bool ln_on = (a.flags & EGT_BF_NO_EDGE_LN) == 0;
+  constexpr int AREA = 4 * NRW_BWD_WAVE > BWD_PRO_WS ? 4 * NRW_BWD_WAVE : BWD_PRO_WS;
+  static_assert(4 * 528 <= AREA, "edge partial staging must fit the per-wave area");
+  float* dab = sm + wave * NRW_BWD_WAVE;   // [NRW_NB][64][2]
+  float* xs = dab + NRW_NB * 128;          // [16 pairs][xhat 8 | de' 8]
+  float* dg = xs + 256;                    // [16 pairs][16 dGE columns]
+  float* hs = dg + 256;                    // [16 pairs][H_hat 8 | 1 | 0 x 7]
+  float* kt = hs + 256;                    // [16 keys][4 q][8 k][2 j]: the tile's K rows, B operand of the dQ products
+  float* qd = sm + AREA;                   // [TL][QD_LD]
+  float* tab = qd + TL * QD_LD;
+  for (int i = threadIdx.x; i < nl * 40; i += 256) {
+    const int r = i / 40, f = i % 40;
+    const size_t rowl = (size_t)b * N + l_begin + r;
+    if (a.pro && f >= 16 && f < 32) continue;   // dV_att comes from the prologue below
+    const float* src = f < 16 ? a.qkvp + rowl * QKVP + f * 4
+                     : f < 32 ? a.dvp + rowl * 64 + (f - 16) * 4
+                              : a.stats + rowl * 32 + (f - 32) * 4;
+    float4 v = *reinterpret_cast<const float4*>(src);
+    if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
+    *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
+  }
+  if (a.pro) {
+    __syncthreads();
+    bwd_node_prologue<NRW_DE>(a, sm, qd, b, l_begin, wg);
+  }
+  // quad-relative weight tables
+  for (int i = threadIdx.x; i < 4 * 32; i += 256) {
+    const int qq = i >> 5, r32 = i & 31;
+    { const int c = r32 >> 4, g = (r32 >> 2) & 3, r = r32 & 3;
+      tab[NRW_TAB_WP + qq * 36 + r32] = a.pw[(2 * qq + c) * 16 + 4 * (g ^ qq) + r]; }
+    { const int r = r32 >> 3, g = (r32 >> 1) & 3, c = r32 & 1;
+      tab[NRW_TAB_WD + qq * 36 + r32] = a.pw[(2 * (g ^ qq) + c) * 16 + 4 * qq + r]; }
+    if (r32 < 16) {
+      const int c = r32 >> 3, g = (r32 >> 1) & 3, j = r32 & 1;
+      tab[NRW_TAB_WR + qq * 20 + r32] = a.Wr[(2 * (g ^ qq) + j) * NRW_DE + 2 * qq + c];
+    }
+  }
+  float c2r[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c2r[r] = a.pw[16 * 16 + 4 * q + r];
+  v4f accT = {0.f, 0.f, 0.f, 0.f}, accR = {0.f, 0.f, 0.f, 0.f};
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();   // prologue scratch dead, tables and qd rows complete
+  // constant columns of the [H_hat | 1] tile: column 8 = 1, columns 9..15 = 0 (columns 0..7 are rewritten every step)
+  hs[(lane >> 2) * 16 + 8 + (lane & 3) * 2] = (lane & 3) == 0 ? 1.0f : 0.0f;
+  hs[(lane >> 2) * 16 + 8 + (lane & 3) * 2 + 1] = 0.0f;
+  const float* wpq = tab + NRW_TAB_WP + q * 36;
+  const float* wrq = tab + NRW_TAB_WR + q * 20;
+  const float* wdq = tab + NRW_TAB_WD + q * 36;
+
+  const int ntile = (N + 15) / 16;
+  for (int mt = wave; mt < ntile; mt += 4) {
+    const int m0 = mt * 16, m = m0 + p;
+    const bool kvalid = m < N;
+    const int mc = kvalid ? m : N - 1;
+    const size_t rowm = (size_t)b * N + mc;
+    float Vf[16], dKa[16], dVa[16];   // (K of the key: read from the wave's LDS tile every step -- 16 registers less)
+    {
+      const float4* kp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 64 + q * 16);
+      const float4* vp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 128 + q * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 vv = vp[i];
+        Vf[4*i] = vv.x; Vf[4*i+1] = vv.y; Vf[4*i+2] = vv.z; Vf[4*i+3] = vv.w;
+        *reinterpret_cast<float4*>(kt + lane * 16 + 4 * i) = kp[i];   // (the previous tile's last flush read kt earlier in program order)
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { dKa[i] = 0.f; dVa[i] = 0.f; }
+    }
+    const float kadd = (a.km && a.km[rowm] == 0) ? -EGT_NEG : 0.0f;
+    const MaskRegs mr{make_float2(1.f, 1.f), 0};
+    const uint32_t pcol = (uint32_t)((size_t)b * N * N + mc);   // pair index of (row 0 of the graph, key mc), mod 2^32: the mask-RNG counter
+    const size_t ugraph = (size_t)b * N * N;      // wave-uniform pair index of the graph's first pair
+    const int loff = mc * NRW_DE + 2 * q;         // the lane's element offset inside a pair row
+    // e / de' two rows ahead
+    typename LD::raw en[2], dn[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const size_t pr = ugraph + (size_t)min(l_begin + i, l_end - 1) * N;
+      en[i] = LD::uload(a.e, pr, loff);
+      dn[i] = LD::uload(a.de_out, pr, loff);
+    }
+    for (int li = 0; li < nl; ++li) {
+      const int l = l_begin + li;
+      const uint32_t pair = pcol + (uint32_t)(l * N);
+      float2 ev = LD::cvt(en[0]), dyv = LD::cvt(dn[0]);
+      en[0] = en[1]; dn[0] = dn[1];
+      {
+        const size_t pr = ugraph + (size_t)min(l + 2, l_end - 1) * N;
+        en[1] = LD::uload(a.e, pr, loff);
+        dn[1] = LD::uload(a.de_out, pr, loff);
+      }
+      if (!kvalid) { ev = make_float2(0.f, 0.f); dyv = make_float2(0.f, 0.f); }   // a key past N: zero tile row
+      // ---- norm_edge (recompute) ----
+      float x0 = ev.x, x1 = ev.y;
+      const float mu = ln_on ? nrw_quad_sum(x0 + x1) * 0.125f : 0.0f;
+      x0 -= mu; x1 -= mu;
+      const float var = nrw_quad_sum(fmaf(x0, x0, x1 * x1)) * 0.125f;
+      const float rstd = ln_on ? __builtin_amdgcn_rsqf(var + a.ln_eps) : 1.0f;
+      x0 *= rstd; x1 *= rstd;
+      // ---- projections: acc[r] = column 4q + r ----
+      float acc[4];
+      {
+        float s[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 w0 = *reinterpret_cast<const float4*>(wpq + g * 4);
+          const float4 w1 = *reinterpret_cast<const float4*>(wpq + 16 + g * 4);
+          s[g][0] = fmaf(x1, w1.x, x0 * w0.x); s[g][1] = fmaf(x1, w1.y, x0 * w0.y);
+          s[g][2] = fmaf(x1, w1.z, x0 * w0.z); s[g][3] = fmaf(x1, w1.w, x0 * w0.w);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = nrw_combine(s[0][r] + c2r[r], s[1][r], s[2][r], s[3][r]);
+      }
+      // ---- dH_ext = de'.Wr^T for heads 2q, 2q+1 ----
+      float dhx[2];
+      {
+        float ph[4][2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {   // h2: g pair {0,1} / {2,3}
+          const float4 w0 = *reinterpret_cast<const float4*>(wrq + h2 * 4);        // c = 0: [g][j]
+          const float4 w1 = *reinterpret_cast<const float4*>(wrq + 8 + h2 * 4);    // c = 1
+          ph[2 * h2][0] = fmaf(dyv.y, w1.x, dyv.x * w0.x); ph[2 * h2][1] = fmaf(dyv.y, w1.y, dyv.x * w0.y);
+          ph[2 * h2 + 1][0] = fmaf(dyv.y, w1.z, dyv.x * w0.z); ph[2 * h2 + 1][1] = fmaf(dyv.y, w1.w, dyv.x * w0.w);
+        }
+        dhx[0] = nrw_combine(ph[0][0], ph[1][0], ph[2][0], ph[3][0]);
+        dhx[1] = nrw_combine(ph[0][1], ph[1][1], ph[2][1], ph[3][1]);
+      }
+      // ---- logits, softmax / gate backward ----
+      const float* qr = qd + li * QD_LD;
+      const float4* qp = reinterpret_cast<const float4*>(qr + q * 16);
+      const float4* dp = reinterpret_cast<const float4*>(qr + 64 + q * 16);
+      float dots[2], dAd[2];
+      {
+        float d0 = 0.f, d1 = 0.f, e0 = 0.f, e1 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float4 v = qp[u], w = dp[u], kf = *reinterpret_cast<const float4*>(kt + lane * 16 + 4 * u);
+          d0 = fmaf(v.x, kf.x, d0); d1 = fmaf(v.y, kf.y, d1);
+          d0 = fmaf(v.z, kf.z, d0); d1 = fmaf(v.w, kf.w, d1);
+          e0 = fmaf(w.x, Vf[4*u], e0);   e1 = fmaf(w.y, Vf[4*u+1], e1);
+          e0 = fmaf(w.z, Vf[4*u+2], e0); e1 = fmaf(w.w, Vf[4*u+3], e1);
+        }
+        dots[0] = d0; dots[1] = d1; dAd[0] = e0; dAd[1] = e1;
+      }
+      const float4 st0 = *reinterpret_cast<const float4*>(qr + 128 + q * 8);
+      const float4 st1 = *reinterpret_cast<const float4*>(qr + 128 + q * 8 + 4);
+      float dge[4], hh[2], dA[2], at[2];
+      {
+        float xl[2], gl[2], inr[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float araw = dots[j] * a.scale;
+          float ah = araw;
+          inr[j] = 1.0f;
+          if (clip) {
+            ah = nrw_min(nrw_max(araw, a.clip_lo), a.clip_hi);
+            inr[j] = (ah == araw) ? 1.0f : 0.0f;   // inside [lo, hi]  <=>  the clamp left it alone
+          }
+          hh[j] = ah + acc[2 * j + 1];
+          xl[j] = hh[j];
+          gl[j] = acc[2 * j];
+        }
+        apply_masks<false>(a, kadd, mr, (size_t)(pair * (uint32_t)BH), q, xl, gl);   // (the counter is taken mod 2^32 there)
+        if (!kvalid) { xl[0] = xl[1] = -3.0e38f; gl[0] = gl[1] = -3.0e38f; }   // a key past N: S = 0, gate = 0
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float smax = j ? st1.x : st0.x, rsum = j ? st1.y : st0.y, delta = j ? st1.z : st0.z;
+          const float S = __expf(xl[j] - smax) * rsum;
+          const float g = gated ? egt_sigmoid(gl[j]) : 1.0f;
+          const float dS = dAd[j] * g;
+          const float dGl = gated ? dAd[j] * S * g * (1.0f - g) : 0.f;
+          const float dH = fmaf(S, dS - delta, dhx[j]);
+          dA[j] = dH * inr[j] * a.scale;
+          at[j] = S * g;
+          dge[2 * j] = dGl;
+          dge[2 * j + 1] = dH;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ssum[r] += dge[r];
+      // ---- operands of the matrix-pipe contractions -> LDS (lane-linear tiles) ----
+      const int bi = li % NRW_NB;
+      *reinterpret_cast<float2*>(xs + p * 16 + 2 * q) = make_float2(x0, x1);
+      *reinterpret_cast<float2*>(xs + p * 16 + 8 + 2 * q) = dyv;
+      *reinterpret_cast<float4*>(dg + p * 16 + 4 * q) = make_float4(dge[0], dge[1], dge[2], dge[3]);
+      *reinterpret_cast<float2*>(hs + p * 16 + 2 * q) = make_float2(hh[0], hh[1]);
+      *reinterpret_cast<float2*>(dab + (bi * 64 + lane) * 2) = make_float2(dA[0], dA[1]);
+      asm volatile("" ::: "memory");   // (DS operations of a wave execute in order: no wait needed, only the compiler's order)
+      // ---- weight-gradient contractions over the step's 16 pairs: operands now, products below among the VALU work ----
+      float wa[4], wb1[4], wb2[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) { wa[s4] = xs[64 * s4 + lane]; wb1[s4] = dg[64 * s4 + lane]; wb2[s4] = hs[64 * s4 + lane]; }
+      // ---- dK / dV (Q / dV_att of the row re-read: not held across the softmax phase) ----
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 v = qp[u], w = dp[u];
+        dKa[4*u]   = fmaf(dA[0], v.x, dKa[4*u]);   dKa[4*u+1] = fmaf(dA[1], v.y, dKa[4*u+1]);
+        dKa[4*u+2] = fmaf(dA[0], v.z, dKa[4*u+2]); dKa[4*u+3] = fmaf(dA[1], v.w, dKa[4*u+3]);
+        dVa[4*u]   = fmaf(at[0], w.x, dVa[4*u]);   dVa[4*u+1] = fmaf(at[1], w.y, dVa[4*u+1]);
+        dVa[4*u+2] = fmaf(at[0], w.z, dVa[4*u+2]); dVa[4*u+3] = fmaf(at[1], w.w, dVa[4*u+3]);
+      }
+      accT = MFMA(wa[0], wb1[0], accT); accR = MFMA(wa[0], wb2[0], accR);
+      accT = MFMA(wa[1], wb1[1], accT); accR = MFMA(wa[1], wb2[1], accR);
+      // ---- d ehat = Wp.dGE for channels 2q, 2q+1; LayerNorm backward; de = de' + ... ----
+      float dxh[2];
+      {
+        float pd[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { pd[g][0] = 0.f; pd[g][1] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float4 w0 = *reinterpret_cast<const float4*>(wdq + r * 8);        // [g 0,1][c]
+          const float4 w1 = *reinterpret_cast<const float4*>(wdq + r * 8 + 4);    // [g 2,3][c]
+          pd[0][0] = fmaf(dge[r], w0.x, pd[0][0]); pd[0][1] = fmaf(dge[r], w0.y, pd[0][1]);
+          pd[1][0] = fmaf(dge[r], w0.z, pd[1][0]); pd[1][1] = fmaf(dge[r], w0.w, pd[1][1]);
+          pd[2][0] = fmaf(dge[r], w1.x, pd[2][0]); pd[2][1] = fmaf(dge[r], w1.y, pd[2][1]);
+          pd[3][0] = fmaf(dge[r], w1.z, pd[3][0]); pd[3][1] = fmaf(dge[r], w1.w, pd[3][1]);
+        }
+        dxh[0] = nrw_combine(pd[0][0], pd[1][0], pd[2][0], pd[3][0]);
+        dxh[1] = nrw_combine(pd[0][1], pd[1][1], pd[2][1], pd[3][1]);
+      }
+      {
+        float m1 = ln_on ? nrw_quad_sum(dxh[0] + dxh[1]) * 0.125f : 0.0f;
+        float m2 = ln_on ? nrw_quad_sum(fmaf(dxh[0], x0, dxh[1] * x1)) * 0.125f : 0.0f;
+        float2 o;
+        o.x = dyv.x + rstd * (dxh[0] - m1 - x0 * m2);
+        o.y = dyv.y + rstd * (dxh[1] - m1 - x1 * m2);
+        if (kvalid) LD::ustore(a.de, ugraph + (size_t)l * N, loff, o);
+      }
+      accT = MFMA(wa[2], wb1[2], accT); accR = MFMA(wa[2], wb2[2], accR);
+      accT = MFMA(wa[3], wb1[3], accT); accR = MFMA(wa[3], wb2[3], accR);
+      // ---- dQ of the batch's rows: dQ[row][k] = sum_keys dA[row][key] K[key][k] per (head pair, j), on the matrix pipe ----
+      if (bi == NRW_NB - 1 || li == nl - 1) {
+        const int lbase = l_begin + li - bi, nr = bi + 1;
+        const int ri = lane & 15, kq = lane >> 4;
+        asm volatile("" ::: "memory");
+#pragma unroll 1
+        for (int cj = 0; cj < 8; ++cj) {   // rolled: the 32 store addresses of an unrolled body would be hoisted into registers
+          const int qq = cj >> 1, j = cj & 1;
+          v4f d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const int pp = 4 * s4 + kq;
+            const float av = ri < NRW_NB ? dab[((ri * 64) + 4 * pp + qq) * 2 + j] : 0.f;
+            const float bv = ri < 8 ? kt[(4 * pp + qq) * 16 + 2 * ri + j] : 0.f;
+            d = MFMA(av, bv, d);
+          }
+          if (kq < 2 && ri < 8) {
+            float* ob = a.dqp + (((size_t)b * ntile + mt) * N + lbase) * 64 + cj * 0;   // wave-uniform
+            const int oo = 4 * kq * 64 + 16 * qq + 2 * ri + j;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+              if (4 * kq + r4 < nr) ob[oo + r4 * 64] = d[r4];
+          }
+        }
+      }
+      asm volatile("" ::: "memory");   // next step's tile writes stay behind this step's reads
+    }
+    if (kvalid) {
+      float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
+      float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
+        vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
+      }
+    }
+  }
+  // ---- edge-parameter gradient partials of the workgroup: T [16][16] | s [16] | R [16][16] ----
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {   // sum over the 16 key lanes with the same q
+    float v = ssum[r];
+    v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    ssum[r] = v;
+  }
+  __syncthreads();
+  {
+    float* ep = sm + wave * 528;
+    const int col = lane & 15, kq = lane >> 4;   // MFMA result layout: rows 4 kq + r4, column col
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int row = 4 * kq + r4;
+      ep[row * 16 + col] = row < 8 ? accT[r4] : 0.f;                          // T = rows 0..7 of [xhat | de']^T.dGE (channels >= De: 0)
+      ep[272 + ((row + 8) & 15) * 16 + col] = row >= 8 ? accR[r4] : 0.f;      // R = rows 8..15 of [xhat | de']^T.[H_hat | 1]
+    }
+    if (lane < 4) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ep[256 + 4 * lane + r] = ssum[r];
+    }
+  }
+  __syncthreads();
+  float* out = a.epart + (size_t)wg * 528;
+  for (int i = threadIdx.x; i < 528; i += 256)
+    out[i] = (sm[i] + sm[528 + i]) + (sm[2 * 528 + i] + sm[3 * 528 + i]);
+}
+
+void egt_narrow_launch_bwd(BlockArgs& a, int nwg, hipStream_t st) {
+  constexpr int AREA = 4 * NRW_BWD_WAVE > BWD_PRO_WS ? 4 * NRW_BWD_WAVE : BWD_PRO_WS;
+  const size_t lds = ((size_t)AREA + BWD_TL * QD_LD + NRW_TAB_FLOATS) * 4;
+  const int full = NRW_F_GATED | NRW_F_CLIP;
+  const int feat = ((a.flags & EGT_BF_GATE) ? NRW_F_GATED : 0) | ((a.flags & EGT_BF_CLIP) ? NRW_F_CLIP : 0);
+#define NRW_BWD(BF_, FEAT_) EGT_LAUNCH("k_block_bwd", (k_narrow_bwd<BF_, FEAT_>), dim3(nwg), dim3(256), lds, st, a)
+  if (a.bf16) { if (feat == full) NRW_BWD(true, NRW_F_GATED | NRW_F_CLIP); else NRW_BWD(true, NRW_F_RUNTIME); }
+  else { if (feat == full) NRW_BWD(false, NRW_F_GATED | NRW_F_CLIP); else NRW_BWD(false, NRW_F_RUNTIME); }
+#undef NRW_BWD
 }

@@ -10,12 +10,12 @@ fi
 WL=${NRW_WORKLOADS:-"cifar10_n150_fp32 cifar10_n150 pattern500k_n120 pattern500k_n120_b128"}
 for w in $WL; do
   for nn in ${NRW_ARMS:-0 1}; do
-    EGT_NO_NARROW=$nn timeout 300 python bench.py --workload $w --no-cpu-baseline --steps 30 --warmup 5 2>>gpurun_out/nrw/err.log | python -c "
+    EGT_NO_NARROW=$nn EGT_NO_NARROW_BWD=${NRW_NOBWD:-0} timeout 300 python bench.py --workload $w --no-cpu-baseline --steps 30 --warmup 5 2>>gpurun_out/nrw/err.log | python -c "
 import sys, json
 for ln in sys.stdin:
     if ln.startswith('{'):
         d = json.loads(ln); k = d['roofline']['kernels']
-        print('$w no_narrow=$nn', round(d['value']), 'graphs/s', round(d['ms_per_step'], 3), 'ms |', ' '.join(f'{n}={v[\"avg_us\"]:.1f}x{v[\"launches\"]}' for n, v in k.items()))
+        print('$w no_narrow=$nn no_bwd=${NRW_NOBWD:-0}', round(d['value']), 'graphs/s', round(d['ms_per_step'], 3), 'ms |', ' '.join(f'{n}={v[\"avg_us\"]:.1f}x{v[\"launches\"]}' for n, v in k.items()))
 " >> gpurun_out/nrw/bench.log
   done
 done
