@@ -423,7 +423,7 @@ extern "C" int egt_attn_fwd(const egt_attn_desc* desc, const void* qkv, const vo
   a.lds_per_wave = (int)fpw;
   const long rows = (long)a.B * a.N;
   dim3 grid((unsigned)((rows + waves - 1) / waves)), block(64 * waves);
-  (void)hipFuncSetAttribute((const void*)k_attn_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  EGT_MAX_LDS_ONCE(k_attn_fwd);
   EGT_LAUNCH("k_attn_fwd", k_attn_fwd, grid, block, lds, (hipStream_t)stream, a);
   EGT_HIP_LAUNCH_CHECK("egt_attn_fwd");
   return EGT_OK;
@@ -469,7 +469,7 @@ extern "C" int egt_attn_bwd(const egt_attn_desc* desc, const void* qkv, const vo
   a.lds_per_wave = (int)fpw;
   const long rows = (long)a.B * a.N;
   dim3 grid((unsigned)((rows + waves - 1) / waves)), block(64 * waves);
-  (void)hipFuncSetAttribute((const void*)k_attn_bwd_row, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  EGT_MAX_LDS_ONCE(k_attn_bwd_row);
   EGT_LAUNCH("k_attn_bwd_row", k_attn_bwd_row, grid, block, lds, (hipStream_t)stream, a);
   EGT_HIP_LAUNCH_CHECK("egt_attn_bwd(row)");
   dim3 grid4((unsigned)((rows + 3) / 4)), block4(256);

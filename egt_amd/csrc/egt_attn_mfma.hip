@@ -979,7 +979,7 @@ static int fill(const egt_attn_desc* desc, const void* qkv, const void* E, const
 template <int D>
 static void launch_pack(const AttnMfmaArgs& a, hipStream_t st) {
   const size_t lds = (size_t)16 * (D * AH + 4) * 4;
-  (void)hipFuncSetAttribute((const void*)k_attn_pack<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  EGT_MAX_LDS_ONCE(k_attn_pack<D>);
   EGT_LAUNCH("k_attn_pack", k_attn_pack<D>, dim3(a.B * (a.NP / 16) * (a.pack_bwd ? 4 : 2)), dim3(256), lds, st, a);
 }
 
@@ -997,11 +997,11 @@ static void launch_fwd_v(const AttnMfmaArgs& a, hipStream_t st) {
   const int f2 = attn_env().fwd2;
   const bool two = f2 >= 0 ? f2 != 0 : (a.B * (a.NP / 16) <= 512);
   if (two) {
-    (void)hipFuncSetAttribute((const void*)k_attn_mfma_fwd2<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_MAX_LDS_ONCE(k_attn_mfma_fwd2<D, V>);
     EGT_LAUNCH("k_attn_mfma_fwd", (k_attn_mfma_fwd2<D, V>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)16 * PT_SZ * 4, st, a);
     return;
   }
-  (void)hipFuncSetAttribute((const void*)k_attn_mfma_fwd<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  EGT_MAX_LDS_ONCE(k_attn_mfma_fwd<D, V>);
   EGT_LAUNCH("k_attn_mfma_fwd", (k_attn_mfma_fwd<D, V>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)8 * PT_SZ * 4, st, a);
 }
 template <int D>
@@ -1035,7 +1035,7 @@ extern "C" int egt_attn_mfma_fwd(const egt_attn_desc* desc, const void* qkv, con
 
 template <int D, int V>
 static void launch_bwd_kv_v(const AttnMfmaArgs& a, hipStream_t st) {
-  (void)hipFuncSetAttribute((const void*)k_attn_mfma_bwd_kv<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  EGT_MAX_LDS_ONCE(k_attn_mfma_bwd_kv<D, V>);
   EGT_LAUNCH("k_attn_mfma_bwd_kv", (k_attn_mfma_bwd_kv<D, V>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)14 * PT_SZ * 4, st, a);
 }
 template <int D>
@@ -1051,7 +1051,7 @@ static void launch_bwd(const AttnMfmaArgs& a, hipStream_t st) {
   {
     const bool four = attn_env().bwdq4 != 0;   // four key tiles per iteration: measured equal to one (49 vs 50 us at B = 8, slower at B = 32), kept as an experiment switch
     if (four) {
-      (void)hipFuncSetAttribute((const void*)k_attn_mfma_bwd_q<D, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      EGT_MAX_LDS_ONCE(k_attn_mfma_bwd_q<D, 4>);
       EGT_LAUNCH("k_attn_mfma_bwd_q", (k_attn_mfma_bwd_q<D, 4>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)8 * PT_SZ * 4, st, a);
     } else {
       EGT_LAUNCH("k_attn_mfma_bwd_q", (k_attn_mfma_bwd_q<D, 1>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)2 * PT_SZ * 4, st, a);

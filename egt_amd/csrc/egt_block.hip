@@ -2233,8 +2233,7 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   const size_t lds = lds_tiles + (kvl ? lds_kv : 0);
 #define FWD_VARIANT_T(KVL_, ML_, FULL_, BF_)                                                           \
   do {                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)k_block_fwd<DE, KVL_, ML_, FULL_, BF_>,                     \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
+    EGT_MAX_LDS_ONCE(k_block_fwd<DE, KVL_, ML_, FULL_, BF_>);                 \
     FWD_TIMING_ATTACH();                                                                                \
     EGT_LAUNCH("k_block_fwd", (k_block_fwd<DE, KVL_, ML_, FULL_, BF_>), grid, block, lds + fwd_lds_pad(), st, a); \
     FWD_TIMING_COLLECT();                                                                               \
@@ -2262,7 +2261,7 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
     if (!(a.Dh == 64 && a.DK == 8) || block_env().no_epilogue) a.epi = 0; else a.epi = epi_req;
 #define R4_LAUNCH_T(FULL_, NW_, BF_)                                                                              \
   do {                                                                                                            \
-    (void)hipFuncSetAttribute((const void*)k_block_fwd_r4<DE, FULL_, NW_, BF_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    EGT_MAX_LDS_ONCE(k_block_fwd_r4<DE, FULL_, NW_, BF_>); \
     EGT_LAUNCH("k_block_fwd", (k_block_fwd_r4<DE, FULL_, NW_, BF_>), dim3(a.B * ((a.N + 4 * NW_ - 1) / (4 * NW_))), dim3(64 * NW_), \
                NW_ == 4 ? lds_r4 : lds_r8, st, a);                                                                \
   } while (0)
@@ -2316,8 +2315,7 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
   const size_t lds = ((size_t)4 * PW + (size_t)4 * BWD_TL * 64 + (size_t)BWD_TL * QD_LD) * 4;
 #define BWD_VARIANT_T(ML_, FULL_, BF_)                                                                 \
   do {                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)k_block_bwd<DE, ML_, FULL_, BF_>,                           \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
+    EGT_MAX_LDS_ONCE(k_block_bwd<DE, ML_, FULL_, BF_>);                 \
     EGT_LAUNCH("k_block_bwd", (k_block_bwd<DE, ML_, FULL_, BF_>), dim3(L.nwg_bwd), dim3(256), lds, st, a); \
   } while (0)
 #define BWD_VARIANT(ML_, FULL_)                                                                        \
@@ -2330,8 +2328,7 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
       a.guard = block_env().bwd_ablate;   // 0 unless this is an ablation build (measurement only: drops phases)
 #define V4_VARIANT_R(ML_, PF_, BF_, RAG_)                                                                  \
   do {                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)k_block_bwd_v4<DE, ML_, PF_, BF_, RAG_>,                    \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
+    EGT_MAX_LDS_ONCE(k_block_bwd_v4<DE, ML_, PF_, BF_, RAG_>);                 \
     EGT_LAUNCH("k_block_bwd", (k_block_bwd_v4<DE, ML_, PF_, BF_, RAG_>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a); \
   } while (0)
 #define V4_VARIANT(ML_, PF_, BF_) do { if (full) V4_VARIANT_R(ML_, PF_, BF_, false); else V4_VARIANT_R(ML_, 0, BF_, true); } while (0)
@@ -2350,10 +2347,10 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
           constexpr int PWR = RR * (2 * GG::TILE_FLOATS + 256 + 192);
           const size_t lds_r = ((size_t)(4 * PWR > BWD_PRO_WS ? 4 * PWR : BWD_PRO_WS) + (size_t)BWD_TL * QD_LD + 3 * GG::TILES * 256) * 4;
           if (a.bf16) {
-            (void)hipFuncSetAttribute((const void*)k_block_bwd_v4r<DE, true, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            EGT_MAX_LDS_ONCE(k_block_bwd_v4r<DE, true, RR>);
             EGT_LAUNCH("k_block_bwd", (k_block_bwd_v4r<DE, true, RR>), dim3(L.nwg_bwd), dim3(256), lds_r, st, a);
           } else {
-            (void)hipFuncSetAttribute((const void*)k_block_bwd_v4r<DE, false, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            EGT_MAX_LDS_ONCE(k_block_bwd_v4r<DE, false, RR>);
             EGT_LAUNCH("k_block_bwd", (k_block_bwd_v4r<DE, false, RR>), dim3(L.nwg_bwd), dim3(256), lds_r, st, a);
           }
           goto pair_done;
@@ -2362,8 +2359,8 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
       if constexpr (DE >= 32) {
         if (full && !ml && !a.bf16 && block_env().bwd_v5) {   // LDS-DMA staged e tiles (k_block_bwd_v5)
           const bool x3 = block_env().bwd_mm == EGT_MM_BF16X3;
-          (void)hipFuncSetAttribute((const void*)k_block_bwd_v5<DE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          (void)hipFuncSetAttribute((const void*)k_block_bwd_v5<DE, EGT_MM_BF16X3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          EGT_MAX_LDS_ONCE(k_block_bwd_v5<DE, 0>);
+          EGT_MAX_LDS_ONCE(k_block_bwd_v5<DE, EGT_MM_BF16X3>);
 #ifdef EGT_BWD_TIMING
           bwd_timing_attach(a, L.nwg_bwd);
 #endif

@@ -102,6 +102,17 @@ struct EgtProfScope {
   ~EgtProfScope() { egt_prof_end(tok, s); }
 };
 
+// Raise a kernel's dynamic-LDS limit ONCE per process (one process drives one GPU): the driver call costs a few
+// microseconds of host time, which is what a launch-bound small batch is made of.
+#define EGT_MAX_LDS_ONCE(...)                                                                              \
+  do {                                                                                                     \
+    static bool done__ = false;                                                                            \
+    if (!done__) {                                                                                         \
+      (void)hipFuncSetAttribute((const void*)(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      done__ = true;                                                                                       \
+    }                                                                                                      \
+  } while (0)
+
 #define EGT_LAUNCH(name, kernel, grid, block, lds, stream, ...)            \
   do {                                                                      \
     EgtProfScope ps__(name, stream);                                        \

@@ -525,7 +525,7 @@ static int edge_proj_bwd_impl(const egt_edge_desc* desc, const void* e, const vo
   DISPATCH_DE(desc->De, {
     constexpr int PSZ = DE * 16 + 16;
     const size_t lds = edge_bwd_lds<DE>(16 * EdgeGeo<DE>::LD + 256, PSZ);
-    (void)hipFuncSetAttribute((const void*)k_edge_proj_bwd<DE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_MAX_LDS_ONCE(k_edge_proj_bwd<DE>);
     EGT_LAUNCH("k_edge_proj_bwd", k_edge_proj_bwd<DE>, dim3(grid), dim3(64 * EDGE_WAVES), lds, (hipStream_t)stream, a);
     float* red = a.ws + (size_t)EDGE_MAX_PARTIALS * PSZ;
     EGT_LAUNCH("k_edge_reduce_partials", k_edge_reduce_partials, dim3((PSZ + 15) / 16), dim3(256), 0,
@@ -594,7 +594,7 @@ extern "C" int egt_edge_update_bwd(const egt_edge_desc* desc, const void* d_e_ou
   DISPATCH_DE(desc->De, {
     constexpr int PSZ = EDGE_H * DE + DE;
     const size_t lds = edge_bwd_lds<DE>(16 * EdgeGeo<DE>::LD, PSZ);
-    (void)hipFuncSetAttribute((const void*)k_edge_update_bwd<DE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_MAX_LDS_ONCE(k_edge_update_bwd<DE>);
     EGT_LAUNCH("k_edge_update_bwd", k_edge_update_bwd<DE>, dim3(grid), dim3(64 * EDGE_WAVES), lds, (hipStream_t)stream, a);
     float* red = a.ws + (size_t)EDGE_MAX_PARTIALS * PSZ;
     EGT_LAUNCH("k_edge_reduce_partials", k_edge_reduce_partials, dim3((PSZ + 15) / 16), dim3(256), 0,

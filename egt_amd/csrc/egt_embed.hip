@@ -245,7 +245,7 @@ static void launch_embed_bwd(const egt_embed_desc* d, const int32_t* fmat, const
 #define EB(V_)                                                                                                      \
   do {                                                                                                              \
     const size_t lds = (size_t)(256 / c4p) * (K_ + V_) * d->De * sizeof(float);                                     \
-    (void)hipFuncSetAttribute((const void*)k_edge_embed_bwd<K_, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    EGT_MAX_LDS_ONCE(k_edge_embed_bwd<K_, V_>); \
     EGT_LAUNCH("k_edge_embed_bwd", (k_edge_embed_bwd<K_, V_>), dim3(nparts), dim3(256), lds, st, fmat, hops, de, part, pairs, d->De, c4p); \
   } while (0)
   switch (d->num_edge_features + 1) {

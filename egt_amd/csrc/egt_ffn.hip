@@ -864,10 +864,10 @@ static void ffn_launch_fwd(const FfnArgs& a, int act, hipStream_t st) {
   const long wantf = (ntiles + 7) / 8;
   const int grid = (int)(wantf < 1 ? 1 : (wantf > 256 ? 256 : wantf));
   if (act == EGT_ACT_RELU) {
-    (void)hipFuncSetAttribute((const void*)k_ffn_fwd<W, EGT_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_MAX_LDS_ONCE(k_ffn_fwd<W, EGT_ACT_RELU>);
     EGT_LAUNCH("k_ffn_fwd", (k_ffn_fwd<W, EGT_ACT_RELU>), dim3(grid), dim3(512), lds, st, a);
   } else {
-    (void)hipFuncSetAttribute((const void*)k_ffn_fwd<W, EGT_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_MAX_LDS_ONCE(k_ffn_fwd<W, EGT_ACT_ELU>);
     EGT_LAUNCH("k_ffn_fwd", (k_ffn_fwd<W, EGT_ACT_ELU>), dim3(grid), dim3(512), lds, st, a);
   }
 }
@@ -882,7 +882,7 @@ static void ffn_launch_fwd_bf(const FfnArgs& a, int act, hipStream_t st) {
   EGT_LAUNCH("k_ffn_prep", k_ffn_prep_bf<W>, dim3(ffn_bf_prep_blocks(W)), dim3(256), 0, st, a);
 #define FBF(ACT_, SPLIT_)                                                                                             \
   do {                                                                                                                \
-    (void)hipFuncSetAttribute((const void*)k_ffn_fwd_bf<W, ACT_, SPLIT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    EGT_MAX_LDS_ONCE(k_ffn_fwd_bf<W, ACT_, SPLIT_>); \
     EGT_LAUNCH("k_ffn_fwd", (k_ffn_fwd_bf<W, ACT_, SPLIT_>), dim3(grid), dim3(512), lds, st, a);                       \
   } while (0)
   const bool split = a.mm == EGT_MM_BF16X3;
@@ -899,10 +899,10 @@ static void ffn_launch_bwd_mm(const FfnArgs& a, int act, hipStream_t st) {
   constexpr size_t part = 2 * (size_t)(2 * W * W) + 3 * W;
   const size_t lds = ((slabs > part ? slabs : part) + 2 * W + 4 * 3 * 16 * W) * 4;
   if (act == EGT_ACT_RELU) {
-    (void)hipFuncSetAttribute((const void*)k_ffn_bwd<W, EGT_ACT_RELU, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_MAX_LDS_ONCE(k_ffn_bwd<W, EGT_ACT_RELU, MM>);
     EGT_LAUNCH("k_ffn_bwd", (k_ffn_bwd<W, EGT_ACT_RELU, MM>), dim3(a.nwg), dim3(256), lds, st, a);
   } else {
-    (void)hipFuncSetAttribute((const void*)k_ffn_bwd<W, EGT_ACT_ELU, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EGT_MAX_LDS_ONCE(k_ffn_bwd<W, EGT_ACT_ELU, MM>);
     EGT_LAUNCH("k_ffn_bwd", (k_ffn_bwd<W, EGT_ACT_ELU, MM>), dim3(a.nwg), dim3(256), lds, st, a);
   }
 }

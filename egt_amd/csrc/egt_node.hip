@@ -781,7 +781,7 @@ static size_t lds_rows(int Dh, int mult) { return (size_t)mult * NODE_RC * (Dh +
 void egt_node_launch_pre(BlockArgs& a, hipStream_t st) {
   size_t lds = lds_rows(a.Dh, 1) + (size_t)a.Dh * (3 * a.Dh + LDP) * 4;
   if (lds < 1024) lds = 1024;  // prep workgroup scratch
-  (void)hipFuncSetAttribute((const void*)k_node_pre, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  EGT_MAX_LDS_ONCE(k_node_pre);
   EGT_LAUNCH("k_node_pre", k_node_pre, dim3(a.B * node_chunks(a) + (a.prep ? 1 : 0)), dim3(512), lds, st, a);
 }
 
@@ -808,7 +808,7 @@ void egt_node_launch_bwd(BlockArgs& a, const BlockArgs* dv_layer, bool do_pre, h
   const dim3 grid(a.B * node_chunks(a) + (prep ? 1 : 0));
 #define NODE_BWD(PRE_, DV_, NP_, NAME)                                                                     \
   do {                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)k_node_bwd<PRE_, DV_, NP_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    EGT_MAX_LDS_ONCE(k_node_bwd<PRE_, DV_, NP_>); \
     EGT_LAUNCH(NAME, (k_node_bwd<PRE_, DV_, NP_>), grid, dim3(512), lds, st, a, x);                    \
   } while (0)
   const bool np4 = a.NQP == 4 && a.NLR == 4;   // N = 64 with 16-row workgroups
