@@ -193,11 +193,13 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
       dho[i] = a.up_dh_out[rc(lnrow) * 64 + p + 16 * i];
       gmm[i] = a.up_nm_g[p + 16 * i];
     }
-    const int NP = a.NQP;   // key tiles = ceil(N / 16)
+    // partial counts of the layer above (same geometry, same kernels): dQ partials per row = a.NQP (key tiles for the
+    // MFMA-tile kernels, 1 for k_narrow_bwd, which reduces its key tiles itself), dK/dV partials per key = a.NLR (row groups)
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int i = t + u * 256, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
       const int rr = min(r, nv - 1);
+      const int NP = sx == 0 ? a.NQP : a.NLR;
       const float* base = sx == 0 ? a.up_dqp + ((size_t)b * NP * N + l_begin + rr) * 64 + pos4
                                   : a.up_dkvp + (((size_t)b * NP * N + l_begin + rr) * 2 + (sx - 1)) * 64 + (pos4 & 63);
       const size_t pstride = sx == 0 ? (size_t)N * 64 : (size_t)N * 128;
