@@ -521,7 +521,7 @@ def main():
                                          share=v[1] / sum(x[1] for x in prof.values()))
                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only (the other ranks would idle at the last barrier)
             if args.scope == "model" and cifar:
                 cpu = None      # (no CPU leg for the CIFAR10 model scope: not a bench line of BASELINE.json's metric)
             else:
