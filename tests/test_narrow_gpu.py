@@ -33,3 +33,90 @@ def test_valu_backward_forced_for_fp32():
 
 def test_mfma_tile_kernels_with_the_valu_kernels_off():
     _run({"EGT_NO_NARROW": "1"})
+
+
+# ---- the less-travelled branches of the De = 8 kernels, in process (default selection) -----------------------------
+import torch  # noqa: E402
+
+from util import assert_close, BWD  # noqa: E402
+
+PMAP = {"norm_edge.gamma": ("norm_edge", "gamma"), "norm_edge.beta": ("norm_edge", "beta"),
+        "attention_gates.kernel": ("attention_gates", "kernel"), "attention_gates.bias": ("attention_gates", "bias"),
+        "dense_edge_b.kernel": ("dense_edge_b", "kernel"), "dense_edge_b.bias": ("dense_edge_b", "bias"),
+        "norm_mha.gamma": ("norm_mha", "gamma"), "norm_mha.beta": ("norm_mha", "beta"),
+        "dense_qkv.kernel": ("dense_qkv", "kernel"), "dense_qkv.bias": ("dense_qkv", "bias"),
+        "dense_mha.kernel": ("dense_mha", "kernel"), "dense_mha.bias": ("dense_mha", "bias"),
+        "dense_edge_r.kernel": ("dense_edge_r", "kernel"), "dense_edge_r.bias": ("dense_edge_r", "bias")}
+
+
+@pytest.mark.parametrize("variant,N,Dh,bf16,train", [
+    ("ungated", 37, 64, False, True),        # call_ungated: no gate input (run-time feature instance of the kernels)
+    ("ungated", 52, 64, True, False),
+    ("noclip", 41, 64, False, True),         # clip_logits_value = None
+    ("bias", 40, 64, False, True),           # EGT-simple: projections of the raw e (no norm_edge), e returned unchanged
+    ("bias", 33, 64, True, False),
+    ("d6", 37, 48, False, True),             # Dh = 48 -> d = 6: zero-padded packed QKV, node side in separate launches
+    ("d6", 50, 48, True, True),
+    ("plain", 188, 64, True, True),          # PATTERN's longest graphs: 12 row groups, ragged last key block
+    ("plain", 7, 64, False, False)])         # fewer keys than one wave's share: empty key ranges in the forward
+def test_narrow_kernel_branches_vs_oracle(variant, N, Dh, bf16, train, gpu, egt_lib):
+    from egt_amd import EGTStack
+    from egt_amd.fused import layer_seed
+    from oracle import egt_oracle as O, rng_ref
+    B, Ly, p, De = 2, 2, 0.2, 8
+    kw, okw = {}, {}
+    if variant == "ungated":
+        kw["gate_attention"] = False; okw["gate_attention"] = False
+    if variant == "noclip":
+        kw["clip_logits_value"] = None; okw["clip_logits_value"] = None
+    if variant == "bias":
+        kw["edge_channel_type"] = "bias"; okw["edge_channel_type"] = "bias"
+    torch.manual_seed(101 + N)
+    st = EGTStack(model_height=Ly, model_width=Dh, edge_width=De, num_heads=8, random_mask_prob=p if train else 0.0,
+                  seed=3, fused=True, **kw).to(gpu).train(train)
+    with torch.no_grad():
+        for prm in st.parameters():
+            if prm.dim() == 1:
+                prm.add_(0.2 * torch.randn_like(prm))
+    g = torch.Generator().manual_seed(N * 3 + Dh)
+    h = torch.randn(B, N, Dh, generator=g); e = torch.randn(B, N, N, De, generator=g) * 1.3
+    dh = torch.randn(B, N, Dh, generator=g); de = torch.randn(B, N, N, De, generator=g)
+    if bf16:
+        e, de = e.bfloat16(), de.bfloat16()
+    mask = torch.ones(B, N, dtype=torch.bool); mask[1, max(1, N - 3):] = False
+    hg = h.to(gpu).requires_grad_(); eg = e.to(gpu).requires_grad_()
+    h2, e2 = st(hg, eg, mask.to(gpu))
+    assert st.last_path == "fused-stack"
+    torch.autograd.backward([h2, e2], [dh.to(gpu), de.to(gpu)])
+    names = dict(PMAP)
+    if variant == "bias":
+        names = {k: v for k, v in PMAP.items() if not (k.startswith("norm_edge") or k.startswith("dense_edge_r"))}
+    if variant == "ungated":
+        names = {k: v for k, v in names.items() if not k.startswith("attention_gates")}
+    layers = [{k: getattr(getattr(blk, m), a_).detach().double().cpu().requires_grad_() for k, (m, a_) in names.items()}
+              for blk in st.blocks]
+    rms = None
+    if train:
+        b0 = st.blocks[0].mha
+        seed = (b0.seed * 0x9E3779B97F4A7C15 + b0._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        rms = [torch.from_numpy(rng_ref.random_mask(layer_seed(seed, l), B, N, 8, p)) for l in range(Ly)]
+    h64 = h.double().requires_grad_(); e64 = e.double().requires_grad_()
+    ho, eo = O.stack_forward(h64, e64, mask, layers, num_heads=8, rand_masks=rms, **okw)
+    flat = [t for lp in layers for t in lp.values()]
+    gr = torch.autograd.grad([ho, eo], [h64, e64] + flat, [dh.double(), de.double()], allow_unused=True)
+    if bf16:
+        tol, ptol = dict(rtol=2e-2, arel=1e-2, zero_atol=2e-4), dict(rtol=3e-2, arel=2e-2, l2=3e-2, zero_atol=2e-4)   # (an analytically zero gradient, e.g. the edge-bias bias of the 'bias' variant, gets an absolute bound)
+    else:
+        tol, ptol = dict(rtol=2e-4, arel=5e-5), BWD
+    gtol = tol if bf16 else BWD
+    assert_close(h2, ho, name="h_out", **tol)
+    assert_close(e2.float(), eo, name="e_out", **tol)
+    assert_close(hg.grad, gr[0], name="dh", **gtol)
+    assert_close(eg.grad.float(), gr[1], name="de", **gtol)
+    gi = iter(gr[2:])
+    for li, blk in enumerate(st.blocks):
+        for k, (m, a_) in names.items():
+            ref = next(gi)
+            if ref is None:
+                continue
+            assert_close(getattr(getattr(blk, m), a_).grad, ref, name=f"L{li}.{k}", **ptol)
