@@ -26,10 +26,16 @@
 #include "egt_block_dev.h"
 
 #define NRW_DE 8
+#ifndef NRW_FWD_OCC
+#define NRW_FWD_OCC 3
+#endif
 #ifndef NRW_ABL          // timing ablations (measurement builds only, tools/build_variant.sh -DNRW_ABL=<bits>):
 #define NRW_ABL 0        // 1 no e' stores, 2 no e loads, 4 no K/V chunk traffic, 8 no mask hash, 16 no exp/sigmoid, 32 no epilogue
 #endif
-#define NRW_KB 4                      // keys per K/V chunk and per e prefetch block (one 128-byte line of a pair row)
+#ifndef NRW_KB
+#define NRW_KB 4
+#endif
+//      NRW_KB: keys per K/V chunk and per e prefetch block (one 128-byte line of a pair row)
 #define NRW_KV_CHUNK (NRW_KB * 128)   // floats: [key][K 64 | V 64]
 
 
@@ -100,9 +106,9 @@ template <> struct NrwLd<true> {
 // NRW_KB keys: logits of the four keys first, then ONE softmax rescale for the block (flash-style blocking).
 // LDS: [NRW_FWD_AREA] = [4 waves][NRW_KV_CHUNK] K/V chunks + [4][NRW_KB] key-mask adds during the key loop, the
 //      merge buffer [3][20][64] after it, then the epilogue's staging rows; [16][QS_LD] V_att rows for the epilogue.
-#define NRW_FWD_AREA (3 * 20 * 64)
+#define NRW_FWD_AREA ((3 * 20 * 64) > (4 * NRW_KV_CHUNK + 4 * NRW_KB) ? (3 * 20 * 64) : (4 * NRW_KV_CHUNK + 4 * NRW_KB))
 template <bool BF, int FEAT>
-__global__ void __launch_bounds__(256, 3) k_narrow_fwd(BlockArgs a) {
+__global__ void __launch_bounds__(256, NRW_FWD_OCC) k_narrow_fwd(BlockArgs a) {
   typedef NrwLd<BF> LD;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -114,6 +120,8 @@ __global__ void __launch_bounds__(256, 3) k_narrow_fwd(BlockArgs a) {
   float* kvw = sm + wave * NRW_KV_CHUNK;
   float* kmw = sm + 4 * NRW_KV_CHUNK + wave * NRW_KB;
   float* qs = sm + NRW_FWD_AREA;
+  float* wrt = qs + 16 * QS_LD;     // [4 q][20]: dense_edge_r weights, quad-relative (fp32 instance only: 16 registers less)
+  constexpr bool WR_LDS = !BF;
   const bool gated = FEAT >= 0 ? (FEAT & NRW_F_GATED) != 0 : (a.flags & EGT_BF_GATE) != 0;
   const bool clip = FEAT >= 0 ? (FEAT & NRW_F_CLIP) != 0 : (a.flags & EGT_BF_CLIP) != 0;
   const bool ln_on = (a.flags & EGT_BF_NO_EDGE_LN) == 0;
@@ -128,6 +136,10 @@ __global__ void __launch_bounds__(256, 3) k_narrow_fwd(BlockArgs a) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const float4 v = qp[u]; Qf[4*u] = v.x; Qf[4*u+1] = v.y; Qf[4*u+2] = v.z; Qf[4*u+3] = v.w; }
   }
+  if (WR_LDS && threadIdx.x < 64) {
+    const int qq = threadIdx.x >> 4, r16 = threadIdx.x & 15, j = r16 >> 3, g = (r16 >> 1) & 3, c = r16 & 1;
+    wrt[qq * 20 + r16] = a.Wr[(2 * qq + j) * NRW_DE + 2 * (g ^ qq) + c];
+  }
   float wp[2][4][4], wr[2][4][2], c2r[4], brr[2];
 #pragma unroll
   for (int c = 0; c < 2; ++c)
@@ -140,10 +152,11 @@ __global__ void __launch_bounds__(256, 3) k_narrow_fwd(BlockArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) wr[j][g][c] = a.Wr[(2 * q + j) * NRW_DE + 2 * (g ^ q) + c];
+      for (int c = 0; c < 2; ++c) wr[j][g][c] = WR_LDS ? 0.f : a.Wr[(2 * q + j) * NRW_DE + 2 * (g ^ q) + c];
 #pragma unroll
   for (int r = 0; r < 4; ++r) c2r[r] = a.pw[16 * 16 + 4 * q + r];
   brr[0] = a.br[2 * q]; brr[1] = a.br[2 * q + 1];
+  if (WR_LDS) __syncthreads();   // the weight table is complete
 
   // ---- the wave's key blocks ----
   const int nblk = (N + NRW_KB - 1) / NRW_KB;
@@ -156,38 +169,42 @@ __global__ void __launch_bounds__(256, 3) k_narrow_fwd(BlockArgs a) {
   const size_t ugraph = (size_t)b * N * N;       // wave-uniform: first pair of the graph
   const int loff = min(l, N - 1) * N * NRW_DE + 2 * q;   // the lane's element offset from the pair (row 0, key m)
   typename LD::raw eb[NRW_KB];
-  float4 kvr[2];
+  constexpr int NU = NRW_KB / 2;   // float4s per lane of a K/V chunk
+  v4f kvr[NU];   // (a plain vector type: hipcc leaves an array of HIP's float4 struct, captured by the lambdas, in scratch memory)
   float kmr = 0.f;
-  auto fetch = [&](int blk) {
+  auto fetch_e = [&](int blk) __attribute__((always_inline)) {
     const int m0 = blk * NRW_KB;
 #pragma unroll
     for (int kk = 0; kk < NRW_KB; ++kk) eb[kk] = LD::uload(a.e, (NRW_ABL & 2) ? (size_t)kk : ugraph + min(m0 + kk, N - 1), loff);
+  };
+  auto fetch_kv = [&](int blk) __attribute__((always_inline)) {   // K / V of the block come from L2: requested half a block ahead
+    const int m0 = blk * NRW_KB;
     const int kmax = N - 1 - m0;   // keys of the block past the graph's last one are clamped to it
     const float* kvb = a.qkvp + ((size_t)b * N + m0) * QKVP;   // wave-uniform
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int f = lane + 64 * u, key = min(f >> 5, kmax), piece = f & 31;
-      if (!(NRW_ABL & 4) || blk == blk0) kvr[u] = *reinterpret_cast<const float4*>(kvb + key * QKVP + 64 + piece * 4);
+      if (!(NRW_ABL & 4) || blk == blk0) kvr[u] = *reinterpret_cast<const v4f*>(kvb + key * QKVP + 64 + piece * 4);
     }
-    if (a.km) kmr = (a.km[(size_t)b * N + m0 + min(lane & 3, kmax)] == 0) ? -EGT_NEG : 0.0f;
+    if (a.km) kmr = (a.km[(size_t)b * N + m0 + min(lane & (NRW_KB - 1), kmax)] == 0) ? -EGT_NEG : 0.0f;
   };
-  if (blk0 < blk1) fetch(blk0);
+  if (blk0 < blk1) { fetch_e(blk0); fetch_kv(blk0); }
 
   // one block of keys; nv = number of real keys in it (NRW_KB except in the graph's last block)
-  auto block = [&](int blk, int nv) {
+  auto block = [&](int blk, int nv) __attribute__((always_inline)) {
     const int m0 = blk * NRW_KB;
     // commit the chunk to the wave's LDS slot (DS operations of a wave retire in order: the previous
     // chunk's reads are behind these writes), take the e registers, then put the next block in flight
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int f = lane + 64 * u;
-      *reinterpret_cast<float4*>(kvw + (f >> 5) * 128 + (f & 31) * 4) = kvr[u];
+      *reinterpret_cast<v4f*>(kvw + (f >> 5) * 128 + (f & 31) * 4) = kvr[u];
     }
     if (lane < NRW_KB) kmw[lane] = kmr;
     float2 ev[NRW_KB];
 #pragma unroll
     for (int kk = 0; kk < NRW_KB; ++kk) ev[kk] = LD::cvt(eb[kk]);
-    if (blk + 1 < blk1) fetch(blk + 1);
+    if (blk + 1 < blk1) fetch_e(blk + 1);
     lds_sync();
     float xl[NRW_KB][2], gl[NRW_KB][2];
 #pragma unroll
@@ -235,20 +252,33 @@ __global__ void __launch_bounds__(256, 3) k_narrow_fwd(BlockArgs a) {
       // ---- dense_edge_r + res_edge: e' = e + H_hat.Wr + br, the lane's two channels ----
       float2 eo;
       {
-        const float t0 = nrw_combine(fmaf(hh[1], wr[1][0][0], fmaf(hh[0], wr[0][0][0], brr[0])), fmaf(hh[1], wr[1][1][0], hh[0] * wr[0][1][0]),
-                                     fmaf(hh[1], wr[1][2][0], hh[0] * wr[0][2][0]), fmaf(hh[1], wr[1][3][0], hh[0] * wr[0][3][0]));
-        const float t1 = nrw_combine(fmaf(hh[1], wr[1][0][1], fmaf(hh[0], wr[0][0][1], brr[1])), fmaf(hh[1], wr[1][1][1], hh[0] * wr[0][1][1]),
-                                     fmaf(hh[1], wr[1][2][1], hh[0] * wr[0][2][1]), fmaf(hh[1], wr[1][3][1], hh[0] * wr[0][3][1]));
+        float w0[4][2], w1[4][2];   // [g][c] of head 2q (w0) and 2q + 1 (w1)
+        if (WR_LDS) {
+          const float4 a0 = *reinterpret_cast<const float4*>(wrt + q * 20), a1 = *reinterpret_cast<const float4*>(wrt + q * 20 + 4);
+          const float4 b0 = *reinterpret_cast<const float4*>(wrt + q * 20 + 8), b1 = *reinterpret_cast<const float4*>(wrt + q * 20 + 12);
+          w0[0][0] = a0.x; w0[0][1] = a0.y; w0[1][0] = a0.z; w0[1][1] = a0.w; w0[2][0] = a1.x; w0[2][1] = a1.y; w0[3][0] = a1.z; w0[3][1] = a1.w;
+          w1[0][0] = b0.x; w1[0][1] = b0.y; w1[1][0] = b0.z; w1[1][1] = b0.w; w1[2][0] = b1.x; w1[2][1] = b1.y; w1[3][0] = b1.z; w1[3][1] = b1.w;
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) { w0[g][0] = wr[0][g][0]; w0[g][1] = wr[0][g][1]; w1[g][0] = wr[1][g][0]; w1[g][1] = wr[1][g][1]; }
+        }
+        const float t0 = nrw_combine(fmaf(hh[1], w1[0][0], fmaf(hh[0], w0[0][0], brr[0])), fmaf(hh[1], w1[1][0], hh[0] * w0[1][0]),
+                                     fmaf(hh[1], w1[2][0], hh[0] * w0[2][0]), fmaf(hh[1], w1[3][0], hh[0] * w0[3][0]));
+        const float t1 = nrw_combine(fmaf(hh[1], w1[0][1], fmaf(hh[0], w0[0][1], brr[1])), fmaf(hh[1], w1[1][1], hh[0] * w0[1][1]),
+                                     fmaf(hh[1], w1[2][1], hh[0] * w0[2][1]), fmaf(hh[1], w1[3][1], hh[0] * w0[3][1]));
         eo.x = ev[kk].x + t0;
         eo.y = ev[kk].y + t1;
       }
       if (row_ok && kk < nv && !(NRW_ABL & 1)) LD::ustore(a.e_out, ugraph + m, loff, eo);
       if ((NRW_ABL & 1) && eo.x == 123.456f) LD::ustore(a.e_out, ugraph + m, loff, eo);
     }
+    if (blk + 1 < blk1) fetch_kv(blk + 1);   // (after the logits phase: its registers are free again)
     // ---- one online-softmax step for the block, x gate, A.V: the row's state never leaves the lane ----
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const float mn = nrw_max(nrw_max(mx[j], nrw_max(xl[0][j], xl[1][j])), nrw_max(xl[2][j], xl[3][j]));
+      float mn = mx[j];
+#pragma unroll
+      for (int kk = 0; kk < NRW_KB; ++kk) mn = nrw_max(mn, xl[kk][j]);
       const float alpha = (NRW_ABL & 16) ? (mx[j] - mn) : __expf(mx[j] - mn);
       mx[j] = mn;
       sum[j] *= alpha;
@@ -327,7 +357,7 @@ static_assert(4 * NRW_KV_CHUNK + 4 * NRW_KB <= NRW_FWD_AREA, "key-loop buffers f
 // a.epi must already hold the epilogue the geometry allows (launch_fwd decides)
 void egt_narrow_launch_fwd(BlockArgs& a, hipStream_t st) {
   const dim3 grid(a.B * ((a.N + 15) / 16)), block(256);
-  const size_t lds = ((size_t)NRW_FWD_AREA + 16 * QS_LD) * 4;
+  const size_t lds = ((size_t)NRW_FWD_AREA + 16 * QS_LD + 80) * 4;
   const int full = NRW_F_GATED | NRW_F_CLIP;
   const int feat = ((a.flags & EGT_BF_GATE) ? NRW_F_GATED : 0) | ((a.flags & EGT_BF_CLIP) ? NRW_F_CLIP : 0);
 #define NRW_FWD(BF_, FEAT_) EGT_LAUNCH("k_block_fwd", (k_narrow_fwd<BF_, FEAT_>), grid, block, lds, st, a)
