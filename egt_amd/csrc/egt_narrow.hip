@@ -446,6 +446,12 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
   const float* wpq = tab + NRW_TAB_WP + q * 36;
   const float* wrq = tab + NRW_TAB_WR + q * 20;
   const float* wdq = tab + NRW_TAB_WD + q * 36;
+  // two waves per SIMD leave 256 registers: the projection and dH_ext weights live in them (12 LDS reads per step less)
+  float4 wpr[2][4], wrr[2][2];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { wpr[0][g] = *reinterpret_cast<const float4*>(wpq + g * 4); wpr[1][g] = *reinterpret_cast<const float4*>(wpq + 16 + g * 4); }
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) { wrr[0][h2] = *reinterpret_cast<const float4*>(wrq + h2 * 4); wrr[1][h2] = *reinterpret_cast<const float4*>(wrq + 8 + h2 * 4); }
 
   const int ntile = (N + 15) / 16;
   for (int mt = wave; mt < ntile; mt += 4) {
@@ -503,8 +509,7 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
         float s[4][4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float4 w0 = *reinterpret_cast<const float4*>(wpq + g * 4);
-          const float4 w1 = *reinterpret_cast<const float4*>(wpq + 16 + g * 4);
+          const float4 w0 = wpr[0][g], w1 = wpr[1][g];
           s[g][0] = fmaf(x1, w1.x, x0 * w0.x); s[g][1] = fmaf(x1, w1.y, x0 * w0.y);
           s[g][2] = fmaf(x1, w1.z, x0 * w0.z); s[g][3] = fmaf(x1, w1.w, x0 * w0.w);
         }
@@ -517,8 +522,7 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
         float ph[4][2];
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {   // h2: g pair {0,1} / {2,3}
-          const float4 w0 = *reinterpret_cast<const float4*>(wrq + h2 * 4);        // c = 0: [g][j]
-          const float4 w1 = *reinterpret_cast<const float4*>(wrq + 8 + h2 * 4);    // c = 1
+          const float4 w0 = wrr[0][h2], w1 = wrr[1][h2];   // c = 0 / c = 1: [g][j]
           ph[2 * h2][0] = fmaf(dyv.y, w1.x, dyv.x * w0.x); ph[2 * h2][1] = fmaf(dyv.y, w1.y, dyv.x * w0.y);
           ph[2 * h2 + 1][0] = fmaf(dyv.y, w1.z, dyv.x * w0.z); ph[2 * h2 + 1][1] = fmaf(dyv.y, w1.w, dyv.x * w0.w);
         }
