@@ -16,9 +16,10 @@ Reference (relative to /root/reference/):
   fit loop, finalize (final weight file)      lib/training/training_base.py:293-327
   data-parallel training                      :230-247 (MirroredStrategy) -> egt_amd.dp, one process per GPU
 
-What is NOT here: the HDF5 dataset reader (h5py and the datasets are absent); ``load_data``
-takes any iterable of batches in the reference's input format, and ``SyntheticZinc`` generates molecules of
-that format.  Weight files are ``.npz`` keyed by the reference's Keras variable names instead of ``.h5``.
+Data: ``load_data`` opens ``config.dataset_path`` through egt_amd.data (a PackedStore ``.npz``, or the
+reference's ``.h5`` where h5py exists) or takes any iterable of batches in the reference's input format
+(``SyntheticZinc`` / ``SyntheticPattern`` / ``SyntheticCifar10`` generate such batches; the datasets themselves are
+not in this image).  Weight files are ``.npz`` keyed by the reference's Keras variable names instead of ``.h5``.
 """
 from __future__ import annotations
 
@@ -636,14 +637,18 @@ def import_scheme(name: str):
 
 
 def main(argv=None):
-    """python -m egt_amd.training cfg.json [--synthetic N_GRAPHS]  (run_training.py:5-10; the dataset reader is not
-    built, so the run trains on SyntheticZinc molecules in the reference's batch format)."""
+    """python -m egt_amd.training cfg.json [--synthetic N_GRAPHS]  (run_training.py:5-10).  The scheme's dataset is read
+    from config.dataset_path when that file exists (egt_amd.data); otherwise, or with --synthetic, the run trains on
+    synthetic graphs in the reference's batch format."""
     argv = list(sys.argv[1:] if argv is None else argv)
     if not argv:
         raise SystemExit("usage: python -m egt_amd.training cfg.json [--synthetic N_GRAPHS]")
     config = read_config_from_file(argv[0])
-    n_graphs = int(argv[argv.index("--synthetic") + 1]) if "--synthetic" in argv else 2048
     scheme = import_scheme(config["scheme"])(config, device=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+    if "--synthetic" not in argv and os.path.exists(scheme.config.dataset_path):
+        scheme.execute_training()
+        return
+    n_graphs = int(argv[argv.index("--synthetic") + 1]) if "--synthetic" in argv else 2048
     bs = scheme.config.batch_size
     data = {"pattern.svd": SyntheticPattern, "cifar10.svd": SyntheticCifar10}.get(config["scheme"], SyntheticZinc)
     scheme.execute_training(data(n_graphs, bs, seed=1), data(max(bs, n_graphs // 8), bs, seed=2))
