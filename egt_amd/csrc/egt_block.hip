@@ -1649,7 +1649,8 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
   const int p = lane & 15, q = lane >> 4;
   const int N = a.N, TL = a.TL;   // TL == 16
   const int wg = a.xcd ? egt_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int b = wg / a.NLR, lr = wg % a.NLR;
+  int b, lr;
+  egt_group_order(wg, a.B, a.NLR, N, b, lr);
   const int l_begin = lr * TL, l_end = min(N, l_begin + TL), nl = l_end - l_begin;
   const bool gated = (a.flags & EGT_BF_GATE) != 0;
   const bool clip = (a.flags & EGT_BF_CLIP) != 0;

@@ -116,7 +116,8 @@ __global__ void __launch_bounds__(256, NRW_FWD_OCC) k_narrow_fwd(BlockArgs a) {
   const int N = a.N;
   const int lgroups = (N + 15) / 16;
   const int wg = a.xcd ? egt_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int b = wg / lgroups, lg = wg % lgroups;
+  int b, lg;
+  egt_group_order(wg, a.B, lgroups, N, b, lg);
   float* kvw = sm + wave * NRW_KV_CHUNK;
   float* kmw = sm + 4 * NRW_KV_CHUNK + wave * NRW_KB;
   float* qs = sm + NRW_FWD_AREA;
@@ -393,7 +394,8 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
   const int p = lane >> 2, q = lane & 3;
   const int N = a.N, TL = a.TL;   // TL == 16
   const int wg = a.xcd ? egt_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int b = wg / a.NLR, lr = wg % a.NLR;
+  int b, lr;
+  egt_group_order(wg, a.B, a.NLR, N, b, lr);
   const int l_begin = lr * TL, l_end = min(N, l_begin + TL), nl = l_end - l_begin;
   const bool gated = FEAT >= 0 ? (FEAT & NRW_F_GATED) != 0 : (a.flags & EGT_BF_GATE) != 0;
   const bool clip = FEAT >= 0 ? (FEAT & NRW_F_CLIP) != 0 : (a.flags & EGT_BF_CLIP) != 0;
