@@ -409,6 +409,9 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
   float* kt = hs + 256;                    // [16 keys][4 q][8 k][2 j]: the tile's K rows, B operand of the dQ products
   float* qd = sm + AREA;                   // [TL][QD_LD]
   float* tab = qd + TL * QD_LD;
+  float* park = tab + NRW_TAB_FLOATS;              // [waves 1..3][32][64]: dK / dV of a key tile shared with the previous wave
+  volatile int* pflag = reinterpret_cast<volatile int*>(park + 3 * 2048);   // [4]: wave w parked its partial
+  if (threadIdx.x < 4) pflag[threadIdx.x] = 0;
   for (int i = threadIdx.x; i < nl * 40; i += 256) {
     const int r = i / 40, f = i % 40;
     const size_t rowl = (size_t)b * N + l_begin + r;
@@ -456,7 +459,22 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
   for (int h2 = 0; h2 < 2; ++h2) { wrr[0][h2] = *reinterpret_cast<const float4*>(wrq + h2 * 4); wrr[1][h2] = *reinterpret_cast<const float4*>(wrq + 8 + h2 * 4); }
 
   const int ntile = (N + 15) / 16;
-  for (int mt = wave; mt < ntile; mt += 4) {
+  // Work of a wave.  ntile a multiple of 4 (or < 4): key tiles w, w+4, ..., all rows.  Otherwise (N = 150: 10 tiles -> 3,3,2,2)
+  // the ntile x nl (tile, row) steps are cut into four CONTIGUOUS equal ranges; a tile that straddles two ranges is shared by
+  // two neighbouring waves: the later wave meets it FIRST and parks its dK / dV partial in LDS, the earlier wave meets it LAST,
+  // adds the parked partial and stores the tile's dK / dV.
+#ifdef NRW_NO_BALANCE
+  const bool balance = false;
+#else
+  // (measured at config 3: bf16 edge tensors 341 -> 315 us, fp32 357 -> 375 us -- unexplained; fp32 keeps whole tiles per wave)
+  const bool balance = BF && ntile >= 4 && (ntile & 3) != 0;
+#endif
+  const int T = ntile * nl;
+  const int t0 = balance ? (wave * T) >> 2 : 0, t1 = balance ? ((wave + 1) * T) >> 2 : 0;
+  const int mt_first = balance ? t0 / nl : wave, mt_last = balance ? (t1 - 1) / nl : ntile - 1, mt_step = balance ? 1 : 4;
+  for (int mt = mt_first; mt <= mt_last; mt += mt_step) {
+    const int r0 = (balance && mt == mt_first) ? t0 - mt * nl : 0;          // rows [r0, r1) of the workgroup's nl
+    const int r1 = (balance && mt == mt_last) ? t1 - mt * nl : nl;
     const int m0 = mt * 16, m = m0 + p;
     const bool kvalid = m < N;
     const int mc = kvalid ? m : N - 1;
@@ -483,11 +501,11 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
     typename LD::raw en[2], dn[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const size_t pr = ugraph + (size_t)min(l_begin + i, l_end - 1) * N;
+      const size_t pr = ugraph + (size_t)min(l_begin + r0 + i, l_end - 1) * N;
       en[i] = LD::uload(a.e, pr, loff);
       dn[i] = LD::uload(a.de_out, pr, loff);
     }
-    for (int li = 0; li < nl; ++li) {
+    for (int li = r0; li < r1; ++li) {
       const int l = l_begin + li;
       const uint32_t pair = pcol + (uint32_t)(l * N);
       float2 ev = LD::cvt(en[0]), dyv = LD::cvt(dn[0]);
@@ -524,7 +542,8 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
         float ph[4][2];
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {   // h2: g pair {0,1} / {2,3}
-          const float4 w0 = wrr[0][h2], w1 = wrr[1][h2];   // c = 0 / c = 1: [g][j]
+          // c = 0 / c = 1: [g][j]
+          const float4 w0 = wrr[0][h2], w1 = wrr[1][h2];
           ph[2 * h2][0] = fmaf(dyv.y, w1.x, dyv.x * w0.x); ph[2 * h2][1] = fmaf(dyv.y, w1.y, dyv.x * w0.y);
           ph[2 * h2 + 1][0] = fmaf(dyv.y, w1.z, dyv.x * w0.z); ph[2 * h2 + 1][1] = fmaf(dyv.y, w1.w, dyv.x * w0.w);
         }
@@ -585,7 +604,7 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) ssum[r] += dge[r];
       // ---- operands of the matrix-pipe contractions -> LDS (lane-linear tiles) ----
-      const int bi = li % NRW_NB;
+      const int bi = (li - r0) % NRW_NB;
       *reinterpret_cast<float2*>(xs + p * 16 + 2 * q) = make_float2(x0, x1);
       *reinterpret_cast<float2*>(xs + p * 16 + 8 + 2 * q) = dyv;
       *reinterpret_cast<float4*>(dg + p * 16 + 4 * q) = make_float4(dge[0], dge[1], dge[2], dge[3]);
@@ -636,7 +655,7 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
       accT = MFMA(wa[2], wb1[2], accT); accR = MFMA(wa[2], wb2[2], accR);
       accT = MFMA(wa[3], wb1[3], accT); accR = MFMA(wa[3], wb2[3], accR);
       // ---- dQ of the batch's rows: dQ[row][k] = sum_keys dA[row][key] K[key][k] per (head pair, j), on the matrix pipe ----
-      if (bi == NRW_NB - 1 || li == nl - 1) {
+      if (bi == NRW_NB - 1 || li == r1 - 1) {
         const int lbase = l_begin + li - bi, nr = bi + 1;
         const int ri = lane & 15, kq = lane >> 4;
         asm volatile("" ::: "memory");
@@ -662,13 +681,28 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
       }
       asm volatile("" ::: "memory");   // next step's tile writes stay behind this step's reads
     }
-    if (kvalid) {
-      float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
-      float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
+    if (r0 > 0) {   // the tile's first rows belong to the previous wave: park this partial for it (it picks it up at its very end)
+      float* pk = park + (wave - 1) * 2048 + lane;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
-        vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
+      for (int i = 0; i < 16; ++i) { pk[i * 64] = dKa[i]; pk[(16 + i) * 64] = dVa[i]; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) pflag[wave] = 1;
+    } else {
+      if (r1 < nl) {   // the tile's last rows were done by the next wave, long ago
+        while (pflag[wave + 1] == 0) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const float* pk = park + wave * 2048 + lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dKa[i] += pk[i * 64]; dVa[i] += pk[(16 + i) * 64]; }
+      }
+      if (kvalid) {
+        float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
+        float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
+          vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
+        }
       }
     }
   }
@@ -702,7 +736,7 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
 
 void egt_narrow_launch_bwd(BlockArgs& a, int nwg, hipStream_t st) {
   constexpr int AREA = 4 * NRW_BWD_WAVE > BWD_PRO_WS ? 4 * NRW_BWD_WAVE : BWD_PRO_WS;
-  const size_t lds = ((size_t)AREA + BWD_TL * QD_LD + NRW_TAB_FLOATS) * 4;
+  const size_t lds = ((size_t)AREA + BWD_TL * QD_LD + NRW_TAB_FLOATS + 3 * 2048 + 4) * 4;
   const int full = NRW_F_GATED | NRW_F_CLIP;
   const int feat = ((a.flags & EGT_BF_GATE) ? NRW_F_GATED : 0) | ((a.flags & EGT_BF_CLIP) ? NRW_F_CLIP : 0);
 #define NRW_BWD(BF_, FEAT_) EGT_LAUNCH("k_block_bwd", (k_narrow_bwd<BF_, FEAT_>), dim3(nwg), dim3(256), lds, st, a)
