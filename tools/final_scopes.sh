@@ -1,4 +1,4 @@
-mkdir -p gpurun_out/r02_final2
+mkdir -p gpurun_out/r02_final2; : > gpurun_out/r02_final2/scopes.jsonl
 for args in "--scope model --workload cifar10_n150_fp32" "--scope model --workload cifar10_n150" "--scope model --workload pattern500k_n120_b128" "--scope model" "--scope model --ffn-matmul bf16x3" "--workload cifar10_n150" "--workload cifar10_n150_fp32" "--workload pattern500k_n120_b128" "--workload pattern500k_n120" ""; do
   timeout 300 python bench.py $args --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import json,sys
