@@ -1667,6 +1667,9 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
   float* wsA = qd + TL * QD_LD;
   float* wsB = wsA + WSLAB;
   float* wsD = wsB + WSLAB;
+  float* park = wsD + WSLAB;           // [waves 1..3][32][64]: dK / dV of a key tile shared with the previous wave (balanced ranges)
+  volatile int* pflag = reinterpret_cast<volatile int*>(park + 3 * 2048);
+  if (threadIdx.x < 4) pflag[threadIdx.x] = 0;
   for (int i = threadIdx.x; i < nl * 40; i += 256) {
     const int r = i / 40, f = i % 40;
     const size_t rowl = (size_t)b * N + l_begin + r;
@@ -1702,7 +1705,22 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
   // Ragged N: the last key tile has kv < 16 valid keys (loads clamped / zero-filled, the lanes of the
   // missing keys get probability and gate exactly 0), the last row group has nl < 16 rows (skipped).
   const int ntile = (N + 15) / 16;
-  for (int mt = wave; mt < ntile; mt += 4) {
+  // Work of a wave: key tiles w, w+4, ... when the tile count is a multiple of 4 (or < 4); otherwise the ntile x (row pairs)
+  // steps are cut into four contiguous equal ranges and a tile that straddles two ranges is shared by neighbouring waves
+  // (the later wave meets it first and parks its dK / dV partial in LDS, the earlier one meets it last and adds it) -- as in
+  // k_narrow_bwd.
+  const int npair = (nl + R - 1) / R;
+#ifdef EGT_V4R_NO_BALANCE
+  const bool balance = false;
+#else
+  const bool balance = ntile >= 4 && (ntile & 3) != 0;
+#endif
+  const int TT = ntile * npair;
+  const int t0 = balance ? (wave * TT) >> 2 : 0, t1 = balance ? ((wave + 1) * TT) >> 2 : 0;
+  const int mt_first = balance ? t0 / npair : wave, mt_last = balance ? (t1 - 1) / npair : ntile - 1, mt_step = balance ? 1 : 4;
+  for (int mt = mt_first; mt <= mt_last; mt += mt_step) {
+    const int q0 = (balance && mt == mt_first) ? t0 - mt * npair : 0;          // row pairs [q0, q1) of the workgroup's npair
+    const int q1 = (balance && mt == mt_last) ? t1 - mt * npair : npair;
     const int m0 = mt * 16, m = m0 + p, kv = min(16, N - m0);
     const bool kvalid = m < N;
     float Kf[16], Vf[16], dKa[16], dVa[16];
@@ -1730,8 +1748,8 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
         tile_gload<DE>(td[i], dey_in + pair0 * DE, lane, kv);
       }
     };
-    prefetch(0);
-    for (int lq = 0; R * lq < nl; ++lq) {
+    prefetch(q0);
+    for (int lq = q0; lq < q1; ++lq) {
       const int lb = l_begin + R * lq;
       const int nr = min(R, nl - R * lq);   // rows of this step that exist
       size_t pair0[R];
@@ -1743,7 +1761,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
         tile_lds_put<DE>(et0 + i * TF, te[i], lane, kv);
         tile_lds_put<DE>(dt0 + i * TF, td[i], lane, kv);
       }
-      if (R * (lq + 1) < nl) prefetch(lq + 1);
+      if (lq + 1 < q1) prefetch(lq + 1);
       lds_sync();
       // ---- P1: norm_edge, projections (recompute) ; P2: dH_ext = de'.Wr^T ----
       float rstd[R];
@@ -1925,13 +1943,28 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
       for (int i = 0; i < R; ++i)
         if (i < nr) tile_from_lds<DE>(dt0 + i * TF, dex_o + pair0[i] * DE, lane, kv);
     }
-    float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
-    float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
-    if (kvalid) {
+    if (q0 > 0) {   // the tile's first rows belong to the previous wave: park this partial for it
+      float* pk = park + (wave - 1) * 2048 + lane;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
-        vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
+      for (int i = 0; i < 16; ++i) { pk[i * 64] = dKa[i]; pk[(16 + i) * 64] = dVa[i]; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) pflag[wave] = 1;
+    } else {
+      if (q1 < npair) {   // the tile's last rows were done by the next wave at the very start of its range
+        while (pflag[wave + 1] == 0) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const float* pk = park + wave * 2048 + lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dKa[i] += pk[i * 64]; dVa[i] += pk[(16 + i) * 64]; }
+      }
+      float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
+      float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
+      if (kvalid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
+          vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
+        }
       }
     }
   }
@@ -2346,7 +2379,7 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
         if (narrow_r) {   // narrow edge channels: R rows per iteration, ragged N included
           constexpr int RR = 2;   // rows per iteration: four spill (the rows' carried state + prefetch exceed 256 VGPRs)
           constexpr int PWR = RR * (2 * GG::TILE_FLOATS + 256 + 192);
-          const size_t lds_r = ((size_t)(4 * PWR > BWD_PRO_WS ? 4 * PWR : BWD_PRO_WS) + (size_t)BWD_TL * QD_LD + 3 * GG::TILES * 256) * 4;
+          const size_t lds_r = ((size_t)(4 * PWR > BWD_PRO_WS ? 4 * PWR : BWD_PRO_WS) + (size_t)BWD_TL * QD_LD + 3 * GG::TILES * 256 + 3 * 2048 + 4) * 4;
           if (a.bf16) {
             EGT_MAX_LDS_ONCE(k_block_bwd_v4r<DE, true, RR>);
             EGT_LAUNCH("k_block_bwd", (k_block_bwd_v4r<DE, true, RR>), dim3(L.nwg_bwd), dim3(256), lds_r, st, a);

@@ -60,6 +60,8 @@ PMAP = {"norm_edge.gamma": ("norm_edge", "gamma"), "norm_edge.beta": ("norm_edge
     ("plain", 188, 64, True, True),          # PATTERN's longest graphs: 12 row groups, ragged last key block
     ("plain", 90, 64, True, True),           # 6 key tiles over 4 waves: balanced (tile, row) ranges, key tiles 1 and 4 shared by two waves
     ("plain", 70, 64, True, False),          # 5 key tiles, ragged last row group (6 rows): every range boundary inside a tile
+    ("plain", 90, 64, False, True),          # the same geometries with fp32 edge tensors: k_block_bwd_v4r's balanced ranges
+    ("plain", 70, 64, False, False),
     ("plain", 7, 64, False, False)])         # fewer keys than one wave's share: empty key ranges in the forward
 def test_narrow_kernel_branches_vs_oracle(variant, N, Dh, bf16, train, gpu, egt_lib):
     from egt_amd import EGTStack
