@@ -124,3 +124,43 @@ def test_narrow_kernel_branches_vs_oracle(variant, N, Dh, bf16, train, gpu, egt_
             if ref is None:
                 continue
             assert_close(getattr(getattr(blk, m), a_).grad, ref, name=f"L{li}.{k}", **ptol)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_narrow_kernels_fully_masked_rows(bf16, gpu, egt_lib):
+    """Rows whose keys are ALL masked (an empty graph; a one-node graph under a 50 % random mask): the additive -1e9 / -2e9
+    semantics of egt_layers.py:89-113 -- uniform attention over the least-masked keys, gates exactly 0 -- through the
+    De = 8 kernels' online softmax (forward) and saved-statistics recompute (backward)."""
+    from egt_amd import EGTStack
+    from egt_amd.fused import layer_seed
+    from oracle import egt_oracle as O, rng_ref
+    B, N, Dh, De, Ly, p = 3, 21, 64, 8, 2, 0.5
+    torch.manual_seed(77)
+    st = EGTStack(model_height=Ly, model_width=Dh, edge_width=De, num_heads=8, random_mask_prob=p, seed=6, fused=True).to(gpu).train(True)
+    g = torch.Generator().manual_seed(5)
+    h = torch.randn(B, N, Dh, generator=g); e = torch.randn(B, N, N, De, generator=g)
+    dh = torch.randn(B, N, Dh, generator=g); de = torch.randn(B, N, N, De, generator=g)
+    if bf16:
+        e, de = e.bfloat16(), de.bfloat16()
+    mask = torch.zeros(B, N, dtype=torch.bool)
+    mask[0, :1] = True          # one real node: every (row, head) whose random mask hits it is fully masked
+    mask[2, :13] = True         # graph 1 stays empty: every row fully masked by the key mask alone
+    hg = h.to(gpu).requires_grad_(); eg = e.to(gpu).requires_grad_()
+    h2, e2 = st(hg, eg, mask.to(gpu))
+    assert st.last_path == "fused-stack"
+    torch.autograd.backward([h2, e2], [dh.to(gpu), de.to(gpu)])
+    layers = [{k: getattr(getattr(blk, m), a_).detach().double().cpu().requires_grad_() for k, (m, a_) in PMAP.items()}
+              for blk in st.blocks]
+    b0 = st.blocks[0].mha
+    seed = (b0.seed * 0x9E3779B97F4A7C15 + b0._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    rms = [torch.from_numpy(rng_ref.random_mask(layer_seed(seed, l), B, N, 8, p)) for l in range(Ly)]
+    h64 = h.double().requires_grad_(); e64 = e.double().requires_grad_()
+    ho, eo = O.stack_forward(h64, e64, mask, layers, num_heads=8, rand_masks=rms)
+    gr = torch.autograd.grad([ho, eo], [h64, e64], [dh.double(), de.double()])
+    tol = dict(rtol=2e-2, arel=1e-2, zero_atol=2e-4) if bf16 else dict(rtol=2e-4, arel=5e-5)
+    gtol = tol if bf16 else BWD
+    assert torch.isfinite(h2).all() and torch.isfinite(e2.float()).all()
+    assert_close(h2, ho, name="h_out", **tol)
+    assert_close(e2.float(), eo, name="e_out", **tol)
+    assert_close(hg.grad, gr[0], name="dh", **gtol)
+    assert_close(eg.grad.float(), gr[1], name="de", **gtol)
