@@ -120,7 +120,21 @@ __global__ void __launch_bounds__(256) k_attn_pack(AttnMfmaArgs a) {
   if (sec == 0) put_rows(PK_QH);
   else if (sec == 1) { put_rows(PK_KH); if (bwd) put_cols(PK_KT); }
   else if (sec == 2) { if (bwd) put_rows(PK_VH); else put_cols(PK_VT); }
-  else put_rows(PK_OH);
+  else {
+    put_rows(PK_OH);
+    // delta[row, h] = sum_k dO[row, k, h] * O[row, k, h] (flash-style): the dO rows are staged here anyway, so the
+    // separate k_attn_mfma_delta launch (15 us of latency at config 5) is folded in -> rowstats[..][3]
+    const int r = tid >> 4, hh = (tid >> 1) & 7, half = tid & 1, n = n0 + r;
+    float sdel = 0.f;
+    if (n < N) {
+      const float* vo = a.v_att_in + ((size_t)b * N + n) * DH + hh;
+      const float* dr = sm + r * LD + hh;
+#pragma unroll 8
+      for (int k = half * (D / 2); k < (half + 1) * (D / 2); ++k) sdel = fmaf(dr[k * AH], vo[k * AH], sdel);
+    }
+    sdel += __shfl_xor(sdel, 1, 64);
+    if (n < N && half == 0) a.rowstats[(((size_t)b * N + n) * AH + hh) * 4 + 3] = sdel;
+  }
 }
 
 // Feature set of a kernel instance.  V = 0 reads every switch at run time (any combination);
@@ -627,7 +641,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd2(AttnMfmaArgs a) {
 // ================================================================= backward =====
 // Launches (flash-attention style, the [N,N,H] probabilities are recomputed):
 //   k_attn_pack        : head-major operand arrays of Q, K, V, dV_att
-//   k_attn_mfma_delta  : delta[l,h] = sum_k dO[l,k,h] * O[l,k,h]            -> rowstats[...][3]
+//   (delta[l,h] = sum_k dO[l,k,h] * O[l,k,h] -> rowstats[...][3] is computed by k_attn_pack's dO section)
 //   k_attn_mfma_bwd_kv : workgroup = (graph, 16-key tile), wave = head, walks the query tiles;
 //                        K/V fragments of the key tile live in registers; per tile S = Q.K^T and
 //                        dP = dO.V^T on MFMA, softmax/gate/clip backward on the VALU, then
@@ -635,18 +649,6 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd2(AttnMfmaArgs a) {
 //                        operands in place; writes dE, dG and dA = dH*c*scale
 //   k_attn_mfma_bwd_q  : workgroup = (graph, 16 query rows), wave = head, walks the key tiles:
 //                        dQ^T += K^T.dA^T on MFMA from the dA tensor
-__global__ void __launch_bounds__(256) k_attn_mfma_delta(AttnMfmaArgs a) {
-  const int d = a.d, DH = d * AH;
-  const long row = (long)blockIdx.x * 32 + (threadIdx.x >> 3);   // 8 threads (heads) per row
-  const int h = threadIdx.x & 7;
-  if (row >= (long)a.B * a.N) return;
-  const float* dv = a.d_v_att + row * DH + h;
-  const float* vo = a.v_att_in + row * DH + h;
-  float s = 0.f;
-  for (int k = 0; k < d; ++k) s = fmaf(dv[k * AH], vo[k * AH], s);
-  a.rowstats[(row * AH + h) * 4 + 3] = s;
-}
-
 // Lane (mm = lane&15, q): key m0 + mm; in every query tile rows l0 + 4q + r.
 template <int D, int V>
 __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
@@ -1040,9 +1042,7 @@ static void launch_bwd_kv_v(const AttnMfmaArgs& a, hipStream_t st) {
 }
 template <int D>
 static void launch_bwd(const AttnMfmaArgs& a, hipStream_t st) {
-  const long rows = (long)a.B * a.N;
-  launch_pack<D>(a, st);
-  EGT_LAUNCH("k_attn_mfma_delta", k_attn_mfma_delta, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, a);
+  launch_pack<D>(a, st);   // (also writes delta = sum_k dO*O into rowstats[..][3])
   switch (variant_of(a, true)) {
     case 1: launch_bwd_kv_v<D, 1>(a, st); break;
     case 2: launch_bwd_kv_v<D, 2>(a, st); break;
