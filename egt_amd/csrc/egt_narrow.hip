@@ -739,7 +739,11 @@ void egt_narrow_launch_bwd(BlockArgs& a, int nwg, hipStream_t st) {
   const size_t lds = ((size_t)AREA + BWD_TL * QD_LD + NRW_TAB_FLOATS + 3 * 2048 + 4) * 4;
   const int full = NRW_F_GATED | NRW_F_CLIP;
   const int feat = ((a.flags & EGT_BF_GATE) ? NRW_F_GATED : 0) | ((a.flags & EGT_BF_CLIP) ? NRW_F_CLIP : 0);
-#define NRW_BWD(BF_, FEAT_) EGT_LAUNCH("k_block_bwd", (k_narrow_bwd<BF_, FEAT_>), dim3(nwg), dim3(256), lds, st, a)
+#define NRW_BWD(BF_, FEAT_)                                                                     \
+  do {                                                                                            \
+    EGT_MAX_LDS_ONCE(k_narrow_bwd<BF_, FEAT_>);   /* 77 KB of dynamic LDS */                       \
+    EGT_LAUNCH("k_block_bwd", (k_narrow_bwd<BF_, FEAT_>), dim3(nwg), dim3(256), lds, st, a);      \
+  } while (0)
   if (a.bf16) { if (feat == full) NRW_BWD(true, NRW_F_GATED | NRW_F_CLIP); else NRW_BWD(true, NRW_F_RUNTIME); }
   else { if (feat == full) NRW_BWD(false, NRW_F_GATED | NRW_F_CLIP); else NRW_BWD(false, NRW_F_RUNTIME); }
 #undef NRW_BWD
