@@ -102,14 +102,17 @@ struct EgtProfScope {
   ~EgtProfScope() { egt_prof_end(tok, s); }
 };
 
-// Raise a kernel's dynamic-LDS limit ONCE per process (one process drives one GPU): the driver call costs a few
-// microseconds of host time, which is what a launch-bound small batch is made of.
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): the driver call costs a few microseconds of host time,
+// which is what a launch-bound small batch is made of.  (One process normally drives one GPU; the per-device bit keeps a
+// process that touches several correct.)
 #define EGT_MAX_LDS_ONCE(...)                                                                              \
   do {                                                                                                     \
-    static bool done__ = false;                                                                            \
-    if (!done__) {                                                                                         \
+    static unsigned long long done__ = 0ull;                                                               \
+    int dev__ = 0;                                                                                         \
+    (void)hipGetDevice(&dev__);                                                                            \
+    if (!((done__ >> (dev__ & 63)) & 1ull)) {                                                              \
       (void)hipFuncSetAttribute((const void*)(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      done__ = true;                                                                                       \
+      done__ |= 1ull << (dev__ & 63);                                                                      \
     }                                                                                                      \
   } while (0)
 
