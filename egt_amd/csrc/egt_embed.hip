@@ -14,35 +14,61 @@ typedef float v4f_e __attribute__((ext_vector_type(4)));
 
 // hop-major storage hops[k][b][l][m] (every plane is a contiguous [B,N,N] matrix stack: the B operand of the next
 // product and the embedding kernels read it with unit stride).
-// hops[k] = clip( adj . hops[k-1] ) per graph; grid = B * T * T waves (T = ceil(N/16)), one 16 x 16 output tile per wave
+// hops[k] = clip( adj . hops[k-1] ) per graph; grid = B * T2 * T2 waves (T2 = ceil(N/32)), one 32 x 32 output block = 2 x 2
+// MFMA tiles per wave: every A / B fragment feeds two products, half the L2 -> L1 operand traffic of one tile per wave
+// (N = 150: 57 us per hop with 16 x 16 tiles and scalar loads -> 42 us with 16-byte A loads -> this form).
 __global__ void __launch_bounds__(64) k_hop_step(const float* __restrict__ adj, float* __restrict__ hops, int B, int N,
                                                  int K, int k, int clip) {
-  const int T = (N + 15) / 16;
-  const int tile = blockIdx.x % (T * T), b = blockIdx.x / (T * T);
-  const int l0 = (tile / T) * 16, m0 = (tile % T) * 16;
+  const int T2 = (N + 31) / 32;
+  const int tile = blockIdx.x % (T2 * T2), b = blockIdx.x / (T2 * T2);
+  const int l0 = (tile / T2) * 32, m0 = (tile % T2) * 32;
   const int lane = threadIdx.x, i = lane & 15, kk = lane >> 4;
   const size_t plane = (size_t)B * N * N;
   const float* A = adj + (size_t)b * N * N;
   const float* P = hops + (size_t)(k - 1) * plane + (size_t)b * N * N;
-  v4f_e acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  const int la = min(l0 + i, N - 1), mb = min(m0 + i, N - 1);
-  for (int j0 = 0; j0 < N; j0 += 8) {     // two independent accumulators: the loads of both steps are in flight together
-    const int ja = j0 + kk, jb = j0 + 4 + kk;
-    const float a0 = ja < N ? A[(size_t)la * N + ja] : 0.f;               // A operand: row l0 + i, contraction index j
-    const float b0 = ja < N ? P[(size_t)ja * N + mb] : 0.f;               // B operand: contraction index j, column m0 + i
-    const float a1 = jb < N ? A[(size_t)la * N + jb] : 0.f;
-    const float b1 = jb < N ? P[(size_t)jb * N + mb] : 0.f;
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+  v4f_e acc[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) acc[u][v] = (v4f_e){0.f, 0.f, 0.f, 0.f};
+  const float* Ar[2] = {A + (size_t)min(l0 + i, N - 1) * N, A + (size_t)min(l0 + 16 + i, N - 1) * N};
+  const int mb[2] = {min(m0 + i, N - 1), min(m0 + 16 + i, N - 1)};
+  // 16 contraction steps per iteration: lane (i, kk) takes A[row][j0 + 4 kk .. + 3] as ONE 16-byte load (contraction index
+  // j = j0 + 4 kk + s in MFMA step s, the same on the B side).  (Exact for 0/1 adjacencies in any summation order.)
+  for (int j0 = 0; j0 < N; j0 += 16) {
+    const int jb = j0 + 4 * kk;
+    float av[2][4], bv[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (jb + 3 < N) {
+        const float4 t = *reinterpret_cast<const float4*>(Ar[u] + jb);   // (4-byte alignment is enough for global loads)
+        av[u][0] = t.x; av[u][1] = t.y; av[u][2] = t.z; av[u][3] = t.w;
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) av[u][s] = jb + s < N ? Ar[u][jb + s] : 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bv[u][s] = jb + s < N ? P[(size_t)(jb + s) * N + mb[u]] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][s], bv[v][s], acc[u][v], 0, 0, 0);
   }
   // D: row 4 * (lane >> 4) + r, column lane & 15
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int l = l0 + 4 * kk + r, m = m0 + i;
-    float v = acc0[r] + acc1[r];
-    if (clip) v = fminf(fmaxf(v, 0.f), 1.f);
-    if (l < N && m < N) hops[(size_t)k * plane + ((size_t)b * N + l) * N + m] = v;
-  }
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int l = l0 + 16 * u + 4 * kk + r, m = m0 + 16 * v + i;
+        float x = acc[u][v][r];
+        if (clip) x = fminf(fmaxf(x, 0.f), 1.f);
+        if (l < N && m < N) hops[(size_t)k * plane + ((size_t)b * N + l) * N + m] = x;
+      }
 }
 
 __global__ void __launch_bounds__(256) k_hop_first(const float* __restrict__ adj, float* __restrict__ hops, long pairs, int K) {
@@ -216,11 +242,11 @@ extern "C" int egt_edge_embed_fwd(const egt_embed_desc* d, const int32_t* featur
   hipStream_t st = (hipStream_t)stream;
   const long pairs = (long)d->B * d->N * d->N;
   if (d->num_float_features > 0 && !float_features) EGT_FAIL(EGT_E_NULL, "num_float_features set but float_features is NULL");
-  const int KH = d->upto_hop, K = KH + d->num_float_features, V = d->num_edge_features + 1, T = (d->N + 15) / 16;
+  const int KH = d->upto_hop, K = KH + d->num_float_features, V = d->num_edge_features + 1, T2 = (d->N + 31) / 32;
   EGT_LAUNCH("k_hop_first", k_hop_first, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, (const float*)graph_matrix,
              (float*)hops, pairs, K);
   for (int k = 1; k < KH; ++k)
-    EGT_LAUNCH("k_hop_step", k_hop_step, dim3((unsigned)(d->B * T * T)), dim3(64), 0, st, (const float*)graph_matrix,
+    EGT_LAUNCH("k_hop_step", k_hop_step, dim3((unsigned)(d->B * T2 * T2)), dim3(64), 0, st, (const float*)graph_matrix,
                (float*)hops, d->B, d->N, K, k, d->clip_hops ? 1 : 0);
   if (d->num_float_features > 0)
     EGT_LAUNCH("k_feature_planes", k_feature_planes, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st,
