@@ -59,26 +59,44 @@ struct FfnArgs {
 template <int W>
 __global__ void __launch_bounds__(256) k_ffn_prep(FfnArgs a) {
   FFN_GEO(W);
+  // width 8 (a.group8, W == 16): the 16-wide block-diagonal parameters are formed on the fly from the caller's 8-wide ones
+  // (the formulas of k_ffn_expand8), and block 0 also writes the expanded copies the main kernels read (a.x16) -- one launch
+  // instead of expand + prep
+  const bool g8 = W == 16 && a.group8;
+  auto Gm = [&](int c) { return g8 ? a.p8_gamma[c & 7] : a.gamma[c]; };
+  auto Bt = [&](int c) { return g8 ? a.p8_beta[c & 7] : a.beta[c]; };
+  auto W1f = [&](int c, int h) { return g8 ? (((c >> 3) == (h >> 4)) ? a.p8_W1[(c & 7) * 16 + (h & 15)] : 0.f) : a.W1[c * FH + h]; };
+  auto W2f = [&](int h, int o) { return g8 ? (((h >> 4) == (o >> 3)) ? a.p8_W2[(h & 15) * 8 + (o & 7)] : 0.f) : a.W2[h * FW + o]; };
+  auto B1f = [&](int h) { return g8 ? a.p8_b1[h & 15] : a.b1[h]; };
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx < SLABF) {
     const int u = idx & 3, lane = (idx >> 2) & 63, pl = lane & 15, q = lane >> 4, blk = idx >> 8;
     {
       const int t = blk % TW, j = blk / TW;
       const int c = 16 * t + 4 * q + u;
-      a.slab1[idx] = a.gamma[c] * a.W1[c * FH + 16 * j + pl];
-      a.slab3[idx] = a.W2[(16 * j + pl) * FW + c];
+      a.slab1[idx] = Gm(c) * W1f(c, 16 * j + pl);
+      a.slab3[idx] = W2f(16 * j + pl, c);
     }
     {
       const int j = blk % TH, i = blk / TH;
       const int hc = 16 * j + 4 * q + u;
-      a.slab2[idx] = a.W2[hc * FW + 16 * i + pl];
-      a.slab4[idx] = a.gamma[16 * i + pl] * a.W1[(16 * i + pl) * FH + hc];
+      a.slab2[idx] = W2f(hc, 16 * i + pl);
+      a.slab4[idx] = Gm(16 * i + pl) * W1f(16 * i + pl, hc);
     }
   }
   if (idx < FH) {
-    float s = a.b1[idx];
-    for (int c = 0; c < FW; ++c) s = fmaf(a.beta[c], a.W1[c * FH + idx], s);
+    float s = B1f(idx);
+    for (int c = 0; c < FW; ++c) s = fmaf(Bt(c), W1f(c, idx), s);
     a.b1p[idx] = s;
+  }
+  if (g8 && blockIdx.x == 0) {   // the expanded parameter copies (k_ffn_expand8's job)
+    float* g = a.x16; float* bt = g + 16; float* w1 = bt + 16; float* b1 = w1 + 512; float* w2 = b1 + 32; float* b2 = w2 + 512;
+    for (int i = threadIdx.x; i < 512; i += 256) {
+      w1[i] = W1f(i >> 5, i & 31);
+      w2[i] = W2f(i >> 4, i & 15);
+    }
+    if (threadIdx.x < 16) { g[threadIdx.x] = a.p8_gamma[threadIdx.x & 7]; bt[threadIdx.x] = a.p8_beta[threadIdx.x & 7]; b2[threadIdx.x] = a.p8_b2[threadIdx.x & 7]; }
+    if (threadIdx.x < 32) b1[threadIdx.x] = a.p8_b1[threadIdx.x & 15];
   }
 }
 
@@ -930,7 +948,7 @@ extern "C" int egt_ffn_fwd(const egt_ffn_desc* desc, const egt_ffn_params* param
   if (!x || !y) EGT_FAIL(EGT_E_NULL, "x/y is NULL");
   a.x = (const float*)x; a.y = (float*)y;
   hipStream_t st = (hipStream_t)stream;
-  if (a.group8) EGT_LAUNCH("k_ffn_prep", k_ffn_expand8, dim3(1), dim3(256), 0, st, a);
+  if (a.group8 && desc->matmul != EGT_MM_F32) EGT_LAUNCH("k_ffn_prep", k_ffn_expand8, dim3(1), dim3(256), 0, st, a);   // (width 8 is fp32-only today; k_ffn_prep expands by itself)
   if (desc->matmul != EGT_MM_F32) {
     FFN_DISPATCH_W(desc->width, ffn_launch_fwd_bf<W>(a, desc->activation, st));
   } else {
@@ -954,8 +972,7 @@ extern "C" int egt_ffn_bwd(const egt_ffn_desc* desc, const egt_ffn_params* param
   a.g_W1 = (float*)grads->lr1_kernel; a.g_b1 = (float*)grads->lr1_bias;
   a.g_W2 = (float*)grads->lr2_kernel; a.g_b2 = (float*)grads->lr2_bias;
   hipStream_t st = (hipStream_t)stream;
-  if (a.group8) EGT_LAUNCH("k_ffn_prep", k_ffn_expand8, dim3(1), dim3(256), 0, st, a);
-  FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep<W>, dim3((2 * W * W + 255) / 256), dim3(256), 0, st, a));
+  FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep<W>, dim3((2 * W * W + 255) / 256), dim3(256), 0, st, a));   // (width 8: expands the parameters too)
   if (desc->matmul != EGT_MM_F32)
     FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep_bf<W>, dim3(ffn_bf_prep_blocks(W)), dim3(256), 0, st, a));
   FFN_DISPATCH_W(desc->width, ffn_launch_bwd<W>(a, desc->activation, st));
