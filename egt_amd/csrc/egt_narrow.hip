@@ -14,8 +14,8 @@
 //   * the forward keeps a whole query row's softmax state in the lane (online softmax over the key loop:
 //     no cross-lane reduction at all); the four waves of a workgroup split the key range and merge their
 //     (max, sum, A.V) triples once at the end;
-//   * ~100-130 VGPRs: 3-4 waves per SIMD, 20 KB of LDS per workgroup (K / V travel through a 2 KB
-//     wave-private LDS chunk four keys at a time).
+//   * forward: 168 VGPRs = three waves per SIMD, 20 KB of LDS per workgroup (K / V travel through a 2 KB wave-private
+//     LDS chunk four keys at a time); backward: ~250 VGPRs = two waves per SIMD (K/V-side accumulators + weights), 77 KB of LDS.
 // Same BlockArgs, saved tensors, partial-buffer layouts, mask order / RNG stream and node-side epilogue /
 // prologue as the wide kernels: the dispatch in launch_fwd / launch_bwd is the only difference.
 // Own translation unit: built with -fno-slp-vectorize (build.py) -- hipcc otherwise pairs the scalar adds into
