@@ -14,16 +14,23 @@ from egt_amd import EGTStack  # noqa: E402
 def main():
     dev = torch.device("cuda", 0)
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    # optional: workload = "zinc" (headline, default) | "cifar" (config 3: N = 150, De = 8, bf16 -- the VALU kernels with the
+    # balanced ranges and their LDS park / pick-up hand-off) | "cifar32" (the same in fp32: v4r)
+    wl = sys.argv[2] if len(sys.argv) > 2 else "zinc"
     torch.manual_seed(0)
-    B, N, Ly = 128, 64, 10
-    st = EGTStack(model_height=Ly, model_width=64, edge_width=64, num_heads=8, random_mask_prob=0.1, seed=3,
+    B, N, Ly, De, lo, hi = (128, 64, 10, 64, 9, 38) if wl == "zinc" else (64, 150, 4, 8, 85, 151)
+    st = EGTStack(model_height=Ly, model_width=64, edge_width=De, num_heads=8, random_mask_prob=0.1, seed=3,
                   fused=True).to(dev).train()
     g = torch.Generator().manual_seed(1)
     h = torch.randn(B, N, 64, generator=g).to(dev).requires_grad_()
-    e = torch.randn(B, N, N, 64, generator=g).to(dev).requires_grad_()
-    n = torch.randint(9, 38, (B,), generator=g)
+    e = torch.randn(B, N, N, De, generator=g)
+    de = torch.randn(B, N, N, De, generator=g)
+    if wl == "cifar":
+        e, de = e.bfloat16(), de.bfloat16()
+    e = e.to(dev).requires_grad_(); de = de.to(dev)
+    n = torch.randint(lo, hi, (B,), generator=g)
     mask = (torch.arange(N)[None] < n[:, None]).to(dev)
-    dh = torch.randn(B, N, 64, generator=g).to(dev); de = torch.randn(B, N, N, 64, generator=g).to(dev)
+    dh = torch.randn(B, N, 64, generator=g).to(dev)
     ref = None
     bad = 0
     for it in range(reps):
