@@ -1,5 +1,5 @@
 // Fused channel FFN of the reference's ffn_block, for gfx950:
-//   y = x + Dense_2( act( Dense_1( LayerNorm(x) ) ) )        width W in {16,32,48,64}, hidden 2W
+//   y = x + Dense_2( act( Dense_1( LayerNorm(x) ) ) )        width W in {16,32,48,64}, hidden 2W  (W = 8: k_ffn8_*, below)
 //   lib/models/graph_xformer_model_base.py:230-258 (ffnlr1 / ffnact / ffnlr2, pre-norm, no
 //   cross-talk), applied to the edge channels [B,N,N,De] and the node channels [B,N,Dh] (:309-324).
 // At De = 64 this is the largest FLOP consumer of the model (24*W^2 flop per row fwd+bwd) and
@@ -39,14 +39,12 @@ struct FfnArgs {
   uint16_t *sA1, *sA2;   // EGT_MM_BF16X3 / EGT_MM_BF16: bf16 (hi | lo) A-operand slabs of the two forward GEMMs
   uint16_t *sA3, *sA4;   // ... and of the backward's dhid = W2 . dy and dxhat = W1p . dpre
   int mm;                // egt_ffn_desc.matmul
-  int group8;            // width 8 (De = 8 of configs 3/4): two 8-wide rows ride in one 16-wide row of the W = 16 kernels
-                         // (block-diagonal weights, LayerNorm statistics per group of 8 channels); p8_* are the caller's
-                         // 8-wide parameters, gamma/beta/W1/b1/W2/b2 then point at the expanded copies in the workspace
-  const float *p8_gamma, *p8_beta, *p8_W1, *p8_b1, *p8_W2, *p8_b2;
-  float *x16;            // workspace: expanded parameters [gamma 16 | beta 16 | W1 16x32 | b1 32 | W2 32x16 | b2 16]
+  float *x16;            // workspace: the prepared operands of the width-8 kernels (F8_* offsets, k_ffn8_prep)
   float *part, *red;   // backward: per-workgroup partials, reduced sums
   float *g_gamma, *g_beta, *g_W1, *g_b1, *g_W2, *g_b2;
   int nwg;
+  int part_len;   // floats per workgroup partial (k_ffn_sum)
+  int row8;       // width 8 on the row-per-lane kernels (k_ffn8_*)
   int W;       // channel width (host copy for the run-time-sized helper kernels)
   int guard;   // always 0: opaque phase guards of the backward (see k_ffn_bwd)
 };
@@ -59,44 +57,26 @@ struct FfnArgs {
 template <int W>
 __global__ void __launch_bounds__(256) k_ffn_prep(FfnArgs a) {
   FFN_GEO(W);
-  // width 8 (a.group8, W == 16): the 16-wide block-diagonal parameters are formed on the fly from the caller's 8-wide ones
-  // (the formulas of k_ffn_expand8), and block 0 also writes the expanded copies the main kernels read (a.x16) -- one launch
-  // instead of expand + prep
-  const bool g8 = W == 16 && a.group8;
-  auto Gm = [&](int c) { return g8 ? a.p8_gamma[c & 7] : a.gamma[c]; };
-  auto Bt = [&](int c) { return g8 ? a.p8_beta[c & 7] : a.beta[c]; };
-  auto W1f = [&](int c, int h) { return g8 ? (((c >> 3) == (h >> 4)) ? a.p8_W1[(c & 7) * 16 + (h & 15)] : 0.f) : a.W1[c * FH + h]; };
-  auto W2f = [&](int h, int o) { return g8 ? (((h >> 4) == (o >> 3)) ? a.p8_W2[(h & 15) * 8 + (o & 7)] : 0.f) : a.W2[h * FW + o]; };
-  auto B1f = [&](int h) { return g8 ? a.p8_b1[h & 15] : a.b1[h]; };
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx < SLABF) {
     const int u = idx & 3, lane = (idx >> 2) & 63, pl = lane & 15, q = lane >> 4, blk = idx >> 8;
     {
       const int t = blk % TW, j = blk / TW;
       const int c = 16 * t + 4 * q + u;
-      a.slab1[idx] = Gm(c) * W1f(c, 16 * j + pl);
-      a.slab3[idx] = W2f(16 * j + pl, c);
+      a.slab1[idx] = a.gamma[c] * a.W1[c * FH + 16 * j + pl];
+      a.slab3[idx] = a.W2[(16 * j + pl) * FW + c];
     }
     {
       const int j = blk % TH, i = blk / TH;
       const int hc = 16 * j + 4 * q + u;
-      a.slab2[idx] = W2f(hc, 16 * i + pl);
-      a.slab4[idx] = Gm(16 * i + pl) * W1f(16 * i + pl, hc);
+      a.slab2[idx] = a.W2[hc * FW + 16 * i + pl];
+      a.slab4[idx] = a.gamma[16 * i + pl] * a.W1[(16 * i + pl) * FH + hc];
     }
   }
   if (idx < FH) {
-    float s = B1f(idx);
-    for (int c = 0; c < FW; ++c) s = fmaf(Bt(c), W1f(c, idx), s);
+    float s = a.b1[idx];
+    for (int c = 0; c < FW; ++c) s = fmaf(a.beta[c], a.W1[c * FH + idx], s);
     a.b1p[idx] = s;
-  }
-  if (g8 && blockIdx.x == 0) {   // the expanded parameter copies (k_ffn_expand8's job)
-    float* g = a.x16; float* bt = g + 16; float* w1 = bt + 16; float* b1 = w1 + 512; float* w2 = b1 + 32; float* b2 = w2 + 512;
-    for (int i = threadIdx.x; i < 512; i += 256) {
-      w1[i] = W1f(i >> 5, i & 31);
-      w2[i] = W2f(i >> 4, i & 15);
-    }
-    if (threadIdx.x < 16) { g[threadIdx.x] = a.p8_gamma[threadIdx.x & 7]; bt[threadIdx.x] = a.p8_beta[threadIdx.x & 7]; b2[threadIdx.x] = a.p8_b2[threadIdx.x & 7]; }
-    if (threadIdx.x < 32) b1[threadIdx.x] = a.p8_b1[threadIdx.x & 15];
   }
 }
 
@@ -109,61 +89,6 @@ template <int ACT>   // derivative from the activation's OUTPUT (hid > 0 <=> pre
 __device__ __forceinline__ float ffn_dact(float hid) {
   if (ACT == EGT_ACT_RELU) return hid > 0.f ? 1.f : 0.f;
   return hid > 0.f ? 1.f : hid + 1.0f;
-}
-
-// LayerNorm of a 16-wide row that carries TWO 8-wide logical rows (channels 0-7: lanes q = 0,1; channels 8-15: q = 2,3):
-// two-pass moments over each group of 8 (one cross-lane add between the lanes q and q ^ 1)
-__device__ __forceinline__ float ln_frags_g8(float4 (&x)[1], float eps) {
-  const float mu = sum_xor16((x[0].x + x[0].y) + (x[0].z + x[0].w)) * (1.0f / 8);
-  x[0].x -= mu; x[0].y -= mu; x[0].z -= mu; x[0].w -= mu;
-  float v = fmaf(x[0].x, x[0].x, 0.f); v = fmaf(x[0].y, x[0].y, v); v = fmaf(x[0].z, x[0].z, v); v = fmaf(x[0].w, x[0].w, v);
-  const float rstd = rsqrtf(sum_xor16(v) * (1.0f / 8) + eps);
-  x[0].x *= rstd; x[0].y *= rstd; x[0].z *= rstd; x[0].w *= rstd;
-  return rstd;
-}
-template <int W>
-__device__ __forceinline__ float ffn_ln(float4 (&x)[W / 16], int q, float eps, int group8) {
-  if constexpr (W == 16) { if (group8) return ln_frags_g8(x, eps); }
-  return ln_frags<W>(x, q, eps);
-}
-
-// width 8: expand the caller's 8-wide parameters to the block-diagonal 16-wide ones the W = 16 kernels consume
-//   gamma'[c] = gamma[c & 7]   W1'[c][h] = (c >> 3 == h >> 4) ? W1[c & 7][h & 15] : 0     b1'[h] = b1[h & 15]
-//   W2'[h][o] = (h >> 4 == o >> 3) ? W2[h & 15][o & 7] : 0                                  b2'[o] = b2[o & 7]
-__global__ void __launch_bounds__(256) k_ffn_expand8(FfnArgs a) {
-  float* g = a.x16; float* bt = g + 16; float* w1 = bt + 16; float* b1 = w1 + 512; float* w2 = b1 + 32; float* b2 = w2 + 512;
-  for (int i = threadIdx.x; i < 512; i += 256) {
-    { const int c = i >> 5, h = i & 31; w1[i] = ((c >> 3) == (h >> 4)) ? a.p8_W1[(c & 7) * 16 + (h & 15)] : 0.f; }
-    { const int h = i >> 4, o = i & 15; w2[i] = ((h >> 4) == (o >> 3)) ? a.p8_W2[(h & 15) * 8 + (o & 7)] : 0.f; }
-  }
-  if (threadIdx.x < 16) { g[threadIdx.x] = a.p8_gamma[threadIdx.x & 7]; bt[threadIdx.x] = a.p8_beta[threadIdx.x & 7]; b2[threadIdx.x] = a.p8_b2[threadIdx.x & 7]; }
-  if (threadIdx.x < 32) b1[threadIdx.x] = a.p8_b1[threadIdx.x & 15];
-}
-// width 8: fold the 16-wide sums back: T1'[16x32], T2'[32x16], s1'[32], s2'[16] (a.red) -> the 8-wide gradients
-//   T1[c][h] = T1'[c][h] + T1'[8+c][16+h] (the two diagonal blocks), likewise T2, s1, s2; then the formulas of k_ffn_param_grads
-__global__ void __launch_bounds__(256) k_ffn_param_grads8(FfnArgs a) {
-  __shared__ float T1[128], T2[128], s1[16], s2[8];
-  const float* R1 = a.red; const float* R2 = a.red + 512; const float* r1 = a.red + 1024; const float* r2 = r1 + 32;
-  const int t = threadIdx.x;
-  if (t < 128) {
-    { const int c = t >> 4, h = t & 15; T1[t] = R1[c * 32 + h] + R1[(8 + c) * 32 + 16 + h]; }
-    { const int h = t >> 3, o = t & 7; T2[t] = R2[h * 16 + o] + R2[(16 + h) * 16 + 8 + o]; }
-  }
-  if (t < 16) s1[t] = r1[t] + r1[16 + t];
-  if (t < 8) s2[t] = r2[t] + r2[8 + t];
-  __syncthreads();
-  if (t < 128) {
-    const int c = t >> 4, h = t & 15;
-    a.g_W1[t] = fmaf(a.p8_gamma[c], T1[t], a.p8_beta[c] * s1[h]);
-    a.g_W2[t] = T2[t];
-  }
-  if (t < 16) a.g_b1[t] = s1[t];
-  if (t < 8) {
-    a.g_b2[t] = s2[t];
-    float dg = 0.f, db = 0.f;
-    for (int h = 0; h < 16; ++h) { const float w = a.p8_W1[t * 16 + h]; dg = fmaf(w, T1[t * 16 + h], dg); db = fmaf(w, s1[h], db); }
-    a.g_gamma[t] = dg; a.g_beta[t] = db;
-  }
 }
 
 __device__ __forceinline__ void slab_to_lds(float* dst, const float* src, int nfloats, int nthreads) {
@@ -266,7 +191,7 @@ __global__ void __launch_bounds__(512, 2) k_ffn_fwd(FfnArgs a) {
     float4 x[TW];
 #pragma unroll
     for (int t = 0; t < TW; ++t) x[t] = frag_read<FW>(tl, p, q, t);
-    ffn_ln<W>(x, q, a.ln_eps, a.group8);                            // norm_fnn (gamma/beta folded into the weights)
+    ln_frags<W>(x, q, a.ln_eps);                            // norm_fnn (gamma/beta folded into the weights)
     v4f h[TH];
 #pragma unroll
     for (int j = 0; j < TH; ++j) {                                    // fnn_lr1 + activation
@@ -401,7 +326,7 @@ __global__ void __launch_bounds__(512, 2) k_ffn_fwd_bf(FfnArgs a) {
     float4 x[TW];
 #pragma unroll
     for (int t = 0; t < TW; ++t) x[t] = frag_read<FW>(tl, p, q, t);
-    ffn_ln<W>(x, q, a.ln_eps, a.group8);                            // norm_fnn (gamma/beta folded into the weights)
+    ln_frags<W>(x, q, a.ln_eps);                            // norm_fnn (gamma/beta folded into the weights)
     Bf8 xh[NS1], xl[NS1];
 #pragma unroll
     for (int s = 0; s < NS1; ++s) {
@@ -539,7 +464,7 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
       float4 x[TW];
 #pragma unroll
       for (int t = 0; t < TW; ++t) x[t] = frag_read<FW>(et, p, q, t);
-      rstd = ffn_ln<W>(x, q, a.ln_eps, a.group8);
+      rstd = ln_frags<W>(x, q, a.ln_eps);
 #pragma unroll
       for (int t = 0; t < TW; ++t) frag_write<FW>(et, p, q, t, x[t]);   // xhat: A operand of T1 (other rows) + LN backward
       if constexpr (MM != 0) {
@@ -683,8 +608,7 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
         m2 = fmaf(acc[0], x[i].x, m2); m2 = fmaf(acc[1], x[i].y, m2);
         m2 = fmaf(acc[2], x[i].z, m2); m2 = fmaf(acc[3], x[i].w, m2);
       }
-      if (W == 16 && a.group8) { m1 = sum_xor16(m1) * (1.0f / 8); m2 = sum_xor16(m2) * (1.0f / 8); }   // statistics per 8-channel group
-      else { m1 = sum_over_q(m1) * (1.0f / FW); m2 = sum_over_q(m2) * (1.0f / FW); }
+      m1 = sum_over_q(m1) * (1.0f / FW); m2 = sum_over_q(m2) * (1.0f / FW);
 #pragma unroll
       for (int i = 0; i < TW; ++i) {
         const float4 dyv = frag_read<FW>(dt, p, q, i);
@@ -701,74 +625,97 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
   lds_sync();
   if (prev >= 0) tile_from_lds<FW>(dt, a.dx + prev * TILEF, lane, (int)min(16L, a.rows - prev * 16));
 
-  // ---- per-workgroup partial: the four waves add their tiles into ONE LDS image, one wave
-  //      after the other (same lane -> same element in every wave: fixed summation order) ----
+  // ---- per-workgroup partial: (wave 0 + wave 2) + (wave 1 + wave 3), a pairwise tree through two LANE-LINEAR LDS images
+  //      (accumulator tile k of lane l at float4 slot k*64 + l: conflict-free b128 moves, no read-modify-write).  The
+  //      canonical [row][col] layout is only formed by the final gather, which all four waves share.  (The first version
+  //      added the waves one after the other into a canonical image: 4-way bank conflicts on ~520 b32 read-modify-writes
+  //      per wave, 7 us per wave = 28 of the 73 us the kernel takes on the node channels.) ----
   const int p = p0, q = q0;
   __syncthreads();
-  float* red = sm;   // [FFN_PART] = 65 KiB over the (now idle) slabs
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-      const bool first = w == 0;
+  constexpr int NT = TW * TH;
+  float* img0 = sm;
+  float* img1 = img0 + 2 * NT * 256;
+  float* ssum = img1 + 2 * NT * 256;   // [4 waves][FH + FW]: bias-gradient sums in canonical order
+  auto img_put = [&](float* img) {
 #pragma unroll
-      for (int t = 0; t < TW; ++t)
-#pragma unroll
-        for (int j = 0; j < TH; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float* d = red + (16 * t + 4 * q + r) * FH + 16 * j + p;
-            *d = first ? accT1[t * TH + j][r] : *d + accT1[t * TH + j][r];
-          }
-#pragma unroll
-      for (int j = 0; j < TH; ++j)
-#pragma unroll
-        for (int i = 0; i < TW; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float* d = red + SLABF + (16 * j + 4 * q + r) * FW + 16 * i + p;
-            *d = first ? accT2[j * TW + i][r] : *d + accT2[j * TW + i][r];
-          }
-#pragma unroll
-      for (int j = 0; j < TH; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = row_sum16(sp[j][r]);
-          float* d = red + 2 * SLABF + 16 * j + 4 * q + r;
-          if (p == 0) *d = first ? v : *d + v;
-        }
-#pragma unroll
-      for (int t = 0; t < TW; ++t) {
-        const float v[4] = {row_sum16(sd[t].x), row_sum16(sd[t].y), row_sum16(sd[t].z), row_sum16(sd[t].w)};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float* d = red + 2 * SLABF + FH + 16 * t + 4 * q + r;
-          if (p == 0) *d = first ? v[r] : *d + v[r];
-        }
-      }
+    for (int k = 0; k < NT; ++k) {
+      *reinterpret_cast<v4f*>(img + (k * 64 + lane) * 4) = accT1[k];
+      *reinterpret_cast<v4f*>(img + ((NT + k) * 64 + lane) * 4) = accT2[k];
     }
-    __syncthreads();
+  };
+  auto img_add = [&](const float* img) {
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      accT1[k] += *reinterpret_cast<const v4f*>(img + (k * 64 + lane) * 4);
+      accT2[k] += *reinterpret_cast<const v4f*>(img + ((NT + k) * 64 + lane) * 4);
+    }
+  };
+  {
+    float* sw = ssum + wave * (FH + FW);
+#pragma unroll
+    for (int j = 0; j < TH; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = row_sum16(sp[j][r]);
+        if (p == 0) sw[16 * j + 4 * q + r] = v;
+      }
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+      const float v[4] = {row_sum16(sd[t].x), row_sum16(sd[t].y), row_sum16(sd[t].z), row_sum16(sd[t].w)};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (p == 0) sw[FH + 16 * t + 4 * q + r] = v[r];
+    }
   }
+  if (wave == 2) img_put(img0);
+  if (wave == 3) img_put(img1);
+  __syncthreads();
+  if (wave == 0) img_add(img0);
+  if (wave == 1) { img_add(img1); img_put(img1); }   // (a lane rewrites the slots it has just read: in order within the wave)
+  __syncthreads();
+  if (wave == 0) { img_add(img1); img_put(img0); }
+  __syncthreads();
   float* out = a.part + (size_t)blockIdx.x * FFN_PART;
-  for (int i = threadIdx.x; i < FFN_PART; i += 256) out[i] = red[i];
+  for (int i = threadIdx.x; i < FFN_PART; i += 256) {
+    float v;
+    if (i < SLABF) {                 // T1[row = 16t + 4q + r][col = 16j + p]
+      const int row = i / FH, col = i % FH;
+      v = img0[(((row >> 4) * TH + (col >> 4)) * 64 + 4 * (row & 12) + (col & 15)) * 4 + (row & 3)];
+    } else if (i < 2 * SLABF) {      // T2[row = 16j + 4q + r][col = 16i + p]
+      const int e = i - SLABF, row = e / FW, col = e % FW;
+      v = img0[((NT + (row >> 4) * TW + (col >> 4)) * 64 + 4 * (row & 12) + (col & 15)) * 4 + (row & 3)];
+    } else {
+      const int e = i - 2 * SLABF;
+      v = ((ssum[e] + ssum[(FH + FW) + e]) + ssum[2 * (FH + FW) + e]) + ssum[3 * (FH + FW) + e];
+    }
+    out[i] = v;
+  }
 }
 
-// deterministic sum over the workgroup partials: 64 outputs per workgroup, partial axis over 4 waves
-__global__ void __launch_bounds__(256) k_ffn_sum(FfnArgs a) {
-  const int FFN_PART = 4 * a.W * a.W + 3 * a.W;
-  __shared__ float red[4][64];
-  const int o = blockIdx.x * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
-  float v0 = 0.f, v1 = 0.f;
+// deterministic sum over the workgroup partials: 64 outputs per workgroup, partial axis over 16 waves with 8 loads in
+// flight each (the loop is a chain of HBM round trips: 1024 partials are 8 trips per thread)
+__global__ void __launch_bounds__(1024) k_ffn_sum(FfnArgs a) {
+  const int FFN_PART = a.part_len;
+  __shared__ float red[16][64];
+  const int l = threadIdx.x & 63, o = blockIdx.x * 64 + l, pg = threadIdx.x >> 6;
+  float v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) v[u] = 0.f;
   if (o < FFN_PART) {
     int pi = pg;
-    for (; pi + 4 < a.nwg; pi += 8) {
-      v0 += a.part[(size_t)pi * FFN_PART + o];
-      v1 += a.part[(size_t)(pi + 4) * FFN_PART + o];
-    }
-    for (; pi < a.nwg; pi += 4) v0 += a.part[(size_t)pi * FFN_PART + o];
+    for (; pi + 112 < a.nwg; pi += 128)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] += a.part[(size_t)(pi + 16 * u) * FFN_PART + o];
+    for (; pi < a.nwg; pi += 16) v[0] += a.part[(size_t)pi * FFN_PART + o];
   }
-  red[pg][threadIdx.x & 63] = v0 + v1;
+  red[pg][l] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
   __syncthreads();
-  if (pg == 0 && o < FFN_PART)
-    a.red[o] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (pg == 0 && o < FFN_PART) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += red[g][l];
+    a.red[o] = s;
+  }
 }
 
 // T1 = sum xhat^T.dpre, s1 = sum dpre, T2 = sum hid^T.dy, s2 = sum dy  ->  parameter gradients
@@ -802,16 +749,255 @@ __global__ void __launch_bounds__(256) k_ffn_param_grads(FfnArgs a) {
   }
 }
 
+// ============================================== width 8: one row per lane =====
+// De = 8 (configs 3/4: the CIFAR10 / PATTERN edge channels).  A 16x16 MFMA tile is the wrong shape for an 8 -> 16 -> 8
+// FFN (two 8-wide rows riding in one 16-wide row behind block-diagonal weights: half of every MFMA multiplies zeros, and the
+// tile round trips through LDS made the W = 16 backward VALU/latency-bound at 0.18 of the HBM roof).  Here a lane owns one
+// whole row: LayerNorm and the three channel contractions (128 FMAs each) are in-lane VALU work on v_pk_fma_f32 with the
+// weights as wave-uniform SGPR pairs (s_load from the constant address space, re-fetched per chunk), x/dy/dx move as two
+// 16-byte accesses per lane (a wave covers 2 KiB of contiguous HBM), and only the two weight-gradient contractions over the
+// ROW axis go to the matrix pipe: the wave transposes [xhat | dy] and dpre / hid through a padded LDS image ([16][68] floats:
+// conflict-free b32 column writes and b128 row reads) and contracts its 64 rows with 16 + 16 v_mfma_f32_16x16x4_f32.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) float* cfp;   // constant address space: uniform reads become s_load
+#define F8_W1P 0      // gamma[c] W1[c][h]            [8][16]   (pairs over h: pre)
+#define F8_W1PT 128   // gamma[c] W1[c][h] as [h][c]  [16][8]   (pairs over c: dxhat)
+#define F8_W2T 256    // W2[h][o] as [o][h]           [8][16]   (pairs over h: dhid)
+#define F8_W2 384     // W2[h][o]                     [16][8]   (pairs over o: y)
+#define F8_B1P 512    // b1[h] + sum_c beta[c] W1[c][h]
+#define F8_B2 528
+#define F8_PREP_FLOATS 536
+#define F8_PART 280   // per-workgroup partial: T1[c][h] 128 | T2^T[o][h] 128 | s1[h] 16 | s2[o] 8
+#define F8_LD 68      // row pitch of the transposed LDS images (floats)
+
+__global__ void __launch_bounds__(128) k_ffn8_prep(FfnArgs a) {
+  const int t = threadIdx.x;
+  float* w = a.x16;
+  const int c = t >> 4, h = t & 15;
+  const float v = a.gamma[c] * a.W1[c * 16 + h];
+  w[F8_W1P + c * 16 + h] = v;
+  w[F8_W1PT + h * 8 + c] = v;
+  const float u = a.W2[h * 8 + c];   // (h, o = c)
+  w[F8_W2 + h * 8 + c] = u;
+  w[F8_W2T + c * 16 + h] = u;
+  if (t < 16) {
+    float s = a.b1[t];
+    for (int k = 0; k < 8; ++k) s = fmaf(a.beta[k], a.W1[k * 16 + t], s);
+    w[F8_B1P + t] = s;
+  }
+  if (t < 8) w[F8_B2 + t] = a.b2[t];
+}
+
+__device__ __forceinline__ v2f splat2(float v) { return (v2f){v, v}; }
+__device__ __forceinline__ v2f ldw2(cfp w, int i) { return (v2f){w[i], w[i + 1]}; }
+
+// the lane's row: two-pass moments, x -> xhat in place, returns rstd
+__device__ __forceinline__ float ffn8_ln(float (&x)[8], float eps) {
+  const float mu = (((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) * 0.125f;
+  float v = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { x[c] -= mu; v = fmaf(x[c], x[c], v); }
+  const float rstd = rsqrtf(fmaf(v, 0.125f, eps));
+#pragma unroll
+  for (int c = 0; c < 8; ++c) x[c] *= rstd;
+  return rstd;
+}
+// hid = act(W1p^T . xhat + b1p)
+template <int ACT>
+__device__ __forceinline__ void ffn8_hidden(cfp w, const float (&xh)[8], float (&hid)[16]) {
+  v2f pre[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pre[k] = ldw2(w, F8_B1P + 2 * k);
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pre[k] = ldw2(w, F8_W1P + c * 16 + 2 * k) * splat2(xh[c]) + pre[k];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { hid[2 * k] = ffn_act<ACT>(pre[k][0]); hid[2 * k + 1] = ffn_act<ACT>(pre[k][1]); }
+}
+__device__ __forceinline__ void ffn8_load(const float* src, long row, bool ok, float (&v)[8]) {
+  float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+  if (ok) {
+    lo = *reinterpret_cast<const float4*>(src + row * 8);
+    hi = *reinterpret_cast<const float4*>(src + row * 8 + 4);
+  }
+  v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+}
+
+template <int ACT>
+__global__ void __launch_bounds__(256, 4) k_ffn8_fwd(FfnArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long nchunk = (a.rows + 63) / 64, stride = (long)gridDim.x * 4;
+  for (long ch = (long)blockIdx.x * 4 + (threadIdx.x >> 6); ch < nchunk; ch += stride) {
+    const long row = ch * 64 + lane;
+    const bool ok = row < a.rows;
+    float x[8], xh[8], hid[16];
+    ffn8_load(a.x, row, ok, x);
+    cfp w = (cfp)a.x16;
+    asm volatile("" : "+s"(w));   // per-chunk copy of the base: the weight fetches stay inside the loop (272 SGPRs do not exist)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xh[c] = x[c];
+    ffn8_ln(xh, a.ln_eps);
+    ffn8_hidden<ACT>(w, xh, hid);
+    v2f y[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[k] = (v2f){x[2 * k], x[2 * k + 1]} + ldw2(w, F8_B2 + 2 * k);
+#pragma unroll
+    for (int h = 0; h < 16; ++h)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = ldw2(w, F8_W2 + h * 8 + 2 * k) * splat2(hid[h]) + y[k];
+    if (ok) {
+      *reinterpret_cast<float4*>(a.y + row * 8) = make_float4(y[0][0], y[0][1], y[1][0], y[1][1]);
+      *reinterpret_cast<float4*>(a.y + row * 8 + 4) = make_float4(y[2][0], y[2][1], y[3][0], y[3][1]);
+    }
+  }
+}
+
+#ifndef F8_BWD_OCC
+#define F8_BWD_OCC 3   // waves per SIMD: 4 (128 registers) spills ~20 values per chunk
+#endif
+template <int ACT>
+__global__ void __launch_bounds__(256, F8_BWD_OCC) k_ffn8_bwd(FfnArgs a) {
+  __shared__ __attribute__((aligned(16))) float sm[4 * 2 * 16 * F8_LD];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m = lane & 15, kq = lane >> 4;
+  float* tA = sm + wave * 2 * 16 * F8_LD;   // [xhat 0-7 | dy 8-15][row]
+  float* tB = tA + 16 * F8_LD;              // dpre, then hid: [h][row]
+  v4f accT1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // [xhat | dy]^T . dpre : rows 0-7 = T1[c][h]
+  v4f accT2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // [xhat | dy]^T . hid  : rows 8-15 = T2^T[o][h]
+  // bias gradients from the transposed images too: lane (m, kq) adds up the 16 rows it reads of dpre[h = m] and of
+  // [xhat | dy][m] (one register each instead of 24 per-row accumulators)
+  v4f sp4 = {0.f, 0.f, 0.f, 0.f}, sd4 = {0.f, 0.f, 0.f, 0.f};
+  const long nchunk = (a.rows + 63) / 64, stride = (long)gridDim.x * 4;
+  for (long ch = (long)blockIdx.x * 4 + wave; ch < nchunk; ch += stride) {
+    const long row = ch * 64 + lane;
+    const bool ok = row < a.rows;
+    float xh[8], dy[8], hid[16], dp[16];
+    ffn8_load(a.x, row, ok, xh);     // rows past the end are zero: xhat = dy = dpre = 0 add nothing to the sums
+    ffn8_load(a.dy, row, ok, dy);
+    cfp w = (cfp)a.x16;
+    asm volatile("" : "+s"(w));
+    const float rstd = ffn8_ln(xh, a.ln_eps);
+    ffn8_hidden<ACT>(w, xh, hid);
+    {   // dhid = W2 . dy ; dpre = dhid * act'(pre)
+      v2f dh[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dh[k] = splat2(0.f);
+#pragma unroll
+      for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dh[k] = ldw2(w, F8_W2T + o * 16 + 2 * k) * splat2(dy[o]) + dh[k];
+#pragma unroll
+      for (int h = 0; h < 16; ++h) dp[h] = dh[h >> 1][h & 1] * ffn_dact<ACT>(hid[h]);
+    }
+    // ---- weight gradients: transpose through LDS, contract the wave's 64 rows on the matrix pipe ----
+    lds_sync();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { tA[c * F8_LD + lane] = xh[c]; tA[(8 + c) * F8_LD + lane] = dy[c]; }
+#pragma unroll
+    for (int h = 0; h < 16; ++h) tB[h * F8_LD + lane] = dp[h];
+    lds_sync();
+    v4f av[4], bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      av[j] = *reinterpret_cast<const v4f*>(tA + m * F8_LD + 16 * kq + 4 * j);
+      bv[j] = *reinterpret_cast<const v4f*>(tB + m * F8_LD + 16 * kq + 4 * j);
+    }
+    lds_sync();
+    sp4 += (bv[0] + bv[1]) + (bv[2] + bv[3]);
+    sd4 += (av[0] + av[1]) + (av[2] + av[3]);
+#pragma unroll
+    for (int h = 0; h < 16; ++h) tB[h * F8_LD + lane] = hid[h];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accT1[u & 1] = MFMA(av[j][u], bv[j][u], accT1[u & 1]);
+    lds_sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const v4f*>(tB + m * F8_LD + 16 * kq + 4 * j);
+    // ---- dxhat = W1p . dpre ; LayerNorm backward ; dx = dy + ... ----
+    v2f dxh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dxh[k] = splat2(0.f);
+#pragma unroll
+    for (int h = 0; h < 16; ++h)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dxh[k] = ldw2(w, F8_W1PT + h * 8 + 2 * k) * splat2(dp[h]) + dxh[k];
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { const float d = dxh[c >> 1][c & 1]; m1 += d; m2 = fmaf(d, xh[c], m2); }
+    m1 *= 0.125f; m2 *= 0.125f;
+    float o8[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o8[c] = dy[c] + rstd * (dxh[c >> 1][c & 1] - m1 - xh[c] * m2);
+    if (ok) {
+      *reinterpret_cast<float4*>(a.dx + row * 8) = make_float4(o8[0], o8[1], o8[2], o8[3]);
+      *reinterpret_cast<float4*>(a.dx + row * 8 + 4) = make_float4(o8[4], o8[5], o8[6], o8[7]);
+    }
+    lds_sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accT2[u & 1] = MFMA(av[j][u], bv[j][u], accT2[u & 1]);
+  }
+  // ---- per-workgroup partial: the four waves add into one LDS image, one after the other (fixed order) ----
+  __syncthreads();
+  float* red = sm;   // [F8_PART]
+  const v4f t1 = accT1[0] + accT1[1], t2 = accT2[0] + accT2[1];
+  const v4f tt = kq < 2 ? t1 : t2;   // D[mrow = 4 kq + r][n = m]: rows 0-7 of T1, rows 8-15 of T2^T  ->  image index 16 mrow + n
+  const float s1m = sum_over_q((sp4[0] + sp4[1]) + (sp4[2] + sp4[3]));   // s1[h = m]
+  const float s2m = sum_over_q((sd4[0] + sd4[1]) + (sd4[2] + sd4[3]));   // m >= 8: s2[o = m - 8]
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+      const bool first = wv == 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* d = red + 16 * (4 * kq + r) + m;
+        *d = first ? tt[r] : *d + tt[r];
+      }
+      if (kq == 0) {
+        red[256 + m] = first ? s1m : red[256 + m] + s1m;
+        if (m >= 8) red[264 + m] = first ? s2m : red[264 + m] + s2m;
+      }
+    }
+    __syncthreads();
+  }
+  float* out = a.part + (size_t)blockIdx.x * F8_PART;
+  for (int i = threadIdx.x; i < F8_PART; i += 256) out[i] = red[i];
+}
+
+// width 8: reduced sums (a.red: T1[c][h] | T2^T[o][h] | s1 | s2) -> parameter gradients (the formulas of k_ffn_param_grads)
+__global__ void __launch_bounds__(128) k_ffn8_param_grads(FfnArgs a) {
+  const float* T1 = a.red; const float* T2t = a.red + 128; const float* s1 = a.red + 256; const float* s2 = a.red + 272;
+  const int t = threadIdx.x;
+  {
+    const int c = t >> 4, h = t & 15;
+    a.g_W1[t] = fmaf(a.gamma[c], T1[t], a.beta[c] * s1[h]);
+  }
+  {
+    const int h = t >> 3, o = t & 7;
+    a.g_W2[t] = T2t[o * 16 + h];
+  }
+  if (t < 16) a.g_b1[t] = s1[t];
+  if (t < 8) {
+    a.g_b2[t] = s2[t];
+    float dg = 0.f, db = 0.f;
+    for (int h = 0; h < 16; ++h) { const float w = a.W1[t * 16 + h]; dg = fmaf(w, T1[t * 16 + h], dg); db = fmaf(w, s1[h], db); }
+    a.g_gamma[t] = dg; a.g_beta[t] = db;
+  }
+}
+
 // ------------------------------------------------------------------ host glue --
-#define FFN_NWG 256   // at most one backward workgroup per CU (4 waves, 1 per SIMD)
+#define FFN_NWG 256   // W >= 48: at most one backward workgroup per CU (4 waves, 1 per SIMD: the 512-register kernel)
+// narrower rows need < 128 registers and ~20 KB of LDS per workgroup: several workgroups per CU hide each other's latency
+static size_t ffn_nwg_cap(size_t W) { return W <= 16 ? 1024 : (W <= 32 ? 512 : FFN_NWG); }   // (measured: 256 -> 1024 workgroups: 128 -> 96 us at De = 8; 1280/2048 no better)
 
 static size_t ffn_al(size_t x) { return (x + 63) & ~(size_t)63; }
 
 extern "C" int egt_ffn_supported(const egt_ffn_desc* d) {
   if (!d || d->dtype != EGT_F32 || d->rows <= 0) return 0;
   if (d->matmul != EGT_MM_F32 && d->matmul != EGT_MM_BF16X3 && d->matmul != EGT_MM_BF16) return 0;
-  if (d->width == 8) return (d->rows % 2 == 0) && d->matmul == EGT_MM_F32 &&   // two 8-wide rows per 16-wide kernel row
-                            (d->activation == EGT_ACT_RELU || d->activation == EGT_ACT_ELU);
+  if (d->width == 8) return d->matmul == EGT_MM_F32 && (d->activation == EGT_ACT_RELU || d->activation == EGT_ACT_ELU);   // VALU kernels: exact fp32 only
   if (d->width != 16 && d->width != 32 && d->width != 48 && d->width != 64) return 0;
   return d->activation == EGT_ACT_RELU || d->activation == EGT_ACT_ELU;
 }
@@ -829,13 +1015,13 @@ static int ffn_bf_prep_blocks(int W) {
 extern "C" size_t egt_ffn_workspace_bytes(const egt_ffn_desc* d) {
   if (!egt_ffn_supported(d)) return 0;
   const size_t W = d->width == 8 ? 16 : d->width, slab = 2 * W * W, part = 2 * slab + 3 * W;
-  return (4 * slab + ffn_al(2 * W) + ffn_al(part) + (size_t)FFN_NWG * part + ffn_bf_slab_floats(W) + 1280) * sizeof(float);
+  return (4 * slab + ffn_al(2 * W) + ffn_al(part) + ffn_nwg_cap(W) * part + ffn_bf_slab_floats(W) + 1280) * sizeof(float);
 }
 
 static int ffn_fill(const egt_ffn_desc* d, const egt_ffn_params* p, void* ws, FfnArgs& a) {
   if (!d || !p || !ws) EGT_FAIL(EGT_E_NULL, "desc/params/workspace is NULL");
   if (!egt_ffn_supported(d))
-    EGT_FAIL(EGT_E_SHAPE, "fused FFN covers widths 16/32/48/64 (and 8 with an even row count, exact fp32 products), fp32, relu/elu "
+    EGT_FAIL(EGT_E_SHAPE, "fused FFN covers widths 16/32/48/64 (and 8 with exact fp32 products), fp32, relu/elu "
                           "(got width %d, rows %lld, act %d, matmul %d)", d->width, (long long)d->rows, d->activation, d->matmul);
   if (!p->norm_gamma || !p->norm_beta || !p->lr1_kernel || !p->lr1_bias || !p->lr2_kernel || !p->lr2_bias)
     EGT_FAIL(EGT_E_NULL, "an FFN parameter pointer is NULL");
@@ -853,7 +1039,7 @@ static int ffn_fill(const egt_ffn_desc* d, const egt_ffn_params* p, void* ws, Ff
   a.mm = d->matmul;
   {
     const size_t TW = W / 16, NS1 = (TW + 1) / 2;
-    float* bf = a.part + (size_t)FFN_NWG * part;
+    float* bf = a.part + ffn_nwg_cap(W) * part;
     const size_t a1 = 2 * TW * NS1 * 2 * 256, a2 = TW * TW * 2 * 256;
     a.sA1 = reinterpret_cast<uint16_t*>(bf);
     a.sA2 = reinterpret_cast<uint16_t*>(bf + a1);
@@ -861,16 +1047,19 @@ static int ffn_fill(const egt_ffn_desc* d, const egt_ffn_params* p, void* ws, Ff
     a.sA4 = reinterpret_cast<uint16_t*>(bf + 2 * a1 + a2);
     a.x16 = bf + 2 * a1 + 2 * a2;
   }
-  if (d->width == 8) {   // ride on the W = 16 kernels: half as many 16-wide rows, expanded parameters
-    a.group8 = 1; a.W = 16; a.rows = d->rows / 2;
-    a.p8_gamma = a.gamma; a.p8_beta = a.beta; a.p8_W1 = a.W1; a.p8_b1 = a.b1; a.p8_W2 = a.W2; a.p8_b2 = a.b2;
-    a.gamma = a.x16; a.beta = a.x16 + 16; a.W1 = a.x16 + 32; a.b1 = a.x16 + 544; a.W2 = a.x16 + 576; a.b2 = a.x16 + 1088;
+  a.part_len = (int)part;
+  if (d->width == 8) {   // one row per lane (k_ffn8_*)
+    a.row8 = 1; a.part_len = F8_PART;
+    const long want = (((a.rows + 63) / 64) + 3) / 4;
+    a.nwg = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+    return EGT_OK;
   }
   {   // backward workgroups: one per CU for large inputs; small inputs (node channels) one tile
       // per wave (a tile is ~16 us of dependent work: spreading beats amortising the slab staging)
     const long ntiles = (a.rows + 15) / 16;
     const long want = (ntiles + 3) / 4;
-    a.nwg = (int)(want < 1 ? 1 : (want > FFN_NWG ? FFN_NWG : want));
+    const long cap = (long)ffn_nwg_cap(W);
+    a.nwg = (int)(want < 1 ? 1 : (want > cap ? cap : want));
   }
   return EGT_OK;
 }
@@ -933,7 +1122,6 @@ static void ffn_launch_bwd(const FfnArgs& a, int act, hipStream_t st) {
 
 #define FFN_DISPATCH_W(width, CALL)               \
   switch (width) {                                \
-    case 8:                                       \
     case 16: { constexpr int W = 16; CALL; } break; \
     case 32: { constexpr int W = 32; CALL; } break; \
     case 48: { constexpr int W = 48; CALL; } break; \
@@ -948,7 +1136,15 @@ extern "C" int egt_ffn_fwd(const egt_ffn_desc* desc, const egt_ffn_params* param
   if (!x || !y) EGT_FAIL(EGT_E_NULL, "x/y is NULL");
   a.x = (const float*)x; a.y = (float*)y;
   hipStream_t st = (hipStream_t)stream;
-  if (a.group8 && desc->matmul != EGT_MM_F32) EGT_LAUNCH("k_ffn_prep", k_ffn_expand8, dim3(1), dim3(256), 0, st, a);   // (width 8 is fp32-only today; k_ffn_prep expands by itself)
+  if (a.row8) {
+    EGT_LAUNCH("k_ffn_prep", k_ffn8_prep, dim3(1), dim3(128), 0, st, a);
+    const long want = (((a.rows + 63) / 64) + 3) / 4;
+    const int grid = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    if (desc->activation == EGT_ACT_RELU) EGT_LAUNCH("k_ffn_fwd", k_ffn8_fwd<EGT_ACT_RELU>, dim3(grid), dim3(256), 0, st, a);
+    else EGT_LAUNCH("k_ffn_fwd", k_ffn8_fwd<EGT_ACT_ELU>, dim3(grid), dim3(256), 0, st, a);
+    EGT_HIP_LAUNCH_CHECK("egt_ffn_fwd");
+    return EGT_OK;
+  }
   if (desc->matmul != EGT_MM_F32) {
     FFN_DISPATCH_W(desc->width, ffn_launch_fwd_bf<W>(a, desc->activation, st));
   } else {
@@ -972,14 +1168,22 @@ extern "C" int egt_ffn_bwd(const egt_ffn_desc* desc, const egt_ffn_params* param
   a.g_W1 = (float*)grads->lr1_kernel; a.g_b1 = (float*)grads->lr1_bias;
   a.g_W2 = (float*)grads->lr2_kernel; a.g_b2 = (float*)grads->lr2_bias;
   hipStream_t st = (hipStream_t)stream;
-  FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep<W>, dim3((2 * W * W + 255) / 256), dim3(256), 0, st, a));   // (width 8: expands the parameters too)
+  if (a.row8) {
+    EGT_LAUNCH("k_ffn_prep", k_ffn8_prep, dim3(1), dim3(128), 0, st, a);
+    if (desc->activation == EGT_ACT_RELU) EGT_LAUNCH("k_ffn_bwd", k_ffn8_bwd<EGT_ACT_RELU>, dim3(a.nwg), dim3(256), 0, st, a);
+    else EGT_LAUNCH("k_ffn_bwd", k_ffn8_bwd<EGT_ACT_ELU>, dim3(a.nwg), dim3(256), 0, st, a);
+    EGT_LAUNCH("k_ffn_sum", k_ffn_sum, dim3((F8_PART + 63) / 64), dim3(1024), 0, st, a);
+    EGT_LAUNCH("k_ffn_param_grads", k_ffn8_param_grads, dim3(1), dim3(128), 0, st, a);
+    EGT_HIP_LAUNCH_CHECK("egt_ffn_bwd");
+    return EGT_OK;
+  }
+  FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep<W>, dim3((2 * W * W + 255) / 256), dim3(256), 0, st, a));
   if (desc->matmul != EGT_MM_F32)
     FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep_bf<W>, dim3(ffn_bf_prep_blocks(W)), dim3(256), 0, st, a));
   FFN_DISPATCH_W(desc->width, ffn_launch_bwd<W>(a, desc->activation, st));
-  const int part = 4 * a.W * a.W + 3 * a.W;
-  EGT_LAUNCH("k_ffn_sum", k_ffn_sum, dim3((part + 63) / 64), dim3(256), 0, st, a);
-  if (a.group8) EGT_LAUNCH("k_ffn_param_grads", k_ffn_param_grads8, dim3(1), dim3(256), 0, st, a);
-  else FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_param_grads", k_ffn_param_grads<W>, dim3(16), dim3(256), 0, st, a));
+  const int part = a.part_len;
+  EGT_LAUNCH("k_ffn_sum", k_ffn_sum, dim3((part + 63) / 64), dim3(1024), 0, st, a);
+  FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_param_grads", k_ffn_param_grads<W>, dim3(16), dim3(256), 0, st, a));
   EGT_HIP_LAUNCH_CHECK("egt_ffn_bwd");
   return EGT_OK;
 }

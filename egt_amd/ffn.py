@@ -2,7 +2,7 @@
     y = x + Dense_2(act(Dense_1(LayerNorm(x))))
 (lib/models/graph_xformer_model_base.py:230-258, applied per channel type by ffn_block :309-324;
 pre-norm, no cross-talk, ffn_multiplier 2).  One C-ABI call per direction (egt_ffn_fwd / egt_ffn_bwd
-in include/egt_amd.h) for widths 16/32/48/64, fp32, elu / relu; there is no CPU fallback."""
+in include/egt_amd.h) for widths 8/16/32/48/64, fp32, elu / relu; there is no CPU fallback."""
 from __future__ import annotations
 
 import ctypes as C
@@ -72,16 +72,6 @@ def ffn(x, norm_gamma, norm_beta, lr1_kernel, lr1_bias, lr2_kernel, lr2_bias, ac
     W = x.shape[-1]
     rows = x.numel() // W
     params = (norm_gamma, norm_beta, lr1_kernel, lr1_bias, lr2_kernel, lr2_bias)
-    if W == 8 and rows % 2 == 1:
-        # width 8 rides two rows per 16-wide kernel row (egt_ffn.hip: group8): an odd row count sends its last row
-        # through a second, 2-row call (padded with a zero row whose output is dropped)
-        flat = x.reshape(rows, W)
-        tail = torch.cat([flat[rows - 1:], torch.zeros_like(flat[:1])], dim=0)
-        y_tail = ffn(tail, *params, activation=activation, eps=eps, matmul=matmul)[:1]
-        if rows == 1:
-            return y_tail.reshape(x.shape)
-        y_main = ffn(flat[:rows - 1], *params, activation=activation, eps=eps, matmul=matmul)
-        return torch.cat([y_main, y_tail], dim=0).reshape(x.shape)
     desc = _desc(rows, W, activation, eps, matmul)
     if not L.load().egt_ffn_supported(C.byref(desc)):
         raise ValueError(f"fused FFN covers widths 8/16/32/48/64 in fp32 (width 8: exact fp32 products only); "

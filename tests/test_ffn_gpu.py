@@ -63,18 +63,19 @@ def test_ffn_other_widths_vs_oracle(W, shape, act, gpu, egt_lib):
 
 
 @pytest.mark.parametrize("shape,act", [((2, 20, 20), "elu"), ((3, 15, 15), "relu"), ((1, 7), "elu"), ((1,), "elu"), ((128, 9), "elu"),
-                                        ((2, 120, 120), "elu")])
+                                        ((2, 120, 120), "elu"), ((5, 251, 251), "relu")])
 def test_ffn_width8_vs_oracle(shape, act, gpu, egt_lib):
-    """edge_width 8 (BASELINE configs 3 / 4: CIFAR10, PATTERN): two 8-wide rows per 16-wide kernel row, LayerNorm per
-    8-channel group, block-diagonal weights; odd row counts take the padded tail call"""
+    """edge_width 8 (BASELINE configs 3 / 4: CIFAR10, PATTERN): the row-per-lane kernels (k_ffn8_*), weight gradients through
+    the transposed LDS images; odd and tiny row counts, a partial last 64-row chunk, more chunks than workgroups"""
     _run(shape, act, gpu, seed=8, W=8)
 
 
-def test_ffn_bit_reproducible_and_linear_in_dy(gpu, egt_lib):
+@pytest.mark.parametrize("W", [64, 8])
+def test_ffn_bit_reproducible_and_linear_in_dy(W, gpu, egt_lib):
     from egt_amd import FFN
     torch.manual_seed(5)
-    m = FFN(64).to(gpu)
-    x = torch.randn(2, 40, 40, 64, device=gpu)
+    m = FFN(W).to(gpu)
+    x = torch.randn(2, 40, 40, W, device=gpu)
     dy = torch.randn_like(x)
     outs = []
     for scale in (1.0, 1.0, 2.0):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """FFN scope of SURVEY.md §8(f)-1: y = x + Dense2(elu(Dense1(LN(x)))) fwd+bwd on the edge channels
-of a BASELINE config (default config 2: [128,64,64,64] fp32).  Prints one JSON line."""
+of a BASELINE config (default config 2: [128,64,64,64] fp32; `bench_ffn.py edge B N W` for another one).  Prints one JSON line."""
 import ctypes as C
 import json
 import os
@@ -14,6 +14,8 @@ from egt_amd import FFN, _lib as L  # noqa: E402
 
 def main():
     B, N, W = 128, 64, 64
+    if len(sys.argv) > 4:   # bench_ffn.py edge|node B N W
+        B, N, W = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     if len(sys.argv) > 1 and sys.argv[1] == "node":
         shape = (B, N, W)
     else:
