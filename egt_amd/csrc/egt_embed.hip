@@ -71,6 +71,81 @@ __global__ void __launch_bounds__(64) k_hop_step(const float* __restrict__ adj, 
       }
 }
 
+// ALL hop planes in one launch.  hops[k][:, c] depends only on A and hops[k-1][:, c]: a workgroup that owns a block of
+// columns of one graph keeps the whole adjacency (zero padded [R16][R16 + 4]) and its column block of the current plane
+// ([R16][16 CT + 4]) in LDS and walks k = 1 .. KH-1 without another global read: per hop every wave contracts its (row tile,
+// column tile) pairs over all of A's columns (A: one ds_read_b128 = 4 contraction steps, B: 4 ds_read_b32; the pitches make
+// both conflict-free), then -- barrier -- clips, stores the plane to HBM and puts it back into LDS as the next B operand.
+// (One launch per hop, operands from L2, 3 waves per SIMD in flight: 36 us per hop at N = 150, 15 launches per batch.)
+#define HOP_NW 8     // waves per workgroup
+#define HOP_MAXT 8   // (row tile, column tile) pairs per wave
+__global__ void __launch_bounds__(HOP_NW * 64) k_hop_chain(const float* __restrict__ adj, float* __restrict__ hops, int B, int N,
+                                                           int KH, int clip, int NB, int CT) {
+  extern __shared__ __attribute__((aligned(16))) float hsm[];
+  const int RT = (N + 15) / 16, R16 = RT * 16, PA = R16 + 4, PH = 16 * CT + 4;
+  float* As = hsm;
+  float* Hs = As + R16 * PA;
+  const int b = blockIdx.x / NB, c0 = (blockIdx.x % NB) * CT * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+  const size_t plane = (size_t)B * N * N;
+  const float* A = adj + (size_t)b * N * N;
+  float* H0 = hops + (size_t)b * N * N;
+  for (int i = threadIdx.x; i < R16 * PA; i += HOP_NW * 64) {
+    const int r = i / PA, c = i % PA;
+    As[i] = (r < N && c < N) ? A[(size_t)r * N + c] : 0.f;
+  }
+  for (int i = threadIdx.x; i < R16 * PH; i += HOP_NW * 64) {
+    const int r = i / PH, c = c0 + i % PH;
+    const bool in = r < N && c < N && (i % PH) < 16 * CT;
+    const float v = in ? A[(size_t)r * N + c] : 0.f;
+    Hs[i] = v;
+    if (in) H0[(size_t)r * N + c] = v;   // plane 0
+  }
+  __syncthreads();
+  const int ntile = RT * CT;
+  for (int k = 1; k < KH; ++k) {
+    v4f_e acc[HOP_MAXT];
+#pragma unroll
+    for (int ti = 0; ti < HOP_MAXT; ++ti) {
+      acc[ti] = (v4f_e){0.f, 0.f, 0.f, 0.f};
+      const int t = wave + HOP_NW * ti;
+      if (t < ntile) {
+        const float* ap = As + (16 * (t / CT) + m) * PA + 4 * kq;
+        const float* bp = Hs + (4 * kq) * PH + 16 * (t % CT) + m;
+        v4f_e c = acc[ti];
+        for (int g = 0; g < RT; ++g) {
+          const v4f_e a4 = *reinterpret_cast<const v4f_e*>(ap + 16 * g);
+          const float* bg = bp + 16 * g * PH;
+          const float b0 = bg[0], b1 = bg[PH], b2 = bg[2 * PH], b3 = bg[3 * PH];
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[0], b0, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[1], b1, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[2], b2, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[3], b3, c, 0, 0, 0);
+        }
+        acc[ti] = c;
+      }
+    }
+    __syncthreads();   // every wave has read the old plane
+    float* Hk = H0 + (size_t)k * plane;
+#pragma unroll
+    for (int ti = 0; ti < HOP_MAXT; ++ti) {
+      const int t = wave + HOP_NW * ti;
+      if (t < ntile) {
+        const int rt = t / CT, ct = t % CT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // D: row 4 kq + r, column m
+          float x = acc[ti][r];
+          if (clip) x = fminf(fmaxf(x, 0.f), 1.f);
+          const int row = 16 * rt + 4 * kq + r, col = c0 + 16 * ct + m;
+          Hs[row * PH + 16 * ct + m] = x;
+          if (row < N && col < N) Hk[(size_t)row * N + col] = x;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void __launch_bounds__(256) k_hop_first(const float* __restrict__ adj, float* __restrict__ hops, long pairs, int K) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i < pairs) hops[i] = adj[i];   // plane 0
@@ -243,11 +318,31 @@ extern "C" int egt_edge_embed_fwd(const egt_embed_desc* d, const int32_t* featur
   const long pairs = (long)d->B * d->N * d->N;
   if (d->num_float_features > 0 && !float_features) EGT_FAIL(EGT_E_NULL, "num_float_features set but float_features is NULL");
   const int KH = d->upto_hop, K = KH + d->num_float_features, V = d->num_edge_features + 1, T2 = (d->N + 31) / 32;
-  EGT_LAUNCH("k_hop_first", k_hop_first, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, (const float*)graph_matrix,
-             (float*)hops, pairs, K);
-  for (int k = 1; k < KH; ++k)
-    EGT_LAUNCH("k_hop_step", k_hop_step, dim3((unsigned)(d->B * T2 * T2)), dim3(64), 0, st, (const float*)graph_matrix,
-               (float*)hops, d->B, d->N, K, k, d->clip_hops ? 1 : 0);
+  // one launch for all planes when the adjacency and one column block fit in LDS (N <= ~180), else a launch per hop
+  int CT = 0;
+  {
+    static const bool no_chain = getenv("EGT_NO_HOP_CHAIN") != nullptr;
+    const int RT = (d->N + 15) / 16, R16 = RT * 16;
+    int ct = (int)((long)RT * d->B / 256);   // >= 256 workgroups when the batch allows it
+    ct = ct < 1 ? 1 : (ct > RT ? RT : ct);
+    while (ct > 1 && RT * ct > HOP_NW * HOP_MAXT) --ct;
+    auto lds_of = [&](int c) { return (size_t)(R16 * (R16 + 4) + R16 * (16 * c + 4)) * sizeof(float); };
+    while (ct > 1 && lds_of(ct) > 160 * 1024) --ct;
+    if (!no_chain && KH > 1 && RT * ct <= HOP_NW * HOP_MAXT && lds_of(ct) <= 160 * 1024) CT = ct;
+    if (CT) {
+      const int NB = (RT + CT - 1) / CT;
+      EGT_MAX_LDS_ONCE(k_hop_chain);
+      EGT_LAUNCH("k_hop_chain", k_hop_chain, dim3((unsigned)(d->B * NB)), dim3(HOP_NW * 64), lds_of(CT), st,
+                 (const float*)graph_matrix, (float*)hops, d->B, d->N, KH, d->clip_hops ? 1 : 0, NB, CT);
+    }
+  }
+  if (!CT) {
+    EGT_LAUNCH("k_hop_first", k_hop_first, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, (const float*)graph_matrix,
+               (float*)hops, pairs, K);
+    for (int k = 1; k < KH; ++k)
+      EGT_LAUNCH("k_hop_step", k_hop_step, dim3((unsigned)(d->B * T2 * T2)), dim3(64), 0, st, (const float*)graph_matrix,
+                 (float*)hops, d->B, d->N, K, k, d->clip_hops ? 1 : 0);
+  }
   if (d->num_float_features > 0)
     EGT_LAUNCH("k_feature_planes", k_feature_planes, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st,
                (const float*)float_features, (float*)hops + (size_t)KH * pairs, pairs, d->num_float_features, d->mask_value);

@@ -101,8 +101,11 @@ def _grad_of(model, key):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,N,De,K,V", [(2, 9, 16, 4, 5), (3, 37, 64, 16, 5), (2, 64, 64, 16, 5), (1, 21, 48, 1, 3), (2, 70, 8, 7, 5)])
+@pytest.mark.parametrize("B,N,De,K,V", [(2, 9, 16, 4, 5), (3, 37, 64, 16, 5), (2, 64, 64, 16, 5), (1, 21, 48, 1, 3), (2, 70, 8, 7, 5),
+                                       (2, 150, 8, 16, 5), (64, 150, 8, 4, 5), (1, 200, 8, 3, 5)])
 def test_edge_embed_vs_oracle(B, N, De, K, V, gpu, egt_lib):
+    """hop planes: k_hop_chain (one launch, adjacency + column block in LDS; B = 64 / N = 150 runs two column tiles per
+    workgroup, B = 2 one) and the per-hop kernels where the adjacency does not fit (N = 200)"""
     from egt_amd import edge_embed
     from oracle import egt_model_oracle as MO, egt_oracle as O
     g = torch.Generator().manual_seed(B * 100 + N)
