@@ -50,10 +50,11 @@ class BlockDesc(C.Structure):
 
 class FfnDesc(C.Structure):
     _fields_ = [("rows", C.c_int64), ("width", C.c_int32), ("dtype", C.c_int32),
-                ("activation", C.c_int32), ("ln_eps", C.c_float), ("matmul", C.c_int32), ("reserved", C.c_int32)]
+                ("activation", C.c_int32), ("ln_eps", C.c_float), ("matmul", C.c_int32), ("flags", C.c_int32)]
 
 
 MM_F32, MM_BF16X3, MM_BF16 = 0, 1, 2   # egt_ffn_desc.matmul
+FFN_WS_PREPARED = 1                      # egt_ffn_desc.flags
 
 
 FFN_PARAM_FIELDS = ("norm_gamma", "norm_beta", "lr1_kernel", "lr1_bias", "lr2_kernel", "lr2_bias")

@@ -692,6 +692,49 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
   }
 }
 
+// T1 = sum xhat^T.dpre, s1 = sum dpre, T2 = sum hid^T.dy, s2 = sum dy (a.red)  ->  parameter gradients
+//   dW1[c][h] = gamma_c T1[c][h] + beta_c s1[h] ; dgamma_c = sum_h W1[c][h] T1[c][h] ; dbeta_c = sum_h W1[c][h] s1[h]
+//   db1 = s1 ; dW2 = T2 ; db2 = s2          (width 8 keeps T2 transposed: T2^T[o][h])
+// One workgroup of 1024 threads, 16 lanes per channel for the gamma / beta contractions.  (Folding this into k_ffn_sum behind
+// a last-workgroup ticket was tried: the device-scope fences cost more than the launch, 20 us against 7 + 10 as two launches.)
+__global__ void __launch_bounds__(1024) k_ffn_param_grads(FfnArgs a) {
+  const int FW = a.W, FH = 2 * a.W, SLABF = FW * FH, t = threadIdx.x;
+  const float* T1 = a.red;
+  const float* T2 = a.red + SLABF;
+  const float* s1 = a.red + 2 * SLABF;
+  const float* s2 = s1 + FH;
+  // every load before the first store (the gradient pointers may alias anything as far as the compiler knows: a store
+  // inside the loops would make each iteration its own memory round trip)
+  float w1v[8], w2v[8];   // SLABF <= 64 * 128 = 8 x 1024
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int i = t + 1024 * u;
+    if (i < SLABF) {
+      w1v[u] = fmaf(a.gamma[i / FH], T1[i], a.beta[i / FH] * s1[i % FH]);
+      w2v[u] = a.row8 ? T2[(i % FW) * FH + i / FW] : T2[i];
+    }
+  }
+  const float b1v = t < FH ? s1[t] : 0.f, b2v = t < FW ? s2[t] : 0.f;
+  float dg = 0.f, db = 0.f;
+  const int c = t >> 4, part = t & 15;   // 16 lanes per channel
+  if (t < FW * 16) {
+    for (int h = part; h < FH; h += 16) {
+      const float w = a.W1[c * FH + h];
+      dg = fmaf(w, T1[c * FH + h], dg);
+      db = fmaf(w, s1[h], db);
+    }
+    dg = row_sum16(dg); db = row_sum16(db);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int i = t + 1024 * u;
+    if (i < SLABF) { a.g_W1[i] = w1v[u]; a.g_W2[i] = w2v[u]; }
+  }
+  if (t < FH) a.g_b1[t] = b1v;
+  if (t < FW) a.g_b2[t] = b2v;
+  if (t < FW * 16 && part == 0) { a.g_gamma[c] = dg; a.g_beta[c] = db; }
+}
+
 // deterministic sum over the workgroup partials: 64 outputs per workgroup, partial axis over 16 waves with 8 loads in
 // flight each (the loop is a chain of HBM round trips: 1024 partials are 8 trips per thread)
 __global__ void __launch_bounds__(1024) k_ffn_sum(FfnArgs a) {
@@ -715,37 +758,6 @@ __global__ void __launch_bounds__(1024) k_ffn_sum(FfnArgs a) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) s += red[g][l];
     a.red[o] = s;
-  }
-}
-
-// T1 = sum xhat^T.dpre, s1 = sum dpre, T2 = sum hid^T.dy, s2 = sum dy  ->  parameter gradients
-//   dW1[c][h] = gamma_c T1[c][h] + beta_c s1[h] ; dgamma_c = sum_h W1[c][h] T1[c][h] ; dbeta_c = sum_h W1[c][h] s1[h]
-//   db1 = s1 ; dW2 = T2 ; db2 = s2
-template <int W>
-__global__ void __launch_bounds__(256) k_ffn_param_grads(FfnArgs a) {
-  FFN_GEO(W);
-  const float* T1 = a.red;
-  const float* T2 = a.red + SLABF;
-  const float* s1 = a.red + 2 * SLABF;
-  const float* s2 = s1 + FH;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < SLABF; i += gridDim.x * 256) {
-    a.g_W1[i] = fmaf(a.gamma[i / FH], T1[i], a.beta[i / FH] * s1[i % FH]);
-    a.g_W2[i] = T2[i];
-  }
-  if (blockIdx.x == 0) {
-    const int t = threadIdx.x;
-    if (t < FH) a.g_b1[t] = s1[t];
-    if (t < FW) {
-      a.g_b2[t] = s2[t];
-      float dg = 0.f, db = 0.f;
-      for (int h = 0; h < FH; ++h) {
-        const float w = a.W1[t * FH + h];
-        dg = fmaf(w, T1[t * FH + h], dg);
-        db = fmaf(w, s1[h], db);
-      }
-      a.g_gamma[t] = dg;
-      a.g_beta[t] = db;
-    }
   }
 }
 
@@ -966,27 +978,6 @@ __global__ void __launch_bounds__(256, F8_BWD_OCC) k_ffn8_bwd(FfnArgs a) {
   for (int i = threadIdx.x; i < F8_PART; i += 256) out[i] = red[i];
 }
 
-// width 8: reduced sums (a.red: T1[c][h] | T2^T[o][h] | s1 | s2) -> parameter gradients (the formulas of k_ffn_param_grads)
-__global__ void __launch_bounds__(128) k_ffn8_param_grads(FfnArgs a) {
-  const float* T1 = a.red; const float* T2t = a.red + 128; const float* s1 = a.red + 256; const float* s2 = a.red + 272;
-  const int t = threadIdx.x;
-  {
-    const int c = t >> 4, h = t & 15;
-    a.g_W1[t] = fmaf(a.gamma[c], T1[t], a.beta[c] * s1[h]);
-  }
-  {
-    const int h = t >> 3, o = t & 7;
-    a.g_W2[t] = T2t[o * 16 + h];
-  }
-  if (t < 16) a.g_b1[t] = s1[t];
-  if (t < 8) {
-    a.g_b2[t] = s2[t];
-    float dg = 0.f, db = 0.f;
-    for (int h = 0; h < 16; ++h) { const float w = a.W1[t * 16 + h]; dg = fmaf(w, T1[t * 16 + h], dg); db = fmaf(w, s1[h], db); }
-    a.g_gamma[t] = dg; a.g_beta[t] = db;
-  }
-}
-
 // ------------------------------------------------------------------ host glue --
 #define FFN_NWG 256   // W >= 48: at most one backward workgroup per CU (4 waves, 1 per SIMD: the 512-register kernel)
 // narrower rows need < 128 registers and ~20 KB of LDS per workgroup: several workgroups per CU hide each other's latency
@@ -1168,22 +1159,27 @@ extern "C" int egt_ffn_bwd(const egt_ffn_desc* desc, const egt_ffn_params* param
   a.g_W1 = (float*)grads->lr1_kernel; a.g_b1 = (float*)grads->lr1_bias;
   a.g_W2 = (float*)grads->lr2_kernel; a.g_b2 = (float*)grads->lr2_bias;
   hipStream_t st = (hipStream_t)stream;
+  const bool prepared = (desc->flags & EGT_FFN_WS_PREPARED) != 0;   // the forward's workspace: its prepared operands are still there
   if (a.row8) {
-    EGT_LAUNCH("k_ffn_prep", k_ffn8_prep, dim3(1), dim3(128), 0, st, a);
+    if (!prepared) EGT_LAUNCH("k_ffn_prep", k_ffn8_prep, dim3(1), dim3(128), 0, st, a);
     if (desc->activation == EGT_ACT_RELU) EGT_LAUNCH("k_ffn_bwd", k_ffn8_bwd<EGT_ACT_RELU>, dim3(a.nwg), dim3(256), 0, st, a);
     else EGT_LAUNCH("k_ffn_bwd", k_ffn8_bwd<EGT_ACT_ELU>, dim3(a.nwg), dim3(256), 0, st, a);
     EGT_LAUNCH("k_ffn_sum", k_ffn_sum, dim3((F8_PART + 63) / 64), dim3(1024), 0, st, a);
-    EGT_LAUNCH("k_ffn_param_grads", k_ffn8_param_grads, dim3(1), dim3(128), 0, st, a);
+    EGT_LAUNCH("k_ffn_param_grads", k_ffn_param_grads, dim3(1), dim3(1024), 0, st, a);
     EGT_HIP_LAUNCH_CHECK("egt_ffn_bwd");
     return EGT_OK;
   }
-  FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep<W>, dim3((2 * W * W + 255) / 256), dim3(256), 0, st, a));
-  if (desc->matmul != EGT_MM_F32)
-    FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep_bf<W>, dim3(ffn_bf_prep_blocks(W)), dim3(256), 0, st, a));
+  if (!prepared) {   // (the bf16 modes read their own slabs and b1p only: k_ffn_prep_bf writes all of that)
+    if (desc->matmul == EGT_MM_F32) {
+      FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep<W>, dim3((2 * W * W + 255) / 256), dim3(256), 0, st, a));
+    } else {
+      FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_prep", k_ffn_prep_bf<W>, dim3(ffn_bf_prep_blocks(W)), dim3(256), 0, st, a));
+    }
+  }
   FFN_DISPATCH_W(desc->width, ffn_launch_bwd<W>(a, desc->activation, st));
   const int part = a.part_len;
   EGT_LAUNCH("k_ffn_sum", k_ffn_sum, dim3((part + 63) / 64), dim3(1024), 0, st, a);
-  FFN_DISPATCH_W(desc->width, EGT_LAUNCH("k_ffn_param_grads", k_ffn_param_grads<W>, dim3(16), dim3(256), 0, st, a));
+  EGT_LAUNCH("k_ffn_param_grads", k_ffn_param_grads, dim3(1), dim3(1024), 0, st, a);
   EGT_HIP_LAUNCH_CHECK("egt_ffn_bwd");
   return EGT_OK;
 }

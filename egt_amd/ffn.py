@@ -27,7 +27,7 @@ def _desc(rows: int, width: int, activation: str, eps: float, matmul: str = "f32
     if matmul not in _MM:
         raise ValueError(f"matmul must be one of {sorted(_MM)} (got {matmul!r})")
     return L.FfnDesc(rows=rows, width=width, dtype=L.EGT_F32, activation=_ACT[activation], ln_eps=eps,
-                     matmul=_MM[matmul], reserved=0)
+                     matmul=_MM[matmul], flags=0)
 
 
 def _pstruct(tensors) -> L.FfnParams:
@@ -49,6 +49,7 @@ class _FusedFFN(torch.autograd.Function):
         pst = _pstruct(params)
         L.check(lib.egt_ffn_fwd(C.byref(desc), C.byref(pst), L.ptr(x), L.ptr(y), L.ptr(ws), L.current_stream()))
         ctx.desc = desc
+        ctx.ws = ws   # the backward reuses the prepared operands in it (EGT_FFN_WS_PREPARED: one launch less)
         ctx.save_for_backward(x, *params)
         return y
 
@@ -60,10 +61,11 @@ class _FusedFFN(torch.autograd.Function):
         dy = _f32c(dy)
         dx = torch.empty_like(x)
         grads = [torch.empty_like(p) for p in params]
-        ws = torch.empty(lib.egt_ffn_workspace_bytes(C.byref(desc)), dtype=torch.uint8, device=x.device)
+        bdesc = L.FfnDesc.from_buffer_copy(desc)
+        bdesc.flags = L.FFN_WS_PREPARED
         pst, gst = _pstruct(params), _pstruct(grads)
-        L.check(lib.egt_ffn_bwd(C.byref(desc), C.byref(pst), L.ptr(x), L.ptr(dy), L.ptr(dx), C.byref(gst),
-                                L.ptr(ws), L.current_stream()))
+        L.check(lib.egt_ffn_bwd(C.byref(bdesc), C.byref(pst), L.ptr(x), L.ptr(dy), L.ptr(dx), C.byref(gst),
+                                L.ptr(ctx.ws), L.current_stream()))
         return (dx, None, *grads)
 
 

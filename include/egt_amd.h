@@ -324,8 +324,12 @@ typedef struct egt_ffn_desc {
   int32_t activation; /* EGT_ACT_* (config.activation) */
   float ln_eps;       /* 1e-3 */
   int32_t matmul;     /* EGT_MM_* */
-  int32_t reserved;
+  int32_t flags;      /* EGT_FFN_* (0 for plain calls) */
 } egt_ffn_desc;
+/* egt_ffn_bwd only: `workspace` is the buffer an egt_ffn_fwd call with the same rows / width / activation / matmul and
+ * the same parameter VALUES has used on this stream or an earlier-ordered one; the prepared operands in it
+ * (LayerNorm-folded weight slabs) are reused and the backward skips its preparation launch. */
+#define EGT_FFN_WS_PREPARED 1
 
 typedef struct egt_ffn_params {
   const void* norm_gamma;  /* [W]     norm_fnn_{node,edge}_XX */
