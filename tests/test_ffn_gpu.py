@@ -148,3 +148,31 @@ def test_ffn_vs_golden(name, gpu, egt_lib):
     assert_close(x.grad, g["out"]["dx"], name="dx", **BWD)
     for k in CS.FFN_NAMES:
         assert_close(prm[k].grad, g["dparams"][k], name=k, **BWD)
+
+
+@pytest.mark.parametrize("W,matmul", [(64, "f32"), (48, "bf16x3"), (8, "f32")])
+def test_ffn_bwd_on_a_fresh_workspace_equals_the_prepared_one(W, matmul, gpu, egt_lib):
+    """egt_ffn_bwd called the plain way (flags = 0: it prepares its own operands) gives the bits of the autograd path, which
+    hands the forward's workspace back with EGT_FFN_WS_PREPARED"""
+    import ctypes as C
+    from egt_amd import FFN, _lib as L
+    from egt_amd.ffn import _desc, _pstruct
+    torch.manual_seed(11)
+    m = FFN(W, matmul=matmul).to(gpu)
+    x = torch.randn(3, 33, 33, W, device=gpu)
+    dy = torch.randn_like(x)
+    xg = x.clone().requires_grad_()
+    m(xg).backward(dy)
+    params = [getattr(m, n).detach().contiguous() for n in NAMES]
+    desc = _desc(x.numel() // W, W, "elu", 1e-3, matmul)
+    assert desc.flags == 0
+    ws = torch.empty(egt_lib.egt_ffn_workspace_bytes(C.byref(desc)), dtype=torch.uint8, device=gpu)
+    dx = torch.empty_like(x)
+    grads = [torch.empty_like(p) for p in params]
+    pst, gst = _pstruct(params), _pstruct(grads)
+    L.check(egt_lib.egt_ffn_bwd(C.byref(desc), C.byref(pst), L.ptr(x), L.ptr(dy), L.ptr(dx), C.byref(gst), L.ptr(ws),
+                                L.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(dx, xg.grad)
+    for n, g in zip(NAMES, grads):
+        assert torch.equal(g, getattr(m, n).grad), n
