@@ -272,6 +272,11 @@ def main():
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--dominant", default="k_block_bwd",
                     help="kernel timed with hipEvents inside the timed region")
+    ap.add_argument("--graph", default="off", choices=["off", "on"],
+                    help="on: forward + backward of the step replayed from ONE captured hipGraph (egt_amd.graph.GraphedStep; the "
+                         "random-mask seeds live in device memory, EGT_BF_SEED_DEVICE, and advance inside the graph, so every "
+                         "replay draws a fresh sample); the gradient collective stays an eager call after the replay.  The "
+                         "dominant kernel is then timed in the untimed eager pass (a replay has no per-launch host hooks)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's B graphs per GPU; strong: B graphs split over the ranks")
     ap.add_argument("--dp-backend", default="torch", choices=["torch", "capi"],
@@ -385,7 +390,7 @@ def main():
     ar_kw = dict(local_count=w["B"], global_count=global_B) if args.scaling == "strong" else {}
     ar_kw["force"] = use_dist            # a launched 1-rank job still issues the RCCL collective
 
-    def step():
+    def compute():
         # fused stack: the backward writes every parameter gradient into one flat buffer whose
         # views autograd adopts as .grad (no per-parameter kernels); the DP collective runs on it.
         # composed path: classic flat buffer pre-bound to .grad (decided on the first warm-up step).
@@ -410,11 +415,14 @@ def main():
             h.grad = None; e.grad = None
             h2, e2 = model(h, e, mask)
             torch.autograd.backward([h2, e2], [dh, de])
+
+    def reduce():
         if state["flat_ok"] is None:
             state["flat_ok"] = flat_grad_view(params, model.grad_holder.flat)
             if not state["flat_ok"]:
                 state["fa"] = FlatGradAllReduce(params)   # takes effect from the next step
                 return
+        fa = state["fa"]
         evs = state["ar_events"]
         if evs is not None:              # hipEvents around the collective (untimed pass only)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -430,6 +438,19 @@ def main():
             e1.record()
             evs.append((e0, e1))
 
+    seeds = None
+    if args.graph == "on":               # from here on every EGT module reads its mask seed from HBM (eager steps too)
+        from egt_amd import DeviceSeeds
+        seeds = DeviceSeeds.attach(model, dev)
+
+    def eager_step():
+        if seeds is not None:
+            seeds.advance()
+        compute()
+        reduce()
+
+    step = eager_step
+
     def fence():
         torch.cuda.synchronize()
         if use_dist:
@@ -439,6 +460,17 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    graphed = None
+    if args.graph == "on":
+        from egt_amd import GraphedStep
+        graphed = GraphedStep(compute, seeds, warmup=1)
+
+        def step():                      # ONE host call for forward + backward, then the eager collective
+            graphed.replay()
+            reduce()
+        for _ in range(3):
+            step()
+        fence()
     # Timed region.  hipEvents bracket ONLY the dominant kernel's launches here (an event pair
     # around every launch costs ~15% of the step); the per-kernel table comes from a second,
     # untimed pass over the same steps below.
@@ -467,7 +499,7 @@ def main():
         lib.egt_prof_filter(b"")
         lib.egt_prof_enable(2)
         for _ in range(min(args.steps, 10)):
-            step()
+            eager_step()                 # (per-launch hipEvents need the host-side launches: eager also in --graph runs)
         fence()
         lib.egt_prof_enable(0)
         all_prof = prof_read_all(lib)
@@ -476,7 +508,7 @@ def main():
     if use_dist:
         state["ar_events"] = []
         for _ in range(min(args.steps, 10)):
-            step()
+            eager_step()
         fence()
         ts = sorted(a.elapsed_time(b) * 1e3 for a, b in state["ar_events"])
         state["ar_events"] = None
@@ -556,7 +588,9 @@ def main():
                        "random_mask_prob": w["rand_p"], "nodes": list(w["nodes"]), "path": path,
                        "parallelism": f"dp{world}", "grad_allreduce_bytes": nbytes,
                        "grad_allreduce_us": ar_us, "backend": ("rccl (egt_dp_* C-ABI)" if comm is not None else "rccl") if use_dist else "none (single process)",
-                       "flat_grad_adopted": bool(state["flat_ok"])},
+                       "flat_grad_adopted": bool(state["flat_ok"]),
+                       "hipgraph": (f"forward + backward replayed from one captured hipGraph ({graphed.replays} replays), device-resident "
+                                    "mask seeds; dominant kernel timed in the untimed eager pass") if graphed is not None else None},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

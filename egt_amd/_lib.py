@@ -22,7 +22,7 @@ F_SCALER_LINEAR, F_TRAINING, F_CLIP = 0x010, 0x020, 0x040
 EP_LAYERNORM, EP_GATES = 0x1, 0x2
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_ELU = 0, 1, 2, 3
 # egt_block_desc.flags
-BF_GATE, BF_ATTN_MASK, BF_TRAINING, BF_CLIP, BF_NO_EDGE_LN = 0x1, 0x2, 0x4, 0x8, 0x10
+BF_GATE, BF_ATTN_MASK, BF_TRAINING, BF_CLIP, BF_NO_EDGE_LN, BF_SEED_DEVICE = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 
 
 class AttnDesc(C.Structure):
@@ -45,7 +45,7 @@ class BlockDesc(C.Structure):
                 ("De", C.c_int32), ("dtype", C.c_int32), ("flags", C.c_uint32),
                 ("clip_lo", C.c_float), ("clip_hi", C.c_float),
                 ("random_mask_prob", C.c_float), ("ln_eps", C.c_float),
-                ("reserved", C.c_int32), ("seed", C.c_uint64)]
+                ("reserved", C.c_int32), ("seed", C.c_uint64), ("seed_device", C.c_void_p)]
 
 
 class FfnDesc(C.Structure):
@@ -171,7 +171,7 @@ def load():
         if hasattr(lib, name):
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-    if lib.egt_abi_version() != 2:
+    if lib.egt_abi_version() != 3:
         raise EGTLibraryError("ABI version mismatch")
     _lib = lib
     return lib

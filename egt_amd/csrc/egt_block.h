@@ -15,6 +15,7 @@ struct BlockArgs {
   int bf16;   // edge tensors e / e' / de' / de are bf16 in HBM (arithmetic stays fp32)
   float clip_lo, clip_hi, scale, ln_eps;
   uint32_t rm_thr, s0, s1;
+  const uint32_t* sd;   // EGT_BF_SEED_DEVICE: the two words XORed into (s0, s1) at kernel entry (seed_from_device)
   int rng_rm;
   int TL, NLR;  // backward: query rows per workgroup, row-ranges per graph
   int NQP;      // backward: dQ partials per row (key tiles) in dqp [B][NQP][N][64]

@@ -61,6 +61,7 @@
 #endif
 template <int DE, bool KVL, bool ML, bool FULL, bool BF>
 __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd(BlockArgs a) {   // narrow tiles without K/V in LDS: more resident waves (with K/V in LDS the LDS footprint caps a CU at two workgroups anyway)
+  seed_from_device(a);
   using G = Geo<DE>;
   typedef typename EdgeT<BF>::type ET;   // element type of the edge tensors in HBM
   const ET* e_in = reinterpret_cast<const ET*>(a.e);
@@ -335,6 +336,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
 // once per 32 rows.
 template <int DE, bool FULL, int NW, bool BF>
 __global__ void __launch_bounds__(64 * NW, 2) k_block_fwd_r4(BlockArgs a) {
+  seed_from_device(a);
   typedef typename EdgeT<BF>::type ET;   // element type of the edge tensors in HBM
   constexpr int RW = 4 * NW, NT = 64 * NW;   // rows / threads per workgroup
   using G = Geo<DE>;
@@ -531,6 +533,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_fwd_r4(BlockArgs a) {
 // it walks the TL rows.  Q / dV_att / softmax statistics of the rows sit in LDS.
 template <int DE, bool ML, bool FULL, bool BF>
 __global__ void __launch_bounds__(256, 1) k_block_bwd(BlockArgs a) {
+  seed_from_device(a);
   using G = Geo<DE>;
   typedef typename EdgeT<BF>::type ET;   // element type of the edge tensors in HBM
   const ET* e_in = reinterpret_cast<const ET*>(a.e);
@@ -836,6 +839,7 @@ __global__ void __launch_bounds__(256, 1) k_block_bwd(BlockArgs a) {
 // gate exactly 0, the last row group is short (the row loop and the prologue already take nl < 16).
 template <int DE, bool ML, int PF, bool BF, bool RAG>
 __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
+  seed_from_device(a);
   using G = Geo<DE>;
   typedef typename EdgeT<BF>::type ET;   // element type of the edge tensors in HBM
   const ET* e_in = reinterpret_cast<const ET*>(a.e);
@@ -1234,6 +1238,7 @@ __device__ __forceinline__ float elem_read_st(const float* lane_base, const floa
 // fp32 value it replaces.
 template <int DE, int MM>
 __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
+  seed_from_device(a);
   constexpr bool SPLIT = MM == EGT_MM_BF16X3;
   constexpr int NS = (Geo<DE>::TILES + 1) / 2;   // 16x16x32 steps over the channel axis
   (void)SPLIT; (void)NS;
@@ -1639,6 +1644,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
 // in flight during the arithmetic.  Same arguments, partial layouts and prologue as v4.
 template <int DE, bool BF, int R>
 __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R rows per iteration
+  seed_from_device(a);
   using G = Geo<DE>;
   typedef typename EdgeT<BF>::type ET;
   const ET* e_in = reinterpret_cast<const ET*>(a.e);
@@ -2060,6 +2066,7 @@ static int block_check(const egt_block_desc* d, bool report) {
     default: BAD(EGT_E_SHAPE, "fused block covers edge_width in {8,16,32,48,64} (got %d)", d->De);
   }
   if ((size_t)d->B * d->N * d->N * d->H > 0xFFFFFFFFull) BAD(EGT_E_SHAPE, "B*N*N*H exceeds the 32-bit RNG counter");
+  if ((d->flags & EGT_BF_SEED_DEVICE) && !d->seed_device) BAD(EGT_E_NULL, "EGT_BF_SEED_DEVICE set but seed_device is NULL");
   return EGT_OK;
 #undef BAD
 }
@@ -2156,6 +2163,7 @@ static int fill_block(const egt_block_desc* d, const egt_block_params* p, BlockA
   a.rm_thr = egt_threshold24(d->random_mask_prob);
   a.s0 = (uint32_t)(d->seed & 0xFFFFFFFFull);
   a.s1 = (uint32_t)(d->seed >> 32);
+  a.sd = (d->flags & EGT_BF_SEED_DEVICE) ? (const uint32_t*)d->seed_device : nullptr;
   a.ne_g = (const float*)p->norm_edge_gamma; a.ne_b = (const float*)p->norm_edge_beta;
   a.Wg = (const float*)p->attention_gates_kernel; a.bg = (const float*)p->attention_gates_bias;
   a.We = (const float*)p->dense_edge_b_kernel; a.be = (const float*)p->dense_edge_b_bias;

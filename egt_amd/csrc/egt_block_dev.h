@@ -23,6 +23,12 @@ __device__ __forceinline__ v4f project(const float4 (&x)[Geo<DE>::TILES],
 // Per-pair mask inputs, fetched with the tile prefetch (unconditional, clamped).
 struct MaskRegs { float2 mv; unsigned short rb; };
 
+// EGT_BF_SEED_DEVICE: the mask stream's seed is completed on the device (uniform scalar loads), so that a
+// captured launch (hipGraph) draws a fresh sample on every replay.  First statement of every pair kernel.
+__device__ __forceinline__ void seed_from_device(BlockArgs& a) {
+  if (a.sd) { a.s0 ^= a.sd[0]; a.s1 ^= a.sd[1]; }
+}
+
 template <bool ML>
 __device__ __forceinline__ void mask_gload(const BlockArgs& a, MaskRegs& mr, size_t pairc, int q) {
   // pairc: linear pair index of a VALID pair (clamped by the caller)

@@ -109,6 +109,7 @@ template <> struct NrwLd<true> {
 #define NRW_FWD_AREA ((3 * 20 * 64) > (4 * NRW_KV_CHUNK + 4 * NRW_KB) ? (3 * 20 * 64) : (4 * NRW_KV_CHUNK + 4 * NRW_KB))
 template <bool BF, int FEAT>
 __global__ void __launch_bounds__(256, NRW_FWD_OCC) k_narrow_fwd(BlockArgs a) {
+  seed_from_device(a);
   typedef NrwLd<BF> LD;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -388,6 +389,7 @@ void egt_narrow_launch_fwd(BlockArgs& a, hipStream_t st) {
 #define NRW_TAB_FLOATS 368
 template <bool BF, int FEAT>
 __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
+  seed_from_device(a);
   typedef NrwLd<BF> LD;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -18,8 +18,10 @@ _GRAD_ORDER = (("norm_edge", "gamma"), ("norm_edge", "beta"),
                ("dense_edge_r", "kernel"), ("dense_edge_r", "bias"))
 
 
-def _desc(blk, B, N, training, seed, edge_dtype=torch.float32) -> L.BlockDesc:
+def _desc(blk, B, N, training, seed, edge_dtype=torch.float32, seed_device=None) -> L.BlockDesc:
     flags = 0
+    if seed_device is not None:      # egt_amd.graph.DeviceSeeds: the kernels complete the seed from HBM
+        flags |= L.BF_SEED_DEVICE
     if blk.gated:
         flags |= L.BF_GATE
     if blk.edge_channel_type == "constrained":
@@ -35,7 +37,8 @@ def _desc(blk, B, N, training, seed, edge_dtype=torch.float32) -> L.BlockDesc:
     return L.BlockDesc(B=B, N=N, H=blk.num_heads, d=blk.model_width // blk.num_heads,
                        De=blk.edge_width, dtype=L.EGT_BF16 if edge_dtype == torch.bfloat16 else L.EGT_F32, flags=flags, clip_lo=lo, clip_hi=hi,
                        random_mask_prob=float(blk.mha.random_mask_prob), ln_eps=1e-3, reserved=0,
-                       seed=int(seed) & 0xFFFFFFFFFFFFFFFF)
+                       seed=int(seed) & 0xFFFFFFFFFFFFFFFF,
+                       seed_device=None if seed_device is None else seed_device[0].ptr(seed_device[1]))
 
 
 def block_supported(blk, h, e, attn_mask, rand_mask) -> bool:
@@ -145,8 +148,9 @@ def _block_params(blk, e):
 
 def block_fused(blk, h, e, mask, attn_mask, rand_mask=None):
     training = blk.training and blk.mha.random_mask_prob > 0.0
-    seed = blk.mha.next_seed() if (training and rand_mask is None) else 0
-    desc = _desc(blk, h.shape[0], h.shape[1], training, seed, e.dtype)
+    sdev = blk.mha.seed_device if (training and rand_mask is None) else None
+    seed = blk.mha.next_seed() if (training and rand_mask is None and sdev is None) else 0
+    desc = _desc(blk, h.shape[0], h.shape[1], training, seed, e.dtype, sdev)
     params = _block_params(blk, e)
     if blk.edge_channel_type != "constrained":
         attn_mask = None
@@ -240,8 +244,9 @@ def stack_fused(stack, h, e, mask, attn_mask):
     blocks = list(stack.blocks)
     b0 = blocks[0]
     training = b0.training and b0.mha.random_mask_prob > 0.0
-    seed = b0.mha.next_seed() if training else 0
-    desc = _desc(b0, h.shape[0], h.shape[1], training, seed, e.dtype)
+    sdev = b0.mha.seed_device if training else None
+    seed = b0.mha.next_seed() if (training and sdev is None) else 0
+    desc = _desc(b0, h.shape[0], h.shape[1], training, seed, e.dtype, sdev)
     params = []
     for blk in blocks:
         params += _block_params(blk, e)

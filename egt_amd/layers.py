@@ -63,6 +63,7 @@ class EGT(nn.Module):
         self.name = name
         self.seed = int(seed)
         self._calls = 0
+        self.seed_device = None   # (DeviceSeeds, index): egt_amd.graph — the fused path then reads the seed on the device
         self.return_a_tild = True
 
     def get_config(self):
@@ -97,6 +98,9 @@ class EGT(nn.Module):
             mask = mask[0]                                         # :66
         assert QKV.shape[2] % (self.num_heads * 3) == 0            # :70
         stochastic = training and (self.random_mask_prob > 0.0 or self.attn_dropout > 0.0)
+        if stochastic and self.seed_device is not None and rand_mask is None:
+            raise RuntimeError("device-resident mask seeds (egt_amd.graph.DeviceSeeds) are a feature of the fused block / "
+                               "stack path; this call runs the composed operator whose seed is a host argument")
         cfg = EF.AttnConfig(num_heads=self.num_heads,
                             clip_logits_value=None if self.clip_logits_value is None
                             else tuple(self.clip_logits_value),

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EGT_ABI_VERSION 2
+#define EGT_ABI_VERSION 3
 
 /* error codes */
 #define EGT_OK 0
@@ -219,6 +219,11 @@ int egt_edge_update_bwd(const egt_edge_desc* desc, const void* d_e_out,
                                   the RAW e.  The caller passes norm_edge gamma = 1, beta = 0 and
                                   dense_edge_r kernel = bias = 0 (then e' = e); their gradient
                                   outputs are scratch */
+#define EGT_BF_SEED_DEVICE 0x20u /* hipGraph-safe random mask: the kernels draw from the stream seeded with
+                                  desc->seed ^ *desc->seed_device (a uint64 in DEVICE memory, read by the
+                                  kernel when it runs, not by the host at launch).  A captured step replays
+                                  with a fresh sample by advancing that word on the device; forward and
+                                  backward of one step must see the same value */
 
 typedef struct egt_block_desc {
   int32_t B, N, H, d, De;   /* model_width Dh = d*H                             */
@@ -229,6 +234,7 @@ typedef struct egt_block_desc {
   float ln_eps;             /* 1e-3                                             */
   int32_t reserved;
   uint64_t seed;
+  const void* seed_device;  /* EGT_BF_SEED_DEVICE: const uint64_t* on the device, else ignored (NULL) */
 } egt_block_desc;
 
 typedef struct egt_block_params {

@@ -38,3 +38,28 @@ def test_ffn_constructor_errors_and_cpu_refusal():
     m = FFN(64)
     with pytest.raises(Exception):          # no CPU fallback: the HIP path refuses CPU tensors
         m(torch.zeros(4, 64))
+
+def test_device_seeds_follow_next_seed_sequence():
+    """egt_amd.graph.DeviceSeeds (CPU tensors here): word i walks the module's host-side next_seed() sequence."""
+    import torch
+    from egt_amd import EGT, DeviceSeeds
+    a = [EGT(num_heads=8, random_mask_prob=0.1, seed=s) for s in (0, 5, 123456789)]
+    b = [EGT(num_heads=8, random_mask_prob=0.1, seed=s) for s in (0, 5, 123456789)]
+    for m in a + b:
+        m._calls = 3
+    seeds = DeviceSeeds(b, "cpu")
+    for _ in range(4):
+        seeds.advance()
+        assert seeds.values() == [m.next_seed() for m in a]
+    seeds.detach()
+    assert [m._calls for m in b] == [m._calls for m in a] and all(m.seed_device is None for m in b)
+
+
+def test_composed_operator_refuses_device_seed():
+    import pytest
+    import torch
+    from egt_amd import EGT, DeviceSeeds
+    m = EGT(num_heads=8, random_mask_prob=0.1, seed=1, edge_input=False, gate_input=False).train()
+    DeviceSeeds([m], "cpu")
+    with pytest.raises(RuntimeError, match="device-resident mask seeds"):
+        m([torch.zeros(1, 4, 3 * 8 * 2)], mask=None)
