@@ -88,6 +88,8 @@ def default_config(scheme: str = "zinc.svd") -> Config:
         save_best_monitor="val_loss", stopping_patience=0,
         predictions_path=lambda c: path.join(c.save_path, "predictions"),
         weight_file=":", prediction_bmult=2, optimizer="adam",
+        use_hipgraph=False,      # (not a reference key) forward + loss + backward of a training batch replayed from a hipGraph
+                                 # captured per batch geometry: egt_amd.graph; for launch-bound per-GPU batches
     )
     c.update(  # BaseDCModelScheme
         model_name="dc", dataset_name="dataset",
@@ -329,9 +331,18 @@ class ZincSVDScheme:
         self.optimizer = self.get_optimizer(params)
         self.loss_fn = self.get_loss()
         self.flat = None
-        if self.config.distributed and torch.distributed.is_available() and torch.distributed.is_initialized():
+        self._graphs, self._seeds = {}, None
+        self._use_graph = bool(self.config.use_hipgraph)
+        if self._use_graph and not (self.device is not None and torch.device(self.device).type == "cuda"):
+            raise ValueError("config.use_hipgraph needs the model on a GPU (device='cuda')")
+        if self._use_graph or (self.config.distributed and torch.distributed.is_available() and torch.distributed.is_initialized()):
             from .dp import FlatGradAllReduce
             self.flat = FlatGradAllReduce(params)     # one flat-buffer all-reduce per step (MirroredStrategy, :230-247)
+        if self._use_graph:                           # every captured geometry writes its gradients into this one flat buffer
+            from .graph import DeviceSeeds
+            from .layers import EGT
+            if any(isinstance(m, EGT) for m in self.model.modules()):
+                self._seeds = DeviceSeeds.attach(self.model, self.device)
 
     # ---- lr ----
     def get_lr(self):
@@ -416,6 +427,32 @@ class ZincSVDScheme:
         y = self.model(nf, fm, adj)
         return self.loss_fn(y, tgt), dict(mae=((y - tgt).abs().sum().detach(), tgt.numel()))
 
+    def _graphed_loss(self, batch):
+        """config.use_hipgraph: forward + loss + backward of a training batch as ONE hipGraph launch.  A graph is captured
+        per batch geometry (the padded node count varies from batch to batch) around static copies of the batch tensors;
+        all graphs accumulate into the scheme's one flat gradient buffer and advance the same device-resident mask seeds.
+        The first batch of a new geometry pays the capture (one eager warm-up step, whose sample is discarded)."""
+        from .graph import GraphedStep
+        dev = self.device
+        moved = {k: v.to(dev) for k, v in batch.items() if torch.is_tensor(v)}
+        key = tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(moved.items()))
+        ent = self._graphs.get(key)
+        if ent is None:
+            static = {k: v.clone() for k, v in moved.items()}
+
+            def fn():
+                self.flat.zero(); self.flat.rebind()
+                loss, _ = self.batch_loss(static)
+                loss.backward()
+                return loss.detach()
+            ent = self._graphs[key] = (static, GraphedStep(fn, self._seeds, warmup=1))
+        else:
+            for k, v in moved.items():
+                ent[0][k].copy_(v, non_blocking=True)
+        loss = ent[1].replay()
+        self.flat.rebind()                           # .grad = this buffer's views, whichever graph ran last
+        return loss
+
     def train_step(self, batch):
         c = self.config
         if c.warmup_steps > 0:
@@ -423,13 +460,16 @@ class ZincSVDScheme:
             if lr is not None:
                 self.set_lr(lr)
             self.stop_training |= stop
-        if self.flat is not None:
-            self.flat.zero(); self.flat.rebind()
-        else:
-            self.optimizer.zero_grad(set_to_none=True)
         self.model.train()
-        loss, _ = self.batch_loss(batch)
-        loss.backward()
+        if self._use_graph:
+            loss = self._graphed_loss(batch)
+        else:
+            if self.flat is not None:
+                self.flat.zero(); self.flat.rebind()
+            else:
+                self.optimizer.zero_grad(set_to_none=True)
+            loss, _ = self.batch_loss(batch)
+            loss.backward()
         if self.flat is not None:
             self.flat.all_reduce(average=True)
         if c.gradient_clipval is not None:           # Keras clipvalue: elementwise clip of every gradient
@@ -523,7 +563,9 @@ class PatternSVDScheme(ZincSVDScheme):
         nf, adj, tgt = mv(batch["node_features"]), mv(batch["graph_matrix"]), mv(batch["target"])
         out = self.model(nf, adj, return_mask=True)
         logits, mask = out
-        w = class_weights_from_sizes(self.config.class_sizes, device=logits.device)
+        if getattr(self, "_class_w", None) is None or self._class_w.device != logits.device:
+            self._class_w = class_weights_from_sizes(self.config.class_sizes, device=logits.device)   # once: a host -> device copy cannot be captured
+        w = self._class_w
         loss = self.loss_fn(logits, tgt, mask, w)
         m = mask.to(logits.dtype)
         hit = ((logits.argmax(-1) == tgt).to(logits.dtype) * m).sum().detach()

@@ -231,3 +231,34 @@ def test_cifar10_scheme_trains_on_the_gpu(tmp_path, gpu, egt_lib):
     assert 0.0 <= s.history[-1]["val_acc"] <= 1.0
     w = np.load(tmp_path / "run" / "saved" / "c.npz")
     assert "node_emb/kernel" in w.files and "edge_emb/kernel" in w.files and "adj_emb/kernel" in w.files
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["zinc", "pattern"])
+def test_use_hipgraph_reproduces_the_eager_training_run(which, tmp_path, gpu, egt_lib):
+    """config.use_hipgraph: forward + loss + backward replayed from one hipGraph per batch geometry.  Without the random
+    mask the run is a deterministic function of the weights and the batches, so the graphed run must reproduce the eager
+    run's loss history EXACTLY; with it, every geometry's graph advances the shared device-resident seeds and trains."""
+    if which == "zinc":
+        cls, data, kw = T.ZincSVDScheme, T.SyntheticZinc, dict(scheme="zinc.svd", model_width=32, edge_width=32, batch_size=32)
+        mk = lambda seed, n: data(n, 32, seed=seed, pad_multiple=16)
+    else:
+        cls, data, kw = T.PatternSVDScheme, T.SyntheticPattern, dict(scheme="pattern.svd", model_width=32, edge_width=8, batch_size=16)
+        mk = lambda seed, n: data(n, 16, nodes=(20, 44), seed=seed, pad_multiple=16)
+
+    def run(tag, graph, p):
+        torch.manual_seed(0)
+        cfg = dict(kw, model_name=tag, num_epochs=2, initial_lr=2e-3, use_svd=False, model_height=2, upto_hop=4,
+                   random_mask_prob=p, use_hipgraph=graph, save_path=str(tmp_path / tag))
+        s = cls(cfg, device=gpu, print_fn=lambda *a: None)
+        s.execute_training(mk(1, 128), mk(2, 32))
+        return s
+    eager, graphed = run("e", False, 0.0), run("g", True, 0.0)
+    assert len(graphed._graphs) >= 2                                   # several padded node counts -> several graphs
+    assert [h["loss"] for h in graphed.history] == [h["loss"] for h in eager.history]
+    for a, b in zip(eager.params, graphed.params):
+        assert torch.equal(a, b)
+    r = run("r", True, 0.1)
+    assert r.history[-1]["loss"] < r.history[0]["loss"] and r._seeds is not None
+    with pytest.raises(ValueError, match="use_hipgraph needs"):
+        cls(dict(kw, use_hipgraph=True, use_svd=False), device=None).load_model()
