@@ -240,11 +240,11 @@ def test_use_hipgraph_reproduces_the_eager_training_run(which, tmp_path, gpu, eg
     mask the run is a deterministic function of the weights and the batches, so the graphed run must reproduce the eager
     run's loss history EXACTLY; with it, every geometry's graph advances the shared device-resident seeds and trains."""
     if which == "zinc":
-        cls, data, kw = T.ZincSVDScheme, T.SyntheticZinc, dict(scheme="zinc.svd", model_width=32, edge_width=32, batch_size=32)
-        mk = lambda seed, n: data(n, 32, seed=seed, pad_multiple=16)
+        cls, data, kw = T.ZincSVDScheme, T.SyntheticZinc, dict(scheme="zinc.svd", model_width=32, edge_width=32, batch_size=8)
+        mk = lambda seed, n: data(n // 2, 8, seed=seed, pad_multiple=1)
     else:
-        cls, data, kw = T.PatternSVDScheme, T.SyntheticPattern, dict(scheme="pattern.svd", model_width=32, edge_width=8, batch_size=16)
-        mk = lambda seed, n: data(n, 16, nodes=(20, 44), seed=seed, pad_multiple=16)
+        cls, data, kw = T.PatternSVDScheme, T.SyntheticPattern, dict(scheme="pattern.svd", model_width=32, edge_width=8, batch_size=8)
+        mk = lambda seed, n: data(n // 2, 8, nodes=(20, 44), seed=seed, pad_multiple=1)
 
     def run(tag, graph, p):
         torch.manual_seed(0)
