@@ -41,6 +41,21 @@ def test_bench_one_rank_under_launcher_uses_rccl():
     assert line["value"] > 0 and line["scaling"] == "weak"
 
 
+def test_bench_graph_replay_under_launcher_with_the_eager_collective():
+    """--graph on: forward + backward replayed from one hipGraph, the RCCL collective issued eagerly after each replay"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", "29634", os.path.join(REPO, "bench.py"),
+           "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--layers", "2", "--graph", "on"]
+    r = subprocess.run(cmd, cwd=REPO, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 1 and line["config"]["backend"] == "rccl"
+    assert "hipGraph (6 replays)" in line["config"]["hipgraph"]            # 3 settle + 3 timed
+    assert line["config"]["grad_allreduce_us"] is not None and line["config"]["grad_allreduce_us"] > 0
+    assert line["roofline"]["timed_in_region"] is False and line["roofline"]["avg_launch_us"] > 0
+    assert line["value"] > 0
+
+
 def test_bench_one_rank_through_the_capi_communicator():
     """--dp-backend capi: the step's collective is egt_dp_allreduce (ncclAllReduce on the compute stream)"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
