@@ -124,3 +124,32 @@ def test_ffn_and_mfma_argument_validation_without_gpu(egt_lib):
     assert egt_lib.egt_block_supported(C.byref(b)) == 1                 # bf16 edge tensors are covered
     b.dtype = 5
     assert egt_lib.egt_block_supported(C.byref(b)) == 0
+
+
+def test_header_compiles_as_c_and_struct_layouts_match_the_ctypes_mirrors(tmp_path):
+    """include/egt_amd.h is the boundary: plain C (gcc -std=c99, no HIP / torch types), and every struct a caller fills has
+    the size and field offsets of its ctypes mirror in egt_amd/_lib.py (a silent mismatch would shift every later field)."""
+    import ctypes as C
+    import subprocess
+    from egt_amd import _lib as L
+    pairs = [("egt_attn_desc", L.AttnDesc), ("egt_edge_desc", L.EdgeDesc), ("egt_block_desc", L.BlockDesc),
+             ("egt_block_params", L.BlockParams), ("egt_ffn_desc", L.FfnDesc), ("egt_ffn_params", L.FfnParams),
+             ("egt_embed_desc", L.EmbedDesc)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "egt_amd.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  printf("abi %d\\n", EGT_ABI_VERSION);', '  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = dict(ln.rsplit(" ", 1) for ln in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+    assert int(got["abi"]) == 3
