@@ -277,6 +277,8 @@ def main():
                          "random-mask seeds live in device memory, EGT_BF_SEED_DEVICE, and advance inside the graph, so every "
                          "replay draws a fresh sample); the gradient collective stays an eager call after the replay.  The "
                          "dominant kernel is then timed in the untimed eager pass (a replay has no per-launch host hooks)")
+    ap.add_argument("--overlap-ffn", action="store_true",
+                    help="layers / model scopes: the node FFN of a layer runs on a side stream beside the edge FFN (EGTLayerStack.overlap_ffn)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's B graphs per GPU; strong: B graphs split over the ranks")
     ap.add_argument("--dp-backend", default="torch", choices=["torch", "capi"],
@@ -379,6 +381,8 @@ def main():
     else:
         model = EGTStack(model_height=w["Ly"], model_width=w["Dh"], edge_width=w["De"], num_heads=w["H"],
                          random_mask_prob=w["rand_p"], seed=mask_seed, fused=fused).to(dev).train()
+    if args.overlap_ffn:
+        (model.layers if args.scope == "model" else model).overlap_ffn = True
     h, e, mask, dh, de = make_inputs(w, dev, seed=1234 + rank)  # each rank its own graphs
     if bf16:
         e, de = e.bfloat16(), de.bfloat16()

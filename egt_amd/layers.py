@@ -348,6 +348,8 @@ class EGTLayerStack(nn.Module):
         self.ffn_node = nn.ModuleList([FFN(model_width, activation=activation) for _ in range(model_height)])
         self.ffn_edge = nn.ModuleList([FFN(edge_width, activation=activation) for _ in range(model_height)]) \
             if ect in ('residual', 'constrained') else None
+        self.overlap_ffn = False     # node FFN on a side stream beside the edge FFN (small per-GPU batches; see forward)
+        self._side = None
 
     def keras_named_parameters(self):
         """every parameter under the reference's Keras variable name: attention sub-layers
@@ -386,7 +388,25 @@ class EGTLayerStack(nn.Module):
         last = len(self.blocks) - 1
         for i, blk in enumerate(self.blocks):
             h, e = blk(h, e, mask, attn_mask)                  # layer/{i}/attention
-            if self.ffn_edge is not None and not (skip_last_edge_ffn and i == last):   # layer/{i}/ffn
+            edge_ffn = self.ffn_edge is not None and not (skip_last_edge_ffn and i == last)
+            if self.overlap_ffn and edge_ffn and h.is_cuda:
+                # the node and the edge FFN of a layer are independent (graph_xformer_model_base.py:309-324): the node FFN
+                # (a few hundred workgroups at most) runs on a side stream beside the edge FFN; autograd runs its backward on
+                # that stream too and orders the streams; inside a hipGraph capture this is a fork / join of the graph
+                cur = torch.cuda.current_stream()
+                if self._side is None:
+                    self._side = torch.cuda.Stream()
+                side = self._side
+                side.wait_stream(cur)
+                h.record_stream(side)
+                with torch.cuda.stream(side):
+                    h2 = self.ffn_node[i](h)
+                e = self.ffn_edge[i](e)                         # layer/{i}/ffn
+                cur.wait_stream(side)
+                h2.record_stream(cur)
+                h = h2
+                continue
+            if edge_ffn:                                        # layer/{i}/ffn
                 e = self.ffn_edge[i](e)
             h = self.ffn_node[i](h)
         return h, e

@@ -115,3 +115,30 @@ def test_seed_device_flag_needs_pointer(gpu, egt_lib):
     d = L.BlockDesc(B=1, N=16, H=8, d=8, De=64, dtype=L.EGT_F32, flags=L.BF_TRAINING | L.BF_SEED_DEVICE, clip_lo=0, clip_hi=0,
                     random_mask_prob=0.1, ln_eps=1e-3, reserved=0, seed=0, seed_device=None)
     assert egt_lib.egt_block_supported(C.byref(d)) == 0
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_overlapped_node_ffn_is_bit_identical(graph, gpu, egt_lib):
+    """EGTLayerStack.overlap_ffn: the node FFN on a side stream beside the edge FFN — same kernels, same results, eager
+    and as a fork / join inside a captured hipGraph."""
+    from egt_amd import EGTLayerStack, DeviceSeeds, GraphedStep
+    B, N, De, Ly = 4, 40, 8, 3
+
+    def make():
+        torch.manual_seed(5)
+        return EGTLayerStack(model_height=Ly, model_width=64, edge_width=De, num_heads=8, random_mask_prob=0.25, seed=3,
+                             fused=True).to(gpu).train()
+    ref, st = make(), make()
+    st.overlap_ffn = True
+    h, e, mask, dh, de = _inputs(gpu, B, N, De)
+    want = [_snapshot(ref, h, e, _run(ref, h, e, mask, dh, de)) for _ in range(4)]
+    if not graph:
+        for k in range(4):
+            _same(_snapshot(st, h, e, _run(st, h, e, mask, dh, de)), want[k], f"overlap, eager call {k + 1}")
+        return
+    seeds = DeviceSeeds.attach(st, gpu)
+    g = GraphedStep(lambda: _run(st, h, e, mask, dh, de), seeds, warmup=2)
+    for k in (2, 3):
+        o = g.replay()
+        torch.cuda.synchronize()
+        _same(_snapshot(st, h, e, o), want[k], f"overlap, replay = call {k + 1}")
