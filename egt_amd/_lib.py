@@ -105,6 +105,7 @@ _PROTOS = {
     "egt_attn_mfma_bwd": (C.c_int, [C.POINTER(AttnDesc)] + [_VP] * 15),
     "egt_mask_sample": (C.c_int, [C.c_int, C.c_uint64, C.c_float, C.c_int32, C.c_int32,
                                   C.c_int32, _VP, _VP]),
+    "egt_seed_advance": (C.c_int, [_VP, C.c_int32, C.c_uint64, _VP]),
     "egt_edge_proj_fwd": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 10),
     "egt_edge_proj_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(EdgeDesc)]),
     "egt_edge_proj_bwd": (C.c_int, [C.POINTER(EdgeDesc)] + [_VP] * 17),

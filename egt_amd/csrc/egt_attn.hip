@@ -492,3 +492,17 @@ extern "C" int egt_mask_sample(int which, uint64_t seed, float prob, int32_t B, 
   EGT_HIP_LAUNCH_CHECK("egt_mask_sample");
   return EGT_OK;
 }
+
+__global__ void k_seed_advance(uint64_t* words, int count, uint64_t inc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) words[i] += inc;
+}
+
+extern "C" int egt_seed_advance(uint64_t* words, int32_t count, uint64_t increment, void* stream) {
+  if (!words) EGT_FAIL(EGT_E_NULL, "words is NULL");
+  if (count < 1) EGT_FAIL(EGT_E_SHAPE, "count must be >= 1");
+  EGT_LAUNCH("k_seed_advance", k_seed_advance, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+             words, (int)count, increment);
+  EGT_HIP_LAUNCH_CHECK("egt_seed_advance");
+  return EGT_OK;
+}

@@ -51,7 +51,11 @@ class DeviceSeeds:
         return self.words.data_ptr() + 8 * i
 
     def advance(self):
-        self.words.add_(self._inc)     # int64 wrap-around == arithmetic mod 2^64
+        if self.words.is_cuda:         # the library's own one-launch advance (what a C host captures in front of the forward)
+            from . import _lib as L
+            L.check(L.load().egt_seed_advance(L.ptr(self.words), len(self.modules), _STEP, L.current_stream()))
+        else:
+            self.words.add_(self._inc)     # int64 wrap-around == arithmetic mod 2^64
         self.steps += 1                # (host-side bookkeeping only; replays advance the device words, not this)
 
     def values(self):

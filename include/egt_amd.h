@@ -136,6 +136,11 @@ int egt_attn_mfma_bwd(const egt_attn_desc* desc, const void* qkv, const void* E,
 int egt_mask_sample(int which, uint64_t seed, float prob, int32_t B, int32_t N,
                     int32_t H, uint8_t* out, void* stream);
 
+/* EGT_BF_SEED_DEVICE companion (see egt_block_desc): words[i] += increment (mod 2^64) for i < count, as ONE launch
+ * on `stream` — capturable, so a hipGraph that contains it in front of the forward draws a fresh random mask on
+ * every replay.  The torch host advances its words by 0xD1B54A32D192ED03 per call (EGT.next_seed's step). */
+int egt_seed_advance(uint64_t* words, int32_t count, uint64_t increment, void* stream);
+
 /* ---- edge-channel projections around the inner op ----------------------------
  * rows = B*N*N edge rows of width De; H must be 8. */
 #define EGT_EP_LAYERNORM 0x1u /* norm_edge before the projections (residual /
