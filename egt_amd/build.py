@@ -94,5 +94,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_c_host(force: bool = False) -> str:
+    """tests/c/graph_replay.cpp -> egt_amd/lib/graph_replay: a C++ host of the C-ABI without torch / Python (stack forward +
+    backward captured into a hipGraph; run by tests/test_capi_graph_gpu.py on the GPU box)."""
+    lib = build()
+    src = os.path.join(REPO, "tests", "c", "graph_replay.cpp")
+    exe = os.path.join(LIBDIR, "graph_replay")
+    newest = max(os.path.getmtime(x) for x in (src, lib, os.path.join(REPO, "include", "egt_amd.h")))
+    if not force and os.path.exists(exe) and os.path.getmtime(exe) >= newest:
+        return exe
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O2", "-std=c++17", src, "-o", exe, "-I", os.path.join(REPO, "include"),
+           "-L", LIBDIR, "-legt_amd", "-Wl,-rpath,$ORIGIN", "-Wno-unused-result"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout.decode(errors="replace"))
+        raise RuntimeError("hipcc failed on tests/c/graph_replay.cpp")
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
