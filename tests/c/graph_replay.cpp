@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "egt_amd.h"
@@ -30,7 +31,9 @@ static float* dev_random(size_t n, float scale, float offset) {
 }
 
 int main(int argc, char** argv) {
-  const int B = 4, N = argc > 1 ? atoi(argv[1]) : 48, H = 8, d = 8, De = argc > 2 ? atoi(argv[2]) : 64, Ly = 3, Dh = H * d;
+  // usage: graph_replay [N [De [B [Ly [timed_replays]]]]]   (timed_replays > 0: also time that many replays with hipEvents)
+  const int N = argc > 1 ? atoi(argv[1]) : 48, H = 8, d = 8, De = argc > 2 ? atoi(argv[2]) : 64, B = argc > 3 ? atoi(argv[3]) : 4,
+            Ly = argc > 4 ? atoi(argv[4]) : 3, timed = argc > 5 ? atoi(argv[5]) : 0, Dh = H * d;
   const uint64_t S0 = 0x0123456789ABCDEFull, STEP = 0xD1B54A32D192ED03ull;
   const int steps = 3;
   if (egt_abi_version() != EGT_ABI_VERSION) { printf("ABI mismatch\n"); return 1; }
@@ -128,6 +131,18 @@ int main(int argc, char** argv) {
   uint64_t w = 0;
   HIP_OK(hipMemcpy(&w, words, 8, hipMemcpyDeviceToHost));
   if (w != S0 + (uint64_t)steps * STEP) { printf("seed word %llx\n", (unsigned long long)w); return 1; }
+  if (timed > 0) {   // library-only throughput of the step: no Python, no torch, one hipGraphLaunch per step
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    for (int k = 0; k < 5; ++k) HIP_OK(hipGraphLaunch(exec, st));
+    HIP_OK(hipEventRecord(e0, st));
+    for (int k = 0; k < timed; ++k) HIP_OK(hipGraphLaunch(exec, st));
+    HIP_OK(hipEventRecord(e1, st));
+    HIP_OK(hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    printf("TIMED %d replays: %.4f ms per step, %.1f graphs/s (C host, hipEvents around the replays)\n", timed, ms / timed, B * 1000.0 * timed / ms);
+  }
   printf("OK B=%d N=%d De=%d Ly=%d: %d hipGraph replays (%zu graph nodes) bit-identical to the eager host-seed calls\n", B, N, De, Ly, steps, nodes);
   return 0;
 }
