@@ -425,7 +425,7 @@ def main():
         if state["flat_ok"] is None:
             state["flat_ok"] = flat_grad_view(params, model.grad_holder.flat)
             if not state["flat_ok"]:
-                state["fa"] = FlatGradAllReduce(params)   # takes effect from the next step
+                state["fa"] = FlatGradAllReduce(params, direct=True)   # takes effect from the next step; fused backwards write their gradients straight into it
                 return
         fa = state["fa"]
         evs = state["ar_events"]

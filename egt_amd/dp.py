@@ -33,7 +33,11 @@ def shard_batch(n_graphs: int, world_size: int, rank: int):
 class FlatGradAllReduce:
     """Owns one flat gradient buffer aliasing every parameter's .grad."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, comm: "CapiComm" = None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, comm: "CapiComm" = None, direct: bool = False):
+        """direct: the fused block / FFN backward writes a parameter's gradient straight into its view of the flat buffer and
+        hands autograd nothing to accumulate (egt_amd.fused.grad_sinks) — otherwise every parameter costs one elementwise
+        `grad += g` launch per step (hundreds of 4-5 us kernels for a 16-layer model).  Valid when every parameter takes part
+        in ONE fused call per step (true for the reference's models) and zero() + rebind() run before each backward."""
         self.comm = comm
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
@@ -45,6 +49,7 @@ class FlatGradAllReduce:
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
+            p._egt_direct_grad = bool(direct)
             off += p.numel()
 
     @property

@@ -43,6 +43,7 @@ class _FusedFFN(torch.autograd.Function):
         _need_gpu(x)
         lib = L.load()
         x = _f32c(x)
+        ctx.param_objs = params
         params = tuple(_f32c(p) for p in params)
         y = torch.empty_like(x)
         ws = torch.empty(lib.egt_ffn_workspace_bytes(C.byref(desc)), dtype=torch.uint8, device=x.device)
@@ -60,13 +61,14 @@ class _FusedFFN(torch.autograd.Function):
         desc = ctx.desc
         dy = _f32c(dy)
         dx = torch.empty_like(x)
-        grads = [torch.empty_like(p) for p in params]
+        from .fused import grad_sinks
+        grads, rets = grad_sinks(ctx.param_objs)
         bdesc = L.FfnDesc.from_buffer_copy(desc)
         bdesc.flags = L.FFN_WS_PREPARED
         pst, gst = _pstruct(params), _pstruct(grads)
         L.check(lib.egt_ffn_bwd(C.byref(bdesc), C.byref(pst), L.ptr(x), L.ptr(dy), L.ptr(dx), C.byref(gst),
                                 L.ptr(ctx.ws), L.current_stream()))
-        return (dx, None, *grads)
+        return (dx, None, *rets)
 
 
 def ffn(x, norm_gamma, norm_beta, lr1_kernel, lr1_bias, lr2_kernel, lr2_bias, activation="elu", eps=1e-3, matmul="f32"):

@@ -86,6 +86,24 @@ def _params_struct(tensors) -> L.BlockParams:
     return st
 
 
+def grad_sinks(params):
+    """Where a fused backward writes each parameter gradient, and what it returns to autograd.  A parameter whose .grad is a
+    pre-bound view of a flat gradient buffer opened for direct writes (FlatGradAllReduce(direct=True)) receives its gradient
+    IN that view and autograd gets None (no `grad += g` launch); everything else gets a fresh tensor as before."""
+    bufs, rets = [], []
+    for p in params:
+        if p is None:
+            bufs.append(None); rets.append(None)
+            continue
+        g = p.grad if getattr(p, "_egt_direct_grad", False) else None
+        if g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape and g.device == p.device:
+            bufs.append(g); rets.append(None)
+        else:
+            t = torch.empty_like(p, dtype=torch.float32)
+            bufs.append(t); rets.append(t)
+    return bufs, rets
+
+
 class _FusedBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, e, key_mask, attn_mask, rand_mask, desc, *params):
@@ -94,6 +112,7 @@ class _FusedBlock(torch.autograd.Function):
         h = _f32c(h); e = _edge_c(e)
         key_mask = _u8c(key_mask); rand_mask = _u8c(rand_mask)
         attn_mask = None if attn_mask is None else _f32c(attn_mask.to(torch.float32))
+        ctx.param_objs = params          # the Parameter objects themselves (grad_sinks looks at their .grad in the backward)
         params = tuple(None if p is None else _f32c(p) for p in params)
         dev = h.device
         h_out = torch.empty_like(h)
@@ -123,14 +142,14 @@ class _FusedBlock(torch.autograd.Function):
         dh_out = _f32c(dh_out); de_out = _edge_c(de_out, e.dtype)
         dh = torch.empty_like(h)
         de = torch.empty_like(e)
-        grads = [None if p is None else torch.empty_like(p) for p in params]
+        grads, rets = grad_sinks(ctx.param_objs)
         ws = torch.empty(lib.egt_block_workspace_bytes(C.byref(desc)), dtype=torch.uint8, device=dev)
         pst, gst = _params_struct(params), _params_struct(grads)
         L.check(lib.egt_block_bwd(C.byref(desc), C.byref(pst), L.ptr(h), L.ptr(e), L.ptr(key_mask),
                                   L.ptr(attn_mask), L.ptr(rand_mask), L.ptr(saved), L.ptr(dh_out),
                                   L.ptr(de_out), L.ptr(dh), L.ptr(de), C.byref(gst), L.ptr(ws),
                                   L.current_stream()))
-        return (dh, de, None, None, None, None, *grads)
+        return (dh, de, None, None, None, None, *rets)
 
 
 def _block_params(blk, e):

@@ -337,7 +337,7 @@ class ZincSVDScheme:
             raise ValueError("config.use_hipgraph needs the model on a GPU (device='cuda')")
         if self._use_graph or (self.config.distributed and torch.distributed.is_available() and torch.distributed.is_initialized()):
             from .dp import FlatGradAllReduce
-            self.flat = FlatGradAllReduce(params)     # one flat-buffer all-reduce per step (MirroredStrategy, :230-247)
+            self.flat = FlatGradAllReduce(params, direct=True)     # one flat-buffer all-reduce per step (MirroredStrategy, :230-247)
         if self._use_graph:                           # every captured geometry writes its gradients into this one flat buffer
             from .graph import DeviceSeeds
             from .layers import EGT

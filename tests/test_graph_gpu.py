@@ -142,3 +142,52 @@ def test_overlapped_node_ffn_is_bit_identical(graph, gpu, egt_lib):
         o = g.replay()
         torch.cuda.synchronize()
         _same(_snapshot(st, h, e, o), want[k], f"overlap, replay = call {k + 1}")
+
+
+def test_direct_gradient_sinks_match_autograd_accumulation(gpu, egt_lib):
+    """FlatGradAllReduce(direct=True): the fused block / FFN backward writes each parameter gradient straight into the
+    parameter's view of the flat buffer (no `grad += g` launch per parameter).  Same numbers as autograd's own accumulation
+    into the zeroed buffer and as plain .grad tensors."""
+    from egt_amd import EGTLayerStack
+    from egt_amd.dp import FlatGradAllReduce
+    from egt_amd import fused
+    B, N, De, Ly = 2, 24, 8, 2
+
+    def make():
+        torch.manual_seed(5)
+        return EGTLayerStack(model_height=Ly, model_width=64, edge_width=De, num_heads=8, random_mask_prob=0.25, seed=3,
+                             fused=True).to(gpu).train()
+    h, e, mask, dh, de = _inputs(gpu, B, N, De)
+    plain = make()
+    want = _snapshot(plain, h, e, _run(plain, h, e, mask, dh, de))
+    for direct in (False, True):
+        st = make()
+        fa = FlatGradAllReduce(list(st.parameters()), direct=direct)
+        bufs, rets = fused.grad_sinks(list(st.parameters())[:3])
+        assert all((r is None) == direct for r in rets)
+        for _ in range(2):                                  # the second step starts from a dirty buffer
+            fa.zero(); fa.rebind()
+            h.grad = None; e.grad = None
+            h2, e2 = st(h, e, mask)
+            torch.autograd.backward([h2, e2], [dh, de])
+            for m in st.modules():                          # (same call index as `plain` for the comparison below)
+                if hasattr(m, "_calls"):
+                    m._calls = 0
+        for m in st.modules():
+            if hasattr(m, "_calls"):
+                m._calls = 0
+        fa.zero(); fa.rebind()
+        got = _snapshot(st, h, e, _run_keep(st, h, e, mask, dh, de))
+        _same(got, want, f"direct={direct}")
+        off = 0
+        for p in st.parameters():                           # .grad still aliases the flat buffer
+            assert p.grad.data_ptr() == fa.flat[off:].data_ptr()
+            off += p.numel()
+
+
+def _run_keep(st, h, e, mask, dh, de):
+    """_run without dropping the pre-bound .grad views"""
+    h.grad = None; e.grad = None
+    h2, e2 = st(h, e, mask)
+    torch.autograd.backward([h2, e2], [dh, de])
+    return h2, e2
