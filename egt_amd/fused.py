@@ -202,6 +202,7 @@ class _FusedStack(torch.autograd.Function):
                                   L.ptr(attn_mask), L.ptr(h_out), L.ptr(e_out), L.ptr(saved), L.ptr(ws),
                                   L.current_stream()))
         ctx.desc, ctx.layers, ctx.holder = desc, layers, holder
+        ctx.parr = parr
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(h, e, key_mask, attn_mask, saved, *params)
         return h_out, e_out
@@ -220,19 +221,20 @@ class _FusedStack(torch.autograd.Function):
         dh, de = torch.empty_like(h), torch.empty_like(e)
         # every parameter gradient is a view of ONE flat buffer: the data-parallel all-reduce
         # (egt_amd.dp) runs on it directly, and autograd adopts the views without copies
-        total = sum(p.numel() for p in params if p is not None)
-        flat = torch.empty(total, dtype=torch.float32, device=dev)
-        grads, off = [], 0
+        sizes = [p.numel() for p in params if p is not None]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        pieces = iter(flat.split(sizes))          # one call for all views (the per-parameter slicing was ~0.4 ms of host time per step)
+        grads = []
         for p in params:
             if p is None:
                 grads.append(None)
             else:
-                grads.append(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
+                v = next(pieces)
+                grads.append(v if p.dim() == 1 else v.view(p.shape))
         if ctx.holder is not None:
             ctx.holder.flat = flat
         ws = torch.empty(lib.egt_stack_workspace_bytes(C.byref(desc), layers), dtype=torch.uint8, device=dev)
-        parr = (L.BlockParams * layers)(*[_params_struct(params[14 * i:14 * i + 14]) for i in range(layers)])
+        parr = ctx.parr                            # the forward's struct array: same parameter tensors (kept alive by saved_tensors)
         garr = (L.BlockParams * layers)(*[_params_struct(grads[14 * i:14 * i + 14]) for i in range(layers)])
         L.check(lib.egt_stack_bwd(C.byref(desc), layers, parr, L.ptr(h), L.ptr(e), L.ptr(key_mask),
                                   L.ptr(attn_mask), L.ptr(saved), L.ptr(dh_out), L.ptr(de_out), L.ptr(dh),
