@@ -299,6 +299,7 @@ class EGTStack(nn.Module):
         seed = block_kwargs.pop('seed', 0)
         self.stack_call = block_kwargs.pop('stack_call', True)
         self.grad_holder = SimpleNamespace(flat=None)   # flat gradient buffer of the last fused backward
+        self._stack_ok = {}
         self.blocks = nn.ModuleList(
             [EGTBlock(seed=seed * 1000 + i, **block_kwargs) for i in range(model_height)])
 
@@ -317,7 +318,13 @@ class EGTStack(nn.Module):
     def forward(self, h, e, mask=None, attn_mask=None):
         if self.stack_call and h.is_cuda:
             from . import fused as FZ
-            if FZ.stack_supported(self, h, e, attn_mask):
+            # the decision depends on construction-time attributes and on this key only: made once per geometry
+            key = (tuple(h.shape), tuple(e.shape), h.dtype, e.dtype, h.device, attn_mask is None,
+                   tuple(b.training for b in self.blocks))
+            ok = self._stack_ok.get(key)
+            if ok is None:
+                ok = self._stack_ok[key] = bool(FZ.stack_supported(self, h, e, attn_mask))
+            if ok:
                 self.last_path = "fused-stack"
                 return FZ.stack_fused(self, h, e, mask, attn_mask)   # one C-ABI call per direction
         self.last_path = "per-block"
