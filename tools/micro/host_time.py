@@ -23,6 +23,15 @@ for _ in range(200): step()
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 print(f"host time per step (B={B}: tiny kernels, the host is the bound): {(t1 - t0) / 200 * 1e3:.3f} ms")
+tf = tb = 0.0
+for _ in range(200):
+    for p in params: p.grad = None
+    h.grad = None; e.grad = None
+    a = time.perf_counter(); h2, e2 = st(h, e, mask); b = time.perf_counter()
+    torch.autograd.backward([h2, e2], [dh, de]); c = time.perf_counter()
+    tf += b - a; tb += c - b
+torch.cuda.synchronize()
+print(f"  of which forward call {tf / 200 * 1e3:.3f} ms, autograd.backward {tb / 200 * 1e3:.3f} ms")
 pr = cProfile.Profile(); pr.enable()
 for _ in range(100): step()
 pr.disable(); torch.cuda.synchronize()
