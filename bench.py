@@ -277,6 +277,9 @@ def main():
                          "random-mask seeds live in device memory, EGT_BF_SEED_DEVICE, and advance inside the graph, so every "
                          "replay draws a fresh sample); the gradient collective stays an eager call after the replay.  The "
                          "dominant kernel is then timed in the untimed eager pass (a replay has no per-launch host hooks)")
+    ap.add_argument("--bind-grads", default="on", choices=["on", "off"],
+                    help="stack scope: EGTStack.bind_flat_gradients() -- the stack backward writes every parameter gradient into one "
+                         "persistent flat buffer whose views ARE the parameters' .grad (no per-parameter autograd work on the host)")
     ap.add_argument("--no-graph-leg", action="store_true", help="skip the secondary hipGraph-replay figure (hipgraph_replay in the line)")
     ap.add_argument("--overlap-ffn", action="store_true",
                     help="layers / model scopes: the node FFN of a layer runs on a side stream beside the edge FFN (EGTLayerStack.overlap_ffn)")
@@ -402,7 +405,7 @@ def main():
         fa = state["fa"]
         if fa is not None:
             fa.zero(); fa.rebind()
-        else:
+        elif not state.get("bound"):
             for p in params:
                 p.grad = None
         if zinc is not None:             # whole model: prediction -> MAE -> backward
@@ -465,6 +468,13 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if args.bind_grads == "on" and zinc is None and not args.with_ffn and state["flat_ok"] and getattr(model, "last_path", "") == "fused-stack":
+        model.bind_flat_gradients()      # from here on .grad is never reset: the backward overwrites the bound buffer
+        state["bound"] = True
+        for _ in range(2):
+            step()
+        fence()
+        assert flat_grad_view(params, model.grad_holder.flat)
     graphed = None
     if args.graph == "on":
         from egt_amd import GraphedStep
@@ -625,7 +635,7 @@ def main():
                        "random_mask_prob": w["rand_p"], "nodes": list(w["nodes"]), "path": path,
                        "parallelism": f"dp{world}", "grad_allreduce_bytes": nbytes,
                        "grad_allreduce_us": ar_us, "backend": ("rccl (egt_dp_* C-ABI)" if comm is not None else "rccl") if use_dist else "none (single process)",
-                       "flat_grad_adopted": bool(state["flat_ok"]),
+                       "flat_grad_adopted": bool(state["flat_ok"]), "flat_grad_bound": bool(state.get("bound")),
                        "hipgraph": (f"forward + backward replayed from one captured hipGraph ({graphed.replays} replays), device-resident "
                                     "mask seeds; dominant kernel timed in the untimed eager pass") if graphed is not None else None},
             "roofline": roof, "cpu_baseline": cpu, "hipgraph_replay": graph_leg,

@@ -220,6 +220,28 @@ class _FusedStack(torch.autograd.Function):
             dh_out = torch.zeros_like(h)
         dh_out = _f32c(dh_out); de_out = _edge_c(de_out, e.dtype)
         dh, de = torch.empty_like(h), torch.empty_like(e)
+        sink = getattr(ctx.holder, "sink", None) if ctx.holder is not None else None
+        if sink is not None:
+            # EGTStack.bind_flat_gradients(): every parameter's .grad already IS its view of the holder's persistent flat
+            # buffer.  The C backward writes there (addresses by arithmetic: no per-parameter view, data_ptr() or
+            # AccumulateGrad node — two thirds of the eager step's host time) and autograd gets nothing to accumulate.
+            sizes = [p.numel() for p in params if p is not None]
+            if sink.numel() != sum(sizes) or sink.device != dev:
+                raise RuntimeError("bound flat gradient buffer does not match the stack's parameters; call bind_flat_gradients() again")
+            base, off, ptrs = sink.data_ptr(), 0, []
+            for p in params:
+                if p is None:
+                    ptrs.append(None)
+                else:
+                    ptrs.append(base + 4 * off)
+                    off += p.numel()
+            garr = C.cast((C.c_void_p * len(ptrs))(*ptrs), C.POINTER(L.BlockParams))
+            ws = torch.empty(lib.egt_stack_workspace_bytes(C.byref(desc), layers), dtype=torch.uint8, device=dev)
+            L.check(lib.egt_stack_bwd(C.byref(desc), layers, ctx.parr, L.ptr(h), L.ptr(e), L.ptr(key_mask),
+                                      L.ptr(attn_mask), L.ptr(saved), L.ptr(dh_out), L.ptr(de_out), L.ptr(dh),
+                                      L.ptr(de), garr, L.ptr(ws), L.current_stream()))
+            ctx.holder.flat = sink
+            return (dh, de, None, None, None, None, None, *([None] * len(params)))
         # every parameter gradient is a view of ONE flat buffer: the data-parallel all-reduce
         # (egt_amd.dp) runs on it directly, and autograd adopts the views without copies
         sizes = [p.numel() for p in params if p is not None]

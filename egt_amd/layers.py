@@ -298,7 +298,7 @@ class EGTStack(nn.Module):
         super().__init__()
         seed = block_kwargs.pop('seed', 0)
         self.stack_call = block_kwargs.pop('stack_call', True)
-        self.grad_holder = SimpleNamespace(flat=None)   # flat gradient buffer of the last fused backward
+        self.grad_holder = SimpleNamespace(flat=None, sink=None)   # flat gradient buffer of the last fused backward; sink: bound buffer
         self._stack_ok = {}
         self.blocks = nn.ModuleList(
             [EGTBlock(seed=seed * 1000 + i, **block_kwargs) for i in range(model_height)])
@@ -315,6 +315,25 @@ class EGTStack(nn.Module):
                     out.append(getattr(m, attr))
         return out
 
+    def bind_flat_gradients(self):
+        """One persistent flat gradient buffer for the whole stack: every parameter's .grad becomes (and stays) its view of
+        it, the fused stack backward writes into it directly, and the data-parallel collective runs on it
+        (grad_holder.flat).  For training loops that never reset .grad to None (the backward OVERWRITES: each parameter takes
+        part in one stack call per step); undo with unbind_flat_gradients()."""
+        ps = self.fused_parameters()
+        flat = torch.zeros(sum(p.numel() for p in ps), dtype=torch.float32, device=ps[0].device)
+        off = 0
+        for p in ps:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.grad_holder.sink = self.grad_holder.flat = flat
+        return flat
+
+    def unbind_flat_gradients(self):
+        self.grad_holder.sink = None
+        for p in self.fused_parameters():
+            p.grad = None
+
     def forward(self, h, e, mask=None, attn_mask=None):
         if self.stack_call and h.is_cuda:
             from . import fused as FZ
@@ -327,6 +346,9 @@ class EGTStack(nn.Module):
             if ok:
                 self.last_path = "fused-stack"
                 return FZ.stack_fused(self, h, e, mask, attn_mask)   # one C-ABI call per direction
+        if self.grad_holder.sink is not None:
+            raise RuntimeError("bind_flat_gradients() needs the fused stack path (the per-block path accumulates through autograd); "
+                               "call unbind_flat_gradients() for this geometry")
         self.last_path = "per-block"
         for blk in self.blocks:
             h, e = blk(h, e, mask, attn_mask)

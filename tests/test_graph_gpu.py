@@ -191,3 +191,30 @@ def _run_keep(st, h, e, mask, dh, de):
     h2, e2 = st(h, e, mask)
     torch.autograd.backward([h2, e2], [dh, de])
     return h2, e2
+
+
+@pytest.mark.parametrize("N,De", [(32, 64), (40, 8)])
+def test_bound_flat_gradients_match_the_adopted_views(N, De, gpu, egt_lib):
+    """EGTStack.bind_flat_gradients(): the stack backward writes into one persistent flat buffer whose views are the
+    parameters' .grad (no per-parameter autograd work); same numbers as the default path, step after step, eager and replayed."""
+    from egt_amd import DeviceSeeds, GraphedStep
+    ref, st = _stack(gpu, N, De, 3, seed=7), _stack(gpu, N, De, 3, seed=7)
+    h, e, mask, dh, de = _inputs(gpu, 2, N, De)
+    want = [_snapshot(ref, h, e, _run(ref, h, e, mask, dh, de)) for _ in range(5)]
+    flat = st.bind_flat_gradients()
+    for k in range(2):
+        flat.fill_(float("nan"))                            # the backward must overwrite every element
+        got = _snapshot(st, h, e, _run_keep(st, h, e, mask, dh, de))
+        _same(got, want[k], f"bound, eager call {k + 1}")
+        assert st.grad_holder.flat is flat and all(p.grad.data_ptr() >= flat.data_ptr() for p in st.parameters())
+    seeds = DeviceSeeds.attach(st, gpu)
+    g = GraphedStep(lambda: _run_keep(st, h, e, mask, dh, de), seeds, warmup=1)     # warm-up = call 3
+    for k in (3, 4):
+        flat.fill_(float("nan"))
+        o = g.replay()
+        torch.cuda.synchronize()
+        _same(_snapshot(st, h, e, o), want[k], f"bound, replay = call {k + 1}")
+    del o, g
+    seeds.detach()
+    st.unbind_flat_gradients()
+    assert all(p.grad is None for p in st.parameters())
