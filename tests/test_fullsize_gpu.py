@@ -157,3 +157,64 @@ def test_synthetic_n512_d64_inner_op_vs_oracle(gpu, egt_lib):
     assert_close(q.grad, ref["dQKV"], name="dQKV", **BWD)
     assert_close(e_.grad, ref["dE"], name="dE", **BWD)
     assert_close(g_.grad, ref["dG"], name="dG", **BWD)
+
+
+def test_synthetic_n512_d64_mfma_forward_and_backward_vs_oracle(gpu, egt_lib):
+    """BASELINE config 5 geometry (N=512, H=8, d=64) on the MFMA-tiled inner op: with need_a_tild=False the FORWARD
+    runs k_attn_mfma_fwd / fwd2 (with need_a_tild=True it falls back to the general kernel, the test above), the
+    backward k_attn_mfma_bwd_*; both against the fp64 oracle (egt_layers.py:57-143).  Ragged key padding and a
+    fully padded tail tile."""
+    from egt_amd import egt_attention, AttnConfig
+    from egt_amd import _lib as L
+    import ctypes as C
+    g = torch.Generator().manual_seed(55)
+    B, N, H, d = 1, 512, 8, 64
+    QKV = torch.randn(B, N, 3 * d * H, generator=g) * 0.5
+    E = torch.randn(B, N, N, H, generator=g); G = torch.randn(B, N, N, H, generator=g)
+    mask = torch.ones(B, N, dtype=torch.bool); mask[0, 489:] = False
+    dV = torch.randn(B, N, d * H, generator=g); dH = torch.randn(B, N, N, H, generator=g)
+    inp = dict(QKV=QKV, E=E, G=G, M=None, mask=mask, rand_mask=None, drop_keep=None, dV=dV, dH=dH)
+    attrs = dict(num_heads=H, clip_logits_value=(-5.0, 5.0), scale_degree=False, scaler_type="log",
+                 num_virtual_nodes=0, attn_dropout=0.0)
+    ref = CS.attn_oracle(inp, attrs)
+    cfg = AttnConfig(need_a_tild=False, use_mfma=True)
+    from egt_amd.functional import _attn_desc
+    desc = _attn_desc(cfg, B, N, d, True, True, False)
+    assert L.load().egt_attn_mfma_supported(C.byref(desc), 0) == 1      # the MFMA kernels DO take this geometry
+    q = QKV.to(gpu).requires_grad_(); e_ = E.to(gpu).requires_grad_(); g_ = G.to(gpu).requires_grad_()
+    V, Hh, At = egt_attention(q, e_, g_, None, mask.to(gpu), cfg=cfg)
+    assert At.numel() == 0
+    torch.autograd.backward([V, Hh], [dV.to(gpu), dH.to(gpu)])
+    assert_close(V, ref["V_att"], name="V_att", **FWD)
+    assert_close(Hh, ref["H_hat"], name="H_hat", **FWD)
+    assert_close(q.grad, ref["dQKV"], name="dQKV", **BWD)
+    assert_close(e_.grad, ref["dE"], name="dE", **BWD)
+    assert_close(g_.grad, ref["dG"], name="dG", **BWD)
+
+
+def test_synthetic_n512_block_scope_vs_oracle(gpu, egt_lib):
+    """BASELINE config 5 at block scope: (h, e, mask) -> (h', e') of ONE block at B=1, N=512, Dh=512 (d=64), De=32
+    (tools/bench_block_cfg5.py's composition: HIP edge projections + MFMA inner op + node-side Dense) forward and
+    backward against block_oracle (graph_xformer_model_base.py:106-145,192-223)."""
+    from oracle import egt_oracle as O
+    from test_block_gpu import build_block
+    g = torch.Generator().manual_seed(56)
+    B, N, Dh, De = 1, 512, 512, 32
+    h = torch.randn(B, N, Dh, generator=g); e = torch.randn(B, N, N, De, generator=g) * 1.2 + 0.2
+    dh = torch.randn(B, N, Dh, generator=g); de = torch.randn(B, N, N, De, generator=g)
+    mask = torch.ones(B, N, dtype=torch.bool); mask[0, 497:] = False
+    params = O.init_block_params(Dh, De, 8, generator=g, randomize_norm=True)
+    attrs = dict(gate_attention=True, edge_activation=None, edge_channel_type="residual")
+    blk = build_block(dict(Dh=Dh, De=De), attrs, params, gpu, "auto").eval()
+    hg = h.to(gpu).requires_grad_(); eg = e.to(gpu).requires_grad_()
+    h2, e2 = blk(hg, eg, mask.to(gpu))
+    torch.autograd.backward([h2, e2], [dh.to(gpu), de.to(gpu)])
+    inp = dict(h=h, e=e, mask=mask, attn_mask=None, rand_mask=None, dh=dh, de=de)
+    ref = CS.block_oracle(inp, params, dict(num_heads=8, **attrs))
+    assert_close(h2, ref["h_out"], name="h_out", **FWD)
+    assert_close(e2, ref["e_out"], name="e_out", **FWD)
+    assert_close(hg.grad, ref["dh"], name="dh", **BWD)
+    assert_close(eg.grad, ref["de"], name="de", **BWD)
+    from test_block_gpu import PMAP
+    for k, (m, a) in PMAP.items():
+        assert_close(getattr(getattr(blk, m), a).grad, ref["dparams"][k], name=k, **BWD)
