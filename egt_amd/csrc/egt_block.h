@@ -78,6 +78,9 @@ __host__ __device__ inline int col_head(int i) { return 2 * (i >> 2) + ((i >> 1)
 void egt_narrow_launch_fwd(BlockArgs& a, hipStream_t st);
 void egt_narrow_launch_bwd(BlockArgs& a, int nwg, hipStream_t st);   // same a.pro / partial-buffer contract as k_block_bwd_v4r
 
+// tile-pair backward (egt_block_bwd6.hip): De in {32, 48, 64}, fp32 edge tensors, no mask tensors, N % 16 == 0
+void egt_bwd6_launch(BlockArgs& a, int nwg, hipStream_t st);
+
 // launchers implemented in egt_node.hip
 void egt_node_launch_pre(BlockArgs& a, hipStream_t st);
 void egt_node_launch_post(BlockArgs& a, hipStream_t st);

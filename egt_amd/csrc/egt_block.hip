@@ -37,6 +37,7 @@
 #include "egt_tile.h"
 
 #include "egt_block_dev.h"
+#include "egt_dma.h"
 
 // ================================================================= forward =====
 // Workgroup = (graph b, 16 query rows); wave w owns rows l = 16*lg + w + 4*i.
@@ -1167,54 +1168,6 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
 //    whole lines) instead of making an LDS round trip through a second de' buffer.
 // Same LDS footprint as v4 (two e buffers + one de' buffer instead of one + two): two workgroups per CU.
 // fp32 edge tensors, no mask tensors, N a multiple of 16, De a multiple of 16.
-template <int DE>
-__device__ __forceinline__ unsigned dma_lane_offset(int lane) {
-  // byte offset (inside the tile) of the 16-byte piece lane `lane` fetches for chunk 0
-  if (DE == 64) return (unsigned)((lane >> 4) * 256 + (((lane & 15) ^ (lane >> 4)) << 4));
-  return (unsigned)(lane * 16);
-}
-// one 16-pair tile HBM -> LDS; `lds` = byte address of the tile in LDS (wave-uniform), `src` = the
-// tile's first byte in HBM (wave-uniform), off0 = dma_lane_offset.  Chunk i (rows 4i .. 4i+3 at
-// De = 64) differs from chunk 0 by +1024 i bytes and, for the swizzle, by flipping slot bits 2..3
-// with i: one XOR with 1088 i (the offsets of chunk 0 are < 1024, so the add is an OR is an XOR).
-template <int DE>
-__device__ __forceinline__ void tile_dma(unsigned lds, const float* src, unsigned off0) {
-  constexpr int NI = Geo<DE>::NF4 / 64;
-  static_assert(Geo<DE>::NF4 % 64 == 0 && NI >= 1 && NI <= 4, "whole 1 KiB chunks");
-  unsigned keep, t;
-  constexpr unsigned X = DE == 64 ? 1088u : 1024u;
-  if (NI == 4)
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
-        "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-        "v_xor_b32 %1, %6, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-        "v_xor_b32 %1, %7, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X), "i"(2 * X), "i"(3 * X) : "memory", "scc");
-  else if (NI == 3)
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
-        "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-        "v_xor_b32 %1, %6, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X), "i"(2 * X) : "memory", "scc");
-  else if (NI == 2)
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
-        "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X) : "memory", "scc");
-  else
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep) : "s"(src), "v"(off0), "s"(lds) : "memory");
-  (void)t;
-}
-// wait until at most N of the wave's vector-memory operations are outstanding (they retire in order)
-template <int N_>
-__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N_) : "memory"); }
-
 // Phase timing of k_block_bwd_v5 (EGT_BLOCK_FLAGS=-DEGT_BWD_TIMING, measurement builds only): the wave
 // stamps s_memtime at the phase boundaries and sums the deltas in SGPRs; every wave of the grid writes its
 // sums to a.dbg [wg][4 waves][16] at the end, the host averages and prints them at exit.
@@ -1223,14 +1176,6 @@ __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :
 #else
 #define TSTAMP(i) do {} while (0)
 #endif
-// transposed element (row q + 4s, channel 16t + p) of a swizzled De = 64 tile: the XOR swizzle splits into a
-// per-lane part and a part that depends only on (s, t), so ONE address register + compile-time offsets
-// replace 32 per-(s,t) address registers:  floats = [64 q + 4 ((p >> 2) ^ q) + (p & 3)] + 256 s + 16 (t ^ s)
-template <int DE>
-__device__ __forceinline__ float elem_read_st(const float* lane_base, const float* tl, int p, int q, int s, int t) {
-  if (DE == 64) return lane_base[256 * s + 16 * (t ^ s)];
-  return elem_read<DE>(tl, q + 4 * s, 16 * t + p);
-}
 // MM = EGT_MM_BF16X3 (opt-in: EGT_BWD_MATMUL=bf16x3): the three channel contractions of a tile (P1 projections,
 // P2 dH_ext, P5 d ehat: 48 of the 80 fp32 MFMAs) run as 3-term bfloat16 split products on the bf16 matrix pipe
 // (20 MFMAs of 16 cycles; per-product error 2^-16, fp32 accumulate); the weight-gradient contractions over the
@@ -2008,6 +1953,7 @@ struct EgtBlockEnv {
   bool narrow_bwd_all;                 // EGT_NARROW_BWD=1: k_narrow_bwd for fp32 edge tensors too (default: bf16 only, where it is faster)
   int fwd_ablate, bwd_ablate, bwd_pf;
   int bwd_v5;   // LDS-DMA staged backward (default on; EGT_BWD_V5=0 selects k_block_bwd_v4)
+  int bwd_v6;   // tile-pair backward k_block_bwd_v6 (EGT_BWD_V6=0 falls back to v5)
   int bwd_mm;   // EGT_BWD_MATMUL=bf16x3: the backward's channel contractions as 3-term bf16 split products (opt-in; default exact fp32)
 };
 static bool env_flag_raw(const char* name) {
@@ -2047,6 +1993,8 @@ static const EgtBlockEnv& block_env() {
     v.bwd_pf = pf ? atoi(pf) : 0;
     const char* v5 = getenv("EGT_BWD_V5");
     v.bwd_v5 = v5 ? atoi(v5) : 1;
+    const char* v6 = getenv("EGT_BWD_V6");
+    v.bwd_v6 = v6 ? atoi(v6) : 0;
     const char* mm = getenv("EGT_BWD_MATMUL");
     v.bwd_mm = (mm && !strcmp(mm, "bf16x3")) ? EGT_MM_BF16X3 : EGT_MM_F32;
     return v;
@@ -2399,6 +2347,10 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
         }
       }
       if constexpr (DE >= 32) {
+        if (full && !ml && !a.bf16 && block_env().bwd_v6 && block_env().bwd_mm == EGT_MM_F32) {   // tile-pair waves (egt_block_bwd6.hip)
+          egt_bwd6_launch(a, L.nwg_bwd, st);
+          goto pair_done;
+        }
         if (full && !ml && !a.bf16 && block_env().bwd_v5) {   // LDS-DMA staged e tiles (k_block_bwd_v5)
           const bool x3 = block_env().bwd_mm == EGT_MM_BF16X3;
           EGT_MAX_LDS_ONCE(k_block_bwd_v5<DE, 0>);

@@ -1,0 +1,61 @@
+// LDS-DMA staging of 16-pair tiles (HBM -> LDS without a VGPR destination) and the transposed-element read of a swizzled
+// tile; shared by k_block_bwd_v5 (egt_block.hip) and k_block_bwd_v6 (egt_block_bwd6.hip).
+#pragma once
+#include "egt_tile.h"
+
+template <int DE>
+__device__ __forceinline__ unsigned dma_lane_offset(int lane) {
+  // byte offset (inside the tile) of the 16-byte piece lane `lane` fetches for chunk 0
+  if (DE == 64) return (unsigned)((lane >> 4) * 256 + (((lane & 15) ^ (lane >> 4)) << 4));
+  return (unsigned)(lane * 16);
+}
+// one 16-pair tile HBM -> LDS; `lds` = byte address of the tile in LDS (wave-uniform), `src` = the
+// tile's first byte in HBM (wave-uniform), off0 = dma_lane_offset.  Chunk i (rows 4i .. 4i+3 at
+// De = 64) differs from chunk 0 by +1024 i bytes and, for the swizzle, by flipping slot bits 2..3
+// with i: one XOR with 1088 i (the offsets of chunk 0 are < 1024, so the add is an OR is an XOR).
+template <int DE>
+__device__ __forceinline__ void tile_dma(unsigned lds, const float* src, unsigned off0) {
+  constexpr int NI = Geo<DE>::NF4 / 64;
+  static_assert(Geo<DE>::NF4 % 64 == 0 && NI >= 1 && NI <= 4, "whole 1 KiB chunks");
+  unsigned keep, t;
+  constexpr unsigned X = DE == 64 ? 1088u : 1024u;
+  if (NI == 4)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
+        "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+        "v_xor_b32 %1, %6, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+        "v_xor_b32 %1, %7, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X), "i"(2 * X), "i"(3 * X) : "memory", "scc");
+  else if (NI == 3)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
+        "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+        "v_xor_b32 %1, %6, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X), "i"(2 * X) : "memory", "scc");
+  else if (NI == 2)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
+        "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X) : "memory", "scc");
+  else
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep) : "s"(src), "v"(off0), "s"(lds) : "memory");
+  (void)t;
+}
+// wait until at most N of the wave's vector-memory operations are outstanding (they retire in order)
+template <int N_>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N_) : "memory"); }
+
+// transposed element (row q + 4s, channel 16t + p) of a swizzled De = 64 tile: the XOR swizzle splits into a
+// per-lane part and a part that depends only on (s, t), so ONE address register + compile-time offsets
+// replace 32 per-(s,t) address registers:  floats = [64 q + 4 ((p >> 2) ^ q) + (p & 3)] + 256 s + 16 (t ^ s)
+template <int DE>
+__device__ __forceinline__ float elem_read_st(const float* lane_base, const float* tl, int p, int q, int s, int t) {
+  if (DE == 64) return lane_base[256 * s + 16 * (t ^ s)];
+  return elem_read<DE>(tl, q + 4 * s, 16 * t + p);
+}
