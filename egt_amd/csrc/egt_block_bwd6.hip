@@ -46,6 +46,15 @@ __device__ __forceinline__ void tile_prefetch(unsigned lds_dump, const float* sr
                : "=&s"(keep) : "s"(src), "v"(lane_off), "s"(lds_dump) : "memory");
 }
 
+// the lane index, recomputed where it is needed (v_mbcnt) and opaque to loop-invariant code motion: at 128 registers per wave
+// hipcc otherwise keeps a dozen lane-derived LDS addresses alive across the row loop and spills some of them -- and a scratch
+// reload inside role A's loop carries an s_waitcnt vmcnt(0), which waits for the LDS-DMA of the next tile
+__device__ __forceinline__ int lane_now() {
+  int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(l));
+  return l;
+}
+
 #ifdef EGT_BWD_TIMING
 #define T6STAMP(i) do { const unsigned tn__ = (unsigned)__builtin_amdgcn_s_memtime(); tacc[i] += tn__ - tlast; tlast = tn__; } while (0)
 #else
@@ -56,8 +65,9 @@ template <int DE>
 struct Geo6 {
   using G = Geo<DE>;
   static constexpr int XCH = 704;                          // sc1 [256] | sc2 [192] | (dA, A~) [256]
-  static constexpr int PW = 3 * G::TILE_FLOATS + XCH;      // per key-tile lane
-  static constexpr int AREA = 4 * PW > BWD_PRO_WS ? 4 * PW : BWD_PRO_WS;
+  static constexpr int PW = 2 * G::TILE_FLOATS + XCH;      // per key-tile lane: e buffer (odd rows) | de' | hand-off
+  static constexpr int E0 = 4 * PW > BWD_PRO_WS ? 4 * PW : BWD_PRO_WS;   // the four e buffers of the even rows sit BEHIND the node-side
+  static constexpr int AREA = E0 + 4 * G::TILE_FLOATS;                   // prologue's scratch: their first DMA is issued before it runs
   static constexpr int WSB = G::TILES * 33 * 4;            // [t][32 entries + 1 zero entry] float4
   static constexpr size_t lds_floats(int TL) { return (size_t)AREA + (size_t)TL * QD_LD + 2 * G::TILES * 256 + WSB + 64; }   // + the prefetch dump (256 B)
 };
@@ -65,6 +75,9 @@ struct Geo6 {
 template <int DE>
 __global__ void __launch_bounds__(512, 4) k_block_bwd_v6(BlockArgs a) {
   seed_from_device(a);
+#ifdef EGT_BWD_TIMING
+  const unsigned tentry = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
   using G = Geo<DE>;
   using G6 = Geo6<DE>;
   constexpr int NI = G::NF4 / 64;
@@ -86,8 +99,9 @@ __global__ void __launch_bounds__(512, 4) k_block_bwd_v6(BlockArgs a) {
   const bool gated = (a.flags & EGT_BF_GATE) != 0;
   const bool clip = (a.flags & EGT_BF_CLIP) != 0;
   float* tb = sm + kt * G6::PW;
-  float* et0 = tb;                            // e / xhat tile, two buffers (row parity)
-  float* dt = tb + 2 * G::TILE_FLOATS;        // de' tile
+  float* etE = sm + G6::E0 + kt * G::TILE_FLOATS;   // e / xhat tile of the even rows (li & 1 == 0)
+  float* etO = tb;                                  // ... of the odd rows
+  float* dt = tb + G::TILE_FLOATS;                  // de' tile
   float* sc1 = dt + G::TILE_FLOATS;           // A -> B, A: dGE [16 pairs][16]
   float* sc2 = sc1 + 256;                     // A -> A, B: [H_hat(8) | 1 | rstd | - | -] [16 pairs][12]
   float* xab = sc2 + 192;                     // A -> B: (dA0, dA1, at0, at1) of the lane
@@ -98,50 +112,67 @@ __global__ void __launch_bounds__(512, 4) k_block_bwd_v6(BlockArgs a) {
   float* wsA = qd + TL * QD_LD;               // projection weights   [t][lane] float4
   float* wsD = wsA + G::TILES * 256;          // d(xhat) weights      [t][lane] float4
   float* wsB = wsD + G::TILES * 256;          // dH_ext weights, rows with a head only: [t][33] float4 (entry 32 = zeros)
-  const unsigned et_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)et0);
+  const unsigned etE_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)etE);
+  const unsigned etO_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)etO);
   const unsigned off0 = dma_lane_offset<DE>(lane);
 
-  for (int i = threadIdx.x; i < nl * 40; i += 512) {
-    const int r = i / 40, f = i % 40;
-    const size_t rowl = (size_t)b * N + l_begin + r;
-    if (a.pro && f >= 16 && f < 32) continue;   // dV_att comes from the prologue below
-    const float* src = f < 16 ? a.qkvp + rowl * QKVP + f * 4
-                     : f < 32 ? a.dvp + rowl * 64 + (f - 16) * 4
-                              : a.stats + rowl * 32 + (f - 32) * 4;
-    float4 v = *reinterpret_cast<const float4*>(src);
-    if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
-    *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
-  }
-  if (a.pro) {
-    __syncthreads();
-    if (!roleB) {
-      bwd_node_prologue<DE>(a, sm, qd, b, l_begin, wg);   // written for the 256 threads of waves 0-3
-    } else {
-      const int nb = a.pro == 2 ? 4 : 2;                  // ... whose barriers the other four waves join
-      for (int i = 0; i < nb; ++i) __syncthreads();
+  // ---- everything the first round needs that does not depend on the node-side prologue is requested FIRST: the first e tile
+  //      (LDS-DMA into the even-row buffer, which lies behind the prologue's scratch), K / V fragments, the first de' tile; the
+  //      staged query-side rows and the weight slabs follow in the same memory round trip.  The two roles are separate
+  //      control-flow paths from here to the end of the kernel (what one role keeps in registers is not live in the other) ----
+  const int ntile = N / 16;
+  const size_t rowm0 = (size_t)b * N + min(kt, ntile - 1) * 16 + p;
+  const size_t tile0 = (((size_t)b * N + l_begin) * N + min(kt, ntile - 1) * 16) * DE;
+  auto stage_rows_and_slabs = [&]() {
+    for (int i = threadIdx.x; i < nl * 40; i += 512) {
+      const int r = i / 40, f = i % 40;
+      const size_t rowl = (size_t)b * N + l_begin + r;
+      if (a.pro && f >= 16 && f < 32) continue;   // dV_att comes from the prologue
+      const float* src = f < 16 ? a.qkvp + rowl * QKVP + f * 4
+                       : f < 32 ? a.dvp + rowl * 64 + (f - 16) * 4
+                                : a.stats + rowl * 32 + (f - 32) * 4;
+      float4 v = *reinterpret_cast<const float4*>(src);
+      if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
+      *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
     }
-  }
-  for (int i = threadIdx.x; i < G::TILES * 256; i += 512) {
-    const int t = i >> 8, ln = (i >> 2) & 63, u = i & 3, pp = ln & 15, qq = ln >> 4;
-    const int c = 16 * t + 4 * qq + u;
-    wsA[i] = a.pw[c * 16 + pp];
-    wsD[i] = a.pw[(16 * t + pp) * 16 + 4 * qq + u];
-  }
-  for (int i = threadIdx.x; i < G6::WSB; i += 512) {
-    const int t = i / 132, r = i % 132, ent = r >> 2, u = r & 3;
-    const int qq = ent >> 3, hd = ent & 7, c = 16 * t + 4 * qq + u;
-    wsB[i] = (ent < 32 && c < DE) ? a.Wr[hd * DE + c] : 0.f;
-  }
-  __syncthreads();   // the prologue's scratch (= the tile area) is dead from here: DMA may land in it
-
+    for (int i = threadIdx.x; i < G::TILES * 256; i += 512) {
+      const int t = i >> 8, ln = (i >> 2) & 63, u = i & 3, pp = ln & 15, qq = ln >> 4;
+      const int c = 16 * t + 4 * qq + u;
+      wsA[i] = a.pw[c * 16 + pp];
+      wsD[i] = a.pw[(16 * t + pp) * 16 + 4 * qq + u];
+    }
+    for (int i = threadIdx.x; i < G6::WSB; i += 512) {
+      const int t = i / 132, r = i % 132, ent = r >> 2, u = r & 3;
+      const int qq = ent >> 3, hd = ent & 7, c = 16 * t + 4 * qq + u;
+      wsB[i] = (ent < 32 && c < DE) ? a.Wr[hd * DE + c] : 0.f;
+    }
+  };
 #ifdef EGT_BWD_TIMING
   unsigned tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned tlast = (unsigned)__builtin_amdgcn_s_memtime();
-  const unsigned tstart = tlast;
+  unsigned tlast = 0, tstart = 0, rstart = 0;
+#define T6START() do { tlast = (unsigned)__builtin_amdgcn_s_memtime(); tstart = tlast; rstart = (unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define T6START() do {} while (0)
 #endif
-  const int ntile = N / 16;
   if (!roleB) {
     // ===================================================================== role A
+    tile_dma<DE>(etE_lds, e_in + tile0, off0);
+    stage_rows_and_slabs();
+    if (a.pro) {
+      __syncthreads();
+      bwd_node_prologue<DE, true>(a, sm, qd, b, l_begin, wg);   // written for the 256 threads of waves 0-3
+    }
+    float Kf[16];   // first needed behind the first row's projections: requested here, not across the prologue (registers)
+    {
+      const float4* kp = reinterpret_cast<const float4*>(a.qkvp + rowm0 * QKVP + 64 + q * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 kv = kp[i];
+        Kf[4*i] = kv.x; Kf[4*i+1] = kv.y; Kf[4*i+2] = kv.z; Kf[4*i+3] = kv.w;
+      }
+    }
+    __syncthreads();
+    T6START();
     v4f accT[G::TILES], accR[G::TILES];
 #pragma unroll
     for (int t = 0; t < G::TILES; ++t) { accT[t] = (v4f){0.f, 0.f, 0.f, 0.f}; accR[t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
@@ -158,27 +189,27 @@ __global__ void __launch_bounds__(512, 4) k_block_bwd_v6(BlockArgs a) {
       const int m0 = mt * 16, m = m0 + p;
       const size_t rowm = (size_t)b * N + m;
       const float kadd = (a.km && a.km[rowm] == 0) ? -EGT_NEG : 0.0f;
-      float Kf[16];
-      {
+      if (mt0 > 0) {
         const float4* kp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 64 + q * 16);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float4 kv = kp[i];
           Kf[4*i] = kv.x; Kf[4*i+1] = kv.y; Kf[4*i+2] = kv.z; Kf[4*i+3] = kv.w;
         }
+        tile_dma<DE>(etE_lds, e_in + (((size_t)b * N + l_begin) * N + m0) * DE, off0);
       }
-      tile_dma<DE>(et_lds, e_in + (((size_t)b * N + l_begin) * N + m0) * DE, off0);
       vm_wait<0>();   // the first e tile of the key tile
       for (int l = l_begin; l < l_end; ++l) {
         const int li = l - l_begin;
         const size_t rowl = (size_t)b * N + l;
         const size_t pair0 = rowl * N + m0;
-        float* et = et0 + (li & 1) * G::TILE_FLOATS;
+        float* et = (li & 1) ? etO : etE;
+        const int lane = lane_now(), p = lane & 15, q = lane >> 4;   // (shadow the kernel-scope values: see lane_now)
         MaskRegs mr{make_float2(1.f, 1.f), 0};
         // ---- S1: e(l+1) -> the other e buffer (its readers, row l-1's P4 / P5, are behind the last barrier); it has the
         //      whole row to land and is retired at the end of S3 ----
         if (l + 1 < l_end)
-          tile_dma<DE>(et_lds + (unsigned)(((li + 1) & 1) * G::TILE_FLOATS * 4), e_in + (pair0 + (size_t)N) * DE, off0);
+          tile_dma<DE>(((li + 1) & 1) ? etO_lds : etE_lds, e_in + (pair0 + (size_t)N) * DE, off0);
         SCHED_FENCE();
         T6STAMP(0);
         float rstd;
@@ -316,6 +347,25 @@ __global__ void __launch_bounds__(512, 4) k_block_bwd_v6(BlockArgs a) {
     }
   } else {
     // ===================================================================== role B
+    float Vf[16];
+    TileRegs<DE> td;
+    tile_gload<DE>(td, dey_in + tile0, lane, 16);
+    {
+      const float4* vp = reinterpret_cast<const float4*>(a.qkvp + rowm0 * QKVP + 128 + q * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 vv = vp[i];
+        Vf[4*i] = vv.x; Vf[4*i+1] = vv.y; Vf[4*i+2] = vv.z; Vf[4*i+3] = vv.w;
+      }
+    }
+    stage_rows_and_slabs();
+    if (a.pro) {
+      __syncthreads();
+      const int nb = a.pro == 2 ? 4 : 2;   // the barriers of the node-side prologue, which waves 0-3 run
+      for (int i = 0; i < nb; ++i) __syncthreads();
+    }
+    __syncthreads();
+    T6START();
     for (int mt0 = 0; mt0 < ntile; mt0 += 4) {
       const int mt = mt0 + kt;
       if (mt >= ntile) {
@@ -324,19 +374,18 @@ __global__ void __launch_bounds__(512, 4) k_block_bwd_v6(BlockArgs a) {
       }
       const int m0 = mt * 16, m = m0 + p;
       const size_t rowm = (size_t)b * N + m;
-      float Vf[16], dKa[16], dVa[16];
-      {
+      float dKa[16], dVa[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { dKa[i] = 0.f; dVa[i] = 0.f; }
+      if (mt0 > 0) {
         const float4* vp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 128 + q * 16);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float4 vv = vp[i];
           Vf[4*i] = vv.x; Vf[4*i+1] = vv.y; Vf[4*i+2] = vv.z; Vf[4*i+3] = vv.w;
         }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { dKa[i] = 0.f; dVa[i] = 0.f; }
+        tile_gload<DE>(td, dey_in + (((size_t)b * N + l_begin) * N + m0) * DE, lane, 16);
       }
-      TileRegs<DE> td;
-      tile_gload<DE>(td, dey_in + (((size_t)b * N + l_begin) * N + m0) * DE, lane, 16);
       const unsigned dump_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dump);
       const unsigned pf_off = (unsigned)lane * 64u < (unsigned)G::TILE_FLOATS * 4u ? (unsigned)lane * 64u : 0u;
       // the lane's slot in the compact dH_ext slab: rows 4q', 4q'+1 carry heads, the others read the zero entry
@@ -345,8 +394,9 @@ __global__ void __launch_bounds__(512, 4) k_block_bwd_v6(BlockArgs a) {
         const int li = l - l_begin;
         const size_t rowl = (size_t)b * N + l;
         const size_t pair0 = rowl * N + m0;
-        const float* et = et0 + (li & 1) * G::TILE_FLOATS;
+        const float* et = (li & 1) ? etO : etE;
         const float* qr = qd + li * QD_LD;
+        const int lane = lane_now(), p = lane & 15, q = lane >> 4;   // (shadow the kernel-scope values: see lane_now)
         // ---- S1: de'(l) -> LDS tile; P2: dH_ext = de'.Wr^T; QK^T / dV_att.V dots ----
         tile_lds_put<DE>(dt, td, lane, 16);   // (the compiler's vmcnt wait for de' sits here)
         lds_sync();
@@ -466,6 +516,9 @@ __global__ void __launch_bounds__(512, 4) k_block_bwd_v6(BlockArgs a) {
     unsigned* o = a.dbg + ((size_t)wg * 8 + wave) * 16;
     for (int i = 0; i < 8; ++i) o[i] = tacc[i];
     o[13] = tlast - tstart;         // loop total
+    o[8] = tstart - tentry;         // kernel entry -> loop (staging, node-side prologue, weight slabs)
+    o[9] = (unsigned)__builtin_amdgcn_s_memrealtime() - rstart;   // loop (+ this wave's tail) in 10 ns ticks
+    o[10] = (unsigned)__builtin_amdgcn_s_memtime() - tstart;
   }
 #endif
   __syncthreads();
@@ -490,6 +543,9 @@ static void bwd_timing_report6() {
     for (int i = 0; i < 7; ++i)
       fprintf(stderr, "    %-28s %10.0f  (%.1f %%)\n", nm[r][i], g_bt6_sum[r][i] / g_bt6_waves[r], 100.0 * g_bt6_sum[r][i] / g_bt6_sum[r][13]);
     fprintf(stderr, "    %-28s %10.0f\n", "loop total", g_bt6_sum[r][13] / g_bt6_waves[r]);
+    fprintf(stderr, "    %-28s %10.0f\n", "entry -> loop", g_bt6_sum[r][8] / g_bt6_waves[r]);
+    fprintf(stderr, "    %-28s %10.3f GHz (%.0f cycles in %.2f us)\n", "shader clock over the loop", g_bt6_sum[r][10] / g_bt6_sum[r][9] * 0.1,
+            g_bt6_sum[r][10] / g_bt6_waves[r], g_bt6_sum[r][9] / g_bt6_waves[r] * 0.01);
   }
 }
 #endif

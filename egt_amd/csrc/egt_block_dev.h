@@ -171,7 +171,10 @@ __device__ __forceinline__ void fwd_node_epilogue(const BlockArgs& a, float* sm,
 // One launch per layer on the dh critical path instead of two; dV_att / delta never touch HBM.
 // `ws`: the (still idle) per-wave tile area; `qd`: the staged [16][QD_LD] rows.
 #define BWD_PRO_WS 8192   // floats of LDS scratch the prologue needs (dQKV, xhat, d h_ln, dh' rows, partials)
-template <int DE>
+// HOIST: the loads of the dV_att step (Wo columns, V_att rows) are issued with the first round of global loads instead of
+// after the dh' rows exist: one memory round trip on the kernel's critical path instead of two (costs 20 registers across
+// the first part)
+template <int DE, bool HOIST = false>
 __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg) {
   constexpr int LD = 68, LD3 = 196;
   float* dqs = ws;                   // dQKV  [16][196]
@@ -189,6 +192,15 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
   // rows past the end contribute zeros to every sum and are never stored
   const int nv = min(16, N - l_begin);                     // valid rows of this workgroup
   auto rc = [&](int r) { return row0 + min(r, nv - 1); };   // clamped global row
+  float4 wo[4];
+  float va[4];
+  auto load_wo_va = [&]() {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wo[s] = *reinterpret_cast<const float4*>(a.Wo + (size_t)(16 * wave + p) * 64 + 16 * q + 4 * s);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) va[r] = a.v_att[rc(4 * q + r) * 64 + 16 * wave + p];
+  };
+  if (HOIST) load_wo_va();
   if (a.pro == 2) {
     // ---- every global input in one round trip ----
     float4 hx = *reinterpret_cast<const float4*>(a.up_h + rc(t >> 4) * 64 + (t & 15) * 4);
@@ -310,12 +322,7 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
         make_float4(ok ? dv4.x : 0.f, ok ? dv4.y : 0.f, ok ? dv4.z : 0.f, ok ? dv4.w : 0.f);
   }
   // ---- dV_att = dh'.Wo^T for i tile = wave (contraction order c = 16 q + s), delta, dbo ----
-  float4 wo[4];
-  float va[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) wo[s] = *reinterpret_cast<const float4*>(a.Wo + (size_t)(16 * wave + p) * 64 + 16 * q + 4 * s);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) va[r] = a.v_att[rc(4 * q + r) * 64 + 16 * wave + p];
+  if (!HOIST) load_wo_va();
   __syncthreads();
   {
     v4f acc = {0.f, 0.f, 0.f, 0.f};
