@@ -38,14 +38,6 @@ __device__ __forceinline__ void wg_sync() {
   asm volatile("" ::: "memory");
 }
 
-// Pull one 16-pair tile (contiguous, <= 4 KiB) into L2 without a VGPR destination: ONE LDS-DMA instruction, lane i fetching
-// the dword at byte 64 i (every 128-byte line of the tile is touched), landing in a dump area of LDS that nobody reads.
-__device__ __forceinline__ void tile_prefetch(unsigned lds_dump, const float* src, unsigned lane_off) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %2, %1\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "s"(src), "v"(lane_off), "s"(lds_dump) : "memory");
-}
-
 // the lane index, recomputed where it is needed (v_mbcnt) and opaque to loop-invariant code motion: at 128 registers per wave
 // hipcc otherwise keeps a dozen lane-derived LDS addresses alive across the row loop and spills some of them -- and a scratch
 // reload inside role A's loop carries an s_waitcnt vmcnt(0), which waits for the LDS-DMA of the next tile

@@ -62,20 +62,51 @@ __device__ __forceinline__ void apply_masks(const BlockArgs& a, float kadd, cons
 }
 
 // transpose-reduce 16 per-lane values over the 16 key lanes (same q): lane p returns the
-// sum of element p
+// sum of element p.  VALU and MFMA issue add up on a gfx950 SIMD (profiles/r03_mfma_valu_issue.md), so instruction count is
+// what this costs: the "xor 8" and "xor 4" levels are DPP adds whose SECOND instruction of a pair writes only the banks
+// (groups of 4 lanes) that keep the other element -- no selects, no moves: 2 instructions per result instead of 6-7
+// (v_cndmask x2, v_mov 0, v_mov_dpp x1-2, v_add).  Same operands, same association order as the select form: bit-identical.
+//   row_ror:8 = lane ^ 8;  row_ror:12 reads lane + 4 (valid for banks 0 and 2), row_ror:4 reads lane - 4 (banks 1 and 3).
+// The s_nop 1 ahead of each block are the two wait states between a VALU write of a VGPR and a DPP read of it (hipcc pads
+// nothing inside an asm statement); inside a block no DPP source was written by one of the two instructions before it.
 __device__ __forceinline__ float reduce16_keep_own(const float (&v)[16], int p) {
-  float w8[8], w4[4], w2[2];
-  const bool b3 = (p & 8) != 0, b2 = (p & 4) != 0, b1 = (p & 2) != 0, b0 = (p & 1) != 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float snd = b3 ? v[i] : v[i + 8], kp = b3 ? v[i + 8] : v[i];
-    w8[i] = kp + lane_xor<8>(snd);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float snd = b2 ? w8[i] : w8[i + 4], kp = b2 ? w8[i + 4] : w8[i];
-    w4[i] = kp + lane_xor<4>(snd);
-  }
+  float t0, t1, t2, t3, t4, t5, t6, t7, u0, u1, u2, u3;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %1, %17, %17 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %2, %18, %18 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %3, %19, %19 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %4, %20, %20 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %5, %21, %21 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %6, %22, %22 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %7, %23, %23 row_ror:8 row_mask:0xf bank_mask:0xc"
+      : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+        "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %4, %4 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %1, %5, %5 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %2, %6, %6 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %3, %7, %7 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %0, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %1, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %2, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %3, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xa"
+      : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)
+      : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(t4), "v"(t5), "v"(t6), "v"(t7));
+  const float w4[4] = {u0, u1, u2, u3};
+  float w2[2];
+  const bool b1 = (p & 2) != 0, b0 = (p & 1) != 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const float snd = b1 ? w4[i] : w4[i + 2], kp = b1 ? w4[i + 2] : w4[i];

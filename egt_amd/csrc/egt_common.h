@@ -57,7 +57,7 @@ __device__ __forceinline__ float wave_xor_f(float v, int m) { return __shfl_xor(
 // DPP: value of lane (i ^ MASK) for MASK in {1,2,4,8} inside each 16-lane row.
 template <int CTRL>
 __device__ __forceinline__ float egt_dpp(float v) {
-  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xF, 0xF, false));
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xF, 0xF, true));   // bound_ctrl: every lane is written, no 'old' value to materialise
 }
 template <int MASK>
 __device__ __forceinline__ float lane_xor(float v) {

@@ -59,3 +59,12 @@ __device__ __forceinline__ float elem_read_st(const float* lane_base, const floa
   if (DE == 64) return lane_base[256 * s + 16 * (t ^ s)];
   return elem_read<DE>(tl, q + 4 * s, 16 * t + p);
 }
+
+// Pull one 16-pair tile (contiguous, <= 4 KiB) into L2 without a VGPR destination: ONE LDS-DMA instruction, lane i fetching
+// the dword at byte 64 i (every 128-byte line of the tile is touched), landing in a dump area of LDS that nobody reads.
+__device__ __forceinline__ void tile_prefetch(unsigned lds_dump, const float* src, unsigned lane_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %2, %1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(src), "v"(lane_off), "s"(lds_dump) : "memory");
+}
+
