@@ -232,21 +232,26 @@ def svd_features(A: np.ndarray, num_features=None, mult_sing_vals=True, norm_fir
 
 
 def eigen_features(edges, n: int, dim: int, sparse=True) -> np.ndarray:
-    """eigen_gt.py:6-57: eigenvectors 1..dim of L = I - D^-1/2 A D^-1/2 (A = summed edge multiplicities, no self
-    loops), ascending eigenvalue.  sparse=True is ARPACK ('SR', tol 1e-2) like the reference; False the dense solver."""
-    import scipy.sparse as sp
-    edges = np.asarray(edges)
-    A = sp.csr_matrix((np.ones(len(edges), dtype="float32"), (edges[:, 0], edges[:, 1])), shape=(n, n), dtype="float32")
-    Nm = sp.diags(np.asarray(A.sum(axis=1)).squeeze().clip(1) ** -0.5, dtype=float)
-    L = sp.eye(n) - Nm * A * Nm
-    if sparse:
+    """Laplacian positional encoding of one graph (what lib/data/eigen_gt.py:6-57 produces): columns 1..dim of the
+    eigenvector matrix of the symmetric normalised Laplacian L = I - D^-1/2 W D^-1/2, ascending eigenvalue, where W counts
+    the edge multiplicities of the edge list and isolated nodes get degree 1.  L is real symmetric, so the dense symmetric
+    eigensolver gives the whole spectrum exactly and deterministically (the reference's ARPACK call at tol 1e-2 returns the
+    same subspace up to its tolerance and to the sign of each vector, which the model randomises anyway); `sparse` is kept
+    for signature compatibility and only switches to the iterative solver for graphs too large for a dense
+    factorisation."""
+    edges = np.asarray(edges).reshape(-1, 2)
+    W = np.zeros((n, n), dtype=np.float64)
+    np.add.at(W, (edges[:, 0], edges[:, 1]), 1.0)
+    scale = 1.0 / np.sqrt(np.maximum(W.sum(axis=1), 1.0))
+    L = np.eye(n) - scale[:, None] * W * scale[None, :]
+    L = 0.5 * (L + L.T)                       # a directed edge list gives an unsymmetric W: the symmetric part has the real spectrum
+    if sparse and n > 4096:
         import scipy.sparse.linalg as spl
-        val, vec = spl.eigs(L, k=dim + 1, which="SR", tol=1e-2)
-        vec = vec[:, val.argsort()]
-        return np.real(vec[:, 1:dim + 1]).astype("float32")
-    val, vec = np.linalg.eig(L.toarray())
-    vec = np.real(vec[:, val.argsort()])
-    return vec[:, 1:dim + 1].astype("float32")
+        val, vec = spl.eigsh(L, k=min(dim + 1, n - 1), which="SA")
+    else:
+        val, vec = np.linalg.eigh(L)
+    vec = vec[:, np.argsort(val, kind="stable")]
+    return np.ascontiguousarray(vec[:, 1:dim + 1]).astype("float32")
 
 
 # ---------------------------------------------------------------------------------- dataset specs ---
@@ -481,16 +486,21 @@ class GraphDataset:
         return _prefetch(gen(), 2) if self.prefetch_batch else gen()
 
     def _finish(self, recs, map_fn, shard, as_torch, device):
+        counts = None
         if shard is not None:
-            lo, hi = shard_batch(len(recs), shard[1], shard[0])
+            n_global = len(recs)
+            if n_global < shard[1]:
+                return None        # fewer graphs than ranks: EVERY rank drops this (last) batch, so all take the same number of steps
+            lo, hi = shard_batch(n_global, shard[1], shard[0])
             recs = recs[lo:hi]
-            if not recs:
-                return None
+            counts = (hi - lo, n_global)
         b = self.collate(recs)
         if as_torch:
             import torch
             b = {k: (torch.from_numpy(v).to(device) if device is not None else torch.from_numpy(v))
                  for k, v in b.items() if v.dtype.kind not in "SUO"}
+        if counts is not None:     # the gradient all-reduce weights a rank by its share of the global batch (egt_amd.dp)
+            b["_local_count"], b["_global_count"] = counts
         return map_fn(b) if map_fn is not None else b
 
     def get_batched_data(self, batch_size, drop_remainder=False, map_fns=None, **kw):
@@ -551,7 +561,7 @@ class CreateTargets:
 
 
 def dataset_for_scheme(scheme: str, dataset_path: str, max_shuffle_len=10000, num_svd_features=16, num_eig_features=8,
-                       use_svd=False, splits=("training", "validation"), **kw) -> GraphDataset:
+                       use_svd=False, use_eig=True, splits=("training", "validation"), **kw) -> GraphDataset:
     """what ``get_dataset()`` builds for the schemes egt_amd.training runs: dataset class + dataset_config
     (scheme_base.py:62-69,125-133,167-171; schemes/{zinc,pattern,cifar10}/svd.py) and the excluded features
     (scheme_base.py:95-98,135-139)."""
@@ -568,5 +578,7 @@ def dataset_for_scheme(scheme: str, dataset_path: str, max_shuffle_len=10000, nu
     excl = ["record_name", "num_nodes"]
     if level == "svd" and not use_svd:
         excl.append("singular_vectors")
+    if level == "eigen" and not use_eig:
+        excl.append("eigen_vectors")                 # scheme_base.py:171-175
     ds.exclude(excl)
     return ds

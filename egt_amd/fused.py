@@ -236,6 +236,17 @@ class _FusedStack(torch.autograd.Function):
                     ptrs.append(base + 4 * off)
                     off += p.numel()
             garr = C.cast((C.c_void_p * len(ptrs))(*ptrs), C.POINTER(L.BlockParams))
+            # the parameters' .grad must still BE the views of the buffer: an optimizer.zero_grad() (set_to_none=True is torch's
+            # default) between bind and backward would otherwise leave every stack parameter without a gradient, silently.
+            # Checked on the first and last parameter only (the per-parameter walk is the host time this path exists to avoid)
+            sp = getattr(ctx.holder, "sink_params", None)
+            if sp:
+                g0, g1 = sp[0].grad, sp[-1].grad
+                if g0 is None or g1 is None or g0.data_ptr() != base or g1.data_ptr() != base + 4 * (off - sp[-1].numel()):
+                    o2 = 0
+                    for q in sp:
+                        q.grad = sink[o2:o2 + q.numel()].view_as(q)
+                        o2 += q.numel()
             ws = torch.empty(lib.egt_stack_workspace_bytes(C.byref(desc), layers), dtype=torch.uint8, device=dev)
             L.check(lib.egt_stack_bwd(C.byref(desc), layers, ctx.parr, L.ptr(h), L.ptr(e), L.ptr(key_mask),
                                       L.ptr(attn_mask), L.ptr(saved), L.ptr(dh_out), L.ptr(de_out), L.ptr(dh),

@@ -62,6 +62,18 @@ class DeviceSeeds:
         """The current words as unsigned Python ints (synchronises; for tests)."""
         return [int(v) & _M64 for v in self.words.tolist()]
 
+    def state_dict(self):
+        """the device words (the position of every module's mask stream), for checkpoints: a resumed run continues the
+        sequence instead of repeating it"""
+        return dict(words=self.values(), steps=self.steps)
+
+    def load_state_dict(self, sd):
+        vals = [_signed(int(v)) for v in sd["words"]]
+        if len(vals) != len(self.modules):
+            raise ValueError("mask-seed state does not match the model's EGT modules")
+        self.words.copy_(torch.tensor(vals, dtype=torch.int64))
+        self.steps = int(sd.get("steps", 0))
+
     def detach(self):
         """Back to host-side seeds; the modules' call counts continue after the device words' position."""
         vals = self.values()

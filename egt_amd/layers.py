@@ -327,10 +327,12 @@ class EGTStack(nn.Module):
             p.grad = flat[off:off + p.numel()].view_as(p)
             off += p.numel()
         self.grad_holder.sink = self.grad_holder.flat = flat
+        self.grad_holder.sink_params = ps          # the backward re-attaches the views if a zero_grad(set_to_none=True) dropped them
         return flat
 
     def unbind_flat_gradients(self):
         self.grad_holder.sink = None
+        self.grad_holder.sink_params = None
         for p in self.fused_parameters():
             p.grad = None
 
@@ -362,11 +364,13 @@ class EGTLayerStack(nn.Module):
     (egt_amd.ffn.FFN; widths 64).  `edge_channel_type` in ('residual', 'constrained') updates
     both channels in ffn_block (:312-320); otherwise only the node channels (:322-323)."""
 
-    def __init__(self, model_height=4, model_width=64, edge_width=64, activation='elu', ffn_matmul='f32', **block_kwargs):
+    def __init__(self, model_height=4, model_width=64, edge_width=64, activation='elu', ffn_matmul='f32', ffn_multiplier=2.0,
+                 **block_kwargs):
         super().__init__()
         from .ffn import FFN as _FFN
         from functools import partial
-        FFN = partial(_FFN, matmul=ffn_matmul)   # "f32" exact | "bf16x3" split products (fp32 tolerances) | "bf16"
+        FFN = partial(_FFN, matmul=ffn_matmul, ffn_multiplier=ffn_multiplier)   # (the FFN refuses a multiplier it is not built for)
+        # "f32" exact | "bf16x3" split products (fp32 tolerances) | "bf16"
         seed = block_kwargs.pop('seed', 0)
         self.blocks = nn.ModuleList(
             [EGTBlock(seed=seed * 1000 + i, model_width=model_width, edge_width=edge_width, **block_kwargs)

@@ -96,26 +96,54 @@ class ZincDCTransformer(nn.Module):
                  edge_channel_type='residual', upto_hop=16, clip_hops=True, random_mask_prob=0.1,
                  clip_logits_value=[-5, 5], mlp_layers=[.5, .25], activation='elu', do_final_norm=True,
                  ffn_multiplier=2., num_node_features=28, num_edge_features=4, num_targets=1,
-                 readout_edges=False, num_virtual_nodes=0, use_svd=False, node_dropout=0., edge_dropout=0.,
-                 seed=0, ffn_matmul='f32', **unused):
+                 readout_edges=False, num_virtual_nodes=0, node_dropout=0., edge_dropout=0.,
+                 # positional encodings (SVDFeatModel / EigFeatModel, graph_model_base.py:284-414)
+                 use_svd=False, num_svd_features=256, sel_svd_features=128, random_neg=False, transform_svd=False,
+                 use_eig=False, num_eig_features=40, sel_eig_features=20, transform_eig=False,
+                 # operator attributes handed to every attention block (graph_xformer_model_base.py:117-127)
+                 scale_degree=False, scaler_type='log', attn_dropout=0., edge_activation=None,
+                 # reference keys that are accepted at their default only (each would change the model: no silent ignore)
+                 l2_reg=0, distance_loss=0., distance_target=8, add_n_norm=False, combine_layer_repr=False,
+                 node2edge_xtalk=0., edge2node_xtalk=0., node2edge_embed=False, node_normalization='layer',
+                 edge_normalization='layer', global_step_layer=False, max_length=None,
+                 seed=0, ffn_matmul='f32', **unknown):
         super().__init__()
-        if readout_edges or num_virtual_nodes or use_svd or node_dropout or edge_dropout:
-            raise NotImplementedError("ZincDCTransformer covers the shipped ZINC configs: readout_edges=False, "
-                                      "num_virtual_nodes=0, use_svd=False, dropout=0")
+        if unknown:
+            raise TypeError(f"{type(self).__name__}: unknown model_config keys {sorted(unknown)}")
+        unsupported = dict(readout_edges=(readout_edges, False), num_virtual_nodes=(num_virtual_nodes, 0),
+                           node_dropout=(node_dropout, 0), edge_dropout=(edge_dropout, 0), l2_reg=(l2_reg, 0),
+                           distance_loss=(distance_loss, 0), add_n_norm=(add_n_norm, False),
+                           combine_layer_repr=(combine_layer_repr, False), node2edge_xtalk=(node2edge_xtalk, 0),
+                           edge2node_xtalk=(edge2node_xtalk, 0), node2edge_embed=(node2edge_embed, False),
+                           node_normalization=(node_normalization, 'layer'), edge_normalization=(edge_normalization, 'layer'))
+        bad = {k: v for k, (v, d) in unsupported.items() if v != d}
+        if bad:    # the reference model applies every one of these: training "a different model without a warning" is not an option
+            raise NotImplementedError(f"{type(self).__name__} covers the shipped configs; not built: {bad}")
         if edge_channel_type not in ('residual', 'constrained'):
             raise NotImplementedError("edge_channel_type must be residual or constrained")
+        if use_svd and use_eig:
+            raise NotImplementedError("use_svd and use_eig together (no reference model class mixes both)")
         self.cfg = dict(model_width=model_width, edge_width=edge_width, num_heads=num_heads, model_height=model_height,
                         upto_hop=upto_hop, clip_hops=clip_hops, mlp_layers=list(mlp_layers), activation=activation,
                         do_final_norm=do_final_norm, num_node_features=num_node_features,
                         num_edge_features=num_edge_features, num_targets=num_targets, ffn_multiplier=ffn_multiplier,
-                        edge_channel_type=edge_channel_type)
+                        edge_channel_type=edge_channel_type,
+                        use_svd=bool(use_svd), num_svd_features=num_svd_features, sel_svd_features=sel_svd_features,
+                        transform_svd=bool(transform_svd), use_eig=bool(use_eig), num_eig_features=num_eig_features,
+                        sel_eig_features=sel_eig_features, transform_eig=bool(transform_eig), random_neg=bool(random_neg))
         self.node_emb = nn.Parameter(torch.empty(num_node_features + 1, model_width).uniform_(-0.05, 0.05))   # keras 'uniform'
         self.fm_emb = nn.Parameter(torch.empty(num_edge_features + 1, edge_width).uniform_(-0.05, 0.05))
         self.adj_emb = KerasDense(upto_hop, edge_width)
+        if use_svd and transform_svd:
+            self.svd_emb = KerasDense(2 * sel_svd_features, model_width)                # graph_model_base.py:343-345
+        if use_eig and transform_eig:
+            self.eig_emb = KerasDense(sel_eig_features, model_width)                    # :408-410
         self.layers = EGTLayerStack(model_height=model_height, model_width=model_width, edge_width=edge_width,
                                     activation=activation, num_heads=num_heads, gate_attention=gate_attention,
                                     edge_channel_type=edge_channel_type, clip_logits_value=clip_logits_value,
-                                    random_mask_prob=random_mask_prob, seed=seed, ffn_matmul=ffn_matmul)
+                                    random_mask_prob=random_mask_prob, scale_degree=scale_degree, scaler_type=scaler_type,
+                                    attn_dropout=attn_dropout, edge_activation=edge_activation, seed=seed,
+                                    ffn_matmul=ffn_matmul, ffn_multiplier=ffn_multiplier)
         self.node_norm_final = KerasLayerNorm(model_width) if do_final_norm else None
         self.mlp_out = nn.ModuleList()
         w = model_width
@@ -123,6 +151,45 @@ class ZincDCTransformer(nn.Module):
             self.mlp_out.append(KerasDense(w, round(f * model_width)))
             w = round(f * model_width)
         self.target = KerasDense(w, num_targets)
+
+    # ---- positional encodings: node_emb_add = Add()([node embedding, PE embedding]) (graph_xformer_model_base.py:390-399) ----
+    def positional(self, h, singular_vectors=None, eigen_vectors=None, pe_signs=None):
+        """h + the SVD / eigenvector embedding of the batch.  Training applies the reference's random sign flip
+        (RandomNeg / RandomNegEig, misc.py:53-94): one sign per (graph, feature), drawn on the device unless `pe_signs`
+        ([B,1,F,1] for SVD, [B,1,F] for eigenvectors) injects the sample."""
+        c = self.cfg
+        if c["use_svd"]:
+            if singular_vectors is None:
+                raise ValueError("use_svd=True: the batch must carry singular_vectors [B,N,num_svd_features,2]")
+            v = singular_vectors.to(h.dtype)[:, :, :c["sel_svd_features"], :]
+            if not c["transform_svd"]:
+                v = F.pad(v, (0, 0, 0, max(0, c["model_width"] // 2 - c["sel_svd_features"])))
+            if c["random_neg"] and self.training:
+                sg = pe_signs if pe_signs is not None else \
+                    torch.where(torch.rand(v.shape[0], 1, v.shape[2], 1, device=v.device) < 0.5, -1.0, 1.0)
+                v = v * sg.to(v.dtype)
+            v = torch.cat(torch.unbind(v, dim=-1), dim=-1)
+            h = h + (self.svd_emb(v) if c["transform_svd"] else v)
+        if c["use_eig"]:
+            if eigen_vectors is None:
+                raise ValueError("use_eig=True: the batch must carry eigen_vectors [B,N,num_eig_features]")
+            v = eigen_vectors.to(h.dtype)[:, :, :c["sel_eig_features"]]
+            if not c["transform_eig"]:
+                v = F.pad(v, (0, max(0, c["model_width"] - c["sel_eig_features"])))
+            if c["random_neg"] and self.training:
+                sg = pe_signs if pe_signs is not None else \
+                    torch.where(torch.rand(v.shape[0], 1, v.shape[2], device=v.device) < 0.5, -1.0, 1.0)
+                v = v * sg.to(v.dtype)
+            h = h + (self.eig_emb(v) if c["transform_eig"] else v)
+        return h
+
+    def edge_mask(self, graph_matrix, attn_mask):
+        """'constrained' edge channels: M = the adjacency tiled over the heads (AdjMatModel.get_edge_mask,
+        graph_model_base.py:131-142) unless the caller passes its own."""
+        if attn_mask is None and self.cfg["edge_channel_type"] == 'constrained':
+            from .masks import constrained_edge_mask
+            return constrained_edge_mask(graph_matrix, self.cfg["num_heads"])
+        return attn_mask
 
     # the Keras functional model contains only layers on a path to the outputs: with readout_edges=False the last
     # layer's dense_edge_r / edge FFN and edge_norm_final are NOT part of the reference model
@@ -136,6 +203,10 @@ class ZincDCTransformer(nn.Module):
     def keras_named_parameters(self):
         dead = {id(p) for p in self._dead_edge_params()}
         out = {"adj_emb/kernel": self.adj_emb.kernel, "adj_emb/bias": self.adj_emb.bias}
+        if hasattr(self, "svd_emb"):
+            out["svd_emb/kernel"], out["svd_emb/bias"] = self.svd_emb.kernel, self.svd_emb.bias
+        if hasattr(self, "eig_emb"):
+            out["eig_emb/kernel"], out["eig_emb/bias"] = self.eig_emb.kernel, self.eig_emb.bias
         if isinstance(self.node_emb, nn.Parameter):
             out["node_emb/embeddings"] = self.node_emb
         if isinstance(self.fm_emb, nn.Parameter):
@@ -160,9 +231,11 @@ class ZincDCTransformer(nn.Module):
                        clip_hops=self.cfg["clip_hops"])                                 # :70-73 + graph_model_base.py:97-127
         return h, e, mask
 
-    def forward(self, node_features, feature_matrix, graph_matrix, attn_mask=None):
+    def forward(self, node_features, feature_matrix, graph_matrix, attn_mask=None, singular_vectors=None,
+                eigen_vectors=None, pe_signs=None):
         h, e, mask = self.embeddings(node_features, feature_matrix, graph_matrix)
-        h, e = self.layers(h, e, mask, attn_mask, skip_last_edge_ffn=True)              # :336-341
+        h = self.positional(h, singular_vectors, eigen_vectors, pe_signs)
+        h, e = self.layers(h, e, mask, self.edge_mask(graph_matrix, attn_mask), skip_last_edge_ffn=True)   # :336-341
         if self.node_norm_final is not None:
             h = self.node_norm_final(h)                                                 # :343-345
         m = mask.to(h.dtype)[..., None]
@@ -191,10 +264,12 @@ class PatternDCTransformer(ZincDCTransformer):
         out.pop("fm_emb/embeddings", None)
         return out
 
-    def forward(self, node_features, graph_matrix, attn_mask=None, return_mask=False):
+    def forward(self, node_features, graph_matrix, attn_mask=None, return_mask=False, singular_vectors=None,
+                eigen_vectors=None, pe_signs=None):
         fmat = torch.full(graph_matrix.shape, -1, dtype=torch.int32, device=graph_matrix.device)
         h, e, mask = self.embeddings(node_features, fmat, graph_matrix)
-        h, e = self.layers(h, e, mask, attn_mask, skip_last_edge_ffn=True)
+        h = self.positional(h, singular_vectors, eigen_vectors, pe_signs)
+        h, e = self.layers(h, e, mask, self.edge_mask(graph_matrix, attn_mask), skip_last_edge_ffn=True)
         if self.node_norm_final is not None:
             h = self.node_norm_final(h)
         x = h

@@ -109,16 +109,23 @@ def default_config(scheme: str = "zinc.svd") -> Config:
         model_name="dc_svd", cache_dir=lambda c: f"data_cache/{c.dataset_name.upper()}/svd_{c.num_svd_features}",
         num_svd_features=16, sel_svd_features=8, use_svd=True, random_neg=True,
     )
+    if scheme.endswith(".eig"):   # BaseEigModelScheme (scheme_base.py:155-165) instead of BaseSVDModelScheme
+        for k in ("num_svd_features", "sel_svd_features", "use_svd", "random_neg"):
+            c.pop(k)
+        c.update(model_name="dc_eig", cache_dir=lambda c: f"data_cache/{c.dataset_name.upper()}/eig_{c.num_eig_features}",
+                 num_eig_features=20, sel_eig_features=8, use_eig=True)
     if scheme == "cifar10.svd":   # CIFAR10DCSVD (schemes/cifar10/svd.py:13-20): rlr_monitor follows save_best_monitor
         c.update(dataset_name="cifar10", num_virtual_nodes=0, save_best_monitor="val_xent")
     elif scheme == "pattern.svd":   # SBMPDCSVD (schemes/pattern/svd.py:16-24)
         c.update(dataset_name="sbm_pattern", class_sizes=[979220, 209900], rlr_monitor="val_xent", save_best_monitor="val_xent")
-    else:                         # ZincDCSVD (schemes/zinc/svd.py:13-21)
+    elif scheme == "pattern.eig":   # SBMPDCEig (schemes/pattern/eig.py:16-22): the monitors stay at the base default (val_loss)
+        c.update(dataset_name="sbm_pattern", class_sizes=[979220, 209900])
+    else:                         # ZincDCSVD (schemes/zinc/svd.py:13-21), ZincDCEig (schemes/zinc/eig.py:14-22)
         c.update(dataset_name="zinc", num_virtual_nodes=0, rlr_monitor="val_mae", save_best_monitor="val_mae")
     return c
 
 
-SCHEMES = ("zinc.svd", "pattern.svd", "cifar10.svd")
+SCHEMES = ("zinc.svd", "zinc.eig", "pattern.svd", "pattern.eig", "cifar10.svd")
 
 
 def make_config(user: Optional[dict], scheme: Optional[str] = None) -> Config:
@@ -149,8 +156,11 @@ def _model_config_common(c: Config) -> dict:
         mlp_layers=c.mlp_layers, edge_channel_type=c.edge_channel_type, edge_activation=c.edge_activation,
         ffn_multiplier=c.ffn_multiplier, global_step_layer=True,
         upto_hop=c.upto_hop, distance_loss=c.distance_loss, distance_target=c.distance_target,
-        use_svd=c.use_svd, transform_svd=True, random_neg=c.random_neg, num_svd_features=c.num_svd_features,
-        sel_svd_features=c.sel_svd_features,
+        **(dict(use_eig=c.use_eig, transform_eig=False, random_neg=True, num_eig_features=c.num_eig_features,
+                sel_eig_features=c.sel_eig_features)                                    # BaseEigModelScheme, scheme_base.py:178-190
+           if "use_eig" in c else
+           dict(use_svd=c.use_svd, transform_svd=True, random_neg=c.random_neg, num_svd_features=c.num_svd_features,
+                sel_svd_features=c.sel_svd_features)),                                  # BaseSVDModelScheme, :139-151
     )
 
 
@@ -277,10 +287,59 @@ class SyntheticZinc:
                        graph_matrix=adj.to(self.device), target=tgt.to(self.device))
 
 
+class WithPositional:
+    """Adds the positional-encoding input of a `*.svd` (use_svd) / `*.eig` scheme to the batches of a synthetic set, computed
+    from each graph's adjacency with the data pipeline's own functions (egt_amd.data.svd_features / eigen_features):
+    singular_vectors [B,N,F,2] or eigen_vectors [B,N,F], zero rows on the padding."""
+
+    def __init__(self, base, kind: str, num_features: int):
+        assert kind in ("svd", "eig")
+        self.base, self.kind, self.F = base, kind, int(num_features)
+
+    def __len__(self):
+        return len(self.base)
+
+    def __iter__(self):
+        from .data import svd_features, eigen_features
+        for b in self.base:
+            adj = b["graph_matrix"].cpu().numpy()
+            nf = b["node_features"].cpu().numpy()
+            real = (nf != -1) if nf.ndim == 2 else (nf != -1).any(-1)
+            B, N = adj.shape[:2]
+            out = np.zeros((B, N, self.F, 2) if self.kind == "svd" else (B, N, self.F), dtype=np.float32)
+            for i in range(B):
+                n = int(real[i].sum())
+                if n == 0:
+                    continue
+                A = adj[i, :n, :n]
+                if self.kind == "svd":
+                    out[i, :n] = svd_features(A, self.F)[0]
+                else:
+                    ed = np.argwhere(A > 0)
+                    ev = eigen_features(ed, n, min(self.F, max(n - 1, 0)))
+                    out[i, :n, :ev.shape[1]] = ev
+            key = "singular_vectors" if self.kind == "svd" else "eigen_vectors"
+            yield dict(b, **{key: torch.from_numpy(out).to(b["graph_matrix"].device)})
+
+
+def _dist_on():
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
+def _rank():
+    return torch.distributed.get_rank() if _dist_on() else 0
+
+
+def _barrier():
+    if _dist_on():
+        torch.distributed.barrier()
+
+
 # ------------------------------------------------------------------------------------------ scheme --
 class ZincSVDScheme:
     """lib.training.schemes.zinc.svd.SCHEME: TrainingBase protocol around the ZINC model."""
     SCHEME = "zinc.svd"
+    MAX_GRAPHS = 16        # config.use_hipgraph: captured step graphs kept alive (least recently used geometry is dropped)
 
     def __init__(self, config: Optional[dict] = None, model_factory=None, device=None, print_fn=print):
         self.config_input = config
@@ -302,11 +361,7 @@ class ZincSVDScheme:
         if self.model_factory is not None:
             return self.model_factory(self.get_model_config())
         from .model import ZincDCTransformer
-        mc = self.get_model_config()
-        if mc["use_svd"]:
-            raise NotImplementedError("use_svd=True (SVD positional encodings) needs the data pipeline's features; "
-                                      "the shipped ZINC configs set use_svd=false")
-        return ZincDCTransformer(**mc)
+        return ZincDCTransformer(**self.get_model_config())
 
     def get_optimizer(self, params):
         c = self.config
@@ -357,11 +412,18 @@ class ZincSVDScheme:
         return os.path.join(self.config.checkpoint_path, "ckpt.pt")
 
     def save_checkpoint(self):
-        os.makedirs(self.config.checkpoint_path, exist_ok=True)
-        tmp = self._ckpt_file() + ".tmp"
-        torch.save(dict(model=self.model.state_dict(), optimizer=self.optimizer.state_dict(), state=self.state.items()), tmp)
-        os.replace(tmp, self._ckpt_file())
-        self.print(f"Checkpoint saved to {self.config.checkpoint_path}")
+        """rank 0 writes (the replicas are identical); everybody waits for the file"""
+        if _rank() == 0:
+            os.makedirs(self.config.checkpoint_path, exist_ok=True)
+            tmp = self._ckpt_file() + ".tmp"
+            extra = {}
+            if getattr(self, "_seeds", None) is not None:
+                extra["mask_seeds"] = self._seeds.state_dict()       # device-resident mask streams (use_hipgraph)
+            extra["mask_calls"] = [int(m._calls) for m in self.model.modules() if hasattr(m, "_calls") and hasattr(m, "next_seed")]
+            torch.save(dict(model=self.model.state_dict(), optimizer=self.optimizer.state_dict(), state=self.state.items(), **extra), tmp)
+            os.replace(tmp, self._ckpt_file())
+            self.print(f"Checkpoint saved to {self.config.checkpoint_path}")
+        _barrier()
 
     def load_checkpoint(self):
         f = self._ckpt_file()
@@ -371,6 +433,12 @@ class ZincSVDScheme:
         self.model.load_state_dict(ck["model"])
         self.optimizer.load_state_dict(ck["optimizer"])
         self.state.load(ck["state"])
+        mods = [m for m in self.model.modules() if hasattr(m, "_calls") and hasattr(m, "next_seed")]
+        if len(ck.get("mask_calls", [])) == len(mods):        # the random-mask streams continue where the run stopped
+            for m, n in zip(mods, ck["mask_calls"]):
+                m._calls = n
+        if getattr(self, "_seeds", None) is not None and "mask_seeds" in ck:
+            self._seeds.load_state_dict(ck["mask_seeds"])
         self.print(f"Checkpoint loaded from {self.config.checkpoint_path}")
         return True
 
@@ -380,40 +448,66 @@ class ZincSVDScheme:
         self.load_checkpoint()
 
     # ---- weight files (Keras variable names; .npz instead of .h5) ----
+    def _named(self):
+        return self.model.keras_named_parameters() if hasattr(self.model, "keras_named_parameters") else dict(self.model.named_parameters())
+
     def save_weights(self, path):
-        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        named = self.model.keras_named_parameters() if hasattr(self.model, "keras_named_parameters") else dict(self.model.named_parameters())
-        np.savez(path, **{k: v.detach().cpu().numpy() for k, v in named.items()})
-        self.print(f"Saved model to {path}")
+        if _rank() == 0:
+            os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+            np.savez(path, **{k: v.detach().cpu().numpy() for k, v in self._named().items()})
+            self.print(f"Saved model to {path}")
+        _barrier()
+
+    @torch.no_grad()
+    def load_weights(self, path):
+        """model.load_weights(file, by_name=True) (:362): every variable the file names is copied; the others stay"""
+        with np.load(path) as z:
+            for k, v in self._named().items():
+                if k in z.files:
+                    v.copy_(torch.from_numpy(z[k]).to(v.device))
 
     def config_summary(self):
         for k, v in self.config.get_dict().items():
             self.print(f"{k} : {v}")
 
     def save_config_file(self):                      # :187-190
-        os.makedirs(os.path.dirname(self.config.config_path), exist_ok=True)
-        save_config_to_file(self.config.get_dict(), self.config.config_path + ".json")
-        save_config_to_file(self.config_input, self.config.config_path + "_input.json")
+        if _rank() == 0:
+            os.makedirs(os.path.dirname(self.config.config_path), exist_ok=True)
+            save_config_to_file(self.config.get_dict(), self.config.config_path + ".json")
+            save_config_to_file(self.config_input, self.config.config_path + "_input.json")
+        _barrier()
 
     # ---- data ----
-    def load_data(self, trainset: Iterable = None, valset: Iterable = None):
+    def load_data(self, trainset: Iterable = None, valset: Iterable = None, testset: Iterable = None,
+                  splits=("training", "validation")):
         """:207-218.  Iterables of batches in the reference's input format are used as they are (SyntheticZinc ...);
         otherwise the scheme's dataset is opened from ``config.dataset_path`` through egt_amd.data (a PackedStore
         ``.npz`` or, where h5py exists, the reference's ``.h5``): record maps, excluded features, per-epoch shuffle,
-        padded batches of ``batch_size``; under DP every rank takes its contiguous slice of each global batch."""
+        padded batches of ``batch_size``.  Under DP every rank takes its contiguous slice of each GLOBAL batch: the
+        shuffle seed is rank 0's (broadcast), so the slices partition the batch; the validation / test splits are sharded
+        the same way and their metric sums are all-reduced in ``evaluate`` (every rank sees the same logs, hence the same
+        save-best / reduce-LR / stop decisions)."""
         if trainset is None:
             from .data import dataset_for_scheme
             c = self.config
             if not os.path.exists(c.dataset_path):
                 raise FileNotFoundError(f"dataset_path {c.dataset_path!r} does not exist (pass iterables of batches, "
                                         "or a PackedStore .npz / reference .h5)")
-            self.dataset = dataset_for_scheme(self.SCHEME, c.dataset_path, max_shuffle_len=c.max_shuffle_len,
-                                              num_svd_features=c.num_svd_features, use_svd=c.use_svd)
-            shard = None
-            if c.distributed and torch.distributed.is_available() and torch.distributed.is_initialized():
+            shard, seed = None, int(np.random.SeedSequence().entropy % (2 ** 62))
+            if c.distributed and _dist_on():
                 shard = (torch.distributed.get_rank(), torch.distributed.get_world_size())
-            trainset, valset = self.dataset.get_batched_data(c.batch_size, shard=shard)
-        self.trainset, self.valset = trainset, valset
+                box = [seed]
+                torch.distributed.broadcast_object_list(box, src=0)     # every rank shuffles like rank 0
+                seed = box[0]
+            kw = dict(num_eig_features=c.num_eig_features, use_eig=c.use_eig) if "use_eig" in c else \
+                dict(num_svd_features=c.num_svd_features, use_svd=c.use_svd)
+            self.dataset = dataset_for_scheme(self.SCHEME, c.dataset_path, max_shuffle_len=c.max_shuffle_len,
+                                              splits=tuple(splits), seed=seed, **kw)
+            bs = {sp: c.batch_size * (1 if sp == "training" else c.prediction_bmult if len(splits) > 2 else 1) for sp in splits}
+            out = self.dataset.get_batched_data(bs, shard=shard)
+            out = out if isinstance(out, tuple) else (out,)
+            trainset, valset, testset = (list(out) + [None, None])[:3]
+        self.trainset, self.valset, self.testset = trainset, valset, testset
 
     # ---- one step / one epoch ----
     def _batch(self, b):
@@ -421,10 +515,20 @@ class ZincSVDScheme:
         mv = (lambda t: t.to(dev)) if dev is not None else (lambda t: t)
         return mv(b["node_features"]), mv(b["feature_matrix"]), mv(b["graph_matrix"]), mv(b["target"])
 
+    def _pe(self, b):
+        """the positional-encoding inputs of the batch (singular_vectors / eigen_vectors), when the scheme uses them"""
+        c, dev = self.config, self.device
+        out = {}
+        if c.get("use_svd") and "singular_vectors" in b:
+            out["singular_vectors"] = b["singular_vectors"] if dev is None else b["singular_vectors"].to(dev)
+        if c.get("use_eig") and "eigen_vectors" in b:
+            out["eigen_vectors"] = b["eigen_vectors"] if dev is None else b["eigen_vectors"].to(dev)
+        return out
+
     def batch_loss(self, batch):
         """(loss, metric sums) of one batch: scheme-specific"""
         nf, fm, adj, tgt = self._batch(batch)
-        y = self.model(nf, fm, adj)
+        y = self.model(nf, fm, adj, **self._pe(batch))
         return self.loss_fn(y, tgt), dict(mae=((y - tgt).abs().sum().detach(), tgt.numel()))
 
     def _graphed_loss(self, batch):
@@ -445,8 +549,13 @@ class ZincSVDScheme:
                 loss, _ = self.batch_loss(static)
                 loss.backward()
                 return loss.detach()
+            # one graph (with its own static batch and activation pool) per padded geometry: keep the most recently used
+            # MAX_GRAPHS of them -- a dataset padded to each batch's longest graph meets dozens of geometries
+            while len(self._graphs) >= self.MAX_GRAPHS:
+                self._graphs.pop(next(iter(self._graphs)))
             ent = self._graphs[key] = (static, GraphedStep(fn, self._seeds, warmup=1))
         else:
+            self._graphs[key] = self._graphs.pop(key)          # most recently used last
             for k, v in moved.items():
                 ent[0][k].copy_(v, non_blocking=True)
         loss = ent[1].replay()
@@ -471,7 +580,10 @@ class ZincSVDScheme:
             loss, _ = self.batch_loss(batch)
             loss.backward()
         if self.flat is not None:
-            self.flat.all_reduce(average=True)
+            # a rank's slice of a short last batch can be one graph smaller than another's: weight by graph counts, so that
+            # every graph of the GLOBAL batch counts once (the Keras loss is a mean over the global batch)
+            lc, gc = batch.get("_local_count"), batch.get("_global_count")
+            self.flat.all_reduce(average=True, local_count=lc, global_count=gc)
         if c.gradient_clipval is not None:           # Keras clipvalue: elementwise clip of every gradient
             torch.nn.utils.clip_grad_value_(self.params, c.gradient_clipval)
         self.optimizer.step()
@@ -489,6 +601,12 @@ class ZincSVDScheme:
             _, ms = self.batch_loss(b)
             for k, (sm, cnt) in ms.items():
                 a = acc.setdefault(k, [0.0, 0.0]); a[0] += float(sm); a[1] += float(cnt)
+        if self.config.distributed and _dist_on():    # the split is sharded: sums and counts of all ranks
+            keys = sorted(self.get_metrics()) if not acc else sorted(acc)
+            t = torch.tensor([x for k in keys for x in acc.get(k, [0.0, 0.0])], dtype=torch.float64,
+                             device=self.device if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.all_reduce(t)
+            acc = {k: [float(t[2 * i]), float(t[2 * i + 1])] for i, k in enumerate(keys)}
         return {k: v[0] / max(v[1], 1e-30) for k, v in acc.items()}
 
     def train_model(self):                           # model.fit (:293-302) with the callbacks' behaviour inlined
@@ -525,6 +643,62 @@ class ZincSVDScheme:
         self.save_weights(self.config.saved_model_path + ".npz")
         self.print("DONE!!!")
 
+    # ---- evaluation drivers (training_base.py:330-392) ----
+    def get_latest_save_file(self):                  # :330-344 (.npz instead of .h5)
+        import re
+        from pathlib import Path
+        pattern = re.compile(r"(?<=epoch)[0-9]+")
+        cur_epoch, cur_file = 0, ""
+        for fp in Path(self.config.saved_model_path).parent.glob("*.npz"):
+            m = pattern.search(fp.name)
+            e = 0 if m is None else int(m.group())
+            if e > cur_epoch:
+                cur_epoch, cur_file = e, str(fp)
+        self.config["weight_file"] = cur_file
+
+    def prepare_for_test(self, trainset=None, valset=None, testset=None):   # :347-363
+        self.config_summary()
+        self.load_data(trainset, valset, testset, splits=("training", "validation", "test"))
+        self.load_model()
+        c = self.config
+        if c.weight_file == ":":
+            self.get_latest_save_file()
+        if c.weight_file == "":
+            c["weight_file"] = c.saved_model_path + ".npz"
+        if c.weight_file == "-":
+            self.load_state()
+            self.print("LOADED TRAINING STATE FOR PREDICTIONS!")
+        else:
+            self.load_weights(c.weight_file)
+            self.print(f'LOADED WEIGHT FILE "{c.weight_file}" FOR PREDICTIONS!')
+
+    def _report(self, split, lines):
+        """print + append to predictions/<split>_evals.txt (schemes/zinc/_eval.py:10-12); rank 0 writes"""
+        for ln in lines:
+            self.print(ln)
+        if _rank() == 0:
+            with open(os.path.join(self.config.predictions_path, f"{split}_evals.txt"), "a") as fl:
+                for ln in lines:
+                    print(ln, file=fl)
+
+    def do_evaluations_on_split(self, split):        # ZINCEval (schemes/zinc/_eval.py:6-12)
+        mae = self.evaluate(getattr(self, split))["mae"]
+        self._report(split, [f"{split} MAE = {mae:0.5f}"])
+
+    def do_evaluations(self, trainset=None, valset=None, testset=None):   # :383-392
+        self.eval_flag = True
+        self.prepare_for_test(trainset, valset, testset)
+        if _rank() == 0:
+            os.makedirs(self.config.predictions_path, exist_ok=True)
+        _barrier()
+        for split in ("trainset", "valset", "testset"):
+            if getattr(self, split, None) is None:
+                continue
+            self.print("=" * 40)
+            self.print(f"Evaluation on {split}.")
+            self.do_evaluations_on_split(split)
+            self.print("")
+
     def execute_training(self, trainset=None, valset=None):   # :305-312
         self.config_summary()
         self.save_config_file()
@@ -544,10 +718,7 @@ class PatternSVDScheme(ZincSVDScheme):
         if self.model_factory is not None:
             return self.model_factory(self.get_model_config())
         from .model import PatternDCTransformer
-        mc = self.get_model_config()
-        if mc["use_svd"]:
-            raise NotImplementedError("use_svd=True needs the data pipeline's SVD features; the shipped PATTERN configs set use_svd=false")
-        return PatternDCTransformer(**mc)
+        return PatternDCTransformer(**self.get_model_config())
 
     def get_loss(self):
         from .model import weighted_sparse_xent_loss
@@ -561,7 +732,7 @@ class PatternSVDScheme(ZincSVDScheme):
         dev = self.device
         mv = (lambda t: t.to(dev)) if dev is not None else (lambda t: t)
         nf, adj, tgt = mv(batch["node_features"]), mv(batch["graph_matrix"]), mv(batch["target"])
-        out = self.model(nf, adj, return_mask=True)
+        out = self.model(nf, adj, return_mask=True, **self._pe(batch))
         logits, mask = out
         if getattr(self, "_class_w", None) is None or self._class_w.device != logits.device:
             self._class_w = class_weights_from_sizes(self.config.class_sizes, device=logits.device)   # once: a host -> device copy cannot be captured
@@ -573,6 +744,70 @@ class PatternSVDScheme(ZincSVDScheme):
         logp = torch.log_softmax(logits.detach(), -1).gather(-1, tgt.clamp(min=0).long()[..., None])[..., 0]
         xs = (-(logp) * w[tgt.clamp(min=0).long()] * m).sum()
         return loss, dict(xent=(xs, m.sum()), acc=(hit, m.sum()))
+
+
+    @torch.no_grad()
+    def do_evaluations_on_split(self, split):        # SBMPATTERNEval (schemes/pattern/_eval.py:9-111)
+        from sklearn.metrics import recall_score, accuracy_score, confusion_matrix
+        self.model.eval()
+        dev = self.device
+        mv = (lambda t: t.to(dev)) if dev is not None else (lambda t: t)
+        targs, preds = [], []
+        for b in getattr(self, split):
+            nf = mv(b["node_features"])
+            logits = self.model(nf, mv(b["graph_matrix"]), **self._pe(b))
+            keep = (nf >= 0).reshape(-1).cpu().numpy()                                   # collate_fn: node_features >= 0
+            targs.append(b["target"].reshape(-1).cpu().numpy()[keep])
+            preds.append(torch.softmax(logits, -1)[..., 1].reshape(-1).cpu().numpy()[keep])
+        targs, preds = np.concatenate(targs), np.concatenate(preds)
+        if self.config.distributed and _dist_on():   # the split is sharded: gather every rank's nodes (strategy ... concat, :62-78)
+            box = [None] * torch.distributed.get_world_size()
+            torch.distributed.all_gather_object(box, (targs, preds))
+            targs, preds = np.concatenate([x[0] for x in box]), np.concatenate([x[1] for x in box])
+        pred_class = np.round(preds).astype(targs.dtype)
+        classes = (np.eye(targs.max() + 1)[targs]).sum(0)
+
+        def accuracy_sbm(t, c):                      # :11-26 (mean per-class recall over the classes of the confusion matrix)
+            cm = confusion_matrix(t, c).astype(np.float32)
+            per = [cm[r, r] / float((t == r).sum()) if (t == r).sum() else 0.0 for r in range(cm.shape[0])]
+            return float(np.sum(per)) / cm.shape[0]
+
+        def weighted_log_loss(t, pr, w, eps=1 - 9):  # :34-39 (the reference's eps literal, 1-9, is kept: it clips to [-8, 9])
+            sw = w[t.astype("int64")].astype("float32")
+            t = np.clip(t.astype("float32"), 0., 1.)
+            pr = np.clip(pr.astype("float32"), eps, 1. - eps)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                return float((-(t * np.log(pr) + (1 - t) * np.log(1 - pr)) * sw).mean())
+
+        cs = np.array(self.config.class_sizes, dtype="float32")
+        cw = (cs.sum() - cs) / (cs.sum() - cs).sum()
+        macro_rec = recall_score(targs, pred_class, average="macro")
+        micro_rec = recall_score(targs, pred_class, average="micro")
+        acc = accuracy_score(targs, pred_class)
+        wacc = accuracy_sbm(targs, pred_class)
+        ll = weighted_log_loss(targs, preds, cw)
+        self.print(f"Binned classes:{classes}")
+        self._report(split, [f"Accuracy = {acc:0.5%}", f"Micro Recall = {macro_rec:0.5%}", f"Macro Recall = {micro_rec:0.5%}",
+                             f"Weighted Accuracy = {wacc:0.5%}", f"Log loss:{ll:0.5f}"])   # (labels as the reference prints them)
+
+
+class ZincEigScheme(ZincSVDScheme):
+    """lib.training.schemes.zinc.eig.SCHEME (ZincDCEig): the ZINC model with Laplacian-eigenvector positional encodings
+    (EigenDataset + DCEigTransformer; BASELINE config 1, configs/main/zinc/100k/egt_epe.json)."""
+    SCHEME = "zinc.eig"
+
+
+class PatternEigScheme(PatternSVDScheme):
+    """lib.training.schemes.pattern.eig.SCHEME (SBMPDCEig): PATTERN with eigenvector encodings; metric acc
+    (schemes/pattern/eig.py:48-50), monitors at the base default."""
+    SCHEME = "pattern.eig"
+
+    def get_metrics(self):
+        return ["acc"]
+
+    def batch_loss(self, batch):
+        loss, ms = super().batch_loss(batch)
+        return loss, dict(acc=ms["acc"], loss=(loss.detach() * ms["acc"][1], ms["acc"][1]))
 
 
 class SyntheticPattern:
@@ -613,10 +848,7 @@ class Cifar10SVDScheme(ZincSVDScheme):
         if self.model_factory is not None:
             return self.model_factory(self.get_model_config())
         from .model import Cifar10DCTransformer
-        mc = self.get_model_config()
-        if mc["use_svd"]:
-            raise NotImplementedError("use_svd=True needs the data pipeline's SVD features; the shipped CIFAR10 configs set use_svd=false")
-        return Cifar10DCTransformer(**mc)
+        return Cifar10DCTransformer(**self.get_model_config())
 
     def get_loss(self):
         from .model import sparse_xent_loss
@@ -627,10 +859,15 @@ class Cifar10SVDScheme(ZincSVDScheme):
 
     def batch_loss(self, batch):
         nf, fm, adj, tgt = self._batch(batch)
-        logits = self.model(nf, fm, adj)
+        logits = self.model(nf, fm, adj, **self._pe(batch))
         loss = self.loss_fn(logits, tgt)
         n = tgt.numel()
         return loss, dict(xent=(loss.detach() * n, n), acc=((logits.argmax(-1) == tgt).sum().detach(), n))
+
+
+    def do_evaluations_on_split(self, split):        # schemes/cifar10/svd.py:45-53
+        v = self.evaluate(getattr(self, split))
+        self._report(split, [f"{split} accuracy = {v['acc']:0.5%}", f"{split} crossentropy = {v['xent']:0.6f}"])
 
 
 class SyntheticCifar10:
@@ -675,25 +912,49 @@ def import_scheme(name: str):
         return ZincSVDScheme
     if name == "pattern.svd":
         return PatternSVDScheme
+    if name == "zinc.eig":
+        return ZincEigScheme
+    if name == "pattern.eig":
+        return PatternEigScheme
     raise KeyError(f"scheme {name!r}: only {SCHEMES} are built")
 
 
 def main(argv=None):
-    """python -m egt_amd.training cfg.json [--synthetic N_GRAPHS]  (run_training.py:5-10).  The scheme's dataset is read
-    from config.dataset_path when that file exists (egt_amd.data); otherwise, or with --synthetic, the run trains on
-    synthetic graphs in the reference's batch format."""
+    """python -m egt_amd.training cfg.json [--synthetic N_GRAPHS] [--evaluate]   (run_training.py:5-10, do_evaluations.py).
+    The scheme's dataset is read from config.dataset_path when that file exists (egt_amd.data); otherwise, or with
+    --synthetic, the run trains on synthetic graphs in the reference's batch format (with the scheme's positional
+    encodings computed by the data pipeline's functions).  Under `torchrun` (WORLD_SIZE > 1) the process group is created
+    here: one process per GPU, RCCL ('nccl')."""
     argv = list(sys.argv[1:] if argv is None else argv)
     if not argv:
-        raise SystemExit("usage: python -m egt_amd.training cfg.json [--synthetic N_GRAPHS]")
+        raise SystemExit("usage: python -m egt_amd.training cfg.json [--synthetic N_GRAPHS] [--evaluate]")
     config = read_config_from_file(argv[0])
-    scheme = import_scheme(config["scheme"])(config, device=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not _dist_on():
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+    scheme = import_scheme(config["scheme"])(config, device=torch.device("cuda", local))
+    evaluate = "--evaluate" in argv
     if "--synthetic" not in argv and os.path.exists(scheme.config.dataset_path):
-        scheme.execute_training()
+        scheme.do_evaluations() if evaluate else scheme.execute_training()
         return
     n_graphs = int(argv[argv.index("--synthetic") + 1]) if "--synthetic" in argv else 2048
-    bs = scheme.config.batch_size
-    data = {"pattern.svd": SyntheticPattern, "cifar10.svd": SyntheticCifar10}.get(config["scheme"], SyntheticZinc)
-    scheme.execute_training(data(n_graphs, bs, seed=1), data(max(bs, n_graphs // 8), bs, seed=2))
+    c = scheme.config
+    bs = c.batch_size
+    name = config["scheme"].split(".")[0]
+    data = {"pattern": SyntheticPattern, "cifar10": SyntheticCifar10}.get(name, SyntheticZinc)
+
+    def mk(n, seed):
+        d = data(n, bs, seed=seed)
+        if c.get("use_eig"):
+            return WithPositional(d, "eig", c.num_eig_features)
+        if c.get("use_svd"):
+            return WithPositional(d, "svd", c.num_svd_features)
+        return d
+    if evaluate:
+        scheme.do_evaluations(mk(n_graphs, 1), mk(max(bs, n_graphs // 8), 2), mk(max(bs, n_graphs // 8), 3))
+    else:
+        scheme.execute_training(mk(n_graphs, 1), mk(max(bs, n_graphs // 8), 2))
 
 
 if __name__ == "__main__":

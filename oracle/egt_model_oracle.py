@@ -70,6 +70,56 @@ def mlp_out(x, params, n_layers, activation="elu"):
     return x
 
 
+def random_neg_signs(uniform):
+    """RandomNeg / RandomNegEig (lib/base/xformer_layers/misc.py:53-94): signs = where(U < 0.5, -1, 1) with U of shape
+    [B,1,F,1] (SVD: one sign per graph and singular pair, shared by the nodes and by U / V) or [B,1,F] (eigenvectors)."""
+    return torch.where(uniform < 0.5, -torch.ones_like(uniform), torch.ones_like(uniform))
+
+
+def svd_embedding(singular_vectors, p, cfg, signs=None):
+    """SVDFeatModel.create_embedding('svdf') (lib/models/graph_model_base.py:322-349): the first sel_svd_features singular
+    pairs [B,N,sf,2] (zero-padded to model_width//2 when there is no transform), the training-time sign flip (signs
+    [B,1,F,1] or None), U and V parts concatenated along the feature axis, Dense 'svd_emb' when transform_svd."""
+    mw, sf = cfg["model_width"], cfg["sel_svd_features"]
+    v = singular_vectors[:, :, :sf, :]
+    if not cfg.get("transform_svd", False):
+        pad = max(0, mw // 2 - sf)
+        v = torch.nn.functional.pad(v, (0, 0, 0, pad))
+    if signs is not None:
+        v = v * signs.to(v.dtype)
+    v = torch.cat(torch.unbind(v, dim=-1), dim=-1)                                            # tf.concat(tf.unstack(v, axis=-1), axis=-1)
+    if cfg.get("transform_svd", False):
+        v = O.dense(v, p["svd_emb.kernel"], p["svd_emb.bias"])
+    return v
+
+
+def eig_embedding(eigen_vectors, p, cfg, signs=None):
+    """EigFeatModel.create_embedding('eigf') (lib/models/graph_model_base.py:388-414): the first sel_eig_features Laplacian
+    eigenvectors [B,N,sf], zero-padded to model_width when there is no transform, sign flip (signs [B,1,F]), Dense 'eig_emb'
+    when transform_eig."""
+    mw, sf = cfg["model_width"], cfg["sel_eig_features"]
+    v = eigen_vectors[:, :, :sf]
+    if not cfg.get("transform_eig", False):
+        v = torch.nn.functional.pad(v, (0, max(0, mw - sf)))
+    if signs is not None:
+        v = v * signs.to(v.dtype)
+    if cfg.get("transform_eig", False):
+        v = O.dense(v, p["eig_emb.kernel"], p["eig_emb.bias"])
+    return v
+
+
+def add_positional(h, p, cfg, pe):
+    """combine_node_embeddings (graph_xformer_model_base.py:390-399): Add()([node embedding, PE embedding]).  pe: dict with
+    'singular_vectors' / 'eigen_vectors' and optional 'svd_signs' / 'eig_signs' (the injected sample of the sign flip)."""
+    if pe is None:
+        return h
+    if cfg.get("use_svd", False):
+        h = h + svd_embedding(pe["singular_vectors"].to(h.dtype), p, cfg, pe.get("svd_signs"))
+    if cfg.get("use_eig", False):
+        h = h + eig_embedding(pe["eigen_vectors"].to(h.dtype), p, cfg, pe.get("eig_signs"))
+    return h
+
+
 def init_zinc_params(cfg, *, dtype=torch.float32, generator=None, randomize=True):
     """Keras defaults: Embedding 'uniform' U(-0.05, 0.05), Dense glorot_uniform / zeros, LN ones / zeros.
     randomize: perturb biases and LN parameters so the parity tests exercise them."""
@@ -92,6 +142,10 @@ def init_zinc_params(cfg, *, dtype=torch.float32, generator=None, randomize=True
         "node_norm_final.gamma": vec(Dh, 1.0), "node_norm_final.beta": vec(Dh, 0.0),
         "edge_norm_final.gamma": vec(De, 1.0), "edge_norm_final.beta": vec(De, 0.0),
     }
+    if cfg.get("use_svd") and cfg.get("transform_svd"):
+        p["svd_emb.kernel"] = glorot(2 * cfg["sel_svd_features"], Dh); p["svd_emb.bias"] = vec(Dh, 0.0)
+    if cfg.get("use_eig") and cfg.get("transform_eig"):
+        p["eig_emb.kernel"] = glorot(cfg["sel_eig_features"], Dh); p["eig_emb.bias"] = vec(Dh, 0.0)
     if cfg.get("float_node_features"):   # CIFAR10 / MNIST: Dense embeddings of real-valued features (cifar10/dc.py:66-73)
         p["node_emb.kernel"] = glorot(cfg["float_node_features"], Dh); p["node_emb.bias"] = vec(Dh, 0.0)
         p["edge_emb.kernel"] = glorot(cfg.get("float_edge_features", 1), De); p["edge_emb.bias"] = vec(De, 0.0)
@@ -140,13 +194,14 @@ def weighted_sparse_xent_loss(logits, y_true, mask, class_weights):
     return per.sum() / per.numel()
 
 
-def pattern_forward(node_features, graph_matrix, p, cfg, rand_masks=None):
+def pattern_forward(node_features, graph_matrix, p, cfg, rand_masks=None, pe=None):
     """lib/models/sbm_pattern/dc.py:14-61 (DCSVDTransformer, use_svd false): node embedding, adjacency hop embedding as the
     only edge channel input, the layer loop, final norm, per-node mlp_out + Dense(num_target_labels) -> logits [B,N,C]."""
     H, Ly = cfg.get("num_heads", 8), cfg["model_height"]
     act = cfg.get("activation", "elu")
     dt = p["node_emb.embeddings"].dtype
     h = neg1_masked_embedding(node_features, p["node_emb.embeddings"])                      # sbm_pattern/dc.py:45-48
+    h = add_positional(h, p, cfg, pe)
     hops = stack_hops(graph_matrix.to(dt), cfg["upto_hop"], cfg.get("clip_hops", True))
     e = O.dense(hops, p["adj_emb.kernel"], p["adj_emb.bias"])                               # graph_model_base.py:97-127
     mask = O.node_mask_from_features(node_features)
@@ -171,7 +226,7 @@ def keras_masking(x, mask_value=-1.0):
     return x * keep[..., None].to(x.dtype), keep
 
 
-def cifar10_forward(node_features, feature_matrix, graph_matrix, p, cfg, rand_masks=None):
+def cifar10_forward(node_features, feature_matrix, graph_matrix, p, cfg, rand_masks=None, pe=None):
     """lib/models/cifar10/dc.py:14-122 (DCSVDTransformer, use_svd false; scheme cifar10.svd): real-valued node features
     [B,N,5] and edge features [B,N,N,1] through Masking(-1) + Dense (:66-73), the adjacency hop embedding added to the
     edge embedding, the layer loop, final norm, masked GlobalAveragePooling1D, mlp_out, Dense(num_target_labels) -> logits."""
@@ -181,6 +236,7 @@ def cifar10_forward(node_features, feature_matrix, graph_matrix, p, cfg, rand_ma
     mv = cfg.get("mask_value", -1.0)
     xn, mask = keras_masking(node_features.to(dt), mv)
     h = O.dense(xn, p["node_emb.kernel"], p["node_emb.bias"])                                # :68-70
+    h = add_positional(h, p, cfg, pe)
     xe, _ = keras_masking(feature_matrix.to(dt), mv)
     e = O.dense(xe, p["edge_emb.kernel"], p["edge_emb.bias"])                                # :71-73
     hops = stack_hops(graph_matrix.to(dt), cfg["upto_hop"], cfg.get("clip_hops", True))
@@ -205,10 +261,11 @@ def sparse_xent_loss(logits, y_true):
     return -torch.log_softmax(logits, dim=-1).gather(-1, y_true.long()[..., None])[..., 0].mean()
 
 
-def zinc_embeddings(node_features, feature_matrix, graph_matrix, p, cfg):
+def zinc_embeddings(node_features, feature_matrix, graph_matrix, p, cfg, pe=None):
     """get_embeddings (graph_xformer_model_base.py:411-431) for the zinc.svd model without SVD features."""
     dt = p["node_emb.embeddings"].dtype
     h = neg1_masked_embedding(node_features, p["node_emb.embeddings"])                      # zinc/dc.py:66-69
+    h = add_positional(h, p, cfg, pe)                                                       # node_emb_add
     e_fm = neg1_masked_embedding(feature_matrix, p["fm_emb.embeddings"])                    # zinc/dc.py:70-73
     hops = stack_hops(graph_matrix.to(dt), cfg["upto_hop"], cfg.get("clip_hops", True))     # graph_model_base.py:101-119
     e_adj = O.dense(hops, p["adj_emb.kernel"], p["adj_emb.bias"])                           # :125-126
@@ -217,12 +274,12 @@ def zinc_embeddings(node_features, feature_matrix, graph_matrix, p, cfg):
     return h, e, mask
 
 
-def zinc_forward(node_features, feature_matrix, graph_matrix, p, cfg, rand_masks=None, return_hidden=False):
+def zinc_forward(node_features, feature_matrix, graph_matrix, p, cfg, rand_masks=None, return_hidden=False, pe=None):
     """DCSVDTransformer.call -> prediction [B, num_targets] (graph_xformer_model_base.py:447-466).
     rand_masks: per-layer injected random attention masks (training with random_mask_prob > 0)."""
     H, Ly = cfg.get("num_heads", 8), cfg["model_height"]
     act = cfg.get("activation", "elu")
-    h, e, mask = zinc_embeddings(node_features, feature_matrix, graph_matrix, p, cfg)
+    h, e, mask = zinc_embeddings(node_features, feature_matrix, graph_matrix, p, cfg, pe)
     for ii in range(Ly):
         bp = {k[len(f"layer{ii}."):]: v for k, v in p.items()
               if k.startswith(f"layer{ii}.") and ".ffn_" not in k}

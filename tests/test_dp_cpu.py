@@ -180,3 +180,62 @@ def test_uneven_shards_weighted_allreduce_gloo_ws2():
     for r in res:
         assert r[2] < 1e-12, f"weighted all-reduce is not the global mean: {r[2]}"
         assert r[3] > 1e-6, "control: the unweighted mean should differ for uneven shards"
+
+
+# ---------------------------------------------------------------- the scheme driver under DP ---
+class _StubModel(torch.nn.Module):
+    """CPU stand-in with ZincDCTransformer's call convention"""
+    def __init__(self, mc):
+        super().__init__()
+        self.emb = torch.nn.Parameter(torch.zeros(29))
+        self.b = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, nf, fm, adj):
+        return (self.emb[(nf + 1).long()] * (nf >= 0)).sum(1, keepdim=True) + self.b + adj.sum((1, 2))[:, None] / 40
+
+
+def _worker_scheme(rank, world, port, q, store, save_path):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from egt_amd import training as T
+        # 50 training graphs, global batch 16 -> 3 full batches + a remainder of 2 graphs (1 per rank);
+        # 11 validation graphs, batch 16 -> one short batch split 6 / 5
+        cfg = dict(scheme="zinc.svd", model_name="dp", num_epochs=3, initial_lr=0.05, batch_size=16, use_svd=False,
+                   distributed=True, dataset_path=store, save_path=save_path, rlr_patience=1)
+        logs = []
+        s = T.ZincSVDScheme(cfg, model_factory=_StubModel, print_fn=logs.append)
+        s.execute_training()
+        steps = s.state.global_step
+        q.put((rank, steps, [round(h["val_mae"], 10) for h in s.history], [h["lr"] for h in s.history],
+               s.model.emb.detach().tolist(), s.state.save_best_epoch))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_scheme_driver_two_ranks_stay_in_lockstep(tmp_path):
+    """execute_training under a 2-rank gloo group: the ranks shuffle alike (rank 0's seed), shard every global batch, take the
+    SAME number of steps, see the same validation logs (all-reduced sums) and therefore the same lr / best-epoch decisions,
+    end with identical weights, and only rank 0 writes the checkpoint / weight files."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_data import _store
+    store = _store(tmp_path, n_train=50, n_val=11)
+    save = str(tmp_path / "run")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_scheme, args=(r, 2, port, q, store, save)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    r0, r1 = res
+    assert r0[1] == r1[1] == 3 * 4                    # 4 steps per epoch on both ranks (the 2-graph remainder is kept: 1 + 1)
+    assert r0[2] == r1[2] and r0[3] == r1[3] and r0[5] == r1[5]
+    assert r0[4] == r1[4] and any(abs(x) > 0 for x in r0[4])
+    assert os.path.exists(os.path.join(save, "checkpoint", "ckpt.pt")) and not os.path.exists(os.path.join(save, "checkpoint", "ckpt.pt.tmp"))
+    assert os.path.exists(os.path.join(save, "saved", "dp.npz"))

@@ -124,8 +124,8 @@ def test_training_loop_checkpoint_resume_and_snapshots(tmp_path):
     assert "emb" in w.files
     with pytest.raises(KeyError):
         T.import_scheme("tsp.svd")
-    with pytest.raises(NotImplementedError):
-        T.ZincSVDScheme(dict(cfg, use_svd=True)).get_model()
+    with pytest.raises(NotImplementedError):    # a reference key that would change the model is refused, never ignored
+        T.ZincSVDScheme(dict(cfg, l2_reg=0.1)).get_model()
 
 
 def test_pattern_scheme_config_and_synthetic_batches():
@@ -262,3 +262,84 @@ def test_use_hipgraph_reproduces_the_eager_training_run(which, tmp_path, gpu, eg
     assert r.history[-1]["loss"] < r.history[0]["loss"] and r._seeds is not None
     with pytest.raises(ValueError, match="use_hipgraph needs"):
         cls(dict(kw, use_hipgraph=True, use_svd=False), device=None).load_model()
+
+
+# ------------------------------------------------------------------ positional encodings, eig schemes, evaluations ---
+def test_zinc_eig_scheme_loads_baseline_config_1_unchanged():
+    """configs/main/zinc/100k/egt_epe.json (BASELINE config 1, scheme zinc.eig) key for key"""
+    cfg = {"scheme": "zinc.eig", "distributed": True, "batch_size": 128, "initial_lr": 0.0005, "num_epochs": 600, "rlr_factor": 0.5,
+           "rlr_patience": 20, "min_lr_factor": 0.01, "model_width": 48, "edge_width": 48, "model_height": 4, "num_heads": 8,
+           "ffn_multiplier": 2.0, "use_eig": True, "sel_eig_features": 8, "random_mask_prob": 0.1, "upto_hop": 16,
+           "model_name": "egt_epe_100k"}
+    s = T.import_scheme("zinc.eig")(cfg, model_factory=lambda mc: mc)
+    c = s.config
+    assert c.dataset_name == "zinc" and c.num_eig_features == 20 and c.sel_eig_features == 8 and c.use_eig is True
+    assert c.cache_dir == "data_cache/ZINC/eig_20" and c.save_best_monitor == "val_mae" and "use_svd" not in c
+    mc = s.get_model()
+    assert mc["use_eig"] is True and mc["transform_eig"] is False and mc["random_neg"] is True       # scheme_base.py:178-190
+    assert mc["num_eig_features"] == 20 and mc["sel_eig_features"] == 8 and "use_svd" not in mc
+    with pytest.raises(KeyError):                # an SVD key is unknown to an eig scheme (TrainingBase.__init__, :28-30)
+        T.import_scheme("zinc.eig")(dict(cfg, use_svd=True))
+    # the SVD config of BASELINE config 3 (configs/main/cifar10/100k/egt_spe.json)
+    spe = {"scheme": "cifar10.svd", "distributed": True, "batch_size": 128, "initial_lr": 0.0005, "num_epochs": 200, "rlr_factor": 0.5,
+           "rlr_patience": 10, "min_lr_factor": 0.01, "model_width": 64, "edge_width": 8, "model_height": 4, "num_heads": 8,
+           "ffn_multiplier": 2.0, "use_svd": True, "sel_svd_features": 8, "random_neg": True, "random_mask_prob": 0.1,
+           "upto_hop": 16, "model_name": "egt_spe_100k"}
+    mc = T.import_scheme("cifar10.svd")(spe, model_factory=lambda mc: mc).get_model()
+    assert mc["use_svd"] is True and mc["transform_svd"] is True and mc["random_neg"] is True and mc["sel_svd_features"] == 8
+    pe = T.import_scheme("pattern.eig")(dict(scheme="pattern.eig"), model_factory=lambda mc: mc)
+    assert pe.config.save_best_monitor == "val_loss" and pe.get_metrics() == ["acc"] and pe.config.class_sizes == [979220, 209900]
+
+
+def test_synthetic_positional_features():
+    base = T.SyntheticZinc(8, 4, seed=3)
+    b = next(iter(T.WithPositional(base, "eig", 6)))
+    ev, adj, nf = b["eigen_vectors"], b["graph_matrix"], b["node_features"]
+    assert ev.shape == (4, adj.shape[1], 6) and ev.dtype == torch.float32
+    n = int((nf[0] >= 0).sum())
+    assert torch.all(ev[0, n:] == 0)                                   # padding rows are zero
+    A = adj[0, :n, :n].double().numpy()
+    d = np.maximum(A.sum(1), 1.0)
+    Lm = np.eye(n) - A / np.sqrt(np.outer(d, d))
+    v = ev[0, :n, 0].double().numpy()
+    lam = v @ Lm @ v / (v @ v)
+    assert np.allclose(Lm @ v, lam * v, atol=1e-4)                     # an eigenvector of the normalised Laplacian
+    sv = next(iter(T.WithPositional(base, "svd", 5)))["singular_vectors"]
+    assert sv.shape == (4, adj.shape[1], 5, 2)
+    U, V = sv[0, :n, :, 0].double(), sv[0, :n, :, 1].double()
+    S5 = torch.linalg.svdvals(adj[0, :n, :n].double())[:5]
+    assert torch.allclose(adj[0, :n, :n].double() @ V, U * S5, atol=1e-4)   # columns are sqrt(S) u, sqrt(S) v:  A v' = S u'
+
+
+class _StubPE(torch.nn.Module):
+    """a CPU stand-in with the model's call convention, using the eigenvector input"""
+    def __init__(self, mc):
+        super().__init__()
+        self.emb = torch.nn.Parameter(torch.zeros(29)); self.w = torch.nn.Parameter(torch.zeros(mc["sel_eig_features"]))
+        self.sf = mc["sel_eig_features"]
+
+    def forward(self, nf, fm, adj, eigen_vectors=None):
+        assert eigen_vectors is not None and eigen_vectors.shape[-1] >= self.sf
+        pe = (eigen_vectors[..., :self.sf].abs() * self.w).sum((1, 2))[:, None]
+        return (self.emb[(nf + 1).long()] * (nf >= 0)).sum(1, keepdim=True) + pe + adj.sum((1, 2))[:, None] / 40
+
+
+def test_eig_scheme_trains_and_writes_eval_reports(tmp_path):
+    cfg = dict(scheme="zinc.eig", model_name="e", num_epochs=2, initial_lr=0.02, batch_size=32, save_path=str(tmp_path / "run"))
+    mk = lambda n, seed: T.WithPositional(T.SyntheticZinc(n, 32, seed=seed), "eig", 20)
+    logs = []
+    s = T.ZincEigScheme(cfg, model_factory=_StubPE, print_fn=logs.append)
+    s.execute_training(mk(96, 1), mk(32, 2))
+    assert s.state.current_epoch == 2 and os.path.exists(tmp_path / "run" / "saved" / "e.npz")
+    # do_evaluations (training_base.py:383-392): latest epochNNNN weight file, three splits, predictions/<split>_evals.txt
+    s2 = T.ZincEigScheme(cfg, model_factory=_StubPE, print_fn=logs.append)
+    s2.do_evaluations(mk(96, 1), mk(32, 2), mk(32, 3))
+    assert "epoch" in s2.config.weight_file and s2.config.weight_file.endswith(".npz")
+    for split in ("trainset", "valset", "testset"):
+        txt = open(tmp_path / "run" / "predictions" / f"{split}_evals.txt").read()
+        assert txt.startswith(f"{split} MAE = ") and len(txt.strip().split("\n")) == 1
+    assert torch.equal(s2.model.emb, torch.from_numpy(np.load(s2.config.weight_file)["emb"]))
+
+
+def test_hipgraph_cache_is_bounded():
+    assert T.ZincSVDScheme.MAX_GRAPHS <= 32
