@@ -53,6 +53,7 @@ struct BlockArgs {
   float *dh, *de;
   float *g_ne_g, *g_ne_b, *g_Wg, *g_bg, *g_We, *g_be, *g_nm_g, *g_nm_b, *g_Wqkv, *g_bqkv, *g_Wo,
       *g_bo, *g_Wr, *g_br;
+  unsigned* dbg2;   // EGT_BWD_TIMING builds: the node-side prologue's phase cycles (last member: the other translation units ignore it)
 };
 
 template <int DE>

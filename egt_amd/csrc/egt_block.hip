@@ -1184,6 +1184,14 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
 template <int DE, int MM>
 __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   seed_from_device(a);
+#ifdef EGT_BWD_TIMING
+  const unsigned t_entry = (unsigned)__builtin_amdgcn_s_memtime();
+  unsigned t_pre[4] = {0, 0, 0, 0};
+  unsigned t_np[6] = {0, 0, 0, 0, 0, 0};
+#define PSTAMP(i) t_pre[i] = (unsigned)__builtin_amdgcn_s_memtime()
+#else
+#define PSTAMP(i) do {} while (0)
+#endif
   constexpr bool SPLIT = MM == EGT_MM_BF16X3;
   constexpr int NS = (Geo<DE>::TILES + 1) / 2;   // 16x16x32 steps over the channel axis
   (void)SPLIT; (void)NS;
@@ -1226,10 +1234,16 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
     if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
     *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
   }
+  PSTAMP(0);
   if (a.pro) {
     __syncthreads();
+#ifdef EGT_BWD_TIMING
+    bwd_node_prologue<DE>(a, sm, qd, b, l_begin, wg, t_np);
+#else
     bwd_node_prologue<DE>(a, sm, qd, b, l_begin, wg);
+#endif
   }
+  PSTAMP(1);
   // weight slabs: element (t, lane, u)
   if constexpr (MM != 0) {
     // bf16 operands.  wsA / wsB: [step s][part hi|lo][lane][8 slots], slot i <-> channel 16 (2s + (i >> 2)) + 4q + (i & 3);
@@ -1277,6 +1291,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   for (int t = 0; t < G::TILES; ++t) { accT[t] = (v4f){0.f, 0.f, 0.f, 0.f}; accR[t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
   float ssum[4] = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();   // the prologue's scratch (= the tile area) is dead from here: DMA may land in it
+  PSTAMP(2);
 
 #ifdef EGT_BWD_TIMING
   unsigned tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1557,7 +1572,10 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   if (a.dbg && lane == 0) {
     unsigned* o = a.dbg + ((size_t)wg * 4 + wave) * 16;
     for (int i = 0; i < 12; ++i) o[i] = tacc[i];
-    o[12] = tstart - a.dbg_t0;      // (unused: absolute start)
+    o[12] = tstart - t_entry;       // kernel entry -> loop start
+    o[14] = t_pre[0] - t_entry; o[15] = t_pre[1] - t_pre[0]; o[11] = t_pre[2] - t_pre[1];
+    for (int i = 0; i < 6; ++i) if (t_np[i] == 0) t_np[i] = i ? t_np[i - 1] : t_pre[0];   // (phases a launch did not run)
+    if (a.dbg2) { unsigned* o2 = a.dbg2 + ((size_t)wg * 4 + wave) * 8; o2[0] = t_np[0] - t_pre[0]; for (int i = 1; i < 6; ++i) o2[i] = t_np[i] - t_np[i - 1]; o2[6] = t_pre[1] - t_np[5]; }
     o[13] = tlast - tstart;         // loop total
   }
 #endif
@@ -2149,6 +2167,8 @@ static void bind_common(const egt_block_desc* d, BlockArgs& a, const void* h, co
 #ifdef EGT_BWD_TIMING
 // measurement builds only: per-phase cycle sums of k_block_bwd_v5 (synchronises after every launch)
 static unsigned* g_bt_dev = nullptr;
+static unsigned* g_bt_dev2 = nullptr;
+static double g_bt2_sum[8];
 static int g_bt_n = 0;
 static double g_bt_sum[16];
 static long g_bt_launch = 0, g_bt_waves = 0;
@@ -2159,24 +2179,34 @@ static void bwd_timing_report() {
   fprintf(stderr, "[egt] k_block_bwd_v5 phase cycles per wave (mean over %ld waves, %ld launches):\n", g_bt_waves, g_bt_launch);
   for (int i = 0; i < 14; ++i)
     if (nm[i][0] != '-') fprintf(stderr, "    %-26s %10.0f  (%.1f %%)\n", nm[i], g_bt_sum[i] / g_bt_waves, 100.0 * g_bt_sum[i] / g_bt_sum[13]);
+  fprintf(stderr, "    entry -> loop %10.0f = staging %.0f + node-side prologue %.0f + weight slabs / c2 / sync %.0f\n", g_bt_sum[12] / g_bt_waves,
+          g_bt_sum[14] / g_bt_waves, g_bt_sum[15] / g_bt_waves, g_bt_sum[11] / g_bt_waves);
+  fprintf(stderr, "    node-side prologue: sync+issue loads %.0f | first round trip %.0f | LN fwd + 48 MFMA %.0f | dQKV out + sync + LN bwd + col sums %.0f | wo/va + sync %.0f | 16 MFMA + delta partials %.0f | dbo + sync + delta %.0f\n",
+          g_bt2_sum[0] / g_bt_waves, g_bt2_sum[1] / g_bt_waves, g_bt2_sum[2] / g_bt_waves, g_bt2_sum[3] / g_bt_waves, g_bt2_sum[4] / g_bt_waves, g_bt2_sum[5] / g_bt_waves, g_bt2_sum[6] / g_bt_waves);
 }
 static void bwd_timing_attach(BlockArgs& a, int nwg) {
   if (g_bt_n < nwg) {
     if (g_bt_dev) (void)hipFree(g_bt_dev);
     (void)hipMalloc(&g_bt_dev, (size_t)nwg * 64 * sizeof(unsigned));
+    (void)hipMalloc(&g_bt_dev2, (size_t)nwg * 32 * sizeof(unsigned));
+    (void)hipMemset(g_bt_dev2, 0, (size_t)nwg * 32 * sizeof(unsigned));
     if (!g_bt_n) atexit(bwd_timing_report);
     g_bt_n = nwg;
   }
-  a.dbg = g_bt_dev; a.dbg_t0 = 0;
+  a.dbg = g_bt_dev; a.dbg_t0 = 0; a.dbg2 = g_bt_dev2;
 }
 static void bwd_timing_collect(const BlockArgs& a, int nwg, hipStream_t st) {
   (void)hipStreamSynchronize(st);
   static std::vector<unsigned> h;
   h.resize((size_t)nwg * 64);
   (void)hipMemcpy(h.data(), a.dbg, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
+  static std::vector<unsigned> h2;
+  h2.resize((size_t)nwg * 32);
+  (void)hipMemcpy(h2.data(), a.dbg2, h2.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
   if (++g_bt_launch <= 20) return;   // warm-up launches
   for (size_t w = 0; w < (size_t)nwg * 4; ++w) {
-    for (int i = 0; i < 14; ++i) g_bt_sum[i] += h[w * 16 + i];
+    for (int i = 0; i < 16; ++i) g_bt_sum[i] += h[w * 16 + i];
+    for (int i = 0; i < 8; ++i) g_bt2_sum[i] += h2[w * 8 + i];
     ++g_bt_waves;
   }
 }

@@ -205,8 +205,13 @@ __device__ __forceinline__ void fwd_node_epilogue(const BlockArgs& a, float* sm,
 // HOIST: the loads of the dV_att step (Wo columns, V_att rows) are issued with the first round of global loads instead of
 // after the dh' rows exist: one memory round trip on the kernel's critical path instead of two (costs 20 registers across
 // the first part)
+#ifdef EGT_BWD_TIMING
+#define NSTAMP(i) do { if (tp) tp[i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NSTAMP(i) do {} while (0)
+#endif
 template <int DE, bool HOIST = false>
-__device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg) {
+__device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg, unsigned* tp = nullptr) {
   constexpr int LD = 68, LD3 = 196;
   float* dqs = ws;                   // dQKV  [16][196]
   float* xs = dqs + 16 * LD3;        // xhat  [16][68]
@@ -266,7 +271,9 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
 #pragma unroll
     for (int s = 0; s < 12; ++s)
       wq[s] = *reinterpret_cast<const float4*>(a.up_Wqkv + (size_t)(16 * wave + p) * 192 + 48 * q + 4 * s);
+    NSTAMP(0);
     *reinterpret_cast<float4*>(xs + (t >> 4) * LD + (t & 15) * 4) = hx;
+    NSTAMP(1);
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int i = t + u * 256, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
@@ -303,6 +310,7 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
 #pragma unroll
       for (int r = 0; r < 4; ++r) dls[(4 * q + r) * LD + 16 * wave + p] = acc[r];
     }
+    NSTAMP(2);
     for (int i = t; i < nv * 48; i += 256) {   // dQKV rows out (natural channel order) for k_node_wgrads
       const int r = i / 48, c4 = (i % 48) * 4;
       *reinterpret_cast<float4*>(a.up_dqkv_sv + (row0 + r) * 192 + c4) = *reinterpret_cast<const float4*>(dqs + r * LD3 + c4);
@@ -353,8 +361,10 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
         make_float4(ok ? dv4.x : 0.f, ok ? dv4.y : 0.f, ok ? dv4.z : 0.f, ok ? dv4.w : 0.f);
   }
   // ---- dV_att = dh'.Wo^T for i tile = wave (contraction order c = 16 q + s), delta, dbo ----
+  NSTAMP(3);
   if (!HOIST) load_wo_va();
   __syncthreads();
+  NSTAMP(4);
   {
     v4f acc = {0.f, 0.f, 0.f, 0.f};
     const float* ar = dhs + p * LD + 16 * q;
@@ -377,6 +387,7 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
       if (p < 8) dlp[(wave * 16 + row) * 8 + p] = pr;
     }
   }
+  NSTAMP(5);
   if (t < 64) {   // dbo: column sums of dh'
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
