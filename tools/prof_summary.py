@@ -66,13 +66,42 @@ def main():
     out.append("")
     out.append("Reading the counters (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 "
                "FETCH_SIZE reports half of the bytes of a wide coalesced streaming read, so it is doubled.\n")
-    pt = {"_source": f"profiles/{name}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, workload zinc500k_n64)"}
-    for k, v in traffic.items():
-        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            pt[k] = int(round((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024))
-            out.append(f"- `{k}`: HBM traffic per launch = 2 x {v['FETCH_SIZE']:.4g} KB + {v['WRITE_SIZE']:.4g} KB = {pt[k] / 1e6:.1f} MB")
+    ptf = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    try:
+        pt = json.load(open(ptf))
+        if "k_block_bwd" in pt:            # round-2 layout (one workload): move it under its workload key
+            pt = {"zinc500k_n64": {k: v for k, v in pt.items() if not k.startswith("_")}}
+    except Exception:  # noqa: BLE001
+        pt = {}
+    pt["_source"] = (f"profiles/{name}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per workload; "
+                     "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024)")
+
+    def put(wl, tr):
+        for k, v in tr.items():
+            if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                pt.setdefault(wl, {})[k] = int(round((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024))
+                out.append(f"- `{wl}` `{k}`: HBM traffic per launch = 2 x {v['FETCH_SIZE']:.4g} KB + {v['WRITE_SIZE']:.4g} KB = {pt[wl][k] / 1e6:.1f} MB")
+    put("zinc500k_n64", traffic)
+    for wl in ("cifar10_n150", "pattern500k_n120_b128"):
+        tr = {}
+        for sub in (f"pmc_fetch_{wl}", f"pmc_write_{wl}"):
+            db = db_of(os.path.join(src, sub))
+            if not db:
+                continue
+            for kn, cn, c, v, d in db.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
+                                              "where kernel_name like '%k_block_%' or kernel_name like '%k_narrow_%' group by kernel_name, counter_name").fetchall():
+                out.append(f"| {wl}: {short(kn)} | {cn} | {c} | {v:.4g} | {d:.0f} |")
+                key = "k_block_bwd" if ("k_block_bwd" in kn or "k_narrow_bwd" in kn) else "k_block_fwd" if ("k_block_fwd" in kn or "k_narrow_fwd" in kn) else None
+                if key and cn in ("FETCH_SIZE", "WRITE_SIZE"):
+                    tr.setdefault(key, {})[cn] = v
+        put(wl, tr)
+        try:
+            line = open(os.path.join(src, f"bench_{wl}.json")).read().strip().splitlines()[-1]
+            out.append(f"\n`python bench.py --workload {wl}`:\n\n```json\n{line}\n```\n")
+        except Exception:  # noqa: BLE001
+            pass
     if len(pt) > 1:
-        json.dump(pt, open(os.path.join(REPO, "profiles", "pmc_traffic.json"), "w"), indent=1)
+        json.dump(pt, open(ptf, "w"), indent=1)
     try:
         log = open(os.path.join(src, "pytest_gpu.log")).read().strip().splitlines()
         open(os.path.join(REPO, "profiles", f"{name}_pytest_gpu.log"), "w").write("\n".join(log[-12:]) + "\n")

@@ -17,5 +17,12 @@ timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kt -o r -- $BENCH > $OUT/be
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o r -- $BENCH > /dev/null 2>> $OUT/bench_err.log
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o r -- $BENCH > /dev/null 2>> $OUT/bench_err.log
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_sq -o r -- $BENCH > /dev/null 2>> $OUT/bench_err.log
+# HBM traffic of the De = 8 workloads (BASELINE configs 3 and 4 at B = 128) for roofline.traffic of their bench lines
+for WL in cifar10_n150 pattern500k_n120_b128; do
+  B2="python bench.py --workload $WL --steps 6 --warmup 2 --no-cpu-baseline --no-prof --no-graph-leg"
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_$WL -o r -- $B2 > /dev/null 2>> $OUT/bench_err.log
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_$WL -o r -- $B2 > /dev/null 2>> $OUT/bench_err.log
+  timeout 300 python bench.py --workload $WL --no-cpu-baseline > $OUT/bench_$WL.json 2>> $OUT/bench_err.log
+done
 find $OUT -name "*.db" | head
 tail -3 $OUT/pytest_gpu.log
