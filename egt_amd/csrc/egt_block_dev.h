@@ -210,42 +210,41 @@ __device__ __forceinline__ void fwd_node_epilogue(const BlockArgs& a, float* sm,
 #else
 #define NSTAMP(i) do {} while (0)
 #endif
-template <int DE, bool HOIST = false>
-__device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg, unsigned* tp = nullptr) {
-  constexpr int LD = 68, LD3 = 196;
-  float* dqs = ws;                   // dQKV  [16][196]
-  float* xs = dqs + 16 * LD3;        // xhat  [16][68]
-  float* dls = xs + 16 * LD;         // d h_ln
-  float* dhs = dls + 16 * LD;        // dh'
-  float* rs = dhs + 16 * LD;         // rstd  [16]
-  float* dlp = rs + 16;              // delta partials [4][16][8]
-  static_assert(16 * LD3 + 3 * 16 * LD + 16 + 4 * 16 * 8 <= BWD_PRO_WS, "prologue scratch");
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int p = lane & 15, q = lane >> 4, N = a.N;
-  const size_t row0 = (size_t)b * N + l_begin;
-  const int lnrow = 4 * wave + q;    // LayerNorm mapping: row 4*wave + q, columns p + 16 i
-  // ragged last row group (N not a multiple of 16): loads are clamped to the graph's last row, the
-  // rows past the end contribute zeros to every sum and are never stored
-  const int nv = min(16, N - l_begin);                     // valid rows of this workgroup
-  auto rc = [&](int r) { return row0 + min(r, nv - 1); };   // clamped global row
-  float4 wo[4];
-  float va[4];
-  auto load_wo_va = [&]() {
+// The prologue's global inputs live in this register set between `bwd_prologue_load` (every load of the step issued: ONE
+// memory round trip, which a kernel can overlap with its other start-up requests) and `bwd_prologue_compute`.
+struct BwdProRegs { float4 hx, gq[3], wq[12], wo[4]; float dho[4], gmm[4], va[4]; };
+
+#define BWD_PRO_COMMON()                                                                                   \
+  constexpr int LD = 68, LD3 = 196;                                                                        \
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);                 \
+  const int p = lane & 15, q = lane >> 4, N = a.N;                                                         \
+  const size_t row0 = (size_t)b * N + l_begin;                                                             \
+  const int lnrow = 4 * wave + q;    /* LayerNorm mapping: row 4*wave + q, columns p + 16 i */            \
+  /* ragged last row group (N not a multiple of 16): loads are clamped to the graph's last row, the rows  \
+     past the end contribute zeros to every sum and are never stored */                                   \
+  const int nv = min(16, N - l_begin);                     /* valid rows of this workgroup */             \
+  auto rc = [&](int r) { return row0 + min(r, nv - 1); };   /* clamped global row */                       \
+  (void)LD; (void)LD3; (void)lnrow; (void)p; (void)q; (void)rc
+
+// Wo columns and V_att rows of the dV_att step
+template <int DE>
+__device__ __forceinline__ void bwd_prologue_load_wo_va(const BlockArgs& a, int b, int l_begin, BwdProRegs& R) {
+  BWD_PRO_COMMON();
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wo[s] = *reinterpret_cast<const float4*>(a.Wo + (size_t)(16 * wave + p) * 64 + 16 * q + 4 * s);
+  for (int s = 0; s < 4; ++s) R.wo[s] = *reinterpret_cast<const float4*>(a.Wo + (size_t)(16 * wave + p) * 64 + 16 * q + 4 * s);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) va[r] = a.v_att[rc(4 * q + r) * 64 + 16 * wave + p];
-  };
-  if (HOIST) load_wo_va();
-  if (a.pro == 2) {
+  for (int r = 0; r < 4; ++r) R.va[r] = a.v_att[rc(4 * q + r) * 64 + 16 * wave + p];
+}
+// [pro == 2] every global input of the dQKV / d h_ln / LayerNorm-backward step
+template <int DE>
+__device__ __forceinline__ void bwd_prologue_load_main(const BlockArgs& a, int b, int l_begin, BwdProRegs& R) {
+  BWD_PRO_COMMON();
     // ---- every global input in one round trip ----
-    float4 hx = *reinterpret_cast<const float4*>(a.up_h + rc(t >> 4) * 64 + (t & 15) * 4);
-    float4 gq[3];
-    float dho[4], gmm[4];
+    R.hx = *reinterpret_cast<const float4*>(a.up_h + rc(t >> 4) * 64 + (t & 15) * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      dho[i] = a.up_dh_out[rc(lnrow) * 64 + p + 16 * i];
-      gmm[i] = a.up_nm_g[p + 16 * i];
+      R.dho[i] = a.up_dh_out[rc(lnrow) * 64 + p + 16 * i];
+      R.gmm[i] = a.up_nm_g[p + 16 * i];
     }
     // partial counts of the layer above (same geometry, same kernels): dQ partials per row = a.NQP (key tiles for the
     // MFMA-tile kernels, 1 for k_narrow_bwd, which reduces its key tiles itself), dK/dV partials per key = a.NLR (row groups)
@@ -264,13 +263,29 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
         acc4.x += w.x; acc4.y += w.y; acc4.z += w.z; acc4.w += w.w;
       }
       if (r >= nv) acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      gq[u] = acc4;
+      R.gq[u] = acc4;
     }
     // B operand of d h_ln = dQKV.Wqkv^T: Wqkv[kk = 16 wave + p][48 q .. 48 q + 47] (contraction order c = 48 q + s)
-    float4 wq[12];
 #pragma unroll
     for (int s = 0; s < 12; ++s)
-      wq[s] = *reinterpret_cast<const float4*>(a.up_Wqkv + (size_t)(16 * wave + p) * 192 + 48 * q + 4 * s);
+      R.wq[s] = *reinterpret_cast<const float4*>(a.up_Wqkv + (size_t)(16 * wave + p) * 192 + 48 * q + 4 * s);
+}
+
+template <int DE>
+__device__ __forceinline__ void bwd_prologue_compute(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg, BwdProRegs& R,
+                                                     bool wo_loaded, unsigned* tp = nullptr) {
+  float* dqs = ws;                   // dQKV  [16][196]
+  float* xs = dqs + 16 * 196;        // xhat  [16][68]
+  float* dls = xs + 16 * 68;         // d h_ln
+  float* dhs = dls + 16 * 68;        // dh'
+  float* rs = dhs + 16 * 68;         // rstd  [16]
+  float* dlp = rs + 16;              // delta partials [4][16][8]
+  static_assert(16 * 196 + 3 * 16 * 68 + 16 + 4 * 16 * 8 <= BWD_PRO_WS, "prologue scratch");
+  BWD_PRO_COMMON();
+  float4 (&wo)[4] = R.wo;
+  float (&va)[4] = R.va;
+  if (a.pro == 2) {
+    float4 (&gq)[3] = R.gq; float4 (&wq)[12] = R.wq; float (&dho)[4] = R.dho; float (&gmm)[4] = R.gmm; const float4 hx = R.hx;
     NSTAMP(0);
     *reinterpret_cast<float4*>(xs + (t >> 4) * LD + (t & 15) * 4) = hx;
     NSTAMP(1);
@@ -362,7 +377,7 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
   }
   // ---- dV_att = dh'.Wo^T for i tile = wave (contraction order c = 16 q + s), delta, dbo ----
   NSTAMP(3);
-  if (!HOIST) load_wo_va();
+  if (!wo_loaded) bwd_prologue_load_wo_va<DE>(a, b, l_begin, R);
   __syncthreads();
   NSTAMP(4);
   {
@@ -400,5 +415,13 @@ __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws,
     qd[row * QD_LD + 128 + hd * 4 + 2] = (dlp[(0 * 16 + row) * 8 + hd] + dlp[(1 * 16 + row) * 8 + hd]) +
                                          (dlp[(2 * 16 + row) * 8 + hd] + dlp[(3 * 16 + row) * 8 + hd]);
   }
+}
+
+template <int DE, bool HOIST = false>
+__device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg, unsigned* tp = nullptr) {
+  BwdProRegs R;
+  if (HOIST) bwd_prologue_load_wo_va<DE>(a, b, l_begin, R);
+  if (a.pro == 2) bwd_prologue_load_main<DE>(a, b, l_begin, R);
+  bwd_prologue_compute<DE>(a, ws, qd, b, l_begin, wg, R, HOIST, tp);
 }
 
