@@ -6,7 +6,7 @@
 template <int DE>
 __device__ __forceinline__ unsigned dma_lane_offset(int lane) {
   // byte offset (inside the tile) of the 16-byte piece lane `lane` fetches for chunk 0
-  if (DE == 64) return (unsigned)((lane >> 4) * 256 + (((lane & 15) ^ (lane >> 4)) << 4));
+  if (DE == 64) return (unsigned)((lane >> 4) * 256 + (((lane & 15) ^ swz<64>(lane >> 4)) << 4));
   return (unsigned)(lane * 16);
 }
 // one 16-pair tile HBM -> LDS; `lds` = byte address of the tile in LDS (wave-uniform), `src` = the
@@ -18,7 +18,13 @@ __device__ __forceinline__ void tile_dma(unsigned lds, const float* src, unsigne
   constexpr int NI = Geo<DE>::NF4 / 64;
   static_assert(Geo<DE>::NF4 % 64 == 0 && NI >= 1 && NI <= 4, "whole 1 KiB chunks");
   unsigned keep, t;
+  // chunk i = rows 4i .. 4i+3: +1024 i bytes and the slot bits flipped by swz(4 i) (an XOR: chunk 0's offsets are < 1024)
+#ifdef EGT_SWZ_NEW
+  constexpr unsigned X1 = DE == 64 ? 1024u + (2u << 4) : 1024u, X2 = DE == 64 ? 2048u + (4u << 4) : 2048u, X3 = DE == 64 ? 3072u + (6u << 4) : 3072u;
+#else
   constexpr unsigned X = DE == 64 ? 1088u : 1024u;
+  constexpr unsigned X1 = X, X2 = 2 * X, X3 = 3 * X;
+#endif
   if (NI == 4)
     asm volatile(
         "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
@@ -26,20 +32,20 @@ __device__ __forceinline__ void tile_dma(unsigned lds, const float* src, unsigne
         "v_xor_b32 %1, %6, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
         "v_xor_b32 %1, %7, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
         "s_mov_b32 m0, %0"
-        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X), "i"(2 * X), "i"(3 * X) : "memory", "scc");
+        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X1), "i"(X2), "i"(X3) : "memory", "scc");
   else if (NI == 3)
     asm volatile(
         "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
         "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
         "v_xor_b32 %1, %6, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
         "s_mov_b32 m0, %0"
-        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X), "i"(2 * X) : "memory", "scc");
+        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X1), "i"(X2) : "memory", "scc");
   else if (NI == 2)
     asm volatile(
         "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
         "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
         "s_mov_b32 m0, %0"
-        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X) : "memory", "scc");
+        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X1) : "memory", "scc");
   else
     asm volatile(
         "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
@@ -56,7 +62,11 @@ __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :
 // replace 32 per-(s,t) address registers:  floats = [64 q + 4 ((p >> 2) ^ q) + (p & 3)] + 256 s + 16 (t ^ s)
 template <int DE>
 __device__ __forceinline__ float elem_read_st(const float* lane_base, const float* tl, int p, int q, int s, int t) {
+#ifdef EGT_SWZ_NEW
+  if (DE == 64) return elem_read<DE>(tl, q + 4 * s, 16 * t + p);   // (experiment: address formed per read)
+#else
   if (DE == 64) return lane_base[256 * s + 16 * (t ^ s)];
+#endif
   return elem_read<DE>(tl, q + 4 * s, 16 * t + p);
 }
 
