@@ -333,6 +333,8 @@ def main():
             raise SystemExit(f"bench.py: egt_dp world {comm.world} != {world}")
 
     w = dict(WORKLOADS[args.workload])
+    if os.environ.get("EGT_BENCH_B"):   # experiments only (batch sweeps): the line's config carries the overridden B
+        w["B"] = int(os.environ["EGT_BENCH_B"])
     if args.layers > 0:
         w["Ly"] = args.layers
     if args.edge_dtype:

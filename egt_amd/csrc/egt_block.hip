@@ -1967,8 +1967,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
 // forces them to 0 (a stray variable can then not drop gradient phases) and says so once.
 struct EgtBlockEnv {
   bool no_xcd_remap, no_kvl, no_epilogue, no_fwd_r4, no_bwd_r4, bwd_v2, no_bwd_ragged, no_bwd_prologue;
-  bool no_narrow_fwd, no_narrow_bwd;   // De = 8: fall back from the VALU pair kernels (egt_narrow.hip) to r4 / v4r
-  bool narrow_bwd_all;                 // EGT_NARROW_BWD=1: k_narrow_bwd for fp32 edge tensors too (default: bf16 only, where it is faster)
+  bool no_narrow_fwd, no_narrow_bwd;   // De = 8: fall back from the De = 8 pair kernels (egt_narrow.hip) to r4 / v4r
   int fwd_ablate, bwd_ablate, bwd_pf;
   int bwd_v5;   // LDS-DMA staged backward (default on; EGT_BWD_V5=0 selects k_block_bwd_v4)
   int bwd_v6;   // tile-pair backward k_block_bwd_v6 (EGT_BWD_V6=0 falls back to v5)
@@ -2000,7 +1999,6 @@ static const EgtBlockEnv& block_env() {
     v.no_fwd_r4 = env_flag_raw("EGT_NO_FWD_R4");
     v.no_narrow_fwd = env_flag_raw("EGT_NO_NARROW_FWD") || env_flag_raw("EGT_NO_NARROW");
     v.no_narrow_bwd = env_flag_raw("EGT_NO_NARROW_BWD") || env_flag_raw("EGT_NO_NARROW");
-    v.narrow_bwd_all = env_flag_raw("EGT_NARROW_BWD");
     v.no_bwd_r4 = env_flag_raw("EGT_NO_BWD_R4");
     v.bwd_v2 = env_flag_raw("EGT_BWD_V2");
     v.no_bwd_ragged = env_flag_raw("EGT_NO_BWD_RAGGED");
@@ -2354,9 +2352,9 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
 #define V4_VARIANT(ML_, PF_, BF_) do { if (full) V4_VARIANT_R(ML_, PF_, BF_, false); else V4_VARIANT_R(ML_, 0, BF_, true); } while (0)
       const int pf = block_env().bwd_pf;   // two resident waves hide the HBM latency; prefetch registers only spill
       if constexpr (DE == 8) {
-        // VALU pair kernel (egt_narrow.hip), ragged N included.  Measured against v4r (two waves per SIMD both): bf16 edge
-        // tensors 373 vs 396 us at config 3, fp32 385 vs 364 us -- so bf16 by default, fp32 on request
-        if (narrow_r && !block_env().no_narrow_bwd && (a.bf16 || block_env().narrow_bwd_all)) {
+        // De = 8 pair kernel (egt_narrow.hip: k_narrow_bwd_m, three workgroups per CU), ragged N included.  Measured at config 3
+        // against v4r / the round-2 quad-lane kernel (two waves per SIMD both): bf16 edge tensors 226 vs 314 us, fp32 243 vs 320 us
+        if (narrow_r && !block_env().no_narrow_bwd) {
           egt_narrow_launch_bwd(a, L.nwg_bwd, st);
           goto pair_done;
         }

@@ -1,21 +1,20 @@
-// Narrow edge channels (De = 8, H = 8, d <= 8: BASELINE configs 3 and 4) -- pair kernels on the VALU.
+// Narrow edge channels (De = 8, H = 8, d <= 8: BASELINE configs 3 and 4) -- their own pair kernels.
 //
 // A De = 8 pair row is 32 bytes: the 16-pair MFMA tile of the wide kernels is 512 B, its per-tile
 // skeleton and dependent phases (LDS round trip -> LayerNorm over lanes -> MFMA chain -> ...) cost more
-// than the arithmetic, and at ~240 VGPRs only two waves per SIMD hide the HBM latency of tiles that
-// small (measured: 1.1 TB/s, 0.08 of the roof).  These kernels turn the mapping around:
-//   lane = 4 p + q,  p = query row (forward) / key (backward) of the wave's 16,  q = head pair AND channel pair:
-//   lane (p, q) owns heads 2q, 2q+1 and edge channels 2q, 2q+1 of ONE pair per step, all in registers.
-//   * e arrives by plain 8-byte global loads straight into the lane (no LDS tile, no transposition);
-//   * LayerNorm statistics, the projection sums and dense_edge_r are 2-channel / 2-head partial sums in
-//     the lane, combined across the QUAD with DPP quad_perm adds.  Each lane evaluates the partial sums in
-//     quad-RELATIVE order (slot g of lane q holds the partial for quarter g ^ q), so the combine is three
-//     DPP adds per value and needs no selects;
-//   * the forward keeps a whole query row's softmax state in the lane (online softmax over the key loop:
-//     no cross-lane reduction at all); the four waves of a workgroup split the key range and merge their
-//     (max, sum, A.V) triples once at the end;
-//   * forward: 168 VGPRs = three waves per SIMD, 20 KB of LDS per workgroup (K / V travel through a 2 KB wave-private
-//     LDS chunk four keys at a time); backward: ~250 VGPRs = two waves per SIMD (K/V-side accumulators + weights), 77 KB of LDS.
+// than the arithmetic, and at ~240 VGPRs only two waves per SIMD hide the latency of tiles that small
+// (measured: 1.1 TB/s, 0.08 of the roof).  These kernels keep a pair's whole working set in FOUR lanes:
+// lane (p, q) owns heads 2q, 2q+1 and edge channels 2q, 2q+1 of ONE pair per step; e arrives by plain 8-byte global
+// loads straight into the lane (no LDS tile, no transposition).
+//   k_narrow_fwd: lane = 4 p + q, p = query row.  LayerNorm statistics, the projection sums and dense_edge_r are
+//     2-channel / 2-head partial sums in the lane, combined across the QUAD with DPP quad_perm adds (each lane evaluates
+//     the partial sums in quad-RELATIVE order -- slot g of lane q holds the partial for quarter g ^ q -- so a combine is
+//     three DPP adds per value and needs no selects); the lane keeps a whole query row's softmax state (online softmax
+//     over the key loop: no cross-lane reduction at all); the four waves of a workgroup split the key range and merge
+//     their (max, sum, A.V) triples once at the end.  168 VGPRs = three waves per SIMD, 20 KB of LDS per workgroup.
+//   k_narrow_bwd: lane = p + 16 q, p = key -- the operand layout of v_mfma_f32_16x16x4_f32, so the channel contractions
+//     of a step run on the matrix core from the lane's own registers (see the kernel's header).  168 VGPRs, 47 KB of LDS:
+//     three workgroups per CU.
 // Same BlockArgs, saved tensors, partial-buffer layouts, mask order / RNG stream and node-side epilogue /
 // prologue as the wide kernels: the dispatch in launch_fwd / launch_bwd is the only difference.
 // Own translation unit: built with -fno-slp-vectorize (build.py) -- hipcc otherwise pairs the scalar adds into
@@ -359,41 +358,48 @@ static_assert(4 * NRW_KV_CHUNK + 4 * NRW_KB <= NRW_FWD_AREA, "key-loop buffers f
 // a.epi must already hold the epilogue the geometry allows (launch_fwd decides)
 void egt_narrow_launch_fwd(BlockArgs& a, hipStream_t st) {
   const dim3 grid(a.B * ((a.N + 15) / 16)), block(256);
-  const size_t lds = ((size_t)NRW_FWD_AREA + 16 * QS_LD + 80) * 4;
+  static const size_t pad = getenv("EGT_NRW_LDS_PAD") ? (size_t)atoi(getenv("EGT_NRW_LDS_PAD")) : 0;   // occupancy experiments only
+  const size_t lds = ((size_t)NRW_FWD_AREA + 16 * QS_LD + 80) * 4 + pad;
   const int full = NRW_F_GATED | NRW_F_CLIP;
   const int feat = ((a.flags & EGT_BF_GATE) ? NRW_F_GATED : 0) | ((a.flags & EGT_BF_CLIP) ? NRW_F_CLIP : 0);
-#define NRW_FWD(BF_, FEAT_) EGT_LAUNCH("k_block_fwd", (k_narrow_fwd<BF_, FEAT_>), grid, block, lds, st, a)
+#define NRW_FWD(BF_, FEAT_) do { if (pad) EGT_MAX_LDS_ONCE(k_narrow_fwd<BF_, FEAT_>); EGT_LAUNCH("k_block_fwd", (k_narrow_fwd<BF_, FEAT_>), grid, block, lds, st, a); } while (0)
   if (a.bf16) { if (feat == full) NRW_FWD(true, NRW_F_GATED | NRW_F_CLIP); else NRW_FWD(true, NRW_F_RUNTIME); }
   else { if (feat == full) NRW_FWD(false, NRW_F_GATED | NRW_F_CLIP); else NRW_FWD(false, NRW_F_RUNTIME); }
 #undef NRW_FWD
 }
 
-// ----------------------------------------------------------------------------------- backward ---
-// Workgroup = (graph b, 16 query rows), 4 waves; a wave owns key tiles w, w+4, ... and walks the rows:
-// lane (p, q) = key m0 + p, heads / channels 2q, 2q+1.  K / V of the key and the dK / dV accumulators live in
-// the lane; e and de' arrive by coalesced 8-byte loads two rows ahead; Q / dV_att / softmax statistics of the
-// rows are the staged qd rows of the wide kernels (same node-side prologue).
-//   per step (16 pairs): LayerNorm + projections (recompute), dH_ext = de'.Wr^T, softmax / gate backward,
-//   d ehat = Wp.dGE, LayerNorm backward -- 2-channel / 2-head partial sums combined across the quad by DPP adds
-//   (quad-relative weight tables in LDS);
-//   weight gradients: [xhat | de']^T . dGE and [xhat | de']^T . [H_hat | 1] over the step's 16 pairs on the matrix
-//   pipe (operands through three lane-linear LDS tiles: 8 MFMAs per step, two accumulators);
-//   dQ: dA of eight rows is parked in LDS, then dQ[row][k] = sum_keys dA . K is 32 MFMAs per eight rows
-//   (no cross-lane reduction on the VALU); dK / dV partials as in the wide kernels.
-// Partial buffers (dqp, dkvp, epart) have the wide kernels' layouts.
-#define NRW_NB 6                                     // rows per dQ batch (16 rows = 6 + 6 + 4)
-#define NRW_BWD_WAVE (NRW_NB * 128 + 3 * 256 + 1024)   // floats per wave: dA of NRW_NB rows [NB][64][2] | XS | DG | HH [16][16] each | K tile [16 keys][64]
-#define NRW_TAB_WP 0                     // [4 q][36]: wp[c][g][r]
-#define NRW_TAB_WR 144                   // [4 q][20]: wr[c][g][j]
-#define NRW_TAB_WD 224                   // [4 q][36]: wd[r][g][c]
-#define NRW_TAB_FLOATS 368
+// ------------------------------------------------------------------- backward, matrix-core lanes ---
+// k_narrow_bwd: workgroup = (graph b, 16 query rows), 4 waves; a wave owns key tiles (w, w+4, ... or a balanced contiguous range
+// of (tile, row) steps) and walks the rows.  Lane roles:  lane = p + 16 q,  p = key of the tile, q = head pair AND channel pair -- the
+// operand / result layout of v_mfma_f32_16x16x4_f32 (B operand: lane (n = p, k = q); result: lane (n = p) holds rows 4q..4q+3).
+// The pair-local channel contractions move to the matrix core with the lane's own registers as B operand and NO exchange:
+//   [gates | E] = Wp'^T.xhat + c   (2 MFMA, accumulator preloaded with c),   dH_ext = Wr.de' (2),   d ehat = Wp'.dGE (4);
+// their weights are 12 A-operand registers (the quad-lane layout of the forward needs 48 registers or 12 LDS reads per step here:
+// the round-2 backward in that layout ran at two workgroups per CU, 314 us at config 3 against 226 us for this kernel).
+// LayerNorm sums run over the four 16-lane rows (v_permlane16_swap / v_permlane32_swap); dQ of a row is the 16-lane
+// transposed reduction of the wide kernels (reduce16_keep_own: p IS the DPP row) -- no dA batch, no LDS.  K and V of the
+// lane's key live in LDS ([u][lane][4]: conflict-free 16-byte reads); the three operand tiles of the weight-gradient products
+// share ONE buffer (DS operations of a wave execute in order).  ~12 KB of LDS per wave and <= 168 VGPRs: THREE workgroups per CU.
+// A key tile shared by two waves (balanced ranges) is parked in its final dkvp slot by the later wave and completed by the
+// earlier one (both waves sit on one CU: plain stores, acknowledged before an LDS flag goes up; no LDS park area).
+#define NRW_OPW 20                                   // row stride of the operand tile (floats): 16-byte aligned rows, spread banks
+#define NRW_M_WAVE (2048 + 16 * NRW_OPW)             // floats per wave: K [4][64][4] | V [4][64][4] | operand tile [16][NRW_OPW]
+__device__ __forceinline__ float nrw_sum4rows(float v) { return sum_xor32(sum_xor16(v)); }
+// both sums in every lane: 7 instructions for the pair (reduce-scatter over lane bit 5, reduce over bit 4, all-gather)
+__device__ __forceinline__ void nrw_sum4rows_pair(float& x, float& y) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);   // [x.lo | y.lo], [x.hi | y.hi]
+  float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);                                             // lanes < 32: x over bit 5; >= 32: y
+  s = sum_xor16(s);
+  auto g = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  x = __uint_as_float(g[0]); y = __uint_as_float(g[1]);
+}
 template <bool BF, int FEAT>
-__global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
+__global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
   seed_from_device(a);
   typedef NrwLd<BF> LD;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int p = lane >> 2, q = lane & 3;
+  const int p = lane & 15, q = lane >> 4;
   const int N = a.N, TL = a.TL;   // TL == 16
   const int wg = a.xcd ? egt_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   int b, lr;
@@ -402,17 +408,13 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
   const bool gated = FEAT >= 0 ? (FEAT & NRW_F_GATED) != 0 : (a.flags & EGT_BF_GATE) != 0;
   const bool clip = FEAT >= 0 ? (FEAT & NRW_F_CLIP) != 0 : (a.flags & EGT_BF_CLIP) != 0;
   const bool ln_on = (a.flags & EGT_BF_NO_EDGE_LN) == 0;
-  constexpr int AREA = 4 * NRW_BWD_WAVE > BWD_PRO_WS ? 4 * NRW_BWD_WAVE : BWD_PRO_WS;
+  constexpr int AREA = 4 * NRW_M_WAVE > BWD_PRO_WS ? 4 * NRW_M_WAVE : BWD_PRO_WS;
   static_assert(4 * 528 <= AREA, "edge partial staging must fit the per-wave area");
-  float* dab = sm + wave * NRW_BWD_WAVE;   // [NRW_NB][64][2]
-  float* xs = dab + NRW_NB * 128;          // [16 pairs][xhat 8 | de' 8]
-  float* dg = xs + 256;                    // [16 pairs][16 dGE columns]
-  float* hs = dg + 256;                    // [16 pairs][H_hat 8 | 1 | 0 x 7]
-  float* kt = hs + 256;                    // [16 keys][4 q][8 k][2 j]: the tile's K rows, B operand of the dQ products
+  float* kt = sm + wave * NRW_M_WAVE;      // [4 u][64 lanes][4]: K[4u .. 4u+3] of (key p, head pair q)
+  float* vt = kt + 1024;                   // the same for V
+  float* op = vt + 1024;                   // [16 pairs][NRW_OPW]
   float* qd = sm + AREA;                   // [TL][QD_LD]
-  float* tab = qd + TL * QD_LD;
-  float* park = tab + NRW_TAB_FLOATS;              // [waves 1..3][32][64]: dK / dV of a key tile shared with the previous wave
-  volatile int* pflag = reinterpret_cast<volatile int*>(park + 3 * 2048);   // [4]: wave w parked its partial
+  volatile int* pflag = reinterpret_cast<volatile int*>(qd + TL * QD_LD);   // [4]: wave w parked its partial
   if (threadIdx.x < 4) pflag[threadIdx.x] = 0;
   for (int i = threadIdx.x; i < nl * 40; i += 256) {
     const int r = i / 40, f = i % 40;
@@ -429,47 +431,31 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
     __syncthreads();
     bwd_node_prologue<NRW_DE>(a, sm, qd, b, l_begin, wg);
   }
-  // quad-relative weight tables
-  for (int i = threadIdx.x; i < 4 * 32; i += 256) {
-    const int qq = i >> 5, r32 = i & 31;
-    { const int c = r32 >> 4, g = (r32 >> 2) & 3, r = r32 & 3;
-      tab[NRW_TAB_WP + qq * 36 + r32] = a.pw[(2 * qq + c) * 16 + 4 * (g ^ qq) + r]; }
-    { const int r = r32 >> 3, g = (r32 >> 1) & 3, c = r32 & 1;
-      tab[NRW_TAB_WD + qq * 36 + r32] = a.pw[(2 * (g ^ qq) + c) * 16 + 4 * qq + r]; }
-    if (r32 < 16) {
-      const int c = r32 >> 3, g = (r32 >> 1) & 3, j = r32 & 1;
-      tab[NRW_TAB_WR + qq * 20 + r32] = a.Wr[(2 * (g ^ qq) + j) * NRW_DE + 2 * qq + c];
-    }
-  }
-  float c2r[4];
+  __syncthreads();   // prologue scratch dead, qd rows complete
+  // ---- A operands (lane = row m = p of the product, k index q) and the accumulator preload ----
+  const int jm = p & 3, hm = 2 * (p >> 2) + jm;   // rows 4q'+0, 4q'+1 of a result carry head / channel 2q'+0, 2q'+1; rows 4q'+2, 4q'+3 are unused
+  float pwA[2], wrA[2], wdA[4], c2r[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) c2r[r] = a.pw[16 * 16 + 4 * q + r];
+  for (int s = 0; s < 2; ++s) {
+    pwA[s] = a.pw[(2 * q + s) * 16 + p];                              // [gates | E] column p from channel 2q + s
+    wrA[s] = jm < 2 ? a.Wr[hm * NRW_DE + 2 * q + s] : 0.0f;           // dH_ext of head hm from de' channel 2q + s
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    wdA[r] = jm < 2 ? a.pw[hm * 16 + 4 * q + r] : 0.0f;               // d ehat of channel hm from dGE column 4q + r
+    c2r[r] = a.pw[16 * 16 + 4 * q + r];
+  }
   v4f accT = {0.f, 0.f, 0.f, 0.f}, accR = {0.f, 0.f, 0.f, 0.f};
   float ssum[4] = {0.f, 0.f, 0.f, 0.f};
-  __syncthreads();   // prologue scratch dead, tables and qd rows complete
-  // constant columns of the [H_hat | 1] tile: column 8 = 1, columns 9..15 = 0 (columns 0..7 are rewritten every step)
-  hs[(lane >> 2) * 16 + 8 + (lane & 3) * 2] = (lane & 3) == 0 ? 1.0f : 0.0f;
-  hs[(lane >> 2) * 16 + 8 + (lane & 3) * 2 + 1] = 0.0f;
-  const float* wpq = tab + NRW_TAB_WP + q * 36;
-  const float* wrq = tab + NRW_TAB_WR + q * 20;
-  const float* wdq = tab + NRW_TAB_WD + q * 36;
-  // two waves per SIMD leave 256 registers: the projection and dH_ext weights live in them (12 LDS reads per step less)
-  float4 wpr[2][4], wrr[2][2];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) { wpr[0][g] = *reinterpret_cast<const float4*>(wpq + g * 4); wpr[1][g] = *reinterpret_cast<const float4*>(wpq + 16 + g * 4); }
-#pragma unroll
-  for (int h2 = 0; h2 < 2; ++h2) { wrr[0][h2] = *reinterpret_cast<const float4*>(wrq + h2 * 4); wrr[1][h2] = *reinterpret_cast<const float4*>(wrq + 8 + h2 * 4); }
+  const float hcst = p == 8 ? 1.0f : 0.0f;   // columns 8..15 of the [H_hat | 1] operand
 
   const int ntile = (N + 15) / 16;
-  // Work of a wave.  ntile a multiple of 4 (or < 4): key tiles w, w+4, ..., all rows.  Otherwise (N = 150: 10 tiles -> 3,3,2,2)
-  // the ntile x nl (tile, row) steps are cut into four CONTIGUOUS equal ranges; a tile that straddles two ranges is shared by
-  // two neighbouring waves: the later wave meets it FIRST and parks its dK / dV partial in LDS, the earlier wave meets it LAST,
-  // adds the parked partial and stores the tile's dK / dV.
+  // Work of a wave: key tiles w, w+4, ... when the tile count is a multiple of 4 (or < 4); otherwise the ntile x nl (tile, row)
+  // steps are cut into four CONTIGUOUS equal ranges and a tile that straddles two ranges is shared by neighbouring waves.
 #ifdef NRW_NO_BALANCE
   const bool balance = false;
 #else
-  // (measured at config 3: bf16 edge tensors 341 -> 315 us, fp32 357 -> 375 us -- unexplained; fp32 keeps whole tiles per wave)
-  const bool balance = BF && ntile >= 4 && (ntile & 3) != 0;
+  const bool balance = ntile >= 4 && (ntile & 3) != 0;
 #endif
   const int T = ntile * nl;
   const int t0 = balance ? (wave * T) >> 2 : 0, t1 = balance ? ((wave + 1) * T) >> 2 : 0;
@@ -481,15 +467,14 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
     const bool kvalid = m < N;
     const int mc = kvalid ? m : N - 1;
     const size_t rowm = (size_t)b * N + mc;
-    float Vf[16], dKa[16], dVa[16];   // (K of the key: read from the wave's LDS tile every step -- 16 registers less)
+    float dKa[16], dVa[16];
     {
       const float4* kp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 64 + q * 16);
       const float4* vp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 128 + q * 16);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 vv = vp[i];
-        Vf[4*i] = vv.x; Vf[4*i+1] = vv.y; Vf[4*i+2] = vv.z; Vf[4*i+3] = vv.w;
-        *reinterpret_cast<float4*>(kt + lane * 16 + 4 * i) = kp[i];   // (the previous tile's last flush read kt earlier in program order)
+      for (int u = 0; u < 4; ++u) {   // (the previous tile's reads of kt / vt are earlier in program order)
+        *reinterpret_cast<float4*>(kt + u * 256 + lane * 4) = kp[u];
+        *reinterpret_cast<float4*>(vt + u * 256 + lane * 4) = vp[u];
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) { dKa[i] = 0.f; dVa[i] = 0.f; }
@@ -499,8 +484,7 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
     const uint32_t pcol = (uint32_t)((size_t)b * N * N + mc);   // pair index of (row 0 of the graph, key mc), mod 2^32: the mask-RNG counter
     const size_t ugraph = (size_t)b * N * N;      // wave-uniform pair index of the graph's first pair
     const int loff = mc * NRW_DE + 2 * q;         // the lane's element offset inside a pair row
-    // e / de' two rows ahead
-    typename LD::raw en[2], dn[2];
+    typename LD::raw en[2], dn[2];                // e / de' two rows ahead
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const size_t pr = ugraph + (size_t)min(l_begin + r0 + i, l_end - 1) * N;
@@ -518,54 +502,45 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
         dn[1] = LD::uload(a.de_out, pr, loff);
       }
       if (!kvalid) { ev = make_float2(0.f, 0.f); dyv = make_float2(0.f, 0.f); }   // a key past N: zero tile row
-      // ---- norm_edge (recompute) ----
+      // ---- norm_edge (recompute): the pair's 8 channels sit in lanes p, p+16, p+32, p+48 ----
       float x0 = ev.x, x1 = ev.y;
-      const float mu = ln_on ? nrw_quad_sum(x0 + x1) * 0.125f : 0.0f;
+      const float mu = ln_on ? nrw_sum4rows(x0 + x1) * 0.125f : 0.0f;
       x0 -= mu; x1 -= mu;
-      const float var = nrw_quad_sum(fmaf(x0, x0, x1 * x1)) * 0.125f;
+      const float var = nrw_sum4rows(fmaf(x0, x0, x1 * x1)) * 0.125f;
       const float rstd = ln_on ? __builtin_amdgcn_rsqf(var + a.ln_eps) : 1.0f;
       x0 *= rstd; x1 *= rstd;
-      // ---- projections: acc[r] = column 4q + r ----
-      float acc[4];
-      {
-        float s[4][4];
+      // ---- projections (acc[r] = column 4q + r) and dH_ext (dhx[j] = head 2q + j) on the matrix core ----
+      v4f acc = {c2r[0], c2r[1], c2r[2], c2r[3]};
+      acc = MFMA(pwA[0], x0, acc);
+      acc = MFMA(pwA[1], x1, acc);
+      v4f dh4 = {0.f, 0.f, 0.f, 0.f};
+      dh4 = MFMA(wrA[0], dyv.x, dh4);
+      dh4 = MFMA(wrA[1], dyv.y, dh4);
+      // ---- weight-gradient operand A = [xhat | de'] of the step's 16 pairs (transposed through the operand tile) ----
+      float wa[4], wb1[4], wb2[4];
+      *reinterpret_cast<float2*>(op + p * NRW_OPW + 2 * q) = make_float2(x0, x1);
+      *reinterpret_cast<float2*>(op + p * NRW_OPW + 8 + 2 * q) = dyv;
+      asm volatile("" ::: "memory");
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 w0 = wpr[0][g], w1 = wpr[1][g];
-          s[g][0] = fmaf(x1, w1.x, x0 * w0.x); s[g][1] = fmaf(x1, w1.y, x0 * w0.y);
-          s[g][2] = fmaf(x1, w1.z, x0 * w0.z); s[g][3] = fmaf(x1, w1.w, x0 * w0.w);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = nrw_combine(s[0][r] + c2r[r], s[1][r], s[2][r], s[3][r]);
-      }
-      // ---- dH_ext = de'.Wr^T for heads 2q, 2q+1 ----
-      float dhx[2];
-      {
-        float ph[4][2];
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {   // h2: g pair {0,1} / {2,3}
-          // c = 0 / c = 1: [g][j]
-          const float4 w0 = wrr[0][h2], w1 = wrr[1][h2];
-          ph[2 * h2][0] = fmaf(dyv.y, w1.x, dyv.x * w0.x); ph[2 * h2][1] = fmaf(dyv.y, w1.y, dyv.x * w0.y);
-          ph[2 * h2 + 1][0] = fmaf(dyv.y, w1.z, dyv.x * w0.z); ph[2 * h2 + 1][1] = fmaf(dyv.y, w1.w, dyv.x * w0.w);
-        }
-        dhx[0] = nrw_combine(ph[0][0], ph[1][0], ph[2][0], ph[3][0]);
-        dhx[1] = nrw_combine(ph[0][1], ph[1][1], ph[2][1], ph[3][1]);
-      }
+      for (int s4 = 0; s4 < 4; ++s4) wa[s4] = op[(4 * s4 + q) * NRW_OPW + p];
+      asm volatile("" ::: "memory");
       // ---- logits, softmax / gate backward ----
       const float* qr = qd + li * QD_LD;
       const float4* qp = reinterpret_cast<const float4*>(qr + q * 16);
       const float4* dp = reinterpret_cast<const float4*>(qr + 64 + q * 16);
-      float dots[2], dAd[2];
+      float dots[2], dAd[2], dq[16];
       {
         float d0 = 0.f, d1 = 0.f, e0 = 0.f, e1 = 0.f;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float4 v = qp[u], w = dp[u], kf = *reinterpret_cast<const float4*>(kt + lane * 16 + 4 * u);
+          const float4 v = qp[u], w = dp[u];
+          const float4 kf = *reinterpret_cast<const float4*>(kt + u * 256 + lane * 4);
+          const float4 vf = *reinterpret_cast<const float4*>(vt + u * 256 + lane * 4);
           d0 = fmaf(v.x, kf.x, d0); d1 = fmaf(v.y, kf.y, d1);
           d0 = fmaf(v.z, kf.z, d0); d1 = fmaf(v.w, kf.w, d1);
-          e0 = fmaf(w.x, Vf[4*u], e0);   e1 = fmaf(w.y, Vf[4*u+1], e1);
-          e0 = fmaf(w.z, Vf[4*u+2], e0); e1 = fmaf(w.w, Vf[4*u+3], e1);
+          e0 = fmaf(w.x, vf.x, e0); e1 = fmaf(w.y, vf.y, e1);
+          e0 = fmaf(w.z, vf.z, e0); e1 = fmaf(w.w, vf.w, e1);
+          dq[4*u] = kf.x; dq[4*u+1] = kf.y; dq[4*u+2] = kf.z; dq[4*u+3] = kf.w;
         }
         dots[0] = d0; dots[1] = d1; dAd[0] = e0; dAd[1] = e1;
       }
@@ -596,7 +571,7 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
           const float g = gated ? egt_sigmoid(gl[j]) : 1.0f;
           const float dS = dAd[j] * g;
           const float dGl = gated ? dAd[j] * S * g * (1.0f - g) : 0.f;
-          const float dH = fmaf(S, dS - delta, dhx[j]);
+          const float dH = fmaf(S, dS - delta, dh4[j]);
           dA[j] = dH * inr[j] * a.scale;
           at[j] = S * g;
           dge[2 * j] = dGl;
@@ -605,18 +580,25 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) ssum[r] += dge[r];
-      // ---- operands of the matrix-pipe contractions -> LDS (lane-linear tiles) ----
-      const int bi = (li - r0) % NRW_NB;
-      *reinterpret_cast<float2*>(xs + p * 16 + 2 * q) = make_float2(x0, x1);
-      *reinterpret_cast<float2*>(xs + p * 16 + 8 + 2 * q) = dyv;
-      *reinterpret_cast<float4*>(dg + p * 16 + 4 * q) = make_float4(dge[0], dge[1], dge[2], dge[3]);
-      *reinterpret_cast<float2*>(hs + p * 16 + 2 * q) = make_float2(hh[0], hh[1]);
-      *reinterpret_cast<float2*>(dab + (bi * 64 + lane) * 2) = make_float2(dA[0], dA[1]);
-      asm volatile("" ::: "memory");   // (DS operations of a wave execute in order: no wait needed, only the compiler's order)
-      // ---- weight-gradient contractions over the step's 16 pairs: operands now, products below among the VALU work ----
-      float wa[4], wb1[4], wb2[4];
+      // ---- B operands of the weight-gradient products: dGE, then [H_hat | 1 | 0] -- the SAME tile, in DS order ----
+      *reinterpret_cast<float4*>(op + p * NRW_OPW + 4 * q) = make_float4(dge[0], dge[1], dge[2], dge[3]);
+      asm volatile("" ::: "memory");
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) { wa[s4] = xs[64 * s4 + lane]; wb1[s4] = dg[64 * s4 + lane]; wb2[s4] = hs[64 * s4 + lane]; }
+      for (int s4 = 0; s4 < 4; ++s4) wb1[s4] = op[(4 * s4 + q) * NRW_OPW + p];
+      asm volatile("" ::: "memory");
+      *reinterpret_cast<float2*>(op + p * NRW_OPW + 2 * q) = make_float2(hh[0], hh[1]);
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) { const float t = op[(4 * s4 + q) * NRW_OPW + p]; wb2[s4] = p < 8 ? t : hcst; }
+      asm volatile("" ::: "memory");   // the next step's tile writes stay behind these reads
+      // ---- d ehat = Wp'.dGE (channels 2q, 2q+1 in d4[0], d4[1]) ----
+      v4f d4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d4 = MFMA(wdA[r], dge[r], d4);
+      // ---- dQ of the row over this tile's 16 keys -> HBM (summed over key tiles by the next prologue / k_node_bwd) ----
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { dq[2 * k] *= dA[0]; dq[2 * k + 1] *= dA[1]; }
+      a.dqp[(((size_t)b * ntile + mt) * N + l) * 64 + lane] = reduce16_keep_own(dq, p);
       // ---- dK / dV (Q / dV_att of the row re-read: not held across the softmax phase) ----
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -626,108 +608,64 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
         dVa[4*u]   = fmaf(at[0], w.x, dVa[4*u]);   dVa[4*u+1] = fmaf(at[1], w.y, dVa[4*u+1]);
         dVa[4*u+2] = fmaf(at[0], w.z, dVa[4*u+2]); dVa[4*u+3] = fmaf(at[1], w.w, dVa[4*u+3]);
       }
-      accT = MFMA(wa[0], wb1[0], accT); accR = MFMA(wa[0], wb2[0], accR);
-      accT = MFMA(wa[1], wb1[1], accT); accR = MFMA(wa[1], wb2[1], accR);
-      // ---- d ehat = Wp.dGE for channels 2q, 2q+1; LayerNorm backward; de = de' + ... ----
-      float dxh[2];
-      {
-        float pd[4][2];
+      // ---- weight gradients over the step's 16 pairs: T += [xhat | de']^T.dGE, R += [xhat | de']^T.[H_hat | 1] ----
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { pd[g][0] = 0.f; pd[g][1] = 0.f; }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float4 w0 = *reinterpret_cast<const float4*>(wdq + r * 8);        // [g 0,1][c]
-          const float4 w1 = *reinterpret_cast<const float4*>(wdq + r * 8 + 4);    // [g 2,3][c]
-          pd[0][0] = fmaf(dge[r], w0.x, pd[0][0]); pd[0][1] = fmaf(dge[r], w0.y, pd[0][1]);
-          pd[1][0] = fmaf(dge[r], w0.z, pd[1][0]); pd[1][1] = fmaf(dge[r], w0.w, pd[1][1]);
-          pd[2][0] = fmaf(dge[r], w1.x, pd[2][0]); pd[2][1] = fmaf(dge[r], w1.y, pd[2][1]);
-          pd[3][0] = fmaf(dge[r], w1.z, pd[3][0]); pd[3][1] = fmaf(dge[r], w1.w, pd[3][1]);
-        }
-        dxh[0] = nrw_combine(pd[0][0], pd[1][0], pd[2][0], pd[3][0]);
-        dxh[1] = nrw_combine(pd[0][1], pd[1][1], pd[2][1], pd[3][1]);
-      }
+      for (int s4 = 0; s4 < 4; ++s4) { accT = MFMA(wa[s4], wb1[s4], accT); accR = MFMA(wa[s4], wb2[s4], accR); }
+      // ---- LayerNorm backward; de = de' + ... ----
       {
-        float m1 = ln_on ? nrw_quad_sum(dxh[0] + dxh[1]) * 0.125f : 0.0f;
-        float m2 = ln_on ? nrw_quad_sum(fmaf(dxh[0], x0, dxh[1] * x1)) * 0.125f : 0.0f;
+        float m1 = d4[0] + d4[1], m2 = fmaf(d4[0], x0, d4[1] * x1);
+        if (ln_on) { nrw_sum4rows_pair(m1, m2); m1 *= 0.125f; m2 *= 0.125f; } else { m1 = 0.f; m2 = 0.f; }
         float2 o;
-        o.x = dyv.x + rstd * (dxh[0] - m1 - x0 * m2);
-        o.y = dyv.y + rstd * (dxh[1] - m1 - x1 * m2);
+        o.x = dyv.x + rstd * (d4[0] - m1 - x0 * m2);
+        o.y = dyv.y + rstd * (d4[1] - m1 - x1 * m2);
         if (kvalid) LD::ustore(a.de, ugraph + (size_t)l * N, loff, o);
       }
-      accT = MFMA(wa[2], wb1[2], accT); accR = MFMA(wa[2], wb2[2], accR);
-      accT = MFMA(wa[3], wb1[3], accT); accR = MFMA(wa[3], wb2[3], accR);
-      // ---- dQ of the batch's rows: dQ[row][k] = sum_keys dA[row][key] K[key][k] per (head pair, j), on the matrix pipe ----
-      if (bi == NRW_NB - 1 || li == r1 - 1) {
-        const int lbase = l_begin + li - bi, nr = bi + 1;
-        const int ri = lane & 15, kq = lane >> 4;
-        asm volatile("" ::: "memory");
-#pragma unroll 1
-        for (int cj = 0; cj < 8; ++cj) {   // rolled: the 32 store addresses of an unrolled body would be hoisted into registers
-          const int qq = cj >> 1, j = cj & 1;
-          v4f d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            const int pp = 4 * s4 + kq;
-            const float av = ri < NRW_NB ? dab[((ri * 64) + 4 * pp + qq) * 2 + j] : 0.f;
-            const float bv = ri < 8 ? kt[(4 * pp + qq) * 16 + 2 * ri + j] : 0.f;
-            d = MFMA(av, bv, d);
-          }
-          if (kq < 2 && ri < 8) {
-            float* ob = a.dqp + (((size_t)b * ntile + mt) * N + lbase) * 64 + cj * 0;   // wave-uniform
-            const int oo = 4 * kq * 64 + 16 * qq + 2 * ri + j;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4)
-              if (4 * kq + r4 < nr) ob[oo + r4 * 64] = d[r4];
-          }
-        }
-      }
-      asm volatile("" ::: "memory");   // next step's tile writes stay behind this step's reads
     }
-    if (r0 > 0) {   // the tile's first rows belong to the previous wave: park this partial for it (it picks it up at its very end)
-      float* pk = park + (wave - 1) * 2048 + lane;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { pk[i * 64] = dKa[i]; pk[(16 + i) * 64] = dVa[i]; }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) pflag[wave] = 1;
-    } else {
-      if (r1 < nl) {   // the tile's last rows were done by the next wave, long ago
-        while (pflag[wave + 1] == 0) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-        const float* pk = park + wave * 2048 + lane;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { dKa[i] += pk[i * 64]; dVa[i] += pk[(16 + i) * 64]; }
-      }
+    // ---- the tile's dK / dV: the workgroup's partial slot of key m ----
+    float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + mc) * 2 + 0) * 4 + q) * 16);
+    float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + mc) * 2 + 1) * 4 + q) * 16);
+    if (r1 < nl && r0 == 0) {   // the tile's last rows were done by the next wave, long ago: its partial sits in the slot
+      while (pflag[wave + 1] == 0) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       if (kvalid) {
-        float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
-        float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
-          vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
+          const float4 kk = ko[i], vv = vo[i];
+          dKa[4*i] += kk.x; dKa[4*i+1] += kk.y; dKa[4*i+2] += kk.z; dKa[4*i+3] += kk.w;
+          dVa[4*i] += vv.x; dVa[4*i+1] += vv.y; dVa[4*i+2] += vv.z; dVa[4*i+3] += vv.w;
         }
       }
+    }
+    if (kvalid) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
+        vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
+      }
+    }
+    if (r0 > 0) {   // the tile's first rows belong to the previous wave: what was just stored is this wave's partial, parked in the
+                    // slot (same CU: the stores are acknowledged by the L2 before the flag goes up, the slot was never in this L1)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) pflag[wave] = 1;
     }
   }
   // ---- edge-parameter gradient partials of the workgroup: T [16][16] | s [16] | R [16][16] ----
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {   // sum over the 16 key lanes with the same q
-    float v = ssum[r];
-    v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-    ssum[r] = v;
-  }
+  for (int r = 0; r < 4; ++r) ssum[r] = row_sum16(ssum[r]);   // sum over the 16 key lanes with the same q
   __syncthreads();
   {
     float* ep = sm + wave * 528;
-    const int col = lane & 15, kq = lane >> 4;   // MFMA result layout: rows 4 kq + r4, column col
+    const int col = p, kq = q;   // MFMA result layout: rows 4 kq + r4, column col
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
       const int row = 4 * kq + r4;
       ep[row * 16 + col] = row < 8 ? accT[r4] : 0.f;                          // T = rows 0..7 of [xhat | de']^T.dGE (channels >= De: 0)
       ep[272 + ((row + 8) & 15) * 16 + col] = row >= 8 ? accR[r4] : 0.f;      // R = rows 8..15 of [xhat | de']^T.[H_hat | 1]
     }
-    if (lane < 4) {
+    if (p == 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ep[256 + 4 * lane + r] = ssum[r];
+      for (int r = 0; r < 4; ++r) ep[256 + 4 * q + r] = ssum[r];
     }
   }
   __syncthreads();
@@ -737,13 +675,14 @@ __global__ void __launch_bounds__(256, 2) k_narrow_bwd(BlockArgs a) {
 }
 
 void egt_narrow_launch_bwd(BlockArgs& a, int nwg, hipStream_t st) {
-  constexpr int AREA = 4 * NRW_BWD_WAVE > BWD_PRO_WS ? 4 * NRW_BWD_WAVE : BWD_PRO_WS;
-  const size_t lds = ((size_t)AREA + BWD_TL * QD_LD + NRW_TAB_FLOATS + 3 * 2048 + 4) * 4;
+  static const size_t pad = getenv("EGT_NRW_LDS_PAD") ? (size_t)atoi(getenv("EGT_NRW_LDS_PAD")) : 0;   // occupancy experiments only
   const int full = NRW_F_GATED | NRW_F_CLIP;
   const int feat = ((a.flags & EGT_BF_GATE) ? NRW_F_GATED : 0) | ((a.flags & EGT_BF_CLIP) ? NRW_F_CLIP : 0);
+  constexpr int AREA = 4 * NRW_M_WAVE > BWD_PRO_WS ? 4 * NRW_M_WAVE : BWD_PRO_WS;
+  const size_t lds = ((size_t)AREA + BWD_TL * QD_LD + 4) * 4 + pad;   // 47 KB: three workgroups per CU
 #define NRW_BWD(BF_, FEAT_)                                                                     \
   do {                                                                                            \
-    EGT_MAX_LDS_ONCE(k_narrow_bwd<BF_, FEAT_>);   /* 77 KB of dynamic LDS */                       \
+    EGT_MAX_LDS_ONCE(k_narrow_bwd<BF_, FEAT_>);                                                    \
     EGT_LAUNCH("k_block_bwd", (k_narrow_bwd<BF_, FEAT_>), dim3(nwg), dim3(256), lds, st, a);      \
   } while (0)
   if (a.bf16) { if (feat == full) NRW_BWD(true, NRW_F_GATED | NRW_F_CLIP); else NRW_BWD(true, NRW_F_RUNTIME); }

@@ -1,7 +1,7 @@
-"""De = 8 pair kernels (egt_narrow.hip): the driver's GPU suite runs the DEFAULT selection (VALU forward for fp32 and
-bf16, VALU backward for bf16, v4r backward for fp32).  The kernel choice is read from the environment once per process,
-so the other selections are exercised in child processes: the VALU backward forced for fp32, and the MFMA-tile kernels
-(r4 / v4r) with the VALU kernels switched off -- all against the same oracle tests."""
+"""De = 8 pair kernels (egt_narrow.hip): the driver's GPU suite runs the DEFAULT selection (k_narrow_fwd / k_narrow_bwd for
+fp32 and bf16 edge tensors).  The kernel choice is read from the environment once per process, so the other selections
+are exercised in child processes: the MFMA-tile backward (v4r) under the De = 8 forward, and the MFMA-tile kernels
+(r4 / v4r) with both De = 8 kernels switched off -- all against the same oracle tests."""
 import os
 import subprocess
 import sys
@@ -27,8 +27,8 @@ def _run(env_extra):
     assert " passed" in r.stdout
 
 
-def test_valu_backward_forced_for_fp32():
-    _run({"EGT_NARROW_BWD": "1"})
+def test_mfma_tile_backward_under_the_narrow_forward():
+    _run({"EGT_NO_NARROW_BWD": "1"})
 
 
 def test_mfma_tile_kernels_with_the_valu_kernels_off():
@@ -60,7 +60,7 @@ PMAP = {"norm_edge.gamma": ("norm_edge", "gamma"), "norm_edge.beta": ("norm_edge
     ("plain", 188, 64, True, True),          # PATTERN's longest graphs: 12 row groups, ragged last key block
     ("plain", 90, 64, True, True),           # 6 key tiles over 4 waves: balanced (tile, row) ranges, key tiles 1 and 4 shared by two waves
     ("plain", 70, 64, True, False),          # 5 key tiles, ragged last row group (6 rows): every range boundary inside a tile
-    ("plain", 90, 64, False, True),          # the same geometries with fp32 edge tensors: k_block_bwd_v4r's balanced ranges
+    ("plain", 90, 64, False, True),          # the same geometries with fp32 edge tensors
     ("plain", 70, 64, False, False),
     ("plain", 7, 64, False, False)])         # fewer keys than one wave's share: empty key ranges in the forward
 def test_narrow_kernel_branches_vs_oracle(variant, N, Dh, bf16, train, gpu, egt_lib):
