@@ -1616,10 +1616,10 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 15, q = lane >> 4;
-  const int N = a.N, TL = a.TL;   // TL == 16
+  const int N = a.N, TL = a.TL;
   const int wg = a.xcd ? egt_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   int b, lr;
-  egt_group_order(wg, a.B, a.NLR, N, b, lr);
+  egt_group_order(wg, a.B, a.NLR, N, b, lr, TL);
   const int l_begin = lr * TL, l_end = min(N, l_begin + TL), nl = l_end - l_begin;
   const bool gated = (a.flags & EGT_BF_GATE) != 0;
   const bool clip = (a.flags & EGT_BF_CLIP) != 0;
@@ -2046,8 +2046,21 @@ struct BlockLayout {
   //  other workgroups of that launch already write their own)
   size_t dvp, dqp, dkvp, dqp_sz, dkvp_sz, common_total;
   size_t pw, epart, spart, sbo, wpart, ered, dqkv, dhbuf, layer_total;
-  int NLR, nwg_bwd, EP;
+  int TL, NLR, nwg_bwd, EP;   // TL: query rows per backward workgroup
 };
+
+// Query rows per backward workgroup.  16 fills the MFMA tiles of the node-side prologue; a De = 8 launch that would leave
+// CUs idle at 16 (BASELINE config 4 as specified: B = 16, N = 120 -> 128 workgroups on 256 CUs) takes 8 rows per workgroup
+// instead -- twice the partial slots (dK / dV, parameter sums), each prologue on a half-filled tile, every CU busy.
+// Measured (pattern500k_n120, k_narrow_bwd per launch): B = 16: 58.7 us at 16 rows, 43.2 at 8, 45.5 at 4; B = 32: 62.9 / 59.1 / 86.2;
+// B = 64: 88.5 / 109.3 / 158.9 -- so 8 rows up to one workgroup per CU, 16 beyond, never 4 (the per-workgroup work that does
+// not shrink with the rows -- prologue, K / V tiles, partial sums -- takes over).  EGT_BWD_TL = 4 | 8 | 16 overrides (De = 8 only; tests).
+static int bwd_rows_per_wg(const egt_block_desc* d) {
+  if (d->De != 8) return BWD_TL;
+  static const int forced = getenv("EGT_BWD_TL") ? atoi(getenv("EGT_BWD_TL")) : 0;
+  if (forced == 4 || forced == 8 || forced == 16) return forced;
+  return d->B * ((d->N + BWD_TL - 1) / BWD_TL) <= 256 ? 8 : BWD_TL;
+}
 
 static BlockLayout layout(const egt_block_desc* d) {
   BlockLayout L{};
@@ -2061,7 +2074,8 @@ static BlockLayout layout(const egt_block_desc* d) {
   L.qkvp = o; o += al(rows * QKVP);
   L.pw_sv = o; o += al((size_t)DEP * 16 + 16);
   L.saved_total = o;
-  L.NLR = (d->N + BWD_TL - 1) / BWD_TL;
+  L.TL = bwd_rows_per_wg(d);
+  L.NLR = (d->N + L.TL - 1) / L.TL;
   L.nwg_bwd = d->B * L.NLR;
   o = 0;
   L.dvp = o; o += al(rows * 64);
@@ -2093,7 +2107,7 @@ static void bind_ws(const BlockLayout& L, BlockArgs& a, float* wc, float* wl, in
   a.epart = wl + L.epart; a.spart = wl + L.spart; a.sbo = wl + L.sbo; a.wpart = wl + L.wpart;
   a.spart_n = a.sbo_n = a.B * ((a.N + NODE_RC - 1) / NODE_RC);   // k_node_bwd's workgroups (prologue path overrides)
   a.ered = wl + L.ered; a.dqkv_sv = wl + L.dqkv;
-  a.TL = BWD_TL; a.NLR = L.NLR; a.NQP = 1;
+  a.TL = L.TL; a.NLR = L.NLR; a.NQP = 1;
   a.xcd = block_env().no_xcd_remap ? 0 : 1;
 }
 

@@ -222,7 +222,7 @@ struct BwdProRegs { float4 hx, gq[3], wq[12], wo[4]; float dho[4], gmm[4], va[4]
   const int lnrow = 4 * wave + q;    /* LayerNorm mapping: row 4*wave + q, columns p + 16 i */            \
   /* ragged last row group (N not a multiple of 16): loads are clamped to the graph's last row, the rows  \
      past the end contribute zeros to every sum and are never stored */                                   \
-  const int nv = min(16, N - l_begin);                     /* valid rows of this workgroup */             \
+  const int nv = min(a.TL, N - l_begin);                   /* valid rows of this workgroup (a.TL <= 16) */ \
   auto rc = [&](int r) { return row0 + min(r, nv - 1); };   /* clamped global row */                       \
   (void)LD; (void)LD3; (void)lnrow; (void)p; (void)q; (void)rc
 

@@ -125,8 +125,8 @@ struct EgtProfScope {
 // (graph, 16-row group) of a logical workgroup index.  When N is not a multiple of 16 the last row group of every graph is
 // short (its workgroup does a fraction of a full group's work): those workgroups are dealt LAST, so they fill the tail of
 // the launch instead of sitting between full-size workgroups while the last round runs half empty.
-__device__ __forceinline__ void egt_group_order(int wg, int B, int groups, int N, int& b, int& g) {
-  if ((N & 15) == 0) { b = wg / groups; g = wg % groups; return; }
+__device__ __forceinline__ void egt_group_order(int wg, int B, int groups, int N, int& b, int& g, int rows = 16) {   // rows per group
+  if ((N % rows) == 0) { b = wg / groups; g = wg % groups; return; }
   const int nfull = groups - 1, split = B * nfull;
   if (wg < split) { b = wg / nfull; g = wg % nfull; }
   else { b = wg - split; g = nfull; }

@@ -400,10 +400,10 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p = lane & 15, q = lane >> 4;
-  const int N = a.N, TL = a.TL;   // TL == 16
+  const int N = a.N, TL = a.TL;   // rows per workgroup: 16, or 8 / 4 for launches that would not fill the chip (layout())
   const int wg = a.xcd ? egt_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   int b, lr;
-  egt_group_order(wg, a.B, a.NLR, N, b, lr);
+  egt_group_order(wg, a.B, a.NLR, N, b, lr, TL);
   const int l_begin = lr * TL, l_end = min(N, l_begin + TL), nl = l_end - l_begin;
   const bool gated = FEAT >= 0 ? (FEAT & NRW_F_GATED) != 0 : (a.flags & EGT_BF_GATE) != 0;
   const bool clip = FEAT >= 0 ? (FEAT & NRW_F_CLIP) != 0 : (a.flags & EGT_BF_CLIP) != 0;

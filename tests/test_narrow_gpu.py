@@ -35,6 +35,15 @@ def test_mfma_tile_kernels_with_the_valu_kernels_off():
     _run({"EGT_NO_NARROW": "1"})
 
 
+@pytest.mark.parametrize("rows", ["16", "4"])
+def test_backward_rows_per_workgroup(rows):
+    """The De = 8 backward takes 16, 8 or 4 query rows per workgroup (egt_block.hip: bwd_rows_per_wg; small batches get 8 so
+    that every CU has work).  The test batches are tiny, so the default selection already runs 8 rows per workgroup
+    everywhere; the other two sizes are forced here, for the De = 8 kernel and for the MFMA-tile fallback."""
+    _run({"EGT_BWD_TL": rows})
+    _run({"EGT_BWD_TL": rows, "EGT_NO_NARROW_BWD": "1"})
+
+
 # ---- the less-travelled branches of the De = 8 kernels, in process (default selection) -----------------------------
 import torch  # noqa: E402
 
