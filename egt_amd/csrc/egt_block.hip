@@ -2049,17 +2049,23 @@ struct BlockLayout {
   int TL, NLR, nwg_bwd, EP;   // TL: query rows per backward workgroup
 };
 
-// Query rows per backward workgroup.  16 fills the MFMA tiles of the node-side prologue; a De = 8 launch that would leave
-// CUs idle at 16 (BASELINE config 4 as specified: B = 16, N = 120 -> 128 workgroups on 256 CUs) takes 8 rows per workgroup
-// instead -- twice the partial slots (dK / dV, parameter sums), each prologue on a half-filled tile, every CU busy.
-// Measured (pattern500k_n120, k_narrow_bwd per launch): B = 16: 58.7 us at 16 rows, 43.2 at 8, 45.5 at 4; B = 32: 62.9 / 59.1 / 86.2;
-// B = 64: 88.5 / 109.3 / 158.9 -- so 8 rows up to one workgroup per CU, 16 beyond, never 4 (the per-workgroup work that does
-// not shrink with the rows -- prologue, K / V tiles, partial sums -- takes over).  EGT_BWD_TL = 4 | 8 | 16 overrides (De = 8 only; tests).
+// Query rows per backward workgroup (<= 16: the MFMA tiles of the node-side prologue).  De = 8 only (k_narrow_bwd and its
+// fallbacks take any value; the wide kernels keep 16):
+//  * equal groups: N = 150 is ten groups of 15 rather than nine of 16 and one of 6 -- same workgroup count, no short group
+//    (config 3: 225 -> 216 us per launch; N = 120: 162 -> 156 us);
+//  * a launch of at most one 16-row workgroup per CU (BASELINE config 4 as specified: B = 16, N = 120 -> 128 workgroups on
+//    256 CUs) takes 8 rows per workgroup: twice the partial slots, each prologue on a half-filled tile, every CU busy
+//    (pattern500k_n120, per launch: B = 16: 59.0 us at 16 rows, 43.3 at 8, 47.9 at 6; B = 32: 63.0 / 59.5 / 65.5).
+//    Smaller groups never pay beyond that: the per-workgroup work that does not shrink with the rows (prologue, K / V tiles,
+//    partial sums) takes over (B = 128, N = 150: 225 us at 16 rows, 253 at 12, 295 at 8).
+// EGT_BWD_TL = 4 .. 16 overrides (tests, sweeps: tools/dbg/nrw_tlsweep.sh).
 static int bwd_rows_per_wg(const egt_block_desc* d) {
   if (d->De != 8) return BWD_TL;
   static const int forced = getenv("EGT_BWD_TL") ? atoi(getenv("EGT_BWD_TL")) : 0;
-  if (forced == 4 || forced == 8 || forced == 16) return forced;
-  return d->B * ((d->N + BWD_TL - 1) / BWD_TL) <= 256 ? 8 : BWD_TL;
+  if (forced >= 4 && forced <= BWD_TL) return forced;
+  const int groups = (d->N + BWD_TL - 1) / BWD_TL;
+  if (d->B * groups <= 256) return d->N > 8 ? 8 : BWD_TL;
+  return (d->N + groups - 1) / groups;
 }
 
 static BlockLayout layout(const egt_block_desc* d) {

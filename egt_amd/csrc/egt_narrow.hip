@@ -382,6 +382,11 @@ void egt_narrow_launch_fwd(BlockArgs& a, hipStream_t st) {
 // share ONE buffer (DS operations of a wave execute in order).  ~12 KB of LDS per wave and <= 168 VGPRs: THREE workgroups per CU.
 // A key tile shared by two waves (balanced ranges) is parked in its final dkvp slot by the later wave and completed by the
 // earlier one (both waves sit on one CU: plain stores, acknowledged before an LDS flag goes up; no LDS park area).
+#ifdef NRW_TIMING   // measurement builds (EGT_NARROW_FLAGS=-DNRW_TIMING): per-wave cycle sums of the kernel's sections, printed at exit
+#define NSTMP(i) do { const unsigned tn__ = (unsigned)__builtin_amdgcn_s_memtime(); nacc[i] += tn__ - nlast; nlast = tn__; } while (0)
+#else
+#define NSTMP(i) do {} while (0)
+#endif
 #define NRW_OPW 20                                   // row stride of the operand tile (floats): 16-byte aligned rows, spread banks
 #define NRW_M_WAVE (2048 + 16 * NRW_OPW)             // floats per wave: K [4][64][4] | V [4][64][4] | operand tile [16][NRW_OPW]
 __device__ __forceinline__ float nrw_sum4rows(float v) { return sum_xor32(sum_xor16(v)); }
@@ -396,6 +401,9 @@ __device__ __forceinline__ void nrw_sum4rows_pair(float& x, float& y) {
 template <bool BF, int FEAT>
 __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
   seed_from_device(a);
+#ifdef NRW_TIMING
+  unsigned nacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nlast = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
   typedef NrwLd<BF> LD;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -427,11 +435,13 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
     if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
     *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
   }
+  NSTMP(0);   // staging issued
   if (a.pro) {
     __syncthreads();
     bwd_node_prologue<NRW_DE>(a, sm, qd, b, l_begin, wg);
   }
   __syncthreads();   // prologue scratch dead, qd rows complete
+  NSTMP(1);   // node-side prologue
   // ---- A operands (lane = row m = p of the product, k index q) and the accumulator preload ----
   const int jm = p & 3, hm = 2 * (p >> 2) + jm;   // rows 4q'+0, 4q'+1 of a result carry head / channel 2q'+0, 2q'+1; rows 4q'+2, 4q'+3 are unused
   float pwA[2], wrA[2], wdA[4], c2r[4];
@@ -491,6 +501,7 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
       en[i] = LD::uload(a.e, pr, loff);
       dn[i] = LD::uload(a.de_out, pr, loff);
     }
+    NSTMP(2);   // tile set-up: weights (first tile), K / V -> LDS, first e / de' requests
     for (int li = r0; li < r1; ++li) {
       const int l = l_begin + li;
       const uint32_t pair = pcol + (uint32_t)(l * N);
@@ -621,6 +632,7 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
         if (kvalid) LD::ustore(a.de, ugraph + (size_t)l * N, loff, o);
       }
     }
+    NSTMP(3);   // row loop
     // ---- the tile's dK / dV: the workgroup's partial slot of key m ----
     float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + mc) * 2 + 0) * 4 + q) * 16);
     float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + mc) * 2 + 1) * 4 + q) * 16);
@@ -650,6 +662,7 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
       if (lane == 0) pflag[wave] = 1;
     }
   }
+  NSTMP(4);   // dK / dV stores, parked partials
   // ---- edge-parameter gradient partials of the workgroup: T [16][16] | s [16] | R [16][16] ----
 #pragma unroll
   for (int r = 0; r < 4; ++r) ssum[r] = row_sum16(ssum[r]);   // sum over the 16 key lanes with the same q
@@ -672,7 +685,28 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
   float* out = a.epart + (size_t)wg * 528;
   for (int i = threadIdx.x; i < 528; i += 256)
     out[i] = (sm[i] + sm[528 + i]) + (sm[2 * 528 + i] + sm[3 * 528 + i]);
+#ifdef NRW_TIMING
+  NSTMP(5);   // workgroup partials (waits for the slowest wave)
+  if (a.dbg && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = nacc[i];
+  }
+#endif
 }
+
+#ifdef NRW_TIMING
+static unsigned* g_nt_dev = nullptr;
+static int g_nt_n = 0;
+static double g_nt_sum[8];
+static long g_nt_launch = 0, g_nt_waves = 0;
+static void nrw_timing_report() {
+  static const char* nm[] = {"staging issue", "node-side prologue + sync", "tile set-up (K/V, first e)", "row loop", "dK/dV stores + park", "workgroup partials + sync"};
+  if (!g_nt_waves) return;
+  double tot = 0; for (int i = 0; i < 6; ++i) tot += g_nt_sum[i];
+  fprintf(stderr, "[egt] k_narrow_bwd section cycles per wave (mean over %ld waves, %ld launches; total %.0f):\n", g_nt_waves, g_nt_launch, tot / g_nt_waves);
+  for (int i = 0; i < 6; ++i) fprintf(stderr, "    %-30s %10.0f  (%.1f %%)\n", nm[i], g_nt_sum[i] / g_nt_waves, 100.0 * g_nt_sum[i] / tot);
+}
+#endif
 
 void egt_narrow_launch_bwd(BlockArgs& a, int nwg, hipStream_t st) {
   static const size_t pad = getenv("EGT_NRW_LDS_PAD") ? (size_t)atoi(getenv("EGT_NRW_LDS_PAD")) : 0;   // occupancy experiments only
@@ -685,7 +719,25 @@ void egt_narrow_launch_bwd(BlockArgs& a, int nwg, hipStream_t st) {
     EGT_MAX_LDS_ONCE(k_narrow_bwd<BF_, FEAT_>);                                                    \
     EGT_LAUNCH("k_block_bwd", (k_narrow_bwd<BF_, FEAT_>), dim3(nwg), dim3(256), lds, st, a);      \
   } while (0)
+#ifdef NRW_TIMING
+  if (g_nt_n < nwg) {
+    if (g_nt_dev) (void)hipFree(g_nt_dev);
+    (void)hipMalloc(&g_nt_dev, (size_t)nwg * 32 * sizeof(unsigned));
+    if (!g_nt_n) atexit(nrw_timing_report);
+    g_nt_n = nwg;
+  }
+  a.dbg = g_nt_dev;
+#endif
   if (a.bf16) { if (feat == full) NRW_BWD(true, NRW_F_GATED | NRW_F_CLIP); else NRW_BWD(true, NRW_F_RUNTIME); }
   else { if (feat == full) NRW_BWD(false, NRW_F_GATED | NRW_F_CLIP); else NRW_BWD(false, NRW_F_RUNTIME); }
 #undef NRW_BWD
+#ifdef NRW_TIMING
+  (void)hipStreamSynchronize(st);
+  if (++g_nt_launch > 20) {
+    static unsigned* h = nullptr; static int hn = 0;
+    if (hn < nwg) { free(h); h = (unsigned*)malloc((size_t)nwg * 32 * sizeof(unsigned)); hn = nwg; }
+    (void)hipMemcpy(h, g_nt_dev, (size_t)nwg * 32 * sizeof(unsigned), hipMemcpyDeviceToHost);
+    for (int w = 0; w < nwg * 4; ++w) { for (int i = 0; i < 8; ++i) g_nt_sum[i] += h[w * 8 + i]; ++g_nt_waves; }
+  }
+#endif
 }
