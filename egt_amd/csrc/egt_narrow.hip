@@ -470,6 +470,22 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
   const int T = ntile * nl;
   const int t0 = balance ? (wave * T) >> 2 : 0, t1 = balance ? ((wave + 1) * T) >> 2 : 0;
   const int mt_first = balance ? t0 / nl : wave, mt_last = balance ? (t1 - 1) / nl : ntile - 1, mt_step = balance ? 1 : 4;
+  // e / de' run two steps ahead of the (tile, row) sequence, ACROSS tile boundaries: the last two rows of a tile request the first
+  // two rows of the wave's next tile (a tile switch then costs the K / V round trip only)
+  const size_t ugraph = (size_t)b * N * N;      // wave-uniform pair index of the graph's first pair
+  typename LD::raw en[2] = {}, dn[2] = {};
+  int cmt = mt_first, cli = balance ? t0 - mt_first * nl : 0;   // request cursor: the (tile, row) step two ahead of the one being worked on
+  auto request = [&](int slot) __attribute__((always_inline)) {
+    if (cmt <= mt_last) {   // (wave-uniform)
+      const int lo = min(cmt * 16 + p, N - 1) * NRW_DE + 2 * q;
+      const size_t pr = ugraph + (size_t)(l_begin + cli) * N;
+      en[slot] = LD::uload(a.e, pr, lo);
+      dn[slot] = LD::uload(a.de_out, pr, lo);
+      if (++cli >= ((balance && cmt == mt_last) ? t1 - cmt * nl : nl)) { cli = 0; cmt += mt_step; }
+    }
+  };
+  request(0);
+  request(1);
   for (int mt = mt_first; mt <= mt_last; mt += mt_step) {
     const int r0 = (balance && mt == mt_first) ? t0 - mt * nl : 0;          // rows [r0, r1) of the workgroup's nl
     const int r1 = (balance && mt == mt_last) ? t1 - mt * nl : nl;
@@ -492,26 +508,14 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
     const float kadd = (a.km && a.km[rowm] == 0) ? -EGT_NEG : 0.0f;
     const MaskRegs mr{make_float2(1.f, 1.f), 0};
     const uint32_t pcol = (uint32_t)((size_t)b * N * N + mc);   // pair index of (row 0 of the graph, key mc), mod 2^32: the mask-RNG counter
-    const size_t ugraph = (size_t)b * N * N;      // wave-uniform pair index of the graph's first pair
     const int loff = mc * NRW_DE + 2 * q;         // the lane's element offset inside a pair row
-    typename LD::raw en[2], dn[2];                // e / de' two rows ahead
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const size_t pr = ugraph + (size_t)min(l_begin + r0 + i, l_end - 1) * N;
-      en[i] = LD::uload(a.e, pr, loff);
-      dn[i] = LD::uload(a.de_out, pr, loff);
-    }
     NSTMP(2);   // tile set-up: weights (first tile), K / V -> LDS, first e / de' requests
     for (int li = r0; li < r1; ++li) {
       const int l = l_begin + li;
       const uint32_t pair = pcol + (uint32_t)(l * N);
       float2 ev = LD::cvt(en[0]), dyv = LD::cvt(dn[0]);
       en[0] = en[1]; dn[0] = dn[1];
-      {
-        const size_t pr = ugraph + (size_t)min(l + 2, l_end - 1) * N;
-        en[1] = LD::uload(a.e, pr, loff);
-        dn[1] = LD::uload(a.de_out, pr, loff);
-      }
+      request(1);
       if (!kvalid) { ev = make_float2(0.f, 0.f); dyv = make_float2(0.f, 0.f); }   // a key past N: zero tile row
       // ---- norm_edge (recompute): the pair's 8 channels sit in lanes p, p+16, p+32, p+48 ----
       float x0 = ev.x, x1 = ev.y;
