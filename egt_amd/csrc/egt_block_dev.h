@@ -201,6 +201,9 @@ __device__ __forceinline__ void fwd_node_epilogue(const BlockArgs& a, float* sm,
 //              delta = sum_k dV_att*V_att into the qd statistics, dbo column sums -> sbo
 // One launch per layer on the dh critical path instead of two; dV_att / delta never touch HBM.
 // `ws`: the (still idle) per-wave tile area; `qd`: the staged [16][QD_LD] rows.
+#ifndef EGT_PRO_UNROLL
+#define EGT_PRO_UNROLL 4   // partial loads in flight per element of the dQ / dK / dV gather
+#endif
 #define BWD_PRO_WS 8192   // floats of LDS scratch the prologue needs (dQKV, xhat, d h_ln, dh' rows, partials)
 // HOIST: the loads of the dV_att step (Wo columns, V_att rows) are issued with the first round of global loads instead of
 // after the dh' rows exist: one memory round trip on the kernel's critical path instead of two (costs 20 registers across
@@ -257,7 +260,7 @@ __device__ __forceinline__ void bwd_prologue_load_main(const BlockArgs& a, int b
                                   : a.up_dkvp + (((size_t)b * NP * N + l_begin + rr) * 2 + (sx - 1)) * 64 + (pos4 & 63);
       const size_t pstride = sx == 0 ? (size_t)N * 64 : (size_t)N * 128;
       float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
+#pragma unroll EGT_PRO_UNROLL
       for (int pi = 0; pi < NP; ++pi) {
         const float4 w = *reinterpret_cast<const float4*>(base + pi * pstride);
         acc4.x += w.x; acc4.y += w.y; acc4.z += w.z; acc4.w += w.w;

@@ -4,29 +4,55 @@
 // skeleton and dependent phases (LDS round trip -> LayerNorm over lanes -> MFMA chain -> ...) cost more
 // than the arithmetic, and at ~240 VGPRs only two waves per SIMD hide the latency of tiles that small
 // (measured: 1.1 TB/s, 0.08 of the roof).  These kernels keep a pair's whole working set in FOUR lanes:
-// lane (p, q) owns heads 2q, 2q+1 and edge channels 2q, 2q+1 of ONE pair per step; e arrives by plain 8-byte global
-// loads straight into the lane (no LDS tile, no transposition).
-//   k_narrow_fwd: lane = 4 p + q, p = query row.  LayerNorm statistics, the projection sums and dense_edge_r are
-//     2-channel / 2-head partial sums in the lane, combined across the QUAD with DPP quad_perm adds (each lane evaluates
-//     the partial sums in quad-RELATIVE order -- slot g of lane q holds the partial for quarter g ^ q -- so a combine is
-//     three DPP adds per value and needs no selects); the lane keeps a whole query row's softmax state (online softmax
-//     over the key loop: no cross-lane reduction at all); the four waves of a workgroup split the key range and merge
-//     their (max, sum, A.V) triples once at the end.  168 VGPRs = three waves per SIMD, 20 KB of LDS per workgroup.
-//   k_narrow_bwd: lane = p + 16 q, p = key -- the operand layout of v_mfma_f32_16x16x4_f32, so the channel contractions
-//     of a step run on the matrix core from the lane's own registers (see the kernel's header).  168 VGPRs, 47 KB of LDS:
-//     three workgroups per CU.
+//   lane = p + 16 q:  lane (p, q) owns heads 2q, 2q+1 and edge channels 2q, 2q+1 of ONE pair per step (p = query row in the
+//   forward, key in the backward); e arrives by plain 8-byte global loads straight into the lane (no LDS tile, no transposition).
+// That is the operand / result layout of v_mfma_f32_16x16x4_f32 (B operand: lane (n = p, k = q); result: lane (n = p) holds
+// rows 4q .. 4q+3), so every pair-local channel contraction -- the [gates | E] projections, dense_edge_r, dH_ext, d ehat -- is
+// two to four MFMAs with the lane's own registers as B operand and the weights as 2-4 A-operand registers: no exchange, no weight
+// table.  LayerNorm sums cross the four 16-lane rows (v_permlane16_swap / v_permlane32_swap).
+//   k_narrow_fwd: the lane keeps a whole query row's softmax state (online softmax over the key loop: no cross-lane reduction);
+//     the four waves of a workgroup split the key range and merge their (max, sum, A.V) triples once at the end.
+//     <= 128 VGPRs, 20 KB of LDS per workgroup: four workgroups per CU.
+//   k_narrow_bwd: see the kernel's header.  168 VGPRs, 47 KB of LDS: three workgroups per CU.
+// (Round 2 ran both on quad lanes, lane = 4 p + q, with 2-channel partial sums combined by DPP quad_perm adds: 48 weight
+// registers, ~70 VALU instructions per step more, the backward at two workgroups per CU -- forward 91 -> 86 us, backward
+// 314 -> 208 us at config 3.)
 // Same BlockArgs, saved tensors, partial-buffer layouts, mask order / RNG stream and node-side epilogue /
 // prologue as the wide kernels: the dispatch in launch_fwd / launch_bwd is the only difference.
-// Own translation unit: built with -fno-slp-vectorize (build.py) -- hipcc otherwise pairs the scalar adds into
-// v_pk_add_f32, which cannot take a DPP operand, and every quad exchange becomes v_mov_dpp + add.
+// Own translation unit: built with -fno-slp-vectorize (build.py) -- hipcc otherwise pairs scalar adds into v_pk_add_f32,
+// which cannot take a DPP operand (the dQ reduction).
 #include "egt_common.h"
 
 #include "egt_block.h"
 #include "egt_block_dev.h"
 
 #define NRW_DE 8
-#ifndef NRW_FWD_OCC
-#define NRW_FWD_OCC 3
+#ifdef NRW_TIMING   // measurement builds (EGT_NARROW_FLAGS=-DNRW_TIMING): per-wave cycle sums of the kernel's sections, printed at exit
+#define NSTMP(i) do { const unsigned tn__ = (unsigned)__builtin_amdgcn_s_memtime(); nacc[i] += tn__ - nlast; nlast = tn__; } while (0)
+#else
+#define NSTMP(i) do {} while (0)
+#endif
+#ifdef NRW_TIMING
+struct NrwTimer {   // host side of a timing build: one device record of 8 counters per wave, summed after every launch (synchronises)
+  const char* kernel; const char* const* names; int nsec;
+  unsigned* dev = nullptr; unsigned* host = nullptr; int n = 0; double sum[8] = {}; long launches = 0, waves = 0;
+  unsigned* attach(int nwg) {
+    if (n < nwg) { if (dev) (void)hipFree(dev); (void)hipMalloc(&dev, (size_t)nwg * 32 * sizeof(unsigned)); free(host); host = (unsigned*)malloc((size_t)nwg * 32 * sizeof(unsigned)); n = nwg; }
+    return dev;
+  }
+  void collect(int nwg, hipStream_t st) {
+    (void)hipStreamSynchronize(st);
+    if (++launches <= 20) return;
+    (void)hipMemcpy(host, dev, (size_t)nwg * 32 * sizeof(unsigned), hipMemcpyDeviceToHost);
+    for (int w = 0; w < nwg * 4; ++w) { for (int i = 0; i < 8; ++i) sum[i] += host[w * 8 + i]; ++waves; }
+  }
+  void report() const {
+    if (!waves) return;
+    double tot = 0; for (int i = 0; i < nsec; ++i) tot += sum[i];
+    fprintf(stderr, "[egt] %s section cycles per wave (mean over %ld waves, %ld launches; total %.0f):\n", kernel, waves, launches, tot / waves);
+    for (int i = 0; i < nsec; ++i) fprintf(stderr, "    %-30s %10.0f  (%.1f %%)\n", names[i], sum[i] / waves, 100.0 * sum[i] / tot);
+  }
+};
 #endif
 #ifndef NRW_ABL          // timing ablations (measurement builds only, tools/build_variant.sh -DNRW_ABL=<bits>):
 #define NRW_ABL 0        // 1 no e' stores, 2 no e loads, 4 no K/V chunk traffic, 8 no mask hash, 16 no exp/sigmoid, 32 no epilogue
@@ -38,26 +64,20 @@
 #define NRW_KV_CHUNK (NRW_KB * 128)   // floats: [key][K 64 | V 64]
 
 
-// quad exchange: value of lane (q ^ X).  bound_ctrl + full masks: `old` is dead, so the DPP move folds into the add that uses it
-template <int CTRL>
-__device__ __forceinline__ float nrw_quad(float v) {
-  return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(v), __float_as_uint(v), CTRL, 0xF, 0xF, true));
-}
-// sum over the quad of slot g of lane (q ^ g): own + xor1 + xor2 + xor3 partner slots
-__device__ __forceinline__ float nrw_combine(float s0, float s1, float s2, float s3) {
-  float t = s0 + nrw_quad<0xB1>(s1);
-  t += nrw_quad<0x4E>(s2);
-  t += nrw_quad<0x1B>(s3);
-  return t;
-}
-__device__ __forceinline__ float nrw_quad_sum(float v) {
-  v += nrw_quad<0xB1>(v);
-  v += nrw_quad<0x4E>(v);
-  return v;
-}
 // plain v_max_f32 / v_min_f32 (fmaxf's llvm.maxnum canonicalises both operands first: three instructions per max)
 __device__ __forceinline__ float nrw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float nrw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// Matrix-core lanes (lane = p + 16 q): the four lanes of a pair are p, p+16, p+32, p+48 -- sums over a pair's channels / heads
+// cross the four 16-lane rows (v_permlane16_swap, v_permlane32_swap: 3 instructions per level)
+__device__ __forceinline__ float nrw_sum4rows(float v) { return sum_xor32(sum_xor16(v)); }
+// both sums in every lane: 7 instructions for the pair (reduce-scatter over lane bit 5, reduce over bit 4, all-gather)
+__device__ __forceinline__ void nrw_sum4rows_pair(float& x, float& y) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);   // [x.lo | y.lo], [x.hi | y.hi]
+  float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);                                             // lanes < 32: x over bit 5; >= 32: y
+  s = sum_xor16(s);
+  auto g = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  x = __uint_as_float(g[0]); y = __uint_as_float(g[1]);
+}
 
 // Wave-uniform base pointer + 32-bit lane offset (in elements): hipcc then uses the SGPR-base addressing mode and
 // keeps ONE offset register per lane instead of a 64-bit address per tensor.
@@ -106,13 +126,20 @@ template <> struct NrwLd<true> {
 // LDS: [NRW_FWD_AREA] = [4 waves][NRW_KV_CHUNK] K/V chunks + [4][NRW_KB] key-mask adds during the key loop, the
 //      merge buffer [3][20][64] after it, then the epilogue's staging rows; [16][QS_LD] V_att rows for the epilogue.
 #define NRW_FWD_AREA ((3 * 20 * 64) > (4 * NRW_KV_CHUNK + 4 * NRW_KB) ? (3 * 20 * 64) : (4 * NRW_KV_CHUNK + 4 * NRW_KB))
+// Projections and dense_edge_r of a pair: two MFMAs each (4 A-operand registers).
+#ifndef NRW_FWDM_OCC
+#define NRW_FWDM_OCC 3
+#endif
 template <bool BF, int FEAT>
-__global__ void __launch_bounds__(256, NRW_FWD_OCC) k_narrow_fwd(BlockArgs a) {
+__global__ void __launch_bounds__(256, NRW_FWDM_OCC) k_narrow_fwd(BlockArgs a) {
   seed_from_device(a);
+#ifdef NRW_TIMING
+  unsigned nacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nlast = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
   typedef NrwLd<BF> LD;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int p = lane >> 2, q = lane & 3;
+  const int p = lane & 15, q = lane >> 4;   // matrix-core lanes
   const int N = a.N;
   const int lgroups = (N + 15) / 16;
   const int wg = a.xcd ? egt_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
@@ -121,8 +148,6 @@ __global__ void __launch_bounds__(256, NRW_FWD_OCC) k_narrow_fwd(BlockArgs a) {
   float* kvw = sm + wave * NRW_KV_CHUNK;
   float* kmw = sm + 4 * NRW_KV_CHUNK + wave * NRW_KB;
   float* qs = sm + NRW_FWD_AREA;
-  float* wrt = qs + 16 * QS_LD;     // [4 q][20]: dense_edge_r weights, quad-relative (fp32 instance only: 16 registers less)
-  constexpr bool WR_LDS = !BF;
   const bool gated = FEAT >= 0 ? (FEAT & NRW_F_GATED) != 0 : (a.flags & EGT_BF_GATE) != 0;
   const bool clip = FEAT >= 0 ? (FEAT & NRW_F_CLIP) != 0 : (a.flags & EGT_BF_CLIP) != 0;
   const bool ln_on = (a.flags & EGT_BF_NO_EDGE_LN) == 0;
@@ -130,34 +155,27 @@ __global__ void __launch_bounds__(256, NRW_FWD_OCC) k_narrow_fwd(BlockArgs a) {
   const bool row_ok = l < N;
   const size_t rowl = (size_t)b * N + min(l, N - 1);
 
-  // ---- lane constants: Q of the row, LN-folded projection weights and dense_edge_r in quad-relative order ----
+  // ---- lane constants: Q of the row (heads 2q, 2q+1); A operands of the two channel contractions ----
   float Qf[16];
   {
     const float4* qp = reinterpret_cast<const float4*>(a.qkvp + rowl * QKVP + q * 16);
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const float4 v = qp[u]; Qf[4*u] = v.x; Qf[4*u+1] = v.y; Qf[4*u+2] = v.z; Qf[4*u+3] = v.w; }
   }
-  if (WR_LDS && threadIdx.x < 64) {
-    const int qq = threadIdx.x >> 4, r16 = threadIdx.x & 15, j = r16 >> 3, g = (r16 >> 1) & 3, c = r16 & 1;
-    wrt[qq * 20 + r16] = a.Wr[(2 * qq + j) * NRW_DE + 2 * (g ^ qq) + c];
+  // [gates | E] = Wp'^T.xhat + c: A[m = column p][k = q] at step s = Wp'[channel 2q + s][column p]; result rows 4q .. 4q+3 = the
+  // lane's four columns.  dense_edge_r: A[m][k = q] at step j = Wr[head 2q + j][channel of row m]; rows 4q', 4q'+1 of the result
+  // carry channels 2q', 2q'+1 (rows 4q'+2, 4q'+3 unused: zero weights).
+  const int jm = p & 3, cm = 2 * (p >> 2) + jm;
+  float pwA[2], wrA[2], brr[2];
+  v4f c2r;
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    pwA[s2] = a.pw[(2 * q + s2) * 16 + p];
+    wrA[s2] = jm < 2 ? a.Wr[(2 * q + s2) * NRW_DE + cm] : 0.0f;
   }
-  float wp[2][4][4], wr[2][4][2], c2r[4], brr[2];
-#pragma unroll
-  for (int c = 0; c < 2; ++c)
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) wp[c][g][r] = a.pw[(2 * q + c) * 16 + 4 * (g ^ q) + r];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) wr[j][g][c] = WR_LDS ? 0.f : a.Wr[(2 * q + j) * NRW_DE + 2 * (g ^ q) + c];
 #pragma unroll
   for (int r = 0; r < 4; ++r) c2r[r] = a.pw[16 * 16 + 4 * q + r];
   brr[0] = a.br[2 * q]; brr[1] = a.br[2 * q + 1];
-  if (WR_LDS) __syncthreads();   // the weight table is complete
 
   // ---- the wave's key blocks ----
   const int nblk = (N + NRW_KB - 1) / NRW_KB;
@@ -190,6 +208,7 @@ __global__ void __launch_bounds__(256, NRW_FWD_OCC) k_narrow_fwd(BlockArgs a) {
     if (a.km) kmr = (a.km[(size_t)b * N + m0 + min(lane & (NRW_KB - 1), kmax)] == 0) ? -EGT_NEG : 0.0f;
   };
   if (blk0 < blk1) { fetch_e(blk0); fetch_kv(blk0); }
+  NSTMP(0);   // lane constants, weight table, first requests
 
   // one block of keys; nv = number of real keys in it (NRW_KB except in the graph's last block)
   auto block = [&](int blk, int nv) __attribute__((always_inline)) {
@@ -213,21 +232,14 @@ __global__ void __launch_bounds__(256, NRW_FWD_OCC) k_narrow_fwd(BlockArgs a) {
       const int m = m0 + kk;
       // ---- norm_edge: the pair's 8 channels sit in the quad, two per lane (two-pass moments) ----
       float x0 = ev[kk].x, x1 = ev[kk].y;
-      const float mu = ln_on ? nrw_quad_sum(x0 + x1) * 0.125f : 0.0f;
+      const float mu = ln_on ? nrw_sum4rows(x0 + x1) * 0.125f : 0.0f;
       x0 -= mu; x1 -= mu;
-      const float var = nrw_quad_sum(fmaf(x0, x0, x1 * x1)) * 0.125f;
+      const float var = nrw_sum4rows(fmaf(x0, x0, x1 * x1)) * 0.125f;
       const float rstd = ln_on ? __builtin_amdgcn_rsqf(var + a.ln_eps) : 1.0f;
       x0 *= rstd; x1 *= rstd;
       // ---- [attention_gates | dense_edge_b]: acc[r] = column 4q + r of the pair ----
-      float acc[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float s0 = fmaf(x1, wp[1][0][r], x0 * wp[0][0][r]);
-        const float s1 = fmaf(x1, wp[1][1][r], x0 * wp[0][1][r]);
-        const float s2 = fmaf(x1, wp[1][2][r], x0 * wp[0][2][r]);
-        const float s3 = fmaf(x1, wp[1][3][r], x0 * wp[0][3][r]);
-        acc[r] = nrw_combine(s0 + c2r[r], s1, s2, s3);
-      }
+      v4f acc = MFMA(pwA[0], x0, c2r);
+      acc = MFMA(pwA[1], x1, acc);
       // ---- scaled QK^T, clip, + E (egt_layers.py:79-86) ----
       float Kf[16];
       {
@@ -253,22 +265,11 @@ __global__ void __launch_bounds__(256, NRW_FWD_OCC) k_narrow_fwd(BlockArgs a) {
       // ---- dense_edge_r + res_edge: e' = e + H_hat.Wr + br, the lane's two channels ----
       float2 eo;
       {
-        float w0[4][2], w1[4][2];   // [g][c] of head 2q (w0) and 2q + 1 (w1)
-        if (WR_LDS) {
-          const float4 a0 = *reinterpret_cast<const float4*>(wrt + q * 20), a1 = *reinterpret_cast<const float4*>(wrt + q * 20 + 4);
-          const float4 b0 = *reinterpret_cast<const float4*>(wrt + q * 20 + 8), b1 = *reinterpret_cast<const float4*>(wrt + q * 20 + 12);
-          w0[0][0] = a0.x; w0[0][1] = a0.y; w0[1][0] = a0.z; w0[1][1] = a0.w; w0[2][0] = a1.x; w0[2][1] = a1.y; w0[3][0] = a1.z; w0[3][1] = a1.w;
-          w1[0][0] = b0.x; w1[0][1] = b0.y; w1[1][0] = b0.z; w1[1][1] = b0.w; w1[2][0] = b1.x; w1[2][1] = b1.y; w1[3][0] = b1.z; w1[3][1] = b1.w;
-        } else {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) { w0[g][0] = wr[0][g][0]; w0[g][1] = wr[0][g][1]; w1[g][0] = wr[1][g][0]; w1[g][1] = wr[1][g][1]; }
-        }
-        const float t0 = nrw_combine(fmaf(hh[1], w1[0][0], fmaf(hh[0], w0[0][0], brr[0])), fmaf(hh[1], w1[1][0], hh[0] * w0[1][0]),
-                                     fmaf(hh[1], w1[2][0], hh[0] * w0[2][0]), fmaf(hh[1], w1[3][0], hh[0] * w0[3][0]));
-        const float t1 = nrw_combine(fmaf(hh[1], w1[0][1], fmaf(hh[0], w0[0][1], brr[1])), fmaf(hh[1], w1[1][1], hh[0] * w0[1][1]),
-                                     fmaf(hh[1], w1[2][1], hh[0] * w0[2][1]), fmaf(hh[1], w1[3][1], hh[0] * w0[3][1]));
-        eo.x = ev[kk].x + t0;
-        eo.y = ev[kk].y + t1;
+        v4f t = {ev[kk].x + brr[0], ev[kk].y + brr[1], 0.f, 0.f};
+        t = MFMA(wrA[0], hh[0], t);
+        t = MFMA(wrA[1], hh[1], t);
+        eo.x = t[0];
+        eo.y = t[1];
       }
       if (row_ok && kk < nv && !(NRW_ABL & 1)) LD::ustore(a.e_out, ugraph + m, loff, eo);
       if ((NRW_ABL & 1) && eo.x == 123.456f) LD::ustore(a.e_out, ugraph + m, loff, eo);
@@ -310,6 +311,7 @@ __global__ void __launch_bounds__(256, NRW_FWD_OCC) k_narrow_fwd(BlockArgs a) {
     for (int blk = blk0; blk < bfull; ++blk) block(blk, NRW_KB);
     if (blk1 > nfull && blk0 <= nfull) block(nfull, N - nfull * NRW_KB);   // the graph's ragged last block
   }
+  NSTMP(1);   // key loop
   // ---- merge the four key quarters (waves 1..3 -> LDS -> wave 0), write V_att / statistics ----
   __syncthreads();   // every wave is done with its K/V chunk: the area becomes the merge buffer
   float* mg = sm;    // [3][20][64]
@@ -350,14 +352,30 @@ __global__ void __launch_bounds__(256, NRW_FWD_OCC) k_narrow_fwd(BlockArgs a) {
       }
     }
   }
+  NSTMP(2);   // sync + merge of the key quarters
   // node-side epilogue on the 16 rows (its own lane roles: MFMA layout); its staging rows reuse the merge area
   if (a.epi && !(NRW_ABL & 32)) fwd_node_epilogue(a, sm, qs, b, lg, N, wave, lane & 15, lane >> 4);
+#ifdef NRW_TIMING
+  NSTMP(3);   // node-side epilogue
+  if (a.dbg && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = nacc[i];
+  }
+#endif
 }
 static_assert(4 * NRW_KV_CHUNK + 4 * NRW_KB <= NRW_FWD_AREA, "key-loop buffers fit the merge area");
 
 // a.epi must already hold the epilogue the geometry allows (launch_fwd decides)
+#ifdef NRW_TIMING
+static const char* const g_nf_names[] = {"constants + first requests", "key loop", "sync + merge", "node-side epilogue"};
+static NrwTimer g_nf{"k_narrow_fwd", g_nf_names, 4};
+#endif
 void egt_narrow_launch_fwd(BlockArgs& a, hipStream_t st) {
   const dim3 grid(a.B * ((a.N + 15) / 16)), block(256);
+#ifdef NRW_TIMING
+  { static bool reg = false; if (!reg) { reg = true; atexit([] { g_nf.report(); }); } }
+  a.dbg = g_nf.attach(grid.x);
+#endif
   static const size_t pad = getenv("EGT_NRW_LDS_PAD") ? (size_t)atoi(getenv("EGT_NRW_LDS_PAD")) : 0;   // occupancy experiments only
   const size_t lds = ((size_t)NRW_FWD_AREA + 16 * QS_LD + 80) * 4 + pad;
   const int full = NRW_F_GATED | NRW_F_CLIP;
@@ -366,6 +384,9 @@ void egt_narrow_launch_fwd(BlockArgs& a, hipStream_t st) {
   if (a.bf16) { if (feat == full) NRW_FWD(true, NRW_F_GATED | NRW_F_CLIP); else NRW_FWD(true, NRW_F_RUNTIME); }
   else { if (feat == full) NRW_FWD(false, NRW_F_GATED | NRW_F_CLIP); else NRW_FWD(false, NRW_F_RUNTIME); }
 #undef NRW_FWD
+#ifdef NRW_TIMING
+  g_nf.collect(grid.x, st);
+#endif
 }
 
 // ------------------------------------------------------------------- backward, matrix-core lanes ---
@@ -382,22 +403,8 @@ void egt_narrow_launch_fwd(BlockArgs& a, hipStream_t st) {
 // share ONE buffer (DS operations of a wave execute in order).  ~12 KB of LDS per wave and <= 168 VGPRs: THREE workgroups per CU.
 // A key tile shared by two waves (balanced ranges) is parked in its final dkvp slot by the later wave and completed by the
 // earlier one (both waves sit on one CU: plain stores, acknowledged before an LDS flag goes up; no LDS park area).
-#ifdef NRW_TIMING   // measurement builds (EGT_NARROW_FLAGS=-DNRW_TIMING): per-wave cycle sums of the kernel's sections, printed at exit
-#define NSTMP(i) do { const unsigned tn__ = (unsigned)__builtin_amdgcn_s_memtime(); nacc[i] += tn__ - nlast; nlast = tn__; } while (0)
-#else
-#define NSTMP(i) do {} while (0)
-#endif
 #define NRW_OPW 20                                   // row stride of the operand tile (floats): 16-byte aligned rows, spread banks
 #define NRW_M_WAVE (2048 + 16 * NRW_OPW)             // floats per wave: K [4][64][4] | V [4][64][4] | operand tile [16][NRW_OPW]
-__device__ __forceinline__ float nrw_sum4rows(float v) { return sum_xor32(sum_xor16(v)); }
-// both sums in every lane: 7 instructions for the pair (reduce-scatter over lane bit 5, reduce over bit 4, all-gather)
-__device__ __forceinline__ void nrw_sum4rows_pair(float& x, float& y) {
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);   // [x.lo | y.lo], [x.hi | y.hi]
-  float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);                                             // lanes < 32: x over bit 5; >= 32: y
-  s = sum_xor16(s);
-  auto g = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-  x = __uint_as_float(g[0]); y = __uint_as_float(g[1]);
-}
 template <bool BF, int FEAT>
 __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
   seed_from_device(a);
@@ -438,7 +445,18 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
   NSTMP(0);   // staging issued
   if (a.pro) {
     __syncthreads();
+#if defined(NRW_TIMING) && defined(EGT_BWD_TIMING)
+    unsigned tpv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned tp_in = (unsigned)__builtin_amdgcn_s_memtime();
+    bwd_node_prologue<NRW_DE>(a, sm, qd, b, l_begin, wg, tpv);
+    const unsigned tp_out = (unsigned)__builtin_amdgcn_s_memtime();
+    if (a.dbg2 && lane == 0 && a.pro == 2) {
+      unsigned* o = a.dbg2 + ((size_t)blockIdx.x * 4 + wave) * 8;
+      o[0] = tpv[0] - tp_in; for (int i = 1; i < 6; ++i) o[i] = tpv[i] - tpv[i - 1]; o[6] = tp_out - tpv[5];
+    }
+#else
     bwd_node_prologue<NRW_DE>(a, sm, qd, b, l_begin, wg);
+#endif
   }
   __syncthreads();   // prologue scratch dead, qd rows complete
   NSTMP(1);   // node-side prologue
@@ -700,6 +718,8 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
 
 #ifdef NRW_TIMING
 static unsigned* g_nt_dev = nullptr;
+static unsigned* g_nt_dev2 = nullptr;
+static double g_nt2_sum[8];
 static int g_nt_n = 0;
 static double g_nt_sum[8];
 static long g_nt_launch = 0, g_nt_waves = 0;
@@ -709,6 +729,8 @@ static void nrw_timing_report() {
   double tot = 0; for (int i = 0; i < 6; ++i) tot += g_nt_sum[i];
   fprintf(stderr, "[egt] k_narrow_bwd section cycles per wave (mean over %ld waves, %ld launches; total %.0f):\n", g_nt_waves, g_nt_launch, tot / g_nt_waves);
   for (int i = 0; i < 6; ++i) fprintf(stderr, "    %-30s %10.0f  (%.1f %%)\n", nm[i], g_nt_sum[i] / g_nt_waves, 100.0 * g_nt_sum[i] / tot);
+  fprintf(stderr, "    prologue (pro = 2 launches, per wave): load issue %.0f | first round trip -> rows in LDS %.0f | sync + LN fwd + 48 MFMA %.0f | dQKV out + sync + LN bwd + col sums %.0f | wo/va + sync %.0f | 16 MFMA + delta partials %.0f | dbo + sync + delta %.0f\n",
+          g_nt2_sum[0] / g_nt_waves, g_nt2_sum[1] / g_nt_waves, g_nt2_sum[2] / g_nt_waves, g_nt2_sum[3] / g_nt_waves, g_nt2_sum[4] / g_nt_waves, g_nt2_sum[5] / g_nt_waves, g_nt2_sum[6] / g_nt_waves);
 }
 #endif
 
@@ -727,10 +749,13 @@ void egt_narrow_launch_bwd(BlockArgs& a, int nwg, hipStream_t st) {
   if (g_nt_n < nwg) {
     if (g_nt_dev) (void)hipFree(g_nt_dev);
     (void)hipMalloc(&g_nt_dev, (size_t)nwg * 32 * sizeof(unsigned));
+    if (g_nt_dev2) (void)hipFree(g_nt_dev2);
+    (void)hipMalloc(&g_nt_dev2, (size_t)nwg * 32 * sizeof(unsigned));
+    (void)hipMemset(g_nt_dev2, 0, (size_t)nwg * 32 * sizeof(unsigned));
     if (!g_nt_n) atexit(nrw_timing_report);
     g_nt_n = nwg;
   }
-  a.dbg = g_nt_dev;
+  a.dbg = g_nt_dev; a.dbg2 = g_nt_dev2;
 #endif
   if (a.bf16) { if (feat == full) NRW_BWD(true, NRW_F_GATED | NRW_F_CLIP); else NRW_BWD(true, NRW_F_RUNTIME); }
   else { if (feat == full) NRW_BWD(false, NRW_F_GATED | NRW_F_CLIP); else NRW_BWD(false, NRW_F_RUNTIME); }
@@ -742,6 +767,8 @@ void egt_narrow_launch_bwd(BlockArgs& a, int nwg, hipStream_t st) {
     if (hn < nwg) { free(h); h = (unsigned*)malloc((size_t)nwg * 32 * sizeof(unsigned)); hn = nwg; }
     (void)hipMemcpy(h, g_nt_dev, (size_t)nwg * 32 * sizeof(unsigned), hipMemcpyDeviceToHost);
     for (int w = 0; w < nwg * 4; ++w) { for (int i = 0; i < 8; ++i) g_nt_sum[i] += h[w * 8 + i]; ++g_nt_waves; }
+    (void)hipMemcpy(h, g_nt_dev2, (size_t)nwg * 32 * sizeof(unsigned), hipMemcpyDeviceToHost);
+    for (int w = 0; w < nwg * 4; ++w) for (int i = 0; i < 8; ++i) g_nt2_sum[i] += h[w * 8 + i];
   }
 #endif
 }
