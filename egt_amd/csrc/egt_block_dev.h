@@ -186,6 +186,12 @@ __device__ __forceinline__ void fwd_node_epilogue(const BlockArgs& a, float* sm,
     }
   }
 
+// the barriers of fwd_node_epilogue, for waves of a workgroup that take no part in it (a.epi is uniform)
+__device__ __forceinline__ void fwd_node_epilogue_idle(const BlockArgs& a) {
+  __syncthreads();
+  if (a.epi == 2) { __syncthreads(); __syncthreads(); }
+}
+
 #define QD_LD 160  // per row: Q[64] | dV_att[64] | stats[32]
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 

@@ -121,17 +121,18 @@ template <> struct NrwLd<true> {
 #define NRW_F_RUNTIME (-1)
 
 // ------------------------------------------------------------------------------------ forward ---
-// Workgroup = (graph b, 16 query rows), 4 waves = the four quarters of the key range.  A step = one block of
-// NRW_KB keys: logits of the four keys first, then ONE softmax rescale for the block (flash-style blocking).
-// LDS: [NRW_FWD_AREA] = [4 waves][NRW_KV_CHUNK] K/V chunks + [4][NRW_KB] key-mask adds during the key loop, the
-//      merge buffer [3][20][64] after it, then the epilogue's staging rows; [16][QS_LD] V_att rows for the epilogue.
-#define NRW_FWD_AREA ((3 * 20 * 64) > (4 * NRW_KV_CHUNK + 4 * NRW_KB) ? (3 * 20 * 64) : (4 * NRW_KV_CHUNK + 4 * NRW_KB))
+// Workgroup = (graph b, 16 query rows), NW waves = NW equal parts of the key range (NW = 4; 8 for launches of at most one
+// workgroup per CU -- BASELINE config 4 as specified, B = 16: 128 workgroups -- where the extra waves are free).  A step = one
+// block of NRW_KB keys: logits of the four keys first, then ONE softmax rescale for the block (flash-style blocking).
+// LDS: [NRW_FWD_AREA(NW)] = [NW waves][NRW_KV_CHUNK] K/V chunks + [NW][NRW_KB] key-mask adds during the key loop, the
+//      merge buffer [NW - 1][20][64] after it, then the epilogue's staging rows; [16][QS_LD] V_att rows for the epilogue.
+#define NRW_FWD_AREA(NW) ((((NW) - 1) * 20 * 64) > ((NW) * NRW_KV_CHUNK + (NW) * NRW_KB) ? (((NW) - 1) * 20 * 64) : ((NW) * NRW_KV_CHUNK + (NW) * NRW_KB))
 // Projections and dense_edge_r of a pair: two MFMAs each (4 A-operand registers).
 #ifndef NRW_FWDM_OCC
 #define NRW_FWDM_OCC 3
 #endif
-template <bool BF, int FEAT>
-__global__ void __launch_bounds__(256, NRW_FWDM_OCC) k_narrow_fwd(BlockArgs a) {
+template <bool BF, int FEAT, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_fwd(BlockArgs a) {
   seed_from_device(a);
 #ifdef NRW_TIMING
   unsigned nacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nlast = (unsigned)__builtin_amdgcn_s_memtime();
@@ -146,8 +147,8 @@ __global__ void __launch_bounds__(256, NRW_FWDM_OCC) k_narrow_fwd(BlockArgs a) {
   int b, lg;
   egt_group_order(wg, a.B, lgroups, N, b, lg);
   float* kvw = sm + wave * NRW_KV_CHUNK;
-  float* kmw = sm + 4 * NRW_KV_CHUNK + wave * NRW_KB;
-  float* qs = sm + NRW_FWD_AREA;
+  float* kmw = sm + NW * NRW_KV_CHUNK + wave * NRW_KB;
+  float* qs = sm + NRW_FWD_AREA(NW);
   const bool gated = FEAT >= 0 ? (FEAT & NRW_F_GATED) != 0 : (a.flags & EGT_BF_GATE) != 0;
   const bool clip = FEAT >= 0 ? (FEAT & NRW_F_CLIP) != 0 : (a.flags & EGT_BF_CLIP) != 0;
   const bool ln_on = (a.flags & EGT_BF_NO_EDGE_LN) == 0;
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(256, NRW_FWDM_OCC) k_narrow_fwd(BlockArgs a) {
 
   // ---- the wave's key blocks ----
   const int nblk = (N + NRW_KB - 1) / NRW_KB;
-  const int blk0 = (wave * nblk) >> 2, blk1 = ((wave + 1) * nblk) >> 2;
+  const int blk0 = (wave * nblk) / NW, blk1 = ((wave + 1) * nblk) / NW;
   float mx[2] = {-3.0e38f, -3.0e38f}, sum[2] = {0.f, 0.f}, O[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) O[k] = 0.f;
@@ -312,9 +313,9 @@ __global__ void __launch_bounds__(256, NRW_FWDM_OCC) k_narrow_fwd(BlockArgs a) {
     if (blk1 > nfull && blk0 <= nfull) block(nfull, N - nfull * NRW_KB);   // the graph's ragged last block
   }
   NSTMP(1);   // key loop
-  // ---- merge the four key quarters (waves 1..3 -> LDS -> wave 0), write V_att / statistics ----
+  // ---- merge the key ranges (waves 1 .. NW-1 -> LDS -> wave 0), write V_att / statistics ----
   __syncthreads();   // every wave is done with its K/V chunk: the area becomes the merge buffer
-  float* mg = sm;    // [3][20][64]
+  float* mg = sm;    // [NW - 1][20][64]
   if (wave > 0) {
     float* o = mg + (wave - 1) * 20 * 64 + lane;
     o[0] = mx[0]; o[64] = mx[1]; o[128] = sum[0]; o[192] = sum[1];
@@ -324,7 +325,7 @@ __global__ void __launch_bounds__(256, NRW_FWDM_OCC) k_narrow_fwd(BlockArgs a) {
   __syncthreads();
   if (wave == 0) {
 #pragma unroll
-    for (int w = 0; w < 3; ++w) {
+    for (int w = 0; w < NW - 1; ++w) {
       const float* o = mg + w * 20 * 64 + lane;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -354,16 +355,19 @@ __global__ void __launch_bounds__(256, NRW_FWDM_OCC) k_narrow_fwd(BlockArgs a) {
   }
   NSTMP(2);   // sync + merge of the key quarters
   // node-side epilogue on the 16 rows (its own lane roles: MFMA layout); its staging rows reuse the merge area
-  if (a.epi && !(NRW_ABL & 32)) fwd_node_epilogue(a, sm, qs, b, lg, N, wave, lane & 15, lane >> 4);
+  if (a.epi && !(NRW_ABL & 32)) {
+    if (NW == 4 || wave < 4) fwd_node_epilogue(a, sm, qs, b, lg, N, wave, lane & 15, lane >> 4);
+    else fwd_node_epilogue_idle(a);   // the epilogue is four waves' work: the others only meet its barriers
+  }
 #ifdef NRW_TIMING
   NSTMP(3);   // node-side epilogue
   if (a.dbg && lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = nacc[i];
+    for (int i = 0; i < 8; ++i) if (wave < 4) a.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = nacc[i];
   }
 #endif
 }
-static_assert(4 * NRW_KV_CHUNK + 4 * NRW_KB <= NRW_FWD_AREA, "key-loop buffers fit the merge area");
+static_assert(16 * QS_LD <= NRW_FWD_AREA(4), "the epilogue's staging rows fit the merge area");
 
 // a.epi must already hold the epilogue the geometry allows (launch_fwd decides)
 #ifdef NRW_TIMING
@@ -371,16 +375,21 @@ static const char* const g_nf_names[] = {"constants + first requests", "key loop
 static NrwTimer g_nf{"k_narrow_fwd", g_nf_names, 4};
 #endif
 void egt_narrow_launch_fwd(BlockArgs& a, hipStream_t st) {
-  const dim3 grid(a.B * ((a.N + 15) / 16)), block(256);
+  const dim3 grid(a.B * ((a.N + 15) / 16));
+  static const int nw_forced = getenv("EGT_NRW_FWD_WAVES") ? atoi(getenv("EGT_NRW_FWD_WAVES")) : 0;   // 4 | 8 (tests, A/B)
+  const bool w8 = nw_forced == 8 || (nw_forced != 4 && grid.x <= 256 && a.N >= 64);   // one workgroup per CU at most: eight key ranges
+  const dim3 block(w8 ? 512 : 256);
 #ifdef NRW_TIMING
   { static bool reg = false; if (!reg) { reg = true; atexit([] { g_nf.report(); }); } }
   a.dbg = g_nf.attach(grid.x);
 #endif
   static const size_t pad = getenv("EGT_NRW_LDS_PAD") ? (size_t)atoi(getenv("EGT_NRW_LDS_PAD")) : 0;   // occupancy experiments only
-  const size_t lds = ((size_t)NRW_FWD_AREA + 16 * QS_LD + 80) * 4 + pad;
+  const size_t lds = ((size_t)(w8 ? NRW_FWD_AREA(8) : NRW_FWD_AREA(4)) + 16 * QS_LD + 80) * 4 + pad;
   const int full = NRW_F_GATED | NRW_F_CLIP;
   const int feat = ((a.flags & EGT_BF_GATE) ? NRW_F_GATED : 0) | ((a.flags & EGT_BF_CLIP) ? NRW_F_CLIP : 0);
-#define NRW_FWD(BF_, FEAT_) do { if (pad) EGT_MAX_LDS_ONCE(k_narrow_fwd<BF_, FEAT_>); EGT_LAUNCH("k_block_fwd", (k_narrow_fwd<BF_, FEAT_>), grid, block, lds, st, a); } while (0)
+#define NRW_FWD(BF_, FEAT_) do { \
+    if (w8) { EGT_MAX_LDS_ONCE(k_narrow_fwd<BF_, FEAT_, 8>); EGT_LAUNCH("k_block_fwd", (k_narrow_fwd<BF_, FEAT_, 8>), grid, block, lds, st, a); } \
+    else { if (pad) EGT_MAX_LDS_ONCE(k_narrow_fwd<BF_, FEAT_, 4>); EGT_LAUNCH("k_block_fwd", (k_narrow_fwd<BF_, FEAT_, 4>), grid, block, lds, st, a); } } while (0)
   if (a.bf16) { if (feat == full) NRW_FWD(true, NRW_F_GATED | NRW_F_CLIP); else NRW_FWD(true, NRW_F_RUNTIME); }
   else { if (feat == full) NRW_FWD(false, NRW_F_GATED | NRW_F_CLIP); else NRW_FWD(false, NRW_F_RUNTIME); }
 #undef NRW_FWD

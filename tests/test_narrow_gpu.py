@@ -35,6 +35,14 @@ def test_mfma_tile_kernels_with_the_valu_kernels_off():
     _run({"EGT_NO_NARROW": "1"})
 
 
+@pytest.mark.parametrize("waves", ["4", "8"])
+def test_forward_waves_per_workgroup(waves):
+    """k_narrow_fwd splits a workgroup's key range over 4 waves, or over 8 when the launch has at most one workgroup per CU
+    (egt_narrow_launch_fwd).  The tiny test batches take 8 by default from N = 64 up; both sizes are forced here for every
+    geometry (8 waves on N = 37 leaves waves with an empty key range)."""
+    _run({"EGT_NRW_FWD_WAVES": waves})
+
+
 @pytest.mark.parametrize("rows", ["16", "4"])
 def test_backward_rows_per_workgroup(rows):
     """The De = 8 backward takes 16, 8 or 4 query rows per workgroup (egt_block.hip: bwd_rows_per_wg; small batches get 8 so
