@@ -23,7 +23,7 @@ ARCH = "gfx950"
 # accumulators compete for the same 256 AccVGPRs and 300+ registers spill; VGPR-form MFMA lets
 # the allocator park the long-lived tiles in AccVGPRs instead (0 spills).
 EXTRA_FLAGS = {"egt_ffn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-               # egt_narrow.hip: SLP-packed v_pk_add_f32 cannot take the DPP operand of the quad exchanges
+               # egt_narrow.hip: SLP-packed v_pk_add_f32 cannot take the DPP operand of the dQ reduction
                "egt_narrow.hip": ["-fno-slp-vectorize"]}
 if os.environ.get("EGT_BLOCK_FLAGS"):   # experiments: extra hipcc flags for egt_block.hip
     EXTRA_FLAGS["egt_block.hip"] = os.environ["EGT_BLOCK_FLAGS"].split()
