@@ -115,6 +115,36 @@ template <> struct NrwLd<true> {
   }
 };
 
+// ---- pair-local channel contractions on the matrix core ------------------------------------------------------------------
+// D[m][n] = C[m][n] + sum_k A[m][k] B[k][n], K <= 16, lane (p, q): A row m = p, B column n = p, contraction slots (q, i):
+//   fp32 edge tensors: K / 4 steps of v_mfma_f32_16x16x4_f32 (slot i = step i);
+//   bf16 edge tensors (BASELINE config 3: the reference computes these layers in bfloat16, mixed_bfloat16 policy): ONE
+//   v_mfma_f32_16x16x16_bf16 with the operands rounded to bfloat16 (fp32 accumulation) -- 16 issue cycles instead of K / 4 x 32.
+typedef short nrw_v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ nrw_v4s nrw_b4(uint32_t lo, uint32_t hi) { union { nrw_v4s v; uint32_t u[2]; } x; x.u[0] = lo; x.u[1] = hi; return x.v; }
+template <bool BF, int NS> struct NrwOp;                       // NS contraction slots per lane (2 or 4)
+template <int NS> struct NrwOp<false, NS> { float v[NS]; };
+template <int NS> struct NrwOp<true, NS> { nrw_v4s v; };
+template <bool BF> __device__ __forceinline__ NrwOp<BF, 2> nrw_op(float a, float b) {
+  NrwOp<BF, 2> o;
+  if constexpr (BF) o.v = nrw_b4(f2_to_bf2(a, b), 0u); else { o.v[0] = a; o.v[1] = b; }
+  return o;
+}
+template <bool BF> __device__ __forceinline__ NrwOp<BF, 4> nrw_op(float a, float b, float c, float d) {
+  NrwOp<BF, 4> o;
+  if constexpr (BF) o.v = nrw_b4(f2_to_bf2(a, b), f2_to_bf2(c, d)); else { o.v[0] = a; o.v[1] = b; o.v[2] = c; o.v[3] = d; }
+  return o;
+}
+__device__ __forceinline__ NrwOp<true, 2> nrw_op_raw(uint32_t bf2) { NrwOp<true, 2> o; o.v = nrw_b4(bf2, 0u); return o; }   // two bf16 values as they sit in memory
+template <bool BF, int NS> __device__ __forceinline__ v4f nrw_mm(const NrwOp<BF, NS>& A, const NrwOp<BF, NS>& B, v4f c) {
+  if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A.v, B.v, c, 0, 0, 0);
+  else {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) c = MFMA(A.v[i], B.v[i], c);
+    return c;
+  }
+}
+
 // feature sets with compile-time flags (the run-time flag tests cost scalar branches / selects in every step)
 #define NRW_F_GATED 1
 #define NRW_F_CLIP 2
@@ -167,13 +197,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
   // lane's four columns.  dense_edge_r: A[m][k = q] at step j = Wr[head 2q + j][channel of row m]; rows 4q', 4q'+1 of the result
   // carry channels 2q', 2q'+1 (rows 4q'+2, 4q'+3 unused: zero weights).
   const int jm = p & 3, cm = 2 * (p >> 2) + jm;
-  float pwA[2], wrA[2], brr[2];
+  float brr[2];
   v4f c2r;
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {
-    pwA[s2] = a.pw[(2 * q + s2) * 16 + p];
-    wrA[s2] = jm < 2 ? a.Wr[(2 * q + s2) * NRW_DE + cm] : 0.0f;
-  }
+  const NrwOp<BF, 2> pwA = nrw_op<BF>(a.pw[(2 * q) * 16 + p], a.pw[(2 * q + 1) * 16 + p]);
+  const NrwOp<BF, 2> wrA = nrw_op<BF>(jm < 2 ? a.Wr[(2 * q) * NRW_DE + cm] : 0.0f, jm < 2 ? a.Wr[(2 * q + 1) * NRW_DE + cm] : 0.0f);
 #pragma unroll
   for (int r = 0; r < 4; ++r) c2r[r] = a.pw[16 * 16 + 4 * q + r];
   brr[0] = a.br[2 * q]; brr[1] = a.br[2 * q + 1];
@@ -239,8 +266,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
       const float rstd = ln_on ? __builtin_amdgcn_rsqf(var + a.ln_eps) : 1.0f;
       x0 *= rstd; x1 *= rstd;
       // ---- [attention_gates | dense_edge_b]: acc[r] = column 4q + r of the pair ----
-      v4f acc = MFMA(pwA[0], x0, c2r);
-      acc = MFMA(pwA[1], x1, acc);
+      const v4f acc = nrw_mm<BF, 2>(pwA, nrw_op<BF>(x0, x1), c2r);
       // ---- scaled QK^T, clip, + E (egt_layers.py:79-86) ----
       float Kf[16];
       {
@@ -267,8 +293,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
       float2 eo;
       {
         v4f t = {ev[kk].x + brr[0], ev[kk].y + brr[1], 0.f, 0.f};
-        t = MFMA(wrA[0], hh[0], t);
-        t = MFMA(wrA[1], hh[1], t);
+        t = nrw_mm<BF, 2>(wrA, nrw_op<BF>(hh[0], hh[1]), t);
         eo.x = t[0];
         eo.y = t[1];
       }
@@ -471,17 +496,14 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
   NSTMP(1);   // node-side prologue
   // ---- A operands (lane = row m = p of the product, k index q) and the accumulator preload ----
   const int jm = p & 3, hm = 2 * (p >> 2) + jm;   // rows 4q'+0, 4q'+1 of a result carry head / channel 2q'+0, 2q'+1; rows 4q'+2, 4q'+3 are unused
-  float pwA[2], wrA[2], wdA[4], c2r[4];
+  float c2r[4];
+  const NrwOp<BF, 2> pwA = nrw_op<BF>(a.pw[(2 * q) * 16 + p], a.pw[(2 * q + 1) * 16 + p]);           // [gates | E] column p from channels 2q, 2q+1
+  const NrwOp<BF, 2> wrA = nrw_op<BF>(jm < 2 ? a.Wr[hm * NRW_DE + 2 * q] : 0.0f,                       // dH_ext of head hm from de' channels 2q, 2q+1
+                                      jm < 2 ? a.Wr[hm * NRW_DE + 2 * q + 1] : 0.0f);
+  const NrwOp<BF, 4> wdA = nrw_op<BF>(jm < 2 ? a.pw[hm * 16 + 4 * q] : 0.0f, jm < 2 ? a.pw[hm * 16 + 4 * q + 1] : 0.0f,   // d ehat of channel hm from
+                                      jm < 2 ? a.pw[hm * 16 + 4 * q + 2] : 0.0f, jm < 2 ? a.pw[hm * 16 + 4 * q + 3] : 0.0f);  // dGE columns 4q .. 4q+3
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    pwA[s] = a.pw[(2 * q + s) * 16 + p];                              // [gates | E] column p from channel 2q + s
-    wrA[s] = jm < 2 ? a.Wr[hm * NRW_DE + 2 * q + s] : 0.0f;           // dH_ext of head hm from de' channel 2q + s
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    wdA[r] = jm < 2 ? a.pw[hm * 16 + 4 * q + r] : 0.0f;               // d ehat of channel hm from dGE column 4q + r
-    c2r[r] = a.pw[16 * 16 + 4 * q + r];
-  }
+  for (int r = 0; r < 4; ++r) c2r[r] = a.pw[16 * 16 + 4 * q + r];
   v4f accT = {0.f, 0.f, 0.f, 0.f}, accR = {0.f, 0.f, 0.f, 0.f};
   float ssum[4] = {0.f, 0.f, 0.f, 0.f};
   const float hcst = p == 8 ? 1.0f : 0.0f;   // columns 8..15 of the [H_hat | 1] operand
@@ -541,6 +563,7 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
       const int l = l_begin + li;
       const uint32_t pair = pcol + (uint32_t)(l * N);
       float2 ev = LD::cvt(en[0]), dyv = LD::cvt(dn[0]);
+      const typename LD::raw dyraw = dn[0];
       en[0] = en[1]; dn[0] = dn[1];
       request(1);
       if (!kvalid) { ev = make_float2(0.f, 0.f); dyv = make_float2(0.f, 0.f); }   // a key past N: zero tile row
@@ -552,12 +575,10 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
       const float rstd = ln_on ? __builtin_amdgcn_rsqf(var + a.ln_eps) : 1.0f;
       x0 *= rstd; x1 *= rstd;
       // ---- projections (acc[r] = column 4q + r) and dH_ext (dhx[j] = head 2q + j) on the matrix core ----
-      v4f acc = {c2r[0], c2r[1], c2r[2], c2r[3]};
-      acc = MFMA(pwA[0], x0, acc);
-      acc = MFMA(pwA[1], x1, acc);
-      v4f dh4 = {0.f, 0.f, 0.f, 0.f};
-      dh4 = MFMA(wrA[0], dyv.x, dh4);
-      dh4 = MFMA(wrA[1], dyv.y, dh4);
+      const v4f acc = nrw_mm<BF, 2>(pwA, nrw_op<BF>(x0, x1), (v4f){c2r[0], c2r[1], c2r[2], c2r[3]});
+      v4f dh4;
+      if constexpr (BF) dh4 = nrw_mm<true, 2>(wrA, nrw_op_raw(kvalid ? dyraw : 0u), (v4f){0.f, 0.f, 0.f, 0.f});   // de' is bfloat16 in memory already
+      else dh4 = nrw_mm<false, 2>(wrA, nrw_op<false>(dyv.x, dyv.y), (v4f){0.f, 0.f, 0.f, 0.f});
       // ---- weight-gradient operand A = [xhat | de'] of the step's 16 pairs (transposed through the operand tile) ----
       float wa[4], wb1[4], wb2[4];
       *reinterpret_cast<float2*>(op + p * NRW_OPW + 2 * q) = make_float2(x0, x1);
@@ -634,9 +655,7 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
       for (int s4 = 0; s4 < 4; ++s4) { const float t = op[(4 * s4 + q) * NRW_OPW + p]; wb2[s4] = p < 8 ? t : hcst; }
       asm volatile("" ::: "memory");   // the next step's tile writes stay behind these reads
       // ---- d ehat = Wp'.dGE (channels 2q, 2q+1 in d4[0], d4[1]) ----
-      v4f d4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) d4 = MFMA(wdA[r], dge[r], d4);
+      const v4f d4 = nrw_mm<BF, 4>(wdA, nrw_op<BF>(dge[0], dge[1], dge[2], dge[3]), (v4f){0.f, 0.f, 0.f, 0.f});
       // ---- dQ of the row over this tile's 16 keys -> HBM (summed over key tiles by the next prologue / k_node_bwd) ----
 #pragma unroll
       for (int k = 0; k < 8; ++k) { dq[2 * k] *= dA[0]; dq[2 * k + 1] *= dA[1]; }
@@ -651,8 +670,11 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
         dVa[4*u+2] = fmaf(at[0], w.z, dVa[4*u+2]); dVa[4*u+3] = fmaf(at[1], w.w, dVa[4*u+3]);
       }
       // ---- weight gradients over the step's 16 pairs: T += [xhat | de']^T.dGE, R += [xhat | de']^T.[H_hat | 1] ----
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) { accT = MFMA(wa[s4], wb1[s4], accT); accR = MFMA(wa[s4], wb2[s4], accR); }
+      {
+        const NrwOp<BF, 4> oa = nrw_op<BF>(wa[0], wa[1], wa[2], wa[3]);
+        accT = nrw_mm<BF, 4>(oa, nrw_op<BF>(wb1[0], wb1[1], wb1[2], wb1[3]), accT);
+        accR = nrw_mm<BF, 4>(oa, nrw_op<BF>(wb2[0], wb2[1], wb2[2], wb2[3]), accR);
+      }
       // ---- LayerNorm backward; de = de' + ... ----
       {
         float m1 = d4[0] + d4[1], m2 = fmaf(d4[0], x0, d4[1] * x1);
