@@ -2060,10 +2060,11 @@ struct BlockLayout {
 //    partial sums) takes over (B = 128, N = 150: 225 us at 16 rows, 253 at 12, 295 at 8).
 // EGT_BWD_TL = 4 .. 16 overrides (tests, sweeps: tools/dbg/nrw_tlsweep.sh).
 static int bwd_rows_per_wg(const egt_block_desc* d) {
-  if (d->De != 8) return BWD_TL;
   static const int forced = getenv("EGT_BWD_TL") ? atoi(getenv("EGT_BWD_TL")) : 0;
-  if (forced >= 4 && forced <= BWD_TL) return forced;
+  static const bool wide_eq = !(getenv("EGT_BWD_EQ_WIDE") && atoi(getenv("EGT_BWD_EQ_WIDE")) == 0);   // A/B: equal groups for De > 8
   const int groups = (d->N + BWD_TL - 1) / BWD_TL;
+  if (d->De != 8) return wide_eq ? (d->N + groups - 1) / groups : BWD_TL;   // equal groups (16 whenever N is a multiple of 16)
+  if (forced >= 4 && forced <= BWD_TL) return forced;
   if (d->B * groups <= 256) return d->N > 8 ? 8 : BWD_TL;
   return (d->N + groups - 1) / groups;
 }
