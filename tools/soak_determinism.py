@@ -14,11 +14,12 @@ from egt_amd import EGTStack  # noqa: E402
 def main():
     dev = torch.device("cuda", 0)
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    # optional: workload = "zinc" (headline, default) | "cifar" (config 3: N = 150, De = 8, bf16 -- the VALU kernels with the
-    # balanced ranges and their LDS park / pick-up hand-off) | "cifar32" (the same in fp32: v4r)
+    # optional: workload = "zinc" (headline, default) | "cifar" (config 3: N = 150, De = 8, bf16 -- the De = 8 kernels with the
+    # balanced ranges and their shared-tile hand-off through the dkvp slot) | "cifar32" (the same in fp32) |
+    # "pattern16" (config 4 as specified: B = 16, N = 120 -- 8-row backward workgroups, 8-wave forward workgroups)
     wl = sys.argv[2] if len(sys.argv) > 2 else "zinc"
     torch.manual_seed(0)
-    B, N, Ly, De, lo, hi = (128, 64, 10, 64, 9, 38) if wl == "zinc" else (64, 150, 4, 8, 85, 151)
+    B, N, Ly, De, lo, hi = (128, 64, 10, 64, 9, 38) if wl == "zinc" else (16, 120, 4, 8, 44, 121) if wl == "pattern16" else (64, 150, 4, 8, 85, 151)
     st = EGTStack(model_height=Ly, model_width=64, edge_width=De, num_heads=8, random_mask_prob=0.1, seed=3,
                   fused=True).to(dev).train()
     g = torch.Generator().manual_seed(1)
