@@ -122,6 +122,22 @@ template <> struct NrwLd<true> {
 //   v_mfma_f32_16x16x16_bf16 with the operands rounded to bfloat16 (fp32 accumulation) -- 16 issue cycles instead of K / 4 x 32.
 typedef short nrw_v4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ nrw_v4s nrw_b4(uint32_t lo, uint32_t hi) { union { nrw_v4s v; uint32_t u[2]; } x; x.u[0] = lo; x.u[1] = hi; return x.v; }
+// Which contractions take bf16 MFMAs when the edge tensors are bf16:
+//   gradient path (dH_ext, d ehat, the weight-gradient products): yes -- rounding there is unbiased noise on sums;
+//   value path (the [gates | E] projections and dense_edge_r, forward AND the backward's recompute): NO by default.  Their
+//   rounding (2^-9 of a logit) compounds through the per-layer LayerNorm over 8 channels: at three layers 2 of 110 k
+//   outputs left SURVEY 8(c)'s bf16 tolerance by 1.8 x (tools/sweep_de8.py: ungated, N = 39, B = 9, Ly = 3); -DNRW_BF16_VALUES
+//   turns them on (config 3: another 6 us per forward, 4 us per backward launch).
+#ifdef NRW_F32_MMA_ONLY   // A/B and parity triage: fp32 MFMAs for bf16 edge tensors too
+#define NRW_MMA_BF(BF) false
+#else
+#define NRW_MMA_BF(BF) (BF)
+#endif
+#if defined(NRW_BF16_VALUES) && !defined(NRW_F32_MMA_ONLY)
+#define NRW_MMA_BF_VALUES(BF) (BF)
+#else
+#define NRW_MMA_BF_VALUES(BF) false
+#endif
 template <bool BF, int NS> struct NrwOp;                       // NS contraction slots per lane (2 or 4)
 template <int NS> struct NrwOp<false, NS> { float v[NS]; };
 template <int NS> struct NrwOp<true, NS> { nrw_v4s v; };
@@ -168,6 +184,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
   unsigned nacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nlast = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
   typedef NrwLd<BF> LD;
+  constexpr bool MV = NRW_MMA_BF_VALUES(BF);   // bf16 MFMAs for the value path (projections, dense_edge_r): off by default, see NRW_MMA_BF_VALUES
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p = lane & 15, q = lane >> 4;   // matrix-core lanes
@@ -199,8 +216,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
   const int jm = p & 3, cm = 2 * (p >> 2) + jm;
   float brr[2];
   v4f c2r;
-  const NrwOp<BF, 2> pwA = nrw_op<BF>(a.pw[(2 * q) * 16 + p], a.pw[(2 * q + 1) * 16 + p]);
-  const NrwOp<BF, 2> wrA = nrw_op<BF>(jm < 2 ? a.Wr[(2 * q) * NRW_DE + cm] : 0.0f, jm < 2 ? a.Wr[(2 * q + 1) * NRW_DE + cm] : 0.0f);
+  const NrwOp<MV, 2> pwA = nrw_op<MV>(a.pw[(2 * q) * 16 + p], a.pw[(2 * q + 1) * 16 + p]);
+  const NrwOp<MV, 2> wrA = nrw_op<MV>(jm < 2 ? a.Wr[(2 * q) * NRW_DE + cm] : 0.0f, jm < 2 ? a.Wr[(2 * q + 1) * NRW_DE + cm] : 0.0f);
 #pragma unroll
   for (int r = 0; r < 4; ++r) c2r[r] = a.pw[16 * 16 + 4 * q + r];
   brr[0] = a.br[2 * q]; brr[1] = a.br[2 * q + 1];
@@ -266,7 +283,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
       const float rstd = ln_on ? __builtin_amdgcn_rsqf(var + a.ln_eps) : 1.0f;
       x0 *= rstd; x1 *= rstd;
       // ---- [attention_gates | dense_edge_b]: acc[r] = column 4q + r of the pair ----
-      const v4f acc = nrw_mm<BF, 2>(pwA, nrw_op<BF>(x0, x1), c2r);
+      const v4f acc = nrw_mm<MV, 2>(pwA, nrw_op<MV>(x0, x1), c2r);
       // ---- scaled QK^T, clip, + E (egt_layers.py:79-86) ----
       float Kf[16];
       {
@@ -293,7 +310,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
       float2 eo;
       {
         v4f t = {ev[kk].x + brr[0], ev[kk].y + brr[1], 0.f, 0.f};
-        t = nrw_mm<BF, 2>(wrA, nrw_op<BF>(hh[0], hh[1]), t);
+        t = nrw_mm<MV, 2>(wrA, nrw_op<MV>(hh[0], hh[1]), t);
         eo.x = t[0];
         eo.y = t[1];
       }
@@ -446,6 +463,7 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
   unsigned nacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nlast = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
   typedef NrwLd<BF> LD;
+  constexpr bool MV = NRW_MMA_BF_VALUES(BF), MB = NRW_MMA_BF(BF);   // bf16 MFMAs: value path (projection recompute) / gradient path
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p = lane & 15, q = lane >> 4;
@@ -497,10 +515,10 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
   // ---- A operands (lane = row m = p of the product, k index q) and the accumulator preload ----
   const int jm = p & 3, hm = 2 * (p >> 2) + jm;   // rows 4q'+0, 4q'+1 of a result carry head / channel 2q'+0, 2q'+1; rows 4q'+2, 4q'+3 are unused
   float c2r[4];
-  const NrwOp<BF, 2> pwA = nrw_op<BF>(a.pw[(2 * q) * 16 + p], a.pw[(2 * q + 1) * 16 + p]);           // [gates | E] column p from channels 2q, 2q+1
-  const NrwOp<BF, 2> wrA = nrw_op<BF>(jm < 2 ? a.Wr[hm * NRW_DE + 2 * q] : 0.0f,                       // dH_ext of head hm from de' channels 2q, 2q+1
+  const NrwOp<MV, 2> pwA = nrw_op<MV>(a.pw[(2 * q) * 16 + p], a.pw[(2 * q + 1) * 16 + p]);           // [gates | E] column p from channels 2q, 2q+1
+  const NrwOp<MB, 2> wrA = nrw_op<MB>(jm < 2 ? a.Wr[hm * NRW_DE + 2 * q] : 0.0f,                       // dH_ext of head hm from de' channels 2q, 2q+1
                                       jm < 2 ? a.Wr[hm * NRW_DE + 2 * q + 1] : 0.0f);
-  const NrwOp<BF, 4> wdA = nrw_op<BF>(jm < 2 ? a.pw[hm * 16 + 4 * q] : 0.0f, jm < 2 ? a.pw[hm * 16 + 4 * q + 1] : 0.0f,   // d ehat of channel hm from
+  const NrwOp<MB, 4> wdA = nrw_op<MB>(jm < 2 ? a.pw[hm * 16 + 4 * q] : 0.0f, jm < 2 ? a.pw[hm * 16 + 4 * q + 1] : 0.0f,   // d ehat of channel hm from
                                       jm < 2 ? a.pw[hm * 16 + 4 * q + 2] : 0.0f, jm < 2 ? a.pw[hm * 16 + 4 * q + 3] : 0.0f);  // dGE columns 4q .. 4q+3
 #pragma unroll
   for (int r = 0; r < 4; ++r) c2r[r] = a.pw[16 * 16 + 4 * q + r];
@@ -575,9 +593,9 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
       const float rstd = ln_on ? __builtin_amdgcn_rsqf(var + a.ln_eps) : 1.0f;
       x0 *= rstd; x1 *= rstd;
       // ---- projections (acc[r] = column 4q + r) and dH_ext (dhx[j] = head 2q + j) on the matrix core ----
-      const v4f acc = nrw_mm<BF, 2>(pwA, nrw_op<BF>(x0, x1), (v4f){c2r[0], c2r[1], c2r[2], c2r[3]});
+      const v4f acc = nrw_mm<MV, 2>(pwA, nrw_op<MV>(x0, x1), (v4f){c2r[0], c2r[1], c2r[2], c2r[3]});
       v4f dh4;
-      if constexpr (BF) dh4 = nrw_mm<true, 2>(wrA, nrw_op_raw(kvalid ? dyraw : 0u), (v4f){0.f, 0.f, 0.f, 0.f});   // de' is bfloat16 in memory already
+      if constexpr (MB) dh4 = nrw_mm<true, 2>(wrA, nrw_op_raw(kvalid ? dyraw : 0u), (v4f){0.f, 0.f, 0.f, 0.f});   // de' is bfloat16 in memory already
       else dh4 = nrw_mm<false, 2>(wrA, nrw_op<false>(dyv.x, dyv.y), (v4f){0.f, 0.f, 0.f, 0.f});
       // ---- weight-gradient operand A = [xhat | de'] of the step's 16 pairs (transposed through the operand tile) ----
       float wa[4], wb1[4], wb2[4];
@@ -655,7 +673,7 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
       for (int s4 = 0; s4 < 4; ++s4) { const float t = op[(4 * s4 + q) * NRW_OPW + p]; wb2[s4] = p < 8 ? t : hcst; }
       asm volatile("" ::: "memory");   // the next step's tile writes stay behind these reads
       // ---- d ehat = Wp'.dGE (channels 2q, 2q+1 in d4[0], d4[1]) ----
-      const v4f d4 = nrw_mm<BF, 4>(wdA, nrw_op<BF>(dge[0], dge[1], dge[2], dge[3]), (v4f){0.f, 0.f, 0.f, 0.f});
+      const v4f d4 = nrw_mm<MB, 4>(wdA, nrw_op<MB>(dge[0], dge[1], dge[2], dge[3]), (v4f){0.f, 0.f, 0.f, 0.f});
       // ---- dQ of the row over this tile's 16 keys -> HBM (summed over key tiles by the next prologue / k_node_bwd) ----
 #pragma unroll
       for (int k = 0; k < 8; ++k) { dq[2 * k] *= dA[0]; dq[2 * k + 1] *= dA[1]; }
@@ -671,9 +689,9 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
       }
       // ---- weight gradients over the step's 16 pairs: T += [xhat | de']^T.dGE, R += [xhat | de']^T.[H_hat | 1] ----
       {
-        const NrwOp<BF, 4> oa = nrw_op<BF>(wa[0], wa[1], wa[2], wa[3]);
-        accT = nrw_mm<BF, 4>(oa, nrw_op<BF>(wb1[0], wb1[1], wb1[2], wb1[3]), accT);
-        accR = nrw_mm<BF, 4>(oa, nrw_op<BF>(wb2[0], wb2[1], wb2[2], wb2[3]), accR);
+        const NrwOp<MB, 4> oa = nrw_op<MB>(wa[0], wa[1], wa[2], wa[3]);
+        accT = nrw_mm<MB, 4>(oa, nrw_op<MB>(wb1[0], wb1[1], wb1[2], wb1[3]), accT);
+        accR = nrw_mm<MB, 4>(oa, nrw_op<MB>(wb2[0], wb2[1], wb2[2], wb2[3]), accR);
       }
       // ---- LayerNorm backward; de = de' + ... ----
       {

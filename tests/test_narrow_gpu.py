@@ -81,10 +81,16 @@ PMAP = {"norm_edge.gamma": ("norm_edge", "gamma"), "norm_edge.beta": ("norm_edge
     ("plain", 70, 64, False, False),
     ("plain", 7, 64, False, False)])         # fewer keys than one wave's share: empty key ranges in the forward
 def test_narrow_kernel_branches_vs_oracle(variant, N, Dh, bf16, train, gpu, egt_lib):
+    check_de8_stack(variant, N, Dh, bf16, train, gpu)
+
+
+def check_de8_stack(variant, N, Dh, bf16, train, gpu, B=2, Ly=2):
+    """One De = 8 stack (forward + backward, every input and parameter gradient) against the fp64 oracle; also the body of
+    tools/sweep_de8.py's random geometries."""
     from egt_amd import EGTStack
     from egt_amd.fused import layer_seed
     from oracle import egt_oracle as O, rng_ref
-    B, Ly, p, De = 2, 2, 0.2, 8
+    p, De = 0.2, 8
     kw, okw = {}, {}
     if variant == "ungated":
         kw["gate_attention"] = False; okw["gate_attention"] = False
@@ -104,7 +110,7 @@ def test_narrow_kernel_branches_vs_oracle(variant, N, Dh, bf16, train, gpu, egt_
     dh = torch.randn(B, N, Dh, generator=g); de = torch.randn(B, N, N, De, generator=g)
     if bf16:
         e, de = e.bfloat16(), de.bfloat16()
-    mask = torch.ones(B, N, dtype=torch.bool); mask[1, max(1, N - 3):] = False
+    mask = torch.ones(B, N, dtype=torch.bool); mask[B - 1, max(1, N - 3):] = False
     hg = h.to(gpu).requires_grad_(); eg = e.to(gpu).requires_grad_()
     h2, e2 = st(hg, eg, mask.to(gpu))
     assert st.last_path == "fused-stack"
