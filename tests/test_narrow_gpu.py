@@ -35,6 +35,18 @@ def test_mfma_tile_kernels_with_the_valu_kernels_off():
     _run({"EGT_NO_NARROW": "1"})
 
 
+def test_random_de8_stacks_under_every_switch():
+    """tools/sweep_de8.py: random N / batch / variant / edge dtype / depth under four kernel-selection settings (a short run;
+    the tool takes a case count and EGT_SWEEP_SEED for longer ones)."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "sweep_de8.py"), "4"], cwd=REPO, env=env, capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "settings with failures: 0" in r.stdout
+
+
 @pytest.mark.parametrize("waves", ["4", "8"])
 def test_forward_waves_per_workgroup(waves):
     """k_narrow_fwd splits a workgroup's key range over 4 waves, or over 8 when the launch has at most one workgroup per CU
