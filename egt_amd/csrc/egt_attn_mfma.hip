@@ -1,25 +1,36 @@
-// Inner op, MFMA-tiled (flash-style) for the large-head geometry (d in {16,32,64}, H = 8):
+// Inner op on MFMA tiles (flash-style) for the large-head geometry (d in {16,32,64}, H = 8):
 //   (V_att, H_hat) = EGT([QKV, E?, G?, M?], mask)     lib/models/egt_layers.py:57-213
 // and its backward (SURVEY.md appendix A / egt_layers.py semantics under autodiff).
-// This is the shape where QK^T / A.V dominate (BASELINE config 5: N=512, d=64: fp32 arithmetic
-// intensity at the ridge), so every contraction runs on v_mfma_f32_16x16x4_f32 and the N x N
-// probabilities never exist outside registers.
+// This is the shape where QK^T / A.V carry the arithmetic (BASELINE config 5: N = 512, d = 64: fp32
+// arithmetic intensity at the ridge), so every contraction runs on v_mfma_f32_16x16x4_f32 (exact fp32)
+// and the N x N probabilities never exist outside registers.
 //
-// Layout decision: a pack kernel first rewrites Q/K/V (and dV_att) head-major, both row-major
-// [B,H,NP/16,d/16,16,16] and transposed [B,H,NP/16,d,16], both tile-major (NP = N rounded up to 16, zero padded).  With that,
-// EVERY MFMA operand that comes from Q/K/V/dO is one aligned 16-byte global load per four
-// contraction steps, straight into the lane that feeds the matrix core:
-//   operand "rows x contraction":  lane (row = lane&15, q = lane>>4) holds X[row][16T + 4q + u]
-//   (the contraction order kappa(T,u,q) = 16T + 4q + u is used on both operands, so it is free).
-// There is no LDS staging, no block barrier and no cross-wave dependency anywhere: a wave owns
-// one head, a workgroup (8 waves = 8 heads) one 16-row tile; the eight waves touch the same
-// 32-byte sectors of the [N,N,8] pair tensors, which the CU's vector L1 merges.
-// The pair-tensor elements of a lane sit in the MFMA accumulator layout (row = 4q + r), which is
-// exactly what the second contraction of each phase needs as its B operand: probabilities never
-// move between lanes.  Softmax reductions over the key axis are 3 in-lane ops + two permlane
-// swaps.
-// Attributes outside this cover (dropout, degree scalers, A_tild output, H != 8, other d) use
-// the general kernels of egt_attn.hip.
+// Round-4 structure (what bounds an fp32 MFMA kernel on gfx950: DESIGN.md 4.0 -- MFMA and VALU issue
+// ADD on a SIMD, everything else can hide):
+//   * a pack kernel rewrites Q (pre-scaled by d^-1/2), K, V, dV_att head-major and tile-major, row form
+//     [B,H,NP/16,d/16,16,16] and transposed form [B,H,NP/16,d,16]: EVERY MFMA operand that comes from
+//     them is one aligned 16-byte global load per four contraction steps, straight into the lane that
+//     feeds the matrix core (contraction order kappa(T,u,q) = 16T + 4q + u on both operands);
+//   * workgroup = (32-row block, 4 heads): 4 COMPUTE waves (one per SIMD, one head each) whose instruction
+//     stream is ds_read + MFMA + VALU only, and 4 LOADER waves that own every vector-memory instruction
+//     (one global_load in an fp32 MFMA stream costs its wave ~80 cycles of issue, a ds_read_b128 ~7; LDS-DMA
+//     loaders beside the compute waves cost them nothing: tools/micro/mfma_stream.hip).  A compute wave
+//     works on two 16-row tiles at once, so every operand fragment read from LDS feeds two MFMAs.  The
+//     [N,N,8] pair tensors cross the heads <-> pairs layout change through head-major LDS planes: a
+//     loader thread moves 16 bytes (4 heads of one pair) per tensor and 16 x 16 sub-tile, two iterations ahead;
+//   * ONE barrier per iteration and it does not drain the vector-memory queue (s_waitcnt lgkmcnt(0) +
+//     s_barrier, not __syncthreads): operand prefetches and output stores stay in flight across it;
+//   * the elementwise skeleton is cut to the arithmetic: additive masks from a per-key LDS table
+//     (0 / -1e9 / -3e38 for keys past N: no selects), v_med3 clip, exp2 with folded constants,
+//     v_rcp sigmoid, Q pre-scaled;
+//   * backward: K / V fragments and the dK / dV accumulators of two key tiles stay in registers while the
+//     workgroup walks the query tiles; the Q / dO tile of a query tile is staged ONCE by LDS-DMA and read
+//     in BOTH operand forms (row form b128, transposed form b32: no transposing MFMAs, no transposed
+//     arrays); planes are key-major there so a lane moves its four query rows with one ds_read_b128;
+//     dA = dH*c leaves in the lane's own layout (one 16-byte store) for k_attn_mfma_bwd_q, which is a
+//     pure operand-streaming MFMA kernel (no LDS, no barrier).
+// Attributes outside this cover (dropout, degree scalers, A_tild output, H != 8, other d) use the
+// general kernels of egt_attn.hip.
 #include <stdlib.h>
 
 #include "egt_common.h"
@@ -28,19 +39,13 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 #define AH 8
+#define L2E 1.4426950408889634f
+#define KEY_OFF (-3.0e38f)   // additive term of key slots past N (below every masked logit, above -inf)
 
-// packed operand arrays, each B*H*NP*d floats, in this order inside the workspace
-enum { PK_KH = 0, PK_VT, PK_QH, PK_QT, PK_KT, PK_VH, PK_OH, PK_OT, PK_COUNT };
-
-// Timing ablations of the forward (which term costs what): build with -DEGT_ATTN_ABLATION
-// (EGT_ATTN_FLAGS, build.py) and set EGT_ATTN_ABLATE=<bits> (1 K/V loads, 2 H_hat stores,
-// 4 pair-tile loads, 8 MFMAs, 16 barrier).  Compiled out otherwise: the always-taken branches
-// split basic blocks and cost 2-3 %.
-#ifdef EGT_ATTN_ABLATION
-#define ABL_ON(a, bit) (!((a).guard & (bit)))
-#else
-#define ABL_ON(a, bit) true
-#endif
+// packed operand arrays, each B*H*NP*d floats.  Forward workspace: K rows, V^T.  Backward workspace:
+// Q rows (pre-scaled), dO rows, K rows, V rows, K^T; then stats2 [B,H,NP,4] and dA [B,H,NP,NP].
+enum { PF_KH = 0, PF_VT, PF_COUNT };
+enum { PB_QH = 0, PB_OH, PB_KH, PB_VH, PB_KT, PB_COUNT };
 
 struct AttnMfmaArgs {
   int B, N, NP, d;
@@ -54,10 +59,32 @@ struct AttnMfmaArgs {
   float* pk;   // packed arrays
   // backward
   const float *v_att_in, *d_v_att, *d_h_ext;
-  float *d_qkv, *d_E, *d_G, *ws_dA;
+  float *d_qkv, *d_E, *d_G, *ws_dA, *stats2;
   int pack_bwd;
-  int guard;   // timing ablations (EGT_ATTN_ABLATE), 0 in production
 };
+
+// Phase stamps (-DEGT_ATTN_STAMPS via EGT_ATTN_FLAGS): s_memtime deltas of every wave of workgroup 0, summed per
+// phase, read back with egt_attn_mfma_read_stamps().  Compiled out otherwise.
+#ifdef EGT_ATTN_STAMPS
+__device__ long long g_attn_stamps[3][8][16];
+#define STAMP_DECL long long st_last = __builtin_readcyclecounter(), st_acc[16] = {}
+#define STAMP(i) do { const long long t__ = __builtin_readcyclecounter(); st_acc[i] += t__ - st_last; st_last = t__; } while (0)
+#define STAMP_OUT(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int i__ = 0; i__ < 16; ++i__) g_attn_stamps[k][threadIdx.x >> 6][i__] = st_acc[i__]; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_OUT(k)
+#endif
+// timing ablations (results are wrong): -DEGT_ATTN_ABL=<bits>: 1 no operand reloads, 2 no pair loads, 4 no output stores
+#ifndef EGT_ATTN_ABL
+#define EGT_ATTN_ABL 0
+#endif
+#define ABL(bit) ((EGT_ATTN_ABL & (bit)) == 0)
+
+// LDS hand-off between the waves of a workgroup WITHOUT draining vector memory: __syncthreads() is
+// s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier on gfx950; the operand prefetches and the output stores of
+// these kernels must stay in flight across the barrier, and nothing here communicates through global memory.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float pair_max_q(float v) {   // max over lanes l, l+16, l+32, l+48
   auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -66,22 +93,23 @@ __device__ __forceinline__ float pair_max_q(float v) {   // max over lanes l, l+
   return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 __device__ __forceinline__ float pair_sum_q(float v) { return sum_xor32(sum_xor16(v)); }
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // ------------------------------------------------------------------- pack --------
-// workgroup = (graph, 16 node rows): the rows' QKV (and dV_att) channels go through an LDS tile
-// and leave head-major.  Channel index of the source: c = s*d*H + k*H + h (egt_layers.py:70-76).
+// workgroup = (graph, 16 node rows, ONE section of [q | k | v | dO]): the rows' channels go through an LDS
+// tile and leave head-major.  Channel index of the source: c = s*d*H + k*H + h (egt_layers.py:70-76).
 template <int D>
 __global__ void __launch_bounds__(256) k_attn_pack(AttnMfmaArgs a) {
-  // workgroup = (graph, 16 node rows, ONE section of [q | k | v | dO]): forward packs k and v only
   constexpr int DH = D * AH, LD = DH + 4;
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [16][LD]
   const int N = a.N, NP = a.NP, tid = threadIdx.x;
   const int tiles = NP / 16;
   const bool bwd = a.pack_bwd != 0;
   const int nsec = bwd ? 4 : 2;
-  const int sec = bwd ? (int)(blockIdx.x % nsec) : (int)(blockIdx.x % nsec) + 1;
+  const int sec = bwd ? (int)(blockIdx.x % nsec) : (int)(blockIdx.x % nsec) + 1;   // 0 q, 1 k, 2 v, 3 dO
   const int tile = blockIdx.x / nsec;
   const int b = tile / tiles, n0 = (tile % tiles) * 16;
+  const float mul = sec == 0 ? a.scale : 1.0f;   // Q leaves pre-scaled: S = (d^-1/2 Q).K^T, dK = dA^T.(d^-1/2 Q)
   for (int i = tid; i < 16 * (DH / 4); i += 256) {
     const int r = i / (DH / 4), c = (i % (DH / 4)) * 4;
     const int n = n0 + r;
@@ -89,12 +117,13 @@ __global__ void __launch_bounds__(256) k_attn_pack(AttnMfmaArgs a) {
     if (n < N)
       v = sec < 3 ? *reinterpret_cast<const float4*>(a.qkv + ((size_t)b * N + n) * 3 * DH + sec * DH + c)
                   : *reinterpret_cast<const float4*>(a.d_v_att + ((size_t)b * N + n) * DH + c);
+    v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
     *reinterpret_cast<float4*>(sm + r * LD + c) = v;
   }
   __syncthreads();
   const size_t arr = (size_t)a.B * AH * NP * D;
-  // the staged rows -> [b,h,n/16,k/16,16 nodes,16 channels] array `which`: a wave's
-  // operand fetch (16 nodes x 16 channels of one k-tile) is ONE contiguous 1 KB block
+  // the staged rows -> [b,h,n/16,k/16,16 nodes,16 channels] array `which`: a wave's operand fetch (16 nodes x
+  // 16 channels of one k-tile) is ONE contiguous 1 KB block
   auto put_rows = [&](int which) {
     float* dst = a.pk + (size_t)which * arr;
     for (int i = tid; i < AH * 16 * (D / 4); i += 256) {
@@ -104,9 +133,8 @@ __global__ void __launch_bounds__(256) k_attn_pack(AttnMfmaArgs a) {
           make_float4(src[0], src[AH], src[2 * AH], src[3 * AH]);
     }
   };
-  // ... -> transposed, tile-major [b,h,n/16,k,16] array: the 16 nodes of a tile are contiguous per
-  // channel and a tile is one 64*D-byte block, so a wave's operand fetch uses whole cache lines
-  // (with [b,h,k,n] rows a 16-node access touches half of each 128-byte line)
+  // ... -> transposed, tile-major [b,h,n/16,k,16] array: the 16 nodes of a tile are contiguous per channel and a
+  // tile is one 64*D-byte block
   auto put_cols = [&](int which) {
     float* dst = a.pk + (size_t)which * arr;
     for (int i = tid; i < AH * D * 4; i += 256) {
@@ -116,14 +144,17 @@ __global__ void __launch_bounds__(256) k_attn_pack(AttnMfmaArgs a) {
           make_float4(src[0], src[LD], src[2 * LD], src[3 * LD]);
     }
   };
-  // forward: K rows + V^T; backward: Q, K, V, dO rows + K^T (bwd_kv transposes Q / dO in registers)
-  if (sec == 0) put_rows(PK_QH);
-  else if (sec == 1) { put_rows(PK_KH); if (bwd) put_cols(PK_KT); }
-  else if (sec == 2) { if (bwd) put_rows(PK_VH); else put_cols(PK_VT); }
+  if (!bwd) {
+    if (sec == 1) put_rows(PF_KH); else put_cols(PF_VT);
+    return;
+  }
+  if (sec == 0) put_rows(PB_QH);
+  else if (sec == 1) { put_rows(PB_KH); put_cols(PB_KT); }
+  else if (sec == 2) put_rows(PB_VH);
   else {
-    put_rows(PK_OH);
-    // delta[row, h] = sum_k dO[row, k, h] * O[row, k, h] (flash-style): the dO rows are staged here anyway, so the
-    // separate k_attn_mfma_delta launch (15 us of latency at config 5) is folded in -> rowstats[..][3]
+    put_rows(PB_OH);
+    // per-row constants of the backward, head-major [b,h,n,4] = (m, 1/l, delta, 0) with
+    // delta[row,h] = sum_k dO[row,k,h] * O[row,k,h] (flash-style); rows past N get 1/l = 0 (their probabilities vanish)
     const int r = tid >> 4, hh = (tid >> 1) & 7, half = tid & 1, n = n0 + r;
     float sdel = 0.f;
     if (n < N) {
@@ -133,14 +164,21 @@ __global__ void __launch_bounds__(256) k_attn_pack(AttnMfmaArgs a) {
       for (int k = half * (D / 2); k < (half + 1) * (D / 2); ++k) sdel = fmaf(dr[k * AH], vo[k * AH], sdel);
     }
     sdel += __shfl_xor(sdel, 1, 64);
-    if (n < N && half == 0) a.rowstats[(((size_t)b * N + n) * AH + hh) * 4 + 3] = sdel;
+    if (half == 0) {
+      float4 s2 = make_float4(3.0e38f, 0.f, 0.f, 0.f);   // rows past N: exp2(-inf) * 0
+      if (n < N) {
+        float* rs = a.rowstats + (((size_t)b * N + n) * AH + hh) * 4;
+        rs[3] = sdel;
+        s2 = make_float4(rs[0], __builtin_amdgcn_rcpf(rs[1]), sdel, 0.f);
+      }
+      *reinterpret_cast<float4*>(a.stats2 + (((size_t)b * AH + hh) * NP + n) * 4) = s2;
+    }
   }
 }
 
 // Feature set of a kernel instance.  V = 0 reads every switch at run time (any combination);
 // V = 1 / 2 are the straight-line instances of the main configuration (edge bias + gates + key
-// padding + clip, no attention-mask tensor, no injected mask bytes; 2 = in-kernel random mask):
-// without the per-feature branches the compiler interleaves the MFMAs with the VALU work.
+// padding + clip, no attention-mask tensor, no injected mask bytes; 2 = in-kernel random mask).
 template <int V>
 struct Feat {
   bool E, G, M, km, clip, rmb, rng, X;
@@ -156,61 +194,39 @@ struct Feat {
   }
 };
 
-// additive masks of one element, in the reference's order (egt_layers.py:91-108)
+// additive mask of one element beyond its key term, in the reference's order (egt_layers.py:96-108)
 template <int V>
-__device__ __forceinline__ float mask_add(const AttnMfmaArgs& a, const Feat<V>& f, float kadd, float mval, size_t gi) {
+__device__ __forceinline__ float mask_extra(const AttnMfmaArgs& a, const Feat<V>& f, float mval, uint32_t gi) {
   float add = 0.f;
-  if (f.km) add += kadd;
   if (f.M) add += (mval - 1.0f) * EGT_NEG;
   if (f.rmb || f.rng) {
-    const bool hit = f.rmb ? (a.rm[gi] != 0) : ((egt_hash32((uint32_t)gi, a.s0, a.s1) >> 8) < a.rm_thr);
+    const bool hit = f.rmb ? (a.rm[gi] != 0) : ((egt_hash32(gi, a.s0, a.s1) >> 8) < a.rm_thr);
     add += hit ? -EGT_NEG : 0.0f;
   }
   return add;
 }
 
-// ---- cooperative pair-tile transfers: a [16 rows][16 cols x 8 heads] tile of a [B,N,N,8]
-// tensor is 16 contiguous 512-byte runs; the workgroup's 512 threads move it with one 16-byte
-// global access each (thread -> row tid>>5, column (tid&31)>>1, heads 4*(tid&1)..+3).  In LDS
-// the tile is HEAD-MAJOR: eight [16][16] planes of stride PT_PL, so the wave that owns head h
-// reads its four consecutive columns with one ds_read_b128 (forward / bwd_q lanes) or walks a
-// column with ds_read_b32 (bwd_kv lanes).  Inside a plane rows 4..7 and 12..15 are pair-swapped
-// and the 4-column chunks are XORed with (row>>1)&3: every access pattern of the three kernels
-// and the 4 x b32 cooperative scatter is bank-conflict free (enumerated against the gfx950
-// lane-group tables; the [row][col][head] layout it replaces was 4- to 8-way conflicted).
-// Rows / columns past N read a valid address and are zeroed (component-wise selects).
+// ---- pair-tile planes: a [16 rows][16 cols x 8 heads] tile of a [B,N,N,8] tensor is 16 contiguous 512-byte
+// runs; the workgroup's 512 threads move it with one 16-byte global access each (thread -> row tid>>5, column
+// (tid&31)>>1, heads 4*(tid&1)..+3).  In LDS the tile is HEAD-MAJOR: eight planes of stride PT_PL.
+//   forward planes  [query row][key]: the wave that owns head h reads the four consecutive keys of its lane with
+//     one ds_read_b128; rows 4..7 / 12..15 pair-swapped, 4-column chunks XORed with (row>>1)&3;
+//   backward planes [key][query row]: lane (key, q) moves query rows 4q..4q+3 with one b128; chunk XOR (0,2,3,1)[key>>2].
+// tools/lds_bank_check.py enumerates every pattern against the gfx950 lane-group tables: all conflict free except the
+// backward's 4 x b32 cooperative scatter / gather (4-way: 8 array cycles under a 4-cycle issue, 2 x).
 #define PT_PL 260
 #define PT_SZ (8 * PT_PL)
 
-__device__ __forceinline__ int pt_off(int row, int m) {   // offset inside one head's plane
+__device__ __forceinline__ int pt_off(int row, int m) {
   return ((row ^ ((row >> 2) & 1)) << 4) + ((((m >> 2) ^ (row >> 1)) & 3) << 2) + (m & 3);
 }
-__device__ __forceinline__ float4 ptile_gload(const float* src, int b, int N, int row0, int col0, int tid) {
-  const int row = tid >> 5, c4 = (tid & 31) * 4;
-  const int rr = min(row0 + row, N - 1), cc = min(col0 + (c4 >> 3), N - 1);
-  return *reinterpret_cast<const float4*>(src + (((size_t)b * N + rr) * N + cc) * AH + (c4 & 7));
+__device__ __forceinline__ int ptT_off(int row, int col) {
+  const int c2 = col >> 2;
+  const int a = (0x78 >> (2 * c2)) & 3;   // (0, 2, 3, 1)[c2]
+  return (col << 4) + ((((row >> 2) ^ a) & 3) << 2) + (row & 3);
 }
-__device__ __forceinline__ void ptile_lds_put(float* tl, float4 v, int N, int row0, int col0, int tid) {
-  const int row = tid >> 5, m = (tid & 31) >> 1;
-  const bool ok = row0 + row < N && col0 + m < N;
-  float* p = tl + (tid & 1) * 4 * PT_PL + pt_off(row, m);
-  p[0] = ok ? v.x : 0.f;
-  p[PT_PL] = ok ? v.y : 0.f;
-  p[2 * PT_PL] = ok ? v.z : 0.f;
-  p[3 * PT_PL] = ok ? v.w : 0.f;
-}
-__device__ __forceinline__ void ptile_gstore(float* dst, const float* tl, int b, int N, int row0, int col0, int tid) {
-  const int row = tid >> 5, m = (tid & 31) >> 1;
-  if (row0 + row < N && col0 + m < N) {
-    const float* p = tl + (tid & 1) * 4 * PT_PL + pt_off(row, m);
-    *reinterpret_cast<float4*>(dst + (((size_t)b * N + row0 + row) * N + col0 + m) * AH + (tid & 1) * 4) =
-        make_float4(p[0], p[PT_PL], p[2 * PT_PL], p[3 * PT_PL]);
-  }
-}
-
-// Same transfers with the address split into a workgroup-uniform base (tensor + graph + first row,
-// scalar registers) and a 32-bit lane offset: rowoff = ptile_rowoff() is fixed for the kernel, the
-// column part is two VALU ops per tile, and one offset serves every [B,N,N,8] tensor.
+// address of a thread's 16 bytes inside a tile: workgroup-uniform base (tensor + graph + first row, scalar
+// registers) + a 32-bit lane offset: rowoff is fixed for the kernel, the column part is two VALU ops per tile
 __device__ __forceinline__ uint32_t ptile_rowoff(int N, int row0, int tid) {
   return (uint32_t)(min(row0 + (tid >> 5), N - 1) - row0) * N * AH + (tid & 1) * 4;
 }
@@ -220,689 +236,702 @@ __device__ __forceinline__ uint32_t ptile_off(uint32_t rowoff, int N, int col0, 
 __device__ __forceinline__ const float* ptile_base(const float* src, int b, int N, int row0) {
   return src + ((size_t)b * N + row0) * N * AH;
 }
-
-// key-mask bytes of keys m .. m+3 (clamped).  Kept as four separate registers: packing them
-// would consume the loads at once, and a wait on these (the youngest loads of the prefetch
-// group) would drain the whole group.
-struct Km4 { uint32_t v[4]; };
-__device__ __forceinline__ Km4 km_load4(const uint8_t* km, int N, int m) {
-  Km4 k;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) k.v[r] = km[min(m + r, N - 1)];
-  return k;
+template <bool T>
+__device__ __forceinline__ void plane_scatter(float* tl, float4 v, int tid) {
+  const int row = tid >> 5, m = (tid & 31) >> 1;
+  float* p = tl + (tid & 1) * 4 * PT_PL + (T ? ptT_off(row, m) : pt_off(row, m));
+  p[0] = v.x; p[PT_PL] = v.y; p[2 * PT_PL] = v.z; p[3 * PT_PL] = v.w;
 }
+template <bool T>
+__device__ __forceinline__ float4 plane_gather(const float* tl, int tid) {
+  const int row = tid >> 5, m = (tid & 31) >> 1;
+  const float* p = tl + (tid & 1) * 4 * PT_PL + (T ? ptT_off(row, m) : pt_off(row, m));
+  return make_float4(p[0], p[PT_PL], p[2 * PT_PL], p[3 * PT_PL]);
+}
+
+// ---- producer / consumer split (tools/micro/mfma_stream.hip, profiles/r04_attn5_microbench.md) ----------------
+// One global_load in an fp32 MFMA stream costs the issuing wave ~80 cycles (= 2.5 MFMAs), a ds_read_b128 ~7; LDS-DMA
+// loader waves on the same SIMDs move 18 TB/s without slowing a compute wave's MFMA stream (33.7 vs 32 cycles per
+// MFMA).  So a workgroup is 4 COMPUTE waves (one per SIMD, one head each: ds_read + MFMA + VALU only) and 4 LOADER
+// waves: operand tiles by LDS-DMA (global_load_lds_dwordx4: no VGPR, no ds_write) one iteration ahead, pair tiles
+// HBM -> registers -> head-major planes two iterations ahead, output planes -> HBM one iteration behind.  One
+// s_barrier per iteration, which does not drain vector memory.
+//
+// Operand tile in LDS: the packed [T][16 rows][16 channels] block with the four 16-byte chunks of a row XORed by
+// (0,2,3,1)[row >> 2] (done by the DMA's lane -> source mapping: LDS slot s of a 1 KB piece receives row s >> 2,
+// chunk (s & 3) ^ a[s >> 4]): the row-form fragment reads (lane (row, q): ds_read_b128 of chunk q) are bank-conflict
+// free and the transposed reads (lane (channel, q): ds_read_b32 of rows 4q + r) 2-way (tools/lds_bank_check.py).
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)p; }   // LDS byte address of a __shared__ pointer
+__device__ __forceinline__ int chunk_xor(int row) { return (0x78 >> (2 * (row >> 2))) & 3; }      // (0, 2, 3, 1)[row >> 2]
+// one 1 KB piece HBM -> LDS (destination below 64 KiB: M0 carries 16 bits): lane i lands at lds + 16 i and fetches src + off
+__device__ __forceinline__ void dma_piece(unsigned lds, const float* src, unsigned off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(src), "v"(off), "s"(lds) : "memory");
+}
+template <int N_>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N_) : "memory"); }
+__device__ __forceinline__ unsigned dma_lane_off(int lane) {   // source byte offset (inside a 1 KB block) of the chunk that lands in slot `lane`
+  return (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ chunk_xor(lane >> 2)) << 4));
+}
+#define OPS_STAGE 32768   // bytes of one operand stage: 4 heads x (two 4 KB tiles)
+#define OPS_BYTES (2 * OPS_STAGE)
 
 // ================================================================== forward =====
-// workgroup = (graph b, 16 query rows), wave = head.  Lane (ll = lane&15, q = lane>>4) owns
-// query row l0 + ll and, in every key tile, keys m0 + 4q + r.  K / V^T operands come straight
-// from the packed arrays (register prefetch one tile ahead); the E / G / M tiles are fetched
-// coalesced by the whole workgroup one tile ahead into double-buffered LDS tiles, H_hat leaves
-// through one: ONE barrier per key tile.
+// workgroup = (graph b, 32 query rows, 4 heads); compute wave w = head 4 hg + w.  Lane (ll = lane&15, q = lane>>4)
+// owns query rows l0 + 16 qt + ll (two query tiles: every K / V^T operand register feeds two MFMAs) and, in the key
+// tile of an iteration, keys m0 + 4q + r.  S^T = K.Q^T puts the key index on the MFMA row axis: the softmax
+// reductions over keys are in-lane ops + two permlane swaps, the online-softmax rescale is lane-uniform, and the
+// gated probabilities feed the A.V MFMA as its B operand in place.
+#define FQ 2   // query tiles per compute wave
 template <int D, int V>
-__global__ void __launch_bounds__(512, 4) k_attn_mfma_fwd(AttnMfmaArgs a) {
-  constexpr int KT = D / 16, DH = D * AH;
+__global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
+  constexpr int KT = D / 16, DH = D * AH, NIN = V ? 2 : 3, TS = FQ * 4 * PT_PL;   // TS: one tensor, one stage of planes
+  static_assert(KT * 1024 * 2 * 4 <= OPS_STAGE, "operand stage");
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* In = sm;                    // [2][E | G | M][PT_SZ]
-  float* Hout = sm + 2 * 3 * PT_SZ;  // [2][PT_SZ]
-  const int tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ll = lane & 15, q = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wv >= 4;
+  const int w = wv & 3;
   const int N = a.N, NP = a.NP;
-  const int ltiles = NP / 16;
-  const int wg = egt_xcd_remap(blockIdx.x, gridDim.x);   // a graph's K / V^T stay within one XCD's L2
-  const int b = wg / ltiles, l0 = (wg % ltiles) * 16;
-  const int l = l0 + ll, lc = min(l, N - 1);
+  const int lgroups = (NP / 16 + FQ - 1) / FQ;
+  const int KA = (NP + 16 + 3) & ~3;
+  float* kaddL = sm + OPS_BYTES / 4;   // [NP + 16] additive key term of the logits
+  float* kaddG = kaddL + KA;           // ... of the gate's exponent
+  float* In = kaddG + KA;              // [2 stages][E | G | M][TS]
+  float* Hout = In + 2 * NIN * TS;     // [2][TS]
+  const int wg = egt_xcd_remap(blockIdx.x, gridDim.x);   // the two head groups of a row block and a graph's K / V^T share an XCD's L2
+  const int hg = wg & 1, grp = wg >> 1;
+  const int b = grp / lgroups, l0 = (grp % lgroups) * 16 * FQ;
+  const int h = 4 * hg + w;
   const Feat<V> f(a);
-  const bool gated = f.G, clip = f.clip;
+  const int mtiles = NP / 16;
   const size_t arr = (size_t)a.B * AH * NP * D;
-  const float* Kh = a.pk + PK_KH * arr + ((size_t)b * AH + h) * NP * D;   // [NP/16][D/16][16][16]
-  const float* VT = a.pk + PK_VT * arr + ((size_t)b * AH + h) * D * NP;   // [NP/16][D][16]
-  // uniform bases + 32-bit lane offsets: scalar address arithmetic, one VGPR per access stream
-  const uint32_t koff = ll * 16 + 4 * q, voff = koff;
-  const uint32_t prow = ptile_rowoff(N, l0, tid);
-  const float* Eb = ptile_base(a.E, b, N, l0);
-  const float* Gb = ptile_base(a.G, b, N, l0);
-  const float* Mb = ptile_base(a.M, b, N, l0);
-  float* Hb = const_cast<float*>(ptile_base(a.h_hat, b, N, l0));
-  auto pload = [&](const float* base, int col0) __attribute__((always_inline)) {
-    return *reinterpret_cast<const float4*>(base + ptile_off(prow, N, col0, tid));
-  };
+  STAMP_DECL;
 
-  // Q fragments (B operand of S^T = K.Q^T): Q[l][16T + 4q + u]
-  float Qr[4 * KT];
-  {
-    const float* qrow = a.qkv + ((size_t)b * N + lc) * 3 * DH + h;
-#pragma unroll
-    for (int t = 0; t < 4 * KT; ++t) Qr[t] = qrow[(16 * (t >> 2) + 4 * q + (t & 3)) * AH];
-  }
-  v4f oacc[KT];
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt) oacc[kt] = (v4f){0.f, 0.f, 0.f, 0.f};
-  float mrun = -3.0e38f, lrun = 0.f;
-
-  // K / V^T operands are single-buffered: the next tile's K is requested right after this tile's
-  // S MFMAs have consumed the registers, V^T right after the P.V MFMAs -- a full tile ahead of its
-  // use either way.  The pair tiles travel TWO key tiles ahead (HBM latency under load is about one
-  // tile's worth of work) in two register sets (A, B) that alternate roles tile by tile; alternating
-  // instead of copying matters: a register copy waits for the load it copies.  All prefetches are
-  // unconditional (clamped to the last tile) so each tile is straight-line code with exact waits.
-  float4 kc[KT], vc[KT];
-  float4 eA = make_float4(0.f, 0.f, 0.f, 0.f), gA = eA, mA = eA, eB = eA, gB = eA, mB = eA;
-  Km4 kmc{{1u, 1u, 1u, 1u}};
-  const int mlast = NP - 16;
-#pragma unroll
-  for (int T = 0; T < KT; ++T) {
-    kc[T] = *reinterpret_cast<const float4*>(Kh + koff + 256 * T);
-    vc[T] = *reinterpret_cast<const float4*>(VT + voff + 256 * T);
-  }
-  if (f.km) kmc = km_load4(a.km + (size_t)b * N, N, 4 * q);
-  if (f.E) ptile_lds_put(In + 0 * PT_SZ, pload(Eb, 0), N, l0, 0, tid);
-  if (f.G) ptile_lds_put(In + 1 * PT_SZ, pload(Gb, 0), N, l0, 0, tid);
-  if (f.M) ptile_lds_put(In + 2 * PT_SZ, pload(Mb, 0), N, l0, 0, tid);
-  {
-    const int m1 = min(16, mlast);
-    if (f.E) eA = pload(Eb, m1);
-    if (f.G) gA = pload(Gb, m1);
-    if (f.M) mA = pload(Mb, m1);
-  }
-  __builtin_amdgcn_s_waitcnt(0);   // nothing pending at the loop header: its waits then reflect the loop alone
-  __syncthreads();
-
-  // one key tile: (pe, pg, pm) hold the pair tiles of it+1 and go to LDS at the bottom,
-  // (qe, qg, qm) receive those of it+2
-  auto tile = [&](const int m0, const int it, float4& pe4, float4& pg4, float4& pm4, float4& qe4, float4& qg4,
-                  float4& qm4) __attribute__((always_inline)) {
-    const int m1 = min(m0 + 16, mlast), m2 = min(m0 + 32, mlast);
-    if (ABL_ON(a, 4)) {
-    if (f.E) qe4 = pload(Eb, m2);
-    if (f.G) qg4 = pload(Gb, m2);
-    if (f.M) qm4 = pload(Mb, m2);
+  if (loader) {
+    // ------------------------------------------------------------------ loader waves ----
+    const int lt = tid - 256;                   // 0..255
+    const int crow = lt >> 4, ccol = lt & 15;   // pair-tile transfers: row crow, key ccol of every 16 x 16 sub-tile, 4 heads (16 bytes)
+    for (int m = lt; m < NP + 16; m += 256) {
+      float ka = 0.f;
+      if (m >= N) ka = KEY_OFF;
+      else if (f.km && a.km[(size_t)b * N + m] == 0) ka = -EGT_NEG;
+      kaddL[m] = ka;
+      kaddG[m] = m >= N ? 3.0e38f : -ka * L2E;
     }
-    __builtin_amdgcn_sched_barrier(0);   // keep the prefetches up here: hipcc otherwise sinks them past the MFMAs
-    const float* Et = In + (it & 1) * 3 * PT_SZ;
-    const float* Gt = Et + PT_SZ;
-    const float* Mt = Gt + PT_SZ;
-    float* Ht = Hout + (it & 1) * PT_SZ;
-    // ---- S^T[m][l] = sum_k K[m][k] Q[l][k] ----
-    v4f s = {0.f, 0.f, 0.f, 0.f};
-    if (ABL_ON(a, 8))
+    const float* Kh = a.pk + PF_KH * arr + ((size_t)b * AH + h) * NP * D;   // [NP/16][D/16][16][16]   (this loader wave feeds head h)
+    const float* VT = a.pk + PF_VT * arr + ((size_t)b * AH + h) * D * NP;   // [NP/16][D][16]
+    const unsigned doff = dma_lane_off(lane);
+    const unsigned ops0 = lds_addr(sm) + w * (KT * 2048);   // head w: K tile, then V^T tile
+    auto dma_ops = [&](int mt, int stage) __attribute__((always_inline)) {
+      const float* ks = Kh + (size_t)mt * 16 * D;
+      const float* vs = VT + (size_t)mt * 16 * D;
+      const unsigned dst = ops0 + stage * OPS_STAGE;
 #pragma unroll
-    for (int T = 0; T < KT; ++T) {
-      s = MFMA(kc[T].x, Qr[4 * T + 0], s);
-      s = MFMA(kc[T].y, Qr[4 * T + 1], s);
-      s = MFMA(kc[T].z, Qr[4 * T + 2], s);
-      s = MFMA(kc[T].w, Qr[4 * T + 3], s);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (ABL_ON(a, 1))
+      for (int T = 0; T < KT; ++T) dma_piece(dst + T * 1024, ks + T * 256, doff);
 #pragma unroll
-    for (int T = 0; T < KT; ++T) kc[T] = *reinterpret_cast<const float4*>(Kh + (size_t)m1 * D + koff + 256 * T);
-    __builtin_amdgcn_sched_barrier(0);
-    float x[4], pa[4];
-    float tmax = -3.0e38f;
-    const int po4 = h * PT_PL + pt_off(ll, 4 * q);   // this lane's keys 4q..4q+3 of row ll: one 16-byte access
-    float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = e4, m4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (f.E) e4 = *reinterpret_cast<const float4*>(Et + po4);
-    if (f.G) g4 = *reinterpret_cast<const float4*>(Gt + po4);
-    if (f.M) m4 = *reinterpret_cast<const float4*>(Mt + po4);
-    const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w};
-    float hv4[4];
+      for (int T = 0; T < KT; ++T) dma_piece(dst + KT * 1024 + T * 1024, vs + T * 256, doff);
+    };
+    const size_t gbase = ((size_t)b * N + l0) * N * AH;
+    uint32_t rowoff[FQ];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + 4 * q + r;
-      const bool valid = m < N;
-      float ah = s[r] * a.scale;
-      if (clip) ah = fminf(fmaxf(ah, a.clip_lo), a.clip_hi);
-      const size_t gi = (((size_t)b * N + lc) * N + min(m, N - 1)) * AH + h;
-      const float hv = ah + ev[r];
-      hv4[r] = hv;                                         // H_hat: post-clip, pre-mask (egt_layers.py:85-86)
-      const float kadd = kmc.v[r] ? 0.0f : -EGT_NEG;
-      const float add = mask_add(a, f, kadd, mv[r], gi);
-      x[r] = valid ? hv + add : -3.0e38f;
-      pa[r] = gated ? egt_sigmoid(gv[r] + add) : 1.0f;    // gate (multiplied into p below)
-      tmax = fmaxf(tmax, x[r]);
-    }
-    *reinterpret_cast<float4*>(Ht + po4) = make_float4(hv4[0], hv4[1], hv4[2], hv4[3]);
-    if (f.km) {   // key mask of the next tile, into the registers this tile just finished with
-      __builtin_amdgcn_sched_barrier(0);
-      kmc = km_load4(a.km + (size_t)b * N, N, m1 + 4 * q);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- online softmax over the key axis: in-lane over r, then across q ----
-    tmax = pair_max_q(tmax);
-    const float mnew = fmaxf(mrun, tmax);
-    const float alpha = __expf(mrun - mnew);
-    float psum = 0.f;
+    for (int qt = 0; qt < FQ; ++qt) rowoff[qt] = (uint32_t)(min(l0 + 16 * qt + crow, N - 1) - l0) * N * AH + 4 * hg;
+    auto pload = [&](const float* src, int qt, int mcol) __attribute__((always_inline)) {
+      return *reinterpret_cast<const float4*>(src + gbase + rowoff[qt] + (uint32_t)min(mcol + ccol, N - 1) * AH);
+    };
+    const int sc_off = pt_off(crow, ccol);
+    auto scatter = [&](float* tl, int qt, float4 v) __attribute__((always_inline)) {
+      float* p = tl + qt * 4 * PT_PL + sc_off;
+      p[0] = v.x; p[PT_PL] = v.y; p[2 * PT_PL] = v.z; p[3 * PT_PL] = v.w;
+    };
+    auto hstore = [&](int itp) __attribute__((always_inline)) {   // H_hat tiles of iteration itp: planes -> whole 16-byte pieces of the [N,N,8] rows
+      const float* Hp = Hout + (itp & 1) * TS;
+      const int mp = 16 * itp;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float pe = (x[r] > -2.9e38f) ? __expf(x[r] - mnew) : 0.f;
-      psum += pe;
-      pa[r] *= pe;
-    }
-    psum = pair_sum_q(psum);
-    lrun = fmaf(lrun, alpha, psum);
-    mrun = mnew;
-    // ---- O^T[k][l] = alpha * O^T + sum_m V^T[k][m] P^T[m][l]  (contraction order m = 4q + t) ----
+      for (int qt = 0; qt < FQ; ++qt)
+        if (l0 + 16 * qt + crow < N && mp + ccol < N) {
+          const float* p = Hp + qt * 4 * PT_PL + sc_off;
+          *reinterpret_cast<float4*>(a.h_hat + gbase + rowoff[qt] + (uint32_t)(mp + ccol) * AH) = make_float4(p[0], p[PT_PL], p[2 * PT_PL], p[3 * PT_PL]);
+        }
+    };
+    dma_ops(0, 0);
+    float4 pe[FQ], pg[FQ], pm[FQ];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      v4f o = oacc[kt];
-      o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
-      if (ABL_ON(a, 8)) {
-      o = MFMA(vc[kt].x, pa[0], o);
-      o = MFMA(vc[kt].y, pa[1], o);
-      o = MFMA(vc[kt].z, pa[2], o);
-      o = MFMA(vc[kt].w, pa[3], o);
-      }
-      oacc[kt] = o;
+    for (int qt = 0; qt < FQ; ++qt) {
+      if (f.E) scatter(In + 0 * TS, qt, pload(a.E, qt, 0));
+      if (f.G) scatter(In + 1 * TS, qt, pload(a.G, qt, 0));
+      if (f.M) scatter(In + 2 * TS, qt, pload(a.M, qt, 0));
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (ABL_ON(a, 1))
+    {
+      const int m1 = min(16, NP - 16);
 #pragma unroll
-    for (int T = 0; T < KT; ++T) vc[T] = *reinterpret_cast<const float4*>(VT + (size_t)m1 * D + voff + 256 * T);
-    __builtin_amdgcn_sched_barrier(0);
-    {   // tile it+1 into the other LDS buffer (its last readers passed the previous barrier)
-      float* nx = In + ((it + 1) & 1) * 3 * PT_SZ;
-      if (f.E) ptile_lds_put(nx, pe4, N, l0, m1, tid);
-      if (f.G) ptile_lds_put(nx + PT_SZ, pg4, N, l0, m1, tid);
-      if (f.M) ptile_lds_put(nx + 2 * PT_SZ, pm4, N, l0, m1, tid);
-    }
-    if (ABL_ON(a, 16)) __syncthreads();
-    {   // H_hat tile out: whole 512-byte runs
-      const int row = tid >> 5, m = (tid & 31) >> 1;
-      if (l0 + row < N && m0 + m < N && ABL_ON(a, 2)) {
-        const float* p = Ht + (tid & 1) * 4 * PT_PL + pt_off(row, m);
-        *reinterpret_cast<float4*>(Hb + ptile_off(prow, N, m0, tid)) = make_float4(p[0], p[PT_PL], p[2 * PT_PL], p[3 * PT_PL]);
+      for (int qt = 0; qt < FQ; ++qt) {
+        pe[qt] = pg[qt] = pm[qt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f.E) pe[qt] = pload(a.E, qt, m1);
+        if (f.G) pg[qt] = pload(a.G, qt, m1);
+        if (f.M) pm[qt] = pload(a.M, qt, m1);
       }
     }
-  };
-  // pairs of tiles in the loop, an odd last tile outside it: a conditional second tile inside the
-  // loop would put the first tile's pending loads on a (never taken) path to the loop header and
-  // make hipcc drain every prefetch there
-  int m0 = 0;
-  for (; m0 + 16 < NP; m0 += 32) {
-    tile(m0, 0, eA, gA, mA, eB, gB, mB);
-    tile(m0 + 16, 1, eB, gB, mB, eA, gA, mA);
-  }
-  if (m0 < NP) tile(m0, 0, eA, gA, mA, eB, gB, mB);
-  // ---- finalize: V_att[l][k*8+h] = O[l][k] / l_run ; row statistics for the backward ----
-  if (l < N) {
-    const float inv = 1.0f / lrun;
-    float* vo = a.v_att + ((size_t)b * N + l) * DH + h;
+    if (V) vm_wait<FQ * NIN>(); else vm_wait<0>();   // the DMA pieces are older than the register loads just issued
+    lds_barrier();
+    for (int it = 0; it < mtiles; ++it) {
+      {   // pair tiles of iteration it+1 (requested one iteration ago) into the other stage: its last readers passed the previous barrier
+        float* nx = In + ((it + 1) & 1) * NIN * TS;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+        for (int qt = 0; qt < FQ; ++qt) {
+          if (f.E) scatter(nx + 0 * TS, qt, pe[qt]);
+          if (f.G) scatter(nx + 1 * TS, qt, pg[qt]);
+          if (f.M) scatter(nx + 2 * TS, qt, pm[qt]);
+        }
+      }
+      if (it > 0) hstore(it - 1);
+      dma_ops(min(it + 1, mtiles - 1), (it + 1) & 1);
+      {
+        const int m2 = min(16 * (it + 2), NP - 16);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) vo[(16 * kt + 4 * q + r) * AH] = oacc[kt][r] * inv;
-    if (q == 0) {
-      float* rs = a.rowstats + (((size_t)b * N + l) * AH + h) * 4;
-      rs[0] = mrun; rs[1] = lrun; rs[2] = 0.f; rs[3] = 0.f;
+        for (int qt = 0; qt < FQ; ++qt) {
+          if (f.E) pe[qt] = pload(a.E, qt, m2);
+          if (f.G) pg[qt] = pload(a.G, qt, m2);
+          if (f.M) pm[qt] = pload(a.M, qt, m2);
+        }
+      }
+      // exactly the register loads above are younger than the DMA pieces (their count is a template constant for the
+      // straight-line instances; the generic instance drains)
+      if (V) vm_wait<FQ * NIN>(); else vm_wait<0>();
+      lds_barrier();
     }
+    hstore(mtiles - 1);
+    return;
   }
-}
 
-// ---- forward, two key tiles per iteration ------------------------------------------------------
-// Same decomposition as k_attn_mfma_fwd, but one iteration covers 32 keys: two independent
-// S^T / softmax chains per wave (the scheduler interleaves them), one barrier and one online-softmax
-// rescale per 32 keys, pair tiles one iteration (= two tiles) ahead in registers -- no role swap
-// needed.  ~190 VGPRs, so ONE workgroup per CU: the variant for grids that cannot give a CU two
-// workgroups anyway (B * N/16 <= 2 x 256 on MI355X).
-template <int D, int V>
-__global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd2(AttnMfmaArgs a) {
-  constexpr int KT = D / 16, DH = D * AH;
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* In = sm;                        // [2][2 sub-tiles][E | G | M][PT_SZ]
-  float* Hout = sm + 2 * 2 * 3 * PT_SZ;  // [2][2][PT_SZ]
-  const int tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // -------------------------------------------------------------------- compute waves ----
   const int ll = lane & 15, q = lane >> 4;
-  const int N = a.N, NP = a.NP;
-  const int ltiles = NP / 16;
-  const int wg = egt_xcd_remap(blockIdx.x, gridDim.x);
-  const int b = wg / ltiles, l0 = (wg % ltiles) * 16;
-  const int l = l0 + ll, lc = min(l, N - 1);
-  const Feat<V> f(a);
   const bool gated = f.G, clip = f.clip;
-  const size_t arr = (size_t)a.B * AH * NP * D;
-  const float* Kh = a.pk + PK_KH * arr + ((size_t)b * AH + h) * NP * D;
-  const float* VT = a.pk + PK_VT * arr + ((size_t)b * AH + h) * D * NP;
-  const uint32_t koff = ll * 16 + 4 * q;
-  const uint32_t prow = ptile_rowoff(N, l0, tid);
-  const float* Eb = ptile_base(a.E, b, N, l0);
-  const float* Gb = ptile_base(a.G, b, N, l0);
-  const float* Mb = ptile_base(a.M, b, N, l0);
-  float* Hb = const_cast<float*>(ptile_base(a.h_hat, b, N, l0));
-  auto pload = [&](const float* base, int col0) __attribute__((always_inline)) {
-    return *reinterpret_cast<const float4*>(base + ptile_off(prow, N, col0, tid));
-  };
-  float Qr[4 * KT];
-  {
-    const float* qrow = a.qkv + ((size_t)b * N + lc) * 3 * DH + h;
+  // Q fragments (B operand of S^T = K.Q^T), pre-scaled: d^-1/2 Q[l][16T + 4q + u]
+  float Qr[FQ][4 * KT];
 #pragma unroll
-    for (int t = 0; t < 4 * KT; ++t) Qr[t] = qrow[(16 * (t >> 2) + 4 * q + (t & 3)) * AH];
+  for (int qt = 0; qt < FQ; ++qt) {
+    const float* qrow = a.qkv + ((size_t)b * N + min(l0 + 16 * qt + ll, N - 1)) * 3 * DH + h;
+#pragma unroll
+    for (int t = 0; t < 4 * KT; ++t) Qr[qt][t] = qrow[(16 * (t >> 2) + 4 * q + (t & 3)) * AH] * a.scale;
   }
-  v4f oacc[KT];
+  v4f oacc[FQ][KT];
+  float mrun[FQ], lrun[FQ];
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) oacc[kt] = (v4f){0.f, 0.f, 0.f, 0.f};
-  float mrun = -3.0e38f, lrun = 0.f;
-  const int mlast = NP - 16;
-  auto clampm = [&](int m) { return min(m, mlast); };   // tiles past the end re-read the last one and are masked off
-  float4 kc[2][KT], vc[2][KT];
-  float4 pe[2], pg[2], pm[2];
-  Km4 kmc[2];
+  for (int qt = 0; qt < FQ; ++qt) {
+    mrun[qt] = KEY_OFF; lrun[qt] = 0.f;
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    const int mk = clampm(16 * kb);
-#pragma unroll
-    for (int T = 0; T < KT; ++T) {
-      kc[kb][T] = *reinterpret_cast<const float4*>(Kh + (size_t)mk * D + koff + 256 * T);
-      vc[kb][T] = *reinterpret_cast<const float4*>(VT + (size_t)mk * D + koff + 256 * T);
-    }
-    kmc[kb] = Km4{{1u, 1u, 1u, 1u}};
-    if (f.km) kmc[kb] = km_load4(a.km + (size_t)b * N, N, mk + 4 * q);
-    pe[kb] = pg[kb] = pm[kb] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (f.E) ptile_lds_put(In + (kb * 3 + 0) * PT_SZ, pload(Eb, mk), N, l0, mk, tid);
-    if (f.G) ptile_lds_put(In + (kb * 3 + 1) * PT_SZ, pload(Gb, mk), N, l0, mk, tid);
-    if (f.M) ptile_lds_put(In + (kb * 3 + 2) * PT_SZ, pload(Mb, mk), N, l0, mk, tid);
+    for (int kt = 0; kt < KT; ++kt) oacc[qt][kt] = (v4f){0.f, 0.f, 0.f, 0.f};
   }
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-
-  for (int m0 = 0, it = 0; m0 < NP; m0 += 32, ++it) {
-    int mn[2];   // the two key tiles of the NEXT iteration
+  const int po4 = w * PT_PL + pt_off(ll, 4 * q);   // this lane's keys 4q..4q+3 of row ll inside a sub-tile: one 16-byte access
+  // operand fragment address: row ll, chunk q of the k-tile blocks of head w's tiles (+ stage, + 1024 T, + KT*1024 for V^T)
+  const float* opl = sm + w * (KT * 512) + ll * 16 + ((q ^ chunk_xor(ll)) << 2);
+  lds_barrier();
+  STAMP(0);
+  for (int it = 0; it < mtiles; ++it) {
+    const int m0 = 16 * it;
+    const float* ops = opl + (it & 1) * (OPS_STAGE / 4);
+    const float* Inb = In + (it & 1) * NIN * TS;
+    float* Hb2 = Hout + (it & 1) * TS;
+    float4 kc[KT], vc[KT];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      mn[kb] = clampm(m0 + 32 + 16 * kb);
-      if (f.E) pe[kb] = pload(Eb, mn[kb]);
-      if (f.G) pg[kb] = pload(Gb, mn[kb]);
-      if (f.M) pm[kb] = pload(Mb, mn[kb]);
+    for (int T = 0; T < KT; ++T) kc[T] = *reinterpret_cast<const float4*>(ops + T * 256);
+    float4 e4[FQ], g4[FQ], m4[FQ], ka4, kg4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    ka4 = *reinterpret_cast<const float4*>(kaddL + m0 + 4 * q);
+    if (V == 1) kg4 = *reinterpret_cast<const float4*>(kaddG + m0 + 4 * q);
+#pragma unroll
+    for (int qt = 0; qt < FQ; ++qt) {
+      e4[qt] = g4[qt] = make_float4(0.f, 0.f, 0.f, 0.f);
+      m4[qt] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (f.E) e4[qt] = *reinterpret_cast<const float4*>(Inb + 0 * TS + qt * 4 * PT_PL + po4);
+      if (f.G) g4[qt] = *reinterpret_cast<const float4*>(Inb + 1 * TS + qt * 4 * PT_PL + po4);
+      if (f.M) m4[qt] = *reinterpret_cast<const float4*>(Inb + 2 * TS + qt * 4 * PT_PL + po4);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    const float* Inb = In + (it & 1) * 6 * PT_SZ;
-    float* Hb2 = Hout + (it & 1) * 2 * PT_SZ;
-    // ---- S^T of both key tiles ----
-    v4f s[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      s[kb] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int T = 0; T < KT; ++T) vc[T] = *reinterpret_cast<const float4*>(ops + KT * 256 + T * 256);
+    STAMP(1);
+    // ---- S^T[m][l] = sum_k K[m][k] (d^-1/2 Q)[l][k]: every K register feeds the two query tiles ----
+    v4f s[FQ];
 #pragma unroll
-      for (int T = 0; T < KT; ++T) {
-        s[kb] = MFMA(kc[kb][T].x, Qr[4 * T + 0], s[kb]);
-        s[kb] = MFMA(kc[kb][T].y, Qr[4 * T + 1], s[kb]);
-        s[kb] = MFMA(kc[kb][T].z, Qr[4 * T + 2], s[kb]);
-        s[kb] = MFMA(kc[kb][T].w, Qr[4 * T + 3], s[kb]);
+    for (int qt = 0; qt < FQ; ++qt) s[qt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < KT; ++T)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float kk = u == 0 ? kc[T].x : u == 1 ? kc[T].y : u == 2 ? kc[T].z : kc[T].w;
+#pragma unroll
+        for (int qt = 0; qt < FQ; ++qt) s[qt] = MFMA(kk, Qr[qt][4 * T + u], s[qt]);
       }
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    STAMP(2);
+    const float kav[4] = {ka4.x, ka4.y, ka4.z, ka4.w}, kgv[4] = {kg4.x, kg4.y, kg4.z, kg4.w};
+    float pa[FQ][4];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int T = 0; T < KT; ++T) kc[kb][T] = *reinterpret_cast<const float4*>(Kh + (size_t)mn[kb] * D + koff + 256 * T);
-    __builtin_amdgcn_sched_barrier(0);
-    float x[2][4], pa[2][4];
-    float tmax = -3.0e38f;
-    const int po4 = h * PT_PL + pt_off(ll, 4 * q);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const int mt0 = m0 + 16 * kb;   // may lie past NP on the last iteration: every key then fails `valid`
-      float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = e4, m4 = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (f.E) e4 = *reinterpret_cast<const float4*>(Inb + (kb * 3 + 0) * PT_SZ + po4);
-      if (f.G) g4 = *reinterpret_cast<const float4*>(Inb + (kb * 3 + 1) * PT_SZ + po4);
-      if (f.M) m4 = *reinterpret_cast<const float4*>(Inb + (kb * 3 + 2) * PT_SZ + po4);
-      const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w};
+    for (int qt = 0; qt < FQ; ++qt) {
+      float x[4];
+      float tmax = KEY_OFF;
+      const int lq = min(l0 + 16 * qt + ll, N - 1);
+      const float ev[4] = {e4[qt].x, e4[qt].y, e4[qt].z, e4[qt].w}, gv[4] = {g4[qt].x, g4[qt].y, g4[qt].z, g4[qt].w};
+      const float mv[4] = {m4[qt].x, m4[qt].y, m4[qt].z, m4[qt].w};
       float hv4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = mt0 + 4 * q + r;
-        const bool valid = m < N;
-        float ah = s[kb][r] * a.scale;
-        if (clip) ah = fminf(fmaxf(ah, a.clip_lo), a.clip_hi);
-        const size_t gi = (((size_t)b * N + lc) * N + min(m, N - 1)) * AH + h;
+        float ah = s[qt][r];
+        if (clip) ah = __builtin_amdgcn_fmed3f(ah, a.clip_lo, a.clip_hi);
         const float hv = ah + ev[r];
-        hv4[r] = hv;
-        const float kadd = kmc[kb].v[r] ? 0.0f : -EGT_NEG;
-        const float add = mask_add(a, f, kadd, mv[r], gi);
-        x[kb][r] = valid ? hv + add : -3.0e38f;
-        pa[kb][r] = gated ? egt_sigmoid(gv[r] + add) : 1.0f;
-        tmax = fmaxf(tmax, x[kb][r]);
+        hv4[r] = hv;                                            // H_hat: post-clip, pre-mask (egt_layers.py:85-86)
+        float add = kav[r];
+        if (V != 1) {
+          const int m = min(m0 + 4 * q + r, N - 1);
+          add += mask_extra(a, f, mv[r], (uint32_t)((((size_t)b * N + lq) * N + m) * AH + h));
+        }
+        x[r] = hv + add;
+        tmax = fmaxf(tmax, x[r]);
+        if (gated) {   // sigmoid(G + add); masked -> exp2(+1.4e9) = inf -> rcp = 0 exactly, as the reference's fp32 path
+          const float tg = V == 1 ? exp2_fast(fmaf(gv[r], -L2E, kgv[r])) : exp2_fast((gv[r] + add) * -L2E);
+          pa[qt][r] = __builtin_amdgcn_rcpf(1.0f + tg);
+        } else {
+          pa[qt][r] = 1.0f;
+        }
       }
-      *reinterpret_cast<float4*>(Hb2 + kb * PT_SZ + po4) = make_float4(hv4[0], hv4[1], hv4[2], hv4[3]);
-    }
-    if (f.km) {
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) kmc[kb] = km_load4(a.km + (size_t)b * N, N, mn[kb] + 4 * q);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- online softmax over the 32 keys ----
-    tmax = pair_max_q(tmax);
-    const float mnew = fmaxf(mrun, tmax);
-    const float alpha = __expf(mrun - mnew);
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      *reinterpret_cast<float4*>(Hb2 + qt * 4 * PT_PL + po4) = make_float4(hv4[0], hv4[1], hv4[2], hv4[3]);
+      // ---- online softmax over the 16 keys: in-lane over r, then across q ----
+      tmax = pair_max_q(tmax);
+      const float mnew = fmaxf(mrun[qt], tmax);
+      const float alpha = exp2_fast((mrun[qt] - mnew) * L2E);
+      float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pexp = (x[kb][r] > -2.9e38f) ? __expf(x[kb][r] - mnew) : 0.f;
+        const float pexp = exp2_fast((x[r] - mnew) * L2E);   // keys past N: exp2(-inf) = 0
         psum += pexp;
-        pa[kb][r] *= pexp;
+        pa[qt][r] *= pexp;
       }
-    psum = pair_sum_q(psum);
-    lrun = fmaf(lrun, alpha, psum);
-    mrun = mnew;
+      psum = pair_sum_q(psum);
+      lrun[qt] = fmaf(lrun[qt], alpha, psum);
+      mrun[qt] = mnew;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      v4f o = oacc[kt];
-      o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        o = MFMA(vc[kb][kt].x, pa[kb][0], o);
-        o = MFMA(vc[kb][kt].y, pa[kb][1], o);
-        o = MFMA(vc[kb][kt].z, pa[kb][2], o);
-        o = MFMA(vc[kb][kt].w, pa[kb][3], o);
-      }
-      oacc[kt] = o;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int T = 0; T < KT; ++T) vc[kb][T] = *reinterpret_cast<const float4*>(VT + (size_t)mn[kb] * D + koff + 256 * T);
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      float* nx = In + ((it + 1) & 1) * 6 * PT_SZ;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        if (f.E) ptile_lds_put(nx + (kb * 3 + 0) * PT_SZ, pe[kb], N, l0, mn[kb], tid);
-        if (f.G) ptile_lds_put(nx + (kb * 3 + 1) * PT_SZ, pg[kb], N, l0, mn[kb], tid);
-        if (f.M) ptile_lds_put(nx + (kb * 3 + 2) * PT_SZ, pm[kb], N, l0, mn[kb], tid);
+      for (int kt = 0; kt < KT; ++kt) {
+        v4f o = oacc[qt][kt];
+        o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+        oacc[qt][kt] = o;
       }
     }
-    __syncthreads();
+    STAMP(3);
+    // ---- O^T[k][l] += sum_m V^T[k][m] P^T[m][l]  (contraction order m = 4q + t): every V^T register feeds two MFMAs ----
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {   // H_hat tiles out: whole 512-byte runs
-      const int row = tid >> 5, m = (tid & 31) >> 1, mt0 = m0 + 16 * kb;
-      if (l0 + row < N && mt0 + m < N) {
-        const float* p = Hb2 + kb * PT_SZ + (tid & 1) * 4 * PT_PL + pt_off(row, m);
-        *reinterpret_cast<float4*>(Hb + ptile_off(prow, N, mt0, tid)) = make_float4(p[0], p[PT_PL], p[2 * PT_PL], p[3 * PT_PL]);
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const float va = r == 0 ? vc[kt].x : r == 1 ? vc[kt].y : r == 2 ? vc[kt].z : vc[kt].w;
+#pragma unroll
+        for (int qt = 0; qt < FQ; ++qt) oacc[qt][kt] = MFMA(va, pa[qt][r], oacc[qt][kt]);
+      }
+    STAMP(4);
+    lds_barrier();
+    STAMP(6);
+  }
+  // ---- finalize: V_att[l][k*8+h] = O[l][k] / l_run ; row statistics for the backward ----
+#pragma unroll
+  for (int qt = 0; qt < FQ; ++qt) {
+    const int l = l0 + 16 * qt + ll;
+    if (l < N) {
+      const float inv = 1.0f / lrun[qt];
+      float* vo = a.v_att + ((size_t)b * N + l) * DH + h;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vo[(16 * kt + 4 * q + r) * AH] = oacc[qt][kt][r] * inv;
+      if (q == 0) {
+        float* rs = a.rowstats + (((size_t)b * N + l) * AH + h) * 4;
+        rs[0] = mrun[qt]; rs[1] = lrun[qt]; rs[2] = 0.f; rs[3] = 0.f;
       }
     }
   }
-  if (l < N) {
-    const float inv = 1.0f / lrun;
-    float* vo = a.v_att + ((size_t)b * N + l) * DH + h;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) vo[(16 * kt + 4 * q + r) * AH] = oacc[kt][r] * inv;
-    if (q == 0) {
-      float* rs = a.rowstats + (((size_t)b * N + l) * AH + h) * 4;
-      rs[0] = mrun; rs[1] = lrun; rs[2] = 0.f; rs[3] = 0.f;
-    }
-  }
+  STAMP(7);
+  STAMP_OUT(0);
 }
 
 // ================================================================= backward =====
 // Launches (flash-attention style, the [N,N,H] probabilities are recomputed):
-//   k_attn_pack        : head-major operand arrays of Q, K, V, dV_att
-//   (delta[l,h] = sum_k dO[l,k,h] * O[l,k,h] -> rowstats[...][3] is computed by k_attn_pack's dO section)
-//   k_attn_mfma_bwd_kv : workgroup = (graph, 16-key tile), wave = head, walks the query tiles;
-//                        K/V fragments of the key tile live in registers; per tile S = Q.K^T and
-//                        dP = dO.V^T on MFMA, softmax/gate/clip backward on the VALU, then
-//                        dV^T += dO^T.A and dK^T += Q^T.dA on MFMA with the probabilities as B
-//                        operands in place; writes dE, dG and dA = dH*c*scale
-//   k_attn_mfma_bwd_q  : workgroup = (graph, 16 query rows), wave = head, walks the key tiles:
-//                        dQ^T += K^T.dA^T on MFMA from the dA tensor
-// Lane (mm = lane&15, q): key m0 + mm; in every query tile rows l0 + 4q + r.
+//   k_attn_pack        : head-major operand arrays of Q (pre-scaled), K, V, dV_att; the per-row constants
+//                        (m, 1/l, delta = sum_k dO*O) head-major
+//   k_attn_mfma_bwd_kv : workgroup = (graph, 32 keys, 4 heads): compute wave = head, K / V fragments and the dK / dV
+//                        accumulators of TWO key tiles in registers while the workgroup walks the query tiles; the loader
+//                        waves stage the Q / dO tiles of a query tile by LDS-DMA (the compute waves read BOTH operand forms
+//                        from that one tile), the pair tiles (E, G, dH_ext) into key-major planes, and store dE / dG;
+//                        per tile S = Q.K^T and dP = dO.V^T on MFMA, softmax / gate / clip backward on the VALU, then
+//                        dV^T += dO^T.A and dK^T += Q^T.dA on MFMA with the probabilities as B operands in place;
+//                        dA = dH*c leaves in the lane's own layout (one 16-byte store per key tile)
+//   k_attn_mfma_bwd_q  : wave = (graph, head, 32 query rows), walks the key tiles: dQ^T += K^T.dA^T straight from the
+//                        dA tiles and the packed K^T
+// Compute lane (mm = lane&15, q): keys m0 + 16 kb + mm; in every query tile rows l0 + 4q + r.
+#define BK 2   // key tiles per compute wave
 template <int D, int V>
 __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
-  constexpr int KT = D / 16, DH = D * AH;
-  const int lane = threadIdx.x & 63, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int mm = lane & 15, q = lane >> 4;
+  constexpr int KT = D / 16, DH = D * AH, NIN = 3, TS = BK * 4 * PT_PL;   // planes E | G | X (an attention-mask tensor is folded into E and G by the loaders)
+  static_assert(KT * 1024 * 2 * 4 <= OPS_STAGE, "operand stage");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wv >= 4;
+  const int w = wv & 3;
   const int N = a.N, NP = a.NP;
-  const int mtiles = NP / 16;
+  const int mtiles = NP / 16, mgroups = (mtiles + BK - 1) / BK;
+  float* statL = sm + OPS_BYTES / 4;   // [2 stages][4 heads][16 rows][4]
+  float* In = statL + 2 * 4 * 64;      // [2][E | G | X][TS], key-major planes
+  float* Out = In + 2 * NIN * TS;      // [2][dE | dG][TS]
   const int wg = egt_xcd_remap(blockIdx.x, gridDim.x);
-  const int b = wg / mtiles, m0 = (wg % mtiles) * 16;
-  const int m = m0 + mm, mc = min(m, N - 1);
-  const bool mvalid = m < N;
+  const int hg = wg & 1, grp = wg >> 1;
+  const int b = grp / mgroups, m0 = (grp % mgroups) * 16 * BK;
+  const int h = 4 * hg + w;
   const Feat<V> f(a);
-  const bool gated = f.G, clip = f.clip;
   const size_t arr = (size_t)a.B * AH * NP * D;
   const size_t hb = ((size_t)b * AH + h) * NP * D;
-  const float* Kh = a.pk + PK_KH * arr + hb;
-  const float* Vh = a.pk + PK_VH * arr + hb;
-  const float* Qh = a.pk + PK_QH * arr + hb;
-  const float* Oh = a.pk + PK_OH * arr + hb;
-  float id4[4];   // identity slices for the in-register transposes
-#pragma unroll
-  for (int u = 0; u < 4; ++u) id4[u] = (mm == 4 * q + u) ? 1.0f : 0.0f;
+  const size_t gb = (size_t)b * N * N * AH;
+  STAMP_DECL;
 
-  // K / V fragments of this lane's key (B operands of S = Q.K^T and dP = dO.V^T); padded keys are zero
-  float4 Kr[KT], Vr[KT];
+  if (loader) {
+    // ------------------------------------------------------------------ loader waves ----
+    const int lt = tid - 256;
+    const int crow = lt >> 4, ccol = lt & 15;   // query row, key of each 16 x 16 sub-tile; the group's 4 heads (16 bytes)
+    const float* Qh = a.pk + PB_QH * arr + hb;  // this loader wave feeds head h
+    const float* Oh = a.pk + PB_OH * arr + hb;
+    const unsigned doff = dma_lane_off(lane);
+    const unsigned ops0 = lds_addr(sm) + w * (KT * 2048);   // head w: Q tile, then dO tile
+    auto dma_ops = [&](int ltile, int stage) __attribute__((always_inline)) {
+      const float* qs = Qh + (size_t)ltile * 16 * D;
+      const float* os = Oh + (size_t)ltile * 16 * D;
+      const unsigned dst = ops0 + stage * OPS_STAGE;
 #pragma unroll
-  for (int T = 0; T < KT; ++T) {
-    Kr[T] = *reinterpret_cast<const float4*>(Kh + (size_t)m0 * D + 256 * T + mm * 16 + 4 * q);
-    Vr[T] = *reinterpret_cast<const float4*>(Vh + (size_t)m0 * D + 256 * T + mm * 16 + 4 * q);
-  }
-  const float kadd = (f.km && a.km[(size_t)b * N + mc] == 0) ? -EGT_NEG : 0.0f;
-  v4f dKacc[KT], dVacc[KT];
+      for (int T = 0; T < KT; ++T) dma_piece(dst + T * 1024, qs + T * 256, doff);
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) { dKacc[kt] = (v4f){0.f, 0.f, 0.f, 0.f}; dVacc[kt] = (v4f){0.f, 0.f, 0.f, 0.f}; }
-
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* In = sm;                     // [2][E | G | M | dH_ext][PT_SZ]
-  float* Out = sm + 2 * 4 * PT_SZ;    // [2][dE | dG | dA][PT_SZ]
-  const int tid = threadIdx.x;
-  float4 pe4 = make_float4(0.f, 0.f, 0.f, 0.f), pg4 = pe4, pm4 = pe4, px4 = pe4;
-  if (f.E) ptile_lds_put(In + 0 * PT_SZ, ptile_gload(a.E, b, N, 0, m0, tid), N, 0, m0, tid);
-  if (f.G) ptile_lds_put(In + 1 * PT_SZ, ptile_gload(a.G, b, N, 0, m0, tid), N, 0, m0, tid);
-  if (f.M) ptile_lds_put(In + 2 * PT_SZ, ptile_gload(a.M, b, N, 0, m0, tid), N, 0, m0, tid);
-  if (f.X) ptile_lds_put(In + 3 * PT_SZ, ptile_gload(a.d_h_ext, b, N, 0, m0, tid), N, 0, m0, tid);
-  float4 qan[KT], oan[KT], stn[4];   // row operands / statistics of the next query tile
+      for (int T = 0; T < KT; ++T) dma_piece(dst + KT * 1024 + T * 1024, os + T * 256, doff);
+    };
+    // per-row constants of the query tile: one float4 per (head, row) -- lanes 0..15 of each loader wave
+    const float* st2 = a.stats2 + ((size_t)b * AH + h) * NP * 4;
+    uint32_t coff[BK];
 #pragma unroll
-  for (int T = 0; T < KT; ++T) {
-    qan[T] = *reinterpret_cast<const float4*>(Qh + 256 * T + mm * 16 + 4 * q);
-    oan[T] = *reinterpret_cast<const float4*>(Oh + 256 * T + mm * 16 + 4 * q);
-  }
+    for (int kb = 0; kb < BK; ++kb) coff[kb] = (uint32_t)min(m0 + 16 * kb + ccol, N - 1) * AH + 4 * hg;   // + row * N * 8
+    auto cload = [&](const float* src, int l0, int kb) __attribute__((always_inline)) {
+      return *reinterpret_cast<const float4*>(src + gb + (size_t)min(l0 + crow, N - 1) * N * AH + coff[kb]);
+    };
+    struct Pair { float4 e, g, x; };
+    // tensors past their valid range read a valid address; only dH_ext must be ZERO there (it is added to dH).  An
+    // attention-mask tensor enters the backward only through the additive term of logit and gate: folded into E and G here.
+    auto pair_load = [&](int l0, int kb) __attribute__((always_inline)) {
+      Pair p;
+      p.e = p.g = p.x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f.E) p.e = cload(a.E, l0, kb);
+      if (f.G) p.g = cload(a.G, l0, kb);
+      if (f.X) {
+        p.x = cload(a.d_h_ext, l0, kb);
+        if (!(l0 + crow < N && m0 + 16 * kb + ccol < N)) p.x = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (f.M) {
+        const float4 mk = cload(a.M, l0, kb);
+        p.e.x += (mk.x - 1.0f) * EGT_NEG; p.e.y += (mk.y - 1.0f) * EGT_NEG; p.e.z += (mk.z - 1.0f) * EGT_NEG; p.e.w += (mk.w - 1.0f) * EGT_NEG;
+        p.g.x += (mk.x - 1.0f) * EGT_NEG; p.g.y += (mk.y - 1.0f) * EGT_NEG; p.g.z += (mk.z - 1.0f) * EGT_NEG; p.g.w += (mk.w - 1.0f) * EGT_NEG;
+      }
+      return p;
+    };
+    const int sc_off = ptT_off(crow, ccol);
+    auto scatter = [&](float* tl, int kb, float4 v) __attribute__((always_inline)) {
+      float* p = tl + kb * 4 * PT_PL + sc_off;
+      p[0] = v.x; p[PT_PL] = v.y; p[2 * PT_PL] = v.z; p[3 * PT_PL] = v.w;
+    };
+    auto pair_put = [&](float* st, int kb, const Pair& p) __attribute__((always_inline)) {
+      scatter(st + 0 * TS, kb, p.e);
+      if (f.G) scatter(st + 1 * TS, kb, p.g);
+      scatter(st + 2 * TS, kb, p.x);
+    };
+    auto gstore = [&](int itp) __attribute__((always_inline)) {   // dE / dG tiles of iteration itp: planes -> 16-byte pieces of the [N,N,8] rows
+      const int lp = 16 * itp;
+      const float* o = Out + (itp & 1) * 2 * TS;
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-    stn[r] = *reinterpret_cast<const float4*>(a.rowstats + (((size_t)b * N + min(4 * q + r, N - 1)) * AH + h) * 4);
-  __syncthreads();
-
-  for (int l0 = 0, it = 0; l0 < NP; l0 += 16, ++it) {
-    const bool more = l0 + 16 < NP;
-    // ---- loads, oldest first: transposed operands of THIS tile (consumed after the elementwise
-    //      phase), then the row operands / statistics / pair tiles of the NEXT tile ----
-    float4 qa[KT], oa[KT], st[4];
+      for (int kb = 0; kb < BK; ++kb)
+        if (lp + crow < N && m0 + 16 * kb + ccol < N) {
+          const float* p = o + kb * 4 * PT_PL + sc_off;
+          const size_t go = gb + (size_t)(lp + crow) * N * AH + coff[kb];
+          if (f.E) *reinterpret_cast<float4*>(a.d_E + go) = make_float4(p[0], p[PT_PL], p[2 * PT_PL], p[3 * PT_PL]);
+          if (f.G) *reinterpret_cast<float4*>(a.d_G + go) = make_float4(p[TS], p[TS + PT_PL], p[TS + 2 * PT_PL], p[TS + 3 * PT_PL]);
+        }
+    };
+    auto stat_put = [&](int ltile, int stage) __attribute__((always_inline)) {
+      if (lane < 16) *reinterpret_cast<float4*>(statL + ((stage * 4 + w) * 16 + lane) * 4) = *reinterpret_cast<const float4*>(st2 + (size_t)(ltile * 16 + lane) * 4);
+    };
+    dma_ops(0, 0);
+    stat_put(0, 0);
+    Pair pr[BK];
 #pragma unroll
-    for (int T = 0; T < KT; ++T) { qa[T] = qan[T]; oa[T] = oan[T]; }
-    // The transposed operands (A rows are channels: Q^T, dO^T of this tile) come from the row
-    // operands through the matrix core itself: D = X . I with the identity split over the four
-    // contraction steps (step u, B[k = q][j] = [j == 4q + u]) leaves lane (mm, q) with
-    // X[l0 + 4q + r][16T + mm] -- exact (one non-zero product per output), 32 extra MFMAs on a
-    // pipe that is 30 % busy instead of a second 8 KB operand fetch per wave and tile.
-    float4 qt[KT], ot[KT];
+    for (int kb = 0; kb < BK; ++kb) pair_put(In, kb, pair_load(0, kb));
 #pragma unroll
-    for (int T = 0; T < KT; ++T) {
-      v4f tq = {0.f, 0.f, 0.f, 0.f}, to = {0.f, 0.f, 0.f, 0.f};
-      tq = MFMA(qa[T].x, id4[0], tq);   to = MFMA(oa[T].x, id4[0], to);
-      tq = MFMA(qa[T].y, id4[1], tq);   to = MFMA(oa[T].y, id4[1], to);
-      tq = MFMA(qa[T].z, id4[2], tq);   to = MFMA(oa[T].z, id4[2], to);
-      tq = MFMA(qa[T].w, id4[3], tq);   to = MFMA(oa[T].w, id4[3], to);
-      qt[T] = make_float4(tq[0], tq[1], tq[2], tq[3]);
-      ot[T] = make_float4(to[0], to[1], to[2], to[3]);
+    for (int kb = 0; kb < BK; ++kb) pr[kb] = pair_load(min(16, NP - 16), kb);
+    vm_wait<0>();
+    lds_barrier();
+    for (int it = 0; it < mtiles; ++it) {
+      {   // pair tiles of query tile it+1 (requested one iteration ago) into the other stage
+        float* nx = In + ((it + 1) & 1) * NIN * TS;
+#pragma unroll
+        for (int kb = 0; kb < BK; ++kb) pair_put(nx, kb, pr[kb]);
+      }
+      if (it > 0) gstore(it - 1);
+      const int ln = min(it + 1, mtiles - 1);
+      stat_put(ln, (it + 1) & 1);
+      dma_ops(ln, (it + 1) & 1);
+      {
+        const int l2 = min(16 * (it + 2), NP - 16);
+#pragma unroll
+        for (int kb = 0; kb < BK; ++kb) pr[kb] = pair_load(l2, kb);
+      }
+      if (V) vm_wait<BK * 3>(); else vm_wait<0>();   // the BK * 3 register loads above are younger than the DMA pieces
+      lds_barrier();
     }
+    gstore(mtiles - 1);
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute waves ----
+  const int mm = lane & 15, q = lane >> 4;
+  const bool gated = f.G, clip = f.clip;
+  const uint32_t ooff = mm * 16 + 4 * q;
+  // K / V fragments of this lane's keys (B operands of S = Q.K^T and dP = dO.V^T); key rows past N are zero in the pack,
+  // a key tile past NP re-reads the last one and is switched off by its additive term
+  float4 Kr[BK][KT], Vr[BK][KT];
+  float kadd[BK], kaddg[BK];
+  bool tile_ok[BK];
+  float* dAb[BK];
+  {
+    const float* Kh = a.pk + PB_KH * arr + hb;
+    const float* Vh = a.pk + PB_VH * arr + hb;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) st[r] = stn[r];
-    size_t gi[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) gi[r] = (((size_t)b * N + min(l0 + 4 * q + r, N - 1)) * N + mc) * AH + h;
-    if (more && ABL_ON(a, 1)) {
+    for (int kb = 0; kb < BK; ++kb) {
+      const int mt = (m0 >> 4) + kb, mtc = min(mt, mtiles - 1);
+      tile_ok[kb] = mt < mtiles;
+      dAb[kb] = a.ws_dA + (((size_t)b * AH + h) * mtiles * mtiles + (size_t)mtc) * 256;   // + ltile * mtiles * 256
 #pragma unroll
       for (int T = 0; T < KT; ++T) {
-        qan[T] = *reinterpret_cast<const float4*>(Qh + (size_t)(l0 + 16) * D + 256 * T + mm * 16 + 4 * q);   // A rows are query rows
-        oan[T] = *reinterpret_cast<const float4*>(Oh + (size_t)(l0 + 16) * D + 256 * T + mm * 16 + 4 * q);
+        Kr[kb][T] = *reinterpret_cast<const float4*>(Kh + (size_t)mtc * 16 * D + 256 * T + ooff);
+        Vr[kb][T] = *reinterpret_cast<const float4*>(Vh + (size_t)mtc * 16 * D + 256 * T + ooff);
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        stn[r] = *reinterpret_cast<const float4*>(a.rowstats + (((size_t)b * N + min(l0 + 16 + 4 * q + r, N - 1)) * AH + h) * 4);
-    }
-    if (more && ABL_ON(a, 4)) {
-      if (f.E) pe4 = ptile_gload(a.E, b, N, l0 + 16, m0, tid);
-      if (f.G) pg4 = ptile_gload(a.G, b, N, l0 + 16, m0, tid);
-      if (f.M) pm4 = ptile_gload(a.M, b, N, l0 + 16, m0, tid);
-      if (f.X) px4 = ptile_gload(a.d_h_ext, b, N, l0 + 16, m0, tid);
-    }
-    const float* Et = In + (it & 1) * 4 * PT_SZ;
-    const float* Gt = Et + PT_SZ;
-    const float* Mt = Gt + PT_SZ;
-    const float* Xt = Mt + PT_SZ;
-    float* dEt = Out + (it & 1) * 3 * PT_SZ;
-    float* dGt = dEt + PT_SZ;
-    float* dAt = dGt + PT_SZ;
-    // ---- S[l][m] = sum_k Q[l][k] K[m][k] ; dP[l][m] = sum_k dO[l][k] V[m][k] ----
-    v4f s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-    if (ABL_ON(a, 8))
-#pragma unroll
-    for (int T = 0; T < KT; ++T) {
-      s = MFMA(qa[T].x, Kr[T].x, s);   dp = MFMA(oa[T].x, Vr[T].x, dp);
-      s = MFMA(qa[T].y, Kr[T].y, s);   dp = MFMA(oa[T].y, Vr[T].y, dp);
-      s = MFMA(qa[T].z, Kr[T].z, s);   dp = MFMA(oa[T].z, Vr[T].z, dp);
-      s = MFMA(qa[T].w, Kr[T].w, s);   dp = MFMA(oa[T].w, Vr[T].w, dp);
-    }
-    float at[4], da[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int l = l0 + 4 * q + r;
-      const bool valid = mvalid && l < N;
-      const float araw = s[r] * a.scale;
-      float ah = araw, inr = 1.0f;
-      if (clip) {
-        inr = (araw >= a.clip_lo && araw <= a.clip_hi) ? 1.0f : 0.0f;
-        ah = fminf(fmaxf(araw, a.clip_lo), a.clip_hi);
-      }
-      const int po = h * PT_PL + pt_off(4 * q + r, mm);
-      const float add = mask_add(a, f, kadd, f.M ? Mt[po] : 1.f, gi[r]);
-      const float xv = ah + (f.E ? Et[po] : 0.f) + add;
-      const float S = valid ? __expf(xv - st[r].x) * __builtin_amdgcn_rcpf(st[r].y) : 0.f;
-      const float g = gated ? egt_sigmoid(Gt[po] + add) : 1.0f;
-      const float dAt_ = dp[r];
-      float dH = S * (dAt_ * g - st[r].w) + (f.X ? Xt[po] : 0.f);
-      if (!valid) dH = 0.f;
-      da[r] = dH * inr * a.scale;
-      at[r] = S * g;
-      dEt[po] = dH;
-      dGt[po] = gated ? dAt_ * S * g * (1.0f - g) : 0.f;
-      dAt[po] = da[r];
-    }
-    // ---- dV^T[k][m] += sum_l dO[l][k] A[l][m] ; dK^T[k][m] += sum_l Q[l][k] dA[l][m] ----
-    if (ABL_ON(a, 8))
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      v4f dv = dVacc[kt], dk = dKacc[kt];
-      dv = MFMA(ot[kt].x, at[0], dv);   dk = MFMA(qt[kt].x, da[0], dk);
-      dv = MFMA(ot[kt].y, at[1], dv);   dk = MFMA(qt[kt].y, da[1], dk);
-      dv = MFMA(ot[kt].z, at[2], dv);   dk = MFMA(qt[kt].z, da[2], dk);
-      dv = MFMA(ot[kt].w, at[3], dv);   dk = MFMA(qt[kt].w, da[3], dk);
-      dVacc[kt] = dv; dKacc[kt] = dk;
-    }
-    if (more) {
-      float* nx = In + ((it + 1) & 1) * 4 * PT_SZ;
-      if (f.E) ptile_lds_put(nx, pe4, N, l0 + 16, m0, tid);
-      if (f.G) ptile_lds_put(nx + PT_SZ, pg4, N, l0 + 16, m0, tid);
-      if (f.M) ptile_lds_put(nx + 2 * PT_SZ, pm4, N, l0 + 16, m0, tid);
-      if (f.X) ptile_lds_put(nx + 3 * PT_SZ, px4, N, l0 + 16, m0, tid);
-    }
-    if (ABL_ON(a, 16)) __syncthreads();
-    if (ABL_ON(a, 2)) {
-    if (f.E) ptile_gstore(a.d_E, dEt, b, N, l0, m0, tid);
-    if (f.G) ptile_gstore(a.d_G, dGt, b, N, l0, m0, tid);
-    ptile_gstore(a.ws_dA, dAt, b, N, l0, m0, tid);
+      const int m = m0 + 16 * kb + mm;
+      kadd[kb] = 0.f;
+      if (m >= N) kadd[kb] = KEY_OFF;
+      else if (f.km && a.km[(size_t)b * N + m] == 0) kadd[kb] = -EGT_NEG;
+      kaddg[kb] = m < N ? -kadd[kb] * L2E : 3.0e38f;
     }
   }
-  if (mvalid) {
-    float* o = a.d_qkv + ((size_t)b * N + m) * 3 * DH + h;
+  v4f dKacc[BK][KT], dVacc[BK][KT];
+#pragma unroll
+  for (int kb = 0; kb < BK; ++kb)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) { dKacc[kb][kt] = (v4f){0.f, 0.f, 0.f, 0.f}; dVacc[kb][kt] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+  const int po4 = w * PT_PL + ptT_off(4 * q, mm);   // this lane's query rows 4q..4q+3 of key mm inside a sub-tile: one 16-byte access
+  // operand tiles of head w (Q, then dO): row form: lane (row mm, chunk q) b128; transposed form: lane (channel mm, q):
+  // rows 4q + r, dword mm & 3 of chunk mm >> 2
+  const float* oprow = sm + w * (KT * 512) + mm * 16 + ((q ^ chunk_xor(mm)) << 2);
+  const float* optr = sm + w * (KT * 512) + (4 * q) * 16 + (((mm >> 2) ^ chunk_xor(4 * q)) << 2) + (mm & 3);
+  lds_barrier();
+  STAMP(0);
+  for (int l0 = 0, it = 0; it < mtiles; l0 += 16, ++it) {
+    const float* opr = oprow + (it & 1) * (OPS_STAGE / 4);
+    const float* opt = optr + (it & 1) * (OPS_STAGE / 4);
+    const float* Inb = In + (it & 1) * NIN * TS;
+    float* Ob = Out + (it & 1) * 2 * TS;
+    float4 e4[BK], g4[BK], x4[BK], stc[4];
+#pragma unroll
+    for (int kb = 0; kb < BK; ++kb) {
+      e4[kb] = *reinterpret_cast<const float4*>(Inb + 0 * TS + kb * 4 * PT_PL + po4);
+      g4[kb] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f.G) g4[kb] = *reinterpret_cast<const float4*>(Inb + 1 * TS + kb * 4 * PT_PL + po4);
+      x4[kb] = *reinterpret_cast<const float4*>(Inb + 2 * TS + kb * 4 * PT_PL + po4);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) stc[r] = *reinterpret_cast<const float4*>(statL + (((it & 1) * 4 + w) * 16 + 4 * q + r) * 4);
+    STAMP(1);
+    // ---- S[l][m] = sum_k (d^-1/2 Q)[l][k] K[m][k] ; dP[l][m] = sum_k dO[l][k] V[m][k]: every Q / dO register feeds two MFMAs ----
+    v4f s[BK], dp[BK];
+#pragma unroll
+    for (int kb = 0; kb < BK; ++kb) { s[kb] = (v4f){0.f, 0.f, 0.f, 0.f}; dp[kb] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int T = 0; T < KT; ++T) {
+      const float4 qa = *reinterpret_cast<const float4*>(opr + T * 256);
+      const float4 oa = *reinterpret_cast<const float4*>(opr + KT * 256 + T * 256);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float qq = u == 0 ? qa.x : u == 1 ? qa.y : u == 2 ? qa.z : qa.w;
+        const float oo = u == 0 ? oa.x : u == 1 ? oa.y : u == 2 ? oa.z : oa.w;
+#pragma unroll
+        for (int kb = 0; kb < BK; ++kb) {
+          const float kk = u == 0 ? Kr[kb][T].x : u == 1 ? Kr[kb][T].y : u == 2 ? Kr[kb][T].z : Kr[kb][T].w;
+          const float vv = u == 0 ? Vr[kb][T].x : u == 1 ? Vr[kb][T].y : u == 2 ? Vr[kb][T].z : Vr[kb][T].w;
+          s[kb] = MFMA(qq, kk, s[kb]);
+          dp[kb] = MFMA(oo, vv, dp[kb]);
+        }
+      }
+    }
+    STAMP(2);
+    float at[BK][4], da[BK][4];
+#pragma unroll
+    for (int kb = 0; kb < BK; ++kb) {
+      const float ev[4] = {e4[kb].x, e4[kb].y, e4[kb].z, e4[kb].w}, gv[4] = {g4[kb].x, g4[kb].y, g4[kb].z, g4[kb].w};
+      const float xv4[4] = {x4[kb].x, x4[kb].y, x4[kb].z, x4[kb].w};
+      float dE4[4], dG4[4];
+      const int mc = min(m0 + 16 * kb + mm, N - 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float araw = s[kb][r];
+        float ah = araw;
+        if (clip) ah = __builtin_amdgcn_fmed3f(araw, a.clip_lo, a.clip_hi);
+        float add = kadd[kb];
+        if (V != 1) {
+          const int lq = min(l0 + 4 * q + r, N - 1);
+          add += mask_extra(a, f, 1.0f, (uint32_t)((((size_t)b * N + lq) * N + mc) * AH + h));   // (the mask tensor arrives inside E / G)
+        }
+        const float xx = ah + ev[r] + add;
+        const float S = exp2_fast((xx - stc[r].x) * L2E) * stc[r].y;   // rows past N: 1/l = 0; keys past N: exp2(-inf) = 0
+        float g = 1.0f;
+        if (gated) {
+          const float tg = V == 1 ? exp2_fast(fmaf(gv[r], -L2E, kaddg[kb])) : exp2_fast((gv[r] + add) * -L2E);
+          g = __builtin_amdgcn_rcpf(1.0f + tg);
+        }
+        const float dAt_ = dp[kb][r];
+        const float Sg = S * g;
+        const float dH = fmaf(S, fmaf(dAt_, g, -stc[r].z), xv4[r]);
+        at[kb][r] = Sg;
+        da[kb][r] = (clip && ah != araw) ? 0.f : dH;   // clip passes the gradient where lo <= x <= hi
+        dE4[r] = dH;
+        dG4[r] = gated ? dAt_ * Sg * (1.0f - g) : 0.f;
+      }
+      if (f.E) *reinterpret_cast<float4*>(Ob + kb * 4 * PT_PL + po4) = make_float4(dE4[0], dE4[1], dE4[2], dE4[3]);
+      if (f.G) *reinterpret_cast<float4*>(Ob + TS + kb * 4 * PT_PL + po4) = make_float4(dG4[0], dG4[1], dG4[2], dG4[3]);
+      // dA tile [key][query] of (head, query tile, key tile): the lane's own four rows, one 16-byte store
+      if (tile_ok[kb] && ABL(4))
+        *reinterpret_cast<float4*>(dAb[kb] + (size_t)it * mtiles * 256 + ooff) = make_float4(da[kb][0], da[kb][1], da[kb][2], da[kb][3]);
+    }
+    STAMP(3);
+    // ---- dV^T[k][m] += sum_l dO[l][k] A[l][m] ; dK^T[k][m] += sum_l (d^-1/2 Q)[l][k] dA[l][m]: transposed operands from the same tiles ----
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int k = 16 * kt + 4 * q + r;
-        o[DH + k * AH] = dKacc[kt][r];
-        o[2 * DH + k * AH] = dVacc[kt][r];
+        const float qq = opt[kt * 256 + r * 16];
+        const float oo = opt[KT * 256 + kt * 256 + r * 16];
+#pragma unroll
+        for (int kb = 0; kb < BK; ++kb) {
+          dVacc[kb][kt] = MFMA(oo, at[kb][r], dVacc[kb][kt]);
+          dKacc[kb][kt] = MFMA(qq, da[kb][r], dKacc[kb][kt]);
+        }
       }
+    STAMP(4);
+    lds_barrier();
+    STAMP(6);
   }
+#pragma unroll
+  for (int kb = 0; kb < BK; ++kb) {
+    const int m = m0 + 16 * kb + mm;
+    if (m < N) {
+      float* o = a.d_qkv + ((size_t)b * N + m) * 3 * DH + h;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * kt + 4 * q + r;
+          o[DH + k * AH] = dKacc[kb][kt][r];
+          o[2 * DH + k * AH] = dVacc[kb][kt][r];
+        }
+    }
+  }
+  STAMP(7);
+  STAMP_OUT(1);
 }
 
-// Lane (ll = lane&15, q): query row l0 + ll; keys m0 + 4q + t as the contraction index.
-// TB key tiles per iteration (one barrier per 16*TB keys; K^T operands single-buffered: the next
-// block's are requested right after the MFMAs have read the registers).  TB = 4 for grids that
-// cannot give a CU two workgroups, TB = 1 (76 VGPRs, several workgroups per CU) otherwise.
-template <int D, int TB>
-__global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_q(AttnMfmaArgs a) {
+// wave = (graph, head, QT query tiles); lane (ll = lane&15, q): query rows l0 + 16 j + ll, keys m0 + 4q + u as the
+// contraction index.  K^T operands (shared by the QT query tiles) and the dA tiles come straight from L2 into the
+// registers that feed the matrix core, two key tiles ahead; no LDS, no barrier.
+template <int D, int QT>
+__global__ void __launch_bounds__(256) k_attn_mfma_bwd_q(AttnMfmaArgs a) {
   constexpr int KT = D / 16, DH = D * AH;
-  const int lane = threadIdx.x & 63, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   const int ll = lane & 15, q = lane >> 4;
   const int N = a.N, NP = a.NP;
-  const int ltiles = NP / 16;
-  const int wg = egt_xcd_remap(blockIdx.x, gridDim.x);
-  const int b = wg / ltiles, l0 = (wg % ltiles) * 16;
-  const int l = l0 + ll;
+  const int mtiles = NP / 16, lgroups = (mtiles + QT - 1) / QT;
+  const int gw = egt_xcd_remap(blockIdx.x, gridDim.x) * 4 + (int)(threadIdx.x >> 6);   // wave index
+  const int per_b = AH * lgroups;
+  const int b = __builtin_amdgcn_readfirstlane(gw / per_b), h = __builtin_amdgcn_readfirstlane((gw % per_b) / lgroups);
+  const int lt0 = __builtin_amdgcn_readfirstlane(((gw % per_b) % lgroups) * QT);
+  if (b >= a.B) return;
   const size_t arr = (size_t)a.B * AH * NP * D;
-  const float* KTp = a.pk + PK_KT * arr + ((size_t)b * AH + h) * D * NP;
+  const float* KTp = a.pk + PB_KT * arr + ((size_t)b * AH + h) * D * NP;
+  const float* dAh = a.ws_dA + ((size_t)b * AH + h) * mtiles * mtiles * 256;
   const uint32_t koff = ll * 16 + 4 * q;
-  v4f dQacc[KT];
+  v4f dQacc[QT][KT];
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) dQacc[kt] = (v4f){0.f, 0.f, 0.f, 0.f};
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // dA tiles [2][TB][PT_SZ]
-  const int tid = threadIdx.x;
-  const int mlast = NP - 16;
-  float4 kc[TB][KT], pa4[TB];
+  for (int j = 0; j < QT; ++j)
 #pragma unroll
-  for (int tb = 0; tb < TB; ++tb) {
-    const int mk = min(16 * tb, mlast);   // tiles past the end: K^T of the last tile against dA columns that are zero
+    for (int kt = 0; kt < KT; ++kt) dQacc[j][kt] = (v4f){0.f, 0.f, 0.f, 0.f};
+  int ltj[QT];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) kc[tb][kt] = *reinterpret_cast<const float4*>(KTp + (size_t)mk * D + koff + 256 * kt);
-    ptile_lds_put(sm + tb * PT_SZ, ptile_gload(a.ws_dA, b, N, l0, 16 * tb, tid), N, l0, 16 * tb, tid);
-    pa4[tb] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  for (int m0 = 0, it = 0; m0 < NP; m0 += 16 * TB, ++it) {
+  for (int j = 0; j < QT; ++j) ltj[j] = min(lt0 + j, mtiles - 1);   // a short last group recomputes the last tile (not stored)
+  // dA tile of (query tile lt, key tile mt) is key-major [key][query]: this lane's B operands are the four keys
+  // 4q + u of its query row
+  auto lda = [&](int j, int mt, float (&d)[4]) __attribute__((always_inline)) {
+    const float* p = dAh + ((size_t)ltj[j] * mtiles + mt) * 256 + 64 * q + ll;
 #pragma unroll
-    for (int tb = 0; tb < TB; ++tb) pa4[tb] = ptile_gload(a.ws_dA, b, N, l0, m0 + 16 * (TB + tb), tid);   // clamped, zeroed at the LDS store
-    __builtin_amdgcn_sched_barrier(0);
-    const float* At = sm + (it & 1) * TB * PT_SZ;
-    float4 da4[TB];
+    for (int u = 0; u < 4; ++u) d[u] = p[16 * u];
+  };
+  float4 kcA[KT], kcB[KT];
+  float daA[QT][4], daB[QT][4];
+  auto ldk = [&](int mt, float4 (&k)[KT]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int tb = 0; tb < TB; ++tb) da4[tb] = *reinterpret_cast<const float4*>(At + tb * PT_SZ + h * PT_PL + pt_off(ll, 4 * q));
-    // dQ^T[k][l] += sum_m K^T[k][m] dA[l][m]
+    for (int kt = 0; kt < KT; ++kt) k[kt] = *reinterpret_cast<const float4*>(KTp + (size_t)mt * 16 * D + koff + 256 * kt);
+  };
+  auto mma = [&](const float4 (&k)[KT], const float (&d)[QT][4]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      v4f dq = dQacc[kt];
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int tb = 0; tb < TB; ++tb) {
-        dq = MFMA(kc[tb][kt].x, da4[tb].x, dq);
-        dq = MFMA(kc[tb][kt].y, da4[tb].y, dq);
-        dq = MFMA(kc[tb][kt].z, da4[tb].z, dq);
-        dq = MFMA(kc[tb][kt].w, da4[tb].w, dq);
+      for (int kt = 0; kt < KT; ++kt) {
+        const float kk = u == 0 ? k[kt].x : u == 1 ? k[kt].y : u == 2 ? k[kt].z : k[kt].w;
+#pragma unroll
+        for (int j = 0; j < QT; ++j) dQacc[j][kt] = MFMA(kk, d[j][u], dQacc[j][kt]);
       }
-      dQacc[kt] = dq;
+  };
+  ldk(0, kcA);
+#pragma unroll
+  for (int j = 0; j < QT; ++j) lda(j, 0, daA[j]);
+  ldk(min(1, mtiles - 1), kcB);
+#pragma unroll
+  for (int j = 0; j < QT; ++j) lda(j, min(1, mtiles - 1), daB[j]);
+  // dQ^T[k][l] += sum_m K^T[k][m] dA[l][m]; two key tiles per trip, each register set reloaded two tiles ahead
+  int mt = 0;
+  for (; mt + 1 < mtiles; mt += 2) {
+    mma(kcA, daA);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int m2 = min(mt + 2, mtiles - 1);
+      ldk(m2, kcA);
+#pragma unroll
+      for (int j = 0; j < QT; ++j) lda(j, m2, daA[j]);
     }
     __builtin_amdgcn_sched_barrier(0);
+    mma(kcB, daB);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int m3 = min(mt + 3, mtiles - 1);
+      ldk(m3, kcB);
 #pragma unroll
-    for (int tb = 0; tb < TB; ++tb) {
-      const int mk = min(m0 + 16 * (TB + tb), mlast);
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt) kc[tb][kt] = *reinterpret_cast<const float4*>(KTp + (size_t)mk * D + koff + 256 * kt);
+      for (int j = 0; j < QT; ++j) lda(j, m3, daB[j]);
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int tb = 0; tb < TB; ++tb)
-      ptile_lds_put(sm + (((it + 1) & 1) * TB + tb) * PT_SZ, pa4[tb], N, l0, m0 + 16 * (TB + tb), tid);
-    __syncthreads();
   }
-  if (l < N) {
-    float* o = a.d_qkv + ((size_t)b * N + l) * 3 * DH + h;
+  if (mt < mtiles) mma(kcA, daA);
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+  for (int j = 0; j < QT; ++j) {
+    const int l = (lt0 + j) * 16 + ll;
+    if (lt0 + j < mtiles && l < N) {
+      float* o = a.d_qkv + ((size_t)b * N + l) * 3 * DH + h;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[(16 * kt + 4 * q + r) * AH] = dQacc[kt][r];
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(16 * kt + 4 * q + r) * AH] = dQacc[j][kt][r] * a.scale;
+    }
   }
 }
 
@@ -914,41 +943,22 @@ extern "C" int egt_attn_mfma_supported(const egt_attn_desc* d, int need_a_tild) 
   if ((d->flags & EGT_F_TRAINING) && d->attn_dropout > 0.0f) return 0;
   if (need_a_tild) return 0;
   if ((size_t)d->B * d->N * d->N * d->H > 0xFFFFFFFFull) return 0;
+  if (d->N > 2048) return 0;   // the forward keeps two per-key tables of N floats in LDS beside its stages
   return 1;
 }
 
 static int np_of(int N) { return (N + 15) & ~15; }
 
-// forward uses the first 2 packed arrays, backward all 8 followed by the dA tensor
+// forward: K rows + V^T; backward: five packed arrays, the per-row constants and the dA tiles
 extern "C" size_t egt_attn_mfma_workspace_bytes(const egt_attn_desc* d) {
   if (!egt_attn_mfma_supported(d, 0)) return 0;
-  const size_t arr = (size_t)d->B * AH * np_of(d->N) * d->d;
-  return (PK_COUNT * arr + (size_t)d->B * d->N * d->N * AH) * sizeof(float);
+  const size_t NP = np_of(d->N), arr = (size_t)d->B * AH * NP * d->d;
+  return (PB_COUNT * arr + (size_t)d->B * AH * NP * 4 + (size_t)d->B * AH * NP * NP) * sizeof(float);
 }
 
 extern "C" size_t egt_attn_mfma_fwd_workspace_bytes(const egt_attn_desc* d) {
   if (!egt_attn_mfma_supported(d, 0)) return 0;
-  return (size_t)2 * d->B * AH * np_of(d->N) * d->d * sizeof(float);
-}
-
-// experiment switches, read once per process (no getenv on the launch path)
-struct EgtAttnEnv { int ablate, generic, fwd2 /* -1: auto */, bwdq4; };
-static const EgtAttnEnv& attn_env() {
-  static const EgtAttnEnv e = [] {
-    EgtAttnEnv v{};
-    const char* g = getenv("EGT_ATTN_ABLATE");
-    v.ablate = g ? atoi(g) : 0;
-#ifndef EGT_ATTN_ABLATION
-    if (v.ablate) { fprintf(stderr, "[egt] EGT_ATTN_ABLATE ignored: build with EGT_ATTN_FLAGS=-DEGT_ATTN_ABLATION\n"); v.ablate = 0; }
-#endif
-    v.generic = getenv("EGT_ATTN_GENERIC") != nullptr;
-    const char* f2 = getenv("EGT_ATTN_FWD2");
-    v.fwd2 = f2 ? (atoi(f2) != 0) : -1;
-    const char* e4 = getenv("EGT_ATTN_BWDQ4");
-    v.bwdq4 = e4 ? (atoi(e4) != 0) : 0;
-    return v;
-  }();
-  return e;
+  return (size_t)PF_COUNT * d->B * AH * np_of(d->N) * d->d * sizeof(float);
 }
 
 static int fill(const egt_attn_desc* desc, const void* qkv, const void* E, const void* G,
@@ -963,7 +973,6 @@ static int fill(const egt_attn_desc* desc, const void* qkv, const void* E, const
   a.B = desc->B; a.N = desc->N; a.NP = np_of(desc->N); a.d = desc->d; a.flags = desc->flags;
   a.clip_lo = desc->clip_lo; a.clip_hi = desc->clip_hi;
   a.scale = 1.0f / sqrtf((float)desc->d);
-  a.guard = attn_env().ablate;
   a.rm_thr = egt_threshold24(desc->random_mask_prob);
   a.s0 = (uint32_t)(desc->seed & 0xFFFFFFFFull); a.s1 = (uint32_t)(desc->seed >> 32);
   a.qkv = (const float*)qkv;
@@ -985,26 +994,22 @@ static void launch_pack(const AttnMfmaArgs& a, hipStream_t st) {
   EGT_LAUNCH("k_attn_pack", k_attn_pack<D>, dim3(a.B * (a.NP / 16) * (a.pack_bwd ? 4 : 2)), dim3(256), lds, st, a);
 }
 
-// 1 / 2: the straight-line instances (see Feat), 0: the run-time-switched one
+// 1 / 2: the straight-line instances (see Feat), 0: the run-time-switched one (EGT_ATTN_GENERIC forces it: tests)
 static int variant_of(const AttnMfmaArgs& a, bool bwd) {
+  static const bool generic = getenv("EGT_ATTN_GENERIC") != nullptr;
   const bool main_cfg = a.E && (a.flags & EGT_F_GATE_INPUT) && a.G && !a.M && a.km && (a.flags & EGT_F_CLIP) && !a.rm &&
                         (!bwd || (a.d_h_ext && a.d_E && a.d_G));
-  if (!main_cfg || attn_env().generic) return 0;
+  if (!main_cfg || generic) return 0;
   return a.rng_rm ? 2 : 1;
 }
 
 template <int D, int V>
 static void launch_fwd_v(const AttnMfmaArgs& a, hipStream_t st) {
-  // small grids (no CU would get two workgroups anyway): two key tiles per iteration
-  const int f2 = attn_env().fwd2;
-  const bool two = f2 >= 0 ? f2 != 0 : (a.B * (a.NP / 16) <= 512);
-  if (two) {
-    EGT_MAX_LDS_ONCE(k_attn_mfma_fwd2<D, V>);
-    EGT_LAUNCH("k_attn_mfma_fwd", (k_attn_mfma_fwd2<D, V>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)16 * PT_SZ * 4, st, a);
-    return;
-  }
+  const size_t ts = (size_t)FQ * 4 * PT_PL;
+  const size_t lds = OPS_BYTES + ((size_t)2 * ((a.NP + 16 + 3) & ~3) + (size_t)(2 * (V ? 2 : 3) + 2) * ts) * 4;
+  const int lgroups = (a.NP / 16 + FQ - 1) / FQ;
   EGT_MAX_LDS_ONCE(k_attn_mfma_fwd<D, V>);
-  EGT_LAUNCH("k_attn_mfma_fwd", (k_attn_mfma_fwd<D, V>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)8 * PT_SZ * 4, st, a);
+  EGT_LAUNCH("k_attn_mfma_fwd", (k_attn_mfma_fwd<D, V>), dim3(a.B * lgroups * 2), dim3(512), lds, st, a);
 }
 template <int D>
 static void launch_fwd(const AttnMfmaArgs& a, hipStream_t st) {
@@ -1037,25 +1042,23 @@ extern "C" int egt_attn_mfma_fwd(const egt_attn_desc* desc, const void* qkv, con
 
 template <int D, int V>
 static void launch_bwd_kv_v(const AttnMfmaArgs& a, hipStream_t st) {
+  const size_t lds = OPS_BYTES + ((size_t)2 * 4 * 64 + (size_t)(2 * 3 + 4) * BK * 4 * PT_PL) * 4;
+  const int mgroups = (a.NP / 16 + BK - 1) / BK;
   EGT_MAX_LDS_ONCE(k_attn_mfma_bwd_kv<D, V>);
-  EGT_LAUNCH("k_attn_mfma_bwd_kv", (k_attn_mfma_bwd_kv<D, V>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)14 * PT_SZ * 4, st, a);
+  EGT_LAUNCH("k_attn_mfma_bwd_kv", (k_attn_mfma_bwd_kv<D, V>), dim3(a.B * mgroups * 2), dim3(512), lds, st, a);
 }
 template <int D>
 static void launch_bwd(const AttnMfmaArgs& a, hipStream_t st) {
-  launch_pack<D>(a, st);   // (also writes delta = sum_k dO*O into rowstats[..][3])
+  launch_pack<D>(a, st);   // (also the per-row constants, delta = sum_k dO*O among them)
   switch (variant_of(a, true)) {
     case 1: launch_bwd_kv_v<D, 1>(a, st); break;
     case 2: launch_bwd_kv_v<D, 2>(a, st); break;
     default: launch_bwd_kv_v<D, 0>(a, st); break;
   }
   {
-    const bool four = attn_env().bwdq4 != 0;   // four key tiles per iteration: measured equal to one (49 vs 50 us at B = 8, slower at B = 32), kept as an experiment switch
-    if (four) {
-      EGT_MAX_LDS_ONCE(k_attn_mfma_bwd_q<D, 4>);
-      EGT_LAUNCH("k_attn_mfma_bwd_q", (k_attn_mfma_bwd_q<D, 4>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)8 * PT_SZ * 4, st, a);
-    } else {
-      EGT_LAUNCH("k_attn_mfma_bwd_q", (k_attn_mfma_bwd_q<D, 1>), dim3(a.B * (a.NP / 16)), dim3(512), (size_t)2 * PT_SZ * 4, st, a);
-    }
+    constexpr int QT = 2;
+    const int waves = a.B * AH * ((a.NP / 16 + QT - 1) / QT);
+    EGT_LAUNCH("k_attn_mfma_bwd_q", (k_attn_mfma_bwd_q<D, QT>), dim3((waves + 3) / 4), dim3(256), 0, st, a);
   }
 }
 
@@ -1076,7 +1079,9 @@ extern "C" int egt_attn_mfma_bwd(const egt_attn_desc* desc, const void* qkv, con
   a.d_qkv = (float*)d_qkv;
   a.d_E = (desc->flags & EGT_F_EDGE_INPUT) ? (float*)d_E : nullptr;
   a.d_G = (desc->flags & EGT_F_GATE_INPUT) ? (float*)d_G : nullptr;
-  a.ws_dA = a.pk + (size_t)PK_COUNT * a.B * AH * a.NP * a.d;
+  const size_t arr = (size_t)a.B * AH * a.NP * a.d;
+  a.stats2 = a.pk + (size_t)PB_COUNT * arr;
+  a.ws_dA = a.stats2 + (size_t)a.B * AH * a.NP * 4;
   a.pack_bwd = 1;
   switch (desc->d) {
     case 16: launch_bwd<16>(a, (hipStream_t)stream); break;
@@ -1086,3 +1091,12 @@ extern "C" int egt_attn_mfma_bwd(const egt_attn_desc* desc, const void* qkv, con
   EGT_HIP_LAUNCH_CHECK("egt_attn_mfma_bwd");
   return EGT_OK;
 }
+
+#ifdef EGT_ATTN_STAMPS
+extern "C" int egt_attn_mfma_read_stamps(long long* host, int n) {
+  long long tmp[3 * 8 * 16];
+  if (hipMemcpyFromSymbol(tmp, HIP_SYMBOL(g_attn_stamps), sizeof(tmp)) != hipSuccess) return -1;
+  for (int i = 0; i < n && i < 3 * 8 * 16; ++i) host[i] = tmp[i];
+  return 0;
+}
+#endif

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Bank-conflict enumeration of the LDS access patterns of egt_attn_mfma.hip against the gfx950 lane-group
+tables (MI355X_MICROARCH.md, LDS): prints the worst number of LDS cycles per lane group for every pattern
+(1 = conflict free).  Run after touching pt_off / ptT_off."""
+import itertools
+
+B128_GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
+               list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+               list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)),
+               list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
+B32_GROUPS = [list(range(0, 32)), list(range(32, 64))]
+W128_GROUPS = [list(range(8 * i, 8 * i + 8)) for i in range(8)]
+
+
+def worst(groups, addr, width, nbanks):
+    """addr(lane) -> dword address (or None = lane inactive); width dwords per lane"""
+    w = 0
+    for g in groups:
+        banks = {}
+        for l in g:
+            a = addr(l)
+            if a is None:
+                continue
+            for k in range(width):
+                banks.setdefault((a + k) % nbanks, set()).add(a + k)
+        if banks:
+            w = max(w, max(len(v) for v in banks.values()))
+    return w
+
+
+PT_PL = 260
+
+
+def pt_off(row, m):          # forward planes: [query row][key], rows 4-7 / 12-15 pair-swapped, chunks XORed
+    return ((row ^ ((row >> 2) & 1)) << 4) + ((((m >> 2) ^ (row >> 1)) & 3) << 2) + (m & 3)
+
+
+A_T = (0, 2, 3, 1)
+
+
+def ptT_off(row, col):       # backward planes: [key col][query row], one b128 = rows 4q..4q+3 of a key
+    return (col << 4) + (((row >> 2) ^ A_T[col >> 2]) << 2) + (row & 3)
+
+
+def report(name, w):
+    print(f"{name:70s} {w}-way" + ("" if w == 1 else "   <-- conflicts"))
+
+
+def main():
+    # cooperative scatter: thread tid -> (row = tid >> 5, key = (tid & 31) >> 1, heads 4 * (tid & 1) + c)
+    for nm, off in (("fwd plane", pt_off), ("bwd plane (transposed)", lambda r, c: ptT_off(r, c))):
+        for wave in range(8):
+            for c in range(4):
+                def addr(l, wave=wave, c=c):
+                    tid = wave * 64 + l
+                    row, m, half = tid >> 5, (tid & 31) >> 1, tid & 1
+                    return (4 * half + c) * PT_PL + off(row, m)
+                w = worst(B32_GROUPS, addr, 1, 32)
+                if wave == 0 or w > 1:
+                    report(f"{nm}: scatter b32, wave {wave}, c {c}", w)
+                    break
+    # forward lanes (ll = lane & 15 query row, q): b128 of keys 4q..4q+3
+    for h in (0, 3):
+        report(f"fwd plane: lane b128 read/write, head {h}",
+               worst(B128_GROUPS, lambda l: h * PT_PL + pt_off(l & 15, 4 * (l >> 4)), 4, 64))
+        report(f"fwd plane: lane b128 WRITE (8-lane groups), head {h}",
+               worst(W128_GROUPS, lambda l: h * PT_PL + pt_off(l & 15, 4 * (l >> 4)), 4, 32))
+    # backward lanes (mm = lane & 15 key, q): b128 of query rows 4q..4q+3
+    for h in (0, 5):
+        report(f"bwd plane: lane b128 read, head {h}",
+               worst(B128_GROUPS, lambda l: h * PT_PL + ptT_off(4 * (l >> 4), l & 15), 4, 64))
+        report(f"bwd plane: lane b128 WRITE (8-lane groups), head {h}",
+               worst(W128_GROUPS, lambda l: h * PT_PL + ptT_off(4 * (l >> 4), l & 15), 4, 32))
+    # search the chunk permutation of the transposed plane
+    best = []
+    for a in itertools.permutations(range(4)):
+        def off(row, col, a=a):
+            return (col << 4) + (((row >> 2) ^ a[col >> 2]) << 2) + (row & 3)
+        r = worst(B128_GROUPS, lambda l: off(4 * (l >> 4), l & 15), 4, 64)
+        wv = worst(W128_GROUPS, lambda l: off(4 * (l >> 4), l & 15), 4, 32)
+        sc = 0
+        for wave in range(8):
+            for c in range(4):
+                def addr(l, wave=wave, c=c):
+                    tid = wave * 64 + l
+                    return (4 * (tid & 1) + c) * PT_PL + off(tid >> 5, (tid & 31) >> 1)
+                sc = max(sc, worst(B32_GROUPS, addr, 1, 32))
+        best.append((r, wv, sc, a))
+    best.sort()
+    print("transposed-plane chunk permutations (b128 read, b128 write, scatter):", best[:6])
+
+
+if __name__ == "__main__":
+    main()
