@@ -19,6 +19,7 @@ EGT_F32 = 0
 EGT_BF16 = 1   # fused block/stack: edge tensors bf16 in HBM, everything else fp32
 F_EDGE_INPUT, F_GATE_INPUT, F_ATTN_MASK, F_SCALE_DEGREE = 0x001, 0x002, 0x004, 0x008
 F_SCALER_LINEAR, F_TRAINING, F_CLIP = 0x010, 0x020, 0x040
+ATTN_WS_SHARED = 0x1   # egt_attn_desc.reserved: one workspace for egt_attn_mfma_fwd and _bwd
 EP_LAYERNORM, EP_GATES = 0x1, 0x2
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_ELU = 0, 1, 2, 3
 # egt_block_desc.flags

@@ -36,16 +36,17 @@
 #include "egt_common.h"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define MFMA_(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 #define AH 8
 #define L2E 1.4426950408889634f
 #define KEY_OFF (-3.0e38f)   // additive term of key slots past N (below every masked logit, above -inf)
 
-// packed operand arrays, each B*H*NP*d floats.  Forward workspace: K rows, V^T.  Backward workspace:
-// Q rows (pre-scaled), dO rows, K rows, V rows, K^T; then stats2 [B,H,NP,4] and dA [B,H,NP,NP].
-enum { PF_KH = 0, PF_VT, PF_COUNT };
-enum { PB_QH = 0, PB_OH, PB_KH, PB_VH, PB_KT, PB_COUNT };
+// packed operand arrays, each B*H*NP*d floats, in workspace order: Q rows (pre-scaled), K rows, V^T (what the forward
+// reads), V rows, K^T, dO rows (the backward's); then stats2 [B,H,NP,4] and dA [B,H,NP,NP].  A forward launched with
+// EGT_ATTN_WS_SHARED packs the five q/k/v arrays once and the backward, given the same workspace, adds only dO.
+enum { PK_QH = 0, PK_KH, PK_VT, PK_FWD_COUNT, PK_VH = PK_FWD_COUNT, PK_KT, PK_OH, PK_COUNT };
+enum { PACK_Q = 1, PACK_KH = 2, PACK_KT = 4, PACK_VT = 8, PACK_VH = 16, PACK_O = 32 };
 
 struct AttnMfmaArgs {
   int B, N, NP, d;
@@ -60,7 +61,7 @@ struct AttnMfmaArgs {
   // backward
   const float *v_att_in, *d_v_att, *d_h_ext;
   float *d_qkv, *d_E, *d_G, *ws_dA, *stats2;
-  int pack_bwd;
+  int pack_what;   // PACK_* bits
 };
 
 // Phase stamps (-DEGT_ATTN_STAMPS via EGT_ATTN_FLAGS): s_memtime deltas of every wave of workgroup 0, summed per
@@ -75,11 +76,17 @@ __device__ long long g_attn_stamps[3][8][16];
 #define STAMP(i)
 #define STAMP_OUT(k)
 #endif
-// timing ablations (results are wrong): -DEGT_ATTN_ABL=<bits>: 1 no operand reloads, 2 no pair loads, 4 no output stores
+// timing ablations (results are wrong): -DEGT_ATTN_ABL=<bits>: 1 no operand DMA, 2 no pair loads / scatter, 4 no output stores,
+// 8 no MFMAs, 16 no elementwise phase (probabilities = logits)
 #ifndef EGT_ATTN_ABL
 #define EGT_ATTN_ABL 0
 #endif
 #define ABL(bit) ((EGT_ATTN_ABL & (bit)) == 0)
+#if EGT_ATTN_ABL & 8
+__device__ __forceinline__ v4f MFMA(float a, float b, v4f c) { c[0] += a * b; return c; }
+#else
+#define MFMA(a, b, c) MFMA_(a, b, c)
+#endif
 
 // LDS hand-off between the waves of a workgroup WITHOUT draining vector memory: __syncthreads() is
 // s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier on gfx950; the operand prefetches and the output stores of
@@ -104,9 +111,13 @@ __global__ void __launch_bounds__(256) k_attn_pack(AttnMfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [16][LD]
   const int N = a.N, NP = a.NP, tid = threadIdx.x;
   const int tiles = NP / 16;
-  const bool bwd = a.pack_bwd != 0;
-  const int nsec = bwd ? 4 : 2;
-  const int sec = bwd ? (int)(blockIdx.x % nsec) : (int)(blockIdx.x % nsec) + 1;   // 0 q, 1 k, 2 v, 3 dO
+  // sections present in this launch, in order q, k, v, dO
+  int secs[4], nsec = 0;
+  if (a.pack_what & PACK_Q) secs[nsec++] = 0;
+  if (a.pack_what & (PACK_KH | PACK_KT)) secs[nsec++] = 1;
+  if (a.pack_what & (PACK_VT | PACK_VH)) secs[nsec++] = 2;
+  if (a.pack_what & PACK_O) secs[nsec++] = 3;
+  const int sec = secs[blockIdx.x % nsec];
   const int tile = blockIdx.x / nsec;
   const int b = tile / tiles, n0 = (tile % tiles) * 16;
   const float mul = sec == 0 ? a.scale : 1.0f;   // Q leaves pre-scaled: S = (d^-1/2 Q).K^T, dK = dA^T.(d^-1/2 Q)
@@ -144,15 +155,15 @@ __global__ void __launch_bounds__(256) k_attn_pack(AttnMfmaArgs a) {
           make_float4(src[0], src[LD], src[2 * LD], src[3 * LD]);
     }
   };
-  if (!bwd) {
-    if (sec == 1) put_rows(PF_KH); else put_cols(PF_VT);
-    return;
-  }
-  if (sec == 0) put_rows(PB_QH);
-  else if (sec == 1) { put_rows(PB_KH); put_cols(PB_KT); }
-  else if (sec == 2) put_rows(PB_VH);
-  else {
-    put_rows(PB_OH);
+  if (sec == 0) put_rows(PK_QH);
+  else if (sec == 1) {
+    if (a.pack_what & PACK_KH) put_rows(PK_KH);
+    if (a.pack_what & PACK_KT) put_cols(PK_KT);
+  } else if (sec == 2) {
+    if (a.pack_what & PACK_VT) put_cols(PK_VT);
+    if (a.pack_what & PACK_VH) put_rows(PK_VH);
+  } else {
+    put_rows(PK_OH);
     // per-row constants of the backward, head-major [b,h,n,4] = (m, 1/l, delta, 0) with
     // delta[row,h] = sum_k dO[row,k,h] * O[row,k,h] (flash-style); rows past N get 1/l = 0 (their probabilities vanish)
     const int r = tid >> 4, hh = (tid >> 1) & 7, half = tid & 1, n = n0 + r;
@@ -319,8 +330,8 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
       kaddL[m] = ka;
       kaddG[m] = m >= N ? 3.0e38f : -ka * L2E;
     }
-    const float* Kh = a.pk + PF_KH * arr + ((size_t)b * AH + h) * NP * D;   // [NP/16][D/16][16][16]   (this loader wave feeds head h)
-    const float* VT = a.pk + PF_VT * arr + ((size_t)b * AH + h) * D * NP;   // [NP/16][D][16]
+    const float* Kh = a.pk + PK_KH * arr + ((size_t)b * AH + h) * NP * D;   // [NP/16][D/16][16][16]   (this loader wave feeds head h)
+    const float* VT = a.pk + PK_VT * arr + ((size_t)b * AH + h) * D * NP;   // [NP/16][D][16]
     const unsigned doff = dma_lane_off(lane);
     const unsigned ops0 = lds_addr(sm) + w * (KT * 2048);   // head w: K tile, then V^T tile
     auto dma_ops = [&](int mt, int stage) __attribute__((always_inline)) {
@@ -328,9 +339,9 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
       const float* vs = VT + (size_t)mt * 16 * D;
       const unsigned dst = ops0 + stage * OPS_STAGE;
 #pragma unroll
-      for (int T = 0; T < KT; ++T) dma_piece(dst + T * 1024, ks + T * 256, doff);
+      for (int T = 0; T < KT; ++T) if (ABL(1)) dma_piece(dst + T * 1024, ks + T * 256, doff);
 #pragma unroll
-      for (int T = 0; T < KT; ++T) dma_piece(dst + KT * 1024 + T * 1024, vs + T * 256, doff);
+      for (int T = 0; T < KT; ++T) if (ABL(1)) dma_piece(dst + KT * 1024 + T * 1024, vs + T * 256, doff);
     };
     const size_t gbase = ((size_t)b * N + l0) * N * AH;
     uint32_t rowoff[FQ];
@@ -356,20 +367,27 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
     };
     dma_ops(0, 0);
     float4 pe[FQ], pg[FQ], pm[FQ];
-#pragma unroll
-    for (int qt = 0; qt < FQ; ++qt) {
-      if (f.E) scatter(In + 0 * TS, qt, pload(a.E, qt, 0));
-      if (f.G) scatter(In + 1 * TS, qt, pload(a.G, qt, 0));
-      if (f.M) scatter(In + 2 * TS, qt, pload(a.M, qt, 0));
-    }
     {
+      float4 fe[FQ], fg[FQ], fm[FQ];
       const int m1 = min(16, NP - 16);
+#pragma unroll
+      for (int qt = 0; qt < FQ; ++qt) {   // both tiles' requests before the first use: one HBM round trip, not two
+        if (f.E) fe[qt] = pload(a.E, qt, 0);
+        if (f.G) fg[qt] = pload(a.G, qt, 0);
+        if (f.M) fm[qt] = pload(a.M, qt, 0);
+      }
 #pragma unroll
       for (int qt = 0; qt < FQ; ++qt) {
         pe[qt] = pg[qt] = pm[qt] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (f.E) pe[qt] = pload(a.E, qt, m1);
         if (f.G) pg[qt] = pload(a.G, qt, m1);
         if (f.M) pm[qt] = pload(a.M, qt, m1);
+      }
+#pragma unroll
+      for (int qt = 0; qt < FQ; ++qt) {
+        if (f.E) scatter(In + 0 * TS, qt, fe[qt]);
+        if (f.G) scatter(In + 1 * TS, qt, fg[qt]);
+        if (f.M) scatter(In + 2 * TS, qt, fm[qt]);
       }
     }
     if (V) vm_wait<FQ * NIN>(); else vm_wait<0>();   // the DMA pieces are older than the register loads just issued
@@ -378,15 +396,15 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
       {   // pair tiles of iteration it+1 (requested one iteration ago) into the other stage: its last readers passed the previous barrier
         float* nx = In + ((it + 1) & 1) * NIN * TS;
 #pragma unroll
-        for (int qt = 0; qt < FQ; ++qt) {
+        for (int qt = 0; qt < FQ; ++qt) if (ABL(2)) {
           if (f.E) scatter(nx + 0 * TS, qt, pe[qt]);
           if (f.G) scatter(nx + 1 * TS, qt, pg[qt]);
           if (f.M) scatter(nx + 2 * TS, qt, pm[qt]);
         }
       }
-      if (it > 0) hstore(it - 1);
+      if (it > 0 && ABL(4)) hstore(it - 1);
       dma_ops(min(it + 1, mtiles - 1), (it + 1) & 1);
-      {
+      if (ABL(2)) {
         const int m2 = min(16 * (it + 2), NP - 16);
 #pragma unroll
         for (int qt = 0; qt < FQ; ++qt) {
@@ -397,23 +415,27 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
       }
       // exactly the register loads above are younger than the DMA pieces (their count is a template constant for the
       // straight-line instances; the generic instance drains)
-      if (V) vm_wait<FQ * NIN>(); else vm_wait<0>();
+      if (V && EGT_ATTN_ABL == 0) vm_wait<FQ * NIN>(); else vm_wait<0>();
       lds_barrier();
     }
     hstore(mtiles - 1);
-    return;
-  }
-
+  } else {
   // -------------------------------------------------------------------- compute waves ----
   const int ll = lane & 15, q = lane >> 4;
   const bool gated = f.G, clip = f.clip;
   // Q fragments (B operand of S^T = K.Q^T), pre-scaled: d^-1/2 Q[l][16T + 4q + u]
   float Qr[FQ][4 * KT];
+  {
+    const float* Qh = a.pk + PK_QH * arr + ((size_t)b * AH + h) * NP * D;
 #pragma unroll
-  for (int qt = 0; qt < FQ; ++qt) {
-    const float* qrow = a.qkv + ((size_t)b * N + min(l0 + 16 * qt + ll, N - 1)) * 3 * DH + h;
+    for (int qt = 0; qt < FQ; ++qt) {
+      const int ltile = min((l0 >> 4) + qt, mtiles - 1);
 #pragma unroll
-    for (int t = 0; t < 4 * KT; ++t) Qr[qt][t] = qrow[(16 * (t >> 2) + 4 * q + (t & 3)) * AH] * a.scale;
+      for (int T = 0; T < KT; ++T) {
+        const float4 v = *reinterpret_cast<const float4*>(Qh + (size_t)ltile * 16 * D + 256 * T + ll * 16 + 4 * q);
+        Qr[qt][4 * T + 0] = v.x; Qr[qt][4 * T + 1] = v.y; Qr[qt][4 * T + 2] = v.z; Qr[qt][4 * T + 3] = v.w;
+      }
+    }
   }
   v4f oacc[FQ][KT];
   float mrun[FQ], lrun[FQ];
@@ -447,8 +469,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
       if (f.G) g4[qt] = *reinterpret_cast<const float4*>(Inb + 1 * TS + qt * 4 * PT_PL + po4);
       if (f.M) m4[qt] = *reinterpret_cast<const float4*>(Inb + 2 * TS + qt * 4 * PT_PL + po4);
     }
-#pragma unroll
-    for (int T = 0; T < KT; ++T) vc[T] = *reinterpret_cast<const float4*>(ops + KT * 256 + T * 256);
+    __builtin_amdgcn_sched_barrier(0);   // every LDS request of the S phase is in flight before its first MFMA
     STAMP(1);
     // ---- S^T[m][l] = sum_k K[m][k] (d^-1/2 Q)[l][k]: every K register feeds the two query tiles ----
     v4f s[FQ];
@@ -462,6 +483,9 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
 #pragma unroll
         for (int qt = 0; qt < FQ; ++qt) s[qt] = MFMA(kk, Qr[qt][4 * T + u], s[qt]);
       }
+#pragma unroll
+    for (int T = 0; T < KT; ++T) vc[T] = *reinterpret_cast<const float4*>(ops + KT * 256 + T * 256);   // V^T fragments: requested behind the S MFMAs, landed long before P.V
+    __builtin_amdgcn_sched_barrier(0);
     STAMP(2);
     const float kav[4] = {ka4.x, ka4.y, ka4.z, ka4.w}, kgv[4] = {kg4.x, kg4.y, kg4.z, kg4.w};
     float pa[FQ][4];
@@ -515,6 +539,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
         oacc[qt][kt] = o;
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     STAMP(3);
     // ---- O^T[k][l] += sum_m V^T[k][m] P^T[m][l]  (contraction order m = 4q + t): every V^T register feeds two MFMAs ----
 #pragma unroll
@@ -529,25 +554,30 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_fwd(AttnMfmaArgs a) {
     lds_barrier();
     STAMP(6);
   }
-  // ---- finalize: V_att[l][k*8+h] = O[l][k] / l_run ; row statistics for the backward ----
+  // ---- finalize: O[l][k] / l_run into the (now idle) operand stages as [row][k][4 heads]; row statistics for the backward ----
 #pragma unroll
   for (int qt = 0; qt < FQ; ++qt) {
     const int l = l0 + 16 * qt + ll;
-    if (l < N) {
-      const float inv = 1.0f / lrun[qt];
-      float* vo = a.v_att + ((size_t)b * N + l) * DH + h;
+    const float inv = 1.0f / lrun[qt];
+    float* vs = sm + ((16 * qt + ll) * D + 4 * q) * 4 + w;
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vo[(16 * kt + 4 * q + r) * AH] = oacc[qt][kt][r] * inv;
-      if (q == 0) {
-        float* rs = a.rowstats + (((size_t)b * N + l) * AH + h) * 4;
-        rs[0] = mrun[qt]; rs[1] = lrun[qt]; rs[2] = 0.f; rs[3] = 0.f;
-      }
-    }
+      for (int r = 0; r < 4; ++r) vs[(16 * kt + r) * 4] = oacc[qt][kt][r] * inv;
+    if (l < N && q == 0)
+      *reinterpret_cast<float4*>(a.rowstats + (((size_t)b * N + l) * AH + h) * 4) = make_float4(mrun[qt], lrun[qt], 0.f, 0.f);
   }
   STAMP(7);
   STAMP_OUT(0);
+  }
+  // V_att[l][k*8 + h]: all eight waves store 16-byte pieces (the group's 4 heads of one channel), consecutive threads
+  // consecutive channels (a dword store per lane and channel costs ~300 cycles each: 19 k cycles per workgroup before)
+  lds_barrier();
+  for (int p = tid; p < 16 * FQ * D; p += 512) {
+    const int row = p / D, k = p % D;
+    if (l0 + row < N)
+      *reinterpret_cast<float4*>(a.v_att + ((size_t)b * N + l0 + row) * DH + k * AH + 4 * hg) = *reinterpret_cast<const float4*>(sm + (size_t)p * 4);
+  }
 }
 
 // ================================================================= backward =====
@@ -592,8 +622,8 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
     // ------------------------------------------------------------------ loader waves ----
     const int lt = tid - 256;
     const int crow = lt >> 4, ccol = lt & 15;   // query row, key of each 16 x 16 sub-tile; the group's 4 heads (16 bytes)
-    const float* Qh = a.pk + PB_QH * arr + hb;  // this loader wave feeds head h
-    const float* Oh = a.pk + PB_OH * arr + hb;
+    const float* Qh = a.pk + PK_QH * arr + hb;  // this loader wave feeds head h
+    const float* Oh = a.pk + PK_OH * arr + hb;
     const unsigned doff = dma_lane_off(lane);
     const unsigned ops0 = lds_addr(sm) + w * (KT * 2048);   // head w: Q tile, then dO tile
     auto dma_ops = [&](int ltile, int stage) __attribute__((always_inline)) {
@@ -601,9 +631,9 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
       const float* os = Oh + (size_t)ltile * 16 * D;
       const unsigned dst = ops0 + stage * OPS_STAGE;
 #pragma unroll
-      for (int T = 0; T < KT; ++T) dma_piece(dst + T * 1024, qs + T * 256, doff);
+      for (int T = 0; T < KT; ++T) if (ABL(1)) dma_piece(dst + T * 1024, qs + T * 256, doff);
 #pragma unroll
-      for (int T = 0; T < KT; ++T) dma_piece(dst + KT * 1024 + T * 1024, os + T * 256, doff);
+      for (int T = 0; T < KT; ++T) if (ABL(1)) dma_piece(dst + KT * 1024 + T * 1024, os + T * 256, doff);
     };
     // per-row constants of the query tile: one float4 per (head, row) -- lanes 0..15 of each loader wave
     const float* st2 = a.stats2 + ((size_t)b * AH + h) * NP * 4;
@@ -654,40 +684,47 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
           if (f.G) *reinterpret_cast<float4*>(a.d_G + go) = make_float4(p[TS], p[TS + PT_PL], p[TS + 2 * PT_PL], p[TS + 3 * PT_PL]);
         }
     };
-    auto stat_put = [&](int ltile, int stage) __attribute__((always_inline)) {
-      if (lane < 16) *reinterpret_cast<float4*>(statL + ((stage * 4 + w) * 16 + lane) * 4) = *reinterpret_cast<const float4*>(st2 + (size_t)(ltile * 16 + lane) * 4);
+    auto stat_load = [&](int ltile) __attribute__((always_inline)) {   // (every lane loads: lanes >= 16 re-read rows 0..15 -- the count of register loads per trip stays fixed)
+      return *reinterpret_cast<const float4*>(st2 + (size_t)(ltile * 16 + (lane & 15)) * 4);
+    };
+    auto stat_put = [&](float4 v, int stage) __attribute__((always_inline)) {
+      if (lane < 16) *reinterpret_cast<float4*>(statL + ((stage * 4 + w) * 16 + lane) * 4) = v;
     };
     dma_ops(0, 0);
-    stat_put(0, 0);
     Pair pr[BK];
+    {
+      Pair p0[BK];
 #pragma unroll
-    for (int kb = 0; kb < BK; ++kb) pair_put(In, kb, pair_load(0, kb));
+      for (int kb = 0; kb < BK; ++kb) p0[kb] = pair_load(0, kb);   // both tiles' requests before the first use: one HBM round trip
 #pragma unroll
-    for (int kb = 0; kb < BK; ++kb) pr[kb] = pair_load(min(16, NP - 16), kb);
+      for (int kb = 0; kb < BK; ++kb) pr[kb] = pair_load(min(16, NP - 16), kb);
+      stat_put(stat_load(0), 0);
+#pragma unroll
+      for (int kb = 0; kb < BK; ++kb) pair_put(In, kb, p0[kb]);
+    }
+    float4 stn = stat_load(min(1, mtiles - 1));
     vm_wait<0>();
     lds_barrier();
     for (int it = 0; it < mtiles; ++it) {
       {   // pair tiles of query tile it+1 (requested one iteration ago) into the other stage
         float* nx = In + ((it + 1) & 1) * NIN * TS;
 #pragma unroll
-        for (int kb = 0; kb < BK; ++kb) pair_put(nx, kb, pr[kb]);
+        for (int kb = 0; kb < BK; ++kb) if (ABL(2)) pair_put(nx, kb, pr[kb]);
       }
-      if (it > 0) gstore(it - 1);
-      const int ln = min(it + 1, mtiles - 1);
-      stat_put(ln, (it + 1) & 1);
-      dma_ops(ln, (it + 1) & 1);
-      {
+      stat_put(stn, (it + 1) & 1);
+      if (it > 0 && ABL(4)) gstore(it - 1);
+      dma_ops(min(it + 1, mtiles - 1), (it + 1) & 1);
+      if (ABL(2)) {
         const int l2 = min(16 * (it + 2), NP - 16);
 #pragma unroll
         for (int kb = 0; kb < BK; ++kb) pr[kb] = pair_load(l2, kb);
+        stn = stat_load(l2 >> 4);
       }
-      if (V) vm_wait<BK * 3>(); else vm_wait<0>();   // the BK * 3 register loads above are younger than the DMA pieces
+      if (V && EGT_ATTN_ABL == 0) vm_wait<BK * 3 + 1>(); else vm_wait<0>();   // exactly the BK * 3 + 1 register loads above are younger than the DMA pieces
       lds_barrier();
     }
     gstore(mtiles - 1);
-    return;
-  }
-
+  } else {
   // -------------------------------------------------------------------- compute waves ----
   const int mm = lane & 15, q = lane >> 4;
   const bool gated = f.G, clip = f.clip;
@@ -699,8 +736,8 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
   bool tile_ok[BK];
   float* dAb[BK];
   {
-    const float* Kh = a.pk + PB_KH * arr + hb;
-    const float* Vh = a.pk + PB_VH * arr + hb;
+    const float* Kh = a.pk + PK_KH * arr + hb;
+    const float* Vh = a.pk + PK_VH * arr + hb;
 #pragma unroll
     for (int kb = 0; kb < BK; ++kb) {
       const int mt = (m0 >> 4) + kb, mtc = min(mt, mtiles - 1);
@@ -735,6 +772,12 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
     const float* opt = optr + (it & 1) * (OPS_STAGE / 4);
     const float* Inb = In + (it & 1) * NIN * TS;
     float* Ob = Out + (it & 1) * 2 * TS;
+    float4 qa[KT], oa[KT];   // row operands first: the S / dP MFMAs start as soon as they land, everything else lands behind them
+#pragma unroll
+    for (int T = 0; T < KT; ++T) {
+      qa[T] = *reinterpret_cast<const float4*>(opr + T * 256);
+      oa[T] = *reinterpret_cast<const float4*>(opr + KT * 256 + T * 256);
+    }
     float4 e4[BK], g4[BK], x4[BK], stc[4];
 #pragma unroll
     for (int kb = 0; kb < BK; ++kb) {
@@ -745,6 +788,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) stc[r] = *reinterpret_cast<const float4*>(statL + (((it & 1) * 4 + w) * 16 + 4 * q + r) * 4);
+    __builtin_amdgcn_sched_barrier(0);   // every LDS request of the first two phases is in flight before the first MFMA
     STAMP(1);
     // ---- S[l][m] = sum_k (d^-1/2 Q)[l][k] K[m][k] ; dP[l][m] = sum_k dO[l][k] V[m][k]: every Q / dO register feeds two MFMAs ----
     v4f s[BK], dp[BK];
@@ -752,12 +796,10 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
     for (int kb = 0; kb < BK; ++kb) { s[kb] = (v4f){0.f, 0.f, 0.f, 0.f}; dp[kb] = (v4f){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int T = 0; T < KT; ++T) {
-      const float4 qa = *reinterpret_cast<const float4*>(opr + T * 256);
-      const float4 oa = *reinterpret_cast<const float4*>(opr + KT * 256 + T * 256);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float qq = u == 0 ? qa.x : u == 1 ? qa.y : u == 2 ? qa.z : qa.w;
-        const float oo = u == 0 ? oa.x : u == 1 ? oa.y : u == 2 ? oa.z : oa.w;
+        const float qq = u == 0 ? qa[T].x : u == 1 ? qa[T].y : u == 2 ? qa[T].z : qa[T].w;
+        const float oo = u == 0 ? oa[T].x : u == 1 ? oa[T].y : u == 2 ? oa[T].z : oa[T].w;
 #pragma unroll
         for (int kb = 0; kb < BK; ++kb) {
           const float kk = u == 0 ? Kr[kb][T].x : u == 1 ? Kr[kb][T].y : u == 2 ? Kr[kb][T].z : Kr[kb][T].w;
@@ -767,6 +809,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     STAMP(2);
     float at[BK][4], da[BK][4];
 #pragma unroll
@@ -806,6 +849,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
       if (tile_ok[kb] && ABL(4))
         *reinterpret_cast<float4*>(dAb[kb] + (size_t)it * mtiles * 256 + ooff) = make_float4(da[kb][0], da[kb][1], da[kb][2], da[kb][3]);
     }
+    __builtin_amdgcn_sched_barrier(0);
     STAMP(3);
     // ---- dV^T[k][m] += sum_l dO[l][k] A[l][m] ; dK^T[k][m] += sum_l (d^-1/2 Q)[l][k] dA[l][m]: transposed operands from the same tiles ----
 #pragma unroll
@@ -824,23 +868,31 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
     lds_barrier();
     STAMP(6);
   }
+  // dK / dV into the (now idle) operand stages as [key][k][4 heads], dK in stage 0, dV in stage 1
 #pragma unroll
   for (int kb = 0; kb < BK; ++kb) {
-    const int m = m0 + 16 * kb + mm;
-    if (m < N) {
-      float* o = a.d_qkv + ((size_t)b * N + m) * 3 * DH + h;
+    float* ks = sm + ((16 * kb + mm) * D + 4 * q) * 4 + w;
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = 16 * kt + 4 * q + r;
-          o[DH + k * AH] = dKacc[kb][kt][r];
-          o[2 * DH + k * AH] = dVacc[kb][kt][r];
-        }
-    }
+      for (int r = 0; r < 4; ++r) {
+        ks[(16 * kt + r) * 4] = dKacc[kb][kt][r];
+        ks[OPS_STAGE / 4 + (16 * kt + r) * 4] = dVacc[kb][kt][r];
+      }
   }
   STAMP(7);
   STAMP_OUT(1);
+  }
+  // dK / dV rows of d_qkv: all eight waves store 16-byte pieces (the group's 4 heads of one channel)
+  lds_barrier();
+  for (int p = tid; p < 16 * BK * D; p += 512) {
+    const int row = p / D, k = p % D;
+    if (m0 + row < N) {
+      float* o = a.d_qkv + ((size_t)b * N + m0 + row) * 3 * DH + k * AH + 4 * hg;
+      *reinterpret_cast<float4*>(o + DH) = *reinterpret_cast<const float4*>(sm + (size_t)p * 4);
+      *reinterpret_cast<float4*>(o + 2 * DH) = *reinterpret_cast<const float4*>(sm + OPS_STAGE / 4 + (size_t)p * 4);
+    }
+  }
 }
 
 // wave = (graph, head, QT query tiles); lane (ll = lane&15, q): query rows l0 + 16 j + ll, keys m0 + 4q + u as the
@@ -859,7 +911,7 @@ __global__ void __launch_bounds__(256) k_attn_mfma_bwd_q(AttnMfmaArgs a) {
   const int lt0 = __builtin_amdgcn_readfirstlane(((gw % per_b) % lgroups) * QT);
   if (b >= a.B) return;
   const size_t arr = (size_t)a.B * AH * NP * D;
-  const float* KTp = a.pk + PB_KT * arr + ((size_t)b * AH + h) * D * NP;
+  const float* KTp = a.pk + PK_KT * arr + ((size_t)b * AH + h) * D * NP;
   const float* dAh = a.ws_dA + ((size_t)b * AH + h) * mtiles * mtiles * 256;
   const uint32_t koff = ll * 16 + 4 * q;
   v4f dQacc[QT][KT];
@@ -949,16 +1001,16 @@ extern "C" int egt_attn_mfma_supported(const egt_attn_desc* d, int need_a_tild) 
 
 static int np_of(int N) { return (N + 15) & ~15; }
 
-// forward: K rows + V^T; backward: five packed arrays, the per-row constants and the dA tiles
+// both directions: six packed arrays, the per-row constants and the dA tiles; forward alone: its three arrays
 extern "C" size_t egt_attn_mfma_workspace_bytes(const egt_attn_desc* d) {
   if (!egt_attn_mfma_supported(d, 0)) return 0;
   const size_t NP = np_of(d->N), arr = (size_t)d->B * AH * NP * d->d;
-  return (PB_COUNT * arr + (size_t)d->B * AH * NP * 4 + (size_t)d->B * AH * NP * NP) * sizeof(float);
+  return (PK_COUNT * arr + (size_t)d->B * AH * NP * 4 + (size_t)d->B * AH * NP * NP) * sizeof(float);
 }
 
 extern "C" size_t egt_attn_mfma_fwd_workspace_bytes(const egt_attn_desc* d) {
   if (!egt_attn_mfma_supported(d, 0)) return 0;
-  return (size_t)PF_COUNT * d->B * AH * np_of(d->N) * d->d * sizeof(float);
+  return (size_t)PK_FWD_COUNT * d->B * AH * np_of(d->N) * d->d * sizeof(float);
 }
 
 static int fill(const egt_attn_desc* desc, const void* qkv, const void* E, const void* G,
@@ -991,7 +1043,9 @@ template <int D>
 static void launch_pack(const AttnMfmaArgs& a, hipStream_t st) {
   const size_t lds = (size_t)16 * (D * AH + 4) * 4;
   EGT_MAX_LDS_ONCE(k_attn_pack<D>);
-  EGT_LAUNCH("k_attn_pack", k_attn_pack<D>, dim3(a.B * (a.NP / 16) * (a.pack_bwd ? 4 : 2)), dim3(256), lds, st, a);
+  const int nsec = ((a.pack_what & PACK_Q) != 0) + ((a.pack_what & (PACK_KH | PACK_KT)) != 0) + ((a.pack_what & (PACK_VT | PACK_VH)) != 0) +
+                   ((a.pack_what & PACK_O) != 0);
+  EGT_LAUNCH("k_attn_pack", k_attn_pack<D>, dim3(a.B * (a.NP / 16) * nsec), dim3(256), lds, st, a);
 }
 
 // 1 / 2: the straight-line instances (see Feat), 0: the run-time-switched one (EGT_ATTN_GENERIC forces it: tests)
@@ -1030,7 +1084,9 @@ extern "C" int egt_attn_mfma_fwd(const egt_attn_desc* desc, const void* qkv, con
   if (rc) return rc;
   if (!v_att || !h_hat || !rowstats) EGT_FAIL(EGT_E_NULL, "v_att/h_hat/rowstats is NULL");
   a.v_att = (float*)v_att; a.h_hat = (float*)h_hat; a.rowstats = (float*)rowstats;
-  a.pack_bwd = 0;
+  // EGT_ATTN_WS_SHARED: the workspace is egt_attn_mfma_workspace_bytes() large and will be handed to the backward:
+  // pack the backward's q / k / v arrays too, once
+  a.pack_what = PACK_Q | PACK_KH | PACK_VT | ((desc->reserved & EGT_ATTN_WS_SHARED) ? (PACK_KT | PACK_VH) : 0);
   switch (desc->d) {
     case 16: launch_fwd<16>(a, (hipStream_t)stream); break;
     case 32: launch_fwd<32>(a, (hipStream_t)stream); break;
@@ -1080,9 +1136,9 @@ extern "C" int egt_attn_mfma_bwd(const egt_attn_desc* desc, const void* qkv, con
   a.d_E = (desc->flags & EGT_F_EDGE_INPUT) ? (float*)d_E : nullptr;
   a.d_G = (desc->flags & EGT_F_GATE_INPUT) ? (float*)d_G : nullptr;
   const size_t arr = (size_t)a.B * AH * a.NP * a.d;
-  a.stats2 = a.pk + (size_t)PB_COUNT * arr;
+  a.stats2 = a.pk + (size_t)PK_COUNT * arr;
   a.ws_dA = a.stats2 + (size_t)a.B * AH * a.NP * 4;
-  a.pack_bwd = 1;
+  a.pack_what = PACK_O | ((desc->reserved & EGT_ATTN_WS_SHARED) ? 0 : (PACK_Q | PACK_KH | PACK_KT | PACK_VH));
   switch (desc->d) {
     case 16: launch_bwd<16>(a, (hipStream_t)stream); break;
     case 32: launch_bwd<32>(a, (hipStream_t)stream); break;

@@ -94,6 +94,7 @@ class _EGTAttention(torch.autograd.Function):
         assert C3 % (H * 3) == 0                      # egt_layers.py:70
         d = C3 // (H * 3)
         desc = _attn_desc(cfg, B, N, d, E is not None, G is not None, M is not None)
+        mfma_ws = None
         v_att = torch.empty(B, N, d * H, device=qkv.device, dtype=torch.float32)
         h_hat = torch.empty(B, N, N, H, device=qkv.device, dtype=torch.float32)
         a_tild = torch.empty(B, N, N, H, device=qkv.device, dtype=torch.float32) if cfg.need_a_tild else None
@@ -101,8 +102,15 @@ class _EGTAttention(torch.autograd.Function):
         if (cfg.use_mfma and drop_keep is None
                 and lib.egt_attn_mfma_supported(C.byref(desc), 1 if cfg.need_a_tild else 0)):
             # large-head geometry: QK^T / A.V on MFMA tiles (egt_attn_mfma.hip)
-            ws = torch.empty(lib.egt_attn_mfma_fwd_workspace_bytes(C.byref(desc)), device=qkv.device,
-                             dtype=torch.uint8)
+            # one workspace for both directions when a backward will follow: q/k/v are packed once (EGT_ATTN_WS_SHARED)
+            shared = any(t is not None and t.requires_grad for t in (qkv, E, G)) and torch.is_grad_enabled()
+            if shared:
+                desc.reserved = L.ATTN_WS_SHARED
+                ws = torch.empty(lib.egt_attn_mfma_workspace_bytes(C.byref(desc)), device=qkv.device, dtype=torch.uint8)
+                mfma_ws = ws
+            else:
+                ws = torch.empty(lib.egt_attn_mfma_fwd_workspace_bytes(C.byref(desc)), device=qkv.device,
+                                 dtype=torch.uint8)
             L.check(lib.egt_attn_mfma_fwd(C.byref(desc), L.ptr(qkv), L.ptr(E), L.ptr(G), L.ptr(key_mask),
                                           L.ptr(M), L.ptr(rand_mask), L.ptr(v_att), L.ptr(h_hat),
                                           L.ptr(rowstats), L.ptr(ws), L.current_stream()))
@@ -113,6 +121,7 @@ class _EGTAttention(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.desc = desc
         ctx.has = (E is not None, G is not None, M is not None)
+        ctx.mfma_ws = mfma_ws
         ctx.save_for_backward(qkv, E, G, M, key_mask, rand_mask, drop_keep, v_att, rowstats)
         ctx.set_materialize_grads(False)
         if a_tild is None:
@@ -133,8 +142,13 @@ class _EGTAttention(torch.autograd.Function):
         d_E = torch.empty_like(E) if E is not None else None
         d_G = torch.empty_like(G) if G is not None else None
         mfma = bool(ctx.cfg.use_mfma and drop_keep is None and lib.egt_attn_mfma_supported(C.byref(desc), 0))
-        nbytes = (lib.egt_attn_mfma_workspace_bytes if mfma else lib.egt_attn_bwd_workspace_bytes)(C.byref(desc))
-        ws = torch.empty(nbytes, device=qkv.device, dtype=torch.uint8)
+        if mfma and ctx.mfma_ws is not None:
+            ws = ctx.mfma_ws                      # the forward's workspace: q/k/v operand copies already in place
+            ctx.mfma_ws = None
+        else:
+            desc.reserved = 0
+            nbytes = (lib.egt_attn_mfma_workspace_bytes if mfma else lib.egt_attn_bwd_workspace_bytes)(C.byref(desc))
+            ws = torch.empty(nbytes, device=qkv.device, dtype=torch.uint8)
         if mfma:
             L.check(lib.egt_attn_mfma_bwd(C.byref(desc), L.ptr(qkv), L.ptr(E), L.ptr(G), L.ptr(key_mask),
                                           L.ptr(M), L.ptr(rand_mask), L.ptr(v_att), L.ptr(rowstats),

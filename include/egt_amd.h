@@ -71,9 +71,14 @@ typedef struct egt_attn_desc {
   float random_mask_prob;    /* egt_layers.py:103                               */
   float attn_dropout;        /* egt_layers.py:116                               */
   int32_t num_virtual_nodes; /* egt_layers.py:131                               */
-  int32_t reserved;
+  int32_t reserved;          /* 0, or EGT_ATTN_WS_* bits (MFMA path only)       */
   uint64_t seed;             /* counter-hash seed for the in-kernel mask RNG    */
 } egt_attn_desc;
+/* egt_attn_desc.reserved, MFMA path: the caller gives egt_attn_mfma_fwd a workspace of
+ * egt_attn_mfma_workspace_bytes() and hands THE SAME, untouched workspace to egt_attn_mfma_bwd:
+ * the forward then packs the q/k/v operand copies of both directions once and the backward packs
+ * only dV_att.  Without the bit each call packs what it needs into its own workspace. */
+#define EGT_ATTN_WS_SHARED 0x1
 
 const char* egt_last_error_string(void);
 int egt_abi_version(void);
@@ -114,16 +119,17 @@ int egt_attn_bwd(const egt_attn_desc* desc, const void* qkv, const void* E,
  * attention dropout, degree scalers, the A_tild output.  egt_attn_mfma_supported
  * returns 1 when `desc` (and the A_tild request) is covered. */
 int egt_attn_mfma_supported(const egt_attn_desc* desc, int need_a_tild);
-/* Workspace of the MFMA path: head-major operand copies of Q/K/V/dV_att (+ the dA tensor in
- * the backward).  *_fwd_* is what egt_attn_mfma_fwd needs; the other covers both directions. */
+/* Workspace of the MFMA path: head-major operand copies of Q/K/V/dV_att (+ per-row constants and
+ * the dA tiles in the backward).  *_fwd_* is what egt_attn_mfma_fwd needs on its own; the other
+ * covers both directions (and is what EGT_ATTN_WS_SHARED asks for). */
 size_t egt_attn_mfma_fwd_workspace_bytes(const egt_attn_desc* desc);
 size_t egt_attn_mfma_workspace_bytes(const egt_attn_desc* desc);
 int egt_attn_mfma_fwd(const egt_attn_desc* desc, const void* qkv, const void* E,
                       const void* G, const uint8_t* key_mask, const void* attn_mask,
                       const uint8_t* rand_mask, void* v_att, void* h_hat, void* rowstats,
                       void* workspace, void* stream);
-/* Backward on MFMA tiles (launches: pack, delta, dK/dV/dE/dG per key tile, dQ per query
- * tile).  rowstats is read and its 4th slot written; workspace: egt_attn_mfma_workspace_bytes. */
+/* Backward on MFMA tiles (launches: pack, dK/dV/dE/dG per 32-key block, dQ per query
+ * block).  rowstats is read and its 4th slot written; workspace: egt_attn_mfma_workspace_bytes. */
 int egt_attn_mfma_bwd(const egt_attn_desc* desc, const void* qkv, const void* E,
                       const void* G, const uint8_t* key_mask, const void* attn_mask,
                       const uint8_t* rand_mask, const void* v_att, void* rowstats,
