@@ -274,7 +274,7 @@ __device__ __forceinline__ float4 plane_gather(const float* tl, int tid) {
 // free and the transposed reads (lane (channel, q): ds_read_b32 of rows 4q + r) 2-way (tools/lds_bank_check.py).
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)p; }   // LDS byte address of a __shared__ pointer
 __device__ __forceinline__ int chunk_xor(int row) { return (0x78 >> (2 * (row >> 2))) & 3; }      // (0, 2, 3, 1)[row >> 2]
-// one 1 KB piece HBM -> LDS (destination below 64 KiB: M0 carries 16 bits): lane i lands at lds + 16 i and fetches src + off
+// one 1 KB piece HBM -> LDS (any LDS address: tools/micro/dma_hi.hip): lane i lands at lds + 16 i and fetches src + off
 __device__ __forceinline__ void dma_piece(unsigned lds, const float* src, unsigned off) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
@@ -895,95 +895,142 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
   }
 }
 
-// wave = (graph, head, QT query tiles); lane (ll = lane&15, q): query rows l0 + 16 j + ll, keys m0 + 4q + u as the
-// contraction index.  K^T operands (shared by the QT query tiles) and the dA tiles come straight from L2 into the
-// registers that feed the matrix core, two key tiles ahead; no LDS, no barrier.
-template <int D, int QT>
-__global__ void __launch_bounds__(256) k_attn_mfma_bwd_q(AttnMfmaArgs a) {
-  constexpr int KT = D / 16, DH = D * AH;
-  const int lane = threadIdx.x & 63;
-  const int ll = lane & 15, q = lane >> 4;
+// dQ: workgroup = (graph, head, 128 query rows): 4 compute waves (32 query rows = two tiles each) + 4 loader waves.  Per
+// iteration the loaders stage two key tiles by LDS-DMA: their K^T tiles (shared by the four compute waves) and the sixteen
+// dA tiles (query tile x key tile) -- the register-direct version issued 24 global loads per 64 MFMAs, i.e. as many issue
+// cycles of loads as of MFMAs.  Compute lane (ll = lane&15, q): query rows 16 j + ll of its tiles; keys 4q + u as the
+// contraction index: K^T fragments by ds_read_b128 (chunk-swizzled like every operand tile), dA[key][query] read
+// transposed by ds_read_b32.
+#define QW_TILES 8   // query tiles per workgroup
+#define QW_STAGES 4  // LDS ring: the DMA of a stage is issued QW_STAGES - 1 trips ahead of its use (issue -> landed is ~1.1 us, a trip ~1 us)
+template <int D>
+__global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_q(AttnMfmaArgs a) {
+  constexpr int KT = D / 16, DH = D * AH, STG = (2 * KT + 2 * QW_TILES) * 256;   // floats per stage
+  constexpr int PPW = (2 * KT + 2 * QW_TILES + 3) / 4;                           // DMA pieces per loader wave and stage (upper bound)
+
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = a.N, NP = a.NP;
-  const int mtiles = NP / 16, lgroups = (mtiles + QT - 1) / QT;
-  const int gw = egt_xcd_remap(blockIdx.x, gridDim.x) * 4 + (int)(threadIdx.x >> 6);   // wave index
-  const int per_b = AH * lgroups;
-  const int b = __builtin_amdgcn_readfirstlane(gw / per_b), h = __builtin_amdgcn_readfirstlane((gw % per_b) / lgroups);
-  const int lt0 = __builtin_amdgcn_readfirstlane(((gw % per_b) % lgroups) * QT);
-  if (b >= a.B) return;
+  const int mtiles = NP / 16, qgroups = (mtiles + QW_TILES - 1) / QW_TILES;
+  const int wg = egt_xcd_remap(blockIdx.x, gridDim.x);
+  const int b = wg / (AH * qgroups), h = (wg / qgroups) % AH, lt0 = (wg % qgroups) * QW_TILES;
   const size_t arr = (size_t)a.B * AH * NP * D;
-  const float* KTp = a.pk + PK_KT * arr + ((size_t)b * AH + h) * D * NP;
-  const float* dAh = a.ws_dA + ((size_t)b * AH + h) * mtiles * mtiles * 256;
-  const uint32_t koff = ll * 16 + 4 * q;
-  v4f dQacc[QT][KT];
+  const float* KTp = a.pk + PK_KT * arr + ((size_t)b * AH + h) * D * NP;           // [mtile][D][16 keys]
+  const float* dAh = a.ws_dA + ((size_t)b * AH + h) * mtiles * mtiles * 256;       // [ltile][mtile][16 keys][16 queries]
+  const int nit = (mtiles + 1) / 2;
+  if (wv >= 4) {
+    // ---- loaders: piece p of a stage: p < 2 KT: K^T block (kb = p / KT, T = p % KT); else dA tile (ltile = (p - 2 KT) >> 1, kb = (p - 2 KT) & 1)
+    const int j = wv - 4;
+    const unsigned doff = dma_lane_off(lane), lin = lane * 16;
+    // piece i of this wave: p = j + 4 i; its source address advances by a constant per trip (two key tiles): K^T blocks by
+    // 32 D floats, dA tiles by 512 -- bases and strides are hoisted (the address arithmetic of a piece was ~45 scalar
+    // instructions, six pieces per trip: the loaders were SALU-bound)
+    const float* base[PPW];
+    int stride[PPW];
+    unsigned voff[PPW];
+    bool second[PPW];   // piece belongs to the second key tile of a trip (absent in the last trip of an odd tile count)
 #pragma unroll
-  for (int j = 0; j < QT; ++j)
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) dQacc[j][kt] = (v4f){0.f, 0.f, 0.f, 0.f};
-  int ltj[QT];
-#pragma unroll
-  for (int j = 0; j < QT; ++j) ltj[j] = min(lt0 + j, mtiles - 1);   // a short last group recomputes the last tile (not stored)
-  // dA tile of (query tile lt, key tile mt) is key-major [key][query]: this lane's B operands are the four keys
-  // 4q + u of its query row
-  auto lda = [&](int j, int mt, float (&d)[4]) __attribute__((always_inline)) {
-    const float* p = dAh + ((size_t)ltj[j] * mtiles + mt) * 256 + 64 * q + ll;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) d[u] = p[16 * u];
-  };
-  float4 kcA[KT], kcB[KT];
-  float daA[QT][4], daB[QT][4];
-  auto ldk = [&](int mt, float4 (&k)[KT]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) k[kt] = *reinterpret_cast<const float4*>(KTp + (size_t)mt * 16 * D + koff + 256 * kt);
-  };
-  auto mma = [&](const float4 (&k)[KT], const float (&d)[QT][4]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        const float kk = u == 0 ? k[kt].x : u == 1 ? k[kt].y : u == 2 ? k[kt].z : k[kt].w;
-#pragma unroll
-        for (int j = 0; j < QT; ++j) dQacc[j][kt] = MFMA(kk, d[j][u], dQacc[j][kt]);
+    for (int i = 0; i < PPW; ++i) {
+      const int p = j + 4 * i;
+      if (p < 2 * KT) {
+        base[i] = KTp + (size_t)(p / KT) * 16 * D + (p % KT) * 256; stride[i] = 32 * D; voff[i] = doff; second[i] = p / KT != 0;
+      } else {
+        const int t = p - 2 * KT, ltile = min(lt0 + (t >> 1), mtiles - 1);
+        base[i] = dAh + ((size_t)ltile * mtiles + (t & 1)) * 256; stride[i] = 512; voff[i] = lin; second[i] = (t & 1) != 0;
       }
-  };
-  ldk(0, kcA);
-#pragma unroll
-  for (int j = 0; j < QT; ++j) lda(j, 0, daA[j]);
-  ldk(min(1, mtiles - 1), kcB);
-#pragma unroll
-  for (int j = 0; j < QT; ++j) lda(j, min(1, mtiles - 1), daB[j]);
-  // dQ^T[k][l] += sum_m K^T[k][m] dA[l][m]; two key tiles per trip, each register set reloaded two tiles ahead
-  int mt = 0;
-  for (; mt + 1 < mtiles; mt += 2) {
-    mma(kcA, daA);
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      const int m2 = min(mt + 2, mtiles - 1);
-      ldk(m2, kcA);
-#pragma unroll
-      for (int j = 0; j < QT; ++j) lda(j, m2, daA[j]);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    mma(kcB, daB);
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      const int m3 = min(mt + 3, mtiles - 1);
-      ldk(m3, kcB);
+    auto stage_in = [&](int it, int stage) __attribute__((always_inline)) {
+      const unsigned dst = lds_addr(sm) + stage * (STG * 4);
+      const bool odd_last = 2 * it + 1 >= mtiles;   // the second key tile of this trip does not exist: re-read the first (its MFMAs are skipped)
 #pragma unroll
-      for (int j = 0; j < QT; ++j) lda(j, m3, daB[j]);
+      for (int i = 0; i < PPW; ++i) {
+        const int p = j + 4 * i;
+        if (p < 2 * KT + 2 * QW_TILES) {
+          const float* src = base[i] + (size_t)it * stride[i];
+          if (odd_last && second[i]) src -= (p < 2 * KT) ? 16 * D : 256;
+          if (p < 2 * KT ? ABL(1) : ABL(32)) dma_piece(dst + p * 1024, src, voff[i]);
+        }
+      }
+    };
+    const bool full = j + 4 * (PPW - 1) < 2 * KT + 2 * QW_TILES;   // this wave issues PPW (else PPW - 1) pieces per stage
+    auto wait_ring = [&]() __attribute__((always_inline)) {
+      if (full) vm_wait<(QW_STAGES - 2) * PPW>(); else vm_wait<(QW_STAGES - 2) * (PPW - 1)>();
+    };
+#pragma unroll
+    for (int t = 0; t < QW_STAGES - 1; ++t) if (t < nit) stage_in(t, t);
+    if (nit >= QW_STAGES - 1) wait_ring(); else vm_wait<0>();
+    lds_barrier();
+    for (int it = 0; it < nit; ++it) {
+      const int tn = it + QW_STAGES - 1;
+      if (tn < nit) { stage_in(tn, tn % QW_STAGES); wait_ring(); }
+      else vm_wait<0>();   // the ring drains: nothing is in flight when the stages are reused by the epilogue
+      lds_barrier();
     }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (mt < mtiles) mma(kcA, daA);
+  } else {
+    const int ll = lane & 15, q = lane >> 4;
+    v4f dQ[2][KT];
 #pragma unroll
-  for (int j = 0; j < QT; ++j) {
-    const int l = (lt0 + j) * 16 + ll;
-    if (lt0 + j < mtiles && l < N) {
-      float* o = a.d_qkv + ((size_t)b * N + l) * 3 * DH + h;
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) dQ[jj][kt] = (v4f){0.f, 0.f, 0.f, 0.f};
+    const float* kfrag = sm + ll * 16 + ((q ^ chunk_xor(ll)) << 2);                 // + stage, + (kb KT + kt) * 256
+    const float* dfrag = sm + 2 * KT * 256 + (2 * wv) * 512 + (4 * q) * 16 + ll;   // + stage, + jj * 512 + kb * 256 + u * 16
+    struct Frag { float4 kc[2][KT]; float da[2][2][4]; };
+    auto fetch = [&](int stage, Frag& fr) __attribute__((always_inline)) {
+      const float* kf = kfrag + stage * STG;
+      const float* df = dfrag + stage * STG;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) fr.kc[kb][kt] = *reinterpret_cast<const float4*>(kf + (kb * KT + kt) * 256);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) fr.da[kb][jj][u] = df[jj * 512 + kb * 256 + u * 16];
+    };
+    // dQ^T[k][l] += sum_m K^T[k][m] dA[l][m]  (a key tile past the end -- odd tile counts -- is skipped)
+    auto mma = [&](int it, const Frag& fr) __attribute__((always_inline)) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        if (2 * it + kb < mtiles) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+              const float kk = u == 0 ? fr.kc[kb][kt].x : u == 1 ? fr.kc[kb][kt].y : u == 2 ? fr.kc[kb][kt].z : fr.kc[kb][kt].w;
+#pragma unroll
+              for (int jj = 0; jj < 2; ++jj) dQ[jj][kt] = MFMA(kk, fr.da[kb][jj][u], dQ[jj][kt]);
+            }
+        }
+    };
+    // The MFMAs lag one trip behind the LDS requests: behind barrier it the fragments of stage it+1 are requested, then the
+    // MFMAs of trip it run from the registers filled a trip ago -- the LDS latency never faces an idle matrix pipe.  Two
+    // named register sets swap roles.
+    Frag fa, fb;
+    lds_barrier();
+    fetch(0, fa);
+    int it = 0;
+    for (; it + 1 < nit; it += 2) {
+      lds_barrier(); fetch((it + 1) % QW_STAGES, fb); mma(it, fa);
+      lds_barrier(); fetch((it + 2) % QW_STAGES, fa); mma(it + 1, fb);
+    }
+    if (it < nit) { lds_barrier(); mma(it, fa); }
+    // d^-1/2 dQ into the (now idle) stages as [query row 128][channel]
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      float* o = sm + ((2 * wv + jj) * 16 + ll) * D + 4 * q;
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[(16 * kt + 4 * q + r) * AH] = dQacc[j][kt][r] * a.scale;
+        *reinterpret_cast<float4*>(o + 16 * kt) = make_float4(dQ[jj][kt][0] * a.scale, dQ[jj][kt][1] * a.scale, dQ[jj][kt][2] * a.scale, dQ[jj][kt][3] * a.scale);
     }
+  }
+  // dQ rows of d_qkv (channel k*8 + h): consecutive lanes consecutive channels of one row
+  lds_barrier();
+  for (int p = tid; p < 16 * QW_TILES * D; p += 512) {
+    const int row = p / D, k = p % D, l = lt0 * 16 + row;
+    if (l < N && ABL(4)) a.d_qkv[((size_t)b * N + l) * 3 * DH + k * AH + h] = sm[p];
   }
 }
 
@@ -1112,9 +1159,10 @@ static void launch_bwd(const AttnMfmaArgs& a, hipStream_t st) {
     default: launch_bwd_kv_v<D, 0>(a, st); break;
   }
   {
-    constexpr int QT = 2;
-    const int waves = a.B * AH * ((a.NP / 16 + QT - 1) / QT);
-    EGT_LAUNCH("k_attn_mfma_bwd_q", (k_attn_mfma_bwd_q<D, QT>), dim3((waves + 3) / 4), dim3(256), 0, st, a);
+    const int qgroups = (a.NP / 16 + QW_TILES - 1) / QW_TILES;
+    const size_t lds = (size_t)QW_STAGES * (2 * (D / 16) + 2 * QW_TILES) * 1024;
+    EGT_MAX_LDS_ONCE(k_attn_mfma_bwd_q<D>);
+    EGT_LAUNCH("k_attn_mfma_bwd_q", (k_attn_mfma_bwd_q<D>), dim3(a.B * AH * qgroups), dim3(512), lds, st, a);
   }
 }
 
