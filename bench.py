@@ -50,7 +50,19 @@ WORKLOADS = {
     # unlocks the 16-row-exact backward (prologue inside the pair kernel) at the price of 14 % more pairs
     "cifar10_n150_pad160": dict(B=128, N=160, Dh=64, De=8, H=8, Ly=4, nodes=(85, 150), rand_p=0.1),
     "pattern500k_n120_pad128_b128": dict(B=128, N=128, Dh=64, De=8, H=8, Ly=16, nodes=(44, 120), rand_p=0.1),
+    # BASELINE.json configs[4]: synthetic dense graphs, the MFMA / HBM roofline stress.  CORE-OP scope of SURVEY 8(d)(i):
+    # ([QKV,E,G],mask) -> (V_att,H_hat) forward + backward on the MFMA inner-op kernels (egt_attn_mfma.hip), every key real
+    "synthetic_n512": dict(B=8, N=512, Dh=512, De=32, H=8, Ly=1, nodes=(512, 512), rand_p=0.1, scope="core"),
+    "synthetic_n512_b32": dict(B=32, N=512, Dh=512, De=32, H=8, Ly=1, nodes=(512, 512), rand_p=0.1, scope="core"),
 }
+# what the metric string says after "graphs/sec EGT fwd+bwd, " (BASELINE.json's metric is quoted on the first)
+METRIC_OF = {"zinc500k_n64": "ZINC-500K padded N=64", "zinc500k_n64_b1024": "ZINC-500K padded N=64 (B=1024)",
+             "zinc100k_n37": "ZINC-100K shapes padded N=37", "cifar10_n150_fp32": "CIFAR10-500K shapes padded N=150 (fp32 edge tensors)",
+             "cifar10_n150": "CIFAR10-500K shapes padded N=150 (bf16 edge tensors)", "pattern500k_n120": "PATTERN-500K shapes padded N=120 (B=16)",
+             "pattern500k_n120_b128": "PATTERN-500K shapes padded N=120 (B=128)", "cifar10_n150_pad160": "CIFAR10-500K shapes padded N=160",
+             "pattern500k_n120_pad128_b128": "PATTERN-500K shapes padded N=128 (B=128)",
+             "synthetic_n512": "synthetic dense N=512 heads=8 d=64 (core op)", "synthetic_n512_b32": "synthetic dense N=512 heads=8 d=64 (core op, B=32)"}
+FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
 
 
 def algorithmic_bytes(kernel: str, w: dict) -> float:
@@ -224,6 +236,150 @@ def cpu_baseline(w, seconds=12.0):
     return out
 
 
+def cpu_baseline_core(w, seconds=12.0):
+    """core-op scope: the torch-CPU fp32 op-by-op restatement of egt_layers.py:57-143 (oracle/egt_oracle.egt_forward),
+    fwd + bwd by autograd, on the host cores; bounded sample (one graph per step)."""
+    from oracle import egt_oracle as O
+    Bs, N, H, d = 1, w["N"], w["H"], w["Dh"] // w["H"]
+    g = torch.Generator().manual_seed(77)
+    QKV = torch.randn(Bs, N, 3 * d * H, generator=g).requires_grad_()
+    E = torch.randn(Bs, N, N, H, generator=g).requires_grad_()
+    G = torch.randn(Bs, N, N, H, generator=g).requires_grad_()
+    mask = torch.ones(Bs, N, dtype=torch.bool)
+    rm = torch.rand(Bs, N, N, H, generator=g) < w["rand_p"]
+    dV = torch.randn(Bs, N, d * H, generator=g); dH = torch.randn(Bs, N, N, H, generator=g)
+
+    def step():
+        V, Hh, _ = O.egt_forward(QKV, E, G, None, mask, rand_mask=rm, drop_keep=None, num_heads=H, clip_logits_value=(-5.0, 5.0),
+                                 scale_degree=False, scaler_type="log", num_virtual_nodes=0, attn_dropout=0.0)
+        torch.autograd.grad([V, Hh], [QKV, E, G], [dV, dH])
+
+    nthr = torch.get_num_threads()
+    thr = min(nthr, 8)
+    torch.set_num_threads(thr)
+    try:
+        step()
+        t0 = time.perf_counter(); reps = 0
+        while time.perf_counter() - t0 < seconds:
+            step(); reps += 1
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(nthr)
+    return dict(value=Bs * reps / dt, unit="graphs/s", cores=thr, kind="port",
+                sample=f"{reps} fwd+bwd steps of the inner op on B={Bs} graph (N={N}, H={H}, d={d}, fp32, torch-CPU restatement of the TF op "
+                       f"sequence egt_layers.py:57-143, {dt:.1f}s, host has {os.cpu_count()} cpus)")
+
+
+def run_core(args, w, dev, lib, rank, world, use_dist):
+    """BASELINE config 5 at the core-op scope of SURVEY 8(d)(i): a step = egt_attn_mfma_fwd + egt_attn_mfma_bwd through the
+    C-ABI on buffers resident in HBM (one shared workspace: q/k/v are packed once), training mode with the in-kernel
+    random mask (a fresh seed per step).  No parameters at this scope: N > 1 ranks are independent shards (no collective)."""
+    from egt_amd import _lib as L
+    B, N, H, Dh = w["B"], w["N"], w["H"], w["Dh"]
+    d = Dh // H
+    g = torch.Generator().manual_seed(1234 + rank)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev)
+    qkv, E, G = mk(B, N, 3 * Dh), mk(B, N, N, H), mk(B, N, N, H)
+    dV, dHx = mk(B, N, Dh), mk(B, N, N, H)
+    km = torch.ones(B, N, dtype=torch.uint8, device=dev)
+    desc = L.AttnDesc(B=B, N=N, H=H, d=d, dtype=L.EGT_F32, flags=L.F_EDGE_INPUT | L.F_GATE_INPUT | L.F_CLIP | L.F_TRAINING,
+                      clip_lo=-5.0, clip_hi=5.0, random_mask_prob=float(w["rand_p"]), attn_dropout=0.0, num_virtual_nodes=0,
+                      reserved=L.ATTN_WS_SHARED, seed=0)
+    assert lib.egt_attn_mfma_supported(C.byref(desc), 0) == 1
+    v_att = torch.empty(B, N, Dh, device=dev); h_hat = torch.empty(B, N, N, H, device=dev)
+    rowstats = torch.empty(B, N, H, 4, device=dev)
+    ws = torch.empty(lib.egt_attn_mfma_workspace_bytes(C.byref(desc)), dtype=torch.uint8, device=dev)
+    d_qkv = torch.empty_like(qkv); d_E = torch.empty_like(E); d_G = torch.empty_like(G)
+    st = L.current_stream()
+    state = {"i": 0}
+
+    def step():
+        state["i"] += 1
+        desc.seed = (1 + rank) * 1000003 + state["i"]      # the replicas and the steps draw independent random masks
+        L.check(lib.egt_attn_mfma_fwd(C.byref(desc), L.ptr(qkv), L.ptr(E), L.ptr(G), L.ptr(km), None, None, L.ptr(v_att), L.ptr(h_hat),
+                                      L.ptr(rowstats), L.ptr(ws), st))
+        L.check(lib.egt_attn_mfma_bwd(C.byref(desc), L.ptr(qkv), L.ptr(E), L.ptr(G), L.ptr(km), None, None, L.ptr(v_att), L.ptr(rowstats),
+                                      L.ptr(dV), L.ptr(dHx), L.ptr(d_qkv), L.ptr(d_E), L.ptr(d_G), L.ptr(ws), st))
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dominant = "k_attn_mfma_bwd_kv"
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_prof:
+        lib.egt_prof_filter(dominant.encode()); lib.egt_prof_enable(2)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.egt_prof_enable(0)
+    graphs_step = B
+    if use_dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+        gs = torch.tensor([B], device=dev, dtype=torch.int64)
+        dist.all_reduce(gs); graphs_step = int(gs.item())
+    dom_prof = prof_read_all(lib) if not args.no_prof else {}
+    prof = {}
+    if not args.no_prof:
+        lib.egt_prof_filter(b""); lib.egt_prof_enable(2)
+        for _ in range(min(args.steps, 10)):
+            step()
+        fence()
+        lib.egt_prof_enable(0)
+        prof = prof_read_all(lib)
+    if rank != 0:
+        return
+    pairs = B * N * N
+    # ALGORITHMIC flops (SURVEY 8(d): core op 12 N^2 Dh per graph fwd+bwd): forward QK^T + A.V = 4, backward dP + dV + dK = 6
+    # in k_attn_mfma_bwd_kv, dQ = 2 in k_attn_mfma_bwd_q; the backward's recompute of S (2 more) is executed, not counted
+    fl = {"k_attn_mfma_fwd": 4.0 * pairs * Dh, "k_attn_mfma_bwd_kv": 6.0 * pairs * Dh, "k_attn_mfma_bwd_q": 2.0 * pairs * Dh}
+    roof = None
+    if prof:
+        cnt, ms = dom_prof.get(dominant, prof[dominant])
+        avg_s = ms / cnt / 1e3
+        ach = fl[dominant] / avg_s / 1e12
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_mfma.json"))).get(args.workload, {})
+        except Exception:  # noqa: BLE001
+            pmc = {}
+        roof = dict(bound="mfma", kernel=dominant, timed_in_region=dominant in dom_prof, achieved=ach, peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s",
+                    frac=ach / FP32_MFMA_PEAK_TF, executed_frac=ach * (8.0 / 6.0) / FP32_MFMA_PEAK_TF,
+                    step_frac=12.0 * pairs * Dh / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TF / max(world, 1) * (graphs_step / B),
+                    traffic=(pmc.get(dominant) or {}).get("hbm_bytes_per_launch"),
+                    mfma_busy=(pmc.get(dominant) or {}).get("mfma_busy"),
+                    pmc_source=("static: profiles/pmc_mfma.json = committed rocprofv3 --pmc passes of this workload (SQ_VALU_MFMA_BUSY_CYCLES / "
+                                "(4 x SQ_BUSY_CU_CYCLES); HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024); not re-measured in this run") if pmc else None,
+                    avg_launch_us=avg_s * 1e6, launches=cnt, algorithmic_flops_per_launch=fl[dominant],
+                    kernels={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3, share=v[1] / sum(x[1] for x in prof.values()),
+                                     tflops=(fl[k] / (v[1] / v[0] / 1e3) / 1e12) if k in fl else None)
+                             for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline_core(w, args.cpu_seconds)
+    line = {
+        "metric": "graphs/sec EGT fwd+bwd, " + METRIC_OF[args.workload],
+        "value": graphs_step * args.steps / elapsed, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: core op ([QKV,E,G],mask) -> (V_att,H_hat) fwd+bwd (egt_layers.py:57-143 under autodiff), "
+                               "training mode, in-kernel random mask", "scope": "core", "graphs_per_gpu": B, "global_batch": graphs_step,
+                   "N": N, "Dh": Dh, "H": H, "d": d, "De": w["De"], "random_mask_prob": w["rand_p"], "nodes": list(w["nodes"]),
+                   "path": "mfma inner op (pack + k_attn_mfma_fwd; pack + k_attn_mfma_bwd_kv + k_attn_mfma_bwd_q), one shared workspace",
+                   "parallelism": f"dp{world}", "backend": "independent shards (the core op has no parameters: no collective)",
+                   "tflops_step": 12.0 * pairs * Dh * (graphs_step / B) / (elapsed / args.steps) / 1e12},
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(line))
+
+
 def _free_port() -> int:
     import socket
     s = socket.socket()
@@ -333,6 +489,12 @@ def main():
             raise SystemExit(f"bench.py: egt_dp world {comm.world} != {world}")
 
     w = dict(WORKLOADS[args.workload])
+    if w.get("scope") == "core":
+        run_core(args, w, dev, lib, rank, world, use_dist)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if os.environ.get("EGT_BENCH_B"):   # experiments only (batch sweeps): the line's config carries the overridden B
         w["B"] = int(os.environ["EGT_BENCH_B"])
     if args.layers > 0:
@@ -583,6 +745,15 @@ def main():
                 traffic = (pt.get(wl) or {}).get(dom) if args.scope in ("", "stack") and args.layers == 0 else None
             except Exception:
                 traffic = None
+            # the OTHER roof of an exact-fp32 pair kernel: instruction issue.  MFMA cycles + VALU cycles per launch over
+            # SIMDs x active cycles, and the matrix-pipe busy fraction, from the committed counter pass of this workload (static)
+            issue = mfma_busy = None
+            try:
+                pm = (json.load(open(os.path.join(REPO, "profiles", "pmc_mfma.json"))).get(args.workload) or {}).get(dom) or {}
+                if args.scope in ("", "stack") and args.layers == 0 and not args.edge_dtype:
+                    issue, mfma_busy = pm.get("issue"), pm.get("mfma_busy")
+            except Exception:  # noqa: BLE001
+                pass
             nprof = min(args.steps, 10)
             fl = algorithmic_flops(dom, w, args.scope)
             if fl > 0:    # MFMA-bound dominant kernel (whole-layer / whole-model scopes): fp32 matrix peak
@@ -597,7 +768,7 @@ def main():
               roof = dict(bound="hbm", kernel=dom, timed_in_region=dom in dom_prof, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=(ach / HBM_PEAK_GBS) if ach else None,
                         achievable_peak=HBM_ACHIEVABLE_GBS, frac_of_achievable=(ach / HBM_ACHIEVABLE_GBS) if ach else None,   # the 6.3 TB/s a streaming copy sustains (MI355X_MICROARCH.md, HBM)
-                        traffic=traffic,
+                        traffic=traffic, issue=issue, mfma_busy=mfma_busy,
                         traffic_source=("static: profiles/pmc_traffic.json = HBM bytes per launch from the committed rocprofv3 --pmc "
                                         "FETCH_SIZE / WRITE_SIZE passes of this workload (FETCH doubled per the gfx950 note); not re-measured in this run"
                                         if traffic is not None else None),
@@ -618,7 +789,8 @@ def main():
         if args.scope == "model":
             path = ("pattern" if pattern else "cifar10" if cifar else "zinc") + "-model (HIP edge embedding + fused blocks + fused FFNs, torch node-side head)"
         line = {
-            "metric": "graphs/sec EGT fwd+bwd, ZINC-500K padded N=64",
+            "metric": "graphs/sec EGT fwd+bwd, " + METRIC_OF[args.workload]
+                      + ("" if (args.scope or "stack") == "stack" and not args.with_ffn else f" ({args.scope or 'layers'} scope)"),
             "value": graphs / elapsed, "unit": "graphs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,

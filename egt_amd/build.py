@@ -16,7 +16,7 @@ REPO = os.path.dirname(ROOT)
 CSRC = os.path.join(ROOT, "csrc")
 LIBDIR = os.path.join(ROOT, "lib")
 LIB = os.path.join(LIBDIR, "libegt_amd.so")
-SOURCES = ["egt_capi.hip", "egt_attn.hip", "egt_attn_mfma.hip", "egt_edge.hip", "egt_block.hip", "egt_block_bwd6.hip", "egt_narrow.hip", "egt_node.hip", "egt_ffn.hip", "egt_masks.hip", "egt_embed.hip", "egt_dp.hip"]
+SOURCES = ["egt_capi.hip", "egt_attn.hip", "egt_attn_mfma.hip", "egt_edge.hip", "egt_block.hip", "egt_narrow.hip", "egt_node.hip", "egt_ffn.hip", "egt_masks.hip", "egt_embed.hip", "egt_dp.hip"]
 ARCH = "gfx950"
 # per-source compiler flags.  egt_ffn.hip: the backward keeps 256 weight-gradient accumulator
 # registers per wave; with hipcc's default (AGPR-form MFMA everywhere) the short-lived GEMM
@@ -27,11 +27,9 @@ EXTRA_FLAGS = {"egt_ffn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "egt_narrow.hip": ["-fno-slp-vectorize"]}
 if os.environ.get("EGT_BLOCK_FLAGS"):   # experiments: extra hipcc flags for egt_block.hip
     EXTRA_FLAGS["egt_block.hip"] = os.environ["EGT_BLOCK_FLAGS"].split()
-if os.environ.get("EGT_BWD6_FLAGS"):   # e.g. -DEGT_BWD_TIMING (per-stage cycle stamps of k_block_bwd_v6)
-    EXTRA_FLAGS["egt_block_bwd6.hip"] = os.environ["EGT_BWD6_FLAGS"].split()
 if os.environ.get("EGT_NARROW_FLAGS"):  # e.g. -DNRW_ABL=<bits> (timing ablations of the De = 8 kernels)
     EXTRA_FLAGS["egt_narrow.hip"] = EXTRA_FLAGS["egt_narrow.hip"] + os.environ["EGT_NARROW_FLAGS"].split()
-if os.environ.get("EGT_ATTN_FLAGS"):    # e.g. -DEGT_ATTN_ABLATION (timing ablations of the MFMA inner op)
+if os.environ.get("EGT_ATTN_FLAGS"):    # e.g. -DEGT_ATTN_STAMPS / -DEGT_ATTN_ABL=<bits> (measurement builds of the MFMA inner op)
     EXTRA_FLAGS["egt_attn_mfma.hip"] = os.environ["EGT_ATTN_FLAGS"].split()
 
 

@@ -31,7 +31,7 @@ struct BlockArgs {
   float *sbo;    // per-workgroup partials of this layer's dense_mha bias gradient
   int spart_n, sbo_n;   // how many workgroup partials the reduction finds in spart / sbo
   int guard;    // backward phase guards (always 0 in production, see k_block_bwd_v4)
-  unsigned* dbg; unsigned dbg_t0;   // EGT_BWD_TIMING builds: per-wave phase cycle sums
+  unsigned* dbg; unsigned dbg_t0;   // measurement builds of egt_narrow.hip (-DNRW_TIMING): per-wave section cycle sums
   int prep;     // node kernels: add the edge-weight preparation workgroup
   const float *nx_nm_g, *nx_nm_b, *nx_Wqkv, *nx_bqkv;   // next block (epi == 2)
   float* nx_qkvp;
@@ -53,7 +53,7 @@ struct BlockArgs {
   float *dh, *de;
   float *g_ne_g, *g_ne_b, *g_Wg, *g_bg, *g_We, *g_be, *g_nm_g, *g_nm_b, *g_Wqkv, *g_bqkv, *g_Wo,
       *g_bo, *g_Wr, *g_br;
-  unsigned* dbg2;   // EGT_BWD_TIMING builds: the node-side prologue's phase cycles (last member: the other translation units ignore it)
+  unsigned* dbg2;   // -DNRW_TIMING: the node-side prologue's phase cycles (last member: the other translation units ignore it)
 };
 
 template <int DE>
@@ -73,14 +73,13 @@ __host__ __device__ inline int col_head(int i) { return 2 * (i >> 2) + ((i >> 1)
 
 
 #define BWD_TL 16   // backward: query rows per workgroup
+int egt_device_cus();   // compute units of the current device (egt_block.hip)
 #define NODE_RC 32  // node rows per workgroup in the node kernels
 
 // De = 8 VALU pair kernels (egt_narrow.hip)
 void egt_narrow_launch_fwd(BlockArgs& a, hipStream_t st);
 void egt_narrow_launch_bwd(BlockArgs& a, int nwg, hipStream_t st);   // same a.pro / partial-buffer contract as k_block_bwd_v4r
 
-// tile-pair backward (egt_block_bwd6.hip): De in {32, 48, 64}, fp32 edge tensors, no mask tensors, N % 16 == 0
-void egt_bwd6_launch(BlockArgs& a, int nwg, hipStream_t st);
 
 // launchers implemented in egt_node.hip
 void egt_node_launch_pre(BlockArgs& a, hipStream_t st);

@@ -45,21 +45,6 @@
 // ML: attention-mask / injected-random-mask byte streams are present (their loads are
 // compiled out of the headline kernel).
 // FULL: N is a multiple of 16 (no ragged key tile): validity selects and address clamps fold away.
-// Timing ablations of the forward (EGT_BLOCK_FLAGS=-DEGT_BLOCK_ABLATION at build time, EGT_FWD_ABLATE=<bits>
-// at run time): 1 K/V fragments + QK^T + softmax + A.V, 2 random-mask hash, 4 LN + projections,
-// 8 dense_edge_r + e' tile, 16 e' stores, 32 K/V/Q staging, 64 node-side epilogue, 128 e-tile loads.
-// Compiled out otherwise.
-#ifdef EGT_BLOCK_ABLATION
-#define FABL(a, bit) (!((a).guard & (bit)))
-#else
-#define FABL(a, bit) true
-#endif
-// Phase timing of k_block_fwd (EGT_BLOCK_FLAGS=-DEGT_FWD_TIMING, measurement builds only; see EGT_BWD_TIMING)
-#ifdef EGT_FWD_TIMING
-#define FSTAMP(i) do { const unsigned tn__ = (unsigned)__builtin_amdgcn_s_memtime(); facc[i] += tn__ - flast; flast = tn__; } while (0)
-#else
-#define FSTAMP(i) do {} while (0)
-#endif
 template <int DE, bool KVL, bool ML, bool FULL, bool BF>
 __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd(BlockArgs a) {   // narrow tiles without K/V in LDS: more resident waves (with K/V in LDS the LDS footprint caps a CU at two workgroups anyway)
   seed_from_device(a);
@@ -84,7 +69,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
   const bool gated = (a.flags & EGT_BF_GATE) != 0;
   const bool clip = (a.flags & EGT_BF_CLIP) != 0;
 
-  if (KVL && FABL(a, 32)) {
+  if (KVL) {
     const float* src = a.qkvp + (size_t)b * N * QKVP;
     for (int i = threadIdx.x; i < N * 32; i += 256) {
       const int row = i >> 5, f = i & 31;
@@ -130,7 +115,6 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
   constexpr int PFD = (DE <= 16 && KVL) ? 4 : 1;   // measured: +3.5 % at De = 8, N = 120; without K/V in LDS the extra registers spill
   TileRegs<DE> ring[PFD];
   auto prefetch = [&](TileRegs<DE>& tr, int it) {
-    if (!FABL(a, 128)) return;
     if (PFD > 1) it = min(it, total - 1);
     const int l = lg * 16 + wave + 4 * (it / ntile), m0 = (it % ntile) * 16;
     const size_t pair0 = ((size_t)b * N + l) * N + m0;
@@ -142,13 +126,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
   }
 
   float Qf[16], mx[2], sum[2], O[16];
-#ifdef EGT_FWD_TIMING
-  unsigned facc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned flast = (unsigned)__builtin_amdgcn_s_memtime();
-  const unsigned fstart = flast;
-#endif
   auto step = [&](const int it_, TileRegs<DE>& tr) __attribute__((always_inline)) {
-    FSTAMP(0);
     const bool live = PFD == 1 || it_ < total;
     const int it = PFD == 1 ? it_ : min(it_, total - 1);
     const int li = it / ntile, mt = it % ntile;
@@ -173,7 +151,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
     // of the next LDS staging therefore never covers a store younger than the loads it needs.
     float* tl = tl0 + (it_ & 1) * G::TILE_FLOATS;
     lds_sync();
-    if (it_ > 0 && live && FABL(a, 16)) {   // stream out e' of the previous tile from the other buffer
+    if (it_ > 0 && live) {   // stream out e' of the previous tile from the other buffer
       const int itp = it - 1, lp = lg * 16 + wave + 4 * (itp / ntile), m0p = (itp % ntile) * 16;
       tile_from_lds<DE>(tl0 + (itp & 1) * G::TILE_FLOATS, e_o + (((size_t)b * N + lp) * N + m0p) * DE,
                         lane, FULL ? 16 : min(16, N - m0p));
@@ -182,16 +160,12 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
     if (PFD == 1) { if (it + 1 < total) prefetch(tr, it + 1); }
     else prefetch(tr, it_ + PFD);   // this slot's next tile (clamped past the end)
     lds_sync();
-    FSTAMP(1);
     float4 x[G::TILES];
 #pragma unroll
     for (int t = 0; t < G::TILES; ++t) x[t] = frag_read<DE>(tl, p, q, t);
     // ---- K/V fragments of key m ----
     float Kf[16], Vf[16], kadd = 0.f;
-    if (!FABL(a, 1)) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { Kf[i] = 1.f; Vf[i] = 1.f; }
-    } else {
+    {
       const int mc = valid ? m : 0;
       const float4* kp;
       const float4* vp;
@@ -214,14 +188,13 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
     }
     // ---- norm_edge + [attention_gates | dense_edge_b] ----
     v4f acc = {c2r[0], c2r[1], c2r[2], c2r[3]};
-    if (FABL(a, 4)) {
+    {
       ln_frags<DE>(x, q, a.ln_eps, (a.flags & EGT_BF_NO_EDGE_LN) == 0);
       acc = project<DE>(x, wA, acc);
     }
-    FSTAMP(2);
     // ---- scaled QK^T, clip, + E (egt_layers.py:79-86) ----
     float hh[2] = {0.f, 0.f}, xl[2] = {0.f, 0.f}, gl[2] = {0.f, 0.f};
-    if (FABL(a, 1)) {
+    {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float dot = 0.f;
@@ -234,9 +207,8 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
       gl[j] = acc[2 * j];
     }
     }
-    if (FABL(a, 2)) apply_masks<ML>(a, kadd, mr, (pair0 + p) * BH, q, xl, gl);
+    apply_masks<ML>(a, kadd, mr, (pair0 + p) * BH, q, xl, gl);
     // ---- online softmax x gate, A.V (per lane) ----
-    if (FABL(a, 1))
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const float xv = xl[j];
@@ -249,10 +221,8 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
 #pragma unroll
       for (int k = 0; k < 8; ++k) O[2 * k + j] = fmaf(O[2 * k + j], alpha, av * Vf[2 * k + j]);
     }
-    FSTAMP(3);
     // ---- dense_edge_r + res_edge: e' = e + H_hat.Wr + br ----
     const float h0 = valid ? hh[0] : 0.f, h1 = valid ? hh[1] : 0.f;
-    if (FABL(a, 8))
 #pragma unroll
     for (int t = 0; t < G::TILES; ++t) {
       v4f d = {brv[t].x, brv[t].y, brv[t].z, brv[t].w};
@@ -265,8 +235,6 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
       lds_sync();
       tile_from_lds<DE>(tl, e_o + pair0 * DE, lane, rows_valid);
     }
-    FSTAMP(4);
-
     if (mt == ntile - 1 && live) {
       // ---- merge the 16 key lanes (same q): max, then sums ----
 #pragma unroll
@@ -292,7 +260,6 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
         st[1] = sj;
       }
     }
-    FSTAMP(5);
   };
   if (PFD == 1) {
     for (int it = 0; it < total; ++it) step(it, ring[0]);
@@ -307,18 +274,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
   //   epi >= 1: h' = V_att.Wo + bo + h                      (dense_mha + res_mha, :136,140)
   //   epi == 2: qkv of the NEXT block = LN(h').Wqkv' + bqkv' (norm_mha + dense_qkv, :109,113), packed
   // Contraction order k = 4s + q on both MFMA operands; weights come straight from L2.
-#ifdef EGT_FWD_TIMING
-  FSTAMP(6);
-#endif
-  if (KVL && a.epi && FABL(a, 64)) fwd_node_epilogue(a, sm, qs, b, lg, N, wave, p, q);
-#ifdef EGT_FWD_TIMING
-  FSTAMP(7);
-  if (a.dbg && lane == 0) {
-    unsigned* o = a.dbg + ((size_t)wg * 4 + wave) * 16;
-    for (int i = 0; i < 8; ++i) o[i] = facc[i];
-    o[13] = flast - fstart;
-  }
-#endif
+  if (KVL && a.epi) fwd_node_epilogue(a, sm, qs, b, lg, N, wave, p, q);
 }
 
 // ---------------------------------------------------------------- forward, narrow edge channels ---
@@ -530,297 +486,10 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_fwd_r4(BlockArgs a) {
 }
 
 // ================================================================ backward =====
-// Workgroup = (graph b, TL query rows); wave w owns key tiles w, w+4, ...; for each
-// it walks the TL rows.  Q / dV_att / softmax statistics of the rows sit in LDS.
-template <int DE, bool ML, bool FULL, bool BF>
-__global__ void __launch_bounds__(256, 1) k_block_bwd(BlockArgs a) {
-  seed_from_device(a);
-  using G = Geo<DE>;
-  typedef typename EdgeT<BF>::type ET;   // element type of the edge tensors in HBM
-  const ET* e_in = reinterpret_cast<const ET*>(a.e);
-  ET* e_o = reinterpret_cast<ET*>(a.e_out);
-  const ET* dey_in = reinterpret_cast<const ET*>(a.de_out);
-  ET* dex_o = reinterpret_cast<ET*>(a.de);
-  (void)e_in; (void)e_o; (void)dey_in; (void)dex_o;
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int p = lane & 15, q = lane >> 4;
-  const int N = a.N, TL = a.TL;
-  const int b = blockIdx.x / a.NLR, lr = blockIdx.x % a.NLR;
-  const int l_begin = lr * TL, l_end = min(N, l_begin + TL), nl = l_end - l_begin;
-  const bool gated = (a.flags & EGT_BF_GATE) != 0;
-  const bool clip = (a.flags & EGT_BF_CLIP) != 0;
-  // LDS carve: per wave [e tile | de' tile | dGE scratch 16x16 | H_hat scratch 16x12],
-  // then dq[4][TL][64], then qd[TL][QD_LD]
-  constexpr int PW = 3 * G::TILE_FLOATS + 256 + 192;
-  float* et = sm + wave * PW;
-  float* dt0 = et + G::TILE_FLOATS;           // two de' tiles (ping-pong)
-  float* sc1 = dt0 + 2 * G::TILE_FLOATS;
-  float* sc2 = sc1 + 256;
-  float* dql = sm + 4 * PW + wave * TL * 64;
-  float* qd = sm + 4 * PW + 4 * TL * 64;
-  for (int i = lane; i < TL * 64; i += 64) dql[i] = 0.f;
-  for (int i = threadIdx.x; i < nl * 40; i += 256) {
-    const int r = i / 40, f = i % 40;
-    const size_t rowl = (size_t)b * N + l_begin + r;
-    const float* src = f < 16 ? a.qkvp + rowl * QKVP + f * 4
-                     : f < 32 ? a.dvp + rowl * 64 + (f - 16) * 4
-                              : a.stats + rowl * 32 + (f - 32) * 4;
-    float4 v = *reinterpret_cast<const float4*>(src);
-    if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
-    *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
-  }
-
-  // lane-constant MFMA operands
-  float wA[4 * G::TILES], wrB[4 * G::TILES], wD[G::TILES][4], c2r[4];
-#pragma unroll
-  for (int t = 0; t < 4 * G::TILES; ++t) {
-    const int c = 16 * (t >> 2) + 4 * q + (t & 3);
-    wA[t] = a.pw[c * 16 + p];
-    // dH_ext rows: i = 4q'+0 -> head 2q', i = 4q'+1 -> head 2q'+1, rows 4q'+2,3 empty
-    const int hd = 2 * (p >> 2) + (p & 1);
-    wrB[t] = ((p & 2) == 0 && c < DE) ? a.Wr[hd * DE + c] : 0.f;
-  }
-#pragma unroll
-  for (int t = 0; t < G::TILES; ++t)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) wD[t][s] = a.pw[(16 * t + p) * 16 + 4 * q + s];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) c2r[r] = a.pw[G::DEP * 16 + 4 * q + r];
-
-  v4f accT[G::TILES], accR[G::TILES];
-#pragma unroll
-  for (int t = 0; t < G::TILES; ++t) { accT[t] = (v4f){0.f, 0.f, 0.f, 0.f}; accR[t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
-  float ssum[4] = {0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-
-  const int ntile = (N + 15) / 16;
-  for (int mt = wave; mt < ntile; mt += 4) {
-    const int m0 = mt * 16, m = m0 + p;
-    const bool valid = FULL ? true : (m < N);
-    const int rows_valid = FULL ? 16 : min(16, N - m0);
-    float Kf[16], Vf[16], dKa[16], dVa[16];
-    const size_t rowm = (size_t)b * N + (valid ? m : 0);
-    {
-      const float4* kp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 64 + q * 16);
-      const float4* vp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 128 + q * 16);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 kv = kp[i], vv = vp[i];
-        Kf[4*i] = kv.x; Kf[4*i+1] = kv.y; Kf[4*i+2] = kv.z; Kf[4*i+3] = kv.w;
-        Vf[4*i] = vv.x; Vf[4*i+1] = vv.y; Vf[4*i+2] = vv.z; Vf[4*i+3] = vv.w;
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { dKa[i] = 0.f; dVa[i] = 0.f; }
-    }
-    const float kadd = (a.km && a.km[rowm] == 0) ? -EGT_NEG : 0.0f;
-
-    TileRegs<DE> te, td;
-    auto prefetch = [&](int l) {
-      const size_t pair0 = ((size_t)b * N + l) * N + m0;
-      tile_gload<DE>(te, e_in + pair0 * DE, lane, rows_valid);
-      tile_gload<DE>(td, dey_in + pair0 * DE, lane, rows_valid);
-    };
-    prefetch(l_begin);
-
-    for (int l = l_begin; l < l_end; ++l) {
-      const size_t rowl = (size_t)b * N + l;
-      const size_t pair0 = rowl * N + m0;
-      MaskRegs mr{make_float2(1.f, 1.f), 0};   // issued before the prefetch, consumed after the MFMAs
-      mask_gload<ML>(a, mr, pair0 + (valid ? p : 0), q);
-      // memory order per step: [stores of row l-1] then [loads of row l+1] (see k_block_fwd)
-      float* dt = dt0 + ((l - l_begin) & 1) * G::TILE_FLOATS;
-      lds_sync();
-      if (l > l_begin)   // stream out de of the previous row from the other buffer
-        tile_from_lds<DE>(dt0 + ((l - l_begin - 1) & 1) * G::TILE_FLOATS, dex_o + (pair0 - (size_t)N) * DE,
-                          lane, rows_valid);
-      tile_lds_put<DE>(et, te, lane, rows_valid);
-      tile_lds_put<DE>(dt, td, lane, rows_valid);
-      if (l + 1 < l_end) prefetch(l + 1);
-      lds_sync();
-      float Qf[16], dVf[16], st[8];
-      {
-        const float* qr = qd + (l - l_begin) * QD_LD;
-        const float4* qp = reinterpret_cast<const float4*>(qr + q * 16);
-        const float4* dp = reinterpret_cast<const float4*>(qr + 64 + q * 16);
-        const float4* sp = reinterpret_cast<const float4*>(qr + 128 + q * 8);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float4 u = qp[i], v = dp[i];
-          Qf[4*i] = u.x; Qf[4*i+1] = u.y; Qf[4*i+2] = u.z; Qf[4*i+3] = u.w;
-          dVf[4*i] = v.x; dVf[4*i+1] = v.y; dVf[4*i+2] = v.z; dVf[4*i+3] = v.w;
-        }
-        const float4 s0 = sp[0], s1 = sp[1];
-        st[0] = s0.x; st[1] = s0.y; st[2] = s0.z; st[4] = s1.x; st[5] = s1.y; st[6] = s1.z;
-      }
-      float4 x[G::TILES], dy[G::TILES];
-#pragma unroll
-      for (int t = 0; t < G::TILES; ++t) { x[t] = frag_read<DE>(et, p, q, t); dy[t] = frag_read<DE>(dt, p, q, t); }
-      const float rstd = ln_frags<DE>(x, q, a.ln_eps, (a.flags & EGT_BF_NO_EDGE_LN) == 0);
-      // xhat back into the tile: the weight-gradient MFMAs read it pair-major
-#pragma unroll
-      for (int t = 0; t < G::TILES; ++t) frag_write<DE>(et, p, q, t, x[t]);
-      v4f acc = {c2r[0], c2r[1], c2r[2], c2r[3]};
-      acc = project<DE>(x, wA, acc);
-      // dH_ext = de'.Wr^T (rows 4q, 4q+1 of D = heads 2q, 2q+1)
-      v4f dhx = {0.f, 0.f, 0.f, 0.f};
-      dhx = project<DE>(dy, wrB, dhx);
-
-      float hh[2], xl[2], gl[2], inr[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float dot = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dot = fmaf(Qf[2 * k + j], Kf[2 * k + j], dot);
-        const float araw = dot * a.scale;
-        float ah = araw;
-        inr[j] = 1.0f;
-        if (clip) {
-          inr[j] = (araw >= a.clip_lo && araw <= a.clip_hi) ? 1.0f : 0.0f;
-          ah = fminf(fmaxf(araw, a.clip_lo), a.clip_hi);
-        }
-        hh[j] = ah + acc[2 * j + 1];
-        xl[j] = hh[j];
-        gl[j] = acc[2 * j];
-      }
-      apply_masks<ML>(a, kadd, mr, (pair0 + p) * BH, q, xl, gl);
-      float dge[4], dq[16];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float S = valid ? __expf(xl[j] - st[4 * j]) * st[4 * j + 1] : 0.f;
-        const float g = gated ? egt_sigmoid(gl[j]) : 1.0f;
-        float dAd = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dAd = fmaf(dVf[2 * k + j], Vf[2 * k + j], dAd);
-        const float dS = dAd * g;
-        const float dGl = gated ? dAd * S * g * (1.0f - g) : 0.f;
-        float dH = S * (dS - st[4 * j + 2]) + dhx[j];
-        if (!valid) dH = 0.f;
-        const float dA = dH * inr[j] * a.scale;
-        const float at = S * g;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          dq[2 * k + j] = dA * Kf[2 * k + j];
-          dKa[2 * k + j] = fmaf(dA, Qf[2 * k + j], dKa[2 * k + j]);
-          dVa[2 * k + j] = fmaf(at, dVf[2 * k + j], dVa[2 * k + j]);
-        }
-        dge[2 * j] = valid ? dGl : 0.f;
-        dge[2 * j + 1] = dH;
-        if (!valid) hh[j] = 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ssum[r] += dge[r];
-      // scratch: dGE[pair][16] and H_hat[pair][8] (+ validity column) for the pair-contractions
-      *reinterpret_cast<float4*>(sc1 + p * 16 + 4 * q) = make_float4(dge[0], dge[1], dge[2], dge[3]);
-      *reinterpret_cast<float2*>(sc2 + p * 12 + 2 * q) = make_float2(hh[0], hh[1]);
-      if (q == 0) sc2[p * 12 + 8] = valid ? 1.0f : 0.0f;
-
-      // d(ehat) = Wp . dGE  -> same fragment layout as x / dy
-      float4 dxh[G::TILES];
-#pragma unroll
-      for (int t = 0; t < G::TILES; ++t) {
-        v4f d = {0.f, 0.f, 0.f, 0.f};
-        d = MFMA(wD[t][0], dge[0], d);
-        d = MFMA(wD[t][1], dge[1], d);
-        d = MFMA(wD[t][2], dge[2], d);
-        d = MFMA(wD[t][3], dge[3], d);
-        dxh[t] = make_float4(d[0], d[1], d[2], d[3]);
-      }
-      // LayerNorm backward
-      float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-      for (int t = 0; t < G::TILES; ++t) {
-        m1 += (dxh[t].x + dxh[t].y) + (dxh[t].z + dxh[t].w);
-        m2 = fmaf(dxh[t].x, x[t].x, m2); m2 = fmaf(dxh[t].y, x[t].y, m2);
-        m2 = fmaf(dxh[t].z, x[t].z, m2); m2 = fmaf(dxh[t].w, x[t].w, m2);
-      }
-      m1 = sum_over_q(m1) * (1.0f / DE);
-      m2 = sum_over_q(m2) * (1.0f / DE);
-      if (a.flags & EGT_BF_NO_EDGE_LN) { m1 = 0.f; m2 = 0.f; }   // no norm_edge: d e = de' + d(proj input)
-
-      lds_sync();
-      // ---- weight-gradient contractions over the 16 pairs of the tile ----
-      float bT[4], bR[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        bT[s] = sc1[(q + 4 * s) * 16 + p];
-        bR[s] = (p < 9) ? sc2[(q + 4 * s) * 12 + p] : 0.f;
-      }
-#pragma unroll
-      for (int t = 0; t < G::TILES; ++t) {
-        const int c = 16 * t + p;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const float ax = c < DE ? elem_read<DE>(et, q + 4 * s, c) : 0.f;
-          const float ad = c < DE ? elem_read<DE>(dt, q + 4 * s, c) : 0.f;
-          accT[t] = MFMA(ax, bT[s], accT[t]);
-          accR[t] = MFMA(ad, bR[s], accR[t]);
-        }
-      }
-      lds_sync();
-      // ---- de = de' + LN_bwd(d ehat), written in place over the de' tile ----
-#pragma unroll
-      for (int t = 0; t < G::TILES; ++t) {
-        float4 o;
-        o.x = dy[t].x + rstd * (dxh[t].x - m1 - x[t].x * m2);
-        o.y = dy[t].y + rstd * (dxh[t].y - m1 - x[t].y * m2);
-        o.z = dy[t].z + rstd * (dxh[t].z - m1 - x[t].z * m2);
-        o.w = dy[t].w + rstd * (dxh[t].w - m1 - x[t].w * m2);
-        frag_write<DE>(dt, p, q, t, o);
-      }
-      if (l + 1 == l_end) {   // last row of this key tile: flush
-        lds_sync();
-        tile_from_lds<DE>(dt, dex_o + pair0 * DE, lane, rows_valid);
-      }
-      // ---- dQ[l] partial over this tile's 16 keys ----
-      dql[(l - l_begin) * 64 + q * 16 + p] += reduce16_keep_own(dq, p);
-    }
-    // dK, dV partial of this (row-range, key tile)
-    if (valid) {
-      float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
-      float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
-        vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
-      }
-    }
-  }
-  // ---- column sums s[i] over the wave's pairs ----
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    ssum[r] = row_sum16(ssum[r]);
-  }
-  __syncthreads();
-  // dQ: sum the four waves' slots, write packed
-  for (int i = threadIdx.x; i < nl * 64; i += 256) {
-    const float* d0 = sm + 4 * PW;
-    a.dqp[((size_t)b * N + l_begin) * 64 + i] =
-        (d0[i] + d0[TL * 64 + i]) + (d0[2 * TL * 64 + i] + d0[3 * TL * 64 + i]);
-  }
-  // edge-parameter partials: per wave into LDS (reusing the tile area), summed over the 4 waves
-  __syncthreads();
-  float* ep = sm + wave * G::EP;
-#pragma unroll
-  for (int t = 0; t < G::TILES; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      ep[(16 * t + 4 * q + r) * 16 + p] = accT[t][r];
-      ep[G::DEP * 16 + 16 + (16 * t + 4 * q + r) * 16 + p] = accR[t][r];
-    }
-  if (p == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ep[G::DEP * 16 + 4 * q + r] = ssum[r];
-  }
-  __syncthreads();
-  float* out = a.epart + (size_t)blockIdx.x * G::EP;
-  for (int i = threadIdx.x; i < G::EP; i += 256)
-    out[i] = (sm[i] + sm[G::EP + i]) + (sm[2 * G::EP + i] + sm[3 * G::EP + i]);
-}
-
-
-// ================================================ backward, register-lean ("v4") ====
-// Same math as k_block_bwd for full 16-key tiles, restructured so that two wavefronts fit a
+// Workgroup = (graph b, TL query rows); wave w owns key tiles w, w+4, ...; for each it walks the TL rows.  Q / dV_att /
+// softmax statistics of the rows sit in LDS.
+// ---- register-lean general variant ("v4": mask tensors, ragged N, bf16 edge tensors on the wide tiles) ----
+// Two wavefronts fit a
 // SIMD (<= 256 registers, <= 80 KiB LDS per workgroup): the long per-tile dependency chain
 // (LayerNorm -> MFMA chain -> exp/sigmoid -> MFMA chain -> LayerNorm backward) is latency-,
 // not throughput-bound, so a second resident wave is worth more than fat register tiles.
@@ -834,11 +503,10 @@ __global__ void __launch_bounds__(256, 1) k_block_bwd(BlockArgs a) {
 //  * phase guards: P2, the dQ/dK/dV block, P4 and P5 sit behind `if (!(a.guard & bit))` with
 //    a.guard == 0 at run time.  The always-taken uniform branches split the tile body into
 //    basic blocks, which stops hipcc from stretching live ranges across phases: 19 -> 4 spilled
-//    registers, 116 -> 104 us.  (EGT_BWD_ABLATE sets the bits for phase-cost measurements.)
-// PF: how many of the two streamed tiles (e, de') are register-prefetched one row ahead.
+//    registers, 116 -> 104 us.
 // RAG: N is not a multiple of 16 -- the last key tile is zero-filled past N and its lanes get probability and
 // gate exactly 0, the last row group is short (the row loop and the prologue already take nl < 16).
-template <int DE, bool ML, int PF, bool BF, bool RAG>
+template <int DE, bool ML, bool BF, bool RAG>
 __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
   seed_from_device(a);
   using G = Geo<DE>;
@@ -924,11 +592,6 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
     const float kadd = (a.km && a.km[rowm] == 0) ? -EGT_NEG : 0.0f;
 
     TileRegs<DE> te, td;
-    {
-      const size_t pair0 = ((size_t)b * N + l_begin) * N + m0;
-      if (PF >= 1) tile_gload<DE>(te, e_in + pair0 * DE, lane, kv);
-      if (PF >= 2) tile_gload<DE>(td, dey_in + pair0 * DE, lane, kv);
-    }
     for (int l = l_begin; l < l_end; ++l) {
       const int li = l - l_begin;
       const size_t rowl = (size_t)b * N + l;
@@ -941,14 +604,10 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
       if (li > 0)
         tile_from_lds<DE>(dt0 + ((li - 1) & 1) * G::TILE_FLOATS, dex_o + (pair0 - (size_t)N) * DE, lane, kv);
       const size_t lp0 = (a.guard & 16) ? (size_t)wave * 16 : pair0;
-      if (PF < 2) tile_gload<DE>(td, dey_in + lp0 * DE, lane, kv);
-      if (PF < 1) tile_gload<DE>(te, e_in + lp0 * DE, lane, kv);
+      tile_gload<DE>(td, dey_in + lp0 * DE, lane, kv);   // (two resident waves hide the HBM latency: a register prefetch of the next row only spilled)
+      tile_gload<DE>(te, e_in + lp0 * DE, lane, kv);
       tile_lds_put<DE>(et, te, lane, kv);
       tile_lds_put<DE>(dt, td, lane, kv);
-      if (l + 1 < l_end) {
-        if (PF >= 1) tile_gload<DE>(te, e_in + (pair0 + (size_t)N) * DE, lane, kv);
-        if (PF >= 2) tile_gload<DE>(td, dey_in + (pair0 + (size_t)N) * DE, lane, kv);
-      }
       lds_sync();
       SCHED_FENCE();
       // ---- P1: norm_edge, projections (recompute) ----
@@ -1168,14 +827,6 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
 //    whole lines) instead of making an LDS round trip through a second de' buffer.
 // Same LDS footprint as v4 (two e buffers + one de' buffer instead of one + two): two workgroups per CU.
 // fp32 edge tensors, no mask tensors, N a multiple of 16, De a multiple of 16.
-// Phase timing of k_block_bwd_v5 (EGT_BLOCK_FLAGS=-DEGT_BWD_TIMING, measurement builds only): the wave
-// stamps s_memtime at the phase boundaries and sums the deltas in SGPRs; every wave of the grid writes its
-// sums to a.dbg [wg][4 waves][16] at the end, the host averages and prints them at exit.
-#ifdef EGT_BWD_TIMING
-#define TSTAMP(i) do { const unsigned tn__ = (unsigned)__builtin_amdgcn_s_memtime(); tacc[i] += tn__ - tlast; tlast = tn__; } while (0)
-#else
-#define TSTAMP(i) do {} while (0)
-#endif
 // MM = EGT_MM_BF16X3 (opt-in: EGT_BWD_MATMUL=bf16x3): the three channel contractions of a tile (P1 projections,
 // P2 dH_ext, P5 d ehat: 48 of the 80 fp32 MFMAs) run as 3-term bfloat16 split products on the bf16 matrix pipe
 // (20 MFMAs of 16 cycles; per-product error 2^-16, fp32 accumulate); the weight-gradient contractions over the
@@ -1184,14 +835,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
 template <int DE, int MM>
 __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   seed_from_device(a);
-#ifdef EGT_BWD_TIMING
-  const unsigned t_entry = (unsigned)__builtin_amdgcn_s_memtime();
-  unsigned t_pre[4] = {0, 0, 0, 0};
-  unsigned t_np[6] = {0, 0, 0, 0, 0, 0};
-#define PSTAMP(i) t_pre[i] = (unsigned)__builtin_amdgcn_s_memtime()
-#else
 #define PSTAMP(i) do {} while (0)
-#endif
   constexpr bool SPLIT = MM == EGT_MM_BF16X3;
   constexpr int NS = (Geo<DE>::TILES + 1) / 2;   // 16x16x32 steps over the channel axis
   (void)SPLIT; (void)NS;
@@ -1237,11 +881,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   PSTAMP(0);
   if (a.pro) {
     __syncthreads();
-#ifdef EGT_BWD_TIMING
-    bwd_node_prologue<DE>(a, sm, qd, b, l_begin, wg, t_np);
-#else
     bwd_node_prologue<DE>(a, sm, qd, b, l_begin, wg);
-#endif
   }
   PSTAMP(1);
   // weight slabs: element (t, lane, u)
@@ -1293,11 +933,6 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   __syncthreads();   // the prologue's scratch (= the tile area) is dead from here: DMA may land in it
   PSTAMP(2);
 
-#ifdef EGT_BWD_TIMING
-  unsigned tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned tlast = (unsigned)__builtin_amdgcn_s_memtime();
-  const unsigned tstart = tlast;
-#endif
   const int ntile = N / 16;
   for (int mt = wave; mt < ntile; mt += 4) {
     const int m0 = mt * 16, m = m0 + p;
@@ -1318,8 +953,6 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       for (int i = 0; i < 16; ++i) { dKa[i] = 0.f; dVa[i] = 0.f; }
     }
     const float kadd = (a.km && a.km[rowm] == 0) ? -EGT_NEG : 0.0f;
-    TSTAMP(10);
-
     for (int l = l_begin; l < l_end; ++l) {
       const int li = l - l_begin;
       const size_t rowl = (size_t)b * N + l;
@@ -1329,12 +962,10 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       // ---- de'(l): requested now, consumed after P1 ----
       TileRegs<DE> td;
       tile_gload<DE>(td, dey_in + pair0 * DE, lane, 16);
-      TSTAMP(0);
       // ---- e(l) has been in flight for a whole iteration: retire it.  Younger operations of this wave:
       // row l-1's dQ-partial store and its NI de stores, then the NI de' loads just issued ----
       if (li == 0) vm_wait<0>(); else vm_wait<2 * ((G::NF4 + 63) / 64) + 1>();
       SCHED_FENCE();
-      TSTAMP(1);
       // ---- P1: norm_edge, projections (recompute) ----
       float rstd;
       v4f acc = {c2r[0], c2r[1], c2r[2], c2r[3]};
@@ -1365,14 +996,12 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
         }
       }
       SCHED_FENCE();
-      TSTAMP(2);
       tile_lds_put<DE>(dt, td, lane, 16);   // (the compiler's own vmcnt wait for de' sits here)
       lds_sync();
       // ---- e(l+1) -> the other e buffer (its last reader, row l-1's P5, retired its LDS reads) ----
       if (l + 1 < l_end)
         tile_dma<DE>(et_lds + (unsigned)(((li + 1) & 1) * G::TILE_FLOATS * 4), e_in + (pair0 + (size_t)N) * DE, off0);
       SCHED_FENCE();
-      TSTAMP(3);
       // ---- P2: dH_ext = de'.Wr^T ----
       v4f dhx = {0.f, 0.f, 0.f, 0.f};
       if (!(a.guard & 8)) {
@@ -1396,7 +1025,6 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       }
       }
       SCHED_FENCE();
-      TSTAMP(4);
       // ---- P3: logits, softmax/gate backward, dQ/dK/dV ----
       float dge[4], hh[2], dA[2], at[2];
       {
@@ -1454,7 +1082,6 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       if (q == 0) sc2[p * 12 + 8] = 1.0f;
       lds_sync();
       SCHED_FENCE();
-      TSTAMP(5);
       if (!(a.guard & 4))
       {
         const float* qr = qd + li * QD_LD;
@@ -1475,7 +1102,6 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
         a.dqp[(((size_t)b * ntile + mt) * N + l) * 64 + lane] = reduce16_keep_own(dq, p);
       }
       SCHED_FENCE();
-      TSTAMP(6);
       // ---- P4: weight-gradient contractions over the 16 pairs of the tile ----
       if (!(a.guard & 1))
       {
@@ -1500,7 +1126,6 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       }
       lds_sync();
       SCHED_FENCE();
-      TSTAMP(7);
       // ---- P5: d(ehat) = Wp . dGE, LayerNorm backward, de = de' + ... straight to HBM ----
       if (!(a.guard & 2)) {
         float4 dxh[G::TILES];
@@ -1557,7 +1182,6 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
         lds_sync();   // the tile reads above retire before the next iteration overwrites dt / DMAs into et
       }
       SCHED_FENCE();
-      TSTAMP(8);
     }
     float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
     float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
@@ -1566,19 +1190,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
       vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
     }
-    TSTAMP(9);
   }
-#ifdef EGT_BWD_TIMING
-  if (a.dbg && lane == 0) {
-    unsigned* o = a.dbg + ((size_t)wg * 4 + wave) * 16;
-    for (int i = 0; i < 12; ++i) o[i] = tacc[i];
-    o[12] = tstart - t_entry;       // kernel entry -> loop start
-    o[14] = t_pre[0] - t_entry; o[15] = t_pre[1] - t_pre[0]; o[11] = t_pre[2] - t_pre[1];
-    for (int i = 0; i < 6; ++i) if (t_np[i] == 0) t_np[i] = i ? t_np[i - 1] : t_pre[0];   // (phases a launch did not run)
-    if (a.dbg2) { unsigned* o2 = a.dbg2 + ((size_t)wg * 4 + wave) * 8; o2[0] = t_np[0] - t_pre[0]; for (int i = 1; i < 6; ++i) o2[i] = t_np[i] - t_np[i - 1]; o2[6] = t_pre[1] - t_np[5]; }
-    o[13] = tlast - tstart;         // loop total
-  }
-#endif
 #pragma unroll
   for (int r = 0; r < 4; ++r) ssum[r] = row_sum16(ssum[r]);
   __syncthreads();
@@ -1961,61 +1573,37 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
 // ================================================================ host glue ====
 
 
-// Experiment switches (EGT_* environment variables) are read ONCE per process: the launch path
-// does no getenv().  The phase-ablation guards of the pair kernels are measurement-only and are
-// honoured only by a library built with EGT_BLOCK_FLAGS=-DEGT_BLOCK_ABLATION; a release build
-// forces them to 0 (a stray variable can then not drop gradient phases) and says so once.
+// Run-time switches (read ONCE per process: the launch path does no getenv()) -- the complete list, see README.md:
+//   EGT_NO_NARROW / EGT_NO_NARROW_FWD / EGT_NO_NARROW_BWD: De = 8 falls back from the De = 8 pair kernels (egt_narrow.hip) to the
+//     MFMA-tile kernels (tests exercise both);  EGT_BWD_MATMUL=bf16x3: the backward's channel contractions as 3-term bf16 split
+//     products (opt-in; default exact fp32);  EGT_BWD_TL: De = 8 query rows per backward workgroup (tests / sweeps).
 struct EgtBlockEnv {
-  bool no_xcd_remap, no_kvl, no_epilogue, no_fwd_r4, no_bwd_r4, bwd_v2, no_bwd_ragged, no_bwd_prologue;
-  bool no_narrow_fwd, no_narrow_bwd;   // De = 8: fall back from the De = 8 pair kernels (egt_narrow.hip) to r4 / v4r
-  int fwd_ablate, bwd_ablate, bwd_pf;
-  int bwd_v5;   // LDS-DMA staged backward (default on; EGT_BWD_V5=0 selects k_block_bwd_v4)
-  int bwd_v6;   // tile-pair backward k_block_bwd_v6 (EGT_BWD_V6=0 falls back to v5)
-  int bwd_mm;   // EGT_BWD_MATMUL=bf16x3: the backward's channel contractions as 3-term bf16 split products (opt-in; default exact fp32)
+  bool no_narrow_fwd, no_narrow_bwd;
+  int bwd_mm;
 };
 static bool env_flag_raw(const char* name) {
   const char* v = getenv(name);
   return v && v[0] && v[0] != '0';
 }
-static int env_guard_raw(const char* name) {
-  const char* v = getenv(name);
-  const int g = v ? atoi(v) : 0;
-#ifndef EGT_BLOCK_ABLATION
-  if (g) {
-    fprintf(stderr, "[egt] %s=%d ignored: phase ablation needs a build with EGT_BLOCK_FLAGS=-DEGT_BLOCK_ABLATION\n", name, g);
-    return 0;
-  }
-#else
-  if (g) fprintf(stderr, "[egt] %s = %d (ablation build: results are WRONG by design)\n", name, g);
-#endif
-  return g;
-}
 static const EgtBlockEnv& block_env() {
   static const EgtBlockEnv e = [] {
     EgtBlockEnv v{};
-    v.no_xcd_remap = env_flag_raw("EGT_NO_XCD_REMAP");
-    v.no_kvl = env_flag_raw("EGT_NO_KVL");
-    v.no_epilogue = env_flag_raw("EGT_NO_EPILOGUE");
-    v.no_fwd_r4 = env_flag_raw("EGT_NO_FWD_R4");
     v.no_narrow_fwd = env_flag_raw("EGT_NO_NARROW_FWD") || env_flag_raw("EGT_NO_NARROW");
     v.no_narrow_bwd = env_flag_raw("EGT_NO_NARROW_BWD") || env_flag_raw("EGT_NO_NARROW");
-    v.no_bwd_r4 = env_flag_raw("EGT_NO_BWD_R4");
-    v.bwd_v2 = env_flag_raw("EGT_BWD_V2");
-    v.no_bwd_ragged = env_flag_raw("EGT_NO_BWD_RAGGED");
-    v.no_bwd_prologue = env_flag_raw("EGT_NO_BWD_PROLOGUE");
-    v.fwd_ablate = env_guard_raw("EGT_FWD_ABLATE");
-    v.bwd_ablate = env_guard_raw("EGT_BWD_ABLATE");
-    const char* pf = getenv("EGT_BWD_PF");
-    v.bwd_pf = pf ? atoi(pf) : 0;
-    const char* v5 = getenv("EGT_BWD_V5");
-    v.bwd_v5 = v5 ? atoi(v5) : 1;
-    const char* v6 = getenv("EGT_BWD_V6");
-    v.bwd_v6 = v6 ? atoi(v6) : 0;
     const char* mm = getenv("EGT_BWD_MATMUL");
     v.bwd_mm = (mm && !strcmp(mm, "bf16x3")) ? EGT_MM_BF16X3 : EGT_MM_F32;
     return v;
   }();
   return e;
+}
+// compute units of the current device (dispatch decisions that depend on whether a launch fills the chip)
+int egt_device_cus() {
+  static const int n = [] {
+    int dev = 0, cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+    return cu > 0 ? cu : 256;
+  }();
+  return n;
 }
 
 static int block_check(const egt_block_desc* d, bool report) {
@@ -2049,8 +1637,7 @@ struct BlockLayout {
   int TL, NLR, nwg_bwd, EP;   // TL: query rows per backward workgroup
 };
 
-// Query rows per backward workgroup (<= 16: the MFMA tiles of the node-side prologue).  De = 8 only (k_narrow_bwd and its
-// fallbacks take any value; the wide kernels keep 16):
+// Query rows per backward workgroup (<= 16: the MFMA tiles of the node-side prologue):
 //  * equal groups: N = 150 is ten groups of 15 rather than nine of 16 and one of 6 -- same workgroup count, no short group
 //    (config 3: 225 -> 216 us per launch; N = 120: 162 -> 156 us);
 //  * a launch of at most one 16-row workgroup per CU (BASELINE config 4 as specified: B = 16, N = 120 -> 128 workgroups on
@@ -2061,11 +1648,10 @@ struct BlockLayout {
 // EGT_BWD_TL = 4 .. 16 overrides (tests, sweeps: tools/dbg/nrw_tlsweep.sh).
 static int bwd_rows_per_wg(const egt_block_desc* d) {
   static const int forced = getenv("EGT_BWD_TL") ? atoi(getenv("EGT_BWD_TL")) : 0;
-  static const bool wide_eq = !(getenv("EGT_BWD_EQ_WIDE") && atoi(getenv("EGT_BWD_EQ_WIDE")) == 0);   // A/B: equal groups for De > 8
   const int groups = (d->N + BWD_TL - 1) / BWD_TL;
-  if (d->De != 8) return wide_eq ? (d->N + groups - 1) / groups : BWD_TL;   // equal groups (16 whenever N is a multiple of 16)
+  if (d->De != 8) return (d->N + groups - 1) / groups;   // equal groups for every De (16 whenever N is a multiple of 16)
   if (forced >= 4 && forced <= BWD_TL) return forced;
-  if (d->B * groups <= 256) return d->N > 8 ? 8 : BWD_TL;
+  if (d->B * groups <= egt_device_cus()) return d->N > 8 ? 8 : BWD_TL;
   return (d->N + groups - 1) / groups;
 }
 
@@ -2115,7 +1701,7 @@ static void bind_ws(const BlockLayout& L, BlockArgs& a, float* wc, float* wl, in
   a.spart_n = a.sbo_n = a.B * ((a.N + NODE_RC - 1) / NODE_RC);   // k_node_bwd's workgroups (prologue path overrides)
   a.ered = wl + L.ered; a.dqkv_sv = wl + L.dqkv;
   a.TL = L.TL; a.NLR = L.NLR; a.NQP = 1;
-  a.xcd = block_env().no_xcd_remap ? 0 : 1;
+  a.xcd = 1;
 }
 
 extern "C" size_t egt_block_saved_bytes(const egt_block_desc* d) {
@@ -2183,76 +1769,6 @@ static void bind_common(const egt_block_desc* d, BlockArgs& a, const void* h, co
     default: { constexpr int DE = 64; CALL; } break;  \
   }
 
-#ifdef EGT_BWD_TIMING
-// measurement builds only: per-phase cycle sums of k_block_bwd_v5 (synchronises after every launch)
-static unsigned* g_bt_dev = nullptr;
-static unsigned* g_bt_dev2 = nullptr;
-static double g_bt2_sum[8];
-static int g_bt_n = 0;
-static double g_bt_sum[16];
-static long g_bt_launch = 0, g_bt_waves = 0;
-static void bwd_timing_report() {
-  static const char* nm[] = {"top+de'issue", "wait e(DMA)", "P1 LN+proj", "wait de'+put+DMA issue", "P2 dHext", "P3 softmax bwd",
-                             "dQ/dK/dV", "P4 wgrad MFMA", "P5 dehat+LNbwd+store", "dkv store", "KV load", "-", "-", "loop total"};
-  if (!g_bt_waves) return;
-  fprintf(stderr, "[egt] k_block_bwd_v5 phase cycles per wave (mean over %ld waves, %ld launches):\n", g_bt_waves, g_bt_launch);
-  for (int i = 0; i < 14; ++i)
-    if (nm[i][0] != '-') fprintf(stderr, "    %-26s %10.0f  (%.1f %%)\n", nm[i], g_bt_sum[i] / g_bt_waves, 100.0 * g_bt_sum[i] / g_bt_sum[13]);
-  fprintf(stderr, "    entry -> loop %10.0f = staging %.0f + node-side prologue %.0f + weight slabs / c2 / sync %.0f\n", g_bt_sum[12] / g_bt_waves,
-          g_bt_sum[14] / g_bt_waves, g_bt_sum[15] / g_bt_waves, g_bt_sum[11] / g_bt_waves);
-  fprintf(stderr, "    node-side prologue: sync+issue loads %.0f | first round trip %.0f | LN fwd + 48 MFMA %.0f | dQKV out + sync + LN bwd + col sums %.0f | wo/va + sync %.0f | 16 MFMA + delta partials %.0f | dbo + sync + delta %.0f\n",
-          g_bt2_sum[0] / g_bt_waves, g_bt2_sum[1] / g_bt_waves, g_bt2_sum[2] / g_bt_waves, g_bt2_sum[3] / g_bt_waves, g_bt2_sum[4] / g_bt_waves, g_bt2_sum[5] / g_bt_waves, g_bt2_sum[6] / g_bt_waves);
-}
-static void bwd_timing_attach(BlockArgs& a, int nwg) {
-  if (g_bt_n < nwg) {
-    if (g_bt_dev) (void)hipFree(g_bt_dev);
-    (void)hipMalloc(&g_bt_dev, (size_t)nwg * 64 * sizeof(unsigned));
-    (void)hipMalloc(&g_bt_dev2, (size_t)nwg * 32 * sizeof(unsigned));
-    (void)hipMemset(g_bt_dev2, 0, (size_t)nwg * 32 * sizeof(unsigned));
-    if (!g_bt_n) atexit(bwd_timing_report);
-    g_bt_n = nwg;
-  }
-  a.dbg = g_bt_dev; a.dbg_t0 = 0; a.dbg2 = g_bt_dev2;
-}
-static void bwd_timing_collect(const BlockArgs& a, int nwg, hipStream_t st) {
-  (void)hipStreamSynchronize(st);
-  static std::vector<unsigned> h;
-  h.resize((size_t)nwg * 64);
-  (void)hipMemcpy(h.data(), a.dbg, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
-  static std::vector<unsigned> h2;
-  h2.resize((size_t)nwg * 32);
-  (void)hipMemcpy(h2.data(), a.dbg2, h2.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
-  if (++g_bt_launch <= 20) return;   // warm-up launches
-  for (size_t w = 0; w < (size_t)nwg * 4; ++w) {
-    for (int i = 0; i < 16; ++i) g_bt_sum[i] += h[w * 16 + i];
-    for (int i = 0; i < 8; ++i) g_bt2_sum[i] += h2[w * 8 + i];
-    ++g_bt_waves;
-  }
-}
-#endif
-
-#ifdef EGT_FWD_TIMING
-static unsigned* g_ft_dev = nullptr;
-static int g_ft_n = 0;
-static double g_ft_sum[16];
-static long g_ft_launch = 0, g_ft_waves = 0;
-static void fwd_timing_report() {
-  static const char* nm[] = {"loop top (between tiles)", "store-out prev + LDS put + prefetch issue", "frag/KV read + LN + projections",
-                             "QK^T softmax A.V", "dense_edge_r + write-back", "row merge / stats", "(after loop)", "node epilogue"};
-  if (!g_ft_waves) return;
-  fprintf(stderr, "[egt] k_block_fwd phase cycles per wave (mean over %ld waves, %ld launches):\n", g_ft_waves, g_ft_launch);
-  for (int i = 0; i < 8; ++i) fprintf(stderr, "    %-44s %10.0f  (%.1f %%)\n", nm[i], g_ft_sum[i] / g_ft_waves, 100.0 * g_ft_sum[i] / g_ft_sum[13]);
-  fprintf(stderr, "    %-44s %10.0f\n", "total", g_ft_sum[13] / g_ft_waves);
-}
-static size_t fwd_lds_pad() { static const char* v = getenv("EGT_FWD_LDS_PAD"); return v ? (size_t)atoi(v) : 0; }
-#define FWD_TIMING_ATTACH() do { const int nwg__ = (int)grid.x; if (g_ft_n < nwg__) { if (g_ft_dev) (void)hipFree(g_ft_dev); (void)hipMalloc(&g_ft_dev, (size_t)nwg__ * 64 * sizeof(unsigned)); if (!g_ft_n) atexit(fwd_timing_report); g_ft_n = nwg__; } a.dbg = g_ft_dev; } while (0)
-#define FWD_TIMING_COLLECT() do { (void)hipStreamSynchronize(st); static std::vector<unsigned> h__; h__.resize((size_t)grid.x * 64); (void)hipMemcpy(h__.data(), a.dbg, h__.size() * 4, hipMemcpyDeviceToHost); if (++g_ft_launch > 20) for (size_t w__ = 0; w__ < (size_t)grid.x * 4; ++w__) { for (int i = 0; i < 14; ++i) g_ft_sum[i] += h__[w__ * 16 + i]; ++g_ft_waves; } } while (0)
-#else
-static size_t fwd_lds_pad() { return 0; }
-#define FWD_TIMING_ATTACH() do {} while (0)
-#define FWD_TIMING_COLLECT() do {} while (0)
-#endif
-
 // Forward of one block.  `skip_pre`: qkvp (and pw) of this block were already produced (by the
 // previous block's epilogue / k_edge_prep).  a.epi is the epilogue the caller would like; the
 // value actually used is returned (0 when the geometry is outside the epilogue's cover, in
@@ -2263,19 +1779,17 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   if (!skip_pre) egt_node_launch_pre(a, st);   // norm_mha + dense_qkv (packed) [+ edge-weight prep]
   const size_t lds_tiles = (size_t)8 * Geo<DE>::TILE_FLOATS * 4;
   const size_t lds_kv = ((size_t)a.N * KV_LD + 16 * QS_LD + a.N) * 4;
-  const bool kvl = lds_tiles + lds_kv <= 80 * 1024 - 512 && !block_env().no_kvl;   // two workgroups per CU keep their K/V in LDS
+  const bool kvl = lds_tiles + lds_kv <= 80 * 1024 - 512;   // two workgroups per CU keep their K/V in LDS
   const int epi_req = a.epi;
-  if (!(kvl && a.Dh == 64 && a.DK == 8) || block_env().no_epilogue) a.epi = 0;
+  if (!(kvl && a.Dh == 64 && a.DK == 8)) a.epi = 0;
   const bool ml = a.M != nullptr || a.rm != nullptr;
-  a.guard = block_env().fwd_ablate;
+  a.guard = 0;   // (the always-taken phase branches of the kernels only shape hipcc's scheduling regions)
   const dim3 grid(a.B * lgroups), block(256);
   const size_t lds = lds_tiles + (kvl ? lds_kv : 0);
 #define FWD_VARIANT_T(KVL_, ML_, FULL_, BF_)                                                           \
   do {                                                                                                 \
     EGT_MAX_LDS_ONCE(k_block_fwd<DE, KVL_, ML_, FULL_, BF_>);                 \
-    FWD_TIMING_ATTACH();                                                                                \
-    EGT_LAUNCH("k_block_fwd", (k_block_fwd<DE, KVL_, ML_, FULL_, BF_>), grid, block, lds + fwd_lds_pad(), st, a); \
-    FWD_TIMING_COLLECT();                                                                               \
+    EGT_LAUNCH("k_block_fwd", (k_block_fwd<DE, KVL_, ML_, FULL_, BF_>), grid, block, lds, st, a); \
   } while (0)
 #define FWD_VARIANT(KVL_, ML_, FULL_)                                                                  \
   do { if (a.bf16) FWD_VARIANT_T(KVL_, ML_, FULL_, true); else FWD_VARIANT_T(KVL_, ML_, FULL_, false); } while (0)
@@ -2289,15 +1803,15 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   if constexpr (DE == 8) {   // VALU pair kernel (egt_narrow.hip): lane = (row, head/channel pair), 4 key quarters per workgroup
     if (!ml && !block_env().no_narrow_fwd) {
       narrow = true;
-      if (!(a.Dh == 64 && a.DK == 8) || block_env().no_epilogue) a.epi = 0; else a.epi = epi_req;
+      if (!(a.Dh == 64 && a.DK == 8)) a.epi = 0; else a.epi = epi_req;
       egt_narrow_launch_fwd(a, st);
     }
   }
   if constexpr (DE <= 16) {
     if (!narrow) {   // (wider channels would not fit the four rows' state in 256 VGPRs: not instantiated)
-    narrow = !ml && (r4 || r8) && !block_env().no_kvl && !block_env().no_fwd_r4;
+    narrow = !ml && (r4 || r8);
     if (narrow) {
-    if (!(a.Dh == 64 && a.DK == 8) || block_env().no_epilogue) a.epi = 0; else a.epi = epi_req;
+    if (!(a.Dh == 64 && a.DK == 8)) a.epi = 0; else a.epi = epi_req;
 #define R4_LAUNCH_T(FULL_, NW_, BF_)                                                                              \
   do {                                                                                                            \
     EGT_MAX_LDS_ONCE(k_block_fwd_r4<DE, FULL_, NW_, BF_>); \
@@ -2332,10 +1846,9 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
   // node-side prologue inside the pair kernel (see bwd_node_prologue): v4 geometry with Dh = 64
   const bool ml = a.M != nullptr || a.rm != nullptr;
   // narrow edge channels without mask tensors run k_block_bwd_v4r, which (with the prologue) also covers ragged N
-  const bool narrow_r = DE <= 16 && !ml && !block_env().no_bwd_r4 && !block_env().bwd_v2;
-  const bool rag_ok = !block_env().no_bwd_ragged;   // v4 / v4r and the prologue take N that is not a multiple of 16
-  const bool pro = (DE % 16 == 0 || DE == 8) && ((a.N % 16) == 0 || rag_ok) && a.Dh == 64 && a.DK == 8 && !block_env().bwd_v2 &&
-                   !block_env().no_bwd_prologue;
+  const bool narrow_r = DE <= 16 && !ml;
+  static_assert(DE % 16 == 0 || DE == 8, "edge widths of the pair kernels");
+  const bool pro = a.Dh == 64 && a.DK == 8;   // (every backward kernel and the prologue take N that is not a multiple of 16)
   a.pro = 0;
   if (pro) {
     a.pro = top ? 1 : 2;
@@ -2350,28 +1863,18 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
     egt_node_launch_bwd(a, &a, false, st);  // dV_att (packed), delta, dbo sums [+ edge-weight prep]
   }
   constexpr int PW = 3 * GG::TILE_FLOATS + 256 + 192;
-  static_assert(4 * GG::EP <= 4 * PW, "edge partial staging must fit the LDS tile area");
-  const size_t lds = ((size_t)4 * PW + (size_t)4 * BWD_TL * 64 + (size_t)BWD_TL * QD_LD) * 4;
-#define BWD_VARIANT_T(ML_, FULL_, BF_)                                                                 \
-  do {                                                                                                 \
-    EGT_MAX_LDS_ONCE(k_block_bwd<DE, ML_, FULL_, BF_>);                 \
-    EGT_LAUNCH("k_block_bwd", (k_block_bwd<DE, ML_, FULL_, BF_>), dim3(L.nwg_bwd), dim3(256), lds, st, a); \
-  } while (0)
-#define BWD_VARIANT(ML_, FULL_)                                                                        \
-  do { if (a.bf16) BWD_VARIANT_T(ML_, FULL_, true); else BWD_VARIANT_T(ML_, FULL_, false); } while (0)
   const bool full = (a.N % 16) == 0;
-  if constexpr (DE % 16 == 0 || DE == 8) {
-    if ((full || rag_ok) && !block_env().bwd_v2) {   // register-lean, 2 waves/SIMD
+  {
+    {
       const size_t lds_v4 = ((size_t)(4 * PW > BWD_PRO_WS ? 4 * PW : BWD_PRO_WS) + (size_t)BWD_TL * QD_LD + 3 * ((GG::TILES + 1) / 2) * 512) * 4;   // slabs padded to whole 32-channel steps (bf16 operands)
       a.NQP = (a.N + 15) / 16;
-      a.guard = block_env().bwd_ablate;   // 0 unless this is an ablation build (measurement only: drops phases)
-#define V4_VARIANT_R(ML_, PF_, BF_, RAG_)                                                                  \
+      a.guard = 0;   // (the always-taken phase branches of the kernels only shape hipcc's scheduling regions)
+#define V4_VARIANT_R(ML_, BF_, RAG_)                                                                       \
   do {                                                                                                 \
-    EGT_MAX_LDS_ONCE(k_block_bwd_v4<DE, ML_, PF_, BF_, RAG_>);                 \
-    EGT_LAUNCH("k_block_bwd", (k_block_bwd_v4<DE, ML_, PF_, BF_, RAG_>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a); \
+    EGT_MAX_LDS_ONCE(k_block_bwd_v4<DE, ML_, BF_, RAG_>);                      \
+    EGT_LAUNCH("k_block_bwd", (k_block_bwd_v4<DE, ML_, BF_, RAG_>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a); \
   } while (0)
-#define V4_VARIANT(ML_, PF_, BF_) do { if (full) V4_VARIANT_R(ML_, PF_, BF_, false); else V4_VARIANT_R(ML_, 0, BF_, true); } while (0)
-      const int pf = block_env().bwd_pf;   // two resident waves hide the HBM latency; prefetch registers only spill
+#define V4_VARIANT(ML_, BF_) do { if (full) V4_VARIANT_R(ML_, BF_, false); else V4_VARIANT_R(ML_, BF_, true); } while (0)
       if constexpr (DE == 8) {
         // De = 8 pair kernel (egt_narrow.hip: k_narrow_bwd_m, three workgroups per CU), ragged N included.  Measured at config 3
         // against v4r / the round-2 quad-lane kernel (two waves per SIMD both): bf16 edge tensors 226 vs 314 us, fp32 243 vs 320 us
@@ -2396,48 +1899,23 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
         }
       }
       if constexpr (DE >= 32) {
-        if (full && !ml && !a.bf16 && block_env().bwd_v6 && block_env().bwd_mm == EGT_MM_F32) {   // tile-pair waves (egt_block_bwd6.hip)
-          egt_bwd6_launch(a, L.nwg_bwd, st);
-          goto pair_done;
-        }
-        if (full && !ml && !a.bf16 && block_env().bwd_v5) {   // LDS-DMA staged e tiles (k_block_bwd_v5)
+        if (full && !ml && !a.bf16) {   // LDS-DMA staged e tiles (k_block_bwd_v5)
           const bool x3 = block_env().bwd_mm == EGT_MM_BF16X3;
           EGT_MAX_LDS_ONCE(k_block_bwd_v5<DE, 0>);
           EGT_MAX_LDS_ONCE(k_block_bwd_v5<DE, EGT_MM_BF16X3>);
-#ifdef EGT_BWD_TIMING
-          bwd_timing_attach(a, L.nwg_bwd);
-#endif
-#ifdef EGT_BWD_TIMING
-          { static const char* padv = getenv("EGT_BWD_LDS_PAD");   // occupancy experiments: extra LDS bytes per workgroup
-            const size_t pad = padv ? (size_t)atoi(padv) : 0;
-            if (x3) EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE, EGT_MM_BF16X3>), dim3(L.nwg_bwd), dim3(256), lds_v4 + pad, st, a);
-            else EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE, 0>), dim3(L.nwg_bwd), dim3(256), lds_v4 + pad, st, a); }
-#else
           if (x3) EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE, EGT_MM_BF16X3>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a);
           else EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE, 0>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a);
-#endif
-#ifdef EGT_BWD_TIMING
-          bwd_timing_collect(a, L.nwg_bwd, st);
-#endif
           goto pair_done;
         }
       }
-      if (a.bf16) { if (ml) V4_VARIANT(true, 0, true); else V4_VARIANT(false, 0, true); }
-      else if (ml) V4_VARIANT(true, 0, false);
-      else if (pf == 0) V4_VARIANT(false, 0, false);
-      else if (pf == 1) V4_VARIANT(false, 1, false);
-      else V4_VARIANT(false, 2, false);
+      if (a.bf16) { if (ml) V4_VARIANT(true, true); else V4_VARIANT(false, true); }
+      else if (ml) V4_VARIANT(true, false);
+      else V4_VARIANT(false, false);
 #undef V4_VARIANT
 #undef V4_VARIANT_R
-      goto pair_done;
     }
   }
-  if (!ml && full) BWD_VARIANT(false, true);
-  else if (ml) BWD_VARIANT(true, false);
-  else BWD_VARIANT(false, false);
 pair_done:
-#undef BWD_VARIANT
-#undef BWD_VARIANT_T
   if (!pro) egt_node_launch_bwd(a, below, true, st);   // dQKV -> dh, bias/LN sums; dV_att + delta of the block below
   else if (!below) egt_node_launch_bwd(a, nullptr, true, st);   // bottom of the chain: only dQKV -> dh is left
 }

@@ -214,11 +214,7 @@ __device__ __forceinline__ void fwd_node_epilogue_idle(const BlockArgs& a) {
 // HOIST: the loads of the dV_att step (Wo columns, V_att rows) are issued with the first round of global loads instead of
 // after the dh' rows exist: one memory round trip on the kernel's critical path instead of two (costs 20 registers across
 // the first part)
-#ifdef EGT_BWD_TIMING
-#define NSTAMP(i) do { if (tp) tp[i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
-#else
 #define NSTAMP(i) do {} while (0)
-#endif
 // The prologue's global inputs live in this register set between `bwd_prologue_load` (every load of the step issued: ONE
 // memory round trip, which a kernel can overlap with its other start-up requests) and `bwd_prologue_compute`.
 struct BwdProRegs { float4 hx, gq[3], wq[12], wo[4]; float dho[4], gmm[4], va[4]; };

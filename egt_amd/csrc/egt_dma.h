@@ -1,5 +1,5 @@
 // LDS-DMA staging of 16-pair tiles (HBM -> LDS without a VGPR destination) and the transposed-element read of a swizzled
-// tile; shared by k_block_bwd_v5 (egt_block.hip) and k_block_bwd_v6 (egt_block_bwd6.hip).
+// tile (k_block_bwd_v5, egt_block.hip).
 #pragma once
 #include "egt_tile.h"
 
@@ -19,12 +19,8 @@ __device__ __forceinline__ void tile_dma(unsigned lds, const float* src, unsigne
   static_assert(Geo<DE>::NF4 % 64 == 0 && NI >= 1 && NI <= 4, "whole 1 KiB chunks");
   unsigned keep, t;
   // chunk i = rows 4i .. 4i+3: +1024 i bytes and the slot bits flipped by swz(4 i) (an XOR: chunk 0's offsets are < 1024)
-#ifdef EGT_SWZ_NEW
-  constexpr unsigned X1 = DE == 64 ? 1024u + (2u << 4) : 1024u, X2 = DE == 64 ? 2048u + (4u << 4) : 2048u, X3 = DE == 64 ? 3072u + (6u << 4) : 3072u;
-#else
   constexpr unsigned X = DE == 64 ? 1088u : 1024u;
   constexpr unsigned X1 = X, X2 = 2 * X, X3 = 3 * X;
-#endif
   if (NI == 4)
     asm volatile(
         "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
@@ -62,11 +58,7 @@ __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :
 // replace 32 per-(s,t) address registers:  floats = [64 q + 4 ((p >> 2) ^ q) + (p & 3)] + 256 s + 16 (t ^ s)
 template <int DE>
 __device__ __forceinline__ float elem_read_st(const float* lane_base, const float* tl, int p, int q, int s, int t) {
-#ifdef EGT_SWZ_NEW
-  if (DE == 64) return elem_read<DE>(tl, q + 4 * s, 16 * t + p);   // (experiment: address formed per read)
-#else
   if (DE == 64) return lane_base[256 * s + 16 * (t ^ s)];
-#endif
   return elem_read<DE>(tl, q + 4 * s, 16 * t + p);
 }
 

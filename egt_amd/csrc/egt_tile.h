@@ -6,18 +6,11 @@
 #include "egt_block.h"
 
 // XOR swizzle of the 16-byte slots of a De = 64 tile row: slot' = slot ^ swz(row).
-// EGT_SWZ_NEW (experiment, profiles/r03_mfma_valu_issue.md §8): the GF(2)-linear map row bit 0 -> 12, bit 1 -> 1, bit 2 -> 2,
-// bit 3 -> 4, found by exhaustive search over all 16^4 linear maps: conflict-free for EVERY access pattern of the pair kernels
-// (fragment b128 reads / writes by (p, q) lanes, linear b128 puts / gets, and the transposed b32 reads of the weight-gradient
-// contractions, which the identity map serves 2-way conflicted)
+// (A GF(2)-linear map that is conflict-free for every access pattern of the pair kernels was measured as a null in
+// round 3: profiles/r03_mfma_valu_issue.md section 8.)
 template <int DE>
 __device__ __forceinline__ int swz(int row) {
-#ifdef EGT_SWZ_NEW
-  if (DE == 64) return ((row & 1) ? 12 : 0) ^ ((row >> 1) & 1) ^ (((row >> 2) & 1) << 1) ^ (((row >> 3) & 1) << 2);
-  return 0;
-#else
   return DE == 64 ? (row & 15) : 0;
-#endif
 }
 
 // LDS hand-offs inside one wavefront: DS operations of a wave complete in order,

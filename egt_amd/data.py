@@ -474,24 +474,32 @@ class GraphDataset:
     def batches(self, split: str, batch_size: int, drop_remainder=False, map_fn: Optional[Callable] = None,
                 shard: Optional[Tuple[int, int]] = None, as_torch=True, device=None) -> Iterator:
         """one epoch of batches of ``split`` (get_batched_split + map + prefetch, dataset_base.py:100-130)"""
+        train = split == "training"   # training steps are collective (gradient all-reduce): every rank must take the same number
         def gen():
             cur: List[dict] = []
             for r in self.iter_records(split):
                 cur.append(r)
                 if len(cur) == batch_size:
-                    yield self._finish(cur, map_fn, shard, as_torch, device)
+                    b = self._finish(cur, map_fn, shard, as_torch, device, train)
+                    if b is not None:
+                        yield b
                     cur = []
             if cur and not drop_remainder:
-                yield self._finish(cur, map_fn, shard, as_torch, device)
+                b = self._finish(cur, map_fn, shard, as_torch, device, train)
+                if b is not None:
+                    yield b
         return _prefetch(gen(), 2) if self.prefetch_batch else gen()
 
-    def _finish(self, recs, map_fn, shard, as_torch, device):
+    def _finish(self, recs, map_fn, shard, as_torch, device, train=True):
         counts = None
         if shard is not None:
             n_global = len(recs)
-            if n_global < shard[1]:
-                return None        # fewer graphs than ranks: EVERY rank drops this (last) batch, so all take the same number of steps
+            if n_global < shard[1] and train:
+                return None        # fewer graphs than ranks: EVERY rank drops this (last) TRAINING batch, so all take the same number of steps
             lo, hi = shard_batch(n_global, shard[1], shard[0])
+            if hi == lo:
+                return None        # validation / test: the reference evaluates every graph; a rank without a share of a short last batch
+                                   # skips it and contributes zero sums and counts to the one all-reduce at the end of the split
             recs = recs[lo:hi]
             counts = (hi - lo, n_global)
         b = self.collate(recs)

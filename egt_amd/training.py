@@ -529,7 +529,9 @@ class ZincSVDScheme:
         """(loss, metric sums) of one batch: scheme-specific"""
         nf, fm, adj, tgt = self._batch(batch)
         y = self.model(nf, fm, adj, **self._pe(batch))
-        return self.loss_fn(y, tgt), dict(mae=((y - tgt).abs().sum().detach(), tgt.numel()))
+        loss = self.loss_fn(y, tgt)
+        sabs = (y - tgt).abs().sum().detach()
+        return loss, dict(mae=(sabs, tgt.numel()), loss=(sabs, tgt.numel()))      # (the MAE loss IS the mae metric)
 
     def _graphed_loss(self, batch):
         """config.use_hipgraph: forward + loss + backward of a training batch as ONE hipGraph launch.  A graph is captured
@@ -602,12 +604,17 @@ class ZincSVDScheme:
             for k, (sm, cnt) in ms.items():
                 a = acc.setdefault(k, [0.0, 0.0]); a[0] += float(sm); a[1] += float(cnt)
         if self.config.distributed and _dist_on():    # the split is sharded: sums and counts of all ranks
-            keys = sorted(self.get_metrics()) if not acc else sorted(acc)
+            keys = self.metric_keys()                 # a fixed list per scheme: a rank without batches sends zeros of the same shape
             t = torch.tensor([x for k in keys for x in acc.get(k, [0.0, 0.0])], dtype=torch.float64,
                              device=self.device if torch.distributed.get_backend() == "nccl" else "cpu")
             torch.distributed.all_reduce(t)
             acc = {k: [float(t[2 * i]), float(t[2 * i + 1])] for i, k in enumerate(keys)}
         return {k: v[0] / max(v[1], 1e-30) for k, v in acc.items()}
+
+    LOSS_METRIC = "mae"      # the metric that IS the training loss of the scheme (None: none of them)
+
+    def metric_keys(self):
+        return sorted(set(self.get_metrics()) | {"loss"})
 
     def train_model(self):                           # model.fit (:293-302) with the callbacks' behaviour inlined
         c = self.config
@@ -621,12 +628,18 @@ class ZincSVDScheme:
                 losses.append(self.train_step(b))
                 if self.stop_training:
                     break
-            logs = dict(loss=float(np.mean(losses)) if losses else math.nan)
-            logs[self.get_metrics()[0]] = logs["loss"]   # the loss IS the first metric of these schemes (MAE / weighted x-ent)
+            loss_mean = float(np.mean(losses)) if losses else math.nan
+            if c.distributed and _dist_on():         # the logged training loss is the mean over all ranks (a rank-local value would let a train-metric monitor desynchronise them)
+                t = torch.tensor([loss_mean if losses else 0.0, 1.0 if losses else 0.0], dtype=torch.float64,
+                                 device=self.device if torch.distributed.get_backend() == "nccl" else "cpu")
+                torch.distributed.all_reduce(t)
+                loss_mean = float(t[0] / t[1]) if float(t[1]) > 0 else math.nan
+            logs = dict(loss=loss_mean)
+            if self.LOSS_METRIC is not None:
+                logs[self.LOSS_METRIC] = logs["loss"]
             if self.valset is not None:
                 v = self.evaluate(self.valset, c.validation_steps)
-                logs["val_loss"] = v[self.get_metrics()[0]]
-                logs.update({"val_" + k: x for k, x in v.items()})
+                logs.update({"val_" + k: x for k, x in v.items()})   # batch_loss always reports 'loss': val_loss is the validation LOSS
             # epoch-end order of the reference's callback list: training callbacks (SaveWhen) first, then the
             # checkpoint callback, whose on_epoch_end runs the state updates and saves (:249-256, checkpoint.py:66-83)
             scope = dict(logs); scope["epoch"] = epoch + 1; scope.update(self.state.items())
@@ -724,6 +737,8 @@ class PatternSVDScheme(ZincSVDScheme):
         from .model import weighted_sparse_xent_loss
         return weighted_sparse_xent_loss
 
+    LOSS_METRIC = "xent"
+
     def get_metrics(self):
         return ["xent", "acc"]
 
@@ -743,7 +758,7 @@ class PatternSVDScheme(ZincSVDScheme):
         # Keras feeds the mask as sample_weight: the metrics are means over the REAL nodes (losses.py:108-118)
         logp = torch.log_softmax(logits.detach(), -1).gather(-1, tgt.clamp(min=0).long()[..., None])[..., 0]
         xs = (-(logp) * w[tgt.clamp(min=0).long()] * m).sum()
-        return loss, dict(xent=(xs, m.sum()), acc=(hit, m.sum()))
+        return loss, dict(xent=(xs, m.sum()), acc=(hit, m.sum()), loss=(loss.detach() * m.sum(), m.sum()))
 
 
     @torch.no_grad()
@@ -759,7 +774,8 @@ class PatternSVDScheme(ZincSVDScheme):
             keep = (nf >= 0).reshape(-1).cpu().numpy()                                   # collate_fn: node_features >= 0
             targs.append(b["target"].reshape(-1).cpu().numpy()[keep])
             preds.append(torch.softmax(logits, -1)[..., 1].reshape(-1).cpu().numpy()[keep])
-        targs, preds = np.concatenate(targs), np.concatenate(preds)
+        targs = np.concatenate(targs) if targs else np.zeros(0, dtype=np.int64)   # (a rank without a share of a tiny split)
+        preds = np.concatenate(preds) if preds else np.zeros(0, dtype=np.float32)
         if self.config.distributed and _dist_on():   # the split is sharded: gather every rank's nodes (strategy ... concat, :62-78)
             box = [None] * torch.distributed.get_world_size()
             torch.distributed.all_gather_object(box, (targs, preds))
@@ -805,9 +821,11 @@ class PatternEigScheme(PatternSVDScheme):
     def get_metrics(self):
         return ["acc"]
 
+    LOSS_METRIC = None       # its only metric is the accuracy
+
     def batch_loss(self, batch):
         loss, ms = super().batch_loss(batch)
-        return loss, dict(acc=ms["acc"], loss=(loss.detach() * ms["acc"][1], ms["acc"][1]))
+        return loss, dict(acc=ms["acc"], loss=ms["loss"])
 
 
 class SyntheticPattern:
@@ -854,6 +872,8 @@ class Cifar10SVDScheme(ZincSVDScheme):
         from .model import sparse_xent_loss
         return sparse_xent_loss
 
+    LOSS_METRIC = "xent"
+
     def get_metrics(self):
         return ["xent", "acc"]     # (the reference lists ['acc', xent]; the loss is the x-ent)
 
@@ -862,7 +882,7 @@ class Cifar10SVDScheme(ZincSVDScheme):
         logits = self.model(nf, fm, adj, **self._pe(batch))
         loss = self.loss_fn(logits, tgt)
         n = tgt.numel()
-        return loss, dict(xent=(loss.detach() * n, n), acc=((logits.argmax(-1) == tgt).sum().detach(), n))
+        return loss, dict(xent=(loss.detach() * n, n), acc=((logits.argmax(-1) == tgt).sum().detach(), n), loss=(loss.detach() * n, n))
 
 
     def do_evaluations_on_split(self, split):        # schemes/cifar10/svd.py:45-53

@@ -6,6 +6,8 @@ import pytest
 import torch
 
 import cases as CS
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from util import assert_close, load_golden, FWD, BWD
 
 pytestmark = pytest.mark.gpu
@@ -227,6 +229,66 @@ def test_fused_accepts_unaligned_parameter_views(gpu, egt_lib):
         outs.append((h2.detach(), e2.detach(), hh.grad, ee.grad, blk.dense_qkv.kernel.grad, blk.dense_edge_r.bias.grad))
     for n, u, v in zip(("h", "e", "dh", "de", "dWqkv", "dbr"), *outs):
         assert_close(u, v, name=n, rtol=1e-3, arel=2e-4, l2=2e-3)
+
+
+def test_config3_as_specified_bf16_depth4_margins(gpu, egt_lib, capsys):
+    """BASELINE config 3 AS SPECIFIED: CIFAR10 shapes N = 150, Dh = 64, De = 8, H = 8, Ly = 4, bf16 edge tensors (the dtype is
+    BASELINE.json's request for this config -- the reference itself is fp32 everywhere), training mode with the in-kernel random
+    mask, node counts in [85, 150].  Forward and every gradient against the fp64 oracle fed the same bf16-rounded inputs, and
+    the worst error / tolerance of every output is PRINTED and written to gpurun_out/bf16_margins.json: the bf16-operand MFMAs
+    of the gradient path (egt_narrow.hip) sit inside SURVEY 8(c)'s bf16 tolerance with the margin on record."""
+    import json
+    from egt_amd import EGTStack
+    from egt_amd.fused import layer_seed
+    from oracle import egt_oracle as O, rng_ref
+    from util import margin
+    B, N, De, Dh, Ly, p = 2, 150, 8, 64, 4, 0.1
+    torch.manual_seed(31)
+    st = EGTStack(model_height=Ly, model_width=Dh, edge_width=De, num_heads=8, random_mask_prob=p, seed=5, fused=True).to(gpu).train()
+    with torch.no_grad():
+        for prm in st.parameters():
+            if prm.dim() == 1:
+                prm.add_(0.2 * torch.randn_like(prm))
+    g = torch.Generator().manual_seed(150 * 4)
+    h = torch.randn(B, N, Dh, generator=g)
+    e = (torch.randn(B, N, N, De, generator=g) * 1.3).bfloat16()
+    mask = torch.ones(B, N, dtype=torch.bool); mask[0, 85:] = False; mask[1, 131:] = False
+    dh = torch.randn(B, N, Dh, generator=g); de = torch.randn(B, N, N, De, generator=g).bfloat16()
+    hg = h.to(gpu).requires_grad_(); eg = e.to(gpu).requires_grad_()
+    h2, e2 = st(hg, eg, mask.to(gpu))
+    assert st.last_path == "fused-stack" and e2.dtype == torch.bfloat16
+    torch.autograd.backward([h2, e2], [dh.to(gpu), de.to(gpu)])
+    layers = [{k: getattr(getattr(blk, m), a_).detach().double().cpu().requires_grad_()
+               for k, (m, a_) in PMAP.items()} for blk in st.blocks]
+    b0 = st.blocks[0].mha
+    seed = (b0.seed * 0x9E3779B97F4A7C15 + b0._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    rms = [torch.from_numpy(rng_ref.random_mask(layer_seed(seed, l), B, N, 8, p)) for l in range(Ly)]
+    h64 = h.double().requires_grad_(); e64 = e.double().requires_grad_()
+    ho, eo = O.stack_forward(h64, e64, mask, layers, num_heads=8, rand_masks=rms)
+    flat = [t for lp in layers for t in lp.values()]
+    gr = torch.autograd.grad([ho, eo], [h64, e64] + flat, [dh.double(), de.double()])
+    tol = dict(rtol=2e-2, arel=1e-2)       # SURVEY 8(c): bf16 rtol 2e-2
+    ptol = dict(rtol=3e-2, arel=2e-2)
+    margins = {"h_out": margin(h2, ho, **tol), "e_out": margin(e2.float(), eo, **tol),
+               "dh": margin(hg.grad, gr[0], **tol), "de": margin(eg.grad.float(), gr[1], **tol)}
+    gi = iter(gr[2:])
+    for li, blk in enumerate(st.blocks):
+        for k, (m, a_) in PMAP.items():
+            margins[f"L{li}.{k}"] = margin(getattr(getattr(blk, m), a_).grad, next(gi), **ptol)
+    worst = max(margins, key=margins.get)
+    with capsys.disabled():
+        print("\n[bf16 margins, config 3 as specified, Ly = 4] worst error / tolerance: "
+              + ", ".join(f"{k} {v:.2f}" for k, v in margins.items() if not k.startswith("L"))
+              + f"; parameter gradients: worst {worst} {margins[worst]:.2f}")
+    try:
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        json.dump(dict(config="cifar10_n150 as specified: B=2, N=150, Dh=64, De=8, H=8, Ly=4, bf16 edge tensors, random_mask_prob 0.1",
+                       tolerance=dict(outputs=tol, parameter_gradients=ptol), worst_error_over_tolerance=margins),
+                  open(os.path.join(REPO, "gpurun_out", "bf16_margins.json"), "w"), indent=1)
+    except OSError:
+        pass
+    assert margins[worst] < 1.0, (worst, margins[worst])
+    assert max(margins[k] for k in ("h_out", "e_out", "dh", "de")) < 1.0, margins
 
 
 @pytest.mark.parametrize("N,De,Dh,train,Ly", [(32, 64, 64, True, 3), (20, 8, 64, False, 2), (37, 48, 48, True, 2),

@@ -194,6 +194,21 @@ def test_dp_shards_partition_every_global_batch(tmp_path):
             assert p.shape[1] == (p != -1).sum(1).max()
 
 
+def test_short_last_batch_under_dp_drops_only_for_training(tmp_path):
+    """A last global batch with fewer graphs than ranks: the TRAINING split drops it on every rank (all ranks take the same
+    number of collective steps); validation keeps it -- the ranks that get a share evaluate their graphs, the others skip the
+    batch (the reference evaluates every graph; the metric sums are all-reduced once at the end of the split)."""
+    path = _store(tmp_path, n_train=22, n_val=12)           # batches of 10 over 4 ranks: training 10 + 10 + 2, validation 10 + 2
+    tr, va = [], []
+    for rank in range(4):
+        ds = D.dataset_for_scheme("zinc.svd", path, seed=3, prefetch_batch=False)
+        t, v = ds.get_batched_data(10, shard=(rank, 4), as_torch=False)[:2]
+        tr.append(list(t)); va.append(list(v))
+    assert [len(o) for o in tr] == [2, 2, 2, 2]                                  # the 2-graph training batch is gone everywhere
+    assert sorted(len(o) for o in va) == [1, 1, 2, 2]                           # two ranks hold one graph of the short validation batch
+    assert sum(len(b["target"]) for o in va for b in o) == 12                    # every validation graph is evaluated exactly once
+
+
 def test_pattern_and_cifar_formats(tmp_path):
     def pattern(n, rng):
         recs = []

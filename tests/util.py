@@ -47,6 +47,15 @@ def assert_close(actual, ref, *, rtol, arel, name="", floor=0.0, l2=None, zero_a
             assert rel <= l2, f"{name}: normalised L2 error {rel:.3e} > {l2:.1e} (max|ref| {scale:.3e})"
 
 
+def margin(actual, ref, *, rtol, arel, floor=0.0):
+    """worst |error| / tolerance over the tensor (the same tolerance model as assert_close): < 1 passes; how close to 1 is
+    the distance to the bound."""
+    a = actual.detach().double().cpu(); r = ref.detach().double().cpu()
+    scale = float(r.abs().max())
+    tol = arel * max(scale, floor) + rtol * r.abs()
+    return float(((a - r).abs() / tol.clamp_min(1e-300)).max())
+
+
 def load_golden(path):
     z = np.load(path)
     tree = {}

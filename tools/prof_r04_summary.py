@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 databases of tools/profile_r04.sh into the committed summaries:
+    python tools/prof_r04_summary.py gpurun_out/<tag> r04_<tag>
+writes profiles/<name>_rocprof_summary.md, profiles/<name>_bench_<workload>.json and refreshes
+profiles/pmc_traffic.json (HBM bytes per launch of the pair kernels) and profiles/pmc_mfma.json (HBM bytes, matrix-pipe
+busy fraction and issue fraction per launch of the dominant kernels).  Corrections as /opt/skills/guides/MI355X_MICROARCH.md
+prescribes: FETCH_SIZE / WRITE_SIZE are KB, and on gfx950 FETCH_SIZE reports half of a wide coalesced read, so fetch
+bytes are doubled.  SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs; SQ_BUSY_CU_CYCLES / SQ_WAVE_CYCLES count
+quad-cycles."""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIMDS = 1024
+# measured issue costs (tools/micro/mfma_stream.hip, valu_rates.hip): cycles a SIMD is occupied per instruction
+MFMA_CYC, VALU_CYC = 32.0, 2.5
+KEYS = {"zinc500k_n64": ["k_block_bwd", "k_block_fwd"], "synthetic_n512": ["k_attn_mfma_bwd_kv", "k_attn_mfma_fwd", "k_attn_mfma_bwd_q", "k_attn_pack"]}
+
+
+def db_of(d):
+    f = sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True))
+    return sqlite3.connect(f[0]) if f else None
+
+
+def key_of(kn, wl):
+    for k in KEYS[wl]:
+        if k in kn:
+            return k
+    return None
+
+
+def counters(src, sub, wl):
+    """{key: {counter: (launches, avg value, avg duration ns)}}"""
+    db = db_of(os.path.join(src, sub))
+    out = {}
+    if not db:
+        return out
+    for kn, cn, c, v, d in db.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
+                                      "group by kernel_name, counter_name").fetchall():
+        k = key_of(kn, wl)
+        if k:
+            out.setdefault(k, {})[cn] = (c, v, d)
+    return out
+
+
+def main():
+    src, name = sys.argv[1], sys.argv[2]
+    out = [f"# {name} — MI355X, measured by tools/profile_r04.sh\n"]
+    traffic_all, mfma_all = {}, {}
+    for wl in KEYS:
+        out.append(f"\n# workload `{wl}`\n")
+        try:
+            bench = json.loads(open(os.path.join(src, f"bench_{wl}.json")).read().strip().splitlines()[-1])
+            out.append(f"## `python bench.py --workload {wl}`\n\n```json\n" + json.dumps(bench, indent=1) + "\n```\n")
+            json.dump(bench, open(os.path.join(REPO, "profiles", f"{name}_bench_{wl}.json"), "w"))
+        except Exception as e:  # noqa: BLE001
+            out.append(f"(bench_{wl}.json unreadable: {e})\n")
+        db = db_of(os.path.join(src, f"kt_{wl}"))
+        if db:
+            out.append(f"## rocprofv3 --kernel-trace --stats -- python bench.py --workload {wl} --steps 10 --warmup 3 --no-cpu-baseline --no-prof --no-graph-leg\n")
+            out.append("| kernel | calls | total_us | avg_us | % |\n|---|---|---|---|---|")
+            rows = db.execute("select name, count(*), sum(duration), avg(duration) from kernels group by name order by 3 desc").fetchall()
+            tot = sum(r[2] for r in rows)
+            for n, c, s, a in rows[:14]:
+                out.append(f"| {n[:100]} | {c} | {s / 1e3:.1f} | {a / 1e3:.2f} | {100 * s / tot:.2f} |")
+            out.append("")
+        out.append("## rocprofv3 --pmc <counters> --kernel-trace (separate passes), per-launch averages\n")
+        out.append("| kernel | counter | launches | avg value | avg duration (ns) |\n|---|---|---|---|---|")
+        allc = {}
+        for sub in (f"pmc_fetch_{wl}", f"pmc_write_{wl}", f"pmc_sq_{wl}", f"pmc_inst_{wl}"):
+            for k, cs in counters(src, sub, wl).items():
+                for cn, (c, v, d) in sorted(cs.items()):
+                    out.append(f"| {k} | {cn} | {c} | {v:.5g} | {d:.0f} |")
+                    allc.setdefault(k, {})[cn] = (c, v, d)
+        out.append("")
+        for k, cs in allc.items():
+            rec = {}
+            if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+                rec["hbm_bytes_per_launch"] = int(round((2 * cs["FETCH_SIZE"][1] + cs["WRITE_SIZE"][1]) * 1024))
+                out.append(f"- `{k}`: HBM traffic per launch = 2 x {cs['FETCH_SIZE'][1]:.5g} KB + {cs['WRITE_SIZE'][1]:.5g} KB = {rec['hbm_bytes_per_launch'] / 1e6:.1f} MB")
+                traffic_all.setdefault(wl, {})[k] = rec["hbm_bytes_per_launch"]
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "GRBM_GUI_ACTIVE" in cs and cs["GRBM_GUI_ACTIVE"][1] > 0:
+                simd_cycles = SIMDS * cs["GRBM_GUI_ACTIVE"][1]
+                rec["mfma_busy"] = cs["SQ_VALU_MFMA_BUSY_CYCLES"][1] / simd_cycles
+                rec["clock_ghz"] = cs["GRBM_GUI_ACTIVE"][1] / cs["GRBM_GUI_ACTIVE"][2]
+                out.append(f"- `{k}`: matrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES {cs['SQ_VALU_MFMA_BUSY_CYCLES'][1]:.4g} / ({SIMDS} SIMDs x GRBM_GUI_ACTIVE "
+                           f"{cs['GRBM_GUI_ACTIVE'][1]:.4g}) = **{rec['mfma_busy']:.3f}** (clock {rec['clock_ghz']:.2f} GHz over the launch)")
+                if "SQ_WAIT_ANY" in cs and "SQ_WAVE_CYCLES" in cs and cs["SQ_WAVE_CYCLES"][1] > 0:
+                    rec["wait_any"] = cs["SQ_WAIT_ANY"][1] / cs["SQ_WAVE_CYCLES"][1]
+                    rec["wait_inst_any"] = cs.get("SQ_WAIT_INST_ANY", (0, 0, 0))[1] / cs["SQ_WAVE_CYCLES"][1]
+                    out.append(f"- `{k}`: SQ_WAIT_ANY / SQ_WAVE_CYCLES = {rec['wait_any']:.2f}, SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = {rec['wait_inst_any']:.2f}")
+            if "SQ_INSTS_VALU" in cs and "SQ_INSTS_MFMA" in cs and "GRBM_GUI_ACTIVE" in allc.get(k, {}):
+                g = allc[k]["GRBM_GUI_ACTIVE"]
+                cyc = cs["SQ_INSTS_MFMA"][1] * MFMA_CYC + (cs["SQ_INSTS_VALU"][1] - cs["SQ_INSTS_MFMA"][1]) * VALU_CYC
+                # the instruction pass runs at its own duration: scale the active cycles by the duration ratio
+                act = g[1] * (cs["SQ_INSTS_VALU"][2] / g[2]) if g[2] else g[1]
+                rec["issue"] = dict(mfma_insts=cs["SQ_INSTS_MFMA"][1], valu_insts=cs["SQ_INSTS_VALU"][1] - cs["SQ_INSTS_MFMA"][1],
+                                    mfma_cycles=cs["SQ_INSTS_MFMA"][1] * MFMA_CYC, valu_cycles=(cs["SQ_INSTS_VALU"][1] - cs["SQ_INSTS_MFMA"][1]) * VALU_CYC,
+                                    simd_cycles=SIMDS * act, frac=cyc / (SIMDS * act))
+                out.append(f"- `{k}`: issue fraction = (MFMA {cs['SQ_INSTS_MFMA'][1]:.4g} x {MFMA_CYC:.0f} + other VALU {cs['SQ_INSTS_VALU'][1] - cs['SQ_INSTS_MFMA'][1]:.4g} x {VALU_CYC}) "
+                           f"/ ({SIMDS} SIMDs x {act:.4g} cycles) = **{rec['issue']['frac']:.3f}**  (SQ_INSTS_VALU counts the MFMAs too)")
+            if rec:
+                mfma_all.setdefault(wl, {})[k] = rec
+        out.append("")
+    out.append("Reading the counters (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 "
+               "FETCH_SIZE reports half of the bytes of a wide coalesced streaming read, so it is doubled.\n")
+    ptf = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    try:
+        pt = json.load(open(ptf))
+    except Exception:  # noqa: BLE001
+        pt = {}
+    if "zinc500k_n64" in traffic_all:
+        pt["zinc500k_n64"] = {k: v for k, v in traffic_all["zinc500k_n64"].items()}
+        pt["_source_zinc500k_n64"] = f"profiles/{name}_rocprof_summary.md"
+        json.dump(pt, open(ptf, "w"), indent=1)
+    if mfma_all:
+        mfma_all["_source"] = (f"profiles/{name}_rocprof_summary.md (rocprofv3 --pmc, separate passes: FETCH_SIZE; WRITE_SIZE; SQ_* + GRBM_GUI_ACTIVE; SQ_INSTS_*): "
+                               "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE); "
+                               f"issue.frac = (MFMAs x {MFMA_CYC:.0f} + other VALU x {VALU_CYC}) / (1024 x active cycles)")
+        json.dump(mfma_all, open(os.path.join(REPO, "profiles", "pmc_mfma.json"), "w"), indent=1)
+    for wl in ("cifar10_n150", "pattern500k_n120_b128", "zinc100k_n37", "pattern500k_n120", "synthetic_n512_b32"):
+        try:
+            line = open(os.path.join(src, f"bench_{wl}.json")).read().strip().splitlines()[-1]
+            out.append(f"\n`python bench.py --workload {wl} --no-cpu-baseline`:\n\n```json\n{line}\n```\n")
+            json.dump(json.loads(line), open(os.path.join(REPO, "profiles", f"{name}_bench_{wl}.json"), "w"))
+        except Exception:  # noqa: BLE001
+            pass
+    try:
+        out.append("\n`python tools/bench_block_cfg5.py`:\n\n```json\n" + open(os.path.join(src, "block_cfg5.json")).read().strip().splitlines()[-1] + "\n```\n")
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        log = open(os.path.join(src, "pytest_gpu.log")).read().strip().splitlines()
+        open(os.path.join(REPO, "profiles", f"{name}_pytest_gpu.log"), "w").write("\n".join(log[-12:]) + "\n")
+        out.append("\n## pytest -m gpu\n\n```\n" + "\n".join(log[-4:]) + "\n```\n")
+    except Exception:  # noqa: BLE001
+        pass
+    open(os.path.join(REPO, "profiles", f"{name}_rocprof_summary.md"), "w").write("\n".join(out) + "\n")
+    print("\n".join(out[-40:]))
+
+
+if __name__ == "__main__":
+    main()
