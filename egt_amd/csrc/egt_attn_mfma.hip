@@ -103,87 +103,106 @@ __device__ __forceinline__ float pair_sum_q(float v) { return sum_xor32(sum_xor1
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // ------------------------------------------------------------------- pack --------
-// workgroup = (graph, 16 node rows, ONE section of [q | k | v | dO]): the rows' channels go through an LDS
-// tile and leave head-major.  Channel index of the source: c = s*d*H + k*H + h (egt_layers.py:70-76).
+// workgroup = (graph, 16 node rows), 512 threads: every section of the launch ([q | k | v | dO]) is de-interleaved
+// through LDS and leaves head-major.  Channel index of the source: c = s*d*H + k*H + h (egt_layers.py:70-76).
+// A thread loads 16 bytes = 4 heads of one channel k of one row and scatters them into head planes [h][row][k]
+// (row stride D + 16, plane stride = 16 rows + 4: the 4 x ds_write_b32 and the 16-byte row reads are bank-conflict
+// free); the next section's loads are in flight while the current one is written out (one launch = one wave of
+// workgroups and, per section, one overlapped HBM round trip: the one-section-per-workgroup kernel took 18 us).
 template <int D>
-__global__ void __launch_bounds__(256) k_attn_pack(AttnMfmaArgs a) {
-  constexpr int DH = D * AH, LD = DH + 4;
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // [16][LD]
+__global__ void __launch_bounds__(512) k_attn_pack(AttnMfmaArgs a) {
+  constexpr int DH = D * AH, RS = D == 16 ? 16 : 80, RP = 16 * RS + 4, NPC = 16 * DH / 4 / 512;   // pieces per thread and section
+  static_assert((16 * DH / 4) % 512 == 0, "whole pieces per thread");
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [8 heads][RP]
   const int N = a.N, NP = a.NP, tid = threadIdx.x;
   const int tiles = NP / 16;
-  // sections present in this launch, in order q, k, v, dO
-  int secs[4], nsec = 0;
+  const int b = blockIdx.x / tiles, n0 = (blockIdx.x % tiles) * 16;
+  int secs[4], nsec = 0;   // sections of this launch, in order q, k, v, dO
   if (a.pack_what & PACK_Q) secs[nsec++] = 0;
   if (a.pack_what & (PACK_KH | PACK_KT)) secs[nsec++] = 1;
   if (a.pack_what & (PACK_VT | PACK_VH)) secs[nsec++] = 2;
   if (a.pack_what & PACK_O) secs[nsec++] = 3;
-  const int sec = secs[blockIdx.x % nsec];
-  const int tile = blockIdx.x / nsec;
-  const int b = tile / tiles, n0 = (tile % tiles) * 16;
-  const float mul = sec == 0 ? a.scale : 1.0f;   // Q leaves pre-scaled: S = (d^-1/2 Q).K^T, dK = dA^T.(d^-1/2 Q)
-  for (int i = tid; i < 16 * (DH / 4); i += 256) {
-    const int r = i / (DH / 4), c = (i % (DH / 4)) * 4;
-    const int n = n0 + r;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < N)
-      v = sec < 3 ? *reinterpret_cast<const float4*>(a.qkv + ((size_t)b * N + n) * 3 * DH + sec * DH + c)
-                  : *reinterpret_cast<const float4*>(a.d_v_att + ((size_t)b * N + n) * DH + c);
-    v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
-    *reinterpret_cast<float4*>(sm + r * LD + c) = v;
-  }
-  __syncthreads();
   const size_t arr = (size_t)a.B * AH * NP * D;
-  // the staged rows -> [b,h,n/16,k/16,16 nodes,16 channels] array `which`: a wave's operand fetch (16 nodes x
-  // 16 channels of one k-tile) is ONE contiguous 1 KB block
-  auto put_rows = [&](int which) {
-    float* dst = a.pk + (size_t)which * arr;
-    for (int i = tid; i < AH * 16 * (D / 4); i += 256) {
-      const int k4 = ((i >> 6) % (D / 16)) * 4 + (i & 3), r = (i >> 2) & 15, h = i / (4 * D);
-      const float* src = sm + r * LD + (k4 * 4) * AH + h;
-      *reinterpret_cast<float4*>(dst + ((size_t)b * AH + h) * NP * D + (size_t)n0 * D + (k4 >> 2) * 256 + r * 16 + (k4 & 3) * 4) =
-          make_float4(src[0], src[AH], src[2 * AH], src[3 * AH]);
+  auto load = [&](int sec, float4 (&v)[NPC]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int p = tid + 512 * i, r = p / (DH / 4), c = (p % (DH / 4)) * 4, n = n0 + r;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N)
+        v[i] = sec < 3 ? *reinterpret_cast<const float4*>(a.qkv + ((size_t)b * N + n) * 3 * DH + sec * DH + c)
+                       : *reinterpret_cast<const float4*>(a.d_v_att + ((size_t)b * N + n) * DH + c);
     }
   };
-  // ... -> transposed, tile-major [b,h,n/16,k,16] array: the 16 nodes of a tile are contiguous per channel and a
+  auto scatter = [&](const float4 (&v)[NPC], float mul) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int p = tid + 512 * i, r = p / (DH / 4), c4 = p % (DH / 4), k = c4 >> 1, h0 = 4 * (c4 & 1);
+      float* o = sm + h0 * RP + r * RS + k;
+      o[0] = v[i].x * mul; o[RP] = v[i].y * mul; o[2 * RP] = v[i].z * mul; o[3 * RP] = v[i].w * mul;
+    }
+  };
+  // planes -> [b,h,n/16,k/16,16 nodes,16 channels] array `which`: a wave's operand fetch (16 nodes x 16 channels of
+  // one k-tile) is ONE contiguous 1 KB block; lanes walk the 16-byte chunks of a block in order
+  auto put_rows = [&](int which) __attribute__((always_inline)) {
+    float* dst = a.pk + (size_t)which * arr;
+    for (int i = tid; i < AH * 16 * (D / 4); i += 512) {
+      const int j = i & 3, r = (i >> 2) & 15, T = (i >> 6) % (D / 16), h = i / (4 * D);
+      *reinterpret_cast<float4*>(dst + ((size_t)b * AH + h) * NP * D + (size_t)n0 * D + T * 256 + r * 16 + j * 4) =
+          *reinterpret_cast<const float4*>(sm + h * RP + r * RS + 16 * T + 4 * j);
+    }
+  };
+  // planes -> transposed, tile-major [b,h,n/16,k,16] array: the 16 nodes of a tile are contiguous per channel and a
   // tile is one 64*D-byte block
-  auto put_cols = [&](int which) {
+  auto put_cols = [&](int which) __attribute__((always_inline)) {
     float* dst = a.pk + (size_t)which * arr;
-    for (int i = tid; i < AH * D * 4; i += 256) {
+    for (int i = tid; i < AH * D * 4; i += 512) {
       const int r4 = i & 3, k = (i >> 2) % D, h = i / (4 * D);
-      const float* src = sm + (r4 * 4) * LD + k * AH + h;
+      const float* src = sm + h * RP + (r4 * 4) * RS + k;
       *reinterpret_cast<float4*>(dst + ((size_t)b * AH + h) * D * NP + (size_t)n0 * D + k * 16 + r4 * 4) =
-          make_float4(src[0], src[LD], src[2 * LD], src[3 * LD]);
+          make_float4(src[0], src[RS], src[2 * RS], src[3 * RS]);
     }
   };
-  if (sec == 0) put_rows(PK_QH);
-  else if (sec == 1) {
-    if (a.pack_what & PACK_KH) put_rows(PK_KH);
-    if (a.pack_what & PACK_KT) put_cols(PK_KT);
-  } else if (sec == 2) {
-    if (a.pack_what & PACK_VT) put_cols(PK_VT);
-    if (a.pack_what & PACK_VH) put_rows(PK_VH);
-  } else {
-    put_rows(PK_OH);
-    // per-row constants of the backward, head-major [b,h,n,4] = (m, 1/l, delta, 0) with
-    // delta[row,h] = sum_k dO[row,k,h] * O[row,k,h] (flash-style); rows past N get 1/l = 0 (their probabilities vanish)
-    const int r = tid >> 4, hh = (tid >> 1) & 7, half = tid & 1, n = n0 + r;
-    float sdel = 0.f;
-    if (n < N) {
-      const float* vo = a.v_att_in + ((size_t)b * N + n) * DH + hh;
-      const float* dr = sm + r * LD + hh;
-#pragma unroll 8
-      for (int k = half * (D / 2); k < (half + 1) * (D / 2); ++k) sdel = fmaf(dr[k * AH], vo[k * AH], sdel);
-    }
-    sdel += __shfl_xor(sdel, 1, 64);
-    if (half == 0) {
-      float4 s2 = make_float4(3.0e38f, 0.f, 0.f, 0.f);   // rows past N: exp2(-inf) * 0
+  float4 cur[NPC], nxt[NPC];
+  load(secs[0], cur);
+  for (int si = 0; si < nsec; ++si) {
+    const int sec = secs[si];
+    if (si + 1 < nsec) load(secs[si + 1], nxt);
+    if (si > 0) __syncthreads();          // the previous section's readers are done with the planes
+    scatter(cur, sec == 0 ? a.scale : 1.0f);   // Q leaves pre-scaled: S = (d^-1/2 Q).K^T, dK = dA^T.(d^-1/2 Q)
+    __syncthreads();
+    if (sec == 0) put_rows(PK_QH);
+    else if (sec == 1) {
+      if (a.pack_what & PACK_KH) put_rows(PK_KH);
+      if (a.pack_what & PACK_KT) put_cols(PK_KT);
+    } else if (sec == 2) {
+      if (a.pack_what & PACK_VT) put_cols(PK_VT);
+      if (a.pack_what & PACK_VH) put_rows(PK_VH);
+    } else {
+      put_rows(PK_OH);
+      // per-row constants of the backward, head-major [b,h,n,4] = (m, 1/l, delta, 0) with
+      // delta[row,h] = sum_k dO[row,k,h] * O[row,k,h] (flash-style); rows past N get 1/l = 0 (their probabilities vanish)
+      const int r = (tid >> 5) & 15, hh = (tid >> 2) & 7, part = tid & 3, n = n0 + r;   // 4 lanes per (row, head)
+      float sdel = 0.f;
       if (n < N) {
-        float* rs = a.rowstats + (((size_t)b * N + n) * AH + hh) * 4;
-        rs[3] = sdel;
-        s2 = make_float4(rs[0], __builtin_amdgcn_rcpf(rs[1]), sdel, 0.f);
+        const float* vo = a.v_att_in + ((size_t)b * N + n) * DH + hh;
+        const float* dr = sm + hh * RP + r * RS;
+#pragma unroll 4
+        for (int k = part * (D / 4); k < (part + 1) * (D / 4); ++k) sdel = fmaf(dr[k], vo[k * AH], sdel);
       }
-      *reinterpret_cast<float4*>(a.stats2 + (((size_t)b * AH + hh) * NP + n) * 4) = s2;
+      sdel += __shfl_xor(sdel, 1, 64);
+      sdel += __shfl_xor(sdel, 2, 64);
+      if (part == 0) {
+        float4 s2 = make_float4(3.0e38f, 0.f, 0.f, 0.f);   // rows past N: exp2(-inf) * 0
+        if (n < N) {
+          float* rs = a.rowstats + (((size_t)b * N + n) * AH + hh) * 4;
+          rs[3] = sdel;
+          s2 = make_float4(rs[0], __builtin_amdgcn_rcpf(rs[1]), sdel, 0.f);
+        }
+        *reinterpret_cast<float4*>(a.stats2 + (((size_t)b * AH + hh) * NP + n) * 4) = s2;
+      }
     }
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) cur[i] = nxt[i];
   }
 }
 
@@ -1088,11 +1107,9 @@ static int fill(const egt_attn_desc* desc, const void* qkv, const void* E, const
 
 template <int D>
 static void launch_pack(const AttnMfmaArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)16 * (D * AH + 4) * 4;
+  const size_t lds = (size_t)AH * (16 * (D == 16 ? 16 : 80) + 4) * 4;
   EGT_MAX_LDS_ONCE(k_attn_pack<D>);
-  const int nsec = ((a.pack_what & PACK_Q) != 0) + ((a.pack_what & (PACK_KH | PACK_KT)) != 0) + ((a.pack_what & (PACK_VT | PACK_VH)) != 0) +
-                   ((a.pack_what & PACK_O) != 0);
-  EGT_LAUNCH("k_attn_pack", k_attn_pack<D>, dim3(a.B * (a.NP / 16) * nsec), dim3(256), lds, st, a);
+  EGT_LAUNCH("k_attn_pack", k_attn_pack<D>, dim3(a.B * (a.NP / 16)), dim3(512), lds, st, a);
 }
 
 // 1 / 2: the straight-line instances (see Feat), 0: the run-time-switched one (EGT_ATTN_GENERIC forces it: tests)
