@@ -15,6 +15,7 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIMDS = 1024
+XCDS = 8   # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (value / duration = 8 x the shader clock)
 # measured issue costs (tools/micro/mfma_stream.hip, valu_rates.hip): cycles a SIMD is occupied per instruction
 MFMA_CYC, VALU_CYC = 32.0, 2.5
 KEYS = {"zinc500k_n64": ["k_block_bwd", "k_block_fwd"], "synthetic_n512": ["k_attn_mfma_bwd_kv", "k_attn_mfma_fwd", "k_attn_mfma_bwd_q", "k_attn_pack"]}
@@ -83,11 +84,12 @@ def main():
                 out.append(f"- `{k}`: HBM traffic per launch = 2 x {cs['FETCH_SIZE'][1]:.5g} KB + {cs['WRITE_SIZE'][1]:.5g} KB = {rec['hbm_bytes_per_launch'] / 1e6:.1f} MB")
                 traffic_all.setdefault(wl, {})[k] = rec["hbm_bytes_per_launch"]
             if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "GRBM_GUI_ACTIVE" in cs and cs["GRBM_GUI_ACTIVE"][1] > 0:
-                simd_cycles = SIMDS * cs["GRBM_GUI_ACTIVE"][1]
+                active = cs["GRBM_GUI_ACTIVE"][1] / XCDS
+                simd_cycles = SIMDS * active
                 rec["mfma_busy"] = cs["SQ_VALU_MFMA_BUSY_CYCLES"][1] / simd_cycles
-                rec["clock_ghz"] = cs["GRBM_GUI_ACTIVE"][1] / cs["GRBM_GUI_ACTIVE"][2]
+                rec["clock_ghz"] = active / cs["GRBM_GUI_ACTIVE"][2]
                 out.append(f"- `{k}`: matrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES {cs['SQ_VALU_MFMA_BUSY_CYCLES'][1]:.4g} / ({SIMDS} SIMDs x GRBM_GUI_ACTIVE "
-                           f"{cs['GRBM_GUI_ACTIVE'][1]:.4g}) = **{rec['mfma_busy']:.3f}** (clock {rec['clock_ghz']:.2f} GHz over the launch)")
+                           f"{cs['GRBM_GUI_ACTIVE'][1]:.4g} / {XCDS} XCDs) = **{rec['mfma_busy']:.3f}** (clock {rec['clock_ghz']:.2f} GHz over the launch)")
                 if "SQ_WAIT_ANY" in cs and "SQ_WAVE_CYCLES" in cs and cs["SQ_WAVE_CYCLES"][1] > 0:
                     rec["wait_any"] = cs["SQ_WAIT_ANY"][1] / cs["SQ_WAVE_CYCLES"][1]
                     rec["wait_inst_any"] = cs.get("SQ_WAIT_INST_ANY", (0, 0, 0))[1] / cs["SQ_WAVE_CYCLES"][1]
@@ -96,7 +98,7 @@ def main():
                 g = allc[k]["GRBM_GUI_ACTIVE"]
                 cyc = cs["SQ_INSTS_MFMA"][1] * MFMA_CYC + (cs["SQ_INSTS_VALU"][1] - cs["SQ_INSTS_MFMA"][1]) * VALU_CYC
                 # the instruction pass runs at its own duration: scale the active cycles by the duration ratio
-                act = g[1] * (cs["SQ_INSTS_VALU"][2] / g[2]) if g[2] else g[1]
+                act = (g[1] / XCDS) * (cs["SQ_INSTS_VALU"][2] / g[2]) if g[2] else g[1] / XCDS
                 rec["issue"] = dict(mfma_insts=cs["SQ_INSTS_MFMA"][1], valu_insts=cs["SQ_INSTS_VALU"][1] - cs["SQ_INSTS_MFMA"][1],
                                     mfma_cycles=cs["SQ_INSTS_MFMA"][1] * MFMA_CYC, valu_cycles=(cs["SQ_INSTS_VALU"][1] - cs["SQ_INSTS_MFMA"][1]) * VALU_CYC,
                                     simd_cycles=SIMDS * act, frac=cyc / (SIMDS * act))
@@ -118,7 +120,7 @@ def main():
         json.dump(pt, open(ptf, "w"), indent=1)
     if mfma_all:
         mfma_all["_source"] = (f"profiles/{name}_rocprof_summary.md (rocprofv3 --pmc, separate passes: FETCH_SIZE; WRITE_SIZE; SQ_* + GRBM_GUI_ACTIVE; SQ_INSTS_*): "
-                               "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE); "
+                               "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); "
                                f"issue.frac = (MFMAs x {MFMA_CYC:.0f} + other VALU x {VALU_CYC}) / (1024 x active cycles)")
         json.dump(mfma_all, open(os.path.join(REPO, "profiles", "pmc_mfma.json"), "w"), indent=1)
     for wl in ("cifar10_n150", "pattern500k_n120_b128", "zinc100k_n37", "pattern500k_n120", "synthetic_n512_b32"):
