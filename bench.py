@@ -429,11 +429,15 @@ def main():
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--dominant", default="k_block_bwd",
                     help="kernel timed with hipEvents inside the timed region")
-    ap.add_argument("--graph", default="off", choices=["off", "on"],
-                    help="on: forward + backward of the step replayed from ONE captured hipGraph (egt_amd.graph.GraphedStep; the "
+    ap.add_argument("--graph", default="auto", choices=["auto", "off", "on"],
+                    help="auto (default): on for the attention-block stack (the headline scope), off for the wider scopes.  "
+                         "on: forward + backward of the step replayed from ONE captured hipGraph (egt_amd.graph.GraphedStep; the "
                          "random-mask seeds live in device memory, EGT_BF_SEED_DEVICE, and advance inside the graph, so every "
                          "replay draws a fresh sample); the gradient collective stays an eager call after the replay.  The "
                          "dominant kernel is then timed in the untimed eager pass (a replay has no per-launch host hooks)")
+    ap.add_argument("--graph-collective", action="store_true",
+                    help="with --graph on under a launcher: the flat gradient all-reduce is captured INTO the step's hipGraph (RCCL "
+                         "supports stream capture), so a DP step is one host call; default: the collective is an eager call after the replay")
     ap.add_argument("--bind-grads", default="on", choices=["on", "off"],
                     help="stack scope: EGTStack.bind_flat_gradients() -- the stack backward writes every parameter gradient into one "
                          "persistent flat buffer whose views ARE the parameters' .grad (no per-parameter autograd work on the host)")
@@ -447,6 +451,8 @@ def main():
     args = ap.parse_args()
     if args.scope == "layers":
         args.with_ffn = True
+    if args.graph == "auto":     # the stack step is ~25 short launches: replayed as one hipGraph (bit-identical to the eager calls,
+        args.graph = "on" if (args.scope in ("", "stack") and not args.with_ffn) else "off"   # tests/test_graph_gpu.py); eager figure: `eager_step`
     if args.scope == "model" and args.dominant == "k_block_bwd":
         args.dominant = "k_ffn_bwd"
 
@@ -643,11 +649,21 @@ def main():
     graphed = None
     if args.graph == "on":
         from egt_amd import GraphedStep
-        graphed = GraphedStep(compute, seeds, warmup=1)
+        in_graph = bool(args.graph_collective and use_dist and state["flat_ok"] is not None and (state["flat_ok"] or state["fa"] is not None))
+        if in_graph:                     # forward + backward + the RCCL all-reduce of the flat gradient buffer: one graph, one host call
 
-        def step():                      # ONE host call for forward + backward, then the eager collective
+            def compute_and_reduce():
+                compute()
+                reduce()
+            graphed = GraphedStep(compute_and_reduce, seeds, warmup=1)
+        else:
+            graphed = GraphedStep(compute, seeds, warmup=1)
+        state["collective_in_graph"] = in_graph
+
+        def step():                      # ONE host call for forward + backward (and the collective when captured), else the eager collective
             graphed.replay()
-            reduce()
+            if not in_graph:
+                reduce()
         for _ in range(3):
             step()
         fence()
@@ -698,10 +714,10 @@ def main():
     # (egt_amd.graph: device-resident mask seeds, fresh sample per replay).  Its own process: nothing it does can cost
     # the contract line.  Single-process runs only.
     graph_leg = None
-    if graphed is None and not args.no_graph_leg and not use_dist and rank == 0:
+    if not args.no_graph_leg and not use_dist and rank == 0:
         try:
             import subprocess
-            cmd = [sys.executable, os.path.abspath(__file__), "--graph", "on", "--no-cpu-baseline", "--no-prof", "--no-graph-leg",
+            cmd = [sys.executable, os.path.abspath(__file__), "--graph", "off" if graphed is not None else "on", "--no-cpu-baseline", "--no-prof", "--no-graph-leg",
                    "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload, "--ffn-matmul", args.ffn_matmul,
                    "--fused", args.fused]
             if args.scope:
@@ -719,8 +735,8 @@ def main():
             if r.returncode == 0 and sub:
                 d = json.loads(sub[-1])
                 graph_leg = dict(value=d["value"], unit=d["unit"], ms_per_step=d["ms_per_step"], steps=d["steps"],
-                                 what="same workload in a second process: " + d["config"]["hipgraph"] + "; replays are bit-identical to "
-                                      "the eager calls (tests/test_graph_gpu.py)")
+                                 what="same workload in a second process: " + (d["config"]["hipgraph"] or "eager launches (one host call per kernel)")
+                                      + "; replays are bit-identical to the eager calls (tests/test_graph_gpu.py)")
             else:
                 graph_leg = dict(error=f"rc={r.returncode}: {r.stderr[-200:]}")
         except Exception as ex:  # noqa: BLE001  (a secondary figure must never cost the contract line)
@@ -814,9 +830,11 @@ def main():
                        "parallelism": f"dp{world}", "grad_allreduce_bytes": nbytes,
                        "grad_allreduce_us": ar_us, "backend": ("rccl (egt_dp_* C-ABI)" if comm is not None else "rccl") if use_dist else "none (single process)",
                        "flat_grad_adopted": bool(state["flat_ok"]), "flat_grad_bound": bool(state.get("bound")),
-                       "hipgraph": (f"forward + backward replayed from one captured hipGraph ({graphed.replays} replays), device-resident "
-                                    "mask seeds; dominant kernel timed in the untimed eager pass") if graphed is not None else None},
-            "roofline": roof, "cpu_baseline": cpu, "hipgraph_replay": graph_leg,
+                       "hipgraph": (f"forward + backward{' + the gradient all-reduce' if state.get('collective_in_graph') else ''} replayed from one "
+                                    f"captured hipGraph ({graphed.replays} replays), device-resident "
+                                    "mask seeds; dominant kernel timed in the untimed eager pass") if graphed is not None else None,
+                       "collective_in_graph": bool(state.get("collective_in_graph"))},
+            "roofline": roof, "cpu_baseline": cpu, ("eager_step" if graphed is not None else "hipgraph_replay"): graph_leg,
         }
         print(json.dumps(line))
     if use_dist:

@@ -56,6 +56,20 @@ def test_bench_graph_replay_under_launcher_with_the_eager_collective():
     assert line["value"] > 0
 
 
+def test_bench_graph_replay_with_the_collective_captured():
+    """--graph on --graph-collective: the RCCL all-reduce of the flat gradient buffer is a node of the step's hipGraph (a DP
+    step is ONE host call); same line otherwise"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", "29635", os.path.join(REPO, "bench.py"),
+           "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--layers", "2", "--graph", "on", "--graph-collective"]
+    r = subprocess.run(cmd, cwd=REPO, env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 1 and line["config"]["backend"] == "rccl"
+    assert line["config"]["collective_in_graph"] is True and "gradient all-reduce" in line["config"]["hipgraph"]
+    assert line["value"] > 0
+
+
 def test_bench_one_rank_through_the_capi_communicator():
     """--dp-backend capi: the step's collective is egt_dp_allreduce (ncclAllReduce on the compute stream)"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",

@@ -15,7 +15,7 @@ if [ -z "$QUICK" ]; then
 fi
 for WL in zinc500k_n64 synthetic_n512; do
   timeout 400 python bench.py --workload $WL > $OUT/bench_$WL.json 2> $OUT/bench_${WL}_err.log
-  B="python bench.py --workload $WL --steps 10 --warmup 3 --no-cpu-baseline --no-prof --no-graph-leg"
+  B="python bench.py --workload $WL --steps 10 --warmup 3 --no-cpu-baseline --no-prof --no-graph-leg --graph off"   # counters per eager launch
   timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kt_$WL -o r -- $B > $OUT/bench_under_rocprof_$WL.json 2>> $OUT/bench_${WL}_err.log
   timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_$WL -o r -- $B > /dev/null 2>> $OUT/bench_${WL}_err.log
   timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_$WL -o r -- $B > /dev/null 2>> $OUT/bench_${WL}_err.log
