@@ -26,3 +26,11 @@ def test_sweep_second_seed_subset(gpu, egt_lib, capsys):
     rc = SP.main(seed=7, n_stack=24, n_attn=20, n_ffn=6)
     out = capsys.readouterr().out
     assert rc == 0, out[-4000:]
+
+
+def test_mfma_inner_op_sweep(gpu, egt_lib, capsys):
+    """the producer / consumer MFMA kernels (d in {16,32,64}) over ragged N, odd tile counts and every feature mix they cover"""
+    import sweep_mfma as SM
+    bad = SM.main(seed=5, count=40)
+    out = capsys.readouterr().out
+    assert bad == 0 and "FAIL" not in out, out[-4000:]
