@@ -1769,6 +1769,13 @@ static void bind_common(const egt_block_desc* d, BlockArgs& a, const void* h, co
     default: { constexpr int DE = 64; CALL; } break;  \
   }
 
+// The node side inside the pair kernels (fwd_node_epilogue / bwd_node_prologue): H = 8 heads of DK <= 8 channels, i.e. node width
+// Dh = 8 DK <= 64 as a zero-padded 64-wide row; the prologue reads Wo / Wqkv rows as 16-byte pieces.
+static bool node_fused_ok(const BlockArgs& a) {
+  return a.Dh == BH * a.DK && a.DK >= 1 && a.DK <= 8 &&
+         ((reinterpret_cast<uintptr_t>(a.Wo) | reinterpret_cast<uintptr_t>(a.Wqkv)) & 15) == 0;
+}
+
 // Forward of one block.  `skip_pre`: qkvp (and pw) of this block were already produced (by the
 // previous block's epilogue / k_edge_prep).  a.epi is the epilogue the caller would like; the
 // value actually used is returned (0 when the geometry is outside the epilogue's cover, in
@@ -1781,7 +1788,7 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   const size_t lds_kv = ((size_t)a.N * KV_LD + 16 * QS_LD + a.N) * 4;
   const bool kvl = lds_tiles + lds_kv <= 80 * 1024 - 512;   // two workgroups per CU keep their K/V in LDS
   const int epi_req = a.epi;
-  if (!(kvl && a.Dh == 64 && a.DK == 8)) a.epi = 0;
+  if (!(kvl && node_fused_ok(a))) a.epi = 0;
   const bool ml = a.M != nullptr || a.rm != nullptr;
   a.guard = 0;   // (the always-taken phase branches of the kernels only shape hipcc's scheduling regions)
   const dim3 grid(a.B * lgroups), block(256);
@@ -1803,7 +1810,7 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   if constexpr (DE == 8) {   // VALU pair kernel (egt_narrow.hip): lane = (row, head/channel pair), 4 key quarters per workgroup
     if (!ml && !block_env().no_narrow_fwd) {
       narrow = true;
-      if (!(a.Dh == 64 && a.DK == 8)) a.epi = 0; else a.epi = epi_req;
+      if (!node_fused_ok(a)) a.epi = 0; else a.epi = epi_req;
       egt_narrow_launch_fwd(a, st);
     }
   }
@@ -1811,7 +1818,7 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
     if (!narrow) {   // (wider channels would not fit the four rows' state in 256 VGPRs: not instantiated)
     narrow = !ml && (r4 || r8);
     if (narrow) {
-    if (!(a.Dh == 64 && a.DK == 8)) a.epi = 0; else a.epi = epi_req;
+    if (!node_fused_ok(a)) a.epi = 0; else a.epi = epi_req;
 #define R4_LAUNCH_T(FULL_, NW_, BF_)                                                                              \
   do {                                                                                                            \
     EGT_MAX_LDS_ONCE(k_block_fwd_r4<DE, FULL_, NW_, BF_>); \
@@ -1841,14 +1848,14 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
 // next block of the chain (NULL at the bottom), whose dV_att / delta this block's node kernel
 // produces.  GEMM-shaped weight gradients and all partial reductions are left to the caller.
 template <int DE>
-static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool top, BlockArgs* below, BlockArgs* above) {
+static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool top, BlockArgs* below, BlockArgs* above, bool fuse) {
   using GG = Geo<DE>;
   // node-side prologue inside the pair kernel (see bwd_node_prologue): v4 geometry with Dh = 64
   const bool ml = a.M != nullptr || a.rm != nullptr;
   // narrow edge channels without mask tensors run k_block_bwd_v4r, which (with the prologue) also covers ragged N
   const bool narrow_r = DE <= 16 && !ml;
   static_assert(DE % 16 == 0 || DE == 8, "edge widths of the pair kernels");
-  const bool pro = a.Dh == 64 && a.DK == 8;   // (every backward kernel and the prologue take N that is not a multiple of 16)
+  const bool pro = fuse;   // node_fused_ok() of EVERY block of the chain (every backward kernel and the prologue take N that is not a multiple of 16)
   a.pro = 0;
   if (pro) {
     a.pro = top ? 1 : 2;
@@ -1972,7 +1979,7 @@ extern "C" int egt_block_bwd(const egt_block_desc* desc, const egt_block_params*
   a.g_Wo = (float*)grads->dense_mha_kernel; a.g_bo = (float*)grads->dense_mha_bias;
   a.g_Wr = (float*)grads->dense_edge_r_kernel; a.g_br = (float*)grads->dense_edge_r_bias;
   const BlockLayout L = layout(desc);
-  DISPATCH_BDE(desc->De, launch_bwd<DE>(a, L, (hipStream_t)stream, true, nullptr, nullptr));
+  DISPATCH_BDE(desc->De, launch_bwd<DE>(a, L, (hipStream_t)stream, true, nullptr, nullptr, node_fused_ok(a)));
   egt_node_launch_wgrads(&a, 1, (hipStream_t)stream);
   egt_node_launch_reduce(&a, 1, L.nwg_bwd, L.EP, (hipStream_t)stream);  // partial sums + edge param grads
   EGT_HIP_LAUNCH_CHECK("egt_block_bwd");
@@ -2126,10 +2133,12 @@ extern "C" int egt_stack_bwd(const egt_block_desc* desc, int32_t layers, const e
     a.g_Wo = (float*)g->dense_mha_kernel; a.g_bo = (float*)g->dense_mha_bias;
     a.g_Wr = (float*)g->dense_edge_r_kernel; a.g_br = (float*)g->dense_edge_r_bias;
   }
+  bool fuse = true;
+  for (int l = 0; l < layers; ++l) fuse = fuse && node_fused_ok(as[l]);
   for (int l = layers - 1; l >= 0; --l) {
     as[l].prep = 0;   // the LN-folded edge weights were prepared by the forward and live in `saved`
     DISPATCH_BDE(desc->De, launch_bwd<DE>(as[l], L, (hipStream_t)stream, l == layers - 1, l > 0 ? &as[l - 1] : nullptr,
-                                             l + 1 < layers ? &as[l + 1] : nullptr));
+                                             l + 1 < layers ? &as[l + 1] : nullptr, fuse));
   }
   egt_node_launch_wgrads(as, layers, (hipStream_t)stream);
   egt_node_launch_reduce(as, layers, L.nwg_bwd, L.EP, (hipStream_t)stream);

@@ -119,27 +119,36 @@ __device__ __forceinline__ float reduce16_keep_own(const float (&v)[16], int p) 
 #define KV_LD 132  // LDS row stride (floats) of the staged [K|V] rows
 #define QS_LD 68   // LDS row stride of the staged Q rows (reused for the V_att rows of the epilogue)
 
-// ---- node-side epilogue (Dh = 64): the workgroup holds V_att of its 16 rows in qs ----
+// ---- node-side epilogue: the workgroup holds V_att of its 16 rows in qs ----
 //   epi >= 1: h' = V_att.Wo + bo + h                      (dense_mha + res_mha, :136,140)
 //   epi == 2: qkv of the NEXT block = LN(h').Wqkv' + bqkv' (norm_mha + dense_qkv, :109,113), packed
 // Contraction order k = 4s + q on both MFMA operands; weights come straight from L2.
-__device__ __forceinline__ void fwd_node_epilogue(const BlockArgs& a, float* sm, float* qs, int b, int lg, int N,
-                                                  int wave, int p, int q) {
-
+// Node width Dh = 8 * DK <= 64 (H = 8 heads): the tiles are always four 16-column tiles of a zero-padded 64-wide row -- channel
+// c = k * 8 + head is the same index in the padded and in the natural row, so the padding is the columns c >= Dh: their weights,
+// biases and inputs read as zero, their outputs are never stored, the LayerNorm divides by Dh and keeps them at zero.  D64: Dh is
+// the compile-time 64 of the headline geometry (no guards).
+template <bool D64>
+__device__ __forceinline__ void fwd_node_epilogue_t(const BlockArgs& a, float* sm, float* qs, int b, int lg, int N,
+                                                    int wave, int p, int q) {
+    const int Dh = D64 ? 64 : a.Dh, D3 = 3 * Dh;
     float wo[16], wq[3][16];
     const int c = wave * 16 + p;
+    const bool cok = D64 || c < Dh;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) wo[s] = a.Wo[(4 * s + q) * 64 + c];
+    for (int s = 0; s < 16; ++s) wo[s] = (D64 || (cok && 4 * s + q < Dh)) ? a.Wo[(4 * s + q) * Dh + c] : 0.f;
     if (a.epi == 2) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
+      for (int j = 0; j < 3; ++j) {
+        const int cq = (wave + 4 * j) * 16 + p, gc = (cq >> 6) * Dh + (cq & 63);   // padded column -> column of Wqkv [Dh][3 Dh]
+        const bool qok = D64 || (cq & 63) < Dh;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) wq[j][s] = a.nx_Wqkv[(4 * s + q) * 192 + (wave + 4 * j) * 16 + p];
+        for (int s = 0; s < 16; ++s) wq[j][s] = (D64 || (qok && 4 * s + q < Dh)) ? a.nx_Wqkv[(4 * s + q) * D3 + gc] : 0.f;
+      }
     }
-    const float bo = a.bo[c];
+    const float bo = cok ? a.bo[c] : 0.f;
     float hres[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) hres[r] = a.h[((size_t)b * N + min(lg * 16 + 4 * q + r, N - 1)) * 64 + c];
+    for (int r = 0; r < 4; ++r) hres[r] = cok ? a.h[((size_t)b * N + min(lg * 16 + 4 * q + r, N - 1)) * Dh + c] : 0.f;
     __syncthreads();   // every row's V_att is in qs; the tile area is idle from here on
     float* hs = sm;    // [16][QS_LD]
     v4f acc = {bo, bo, bo, bo};
@@ -149,29 +158,34 @@ __device__ __forceinline__ void fwd_node_epilogue(const BlockArgs& a, float* sm,
     for (int r = 0; r < 4; ++r) {
       const int row = 4 * q + r, l = lg * 16 + row;
       const float hv = acc[r] + hres[r];
-      if (l < N) a.h_out[((size_t)b * N + l) * 64 + c] = hv;
+      if (l < N && cok) a.h_out[((size_t)b * N + l) * Dh + c] = hv;
       hs[row * QS_LD + c] = hv;
     }
     if (a.epi == 2) {
       __syncthreads();
       {   // LayerNorm of row 4*wave + q: 16 lanes x 4 columns
         float* x = hs + (4 * wave + q) * QS_LD;
+        const float inv = D64 ? 1.0f / 64 : 1.0f / (float)Dh;
         float v[4], sm1 = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[i] = x[p + 16 * i]; sm1 += v[i]; }
-        const float mu = row_sum16(sm1) * (1.0f / 64);
+        const float mu = row_sum16(sm1) * inv;
         float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] -= mu; ss = fmaf(v[i], v[i], ss); }
-        const float rstd = rsqrtf(row_sum16(ss) * (1.0f / 64) + a.ln_eps);
+        for (int i = 0; i < 4; ++i) { v[i] = (D64 || p + 16 * i < Dh) ? v[i] - mu : 0.f; ss = fmaf(v[i], v[i], ss); }
+        const float rstd = rsqrtf(row_sum16(ss) * inv + a.ln_eps);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) x[p + 16 * i] = fmaf(v[i] * rstd, a.nx_nm_g[p + 16 * i], a.nx_nm_b[p + 16 * i]);
+        for (int i = 0; i < 4; ++i) {
+          const int ci = p + 16 * i;
+          const bool ok = D64 || ci < Dh;
+          x[ci] = ok ? fmaf(v[i] * rstd, a.nx_nm_g[ci], a.nx_nm_b[ci]) : 0.f;
+        }
       }
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int cq = (wave + 4 * j) * 16 + p;
-        const float bq = a.nx_bqkv[cq];
+        const float bq = (D64 || (cq & 63) < Dh) ? a.nx_bqkv[(cq >> 6) * Dh + (cq & 63)] : 0.f;
         v4f aq = {bq, bq, bq, bq};
 #pragma unroll
         for (int s = 0; s < 16; ++s) aq = MFMA(hs[p * QS_LD + 4 * s + q], wq[j][s], aq);
@@ -180,11 +194,16 @@ __device__ __forceinline__ void fwd_node_epilogue(const BlockArgs& a, float* sm,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int l = lg * 16 + 4 * q + r;
-          if (l < N) a.nx_qkvp[((size_t)b * N + l) * QKVP + pos] = aq[r];
+          if (l < N) a.nx_qkvp[((size_t)b * N + l) * QKVP + pos] = aq[r];   // (padding columns store the zeros the pair kernels expect there)
         }
       }
     }
   }
+__device__ __forceinline__ void fwd_node_epilogue(const BlockArgs& a, float* sm, float* qs, int b, int lg, int N,
+                                                  int wave, int p, int q) {
+  if (a.Dh == 64) fwd_node_epilogue_t<true>(a, sm, qs, b, lg, N, wave, p, q);
+  else fwd_node_epilogue_t<false>(a, sm, qs, b, lg, N, wave, p, q);
+}
 
 // the barriers of fwd_node_epilogue, for waves of a workgroup that take no part in it (a.epi is uniform)
 __device__ __forceinline__ void fwd_node_epilogue_idle(const BlockArgs& a) {
@@ -195,7 +214,8 @@ __device__ __forceinline__ void fwd_node_epilogue_idle(const BlockArgs& a) {
 #define QD_LD 160  // per row: Q[64] | dV_att[64] | stats[32]
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-// ---- node-side prologue of the backward pair kernel (Dh = 64, 16 rows, 256 threads) -------------
+// ---- node-side prologue of the backward pair kernel (16 rows, 256 threads; Dh = 8 DK <= 64 as a zero-padded 64-wide row,
+//      see fwd_node_epilogue_t: D64 = the compile-time 64 of the headline geometry) -------------
 // What k_node_bwd does between two pair kernels is local to a node row, so the workgroup that
 // owns 16 query rows of layer L does it itself before its tile loop:
 //   [pro == 2] rows of the layer above (L+1): dQKV = packed dQ + dK/dV partial sums (written by the
@@ -229,27 +249,33 @@ struct BwdProRegs { float4 hx, gq[3], wq[12], wo[4]; float dho[4], gmm[4], va[4]
      past the end contribute zeros to every sum and are never stored */                                   \
   const int nv = min(a.TL, N - l_begin);                   /* valid rows of this workgroup (a.TL <= 16) */ \
   auto rc = [&](int r) { return row0 + min(r, nv - 1); };   /* clamped global row */                       \
-  (void)LD; (void)LD3; (void)lnrow; (void)p; (void)q; (void)rc
+  const int Dh = D64 ? 64 : a.Dh;                                                                          \
+  (void)LD; (void)LD3; (void)lnrow; (void)p; (void)q; (void)rc; (void)Dh
 
 // Wo columns and V_att rows of the dV_att step
-template <int DE>
+template <int DE, bool D64>
 __device__ __forceinline__ void bwd_prologue_load_wo_va(const BlockArgs& a, int b, int l_begin, BwdProRegs& R) {
   BWD_PRO_COMMON();
+  const bool iok = D64 || 16 * wave + p < Dh;   // the lane's dV_att channel exists
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int s = 0; s < 4; ++s) R.wo[s] = *reinterpret_cast<const float4*>(a.Wo + (size_t)(16 * wave + p) * 64 + 16 * q + 4 * s);
+  for (int s = 0; s < 4; ++s)
+    R.wo[s] = (D64 || (iok && 16 * q + 4 * s < Dh)) ? *reinterpret_cast<const float4*>(a.Wo + (size_t)(16 * wave + p) * Dh + 16 * q + 4 * s) : z4;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) R.va[r] = a.v_att[rc(4 * q + r) * 64 + 16 * wave + p];
+  for (int r = 0; r < 4; ++r) R.va[r] = iok ? a.v_att[rc(4 * q + r) * Dh + 16 * wave + p] : 0.f;
 }
 // [pro == 2] every global input of the dQKV / d h_ln / LayerNorm-backward step
-template <int DE>
+template <int DE, bool D64>
 __device__ __forceinline__ void bwd_prologue_load_main(const BlockArgs& a, int b, int l_begin, BwdProRegs& R) {
   BWD_PRO_COMMON();
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // ---- every global input in one round trip ----
-    R.hx = *reinterpret_cast<const float4*>(a.up_h + rc(t >> 4) * 64 + (t & 15) * 4);
+    R.hx = (D64 || (t & 15) * 4 < Dh) ? *reinterpret_cast<const float4*>(a.up_h + rc(t >> 4) * Dh + (t & 15) * 4) : z4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      R.dho[i] = a.up_dh_out[rc(lnrow) * 64 + p + 16 * i];
-      R.gmm[i] = a.up_nm_g[p + 16 * i];
+      const bool ok = D64 || p + 16 * i < Dh;
+      R.dho[i] = ok ? a.up_dh_out[rc(lnrow) * Dh + p + 16 * i] : 0.f;
+      R.gmm[i] = ok ? a.up_nm_g[p + 16 * i] : 0.f;
     }
     // partial counts of the layer above (same geometry, same kernels): dQ partials per row = a.NQP (key tiles for the
     // MFMA-tile kernels, 1 for k_narrow_bwd, which reduces its key tiles itself), dK/dV partials per key = a.NLR (row groups)
@@ -270,13 +296,17 @@ __device__ __forceinline__ void bwd_prologue_load_main(const BlockArgs& a, int b
       if (r >= nv) acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
       R.gq[u] = acc4;
     }
-    // B operand of d h_ln = dQKV.Wqkv^T: Wqkv[kk = 16 wave + p][48 q .. 48 q + 47] (contraction order c = 48 q + s)
+    // B operand of d h_ln = dQKV.Wqkv^T: Wqkv[kk = 16 wave + p][48 q .. 48 q + 47] (contraction order c = 48 q + s, c a column of
+    // the padded [3][64] row: section c >> 6, channel c & 63)
+    const bool kok = D64 || 16 * wave + p < Dh;
 #pragma unroll
-    for (int s = 0; s < 12; ++s)
-      R.wq[s] = *reinterpret_cast<const float4*>(a.up_Wqkv + (size_t)(16 * wave + p) * 192 + 48 * q + 4 * s);
+    for (int s = 0; s < 12; ++s) {
+      const int c = 48 * q + 4 * s;
+      R.wq[s] = (D64 || (kok && (c & 63) < Dh)) ? *reinterpret_cast<const float4*>(a.up_Wqkv + (size_t)(16 * wave + p) * (3 * Dh) + (c >> 6) * Dh + (c & 63)) : z4;
+    }
 }
 
-template <int DE>
+template <int DE, bool D64>
 __device__ __forceinline__ void bwd_prologue_compute(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg, BwdProRegs& R,
                                                      bool wo_loaded, unsigned* tp = nullptr) {
   float* dqs = ws;                   // dQKV  [16][196]
@@ -299,19 +329,21 @@ __device__ __forceinline__ void bwd_prologue_compute(const BlockArgs& a, float* 
       const int i = t + u * 256, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
       const int qq = (pos4 >> 4) & 3, k0 = (pos4 >> 1) & 7;
       float* d = dqs + r * LD3 + sx * 64 + k0 * 8 + 2 * qq;
-      d[0] = gq[u].x; d[1] = gq[u].y; d[8] = gq[u].z; d[9] = gq[u].w;
+      const bool k0ok = D64 || k0 * 8 < Dh, k1ok = D64 || (k0 + 1) * 8 < Dh;   // per-head channels k0, k0 + 1 < DK
+      d[0] = k0ok ? gq[u].x : 0.f; d[1] = k0ok ? gq[u].y : 0.f; d[8] = k1ok ? gq[u].z : 0.f; d[9] = k1ok ? gq[u].w : 0.f;
     }
     __syncthreads();
+    const float invD = D64 ? 1.0f / 64 : 1.0f / (float)Dh;
     {   // LN forward statistics -> xhat in place
       float* xr = xs + lnrow * LD;
       float v[4], s1 = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) { v[i] = xr[p + 16 * i]; s1 += v[i]; }
-      const float mu = row_sum16(s1) * (1.0f / 64);
+      const float mu = row_sum16(s1) * invD;
       float ss = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] -= mu; ss = fmaf(v[i], v[i], ss); }
-      const float rstd = rsqrtf(row_sum16(ss) * (1.0f / 64) + a.ln_eps);
+      for (int i = 0; i < 4; ++i) { v[i] = (D64 || p + 16 * i < Dh) ? v[i] - mu : 0.f; ss = fmaf(v[i], v[i], ss); }
+      const float rstd = rsqrtf(row_sum16(ss) * invD + a.ln_eps);
 #pragma unroll
       for (int i = 0; i < 4; ++i) xr[p + 16 * i] = v[i] * rstd;
       if (p == 0) rs[lnrow] = rstd;
@@ -331,9 +363,10 @@ __device__ __forceinline__ void bwd_prologue_compute(const BlockArgs& a, float* 
       for (int r = 0; r < 4; ++r) dls[(4 * q + r) * LD + 16 * wave + p] = acc[r];
     }
     NSTAMP(2);
-    for (int i = t; i < nv * 48; i += 256) {   // dQKV rows out (natural channel order) for k_node_wgrads
+    for (int i = t; i < nv * 48; i += 256) {   // dQKV rows out (natural channel order, [3][Dh] per row) for k_node_wgrads
       const int r = i / 48, c4 = (i % 48) * 4;
-      *reinterpret_cast<float4*>(a.up_dqkv_sv + (row0 + r) * 192 + c4) = *reinterpret_cast<const float4*>(dqs + r * LD3 + c4);
+      if (D64 || (c4 & 63) < Dh)
+        *reinterpret_cast<float4*>(a.up_dqkv_sv + (row0 + r) * (3 * Dh) + (c4 >> 6) * Dh + (c4 & 63)) = *reinterpret_cast<const float4*>(dqs + r * LD3 + c4);
     }
     __syncthreads();
     {   // LayerNorm backward + residual -> dh' rows (HBM + LDS)
@@ -346,43 +379,46 @@ __device__ __forceinline__ void bwd_prologue_compute(const BlockArgs& a, float* 
         m1 += dx[i];
         m2 = fmaf(dx[i], xr[p + 16 * i], m2);
       }
-      m1 = row_sum16(m1) * (1.0f / 64);
-      m2 = row_sum16(m2) * (1.0f / 64);
+      m1 = row_sum16(m1) * invD;
+      m2 = row_sum16(m2) * invD;
       const float rstd = rs[lnrow];
       float* dh_out_rw = const_cast<float*>(a.dh_out);   // this layer's dh' IS the upper layer's dh
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c = p + 16 * i;
-        const float dv = lnrow < nv ? dho[i] + rstd * (dx[i] - m1 - xr[c] * m2) : 0.f;
-        if (lnrow < nv) dh_out_rw[(row0 + lnrow) * 64 + c] = dv;
+        const bool ok = lnrow < nv && (D64 || c < Dh);
+        const float dv = ok ? dho[i] + rstd * (dx[i] - m1 - xr[c] * m2) : 0.f;
+        if (ok) dh_out_rw[(row0 + lnrow) * Dh + c] = dv;
         dhs[lnrow * LD + c] = dv;
       }
     }
     {   // column sums over the 16 rows: dbqkv | dgamma, dbeta of the layer above
-      float* sp = a.up_spart + (size_t)wg * (192 + 128);
+      float* sp = a.up_spart + (size_t)wg * (5 * Dh);   // [3 Dh: dbqkv | Dh: dgamma | Dh: dbeta]
       if (t < 192) {
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) { s0 += dqs[r * LD3 + t]; s1 += dqs[(r + 1) * LD3 + t]; }
-        sp[t] = s0 + s1;
+        if (D64 || (t & 63) < Dh) sp[(t >> 6) * Dh + (t & 63)] = s0 + s1;
       } else {
         const int c = t - 192;
         float g0 = 0.f, b0 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { const float d0 = dls[r * LD + c]; g0 = fmaf(d0, xs[r * LD + c], g0); b0 += d0; }
-        sp[192 + c] = g0;
-        sp[256 + c] = b0;
+        if (D64 || c < Dh) {
+          sp[3 * Dh + c] = g0;
+          sp[4 * Dh + c] = b0;
+        }
       }
     }
   } else {
-    const float4 dv4 = *reinterpret_cast<const float4*>(a.dh_out + rc(t >> 4) * 64 + (t & 15) * 4);
-    const bool ok = (t >> 4) < nv;
+    const bool ok = (t >> 4) < nv && (D64 || (t & 15) * 4 < Dh);
+    const float4 dv4 = ok ? *reinterpret_cast<const float4*>(a.dh_out + rc(t >> 4) * Dh + (t & 15) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     *reinterpret_cast<float4*>(dhs + (t >> 4) * LD + (t & 15) * 4) =
         make_float4(ok ? dv4.x : 0.f, ok ? dv4.y : 0.f, ok ? dv4.z : 0.f, ok ? dv4.w : 0.f);
   }
   // ---- dV_att = dh'.Wo^T for i tile = wave (contraction order c = 16 q + s), delta, dbo ----
   NSTAMP(3);
-  if (!wo_loaded) bwd_prologue_load_wo_va<DE>(a, b, l_begin, R);
+  if (!wo_loaded) bwd_prologue_load_wo_va<DE, D64>(a, b, l_begin, R);
   __syncthreads();
   NSTAMP(4);
   {
@@ -412,7 +448,7 @@ __device__ __forceinline__ void bwd_prologue_compute(const BlockArgs& a, float* 
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) { s0 += dhs[r * LD + t]; s1 += dhs[(r + 1) * LD + t]; }
-    a.sbo[(size_t)wg * 64 + t] = s0 + s1;
+    if (D64 || t < Dh) a.sbo[(size_t)wg * Dh + t] = s0 + s1;
   }
   __syncthreads();
   if (t < 128) {   // delta of (row, head)
@@ -422,11 +458,16 @@ __device__ __forceinline__ void bwd_prologue_compute(const BlockArgs& a, float* 
   }
 }
 
+template <int DE, bool D64, bool HOIST>
+__device__ __forceinline__ void bwd_node_prologue_t(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg, unsigned* tp) {
+  BwdProRegs R;
+  if (HOIST) bwd_prologue_load_wo_va<DE, D64>(a, b, l_begin, R);
+  if (a.pro == 2) bwd_prologue_load_main<DE, D64>(a, b, l_begin, R);
+  bwd_prologue_compute<DE, D64>(a, ws, qd, b, l_begin, wg, R, HOIST, tp);
+}
 template <int DE, bool HOIST = false>
 __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg, unsigned* tp = nullptr) {
-  BwdProRegs R;
-  if (HOIST) bwd_prologue_load_wo_va<DE>(a, b, l_begin, R);
-  if (a.pro == 2) bwd_prologue_load_main<DE>(a, b, l_begin, R);
-  bwd_prologue_compute<DE>(a, ws, qd, b, l_begin, wg, R, HOIST, tp);
+  if (a.Dh == 64) bwd_node_prologue_t<DE, true, HOIST>(a, ws, qd, b, l_begin, wg, tp);
+  else bwd_node_prologue_t<DE, false, HOIST>(a, ws, qd, b, l_begin, wg, tp);
 }
 

@@ -150,7 +150,10 @@ def test_fused_stack_matches_composed(gpu, egt_lib):
 @pytest.mark.parametrize("N,De,Dh,train", [(24, 64, 64, False), (32, 64, 64, True), (11, 48, 48, False),
                                            (20, 8, 64, True), (80, 16, 64, True), (32, 32, 64, False), (48, 48, 64, True),
                                            (32, 8, 64, True), (128, 8, 64, False),
-                                           (150, 8, 64, True), (144, 16, 64, False)])   # 32-row workgroups of k_block_fwd_r4
+                                           (150, 8, 64, True), (144, 16, 64, False),   # 32-row workgroups of k_block_fwd_r4
+                                           # node widths below 64 on the fused node side (zero-padded column tiles): ZINC-100K's
+                                           # N = 37 / Dh = 48 (d = 6), two empty tiles (d = 4), a partial tile (d = 5), d = 1
+                                           (37, 48, 48, True), (40, 8, 32, True), (24, 16, 40, False), (20, 64, 8, False)])
 def test_stack_call_vs_oracle(N, De, Dh, train, gpu, egt_lib):
     """egt_stack_fwd/bwd (one C call per direction, deferred partial reduction) vs the fp64 oracle,
     including the per-layer in-kernel random masks."""
@@ -372,6 +375,41 @@ def test_stack_bf16_edge_tensors_vs_oracle(N, De, Dh, train, Ly, gpu, egt_lib):
     for li, blk in enumerate(st.blocks):
         for k, (m, a_) in PMAP.items():
             assert_close(getattr(getattr(blk, m), a_).grad, next(gi), name=f"L{li}.{k}", rtol=3e-2, arel=2e-2, l2=3e-2)
+
+
+@pytest.mark.parametrize("N,De,Dh", [(37, 48, 48), (64, 64, 64), (40, 8, 32)])
+def test_node_side_runs_inside_the_pair_kernels(N, De, Dh, gpu, egt_lib):
+    """One launch per layer and direction: dense_mha + residual + the next block's norm_mha / dense_qkv run as the forward pair
+    kernel's epilogue, dQKV -> dh -> dV_att / delta as the backward pair kernel's prologue (egt_block_dev.h).  Node widths
+    below 64 (ZINC-100K: Dh = 48, d = 6) take the zero-padded fourth column tile.  Counted with the C-ABI's launch profiler:
+    a 3-layer stack is ONE k_node_pre, no k_node_post, ONE k_node_bwd (the bottom of the chain) -- parity of these shapes is
+    test_stack_call_vs_oracle / test_other_baseline_shapes_fused_vs_oracle / test_stack_bf16_edge_tensors_vs_oracle."""
+    import ctypes as C
+    from egt_amd import EGTStack, _lib
+    lib = _lib.load()
+    torch.manual_seed(5)
+    Ly, B = 3, 2
+    st = EGTStack(model_height=Ly, model_width=Dh, edge_width=De, num_heads=8, fused=True).to(gpu).eval()
+    g = torch.Generator().manual_seed(N)
+    h = torch.randn(B, N, Dh, generator=g).to(gpu).requires_grad_(); e = torch.randn(B, N, N, De, generator=g).to(gpu).requires_grad_()
+    mask = torch.ones(B, N, dtype=torch.bool, device=gpu)
+    lib.egt_prof_filter(b""); lib.egt_prof_enable(2)
+    try:
+        h2, e2 = st(h, e, mask)
+        assert st.last_path == "fused-stack"
+        torch.autograd.backward([h2, e2], [torch.ones_like(h2), torch.ones_like(e2)])
+        torch.cuda.synchronize()
+    finally:
+        lib.egt_prof_enable(0)
+    buf = C.create_string_buffer(4096)
+    lib.egt_prof_names(buf, 4096)
+    count = {}
+    for name in buf.value.decode().split():
+        cnt, ms = C.c_int64(0), C.c_double(0.0)
+        lib.egt_prof_read(name.encode(), C.byref(cnt), C.byref(ms))
+        count[name] = cnt.value
+    assert count.get("k_block_fwd") == Ly and count.get("k_block_bwd") == Ly, count
+    assert count.get("k_node_pre") == 1 and count.get("k_node_post", 0) == 0 and count.get("k_node_bwd") == 1, count
 
 
 def test_block_bf16_single_block_and_dtype_errors(gpu, egt_lib):

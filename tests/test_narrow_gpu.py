@@ -84,7 +84,7 @@ PMAP = {"norm_edge.gamma": ("norm_edge", "gamma"), "norm_edge.beta": ("norm_edge
     ("noclip", 41, 64, False, True),         # clip_logits_value = None
     ("bias", 40, 64, False, True),           # EGT-simple: projections of the raw e (no norm_edge), e returned unchanged
     ("bias", 33, 64, True, False),
-    ("d6", 37, 48, False, True),             # Dh = 48 -> d = 6: zero-padded packed QKV, node side in separate launches
+    ("d6", 37, 48, False, True),             # Dh = 48 -> d = 6: zero-padded packed QKV, node side on the zero-padded fourth column tile
     ("d6", 50, 48, True, True),
     ("plain", 188, 64, True, True),          # PATTERN's longest graphs: 12 row groups, ragged last key block
     ("plain", 90, 64, True, True),           # 6 key tiles over 4 waves: balanced (tile, row) ranges, key tiles 1 and 4 shared by two waves
