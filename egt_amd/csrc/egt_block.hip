@@ -1576,7 +1576,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4r(BlockArgs a) {   // R 
 // Run-time switches (read ONCE per process: the launch path does no getenv()) -- the complete list, see README.md:
 //   EGT_NO_NARROW / EGT_NO_NARROW_FWD / EGT_NO_NARROW_BWD: De = 8 falls back from the De = 8 pair kernels (egt_narrow.hip) to the
 //     MFMA-tile kernels (tests exercise both);  EGT_BWD_MATMUL=bf16x3: the backward's channel contractions as 3-term bf16 split
-//     products (opt-in; default exact fp32);  EGT_BWD_TL: De = 8 query rows per backward workgroup (tests / sweeps).
+//     products (opt-in; default exact fp32);  EGT_BWD_TL: query rows per backward workgroup (tests / sweeps).
 struct EgtBlockEnv {
   bool no_narrow_fwd, no_narrow_bwd;
   int bwd_mm;
@@ -1645,12 +1645,21 @@ struct BlockLayout {
 //    (pattern500k_n120, per launch: B = 16: 59.0 us at 16 rows, 43.3 at 8, 47.9 at 6; B = 32: 63.0 / 59.5 / 65.5).
 //    Smaller groups never pay beyond that: the per-workgroup work that does not shrink with the rows (prologue, K / V tiles,
 //    partial sums) takes over (B = 128, N = 150: 225 us at 16 rows, 253 at 12, 295 at 8).
-// EGT_BWD_TL = 4 .. 16 overrides (tests, sweeps: tools/dbg/nrw_tlsweep.sh).
+// EGT_BWD_TL = 4 .. 16 overrides, for every De (tests, sweeps: tools/dbg/nrw_tlsweep.sh).
 static int bwd_rows_per_wg(const egt_block_desc* d) {
   static const int forced = getenv("EGT_BWD_TL") ? atoi(getenv("EGT_BWD_TL")) : 0;
   const int groups = (d->N + BWD_TL - 1) / BWD_TL;
-  if (d->De != 8) return (d->N + groups - 1) / groups;   // equal groups for every De (16 whenever N is a multiple of 16)
   if (forced >= 4 && forced <= BWD_TL) return forced;
+  if (d->De != 8) {   // MFMA-tile kernels: two workgroups per CU
+    // equal groups (16 whenever N is a multiple of 16); a launch that leaves slots empty takes more, shorter groups while they
+    // still fit one round and keep 8 rows (ZINC-100K, B = 128, N = 37: 3 x 13 rows = 384 workgroups on 512 slots -> 4 x 10 rows:
+    // k_block_bwd 73.6 -> 64.3 us; 5 x 8 rows = 640 workgroups is a second round: 92.9 us)
+    const int slots = 2 * egt_device_cus();
+    int g = slots / (d->B > 0 ? d->B : 1);
+    if (g > (d->N + 7) / 8) g = (d->N + 7) / 8;
+    if (g < groups) g = groups;
+    return (d->N + g - 1) / g;
+  }
   if (d->B * groups <= egt_device_cus()) return d->N > 8 ? 8 : BWD_TL;
   return (d->N + groups - 1) / groups;
 }

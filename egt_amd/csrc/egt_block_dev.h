@@ -437,7 +437,9 @@ __device__ __forceinline__ void bwd_prologue_compute(const BlockArgs& a, float* 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 4 * q + r;
-      qd[row * QD_LD + 64 + pos] = acc[r];
+      // the kernels stage a.TL (<= 16) rows and put other buffers right behind them: rows past the group's last one are not
+      // qd's to write (an unguarded store here raced with the weight slabs that k_block_bwd_v4r fills next, at TL < 16)
+      if (row < nv) qd[row * QD_LD + 64 + pos] = acc[r];
       float pr = acc[r] * va[r];
       pr += lane_xor<8>(pr);   // the tile's two k values of head p & 7
       if (p < 8) dlp[(wave * 16 + row) * 8 + p] = pr;
@@ -451,7 +453,7 @@ __device__ __forceinline__ void bwd_prologue_compute(const BlockArgs& a, float* 
     if (D64 || t < Dh) a.sbo[(size_t)wg * Dh + t] = s0 + s1;
   }
   __syncthreads();
-  if (t < 128) {   // delta of (row, head)
+  if (t < 128 && (t >> 3) < nv) {   // delta of (row, head)
     const int row = t >> 3, hd = t & 7;
     qd[row * QD_LD + 128 + hd * 4 + 2] = (dlp[(0 * 16 + row) * 8 + hd] + dlp[(1 * 16 + row) * 8 + hd]) +
                                          (dlp[(2 * 16 + row) * 8 + hd] + dlp[(3 * 16 + row) * 8 + hd]);

@@ -1,5 +1,6 @@
 // C-ABI plumbing: per-thread error string, version, per-kernel HIP-event timing.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -47,6 +48,24 @@ hipEvent_t get_event() {
   return e;
 }
 }  // namespace
+
+// ---- EGT_DEBUG_POISON_LDS (egt_common.h) ----------------------------------------
+__global__ void __launch_bounds__(256) k_debug_poison_lds() {
+  extern __shared__ unsigned poison_sm[];
+  for (int i = threadIdx.x; i < 160 * 256; i += 256) poison_sm[i] = 0x7FC00BADu;   // quiet NaN
+  __syncthreads();
+  if (poison_sm[(threadIdx.x * 37) % (160 * 256)] != 0x7FC00BADu) __builtin_trap();   // (keeps the stores)
+  for (int i = 0; i < 200; ++i) __builtin_amdgcn_s_sleep(100);   // long enough that every CU takes workgroups of this launch
+}
+int egt_debug_poison_enabled() {
+  static const int on = [] { const char* v = getenv("EGT_DEBUG_POISON_LDS"); return (v && v[0] && v[0] != '0') ? 1 : 0; }();
+  return on;
+}
+void egt_debug_poison_lds(hipStream_t s) {
+  static bool once = false;
+  if (!once) { once = true; (void)hipFuncSetAttribute((const void*)k_debug_poison_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+  hipLaunchKernelGGL(k_debug_poison_lds, dim3(1024), dim3(256), 160 * 1024, s);   // one workgroup fills a CU's whole LDS
+}
 
 int egt_prof_is_enabled() { return g_enabled; }
 

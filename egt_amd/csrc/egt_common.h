@@ -116,8 +116,15 @@ struct EgtProfScope {
     }                                                                                                      \
   } while (0)
 
+// EGT_DEBUG_POISON_LDS=1 (debugging aid, read once): every launch is preceded by a kernel that fills the LDS of every CU with NaN
+// bit patterns, so a kernel that consumes LDS it never wrote (stale contents of whatever ran before: results that change with
+// the launch history) produces NaNs deterministically.  egt_capi.hip.
+int egt_debug_poison_enabled();
+void egt_debug_poison_lds(hipStream_t s);
+
 #define EGT_LAUNCH(name, kernel, grid, block, lds, stream, ...)            \
   do {                                                                      \
+    if (egt_debug_poison_enabled()) egt_debug_poison_lds(stream);           \
     EgtProfScope ps__(name, stream);                                        \
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);      \
   } while (0)

@@ -64,6 +64,25 @@ def test_backward_rows_per_workgroup(rows):
     _run({"EGT_BWD_TL": rows, "EGT_NO_NARROW_BWD": "1"})
 
 
+WIDE = ["tests/test_block_gpu.py::test_stack_call_vs_oracle", "tests/test_block_gpu.py::test_block_fused_vs_oracle",
+        "tests/test_block_gpu.py::test_stack_bf16_edge_tensors_vs_oracle", "tests/test_block_gpu.py::test_fused_in_kernel_random_mask",
+        "tests/test_graph_gpu.py"]
+
+
+@pytest.mark.parametrize("rows", ["16", "5"])
+def test_backward_rows_per_workgroup_every_edge_width(rows):
+    """Every backward pair kernel takes 4 .. 16 query rows per workgroup; the tiny test batches select 8-row groups by default
+    (bwd_rows_per_wg: a launch that leaves workgroup slots empty takes shorter groups), so the 16-row geometry of the full-size
+    launches (the headline's) and an odd size are forced here for the De >= 16 kernels too."""
+    env = dict(os.environ, EGT_BWD_TL=rows)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + WIDE,
+                       cwd=REPO, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    assert " passed" in r.stdout
+
+
 # ---- the less-travelled branches of the De = 8 kernels, in process (default selection) -----------------------------
 import torch  # noqa: E402
 

@@ -36,10 +36,15 @@ def assert_close(actual, ref, *, rtol, arel, name="", floor=0.0, l2=None, zero_a
     bad = err > tol
     if bad.any():
         i = int(torch.argmax(err - tol))
+        where = ""
+        if a.dim() >= 2:   # which slices hold the bad elements (a wrong row group / column tile reads differently from noise)
+            idx = bad.nonzero()
+            where = "; bad indices per axis: " + " | ".join(
+                f"axis{ax}: {sorted(set(idx[:, ax].tolist()))[:24]}" for ax in range(a.dim()) if a.shape[ax] <= 4096)
         raise AssertionError(
             f"{name}: {int(bad.sum())}/{a.numel()} elements out of tolerance; worst err "
             f"{float(err.flatten()[i]):.3e} (ref {float(r.flatten()[i]):.6e}, got {float(a.flatten()[i]):.6e}, "
-            f"max|ref| {scale:.3e})")
+            f"max|ref| {scale:.3e}){where}")
     if l2 is not None:
         rn = float(r.norm())
         if rn > 0 and scale >= floor:
