@@ -1,4 +1,4 @@
-// Device helpers shared by the pair kernels of the fused attention block (egt_block.hip: MFMA-tile kernels;
+// Device helpers shared by the pair kernels of the fused attention block (egt_block_fwd.h / egt_block_bwd.h: MFMA-tile kernels;
 // egt_narrow.hip: De = 8 VALU kernels): mask application in the reference order, the node-side epilogue of the
 // forward and the node-side prologue of the backward.
 #pragma once

@@ -5,7 +5,7 @@
 //   k_node_bwd      : [layer l] dQKV -> d(h_ln) -> LN backward -> dh ; bias / LN-parameter sums
 //                     [layer l-1] dV_att = dh.Wo^T (packed), delta = sum_k dV_att*V_att
 //                     (on the headline geometry both run as the prologue of the backward pair
-//                      kernel, egt_block.hip:bwd_node_prologue; this kernel then only closes the chain)
+//                      kernel, egt_block_dev.h:bwd_node_prologue; this kernel then only closes the chain)
 //   k_node_wgrads   : dWqkv, dWo of every layer in one launch (deferred, off the critical path)
 //   k_sum_segments  : deterministic reduction of all per-workgroup partials
 //   k_edge_param_grads : T,s,R -> grads of norm_edge / attention_gates / dense_edge_b / dense_edge_r
