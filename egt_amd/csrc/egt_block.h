@@ -20,6 +20,7 @@ struct BlockArgs {
   int TL, NLR;  // backward: query rows per workgroup, row-ranges per graph
   int NQP;      // backward: dQ partials per row (key tiles) in dqp [B][NQP][N][64]
   int epi;      // forward epilogue in k_block_fwd: 0 none, 1 dense_mha+res, 2 + next block's norm_mha/dense_qkv
+  int RGF;      // k_block_fwd: query rows per workgroup (<= 16)
   int xcd;      // pair kernels: XCD-aware workgroup order
   // backward prologue of k_block_bwd_v4 (Dh = 64): the node-side step between two pair kernels is
   // done per 16-row workgroup inside the lower layer's kernel.  pro = 0: dV_att / delta come from

@@ -48,7 +48,7 @@
 // Run-time switches (read ONCE per process: the launch path does no getenv()) -- the complete list, see README.md:
 //   EGT_NO_NARROW / EGT_NO_NARROW_FWD / EGT_NO_NARROW_BWD: De = 8 falls back from the De = 8 pair kernels (egt_narrow.hip) to the
 //     MFMA-tile kernels (tests exercise both);  EGT_BWD_MATMUL=bf16x3: the backward's channel contractions as 3-term bf16 split
-//     products (opt-in; default exact fp32);  EGT_BWD_TL: query rows per backward workgroup (tests / sweeps).
+//     products (opt-in; default exact fp32);  EGT_BWD_TL / EGT_FWD_ROWS: query rows per backward / forward workgroup (tests / sweeps).
 struct EgtBlockEnv {
   bool no_narrow_fwd, no_narrow_bwd;
   int bwd_mm;
@@ -272,7 +272,18 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   if (!(kvl && node_fused_ok(a))) a.epi = 0;
   const bool ml = a.M != nullptr || a.rm != nullptr;
   a.guard = 0;   // (the always-taken phase branches of the kernels only shape hipcc's scheduling regions)
-  const dim3 grid(a.B * lgroups), block(256);
+  // k_block_fwd: 16 query rows per workgroup (four per wave); a launch that leaves workgroup slots empty (two per CU) takes
+  // more, shorter groups -- whole multiples of four rows, so the waves stay balanced -- while they fit one round
+  // (ZINC-100K, B = 128, N = 37: 3 x 16 rows = 384 workgroups -> 4 x 12 rows = 512: the longest wave walks 3 rows instead of 4)
+  a.RGF = 16;
+  {
+    static const int forced = getenv("EGT_FWD_ROWS") ? atoi(getenv("EGT_FWD_ROWS")) : 0;   // 4 .. 16 (tests)
+    int g = (2 * egt_device_cus()) / (a.B > 0 ? a.B : 1);
+    if (g > (a.N + 7) / 8) g = (a.N + 7) / 8;
+    if (g > lgroups) a.RGF = (((a.N + g - 1) / g + 3) / 4) * 4;
+    if (forced >= 4 && forced <= 16) a.RGF = forced;
+  }
+  const dim3 grid(a.B * ((a.N + a.RGF - 1) / a.RGF)), block(256);
   const size_t lds = lds_tiles + (kvl ? lds_kv : 0);
 #define FWD_VARIANT_T(KVL_, ML_, FULL_, BF_)                                                           \
   do {                                                                                                 \

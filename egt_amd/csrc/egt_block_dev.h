@@ -128,8 +128,8 @@ __device__ __forceinline__ float reduce16_keep_own(const float (&v)[16], int p) 
 // biases and inputs read as zero, their outputs are never stored, the LayerNorm divides by Dh and keeps them at zero.  D64: Dh is
 // the compile-time 64 of the headline geometry (no guards).
 template <bool D64>
-__device__ __forceinline__ void fwd_node_epilogue_t(const BlockArgs& a, float* sm, float* qs, int b, int lg, int N,
-                                                    int wave, int p, int q) {
+__device__ __forceinline__ void fwd_node_epilogue_t(const BlockArgs& a, float* sm, float* qs, int b, int l0, int nrows, int N,
+                                                    int wave, int p, int q) {   // rows [l0, l0 + nrows) of graph b, nrows <= 16 (<= 0: nothing to store)
     const int Dh = D64 ? 64 : a.Dh, D3 = 3 * Dh;
     float wo[16], wq[3][16];
     const int c = wave * 16 + p;
@@ -148,7 +148,7 @@ __device__ __forceinline__ void fwd_node_epilogue_t(const BlockArgs& a, float* s
     const float bo = cok ? a.bo[c] : 0.f;
     float hres[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) hres[r] = cok ? a.h[((size_t)b * N + min(lg * 16 + 4 * q + r, N - 1)) * Dh + c] : 0.f;
+    for (int r = 0; r < 4; ++r) hres[r] = cok ? a.h[((size_t)b * N + min(l0 + 4 * q + r, N - 1)) * Dh + c] : 0.f;
     __syncthreads();   // every row's V_att is in qs; the tile area is idle from here on
     float* hs = sm;    // [16][QS_LD]
     v4f acc = {bo, bo, bo, bo};
@@ -156,9 +156,9 @@ __device__ __forceinline__ void fwd_node_epilogue_t(const BlockArgs& a, float* s
     for (int s = 0; s < 16; ++s) acc = MFMA(qs[p * QS_LD + 4 * s + q], wo[s], acc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = 4 * q + r, l = lg * 16 + row;
+      const int row = 4 * q + r, l = l0 + row;
       const float hv = acc[r] + hres[r];
-      if (l < N && cok) a.h_out[((size_t)b * N + l) * Dh + c] = hv;
+      if (row < nrows && cok) a.h_out[((size_t)b * N + l) * Dh + c] = hv;
       hs[row * QS_LD + c] = hv;
     }
     if (a.epi == 2) {
@@ -193,16 +193,16 @@ __device__ __forceinline__ void fwd_node_epilogue_t(const BlockArgs& a, float* s
         const int pos = sx * 64 + (hh >> 1) * 16 + kk * 2 + (hh & 1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int l = lg * 16 + 4 * q + r;
-          if (l < N) a.nx_qkvp[((size_t)b * N + l) * QKVP + pos] = aq[r];   // (padding columns store the zeros the pair kernels expect there)
+          const int l = l0 + 4 * q + r;
+          if (4 * q + r < nrows) a.nx_qkvp[((size_t)b * N + l) * QKVP + pos] = aq[r];   // (padding columns store the zeros the pair kernels expect there)
         }
       }
     }
   }
-__device__ __forceinline__ void fwd_node_epilogue(const BlockArgs& a, float* sm, float* qs, int b, int lg, int N,
+__device__ __forceinline__ void fwd_node_epilogue(const BlockArgs& a, float* sm, float* qs, int b, int l0, int nrows, int N,
                                                   int wave, int p, int q) {
-  if (a.Dh == 64) fwd_node_epilogue_t<true>(a, sm, qs, b, lg, N, wave, p, q);
-  else fwd_node_epilogue_t<false>(a, sm, qs, b, lg, N, wave, p, q);
+  if (a.Dh == 64) fwd_node_epilogue_t<true>(a, sm, qs, b, l0, nrows, N, wave, p, q);
+  else fwd_node_epilogue_t<false>(a, sm, qs, b, l0, nrows, N, wave, p, q);
 }
 
 // the barriers of fwd_node_epilogue, for waves of a workgroup that take no part in it (a.epi is uniform)

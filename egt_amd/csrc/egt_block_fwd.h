@@ -22,9 +22,11 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 15, q = lane >> 4;
   const int N = a.N;
-  const int lgroups = (N + 15) / 16;
+  const int RG = a.RGF;   // query rows per workgroup (<= 16; launch_fwd: fewer when the launch would leave workgroup slots empty)
+  const int lgroups = (N + RG - 1) / RG;
   const int wg = a.xcd ? egt_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int b = wg / lgroups, lg = wg % lgroups;
+  const int l0 = lg * RG, nlr = min(RG, N - l0);   // the group's rows [l0, l0 + nlr)
   float* tl0 = sm + wave * 2 * G::TILE_FLOATS;  // two tiles per wave (ping-pong)
   float* kvs = sm + 8 * G::TILE_FLOATS;         // [N][KV_LD]   (KVL)
   float* qs = kvs + (KVL ? N * KV_LD : 0);     // [16][QS_LD]  (KVL)
@@ -40,7 +42,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
           *reinterpret_cast<const float4*>(src + (size_t)row * QKVP + 64 + f * 4);
     }
     for (int i = threadIdx.x; i < 16 * 16; i += 256) {
-      const int row = i >> 4, f = i & 15, l = min(lg * 16 + row, N - 1);
+      const int row = i >> 4, f = i & 15, l = min(l0 + row, N - 1);
       *reinterpret_cast<float4*>(qs + row * QS_LD + f * 4) =
           *reinterpret_cast<const float4*>(src + (size_t)l * QKVP + f * 4);
     }
@@ -68,7 +70,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
 
   const int ntile = (N + 15) / 16;
   int nrows = 0;
-  for (int li = 0; li < 4; ++li) nrows += (lg * 16 + wave + 4 * li < N) ? 1 : 0;
+  for (int li = 0; li < 4; ++li) nrows += (wave + 4 * li < nlr) ? 1 : 0;
   const int total = nrows * ntile;
 
   // e tiles in flight per wave.  A De <= 16 tile is 0.5 - 1 KB, so narrow tiles travel PFD
@@ -79,7 +81,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
   TileRegs<DE> ring[PFD];
   auto prefetch = [&](TileRegs<DE>& tr, int it) {
     if (PFD > 1) it = min(it, total - 1);
-    const int l = lg * 16 + wave + 4 * (it / ntile), m0 = (it % ntile) * 16;
+    const int l = l0 + wave + 4 * (it / ntile), m0 = (it % ntile) * 16;
     const size_t pair0 = ((size_t)b * N + l) * N + m0;
     tile_gload<DE>(tr, e_in + pair0 * DE, lane, FULL ? 16 : min(16, N - m0));
   };
@@ -93,7 +95,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
     const bool live = PFD == 1 || it_ < total;
     const int it = PFD == 1 ? it_ : min(it_, total - 1);
     const int li = it / ntile, mt = it % ntile;
-    const int l = lg * 16 + wave + 4 * li, m0 = mt * 16, m = m0 + p;
+    const int l = l0 + wave + 4 * li, m0 = mt * 16, m = m0 + p;
     const bool valid = FULL ? true : (m < N);
     const int rows_valid = FULL ? 16 : min(16, N - m0);
     const size_t rowl = (size_t)b * N + l;
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
     float* tl = tl0 + (it_ & 1) * G::TILE_FLOATS;
     lds_sync();
     if (it_ > 0 && live) {   // stream out e' of the previous tile from the other buffer
-      const int itp = it - 1, lp = lg * 16 + wave + 4 * (itp / ntile), m0p = (itp % ntile) * 16;
+      const int itp = it - 1, lp = l0 + wave + 4 * (itp / ntile), m0p = (itp % ntile) * 16;
       tile_from_lds<DE>(tl0 + (itp & 1) * G::TILE_FLOATS, e_o + (((size_t)b * N + lp) * N + m0p) * DE,
                         lane, FULL ? 16 : min(16, N - m0p));
     }
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
   //   epi >= 1: h' = V_att.Wo + bo + h                      (dense_mha + res_mha, :136,140)
   //   epi == 2: qkv of the NEXT block = LN(h').Wqkv' + bqkv' (norm_mha + dense_qkv, :109,113), packed
   // Contraction order k = 4s + q on both MFMA operands; weights come straight from L2.
-  if (KVL && a.epi) fwd_node_epilogue(a, sm, qs, b, lg, N, wave, p, q);
+  if (KVL && a.epi) fwd_node_epilogue(a, sm, qs, b, l0, nlr, N, wave, p, q);
 }
 
 // ---------------------------------------------------------------- forward, narrow edge channels ---
@@ -445,6 +447,6 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_fwd_r4(BlockArgs a) {
     }
   }
   // each 16-row half runs the 4-wave epilogue on its own rows (staging area hs = its own tiles)
-  if (a.epi) fwd_node_epilogue(a, sm + hf * 16 * QS_LD, qs + hf * 16 * QS_LD, b, lg * (RW / 16) + hf, N, wv, p, q);
+  if (a.epi) fwd_node_epilogue(a, sm + hf * 16 * QS_LD, qs + hf * 16 * QS_LD, b, lg * RW + hf * 16, min(16, N - (lg * RW + hf * 16)), N, wv, p, q);
 }
 

@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
   NSTMP(2);   // sync + merge of the key quarters
   // node-side epilogue on the 16 rows (its own lane roles: MFMA layout); its staging rows reuse the merge area
   if (a.epi && !(NRW_ABL & 32)) {
-    if (NW == 4 || wave < 4) fwd_node_epilogue(a, sm, qs, b, lg, N, wave, lane & 15, lane >> 4);
+    if (NW == 4 || wave < 4) fwd_node_epilogue(a, sm, qs, b, lg * 16, min(16, N - lg * 16), N, wave, lane & 15, lane >> 4);
     else fwd_node_epilogue_idle(a);   // the epilogue is four waves' work: the others only meet its barriers
   }
 #ifdef NRW_TIMING

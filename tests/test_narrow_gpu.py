@@ -83,6 +83,19 @@ def test_backward_rows_per_workgroup_every_edge_width(rows):
     assert " passed" in r.stdout
 
 
+@pytest.mark.parametrize("rows", ["16", "13", "4"])
+def test_forward_rows_per_workgroup(rows):
+    """k_block_fwd takes 4 .. 16 query rows per workgroup (launch_fwd: the tiny test batches select shorter groups than the
+    full-size launches, which take 16); forced here: the headline's 16, an odd size, and one row per wave."""
+    env = dict(os.environ, EGT_FWD_ROWS=rows)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + WIDE,
+                       cwd=REPO, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    assert " passed" in r.stdout
+
+
 # ---- the less-travelled branches of the De = 8 kernels, in process (default selection) -----------------------------
 import torch  # noqa: E402
 
