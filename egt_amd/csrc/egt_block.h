@@ -87,6 +87,6 @@ void egt_node_launch_pre(BlockArgs& a, hipStream_t st);
 void egt_node_launch_post(BlockArgs& a, hipStream_t st);
 void egt_node_launch_bwd(BlockArgs& a, const BlockArgs* dv_layer, bool do_pre, hipStream_t st);
 void egt_node_launch_wgrads(BlockArgs* as, int n, hipStream_t st);   // n <= 64 layers
-int egt_node_wgrad_chunks(int rows);
+int egt_node_wgrad_chunks(int rows, int layers);   // row chunks (= partial slots in wpart) of a k_node_wgrads launch over `layers` layers
 void egt_node_launch_prep(BlockArgs* as, int n, hipStream_t st);   // n <= 64 layers
 void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, hipStream_t st);

@@ -167,7 +167,7 @@ static BlockLayout layout(const egt_block_desc* d) {
     L.spart = o; o += al(nmax * (5 * Dh));
     L.sbo = o; o += al(nmax * Dh);
   }
-  L.wpart = o; o += al((size_t)egt_node_wgrad_chunks((int)rows) * (Dh * 3 * Dh + Dh * Dh));
+  L.wpart = o; o += al((size_t)egt_node_wgrad_chunks((int)rows, 1) * (Dh * 3 * Dh + Dh * Dh));
   L.ered = o; o += al(L.EP);
   L.dqkv = o; o += al(rows * 3 * Dh);
   L.dhbuf = o; o += al(rows * Dh);

@@ -558,7 +558,7 @@ __global__ void __launch_bounds__(512, 2) k_node_bwd(BlockArgs a, NodeBwdArgs x)
 // Partials [layer][chunk][Dh*3Dh + Dh*Dh] are reduced by k_sum_segments.
 #define WG_ROWS 128
 struct WGradLayer { const float *h, *nm_g, *nm_b, *dqkv, *v_att, *dh_out; float* part; };
-struct WGradArgs { WGradLayer L[64]; int rows, Dh; float ln_eps; };
+struct WGradArgs { WGradLayer L[64]; int rows, Dh, rows_per_wg; float ln_eps; };
 
 template <bool D64>   // D64: Dh == 64, every tile exists -> no guards around the MFMAs
 __global__ void __launch_bounds__(512, 4) k_node_wgrads(WGradArgs wa) {
@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(512, 4) k_node_wgrads(WGradArgs wa) {
   for (int j = 0; j < 6; ++j) accW[j] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 2; ++j) accO[j] = (v4f){0.f, 0.f, 0.f, 0.f};
-  const int rbeg = blockIdx.x * WG_ROWS, rend = min(wa.rows, rbeg + WG_ROWS);
+  const int rbeg = blockIdx.x * wa.rows_per_wg, rend = min(wa.rows, rbeg + wa.rows_per_wg);
   // per-thread 16-byte units of a 32-row step: one of h / v_att / dh' each, three of dQKV.  The
   // loads of step i+1 are issued before the arithmetic of step i (register prefetch); addresses
   // are clamped so that every load is unconditional, rows past the end are zeroed at the LDS store
@@ -818,20 +818,30 @@ void egt_node_launch_bwd(BlockArgs& a, const BlockArgs* dv_layer, bool do_pre, h
 #undef NODE_BWD
 }
 
-int egt_node_wgrad_chunks(int rows) { return (rows + WG_ROWS - 1) / WG_ROWS; }
+// Node rows per workgroup of k_node_wgrads: WG_ROWS, or more (whole 32-row steps) when that keeps the launch's
+// (chunks x layers) workgroups within ONE round of the two workgroups per CU its 57 KB of LDS allow -- the headline's ten layers
+// of 8 192 rows are 640 workgroups of four steps at 128 rows (a second, quarter-full round) and 430 of six steps at 192.
+// `layers` = 1 gives the largest chunk count (what the workspace layout reserves).
+static int wgrad_rows_per_wg(int rows, int layers) {
+  int per_layer = (2 * egt_device_cus()) / (layers > 0 ? layers : 1);
+  if (per_layer < 1) per_layer = 1;
+  const int r = (((rows + per_layer - 1) / per_layer + 31) / 32) * 32;
+  return r < WG_ROWS ? WG_ROWS : r;
+}
+int egt_node_wgrad_chunks(int rows, int layers) { const int r = wgrad_rows_per_wg(rows, layers); return (rows + r - 1) / r; }
 
 // deferred GEMM-shaped weight gradients of `n` layers (n <= 64) in one launch
 void egt_node_launch_wgrads(BlockArgs* as, int n, hipStream_t st) {
   WGradArgs wa{};
   const BlockArgs& a0 = as[0];
-  wa.rows = a0.B * a0.N; wa.Dh = a0.Dh; wa.ln_eps = a0.ln_eps;
+  wa.rows = a0.B * a0.N; wa.Dh = a0.Dh; wa.ln_eps = a0.ln_eps; wa.rows_per_wg = wgrad_rows_per_wg(wa.rows, n);
   for (int l = 0; l < n; ++l) {
     const BlockArgs& a = as[l];
     wa.L[l] = WGradLayer{a.h, a.nm_g, a.nm_b, a.dqkv_sv, a.v_att, a.dh_out, a.wpart};
   }
   const int Dh = a0.Dh;
   const size_t lds = ((size_t)3 * 32 * (Dh + 16) + (size_t)32 * (3 * Dh + 16)) * 4;
-  const dim3 grid(egt_node_wgrad_chunks(wa.rows), n);
+  const dim3 grid(egt_node_wgrad_chunks(wa.rows, n), n);
   if (Dh == 64) EGT_LAUNCH("k_node_wgrads", k_node_wgrads<true>, grid, dim3(512), lds, st, wa);
   else EGT_LAUNCH("k_node_wgrads", k_node_wgrads<false>, grid, dim3(512), lds, st, wa);
 }
@@ -861,7 +871,7 @@ void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, hipStream
     for (int l = l0; l < l0 + nl; ++l) {
       BlockArgs& a = as[l];
       const int Dh = a.Dh, D3 = 3 * Dh, SP = D3 + 2 * Dh;
-      const int nwc = egt_node_wgrad_chunks(a.B * a.N), WS = Dh * D3 + Dh * Dh;
+      const int nwc = egt_node_wgrad_chunks(a.B * a.N, n), WS = Dh * D3 + Dh * Dh;   // (n: the layer count k_node_wgrads was launched with)
       seg(a.wpart, a.g_Wqkv, Dh * D3, nwc, WS);
       seg(a.wpart + Dh * D3, a.g_Wo, Dh * Dh, nwc, WS);
       seg(a.spart, a.g_bqkv, D3, a.spart_n, SP);          // written by k_node_bwd or by the pair kernel's prologue
