@@ -109,6 +109,12 @@ def main():
         out.append("")
     out.append("Reading the counters (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 "
                "FETCH_SIZE reports half of the bytes of a wide coalesced streaming read, so it is doubled.\n")
+    out.append("Reading the durations: the `avg duration (ns)` column of the counter passes (kernels serialised by the counter "
+               "collection) agrees with bench.py's hipEvent figure (`roofline.avg_launch_us`) to 1-3 %; the plain `--kernel-trace` "
+               "table is 6-10 % above both for the back-to-back pair kernels of a stack (rounds 3 and 4 alike: 105.8-110.7 us "
+               "against 98-103 us for `k_block_bwd_v5`) -- a dispatch's start timestamp precedes the drain of the previous kernel "
+               "on the same queue, so consecutive launches overlap in the trace; the first pair kernel of each backward chain, "
+               "which follows a short kernel, is the shortest in the trace.\n")
     ptf = os.path.join(REPO, "profiles", "pmc_traffic.json")
     try:
         pt = json.load(open(ptf))
