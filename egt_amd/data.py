@@ -233,18 +233,25 @@ def svd_features(A: np.ndarray, num_features=None, mult_sing_vals=True, norm_fir
 
 def eigen_features(edges, n: int, dim: int, sparse=True) -> np.ndarray:
     """Laplacian positional encoding of one graph (what lib/data/eigen_gt.py:6-57 produces): columns 1..dim of the
-    eigenvector matrix of the symmetric normalised Laplacian L = I - D^-1/2 W D^-1/2, ascending eigenvalue, where W counts
-    the edge multiplicities of the edge list and isolated nodes get degree 1.  L is real symmetric, so the dense symmetric
-    eigensolver gives the whole spectrum exactly and deterministically (the reference's ARPACK call at tol 1e-2 returns the
-    same subspace up to its tolerance and to the sign of each vector, which the model randomises anyway); `sparse` is kept
-    for signature compatibility and only switches to the iterative solver for graphs too large for a dense
-    factorisation."""
+    eigenvector matrix of the normalised Laplacian L = I - D^-1/2 W D^-1/2 (row degrees, isolated nodes get degree 1), ascending
+    eigenvalue, where W counts the edge multiplicities of the edge list.
+    * Symmetric edge list (ZINC, PATTERN: every edge is stored in both directions): L is real symmetric, and the dense symmetric
+      eigensolver gives the whole spectrum exactly and deterministically (the reference's ARPACK call at tol 1e-2 returns the
+      same subspace up to its tolerance and to the sign of each vector, which the model randomises anyway).
+    * Directed edge list: L is NOT symmetric and its spectrum is not that of its symmetric part; the reference's dense form is
+      followed as written (eigen_gt.py:54-56: np.linalg.eig, argsort of the complex eigenvalues, real part of the vectors).
+    `sparse` is kept for signature compatibility and only switches to the iterative solver for symmetric graphs too large for a
+    dense factorisation."""
     edges = np.asarray(edges).reshape(-1, 2)
     W = np.zeros((n, n), dtype=np.float64)
     np.add.at(W, (edges[:, 0], edges[:, 1]), 1.0)
     scale = 1.0 / np.sqrt(np.maximum(W.sum(axis=1), 1.0))
     L = np.eye(n) - scale[:, None] * W * scale[None, :]
-    L = 0.5 * (L + L.T)                       # a directed edge list gives an unsymmetric W: the symmetric part has the real spectrum
+    if not np.array_equal(W, W.T):
+        val, vec = np.linalg.eig(L)
+        vec = np.real(vec[:, np.argsort(val)])
+        return np.ascontiguousarray(vec[:, 1:dim + 1]).astype("float32")
+    L = 0.5 * (L + L.T)                       # (symmetric up to rounding: make it exactly so for eigh)
     if sparse and n > 4096:
         import scipy.sparse.linalg as spl
         val, vec = spl.eigsh(L, k=min(dim + 1, n - 1), which="SA")

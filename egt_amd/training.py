@@ -461,10 +461,17 @@ class ZincSVDScheme:
     @torch.no_grad()
     def load_weights(self, path):
         """model.load_weights(file, by_name=True) (:362): every variable the file names is copied; the others stay"""
+        missing = []
         with np.load(path) as z:
             for k, v in self._named().items():
                 if k in z.files:
                     v.copy_(torch.from_numpy(z[k]).to(v.device))
+                else:
+                    missing.append(k)
+        if missing:   # by_name loading is silent about these in Keras; a run that continues from a partial file should say so
+            self.print(f"load_weights: {len(missing)} variable(s) not in {path} keep their current values: " + ", ".join(missing[:8]) +
+                       (" ..." if len(missing) > 8 else ""))
+        return missing
 
     def config_summary(self):
         for k, v in self.config.get_dict().items():
@@ -503,7 +510,10 @@ class ZincSVDScheme:
                 dict(num_svd_features=c.num_svd_features, use_svd=c.use_svd)
             self.dataset = dataset_for_scheme(self.SCHEME, c.dataset_path, max_shuffle_len=c.max_shuffle_len,
                                               splits=tuple(splits), seed=seed, **kw)
-            bs = {sp: c.batch_size * (1 if sp == "training" else c.prediction_bmult if len(splits) > 2 else 1) for sp in splits}
+            # training_base.py:202-206: evaluation / prediction runs batch EVERY split (the training split included) at
+            # batch_size * prediction_bmult; a training run batches every split at batch_size
+            mult = c.prediction_bmult if (getattr(self, "eval_flag", False) or getattr(self, "pred_flag", False)) else 1
+            bs = {sp: c.batch_size * mult for sp in splits}
             out = self.dataset.get_batched_data(bs, shard=shard)
             out = out if isinstance(out, tuple) else (out,)
             trainset, valset, testset = (list(out) + [None, None])[:3]

@@ -153,7 +153,8 @@ def test_fused_stack_matches_composed(gpu, egt_lib):
                                            (150, 8, 64, True), (144, 16, 64, False),   # 32-row workgroups of k_block_fwd_r4
                                            # node widths below 64 on the fused node side (zero-padded column tiles): ZINC-100K's
                                            # N = 37 / Dh = 48 (d = 6), two empty tiles (d = 4), a partial tile (d = 5), d = 1
-                                           (37, 48, 48, True), (40, 8, 32, True), (24, 16, 40, False), (20, 64, 8, False)])
+                                           (37, 48, 48, True), (40, 8, 32, True), (24, 16, 40, False), (20, 64, 8, False),
+                                           (40, 64, 64, True), (150, 64, 64, False)])   # De = 64 with several ragged row groups (k_block_bwd_v4)
 def test_stack_call_vs_oracle(N, De, Dh, train, gpu, egt_lib):
     """egt_stack_fwd/bwd (one C call per direction, deferred partial reduction) vs the fp64 oracle,
     including the per-layer in-kernel random masks."""

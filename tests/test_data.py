@@ -93,6 +93,24 @@ def test_eigen_features_are_laplacian_eigenvectors():
     assert np.allclose(P @ (P.T @ Vs), Vs, atol=5e-2)
 
 
+def test_eigen_features_of_a_directed_edge_list_follow_the_reference_dense_form():
+    """lib/data/eigen_gt.py:38-57 on an edge list that is not stored in both directions: L = I - D^-1/2 W D^-1/2 with ROW
+    degrees is not symmetric; the reference takes np.linalg.eig, sorts the (complex) eigenvalues and keeps the real part of
+    the vectors.  Restated here with scipy exactly as the reference writes it."""
+    import scipy.sparse as sp
+    edges = np.array([[0, 1], [1, 2], [2, 0], [2, 3], [3, 4], [4, 2], [1, 4]], dtype=np.int32)
+    n, dim = 5, 3
+    A = sp.csr_matrix((np.ones(len(edges), dtype="float32"), (edges[:, 0], edges[:, 1])), shape=(n, n), dtype="float32")
+    Nm = sp.diags(np.asarray(A.sum(axis=1)).squeeze().clip(1) ** -0.5, dtype=float)
+    L = (sp.eye(n) - Nm * A * Nm).toarray()
+    val, vec = np.linalg.eig(L)
+    ref = np.real(vec[:, val.argsort()])[:, 1:dim + 1].astype("float32")
+    got = D.eigen_features(edges, n, dim, sparse=False)
+    assert got.shape == ref.shape
+    for j in range(dim):   # an eigenvector is defined up to a (complex) phase: compare up to sign
+        assert np.allclose(got[:, j], ref[:, j], atol=1e-5) or np.allclose(got[:, j], -ref[:, j], atol=1e-5)
+
+
 # ---------------------------------------------------------------------------------------- store ---
 def test_packed_store_round_trip(tmp_path):
     path = _store(tmp_path, n_train=7, n_val=3)
