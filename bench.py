@@ -430,7 +430,9 @@ def main():
     ap.add_argument("--dominant", default="k_block_bwd",
                     help="kernel timed with hipEvents inside the timed region")
     ap.add_argument("--graph", default="auto", choices=["auto", "off", "on"],
-                    help="auto (default): on for the attention-block stack (the headline scope), off for the wider scopes.  "
+                    help="auto (default): for the attention-block stack (the headline scope) a few steps of BOTH step modes are timed after "
+                         "the warm-up and the faster one runs the timed region (config.step_mode; the other mode's figure is the line's "
+                         "secondary leg); off for the wider scopes.  "
                          "on: forward + backward of the step replayed from ONE captured hipGraph (egt_amd.graph.GraphedStep; the "
                          "random-mask seeds live in device memory, EGT_BF_SEED_DEVICE, and advance inside the graph, so every "
                          "replay draws a fresh sample); the gradient collective stays an eager call after the replay.  The "
@@ -452,7 +454,9 @@ def main():
     if args.scope == "layers":
         args.with_ffn = True
     if args.graph == "auto":     # the stack step is ~25 short launches: replayed as one hipGraph (bit-identical to the eager calls,
-        args.graph = "on" if (args.scope in ("", "stack") and not args.with_ffn) else "off"   # tests/test_graph_gpu.py); eager figure: `eager_step`
+        args.graph = "calibrate" if (args.scope in ("", "stack") and not args.with_ffn) else "off"   # tests/test_graph_gpu.py); "calibrate": a few steps of
+        # both modes are timed after the warm-up and the faster one runs the timed region (`config.step_mode`); the other mode's figure is the
+        # line's secondary leg.  Launch-bound small batches favour the replay, the full-size headline batch the eager stream.
     if args.scope == "model" and args.dominant == "k_block_bwd":
         args.dominant = "k_ffn_bwd"
 
@@ -621,6 +625,7 @@ def main():
     if args.graph == "on":               # from here on every EGT module reads its mask seed from HBM (eager steps too)
         from egt_amd import DeviceSeeds
         seeds = DeviceSeeds.attach(model, dev)
+    step_mode = None
 
     def eager_step():
         if seeds is not None:
@@ -647,7 +652,30 @@ def main():
         fence()
         assert flat_grad_view(params, model.grad_holder.flat)
     graphed = None
-    if args.graph == "on":
+
+    def time_steps(fn, n):               # calibration: n fenced steps, MAX over ranks (every rank must pick the same mode)
+        fence()
+        t_ = time.perf_counter()
+        for _ in range(n):
+            fn()
+        fence()
+        dt = time.perf_counter() - t_
+        if use_dist:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt / n * 1e3
+
+    eager_ms = None
+    if args.graph == "calibrate":
+        ncal = max(5, min(20, args.steps))
+        eager_ms = time_steps(eager_step, ncal)      # host-side mask seeds, one host call per kernel
+        from egt_amd import DeviceSeeds
+        seeds = DeviceSeeds.attach(model, dev)
+        for _ in range(2):
+            eager_step()
+        fence()
+    if args.graph in ("on", "calibrate"):
         from egt_amd import GraphedStep
         in_graph = bool(args.graph_collective and use_dist and state["flat_ok"] is not None and (state["flat_ok"] or state["fa"] is not None))
         if in_graph:                     # forward + backward + the RCCL all-reduce of the flat gradient buffer: one graph, one host call
@@ -667,6 +695,18 @@ def main():
         for _ in range(3):
             step()
         fence()
+        if args.graph == "calibrate":
+            graph_ms = time_steps(step, ncal)
+            step_mode = dict(chosen="graph" if graph_ms <= eager_ms else "eager", eager_ms_per_step=eager_ms, graph_ms_per_step=graph_ms,
+                             calibration_steps=ncal, rule="the faster of the two runs the timed region; outputs are bit-identical")
+            if graph_ms > eager_ms:          # back to host-side seeds and one host call per kernel
+                seeds.detach()
+                seeds = None
+                graphed = None
+                step = eager_step
+                for _ in range(2):
+                    step()
+                fence()
     # Timed region.  hipEvents bracket ONLY the dominant kernel's launches here (an event pair
     # around every launch costs ~15% of the step); the per-kernel table comes from a second,
     # untimed pass over the same steps below.
@@ -833,6 +873,7 @@ def main():
                        "hipgraph": (f"forward + backward{' + the gradient all-reduce' if state.get('collective_in_graph') else ''} replayed from one "
                                     f"captured hipGraph ({graphed.replays} replays), device-resident "
                                     "mask seeds; dominant kernel timed in the untimed eager pass") if graphed is not None else None,
+                       "step_mode": step_mode,
                        "collective_in_graph": bool(state.get("collective_in_graph"))},
             "roofline": roof, "cpu_baseline": cpu, ("eager_step" if graphed is not None else "hipgraph_replay"): graph_leg,
         }

@@ -41,6 +41,23 @@ def test_bench_one_rank_under_launcher_uses_rccl():
     assert line["value"] > 0 and line["scaling"] == "weak"
 
 
+def test_bench_default_calibrates_the_step_mode():
+    """--graph auto (the default) at stack scope: a few steps of the eager stream and of the hipGraph replay are timed after the
+    warm-up, the faster mode runs the timed region, and the line says which one and by how much (config.step_mode); the other
+    mode's figure travels as the secondary leg."""
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--layers", "2"]
+    r = subprocess.run(cmd, cwd=REPO, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    sm = line["config"]["step_mode"]
+    assert sm["chosen"] in ("eager", "graph") and sm["eager_ms_per_step"] > 0 and sm["graph_ms_per_step"] > 0
+    assert (sm["chosen"] == "graph") == (sm["graph_ms_per_step"] <= sm["eager_ms_per_step"])
+    assert (line["config"]["hipgraph"] is not None) == (sm["chosen"] == "graph")
+    other = "eager_step" if sm["chosen"] == "graph" else "hipgraph_replay"
+    assert other in line and line[other] and line[other].get("value", 0) > 0, line.get(other)
+    assert line["roofline"]["kernel"] == "k_block_bwd" and line["roofline"]["achieved"] > 0
+
+
 def test_bench_graph_replay_under_launcher_with_the_eager_collective():
     """--graph on: forward + backward replayed from one hipGraph, the RCCL collective issued eagerly after each replay"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
