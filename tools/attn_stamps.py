@@ -1,6 +1,9 @@
 #!/usr/bin/env python
 """Phase stamps of the MFMA inner-op kernels (build with EGT_ATTN_FLAGS=-DEGT_ATTN_STAMPS): per-phase s_memtime
-cycles of the eight waves of workgroup 0, one launch.  Usage: EGT_ATTN_FLAGS=-DEGT_ATTN_STAMPS python tools/attn_stamps.py [cfg]"""
+cycles of the eight waves of workgroup 0, one launch.  Usage: EGT_ATTN_FLAGS=-DEGT_ATTN_STAMPS python tools/attn_stamps.py [cfg]
+Caveat (round 4): hipcc rotates the forward's loop -- the S MFMAs open the loop body and the P.V MFMAs follow the barrier -- so the
+forward's per-phase figures are NOT phase times (the MFMAs are not where the source has them); use the ablation builds
+(-DEGT_ATTN_ABL=<bits>) for attribution and the stamps for totals / the loader waves."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
