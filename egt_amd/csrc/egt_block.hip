@@ -398,12 +398,16 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
         }
       }
       if constexpr (DE >= 32) {
-        if (full && !ml && !a.bf16) {   // LDS-DMA staged e tiles (k_block_bwd_v5)
+        if (!ml && !a.bf16) {   // LDS-DMA staged e tiles (k_block_bwd_v5), ragged N included
           const bool x3 = block_env().bwd_mm == EGT_MM_BF16X3;
-          EGT_MAX_LDS_ONCE(k_block_bwd_v5<DE, 0>);
-          EGT_MAX_LDS_ONCE(k_block_bwd_v5<DE, EGT_MM_BF16X3>);
-          if (x3) EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE, EGT_MM_BF16X3>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a);
-          else EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE, 0>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a);
+#define V5_LAUNCH(MM_, RAG_)                                                                                 \
+  do {                                                                                                       \
+    EGT_MAX_LDS_ONCE(k_block_bwd_v5<DE, MM_, RAG_>);                                                         \
+    EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE, MM_, RAG_>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a);   \
+  } while (0)
+          if (full) { if (x3) V5_LAUNCH(EGT_MM_BF16X3, false); else V5_LAUNCH(0, false); }
+          else { if (x3) V5_LAUNCH(EGT_MM_BF16X3, true); else V5_LAUNCH(0, true); }
+#undef V5_LAUNCH
           goto pair_done;
         }
       }

@@ -344,13 +344,15 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
 //  * de leaves from the registers that hold it (64-byte row segments, the four stores of a tile fill
 //    whole lines) instead of making an LDS round trip through a second de' buffer.
 // Same LDS footprint as v4 (two e buffers + one de' buffer instead of one + two): two workgroups per CU.
-// fp32 edge tensors, no mask tensors, N a multiple of 16, De a multiple of 16.
+// fp32 edge tensors, no mask tensors, De a multiple of 16.  RAG: N is not a multiple of 16 -- the last key tile has kv < 16 keys:
+// its e tiles are fetched with the missing rows replaced by the last valid one (tile_dma_ragged), its de' rows are zero-filled,
+// the lanes of the missing keys get probability and gate exactly 0 (so every product they enter is 0) and store nothing.
 // MM = EGT_MM_BF16X3 (opt-in: EGT_BWD_MATMUL=bf16x3): the three channel contractions of a tile (P1 projections,
 // P2 dH_ext, P5 d ehat: 48 of the 80 fp32 MFMAs) run as 3-term bfloat16 split products on the bf16 matrix pipe
 // (20 MFMAs of 16 cycles; per-product error 2^-16, fp32 accumulate); the weight-gradient contractions over the
 // pair axis (P4) and everything else stay exact fp32.  Same LDS footprint: a bf16 hi + lo pair is as large as the
 // fp32 value it replaces.
-template <int DE, int MM>
+template <int DE, int MM, bool RAG>
 __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   seed_from_device(a);
 #define PSTAMP(i) do {} while (0)
@@ -451,13 +453,16 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   __syncthreads();   // the prologue's scratch (= the tile area) is dead from here: DMA may land in it
   PSTAMP(2);
 
-  const int ntile = N / 16;
+  const int ntile = RAG ? (N + 15) / 16 : N / 16;
   for (int mt = wave; mt < ntile; mt += 4) {
     const int m0 = mt * 16, m = m0 + p;
+    const int kv = RAG ? min(16, N - m0) : 16;          // valid keys of the tile (wave-uniform)
+    const bool kvalid = RAG ? (p < kv) : true;
     // first e tile of this key tile: in flight while K / V are fetched
-    tile_dma<DE>(et_lds, e_in + (((size_t)b * N + l_begin) * N + m0) * DE, off0);
+    if (RAG && kv < 16) tile_dma_ragged<DE>(et_lds, e_in + (((size_t)b * N + l_begin) * N + m0) * DE, lane, kv);
+    else tile_dma<DE>(et_lds, e_in + (((size_t)b * N + l_begin) * N + m0) * DE, off0);
     float Kf[16], Vf[16], dKa[16], dVa[16];
-    const size_t rowm = (size_t)b * N + m;
+    const size_t rowm = (size_t)b * N + (RAG ? min(m, N - 1) : m);
     {
       const float4* kp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 64 + q * 16);
       const float4* vp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 128 + q * 16);
@@ -479,7 +484,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       MaskRegs mr{make_float2(1.f, 1.f), 0};
       // ---- de'(l): requested now, consumed after P1 ----
       TileRegs<DE> td;
-      tile_gload<DE>(td, dey_in + pair0 * DE, lane, 16);
+      tile_gload<DE>(td, dey_in + pair0 * DE, lane, kv);
       // ---- e(l) has been in flight for a whole iteration: retire it.  Younger operations of this wave:
       // row l-1's dQ-partial store and its NI de stores, then the NI de' loads just issued ----
       if (li == 0) vm_wait<0>(); else vm_wait<2 * ((G::NF4 + 63) / 64) + 1>();
@@ -514,11 +519,13 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
         }
       }
       SCHED_FENCE();
-      tile_lds_put<DE>(dt, td, lane, 16);   // (the compiler's own vmcnt wait for de' sits here)
+      tile_lds_put<DE>(dt, td, lane, kv);   // (the compiler's own vmcnt wait for de' sits here; rows past kv are zero-filled)
       lds_sync();
       // ---- e(l+1) -> the other e buffer (its last reader, row l-1's P5, retired its LDS reads) ----
-      if (l + 1 < l_end)
-        tile_dma<DE>(et_lds + (unsigned)(((li + 1) & 1) * G::TILE_FLOATS * 4), e_in + (pair0 + (size_t)N) * DE, off0);
+      if (l + 1 < l_end) {
+        if (RAG && kv < 16) tile_dma_ragged<DE>(et_lds + (unsigned)(((li + 1) & 1) * G::TILE_FLOATS * 4), e_in + (pair0 + (size_t)N) * DE, lane, kv);
+        else tile_dma<DE>(et_lds + (unsigned)(((li + 1) & 1) * G::TILE_FLOATS * 4), e_in + (pair0 + (size_t)N) * DE, off0);
+      }
       SCHED_FENCE();
       // ---- P2: dH_ext = de'.Wr^T ----
       v4f dhx = {0.f, 0.f, 0.f, 0.f};
@@ -580,10 +587,11 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
           gl[j] = acc[2 * j];
         }
         apply_masks<false>(a, kadd, mr, (pair0 + p) * BH, q, xl, gl);
+        if (RAG && !kvalid) { xl[0] = xl[1] = -3.0e38f; gl[0] = gl[1] = -3.0e38f; }   // a key past N: S = 0, gate = 0 (exactly)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float S = __expf(xl[j] - st[4 * j]) * st[4 * j + 1];
-          const float g = gated ? egt_sigmoid(gl[j]) : 1.0f;
+          const float g = (gated || (RAG && !kvalid)) ? egt_sigmoid(gl[j]) : 1.0f;
           const float dS = dAd[j] * g;
           const float dGl = gated ? dAd[j] * S * g * (1.0f - g) : 0.f;
           const float dH = S * (dS - st[4 * j + 2]) + dhx[j];
@@ -694,7 +702,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
             o.y = dyv.y + rstd * (dxh[t].y - m1 - xh.y * m2);
             o.z = dyv.z + rstd * (dxh[t].z - m1 - xh.z * m2);
             o.w = dyv.w + rstd * (dxh[t].w - m1 - xh.w * m2);
-            *reinterpret_cast<float4*>(orow + 16 * t) = o;
+            if (kvalid) *reinterpret_cast<float4*>(orow + 16 * t) = o;
           }
         }
         lds_sync();   // the tile reads above retire before the next iteration overwrites dt / DMAs into et
@@ -703,10 +711,12 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
     }
     float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
     float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
+    if (kvalid) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
-      vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
+      for (int i = 0; i < 4; ++i) {
+        ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
+        vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
+      }
     }
   }
 #pragma unroll

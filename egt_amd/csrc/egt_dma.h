@@ -49,6 +49,24 @@ __device__ __forceinline__ void tile_dma(unsigned lds, const float* src, unsigne
         : "=&s"(keep) : "s"(src), "v"(off0), "s"(lds) : "memory");
   (void)t;
 }
+// The same tile when fewer than 16 of its pair rows exist (the last key tile of a ragged N): rows past `rows_valid` would
+// lie in the NEXT query row of the tensor (past its end for the last one), so their pieces are fetched from the last valid row
+// instead -- finite stand-ins that the kernel's key-validity selects keep out of every result.  Same NI instructions as
+// tile_dma (the callers' counted vmcnt waits do not change).
+template <int DE>
+__device__ __forceinline__ void tile_dma_ragged(unsigned lds, const float* src, int lane, int rows_valid) {
+  using G = Geo<DE>;
+  constexpr int NI = G::NF4 / 64;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int f = 64 * i + lane, row = f / G::NSLOT, slot = f % G::NSLOT;
+    const int rc = min(row, rows_valid - 1);
+    const unsigned off = (unsigned)((rc * G::NSLOT + (DE == 64 ? (slot ^ swz<64>(row)) : slot)) << 4);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(src), "v"(off), "s"(lds + 1024u * i) : "memory");
+  }
+}
 // wait until at most N of the wave's vector-memory operations are outstanding (they retire in order)
 template <int N_>
 __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N_) : "memory"); }
