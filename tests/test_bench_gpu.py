@@ -51,7 +51,8 @@ def test_bench_default_calibrates_the_step_mode():
     line = _json_line(r.stdout)
     sm = line["config"]["step_mode"]
     assert sm["chosen"] in ("eager", "graph") and sm["eager_ms_per_step"] > 0 and sm["graph_ms_per_step"] > 0
-    assert (sm["chosen"] == "graph") == (sm["graph_ms_per_step"] <= sm["eager_ms_per_step"])
+    assert (sm["chosen"] == "graph") == (sm["graph_ms_per_step"] < 0.99 * sm["eager_ms_per_step"])
+    assert line["roofline"]["timed_in_region"] == (sm["chosen"] == "eager")
     assert (line["config"]["hipgraph"] is not None) == (sm["chosen"] == "graph")
     other = "eager_step" if sm["chosen"] == "graph" else "hipgraph_replay"
     assert other in line and line[other] and line[other].get("value", 0) > 0, line.get(other)
