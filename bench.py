@@ -54,6 +54,10 @@ WORKLOADS = {
     # ([QKV,E,G],mask) -> (V_att,H_hat) forward + backward on the MFMA inner-op kernels (egt_attn_mfma.hip), every key real
     "synthetic_n512": dict(B=8, N=512, Dh=512, De=32, H=8, Ly=1, nodes=(512, 512), rand_p=0.1, scope="core"),
     "synthetic_n512_b32": dict(B=32, N=512, Dh=512, De=32, H=8, Ly=1, nodes=(512, 512), rand_p=0.1, scope="core"),
+    # the same config at the BLOCK scope of SURVEY 8(d)(ii): (h, e, mask) -> (h', e') of ONE attention block, forward + backward with
+    # all parameter gradients.  d = 64 is outside the fused pair kernels (d <= 8): the composed path -- HIP edge projections / edge
+    # update (egt_edge.hip) + the MFMA inner op + rocBLAS node-side Dense
+    "synthetic_n512_block": dict(B=8, N=512, Dh=512, De=32, H=8, Ly=1, nodes=(512, 512), rand_p=0.1, scope="block"),
 }
 # what the metric string says after "graphs/sec EGT fwd+bwd, " (BASELINE.json's metric is quoted on the first)
 METRIC_OF = {"zinc500k_n64": "ZINC-500K padded N=64", "zinc500k_n64_b1024": "ZINC-500K padded N=64 (B=1024)",
@@ -61,7 +65,8 @@ METRIC_OF = {"zinc500k_n64": "ZINC-500K padded N=64", "zinc500k_n64_b1024": "ZIN
              "cifar10_n150": "CIFAR10-500K shapes padded N=150 (bf16 edge tensors)", "pattern500k_n120": "PATTERN-500K shapes padded N=120 (B=16)",
              "pattern500k_n120_b128": "PATTERN-500K shapes padded N=120 (B=128)", "cifar10_n150_pad160": "CIFAR10-500K shapes padded N=160",
              "pattern500k_n120_pad128_b128": "PATTERN-500K shapes padded N=128 (B=128)",
-             "synthetic_n512": "synthetic dense N=512 heads=8 d=64 (core op)", "synthetic_n512_b32": "synthetic dense N=512 heads=8 d=64 (core op, B=32)"}
+             "synthetic_n512": "synthetic dense N=512 heads=8 d=64 (core op)", "synthetic_n512_b32": "synthetic dense N=512 heads=8 d=64 (core op, B=32)",
+             "synthetic_n512_block": "synthetic dense N=512 heads=8 d=64 (block op)"}
 FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
 
 
@@ -187,12 +192,11 @@ def cpu_baseline_model(w, seconds=12.0, pattern=False):
                        f"(N={w['N']}, fp32, torch-CPU restatement, {dt:.1f}s, host has {os.cpu_count()} cpus)")
 
 
-def cpu_baseline(w, seconds=12.0):
+def cpu_baseline(w, seconds=12.0, Bs=8):
     """Reference-equivalent CPU path: the torch-CPU fp32 op-by-op restatement of
     the TF op sequence (oracle/egt_oracle.py), fwd+bwd by autograd, on the host
     cores.  Bounded sample of the same workload (fewer graphs per batch)."""
     from oracle import egt_oracle as O
-    Bs = 8
     ws = dict(w, B=Bs)
     h, e, mask, dh, de = make_inputs(ws, "cpu", seed=77)
     g = torch.Generator().manual_seed(3)
@@ -380,6 +384,111 @@ def run_core(args, w, dev, lib, rank, world, use_dist):
     print(json.dumps(line))
 
 
+def run_block(args, w, dev, lib, rank, world, use_dist):
+    """BASELINE config 5 at the block scope of SURVEY 8(d)(ii): a step = forward + backward of ONE EGTBlock (composed path) with
+    every parameter gradient, training mode with the in-kernel random mask; N > 1: batch-DP, the gradients all-reduced through one
+    flat buffer per step.  Roofline: the step's ALGORITHMIC flops (3 (6 N^2 De H + 8 N Dh^2 + 4 N^2 Dh) per graph)
+    against the fp32 matrix peak -- the scope is MFMA-bound by arithmetic intensity (34.7 flop/B) -- and the dominant HIP kernel's own."""
+    from egt_amd import EGTBlock
+    from egt_amd.dp import FlatGradAllReduce
+    B, N, H, Dh, De = w["B"], w["N"], w["H"], w["Dh"], w["De"]
+    g = torch.Generator().manual_seed(1234 + rank)
+    torch.manual_seed(7)                                  # the same parameters on every rank
+    blk = EGTBlock(model_width=Dh, edge_width=De, num_heads=H, random_mask_prob=w["rand_p"]).to(dev).train()
+    h = torch.randn(B, N, Dh, generator=g).to(dev).requires_grad_()
+    e = torch.randn(B, N, N, De, generator=g).to(dev).requires_grad_()
+    mask = torch.ones(B, N, dtype=torch.bool, device=dev)
+    dh = torch.randn(B, N, Dh, generator=g).to(dev); de = torch.randn(B, N, N, De, generator=g).to(dev)
+    params = [p for p in blk.parameters()]
+    fa = FlatGradAllReduce(params) if use_dist else None
+
+    def step():
+        h.grad = e.grad = None
+        if fa is not None:
+            fa.zero(); fa.rebind()
+        else:
+            for p in params:
+                p.grad = None
+        h2, e2 = blk(h, e, mask)
+        torch.autograd.backward([h2, e2], [dh, de])
+        if fa is not None:
+            fa.all_reduce(average=True, force=True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dominant = "k_attn_mfma_bwd_kv"
+    for _ in range(max(args.warmup, 6)):                  # rocBLAS picks its kernels on the first calls
+        step()
+    fence()
+    if not args.no_prof:
+        lib.egt_prof_filter(dominant.encode()); lib.egt_prof_enable(2)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.egt_prof_enable(0)
+    graphs_step = B
+    if use_dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+        gs = torch.tensor([B], device=dev, dtype=torch.int64)
+        dist.all_reduce(gs); graphs_step = int(gs.item())
+    dom_prof = prof_read_all(lib) if not args.no_prof else {}
+    prof = {}
+    if not args.no_prof:
+        lib.egt_prof_filter(b""); lib.egt_prof_enable(2)
+        for _ in range(min(args.steps, 10)):
+            step()
+        fence()
+        lib.egt_prof_enable(0)
+        prof = prof_read_all(lib)
+    if rank != 0:
+        return
+    pairs = B * N * N
+    step_s = elapsed / args.steps
+    flops_blk = 3.0 * (6.0 * pairs * De * H + 8.0 * B * N * Dh * Dh + 4.0 * pairs * Dh)
+    bytes_blk = B * (5.0 * N * N * De * 4 + 6.0 * N * Dh * 4)
+    fl = {"k_attn_mfma_fwd": 4.0 * pairs * Dh, "k_attn_mfma_bwd_kv": 6.0 * pairs * Dh, "k_attn_mfma_bwd_q": 2.0 * pairs * Dh}
+    roof = None
+    if prof and dominant in prof:
+        cnt, ms = dom_prof.get(dominant, prof[dominant])
+        avg_s = ms / cnt / 1e3
+        hip_ms = sum(v[1] / v[0] * (v[0] / min(args.steps, 10)) for v in prof.values())   # HIP kernels of this library per step
+        roof = dict(bound="mfma", kernel=dominant, timed_in_region=dominant in dom_prof, achieved=fl[dominant] / avg_s / 1e12,
+                    peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", frac=fl[dominant] / avg_s / 1e12 / FP32_MFMA_PEAK_TF,
+                    step_frac=flops_blk * (graphs_step / B) / step_s / 1e12 / FP32_MFMA_PEAK_TF / max(world, 1),
+                    step_hbm_frac=bytes_blk / step_s / 1e9 / HBM_PEAK_GBS,
+                    traffic=None, avg_launch_us=avg_s * 1e6, launches=cnt, algorithmic_flops_per_launch=fl[dominant],
+                    algorithmic_flops_per_step=flops_blk, algorithmic_bytes_per_step=bytes_blk,
+                    library_kernels_ms_per_step=hip_ms, other_ms_per_step=step_s * 1e3 - hip_ms,
+                    note="other_ms_per_step = the rocBLAS node-side GEMMs, torch glue and launch gaps (not behind the C-ABI's launch profiler)",
+                    kernels={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3, share_of_step=(v[1] / min(args.steps, 10)) / (step_s * 1e3),
+                                     tflops=(fl[k] / (v[1] / v[0] / 1e3) / 1e12) if k in fl else None)
+                             for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline(w, args.cpu_seconds, Bs=1)
+    line = {
+        "metric": "graphs/sec EGT fwd+bwd, " + METRIC_OF[args.workload],
+        "value": graphs_step * args.steps / elapsed, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: ONE attention block (h,e,mask)->(h',e') fwd+bwd + param grads "
+                               "(graph_xformer_model_base.py:192-223 around egt_layers.py:57-143), training mode, in-kernel random mask",
+                   "scope": "block", "graphs_per_gpu": B, "global_batch": graphs_step, "N": N, "Dh": Dh, "De": De, "H": H, "d": Dh // H,
+                   "random_mask_prob": w["rand_p"], "nodes": list(w["nodes"]),
+                   "path": "composed: k_edge_proj (LN + gates / edge bias) -> MFMA inner op -> k_edge_update (dense_edge_r + residual), rocBLAS node-side Dense",
+                   "parallelism": f"dp{world}", "backend": "rccl" if use_dist else "none (single process)",
+                   "tflops_step": flops_blk * (graphs_step / B) / step_s / 1e12},
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(line))
+
+
 def _free_port() -> int:
     import socket
     s = socket.socket()
@@ -499,8 +608,8 @@ def main():
             raise SystemExit(f"bench.py: egt_dp world {comm.world} != {world}")
 
     w = dict(WORKLOADS[args.workload])
-    if w.get("scope") == "core":
-        run_core(args, w, dev, lib, rank, world, use_dist)
+    if w.get("scope") in ("core", "block"):
+        (run_core if w["scope"] == "core" else run_block)(args, w, dev, lib, rank, world, use_dist)
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -712,10 +821,13 @@ def main():
                     step()
                 fence()
     # Timed region.  hipEvents bracket ONLY the dominant kernel's launches here (an event pair
-    # around every launch costs ~15% of the step); the per-kernel table comes from a second,
-    # untimed pass over the same steps below.
+    # around every launch costs ~15% of the step), and of those every PROF_STRIDE-th launch: an event pair costs the stream
+    # 4-5 us (ten of them per step were 2.5 % of the headline step), and a stride coprime with the launches per step walks
+    # through the layers.  The per-kernel table comes from a second, untimed pass over the same steps below.
+    PROF_STRIDE = 7
     if not args.no_prof:
         lib.egt_prof_filter(args.dominant.encode())
+        lib.egt_prof_stride(PROF_STRIDE)
         lib.egt_prof_enable(2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -723,6 +835,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     lib.egt_prof_enable(0)
+    lib.egt_prof_stride(1)
     graphs_step = w["B"]
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -833,6 +946,8 @@ def main():
                                         "FETCH_SIZE / WRITE_SIZE passes of this workload (FETCH doubled per the gfx950 note); not re-measured in this run"
                                         if traffic is not None else None),
                         avg_launch_us=avg_s * 1e6, launches=cnt, algorithmic_bytes_per_launch=ab,
+                        launches_sampled=(f"hipEvents around every {PROF_STRIDE}th launch of the kernel inside the timed region" if dom in dom_prof
+                                          else "every launch of the untimed eager pass"),
                         kernels={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3,
                                          share=v[1] / sum(x[1] for x in prof.values()))
                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})

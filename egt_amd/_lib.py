@@ -130,6 +130,7 @@ _PROTOS = {
     "egt_dp_finalize": (C.c_int, []),
     "egt_prof_enable": (C.c_int, [C.c_int]),
     "egt_prof_filter": (C.c_int, [C.c_char_p]),
+    "egt_prof_stride": (C.c_int, [C.c_int]),
     "egt_prof_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "egt_prof_names": (C.c_int, [C.c_char_p, C.c_size_t]),
 }

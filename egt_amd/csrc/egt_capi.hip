@@ -30,10 +30,12 @@ struct ProfEntry {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   int64_t count = 0;
   double ms = 0.0;
+  int64_t seen = 0;   // launches met while enabled (egt_prof_stride samples them)
 };
 std::mutex g_mu;
 int g_enabled = 0;
 std::string g_filter;  // when non-empty only this kernel is timed
+int g_stride = 1;      // time every g_stride-th launch of a timed kernel
 std::unordered_map<std::string, ProfEntry> g_prof;
 std::vector<hipEvent_t> g_pool;
 
@@ -74,9 +76,10 @@ void egt_prof_begin(const char* name, hipStream_t s, void** tok) {
   if (!g_enabled) return;
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_filter.empty() && g_filter != name) return;
+  auto& e = g_prof[name];
+  if (g_stride > 1 && (e.seen++ % g_stride) != 0) return;
   hipEvent_t a = get_event(), b = get_event();
   (void)hipEventRecord(a, s);
-  auto& e = g_prof[name];
   e.pending.emplace_back(a, b);
   *tok = (void*)b;
 }
@@ -103,6 +106,12 @@ extern "C" int egt_prof_enable(int on) {
 extern "C" int egt_prof_filter(const char* name) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_filter = name ? name : "";
+  return EGT_OK;
+}
+
+extern "C" int egt_prof_stride(int every) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_stride = every > 1 ? every : 1;
   return EGT_OK;
 }
 

@@ -441,6 +441,8 @@ int egt_dp_finalize(void);
  * and summed milliseconds of kernel `name`; egt_prof_names lists the names. */
 int egt_prof_enable(int on);
 int egt_prof_filter(const char* kernel_name); /* time only this kernel (NULL/"" = all) */
+int egt_prof_stride(int every);               /* time every `every`-th launch of each timed kernel (default 1 = all): an event pair
+                                                * costs the stream a few microseconds, a sample keeps a throughput measurement honest */
 int egt_prof_read(const char* name, int64_t* count, double* total_ms);
 int egt_prof_names(char* buf, size_t cap);
 

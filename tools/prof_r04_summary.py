@@ -129,7 +129,7 @@ def main():
                                "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); "
                                f"issue.frac = (MFMAs x {MFMA_CYC:.0f} + other VALU x {VALU_CYC}) / (1024 x active cycles)")
         json.dump(mfma_all, open(os.path.join(REPO, "profiles", "pmc_mfma.json"), "w"), indent=1)
-    for wl in ("cifar10_n150", "pattern500k_n120_b128", "zinc100k_n37", "pattern500k_n120", "synthetic_n512_b32"):
+    for wl in ("cifar10_n150", "pattern500k_n120_b128", "zinc100k_n37", "pattern500k_n120", "synthetic_n512_b32", "synthetic_n512_block"):
         try:
             line = open(os.path.join(src, f"bench_{wl}.json")).read().strip().splitlines()[-1]
             out.append(f"\n`python bench.py --workload {wl} --no-cpu-baseline`:\n\n```json\n{line}\n```\n")

@@ -25,7 +25,7 @@ for WL in zinc500k_n64 synthetic_n512; do
   timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CU_CYCLES -d $OUT/pmc_inst_$WL -o r -- $B > /dev/null 2>> $OUT/bench_${WL}_err.log
 done
 if [ -z "$QUICK" ]; then
-  for WL in cifar10_n150 pattern500k_n120_b128 zinc100k_n37 pattern500k_n120 synthetic_n512_b32; do
+  for WL in cifar10_n150 pattern500k_n120_b128 zinc100k_n37 pattern500k_n120 synthetic_n512_b32 synthetic_n512_block; do
     timeout 300 python bench.py --workload $WL --no-cpu-baseline > $OUT/bench_$WL.json 2>> $OUT/bench_err.log
   done
   timeout 300 python tools/bench_block_cfg5.py > $OUT/block_cfg5.json 2>> $OUT/bench_err.log
