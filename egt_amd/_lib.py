@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EGT_AMD_LIB") or os.path.join(_HERE, "lib", "libegt_amd.so")   # EGT_AMD_LIB: A/B experiments with variant builds
 
 # --- constants mirrored from include/egt_amd.h ---------------------------------
+ABI_VERSION = 4   # include/egt_amd.h EGT_ABI_VERSION
 EGT_OK = 0
 EGT_E_NULL, EGT_E_SHAPE, EGT_E_DTYPE, EGT_E_FLAGS, EGT_E_HIP, EGT_E_WORKSPACE, EGT_E_RCCL = -1, -2, -3, -4, -5, -6, -7
 EGT_F32 = 0
@@ -138,6 +139,7 @@ _PROTOS = {
 # "every declared symbol is exported" test sees one table
 _OPTIONAL_PROTOS = {
     "egt_block_supported": (C.c_int, [C.POINTER(BlockDesc)]),
+    "egt_block_bwd_kernel": (C.c_char_p, [C.POINTER(BlockDesc)]),
     "egt_block_saved_bytes": (C.c_size_t, [C.POINTER(BlockDesc)]),
     "egt_block_workspace_bytes": (C.c_size_t, [C.POINTER(BlockDesc)]),
     "egt_block_fwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams)] + [_VP] * 10),
@@ -174,7 +176,7 @@ def load():
         if hasattr(lib, name):
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-    if lib.egt_abi_version() != 3:
+    if lib.egt_abi_version() != ABI_VERSION:
         raise EGTLibraryError("ABI version mismatch")
     _lib = lib
     return lib

@@ -41,6 +41,7 @@
 
 #include "egt_block_fwd.h"   // k_block_fwd, k_block_fwd_r4
 #include "egt_block_bwd.h"   // k_block_bwd_v4, k_block_bwd_v5, k_block_bwd_v4r
+#include "egt_block_bwd7.h"  // k_block_bwd_v7 (twelve waves per CU)
 
 // ================================================================ host glue ====
 
@@ -107,6 +108,7 @@ struct BlockLayout {
   size_t dvp, dqp, dkvp, dqp_sz, dkvp_sz, common_total;
   size_t pw, epart, spart, sbo, wpart, ered, dqkv, dhbuf, layer_total;
   int TL, NLR, nwg_bwd, EP;   // TL: query rows per backward workgroup
+  bool v7;                    // geometry of k_block_bwd_v7 (32-row workgroups of twelve waves): two 16-row groups of this layout per workgroup
 };
 
 // Query rows per backward workgroup (<= 16: the MFMA tiles of the node-side prologue):
@@ -151,6 +153,15 @@ static BlockLayout layout(const egt_block_desc* d) {
   L.TL = bwd_rows_per_wg(d);
   L.NLR = (d->N + L.TL - 1) / L.TL;
   L.nwg_bwd = d->B * L.NLR;
+  {   // k_block_bwd_v7: fp32 edge tensors of 64 channels, no attention-mask tensor, N = 32 or 64 (a multiple of 32 whose key tiles divide
+      // the twelve waves), 16-row groups (the layout's partial slots are then exactly two per workgroup), and a launch of at least one
+      // 32-row workgroup per CU.  EGT_BWD_V7=0 switches it off, =1 takes it for every geometry it covers (tests).
+    static const int sw = getenv("EGT_BWD_V7") ? atoi(getenv("EGT_BWD_V7")) : -1;
+    const int nt = d->N / 16;
+    const bool geo = d->dtype == EGT_F32 && d->De == 64 && !(d->flags & EGT_BF_ATTN_MASK) && d->N % 32 == 0 && d->N <= 64 &&
+                     V7_WAVES % nt == 0 && L.TL == 16;   // (N <= 64: the graph's V rows live in LDS)
+    L.v7 = geo && sw != 0 && (sw == 1 || d->B * (d->N / 32) >= egt_device_cus());
+  }
   o = 0;
   L.dvp = o; o += al(rows * 64);
   L.dqp_sz = al(rows * 64 * (size_t)((d->N + 15) / 16));
@@ -183,6 +194,19 @@ static void bind_ws(const BlockLayout& L, BlockArgs& a, float* wc, float* wl, in
   a.ered = wl + L.ered; a.dqkv_sv = wl + L.dqkv;
   a.TL = L.TL; a.NLR = L.NLR; a.NQP = 1;
   a.xcd = 1;
+}
+
+// Which backward pair kernel launch_bwd takes for `d` when no mask TENSOR is passed (the in-kernel random mask is not one) and
+// the node side is fused: the families of DESIGN.md section 4 by name.  For tests and bench lines; NULL when `d` is not covered.
+extern "C" const char* egt_block_bwd_kernel(const egt_block_desc* d) {
+  if (block_check(d, false)) return nullptr;
+  const BlockLayout L = layout(d);
+  const bool ml = (d->flags & EGT_BF_ATTN_MASK) != 0, bf = d->dtype == EGT_BF16;
+  if (d->De == 8 && !ml && !block_env().no_narrow_bwd) return "k_narrow_bwd";
+  if (d->De <= 16 && !ml) return "k_block_bwd_v4r";
+  if (d->De == 64 && L.v7 && !ml && !bf) return "k_block_bwd_v7";
+  if (d->De >= 32 && !ml && !bf) return "k_block_bwd_v5";
+  return "k_block_bwd_v4";
 }
 
 extern "C" size_t egt_block_saved_bytes(const egt_block_desc* d) {
@@ -340,8 +364,10 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
 // next block of the chain (NULL at the bottom), whose dV_att / delta this block's node kernel
 // produces.  GEMM-shaped weight gradients and all partial reductions are left to the caller.
 template <int DE>
-static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool top, BlockArgs* below, BlockArgs* above, bool fuse) {
+// Returns the number of edge-parameter partials (workgroups) the pair kernel wrote into a.epart.
+static int launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool top, BlockArgs* below, BlockArgs* above, bool fuse) {
   using GG = Geo<DE>;
+  int nep = L.nwg_bwd;
   // node-side prologue inside the pair kernel (see bwd_node_prologue): v4 geometry with Dh = 64
   const bool ml = a.M != nullptr || a.rm != nullptr;
   // narrow edge channels without mask tensors run k_block_bwd_v4r, which (with the prologue) also covers ragged N
@@ -398,6 +424,22 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
         }
       }
       if constexpr (DE >= 32) {
+        if constexpr (DE == 64) {
+        if (L.v7 && !ml && !a.bf16) {   // twelve waves per CU (k_block_bwd_v7): one workgroup = two of the layout's 16-row groups
+          constexpr int PW7 = 2 * GG::TILE_FLOATS + 256 + 128;
+          size_t area = (size_t)V7_WAVES * PW7;
+          if (area < 3 * BWD_PRO_WS) area = 3 * BWD_PRO_WS;
+          if (area < (size_t)V7_WAVES * 2048) area = (size_t)V7_WAVES * 2048;
+          if (area < (size_t)V7_WAVES * GG::EP) area = (size_t)V7_WAVES * GG::EP;
+          // tile area + 32 staged node rows + weight slabs (wsA, compact wsB, wsD) + the graph's V rows
+          const size_t lds7 = (area + (size_t)V7_ROWS * QD_LD + (size_t)GG::TILES * 256 * 5 / 2 + (size_t)a.N * 64) * 4;
+          a.NLR = L.NLR / 2;                 // dK / dV partials per key (the consumer -- the next prologue / k_node_bwd -- reads a.NLR of its own launch: same value)
+          nep = L.nwg_bwd / 2;
+          EGT_MAX_LDS_ONCE(k_block_bwd_v7<DE>);
+          EGT_LAUNCH("k_block_bwd", (k_block_bwd_v7<DE>), dim3(nep), dim3(64 * V7_WAVES), lds7, st, a);
+          goto pair_done;
+        }
+        }
         if (!ml && !a.bf16) {   // LDS-DMA staged e tiles (k_block_bwd_v5), ragged N included
           const bool x3 = block_env().bwd_mm == EGT_MM_BF16X3;
 #define V5_LAUNCH(MM_, RAG_)                                                                                 \
@@ -421,6 +463,7 @@ static void launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool 
 pair_done:
   if (!pro) egt_node_launch_bwd(a, below, true, st);   // dQKV -> dh, bias/LN sums; dV_att + delta of the block below
   else if (!below) egt_node_launch_bwd(a, nullptr, true, st);   // bottom of the chain: only dQKV -> dh is left
+  return nep;
 }
 
 
@@ -475,9 +518,10 @@ extern "C" int egt_block_bwd(const egt_block_desc* desc, const egt_block_params*
   a.g_Wo = (float*)grads->dense_mha_kernel; a.g_bo = (float*)grads->dense_mha_bias;
   a.g_Wr = (float*)grads->dense_edge_r_kernel; a.g_br = (float*)grads->dense_edge_r_bias;
   const BlockLayout L = layout(desc);
-  DISPATCH_BDE(desc->De, launch_bwd<DE>(a, L, (hipStream_t)stream, true, nullptr, nullptr, node_fused_ok(a)));
+  int nep = L.nwg_bwd;
+  DISPATCH_BDE(desc->De, nep = launch_bwd<DE>(a, L, (hipStream_t)stream, true, nullptr, nullptr, node_fused_ok(a)));
   egt_node_launch_wgrads(&a, 1, (hipStream_t)stream);
-  egt_node_launch_reduce(&a, 1, L.nwg_bwd, L.EP, (hipStream_t)stream);  // partial sums + edge param grads
+  egt_node_launch_reduce(&a, 1, nep, L.EP, (hipStream_t)stream);  // partial sums + edge param grads
   EGT_HIP_LAUNCH_CHECK("egt_block_bwd");
   return EGT_OK;
 }
@@ -631,13 +675,14 @@ extern "C" int egt_stack_bwd(const egt_block_desc* desc, int32_t layers, const e
   }
   bool fuse = true;
   for (int l = 0; l < layers; ++l) fuse = fuse && node_fused_ok(as[l]);
+  int nep = L.nwg_bwd;
   for (int l = layers - 1; l >= 0; --l) {
     as[l].prep = 0;   // the LN-folded edge weights were prepared by the forward and live in `saved`
-    DISPATCH_BDE(desc->De, launch_bwd<DE>(as[l], L, (hipStream_t)stream, l == layers - 1, l > 0 ? &as[l - 1] : nullptr,
-                                             l + 1 < layers ? &as[l + 1] : nullptr, fuse));
+    DISPATCH_BDE(desc->De, nep = launch_bwd<DE>(as[l], L, (hipStream_t)stream, l == layers - 1, l > 0 ? &as[l - 1] : nullptr,
+                                                   l + 1 < layers ? &as[l + 1] : nullptr, fuse));
   }
   egt_node_launch_wgrads(as, layers, (hipStream_t)stream);
-  egt_node_launch_reduce(as, layers, L.nwg_bwd, L.EP, (hipStream_t)stream);
+  egt_node_launch_reduce(as, layers, nep, L.EP, (hipStream_t)stream);
   EGT_HIP_LAUNCH_CHECK("egt_stack_bwd");
   return EGT_OK;
 }

@@ -241,20 +241,21 @@ struct BwdProRegs { float4 hx, gq[3], wq[12], wo[4]; float dho[4], gmm[4], va[4]
 
 #define BWD_PRO_COMMON()                                                                                   \
   constexpr int LD = 68, LD3 = 196;                                                                        \
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);                 \
+  const int t = ptid, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);                        \
   const int p = lane & 15, q = lane >> 4, N = a.N;                                                         \
   const size_t row0 = (size_t)b * N + l_begin;                                                             \
   const int lnrow = 4 * wave + q;    /* LayerNorm mapping: row 4*wave + q, columns p + 16 i */            \
   /* ragged last row group (N not a multiple of 16): loads are clamped to the graph's last row, the rows  \
      past the end contribute zeros to every sum and are never stored */                                   \
-  const int nv = min(a.TL, N - l_begin);                   /* valid rows of this workgroup (a.TL <= 16) */ \
-  auto rc = [&](int r) { return row0 + min(r, nv - 1); };   /* clamped global row */                       \
+  const int nv = pnv >= 0 ? pnv : min(a.TL, N - l_begin);  /* valid rows of this 16-row group (<= 16; 0: an idle group of  \
+                                                              k_block_bwd_v7 that only keeps the barriers) */             \
+  auto rc = [&](int r) { return row0 + max(min(r, nv - 1), 0); };   /* clamped global row */               \
   const int Dh = D64 ? 64 : a.Dh;                                                                          \
   (void)LD; (void)LD3; (void)lnrow; (void)p; (void)q; (void)rc; (void)Dh
 
 // Wo columns and V_att rows of the dV_att step
 template <int DE, bool D64>
-__device__ __forceinline__ void bwd_prologue_load_wo_va(const BlockArgs& a, int b, int l_begin, BwdProRegs& R) {
+__device__ __forceinline__ void bwd_prologue_load_wo_va(const BlockArgs& a, int b, int l_begin, BwdProRegs& R, int ptid, int pnv) {
   BWD_PRO_COMMON();
   const bool iok = D64 || 16 * wave + p < Dh;   // the lane's dV_att channel exists
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -266,7 +267,7 @@ __device__ __forceinline__ void bwd_prologue_load_wo_va(const BlockArgs& a, int 
 }
 // [pro == 2] every global input of the dQKV / d h_ln / LayerNorm-backward step
 template <int DE, bool D64>
-__device__ __forceinline__ void bwd_prologue_load_main(const BlockArgs& a, int b, int l_begin, BwdProRegs& R) {
+__device__ __forceinline__ void bwd_prologue_load_main(const BlockArgs& a, int b, int l_begin, BwdProRegs& R, int ptid, int pnv) {
   BWD_PRO_COMMON();
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // ---- every global input in one round trip ----
@@ -282,7 +283,7 @@ __device__ __forceinline__ void bwd_prologue_load_main(const BlockArgs& a, int b
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int i = t + u * 256, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
-      const int rr = min(r, nv - 1);
+      const int rr = max(min(r, nv - 1), 0);
       const int NP = sx == 0 ? a.NQP : a.NLR;
       const float* base = sx == 0 ? a.up_dqp + ((size_t)b * NP * N + l_begin + rr) * 64 + pos4
                                   : a.up_dkvp + (((size_t)b * NP * N + l_begin + rr) * 2 + (sx - 1)) * 64 + (pos4 & 63);
@@ -308,7 +309,7 @@ __device__ __forceinline__ void bwd_prologue_load_main(const BlockArgs& a, int b
 
 template <int DE, bool D64>
 __device__ __forceinline__ void bwd_prologue_compute(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg, BwdProRegs& R,
-                                                     bool wo_loaded, unsigned* tp = nullptr) {
+                                                     bool wo_loaded, unsigned* tp, int ptid, int pnv) {
   float* dqs = ws;                   // dQKV  [16][196]
   float* xs = dqs + 16 * 196;        // xhat  [16][68]
   float* dls = xs + 16 * 68;         // d h_ln
@@ -398,13 +399,13 @@ __device__ __forceinline__ void bwd_prologue_compute(const BlockArgs& a, float* 
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) { s0 += dqs[r * LD3 + t]; s1 += dqs[(r + 1) * LD3 + t]; }
-        if (D64 || (t & 63) < Dh) sp[(t >> 6) * Dh + (t & 63)] = s0 + s1;
+        if ((D64 || (t & 63) < Dh) && nv > 0) sp[(t >> 6) * Dh + (t & 63)] = s0 + s1;
       } else {
         const int c = t - 192;
         float g0 = 0.f, b0 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { const float d0 = dls[r * LD + c]; g0 = fmaf(d0, xs[r * LD + c], g0); b0 += d0; }
-        if (D64 || c < Dh) {
+        if ((D64 || c < Dh) && nv > 0) {
           sp[3 * Dh + c] = g0;
           sp[4 * Dh + c] = b0;
         }
@@ -418,7 +419,7 @@ __device__ __forceinline__ void bwd_prologue_compute(const BlockArgs& a, float* 
   }
   // ---- dV_att = dh'.Wo^T for i tile = wave (contraction order c = 16 q + s), delta, dbo ----
   NSTAMP(3);
-  if (!wo_loaded) bwd_prologue_load_wo_va<DE, D64>(a, b, l_begin, R);
+  if (!wo_loaded) bwd_prologue_load_wo_va<DE, D64>(a, b, l_begin, R, ptid, pnv);
   __syncthreads();
   NSTAMP(4);
   {
@@ -450,7 +451,7 @@ __device__ __forceinline__ void bwd_prologue_compute(const BlockArgs& a, float* 
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) { s0 += dhs[r * LD + t]; s1 += dhs[(r + 1) * LD + t]; }
-    if (D64 || t < Dh) a.sbo[(size_t)wg * Dh + t] = s0 + s1;
+    if ((D64 || t < Dh) && nv > 0) a.sbo[(size_t)wg * Dh + t] = s0 + s1;
   }
   __syncthreads();
   if (t < 128 && (t >> 3) < nv) {   // delta of (row, head)
@@ -461,15 +462,20 @@ __device__ __forceinline__ void bwd_prologue_compute(const BlockArgs& a, float* 
 }
 
 template <int DE, bool D64, bool HOIST>
-__device__ __forceinline__ void bwd_node_prologue_t(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg, unsigned* tp) {
+__device__ __forceinline__ void bwd_node_prologue_t(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg, unsigned* tp, int ptid, int pnv) {
   BwdProRegs R;
-  if (HOIST) bwd_prologue_load_wo_va<DE, D64>(a, b, l_begin, R);
-  if (a.pro == 2) bwd_prologue_load_main<DE, D64>(a, b, l_begin, R);
-  bwd_prologue_compute<DE, D64>(a, ws, qd, b, l_begin, wg, R, HOIST, tp);
+  if (HOIST) bwd_prologue_load_wo_va<DE, D64>(a, b, l_begin, R, ptid, pnv);
+  if (a.pro == 2) bwd_prologue_load_main<DE, D64>(a, b, l_begin, R, ptid, pnv);
+  bwd_prologue_compute<DE, D64>(a, ws, qd, b, l_begin, wg, R, HOIST, tp, ptid, pnv);
 }
+// ptid / pnv: the calling thread's index inside its 256-thread group and the group's valid rows -- defaults: the workgroup IS the
+// group (threadIdx.x, min(a.TL, N - l_begin)).  k_block_bwd_v7 runs one group per 16 of its 32 rows (wg = the group's partial slot);
+// every thread of the workgroup must make the call (the barriers inside are workgroup barriers), surplus groups with pnv = 0.
 template <int DE, bool HOIST = false>
-__device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg, unsigned* tp = nullptr) {
-  if (a.Dh == 64) bwd_node_prologue_t<DE, true, HOIST>(a, ws, qd, b, l_begin, wg, tp);
-  else bwd_node_prologue_t<DE, false, HOIST>(a, ws, qd, b, l_begin, wg, tp);
+__device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg, unsigned* tp = nullptr,
+                                                  int ptid = -1, int pnv = -1) {
+  if (ptid < 0) ptid = threadIdx.x;
+  if (a.Dh == 64) bwd_node_prologue_t<DE, true, HOIST>(a, ws, qd, b, l_begin, wg, tp, ptid, pnv);
+  else bwd_node_prologue_t<DE, false, HOIST>(a, ws, qd, b, l_begin, wg, tp, ptid, pnv);
 }
 

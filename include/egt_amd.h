@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EGT_ABI_VERSION 3
+#define EGT_ABI_VERSION 4
 
 /* error codes */
 #define EGT_OK 0
@@ -267,6 +267,10 @@ typedef struct egt_block_params {
 
 /* 1 when the fused kernels cover `desc`, else 0 (caller composes instead). */
 int egt_block_supported(const egt_block_desc* desc);
+/* Name of the backward pair-kernel family the dispatch takes for `desc` when no mask tensor is passed ("k_block_bwd_v7",
+ * "k_block_bwd_v5", "k_block_bwd_v4", "k_block_bwd_v4r", "k_narrow_bwd": DESIGN.md section 4); NULL when `desc` is not covered.
+ * Static string; for tests and bench lines (the launch profiler reports every family as "k_block_bwd"). */
+const char* egt_block_bwd_kernel(const egt_block_desc* desc);
 /* bytes of the forward->backward buffer (V_att, softmax row statistics, packed
  * Q/K/V, the LN-folded edge weights) and of the scratch workspace (max of forward and backward needs). */
 size_t egt_block_saved_bytes(const egt_block_desc* desc);

@@ -152,4 +152,4 @@ def test_header_compiles_as_c_and_struct_layouts_match_the_ctypes_mirrors(tmp_pa
         assert int(got[cname]) == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
-    assert int(got["abi"]) == 3
+    assert int(got["abi"]) == 4
