@@ -1076,6 +1076,7 @@ extern "C" size_t egt_attn_mfma_workspace_bytes(const egt_attn_desc* d) {
 
 extern "C" size_t egt_attn_mfma_fwd_workspace_bytes(const egt_attn_desc* d) {
   if (!egt_attn_mfma_supported(d, 0)) return 0;
+  if (d->reserved & EGT_ATTN_WS_SHARED) return egt_attn_mfma_workspace_bytes(d);   // the forward then packs the backward's arrays too
   return (size_t)PK_FWD_COUNT * d->B * AH * np_of(d->N) * d->d * sizeof(float);
 }
 
@@ -1084,6 +1085,7 @@ static int fill(const egt_attn_desc* desc, const void* qkv, const void* E, const
                 AttnMfmaArgs& a) {
   if (!egt_attn_mfma_supported(desc, 0)) EGT_FAIL(EGT_E_SHAPE, "configuration not covered by the MFMA inner-op kernel");
   if (!qkv || !workspace) EGT_FAIL(EGT_E_NULL, "qkv/workspace is NULL");
+  if (desc->reserved & ~EGT_ATTN_WS_SHARED) EGT_FAIL(EGT_E_FLAGS, "egt_attn_desc.reserved: unknown bits 0x%x (EGT_ATTN_WS_SHARED is the only one)", desc->reserved);
   if ((desc->flags & EGT_F_EDGE_INPUT) && !E) EGT_FAIL(EGT_E_NULL, "edge_input set but E is NULL");
   if ((desc->flags & EGT_F_GATE_INPUT) && !G) EGT_FAIL(EGT_E_NULL, "gate_input set but G is NULL");
   if ((desc->flags & EGT_F_ATTN_MASK) && !attn_mask) EGT_FAIL(EGT_E_NULL, "attn_mask set but M is NULL");

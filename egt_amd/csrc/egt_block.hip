@@ -150,18 +150,20 @@ static BlockLayout layout(const egt_block_desc* d) {
   L.qkvp = o; o += al(rows * QKVP);
   L.pw_sv = o; o += al((size_t)DEP * 16 + 16);
   L.saved_total = o;
-  L.TL = bwd_rows_per_wg(d);
+  {   // k_block_bwd_v7: fp32 edge tensors of 64 channels, no attention-mask tensor, N = 32 or 64 (a multiple of 32 whose key tiles divide
+      // the twelve waves; the graph's V rows live in LDS), and a launch of at least one 32-row workgroup per CU.  It works on pairs of the
+      // layout's 16-row groups.  OPT-IN (EGT_BWD_V7=1: every geometry it covers; =2: only launches of at least one 32-row workgroup
+      // per CU): measured 104.7 us per launch at the headline batch against k_block_bwd_v5's 98.6 -- the third
+      // wave per SIMD does not pay, the kernels are bound by instruction issue and the memory path together, not by latency.
+    static const int sw = getenv("EGT_BWD_V7") ? atoi(getenv("EGT_BWD_V7")) : 0;
+    const int nt = d->N / 16;
+    const bool geo = d->dtype == EGT_F32 && d->De == 64 && !(d->flags & EGT_BF_ATTN_MASK) && d->N % 32 == 0 && d->N <= 64 && V7_WAVES % nt == 0;
+    static const bool tl_forced = getenv("EGT_BWD_TL") != nullptr;
+    L.v7 = geo && !tl_forced && (sw == 1 || (sw == 2 && d->B * (d->N / 32) >= egt_device_cus()));
+  }
+  L.TL = L.v7 ? 16 : bwd_rows_per_wg(d);
   L.NLR = (d->N + L.TL - 1) / L.TL;
   L.nwg_bwd = d->B * L.NLR;
-  {   // k_block_bwd_v7: fp32 edge tensors of 64 channels, no attention-mask tensor, N = 32 or 64 (a multiple of 32 whose key tiles divide
-      // the twelve waves), 16-row groups (the layout's partial slots are then exactly two per workgroup), and a launch of at least one
-      // 32-row workgroup per CU.  EGT_BWD_V7=0 switches it off, =1 takes it for every geometry it covers (tests).
-    static const int sw = getenv("EGT_BWD_V7") ? atoi(getenv("EGT_BWD_V7")) : -1;
-    const int nt = d->N / 16;
-    const bool geo = d->dtype == EGT_F32 && d->De == 64 && !(d->flags & EGT_BF_ATTN_MASK) && d->N % 32 == 0 && d->N <= 64 &&
-                     V7_WAVES % nt == 0 && L.TL == 16;   // (N <= 64: the graph's V rows live in LDS)
-    L.v7 = geo && sw != 0 && (sw == 1 || d->B * (d->N / 32) >= egt_device_cus());
-  }
   o = 0;
   L.dvp = o; o += al(rows * 64);
   L.dqp_sz = al(rows * 64 * (size_t)((d->N + 15) / 16));

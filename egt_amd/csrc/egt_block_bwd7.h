@@ -1,37 +1,35 @@
 // k_block_bwd_v7: the fused backward of the attention block at THREE wavefronts per SIMD (included by egt_block.hip).
+// OPT-IN (EGT_BWD_V7 = 1 | 2, egt_block.hip: layout()).  Built in round 5 as the experiment VERDICT r4 item 1 asked for ("a third
+// resident workgroup per CU"); measured at the headline batch it takes 104.7 us per launch against k_block_bwd_v5's 98.6 us
+// (profiles/r05_v7_*): the third wave per SIMD does not pay.  Staggered wave starts and static wave priorities change nothing
+// (104.5 - 107 us), i.e. the waves are not phase-locked on their tile requests: v5 already sits at ~77 % of its instruction-issue
+// bound and ~84 % of the sustainable HBM rate inside its row loop (profiles/r03_mfma_valu_issue.md), and this kernel pays ~15 % more
+// VALU instructions per step for the address arithmetic that fits it into 168 registers.  Kept as a tested alternative.
 //
-// k_block_bwd_v5 runs two workgroups of four waves per CU (222 VGPRs, 78 KB of LDS each): its per-wave chain of
-// (row, key tile) steps is long and dependent (LayerNorm -> 16-MFMA chain -> exp / sigmoid -> MFMA chain -> LayerNorm backward, six
-// LDS hand-offs), and two waves per SIMD cover each other's stalls only partly (round 4's occupancy probe: T = I + L/n with
-// I = 69 us, L/2 = 33 us).  A third four-wave workgroup per CU would need <= 53 KB of LDS and 50 % more workgroups on shorter row
-// groups, whose per-workgroup costs (node-side prologue, weight slabs, K / V, partial sums) do not shrink with the rows.  This kernel
-// gets the third wave per SIMD the other way round:
+// k_block_bwd_v5 runs two workgroups of four waves per CU (218 VGPRs, 77 KB of LDS each).  A third four-wave workgroup per CU would
+// need <= 53 KB of LDS and 50 % more workgroups on shorter row groups, whose per-workgroup costs (node-side prologue, weight slabs,
+// K / V, partial sums) do not shrink with the rows.  This kernel gets the third wave per SIMD the other way round:
 //  * ONE workgroup of TWELVE waves per CU owns 32 query rows of a graph: the per-workgroup costs halve per row instead of growing
 //    (one weight-slab fill, one edge-partial slot and one dK / dV partial per 32 rows; the prologue still runs per 16 rows, two
-//    groups of four waves side by side);
+//    groups of four waves side by side, the remaining four waves only keep its barriers);
 //  * a wave owns (key tile, row chunk): the 12 / ntile waves of a key tile split the workgroup's rows into equal contiguous chunks,
 //    so no two waves ever touch the same LDS tile (no barrier inside the row loop); the chunks' dK / dV accumulators are added
 //    through LDS after the loop;
-//  * 168 VGPRs: BOTH streamed tiles of a row, e and de', arrive by LDS-DMA (no register staging), one buffer each -- the request
-//    for row l+1 goes out when row l's last LDS reads have retired, ahead of row l's de stores, and its latency is covered by the
-//    other two waves of the SIMD instead of by a second buffer;
-//  * LDS: 12 x (e tile + de' tile + dGE + H_hat) = 117 KB, 32 staged node rows 20 KB, weight slabs 12 KB.
-// Geometry: fp32 edge tensors, no mask tensors, N a multiple of 16 with 12 % (N / 16) == 0 (N = 16, 32, 48, 64, 96, 192); the
-// dispatch (launch_bwd) takes it when the launch fills the chip with one workgroup per CU.  Everything a row step computes is
-// k_block_bwd_v5's arithmetic in k_block_bwd_v5's order: the two kernels are bit-identical per (row, key tile); the sums over row
-// chunks (dK, dV, the weight-gradient partials) associate differently.
+//  * 160 VGPRs, 0 spills in the loop (v5: 218).  What it took: BOTH streamed tiles of a row, e and de', arrive by LDS-DMA (no
+//    register staging), one buffer each -- the request for row l+1 goes out as soon as P5 has the row's xhat / de' fragments in
+//    registers, ahead of its 16 MFMAs and of the de stores; V of the graph's keys lives in LDS (16 KB, XOR-swizzled pieces) instead
+//    of 16 registers per lane; the bias-gradient sums ride on P4's B operands (1 register instead of 4); every LDS / global address
+//    is derived inside its phase from nine lane constants (hipcc otherwise carries 39 address registers through the loop:
+//    tools/isa_pressure.py shows the live ranges);
+//  * LDS: 12 x (e tile + de' tile + dGE + H_hat) = 114 KB, 32 staged node rows 20 KB, weight slabs 10 KB (the dH_ext slab without
+//    its zero rows), V 16 KB = exactly the 160 KB of a CU.
+// Geometry: fp32 edge tensors of 64 channels, no mask tensors, N = 32 or 64.  A row step is k_block_bwd_v5's arithmetic; the sums
+// over row chunks (dK, dV, the weight-gradient partials), the order of the dV_att pieces and the bias-gradient sums associate
+// differently: equal to v5 within a few ulps, not bit for bit (tests/test_bwd_v7_gpu.py).
 #pragma once
 
 #define V7_WAVES 12
 #define V7_ROWS 32
-#ifdef V7_TFENCE
-#define V7_FENCE_T() SCHED_FENCE()
-#else
-#define V7_FENCE_T() do {} while (0)
-#endif
-#ifndef V7_LB
-#define V7_LB (64 * V7_WAVES)
-#endif
 constexpr int cmax(int x, int y) { return x > y ? x : y; }
 
 // LDS accesses by byte address (native vector types: the HIP float4 class does not bind to address-space pointers)
@@ -46,7 +44,7 @@ __device__ __forceinline__ void v7_st4(unsigned addr, float4 v) { *reinterpret_c
 __device__ __forceinline__ void v7_st2(unsigned addr, float2 v) { *reinterpret_cast<V7_AS3 v2f*>((size_t)addr) = (v2f){v.x, v.y}; }
 
 template <int DE>
-__global__ void __launch_bounds__(V7_LB) k_block_bwd_v7(BlockArgs a) {
+__global__ void __launch_bounds__(64 * V7_WAVES) k_block_bwd_v7(BlockArgs a) {
   seed_from_device(a);
   using G = Geo<DE>;
   constexpr int NI = G::NF4 / 64;            // LDS-DMA instructions (= 16-byte stores per lane) of one tile
@@ -89,7 +87,6 @@ __global__ void __launch_bounds__(V7_LB) k_block_bwd_v7(BlockArgs a) {
     if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
     *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
   }
-#ifndef V7_NO_PRO
   if (a.pro) {
     __syncthreads();
     // two 16-row groups of four waves side by side, each on its own scratch; waves 8..11 only keep the barriers (pnv = 0: every load
@@ -100,7 +97,6 @@ __global__ void __launch_bounds__(V7_LB) k_block_bwd_v7(BlockArgs a) {
     const int gnv = grp < 2 ? max(0, min(16, l_end - gl)) : 0;
     bwd_node_prologue<DE>(a, sm + grp * BWD_PRO_WS, qd + 16 * g2 * QD_LD, b, min(gl, N - 1), 2 * wg + g2, nullptr, threadIdx.x & 255, gnv);
   }
-#endif
   for (int i = threadIdx.x; i < G::TILES * 256; i += 64 * V7_WAVES) {   // weight slabs: element (t, lane, u)
     const int t = i >> 8, ln = (i >> 2) & 63, u = i & 3, pp = ln & 15, qq = ln >> 4;
     const int c = 16 * t + 4 * qq + u;
@@ -342,14 +338,31 @@ __global__ void __launch_bounds__(V7_LB) k_block_bwd_v7(BlockArgs a) {
       }
       lds_sync();
       SCHED_FENCE();
-      // ---- P5: d(ehat) = Wp . dGE, LayerNorm backward, de = de' + ... ; the next row's tiles are requested before de is stored ----
+      // ---- P5: d(ehat) = Wp . dGE, LayerNorm backward, de = de' + ... ----
+      // The xhat / de' fragments go to registers FIRST: with them read, both LDS tiles are dead and the next row's tiles are requested
+      // before this phase's 16 MFMAs and its LayerNorm arithmetic instead of behind them (each tile has one buffer: the request cannot
+      // go out earlier than its last reader, and its latency is what the other two waves of the SIMD have to cover).
       if (!(a.guard & 2)) {
-        float4 dxh[4];
-        float m1 = 0.f, m2 = 0.f;
-        V7_OPQ(aF); V7_OPQ(aW);
+        float4 xh[4], dy[4];
+        V7_OPQ(aF);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const float4 xh = LD4(aF ^ (unsigned)(t << 6));
+          const unsigned ft = aF ^ (unsigned)(t << 6);
+          xh[t] = LD4(ft);
+          dy[t] = LD4(ft + TB);
+        }
+        lds_sync();   // the last reads of both tiles have retired: the next row may land
+        SCHED_FENCE();
+        if (l + 1 < r_hi) {
+          tile_dma<DE>(et_lds, e_in + (pair0 + (size_t)N) * DE, off0);
+          tile_dma<DE>(dt_lds, dey_in + (pair0 + (size_t)N) * DE, off0);
+        }
+        SCHED_FENCE();
+        float4 dxh[4];
+        float m1 = 0.f, m2 = 0.f;
+        V7_OPQ(aW);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
           v4f d = {0.f, 0.f, 0.f, 0.f};
           const float4 w = LD4(aW + oD + 1024u * t);
           d = MFMA(w.x, dge[0], d);
@@ -358,34 +371,18 @@ __global__ void __launch_bounds__(V7_LB) k_block_bwd_v7(BlockArgs a) {
           d = MFMA(w.w, dge[3], d);
           dxh[t] = make_float4(d[0], d[1], d[2], d[3]);
           m1 += (d[0] + d[1]) + (d[2] + d[3]);
-          m2 = fmaf(d[0], xh.x, m2); m2 = fmaf(d[1], xh.y, m2);
-          m2 = fmaf(d[2], xh.z, m2); m2 = fmaf(d[3], xh.w, m2);
+          m2 = fmaf(d[0], xh[t].x, m2); m2 = fmaf(d[1], xh[t].y, m2);
+          m2 = fmaf(d[2], xh[t].z, m2); m2 = fmaf(d[3], xh[t].w, m2);
         }
         m1 = sum_over_q(m1) * (1.0f / DE);
         m2 = sum_over_q(m2) * (1.0f / DE);
         if (a.flags & EGT_BF_NO_EDGE_LN) { m1 = 0.f; m2 = 0.f; }   // no norm_edge: d e = de' + d(proj input)
-        SCHED_FENCE();
-        V7_OPQ(aF);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const unsigned ft = aF ^ (unsigned)(t << 6);
-          const float4 dyv = LD4(ft + TB);
-          const float4 xh = LD4(ft);
-          dxh[t].x = dyv.x + rstd * (dxh[t].x - m1 - xh.x * m2);
-          dxh[t].y = dyv.y + rstd * (dxh[t].y - m1 - xh.y * m2);
-          dxh[t].z = dyv.z + rstd * (dxh[t].z - m1 - xh.z * m2);
-          dxh[t].w = dyv.w + rstd * (dxh[t].w - m1 - xh.w * m2);
-          if (t == 1) {   // two channel tiles of de' / xhat in flight at a time (the pins keep the arithmetic on this side)
-            V7_OPQ(dxh[0].x); V7_OPQ(dxh[0].y); V7_OPQ(dxh[0].z); V7_OPQ(dxh[0].w);
-            V7_OPQ(dxh[1].x); V7_OPQ(dxh[1].y); V7_OPQ(dxh[1].z); V7_OPQ(dxh[1].w);
-            SCHED_FENCE();
-          }
-        }
-        lds_sync();   // the last reads of both tiles have retired: the next row may land
-        SCHED_FENCE();
-        if (l + 1 < r_hi) {
-          tile_dma<DE>(et_lds, e_in + (pair0 + (size_t)N) * DE, off0);
-          tile_dma<DE>(dt_lds, dey_in + (pair0 + (size_t)N) * DE, off0);
+          dxh[t].x = dy[t].x + rstd * (dxh[t].x - m1 - xh[t].x * m2);
+          dxh[t].y = dy[t].y + rstd * (dxh[t].y - m1 - xh[t].y * m2);
+          dxh[t].z = dy[t].z + rstd * (dxh[t].z - m1 - xh[t].z * m2);
+          dxh[t].w = dy[t].w + rstd * (dxh[t].w - m1 - xh[t].w * m2);
         }
         SCHED_FENCE();
         V7_OPQ(gOff);

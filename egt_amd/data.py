@@ -479,9 +479,12 @@ class GraphDataset:
         return out
 
     def batches(self, split: str, batch_size: int, drop_remainder=False, map_fn: Optional[Callable] = None,
-                shard: Optional[Tuple[int, int]] = None, as_torch=True, device=None) -> Iterator:
-        """one epoch of batches of ``split`` (get_batched_split + map + prefetch, dataset_base.py:100-130)"""
-        train = split == "training"   # training steps are collective (gradient all-reduce): every rank must take the same number
+                shard: Optional[Tuple[int, int]] = None, as_torch=True, device=None, collective: Optional[bool] = None) -> Iterator:
+        """one epoch of batches of ``split`` (get_batched_split + map + prefetch, dataset_base.py:100-130).
+        collective: every step of the pass is a collective (gradient all-reduce), so every rank must take the same number of
+        steps and a last batch with fewer graphs than ranks is dropped by all; False for evaluation / prediction passes, which
+        keep every graph (a rank without a share skips the batch).  Default: the training split's passes are collective."""
+        train = (split == "training") if collective is None else bool(collective)
         def gen():
             cur: List[dict] = []
             for r in self.iter_records(split):
@@ -532,9 +535,10 @@ class _Epochs:
     def __init__(self, ds, split, batch_size, drop_remainder, map_fn, kw):
         self.ds, self.split, self.a = ds, split, (batch_size, drop_remainder, map_fn)
         self.kw = kw
+        self.collective = None     # None: by split name; the scheme driver sets False while it EVALUATES the training split
 
     def __iter__(self):
-        return (b for b in self.ds.batches(self.split, *self.a, **self.kw) if b is not None)
+        return (b for b in self.ds.batches(self.split, *self.a, collective=self.collective, **self.kw) if b is not None)
 
     def __len__(self):
         n, bs = len(self.ds.record_tokens[self.split]), self.a[0]

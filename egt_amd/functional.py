@@ -103,7 +103,8 @@ class _EGTAttention(torch.autograd.Function):
                 and lib.egt_attn_mfma_supported(C.byref(desc), 1 if cfg.need_a_tild else 0)):
             # large-head geometry: QK^T / A.V on MFMA tiles (egt_attn_mfma.hip)
             # one workspace for both directions when a backward will follow: q/k/v are packed once (EGT_ATTN_WS_SHARED)
-            shared = any(t is not None and t.requires_grad for t in (qkv, E, G)) and torch.is_grad_enabled()
+            # (grad mode is always off inside autograd.Function.forward: the backward is announced by ctx.needs_input_grad)
+            shared = any(ctx.needs_input_grad[:3])
             if shared:
                 desc.reserved = L.ATTN_WS_SHARED
                 ws = torch.empty(lib.egt_attn_mfma_workspace_bytes(C.byref(desc)), device=qkv.device, dtype=torch.uint8)

@@ -719,7 +719,15 @@ class ZincSVDScheme:
                 continue
             self.print("=" * 40)
             self.print(f"Evaluation on {split}.")
-            self.do_evaluations_on_split(split)
+            src = getattr(self, split)
+            had = getattr(src, "collective", None)
+            if hasattr(src, "collective"):
+                src.collective = False     # an evaluation pass has ONE collective at its end: no graph is dropped
+            try:
+                self.do_evaluations_on_split(split)
+            finally:
+                if hasattr(src, "collective"):
+                    src.collective = had
             self.print("")
 
     def execute_training(self, trainset=None, valset=None):   # :305-312
@@ -768,7 +776,9 @@ class PatternSVDScheme(ZincSVDScheme):
         # Keras feeds the mask as sample_weight: the metrics are means over the REAL nodes (losses.py:108-118)
         logp = torch.log_softmax(logits.detach(), -1).gather(-1, tgt.clamp(min=0).long()[..., None])[..., 0]
         xs = (-(logp) * w[tgt.clamp(min=0).long()] * m).sum()
-        return loss, dict(xent=(xs, m.sum()), acc=(hit, m.sum()), loss=(loss.detach() * m.sum(), m.sum()))
+        # `loss` is a mean over the batch's padded (graph, node) slots (Keras SUM_OVER_BATCH_SIZE): its epoch figure is the slot-weighted mean
+        slots = torch.tensor(float(m.numel()), device=m.device, dtype=m.dtype)
+        return loss, dict(xent=(xs, m.sum()), acc=(hit, m.sum()), loss=(loss.detach() * slots, slots))
 
 
     @torch.no_grad()

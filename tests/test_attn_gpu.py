@@ -207,3 +207,45 @@ def test_attn_mfma_in_kernel_random_mask(N, d, gpu, egt_lib):
     assert_close(q.grad, ref["dQKV"], name="dQKV", **BWD)
     assert_close(e_.grad, ref["dE"], name="dE", **BWD)
     assert_close(g_.grad, ref["dG"], name="dG", **BWD)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,d", [(48, 64), (37, 16)])
+def test_attn_mfma_shared_workspace_fwd_to_bwd(N, d, gpu, egt_lib):
+    """EGT_ATTN_WS_SHARED: the forward packs the q / k / v operand copies of BOTH directions into one workspace and the backward
+    adds only dO.  The autograd front-end takes that path whenever an input needs a gradient (ctx.needs_input_grad); a second
+    backward through the same node (retain_graph) finds the workspace spent and re-packs: both must give the same gradients, bit
+    for bit, and the C-ABI pair called by hand with the two workspace modes likewise."""
+    import ctypes as C
+    from egt_amd import egt_attention, AttnConfig, _lib as L
+    B, H = 2, 8
+    g = torch.Generator().manual_seed(N * 3 + d)
+    QKV = (torch.randn(B, N, 3 * d * H, generator=g) * 0.7).to(gpu)
+    E = torch.randn(B, N, N, H, generator=g).to(gpu); G = torch.randn(B, N, N, H, generator=g).to(gpu)
+    mask = torch.ones(B, N, dtype=torch.bool); mask[1, N - 7:] = False
+    dV = torch.randn(B, N, d * H, generator=g).to(gpu); dH = torch.randn(B, N, N, H, generator=g).to(gpu)
+    cfg = AttnConfig(num_heads=H, need_a_tild=False, use_mfma=True)
+    q = QKV.clone().requires_grad_(); e_ = E.clone().requires_grad_(); g_ = G.clone().requires_grad_()
+    V, Hh, _ = egt_attention(q, e_, g_, None, mask.to(gpu), cfg=cfg)
+    assert V.grad_fn.mfma_ws is not None, "a forward that will be differentiated must take the shared workspace"
+    torch.autograd.backward([V, Hh], [dV, dH], retain_graph=True)
+    first = (q.grad.clone(), e_.grad.clone(), g_.grad.clone())
+    assert V.grad_fn.mfma_ws is None
+    q.grad = e_.grad = g_.grad = None
+    torch.autograd.backward([V, Hh], [dV, dH])                       # second pass: the re-packing backward
+    for a, b, n in zip(first, (q.grad, e_.grad, g_.grad), ("dQKV", "dE", "dG")):
+        assert torch.equal(a, b), n
+    with torch.no_grad():                                            # no gradient wanted: the forward-only workspace
+        V2, Hh2, _ = egt_attention(QKV, E, G, None, mask.to(gpu), cfg=cfg)
+    assert torch.equal(V2, V) and torch.equal(Hh2, Hh)
+    # the workspace-size contract at the C-ABI: the forward's size follows the SHARED bit
+    desc = L.AttnDesc(B=B, N=N, H=H, d=d, dtype=L.EGT_F32, flags=L.F_EDGE_INPUT | L.F_GATE_INPUT | L.F_CLIP, clip_lo=-5.0, clip_hi=5.0,
+                      random_mask_prob=0.0, attn_dropout=0.0, num_virtual_nodes=0, reserved=0, seed=0)
+    small = egt_lib.egt_attn_mfma_fwd_workspace_bytes(C.byref(desc))
+    desc.reserved = L.ATTN_WS_SHARED
+    assert egt_lib.egt_attn_mfma_fwd_workspace_bytes(C.byref(desc)) == egt_lib.egt_attn_mfma_workspace_bytes(C.byref(desc)) > small
+    desc.reserved = 0x40
+    ws = torch.empty(egt_lib.egt_attn_mfma_workspace_bytes(C.byref(desc)) or 16, dtype=torch.uint8, device=gpu)
+    rc = egt_lib.egt_attn_mfma_fwd(C.byref(desc), L.ptr(QKV), L.ptr(E), L.ptr(G), None, None, None, L.ptr(V2), L.ptr(Hh2),
+                                   L.ptr(torch.empty(B, N, H, 4, device=gpu)), L.ptr(ws), L.current_stream())
+    assert rc == L.EGT_E_FLAGS                                      # unknown reserved bits are refused, not ignored

@@ -1,7 +1,7 @@
 """k_block_bwd_v7 (twelve waves per CU, 32-row workgroups: egt_amd/csrc/egt_block_bwd7.h) against the fp64 oracle and against
-k_block_bwd_v5.  The dispatch takes v7 on its own only when a launch fills the chip (B * N / 32 >= CUs: the headline batch, covered
-by tests/test_fullsize_gpu.py); EGT_BWD_V7 = 1 / 0 (read once per process) forces / forbids it, so the small oracle-sized cases
-run in subprocesses with the variable set."""
+k_block_bwd_v5.  (With EGT_BWD_V7 = 2 it runs where a launch fills the chip -- B * N / 32 >= CUs: the headline batch, covered
+by tests/test_fullsize_gpu.py); it is OPT-IN -- EGT_BWD_V7 = 1 (every geometry it covers) / 2 (launches that fill the chip), read once
+per process -- so the cases run in subprocesses with the variable set."""
 import ctypes as C
 import json
 import os
@@ -98,8 +98,8 @@ def test_v7_stack_vs_oracle_and_v5(B, N, Ly, train, gpu, egt_lib, tmp_path):
             assert_close(a["grads"][f"blocks.{li}.{k}"], next(gi), name=f"L{li}.{k}", **BWD)
 
 
-def test_v7_is_the_headline_backward(gpu, egt_lib):
-    """the dispatch takes v7 by itself at the headline batch (one 32-row workgroup per CU) and not for launches that would leave CUs idle"""
+def test_v7_is_opt_in(gpu, egt_lib):
+    """k_block_bwd_v7 measured slower than k_block_bwd_v5 at the headline batch: without EGT_BWD_V7 the dispatch never takes it"""
     from egt_amd import _lib as L
     if os.environ.get("EGT_BWD_V7"):
         pytest.skip("EGT_BWD_V7 is set: the default dispatch is not what runs")
@@ -107,10 +107,18 @@ def test_v7_is_the_headline_backward(gpu, egt_lib):
                                                              random_mask_prob=0.0, ln_eps=1e-3, reserved=0, seed=0, seed_device=None)
     k = lambda d: egt_lib.egt_block_bwd_kernel(C.byref(d)).decode()
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    assert k(mk(cus // 2, 64)) == "k_block_bwd_v7"          # B * N / 32 == CUs (B = 128 on MI355X)
+    assert k(mk(cus // 2, 64)) == "k_block_bwd_v5"          # the headline batch (B = 128 on MI355X)
     assert k(mk(2, 64)) == "k_block_bwd_v5"
-    assert k(mk(cus // 2, 48)) == "k_block_bwd_v5"          # N not a multiple of 32
     assert k(mk(cus // 2, 64, De=48)) == "k_block_bwd_v5"
     assert k(mk(cus // 2, 64, dt=L.EGT_BF16)) == "k_block_bwd_v4"
     assert k(mk(cus // 2, 64, fl=L.BF_ATTN_MASK)) == "k_block_bwd_v4"
     assert k(mk(cus // 2, 64, De=8)) == "k_narrow_bwd"
+
+
+def test_v7_full_size_properties(gpu, egt_lib):
+    """the full-size property tests (fused == composed, linearity, bit-reproducibility, padded-key invariance at B = 128, N = 64) on v7"""
+    env = dict(os.environ, EGT_BWD_V7="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_fullsize_gpu.py"), "-m", "gpu", "-x", "-q", "-k", "zinc500k"],
+                       cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "passed" in r.stdout
