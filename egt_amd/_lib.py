@@ -134,6 +134,8 @@ _PROTOS = {
     "egt_prof_stride": (C.c_int, [C.c_int]),
     "egt_prof_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "egt_prof_names": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "egt_prof_collect_graph": (C.c_int, [C.c_int]),
+    "egt_prof_forget_graphs": (C.c_int, []),
 }
 # entry points added by later build stages; bound when present, listed here so the
 # "every declared symbol is exported" test sees one table

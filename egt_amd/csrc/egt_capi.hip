@@ -28,6 +28,9 @@ extern "C" int egt_abi_version(void) { return EGT_ABI_VERSION; }
 namespace {
 struct ProfEntry {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  // event pairs recorded as EXTERNAL event-record nodes of a hipGraph under capture: every replay of that graph re-records them,
+  // egt_prof_collect_graph() reads the latest completed replay.  They belong to the captured graph: never pooled, never dropped.
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> graph_pairs;
   int64_t count = 0;
   double ms = 0.0;
   int64_t seen = 0;   // launches met while enabled (egt_prof_stride samples them)
@@ -38,6 +41,12 @@ std::string g_filter;  // when non-empty only this kernel is timed
 int g_stride = 1;      // time every g_stride-th launch of a timed kernel
 std::unordered_map<std::string, ProfEntry> g_prof;
 std::vector<hipEvent_t> g_pool;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_retired;   // graph-resident pairs of a reset profile: their graphs may still replay
+
+bool stream_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
+}
 
 hipEvent_t get_event() {
   if (!g_pool.empty()) {
@@ -78,6 +87,14 @@ void egt_prof_begin(const char* name, hipStream_t s, void** tok) {
   if (!g_filter.empty() && g_filter != name) return;
   auto& e = g_prof[name];
   if (g_stride > 1 && (e.seen++ % g_stride) != 0) return;
+  if (stream_capturing(s)) {   // the launch is being captured into a hipGraph: the events become event-record nodes of that graph
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecordWithFlags(a, s, hipEventRecordExternal);
+    e.graph_pairs.emplace_back(a, b);
+    *tok = (void*)b;
+    return;
+  }
   hipEvent_t a = get_event(), b = get_event();
   (void)hipEventRecord(a, s);
   e.pending.emplace_back(a, b);
@@ -85,17 +102,22 @@ void egt_prof_begin(const char* name, hipStream_t s, void** tok) {
 }
 
 void egt_prof_end(void* tok, hipStream_t s) {
-  if (tok) (void)hipEventRecord((hipEvent_t)tok, s);
+  if (!tok) return;
+  if (stream_capturing(s)) (void)hipEventRecordWithFlags((hipEvent_t)tok, s, hipEventRecordExternal);
+  else (void)hipEventRecord((hipEvent_t)tok, s);
 }
 
 extern "C" int egt_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_enabled = on ? 1 : 0;
-  if (on == 2) {  // reset
-    for (auto& kv : g_prof) {
-      for (auto& p : kv.second.pending) { g_pool.push_back(p.first); g_pool.push_back(p.second); }
+  if (on == 2) {  // reset: counts, sums and un-read eager pairs go; the pairs that live inside captured graphs stay with their kernels
+    for (auto it = g_prof.begin(); it != g_prof.end();) {
+      auto& e = it->second;
+      for (auto& p : e.pending) { g_pool.push_back(p.first); g_pool.push_back(p.second); }
+      e.pending.clear();
+      e.count = 0; e.ms = 0.0; e.seen = 0;
+      if (e.graph_pairs.empty()) it = g_prof.erase(it); else ++it;
     }
-    g_prof.clear();
     g_enabled = 1;
   }
   return EGT_OK;
@@ -134,6 +156,37 @@ extern "C" int egt_prof_read(const char* name, int64_t* count, double* total_ms)
   e.pending.clear();
   *count = e.count;
   *total_ms = e.ms;
+  return EGT_OK;
+}
+
+// Timings of the launches that were captured into hipGraphs while the profile was enabled (their hipEvents are external
+// event-record nodes of those graphs): adds the LATEST replay's elapsed time of every such pair to the kernel's count / sum.
+// Call it when the replay to be read has completed (after a stream synchronisation); returns the number of pairs read.
+// `reset_counts` != 0 first zeroes the counts / sums of every kernel (the pairs stay: they belong to the graphs).
+extern "C" int egt_prof_collect_graph(int reset_counts) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int n = 0;
+  for (auto& kv : g_prof) {
+    auto& e = kv.second;
+    if (reset_counts) { e.count = 0; e.ms = 0.0; }
+    for (auto& p : e.graph_pairs) {
+      float ms = 0.f;
+      if (hipEventQuery(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess && ms > 0.f) {
+        e.ms += ms; e.count += 1; ++n;
+      }
+    }
+  }
+  return n;
+}
+
+// Forget the event pairs of captured graphs (call when those graphs are destroyed or no longer of interest; the events themselves
+// are kept alive -- a graph that still replays would otherwise record into freed events).
+extern "C" int egt_prof_forget_graphs(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& kv : g_prof) {
+    for (auto& p : kv.second.graph_pairs) g_retired.push_back(p);
+    kv.second.graph_pairs.clear();
+  }
   return EGT_OK;
 }
 

@@ -31,3 +31,4 @@ for v in ("0", "2"):
 json.dump(out, open("gpurun_out/r05_v7pmc/summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
+rm -rf $OUT/kt_* $OUT/pmc_*     # the rocprofv3 databases stay on the box (gpurun merges at most 64 MiB back)
