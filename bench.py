@@ -40,12 +40,20 @@ WORKLOADS = {
     # BASELINE.json configs[1]
     "zinc500k_n64": dict(B=128, N=64, Dh=64, De=64, H=8, Ly=10, nodes=(9, 37), rand_p=0.1),
     "zinc500k_n64_b1024": dict(B=1024, N=64, Dh=64, De=64, H=8, Ly=10, nodes=(9, 37), rand_p=0.1),   # large-batch sanity
+    # the full-occupancy variant of config 2 (every padded slot a real node: n_b = 64)
+    "zinc500k_n64_full": dict(B=128, N=64, Dh=64, De=64, H=8, Ly=10, nodes=(64, 64), rand_p=0.1),
     # the other BASELINE.json configs' shapes, for reference runs -- not bench lines
     "zinc100k_n37": dict(B=128, N=37, Dh=48, De=48, H=8, Ly=4, nodes=(9, 37), rand_p=0.1),
     "cifar10_n150_fp32": dict(B=128, N=150, Dh=64, De=8, H=8, Ly=4, nodes=(85, 150), rand_p=0.1),
     "cifar10_n150": dict(B=128, N=150, Dh=64, De=8, H=8, Ly=4, nodes=(85, 150), rand_p=0.1, edge_dtype="bf16"),
     "pattern500k_n120": dict(B=16, N=120, Dh=64, De=8, H=8, Ly=16, nodes=(44, 120), rand_p=0.1),
     "pattern500k_n120_b128": dict(B=128, N=120, Dh=64, De=8, H=8, Ly=16, nodes=(44, 120), rand_p=0.1),
+    # SURVEY 8(d) for config 4: n_b ~ U[44,188] padded to the PER-BATCH maximum (what the reference's padded_batch does,
+    # scheme_base.py:66 + dataset_base.py:106-111: N = None -> the batch's largest graph), and the fixed N = 188 row
+    "pattern500k_bmax": dict(B=16, N=None, Dh=64, De=8, H=8, Ly=16, nodes=(44, 188), rand_p=0.1),
+    "pattern500k_bmax_b128": dict(B=128, N=None, Dh=64, De=8, H=8, Ly=16, nodes=(44, 188), rand_p=0.1),
+    "pattern500k_n188": dict(B=16, N=188, Dh=64, De=8, H=8, Ly=16, nodes=(44, 188), rand_p=0.1),
+    "pattern500k_n188_b128": dict(B=128, N=188, Dh=64, De=8, H=8, Ly=16, nodes=(44, 188), rand_p=0.1),
     # the same graphs padded to the next multiple of 16 (what a caller's padded_batch can do for free):
     # unlocks the 16-row-exact backward (prologue inside the pair kernel) at the price of 14 % more pairs
     "cifar10_n150_pad160": dict(B=128, N=160, Dh=64, De=8, H=8, Ly=4, nodes=(85, 150), rand_p=0.1),
@@ -61,6 +69,9 @@ WORKLOADS = {
 }
 # what the metric string says after "graphs/sec EGT fwd+bwd, " (BASELINE.json's metric is quoted on the first)
 METRIC_OF = {"zinc500k_n64": "ZINC-500K padded N=64", "zinc500k_n64_b1024": "ZINC-500K padded N=64 (B=1024)",
+             "zinc500k_n64_full": "ZINC-500K shapes N=64, every node real (full occupancy)",
+             "pattern500k_bmax": "PATTERN-500K shapes padded to the per-batch max (B=16)", "pattern500k_bmax_b128": "PATTERN-500K shapes padded to the per-batch max (B=128)",
+             "pattern500k_n188": "PATTERN-500K shapes padded N=188 (B=16)", "pattern500k_n188_b128": "PATTERN-500K shapes padded N=188 (B=128)",
              "zinc100k_n37": "ZINC-100K shapes padded N=37", "cifar10_n150_fp32": "CIFAR10-500K shapes padded N=150 (fp32 edge tensors)",
              "cifar10_n150": "CIFAR10-500K shapes padded N=150 (bf16 edge tensors)", "pattern500k_n120": "PATTERN-500K shapes padded N=120 (B=16)",
              "pattern500k_n120_b128": "PATTERN-500K shapes padded N=120 (B=128)", "cifar10_n150_pad160": "CIFAR10-500K shapes padded N=160",
@@ -223,20 +234,34 @@ def cpu_baseline(w, seconds=12.0, Bs=8):
         return reps, time.perf_counter() - t0
 
     nthr = torch.get_num_threads()
-    runs = []                                            # (threads, graphs/s, reps, seconds)
-    for thr, sec in ((nthr, seconds * 0.5), (8, seconds * 0.5)) if nthr > 8 else ((nthr, seconds),):
+    ncpu = os.cpu_count() or nthr
+    # the all-cores figure (os.cpu_count() threads) and the 8-core figure.  Each leg is timed TWICE; when the two runs
+    # differ by more than 10 % a third decides (median) -- a baseline that wanders between runs of the same code is not one.
+    legs = [ncpu, 8] if ncpu > 8 else [ncpu]
+    runs = []                                            # (threads, graphs/s, reps, seconds, spread)
+    per = max(2.0, seconds / (2.0 * len(legs)))
+    for thr in legs:
         torch.set_num_threads(thr)
         try:
-            reps, dt = timed(sec)
+            rates, reps_t, secs_t = [], 0, 0.0
+            for _ in range(2):
+                reps, dt = timed(per)
+                rates.append(Bs * reps / dt); reps_t += reps; secs_t += dt
+            if abs(rates[0] - rates[1]) > 0.10 * max(rates):
+                reps, dt = timed(per)
+                rates.append(Bs * reps / dt); reps_t += reps; secs_t += dt
         finally:
             torch.set_num_threads(nthr)
-        runs.append((thr, Bs * reps / dt, reps, dt))
+        rs = sorted(rates)
+        runs.append((thr, rs[len(rs) // 2], reps_t, secs_t, (rs[-1] - rs[0]) / rs[len(rs) // 2]))
     best = max(runs, key=lambda r: r[1])                 # the baseline is the FASTER thread count
     out = dict(value=best[1], unit="graphs/s", cores=best[0], kind="port",
+               all_cores=dict(threads=runs[0][0], value=runs[0][1], spread=runs[0][4]),
+               eight_cores=(dict(threads=runs[1][0], value=runs[1][1], spread=runs[1][4]) if len(runs) > 1 else None),
                sample=f"{best[2]} fwd+bwd steps of the Ly={w['Ly']} block stack on B={Bs} graphs "
                       f"(N={w['N']}, fp32, torch-CPU restatement of the TF op sequence, "
-                      f"{best[3]:.1f}s, host has {os.cpu_count()} cpus; "
-                      + ", ".join(f"{t} threads: {v:.1f} graphs/s" for t, v, _, _ in runs) + ")")
+                      f"{best[3]:.1f}s, host has {ncpu} cpus; median of {2}-{3} timed runs per thread count: "
+                      + ", ".join(f"{t} threads: {v:.1f} graphs/s (spread {sp:.0%})" for t, v, _, _, sp in runs) + ")")
     return out
 
 
@@ -545,7 +570,7 @@ def main():
                          "on: forward + backward of the step replayed from ONE captured hipGraph (egt_amd.graph.GraphedStep; the "
                          "random-mask seeds live in device memory, EGT_BF_SEED_DEVICE, and advance inside the graph, so every "
                          "replay draws a fresh sample); the gradient collective stays an eager call after the replay.  The "
-                         "dominant kernel is then timed in the untimed eager pass (a replay has no per-launch host hooks)")
+                         "dominant kernel is timed by hipEvent-record nodes inside the captured graph (egt_prof_collect_graph)")
     ap.add_argument("--graph-collective", action="store_true",
                     help="with --graph on under a launcher: the flat gradient all-reduce is captured INTO the step's hipGraph (RCCL "
                          "supports stream capture), so a DP step is one host call; default: the collective is an eager call after the replay")
@@ -629,6 +654,9 @@ def main():
         w["B"] = hi - lo                 # this rank's contiguous slice of the global batch
         if w["B"] < 1:
             raise SystemExit("bench.py: strong scaling needs at least one graph per rank")
+    if w["N"] is None:                   # padded to the per-batch max (each rank pads to ITS shard's largest graph: SURVEY 8(e))
+        gN = torch.Generator().manual_seed(1234 + rank)     # the same first draw make_inputs() makes
+        w["N"] = int(torch.randint(w["nodes"][0], w["nodes"][1] + 1, (w["B"],), generator=gN).max())
     torch.manual_seed(1234)  # same weights on every rank (replicated parameters)
     mask_seed = 1 * world + rank  # the replicas draw independent random attention masks
     fused = {"auto": "auto", "on": True, "off": False}[args.fused]
@@ -784,8 +812,17 @@ def main():
         for _ in range(2):
             eager_step()
         fence()
+    # hipEvents around the dominant kernel INSIDE the captured graph: launches captured while the profile is enabled carry their
+    # events as external event-record nodes (egt_prof_collect_graph), so the dominant kernel is timed inside the timed region in the
+    # replay mode too.  Every GRAPH_STRIDE-th launch of it (of the 10 per step: launches 0, 3, 6, 9).
+    GRAPH_STRIDE = 3
     if args.graph in ("on", "calibrate"):
         from egt_amd import GraphedStep
+        if not args.no_prof:
+            lib.egt_prof_forget_graphs()
+            lib.egt_prof_filter(args.dominant.encode())
+            lib.egt_prof_stride(GRAPH_STRIDE)
+            lib.egt_prof_enable(2)
         in_graph = bool(args.graph_collective and use_dist and state["flat_ok"] is not None and (state["flat_ok"] or state["fa"] is not None))
         if in_graph:                     # forward + backward + the RCCL all-reduce of the flat gradient buffer: one graph, one host call
 
@@ -796,6 +833,8 @@ def main():
         else:
             graphed = GraphedStep(compute, seeds, warmup=1)
         state["collective_in_graph"] = in_graph
+        lib.egt_prof_enable(0)           # (the event nodes stay inside the graph)
+        lib.egt_prof_stride(1)
 
         def step():                      # ONE host call for forward + backward (and the collective when captured), else the eager collective
             graphed.replay()
@@ -810,9 +849,10 @@ def main():
             # (roofline.timed_in_region), a replay has no per-launch host hooks and the kernel is timed in the untimed eager pass
             use_graph = graph_ms < 0.99 * eager_ms
             step_mode = dict(chosen="graph" if use_graph else "eager", eager_ms_per_step=eager_ms, graph_ms_per_step=graph_ms,
-                             calibration_steps=ncal, rule="hipGraph replay if it is more than 1 % faster than the eager stream, else eager (the "
-                                                          "dominant kernel is then timed inside the timed region); outputs are bit-identical")
+                             calibration_steps=ncal, rule="hipGraph replay if it is more than 1 % faster than the eager stream, else eager; "
+                                                          "outputs are bit-identical; the dominant kernel is timed inside the timed region in both modes")
             if not use_graph:                # back to host-side seeds and one host call per kernel
+                lib.egt_prof_forget_graphs()
                 seeds.detach()
                 seeds = None
                 graphed = None
@@ -825,17 +865,29 @@ def main():
     # 4-5 us (ten of them per step were 2.5 % of the headline step), and a stride coprime with the launches per step walks
     # through the layers.  The per-kernel table comes from a second, untimed pass over the same steps below.
     PROF_STRIDE = 7
+    COLLECT_EVERY = 5                    # replay mode: the graph's event pairs are read after every 5th replay (one stream sync each)
     if not args.no_prof:
         lib.egt_prof_filter(args.dominant.encode())
         lib.egt_prof_stride(PROF_STRIDE)
-        lib.egt_prof_enable(2)
+        lib.egt_prof_enable(2)           # (reset: counts and un-read eager pairs; event pairs inside captured graphs are kept)
+    graph_prof = graphed is not None and not args.no_prof
+    # per-step hipEvents on the launch stream: SURVEY 8(d) asks for the MEDIAN step time beside the wall-clock mean
+    sev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    cur = torch.cuda.current_stream()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        sev[i].record(cur)
         step()
+        if graph_prof and (i % COLLECT_EVERY == COLLECT_EVERY - 1 or i == args.steps - 1):
+            cur.synchronize()
+            lib.egt_prof_collect_graph(0)
+    sev[args.steps].record(cur)
     fence()
     elapsed = time.perf_counter() - t0
     lib.egt_prof_enable(0)
     lib.egt_prof_stride(1)
+    step_ms = sorted(sev[i].elapsed_time(sev[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if step_ms else None
     graphs_step = w["B"]
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -848,14 +900,36 @@ def main():
         graphs_step = w["B"]
     dom_prof = prof_read_all(lib) if not args.no_prof else {}
     all_prof = {}
+    table_mode = "untimed eager pass, hipEvents around every launch"
     if not args.no_prof:   # every rank runs it (the step contains the collective)
         lib.egt_prof_filter(b"")
-        lib.egt_prof_enable(2)
-        for _ in range(min(args.steps, 10)):
-            eager_step()                 # (per-launch hipEvents need the host-side launches: eager also in --graph runs)
-        fence()
-        lib.egt_prof_enable(0)
-        all_prof = prof_read_all(lib)
+        if graphed is not None:
+            # replay mode: the per-kernel table comes from a SECOND captured graph of the same step with an event pair around EVERY
+            # launch, replayed and read ten times -- kernel durations as they are inside a replay, not inside an eager stream
+            from egt_amd import GraphedStep
+            lib.egt_prof_forget_graphs()
+            lib.egt_prof_enable(2)
+            pg = GraphedStep(graphed.fn, seeds, warmup=1)
+            lib.egt_prof_enable(2)       # drop the warm-up's eager pairs; the graph's pairs stay
+            lib.egt_prof_enable(0)
+            for _ in range(min(args.steps, 10)):
+                pg.replay()
+                if not state.get("collective_in_graph"):
+                    reduce()
+                torch.cuda.current_stream().synchronize()
+                lib.egt_prof_collect_graph(0)
+            fence()
+            all_prof = prof_read_all(lib)
+            lib.egt_prof_forget_graphs()
+            del pg
+            table_mode = "untimed replays of a second captured graph with an event-record pair around every launch"
+        else:
+            lib.egt_prof_enable(2)
+            for _ in range(min(args.steps, 10)):
+                eager_step()
+            fence()
+            lib.egt_prof_enable(0)
+            all_prof = prof_read_all(lib)
     # the one exchange step, timed on its own: hipEvents around the flat-buffer collective
     ar_us = None
     if use_dist:
@@ -939,6 +1013,8 @@ def main():
                                      for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
             else:
               roof = dict(bound="hbm", kernel=dom, timed_in_region=dom in dom_prof, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                        kernels_table=table_mode,
+                        kernels_sum_ms_per_step=sum(v[1] for v in prof.values()) / nprof,
                         frac=(ach / HBM_PEAK_GBS) if ach else None,
                         achievable_peak=HBM_ACHIEVABLE_GBS, frac_of_achievable=(ach / HBM_ACHIEVABLE_GBS) if ach else None,   # the 6.3 TB/s a streaming copy sustains (MI355X_MICROARCH.md, HBM)
                         traffic=traffic, issue=issue, mfma_busy=mfma_busy,
@@ -946,8 +1022,10 @@ def main():
                                         "FETCH_SIZE / WRITE_SIZE passes of this workload (FETCH doubled per the gfx950 note); not re-measured in this run"
                                         if traffic is not None else None),
                         avg_launch_us=avg_s * 1e6, launches=cnt, algorithmic_bytes_per_launch=ab,
-                        launches_sampled=(f"hipEvents around every {PROF_STRIDE}th launch of the kernel inside the timed region" if dom in dom_prof
-                                          else "every launch of the untimed eager pass"),
+                        launches_sampled=((f"external hipEvent-record nodes around every {GRAPH_STRIDE}rd launch of the kernel inside the captured graph, read "
+                                           f"after every {COLLECT_EVERY}th replay of the timed region") if (dom in dom_prof and graphed is not None) else
+                                          f"hipEvents around every {PROF_STRIDE}th launch of the kernel inside the timed region" if dom in dom_prof
+                                          else "every launch of the untimed pass"),
                         kernels={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3,
                                          share=v[1] / sum(x[1] for x in prof.values()))
                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
@@ -968,6 +1046,8 @@ def main():
                       + ("" if (args.scope or "stack") == "stack" and not args.with_ffn else f" ({args.scope or 'layers'} scope)"),
             "value": graphs / elapsed, "unit": "graphs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "median_ms_per_step": median_ms,     # per-step hipEvents on the launch stream; `value` stays the wall-clock figure of the contract
+            "value_at_median": (graphs_step / (median_ms * 1e-3)) if median_ms else None,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32 (edge tensors stored bf16)" if bf16 else "f32",
             "data": "synthetic",
@@ -988,10 +1068,11 @@ def main():
                        "random_mask_prob": w["rand_p"], "nodes": list(w["nodes"]), "path": path,
                        "parallelism": f"dp{world}", "grad_allreduce_bytes": nbytes,
                        "grad_allreduce_us": ar_us, "backend": ("rccl (egt_dp_* C-ABI)" if comm is not None else "rccl") if use_dist else "none (single process)",
+                       "rccl_nranks": (comm.world if comm is not None else dist.get_world_size()) if use_dist else None,   # what the communicator reports
                        "flat_grad_adopted": bool(state["flat_ok"]), "flat_grad_bound": bool(state.get("bound")),
                        "hipgraph": (f"forward + backward{' + the gradient all-reduce' if state.get('collective_in_graph') else ''} replayed from one "
                                     f"captured hipGraph ({graphed.replays} replays), device-resident "
-                                    "mask seeds; dominant kernel timed in the untimed eager pass") if graphed is not None else None,
+                                    "mask seeds; dominant kernel timed by event-record nodes inside the graph") if graphed is not None else None,
                        "step_mode": step_mode,
                        "collective_in_graph": bool(state.get("collective_in_graph"))},
             "roofline": roof, "cpu_baseline": cpu, ("eager_step" if graphed is not None else "hipgraph_replay"): graph_leg,

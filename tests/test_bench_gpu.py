@@ -52,7 +52,9 @@ def test_bench_default_calibrates_the_step_mode():
     sm = line["config"]["step_mode"]
     assert sm["chosen"] in ("eager", "graph") and sm["eager_ms_per_step"] > 0 and sm["graph_ms_per_step"] > 0
     assert (sm["chosen"] == "graph") == (sm["graph_ms_per_step"] < 0.99 * sm["eager_ms_per_step"])
-    assert line["roofline"]["timed_in_region"] == (sm["chosen"] == "eager")
+    assert line["roofline"]["timed_in_region"] is True      # eager: per-launch hipEvents; replay: event-record nodes inside the captured graph
+    assert line["roofline"]["launches"] >= 1 and line["median_ms_per_step"] > 0 and line["value_at_median"] > 0
+    assert line["roofline"]["kernels_sum_ms_per_step"] > 0
     assert (line["config"]["hipgraph"] is not None) == (sm["chosen"] == "graph")
     other = "eager_step" if sm["chosen"] == "graph" else "hipgraph_replay"
     assert other in line and line[other] and line[other].get("value", 0) > 0, line.get(other)
@@ -70,7 +72,8 @@ def test_bench_graph_replay_under_launcher_with_the_eager_collective():
     assert line["n_gpus"] == 1 and line["config"]["backend"] == "rccl"
     assert "hipGraph (6 replays)" in line["config"]["hipgraph"]            # 3 settle + 3 timed
     assert line["config"]["grad_allreduce_us"] is not None and line["config"]["grad_allreduce_us"] > 0
-    assert line["roofline"]["timed_in_region"] is False and line["roofline"]["avg_launch_us"] > 0
+    assert line["roofline"]["timed_in_region"] is True and line["roofline"]["avg_launch_us"] > 0   # event-record nodes inside the graph
+    assert "captured graph" in line["roofline"]["launches_sampled"] and line["config"]["rccl_nranks"] == 1
     assert line["value"] > 0
 
 
@@ -152,3 +155,31 @@ def test_bench_world_size_mismatch_is_an_error():
     r = subprocess.run(cmd, cwd=REPO, env=_env(), capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     assert "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_capi_allreduce_is_a_node_of_a_captured_graph():
+    """egt_dp_allreduce under stream capture (1-rank RCCL communicator): the collective becomes part of the graph -- nothing runs at
+    capture time, and every REPLAY applies it (the count-weighted form scales the buffer by local / global each time)."""
+    code = r"""
+import torch
+from egt_amd.dp import CapiComm
+torch.cuda.set_device(0)
+c = CapiComm(rank=0, world=1)
+x = torch.randn(100003, device="cuda"); ref = x.clone()
+c.all_reduce_flat(x, True, local_count=1, global_count=1)       # un-captured first call: RCCL's lazy set-up
+torch.cuda.synchronize(); assert torch.equal(x, ref)
+side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g, stream=side):
+    c.all_reduce_flat(x, True, local_count=3, global_count=4)
+torch.cuda.synchronize()
+assert torch.equal(x, ref), "a captured collective must not execute at capture time"
+g.replay(); torch.cuda.synchronize()
+assert torch.allclose(x, ref * 0.75)
+g.replay(); g.replay(); torch.cuda.synchronize()
+assert torch.allclose(x, ref * 0.75 ** 3)
+c.close()
+print("CAPTURED_COLLECTIVE_OK")
+"""
+    r = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CAPTURED_COLLECTIVE_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]

@@ -253,17 +253,17 @@ def test_config3_as_specified_bf16_depth4_margins(gpu, egt_lib, capsys):
     BASELINE.json's request for this config -- the reference itself is fp32 everywhere), training mode with the in-kernel random
     mask, node counts in [85, 150].  Forward and every gradient against the fp64 oracle fed the same bf16-rounded inputs; the
     worst error / tolerance of every output is PRINTED and written to gpurun_out/bf16_margins.json.
-    Two oracles: (a) the one that also ROUNDS the intermediate e_l / de_l to bfloat16 where the kernels store them (what "bf16
-    edge tensors" means: the storage type) -- its margins isolate the ARITHMETIC of the kernels, including the bf16-operand
-    MFMAs of the gradient path (egt_narrow.hip), and are asserted; (b) the plain fp64 oracle without storage rounding, as in
-    test_stack_bf16_edge_tensors_vs_oracle -- at depth 4 the storage rounding alone takes de to ~1.0 of the bound (measured
-    1.02 with bf16-operand MFMAs, 1.04 with exact fp32 MFMAs: the arithmetic is not what uses the margin), recorded and
-    bounded at 1.25."""
+    Two oracles, both ASSERTED: (a) the plain fp64 oracle, under the depth-dependent bf16 contract of BASELINE.md section 2b
+    (tests/util.py: bf16_stack_tol(Ly) = SURVEY's single-operator rtol 2e-2 times max(1, sqrt(Ly / 2)) -- the storage rounding of
+    e_l / de_l at 2 Ly points is the error, and it adds in quadrature: measured 1.02 x the single-operator bound at Ly = 4, i.e.
+    0.72 of the contract); (b) the oracle that also ROUNDS the intermediate e_l / de_l to bfloat16 where the kernels store them,
+    under the SINGLE-operator tolerance: its margins isolate the ARITHMETIC of the kernels, including the bf16-operand MFMAs of
+    the gradient path (egt_narrow.hip)."""
     import json
     from egt_amd import EGTStack
     from egt_amd.fused import layer_seed
     from oracle import egt_oracle as O, rng_ref
-    from util import margin
+    from util import margin, bf16_stack_tol
     B, N, De, Dh, Ly, p = 2, 150, 8, 64, 4, 0.1
     torch.manual_seed(31)
     st = EGTStack(model_height=Ly, model_width=Dh, edge_width=De, num_heads=8, random_mask_prob=p, seed=5, fused=True).to(gpu).train()
@@ -283,10 +283,11 @@ def test_config3_as_specified_bf16_depth4_margins(gpu, egt_lib, capsys):
     b0 = st.blocks[0].mha
     seed = (b0.seed * 0x9E3779B97F4A7C15 + b0._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
     rms = [torch.from_numpy(rng_ref.random_mask(layer_seed(seed, l), B, N, 8, p)) for l in range(Ly)]
-    tol = dict(rtol=2e-2, arel=1e-2)       # bf16 rtol 2e-2
-    ptol = dict(rtol=3e-2, arel=2e-2)
+    tol1, ptol1 = bf16_stack_tol(1), bf16_stack_tol(1, params=True)        # bf16 rtol 2e-2 (one operator)
+    tolL, ptolL = bf16_stack_tol(Ly), bf16_stack_tol(Ly, params=True)      # the stack contract
 
     def oracle_margins(storage):
+        tol, ptol = (tol1, ptol1) if storage else (tolL, ptolL)
         layers = [{k: getattr(getattr(blk, m), a_).detach().double().cpu().requires_grad_()
                    for k, (m, a_) in PMAP.items()} for blk in st.blocks]
         h64 = h.double().requires_grad_(); e64 = e.double().requires_grad_()
@@ -315,13 +316,14 @@ def test_config3_as_specified_bf16_depth4_margins(gpu, egt_lib, capsys):
     try:
         os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
         json.dump(dict(config="cifar10_n150 as specified: B=2, N=150, Dh=64, De=8, H=8, Ly=4, bf16 edge tensors, random_mask_prob 0.1",
-                       tolerance=dict(outputs=tol, parameter_gradients=ptol),
+                       tolerance=dict(single_operator=dict(outputs=tol1, parameter_gradients=ptol1), stack_contract=dict(outputs=tolL, parameter_gradients=ptolL),
+                                      note="storage-aware oracle judged by the single-operator tolerance, plain fp64 oracle by the stack contract (BASELINE.md 2b)"),
                        worst_error_over_tolerance_vs_oracle_with_bf16_storage=ms, worst_error_over_tolerance_vs_plain_fp64_oracle=mp),
                   open(os.path.join(REPO, "gpurun_out", "bf16_margins.json"), "w"), indent=1)
     except OSError:
         pass
     assert ms[ws] < 1.0, (ws, ms[ws])
-    assert mp[wp] < 1.25, (wp, mp[wp])
+    assert mp[wp] < 1.0, (wp, mp[wp])          # the as-specified config against the PLAIN fp64 oracle, under the documented stack contract
 
 
 @pytest.mark.parametrize("N,De,Dh,train,Ly", [(32, 64, 64, True, 3), (20, 8, 64, False, 2), (37, 48, 48, True, 2),
@@ -332,8 +334,9 @@ def test_config3_as_specified_bf16_depth4_margins(gpu, egt_lib, capsys):
                                               (150, 8, 64, True, 2), (160, 8, 64, False, 2), (120, 8, 64, True, 2)])
 def test_stack_bf16_edge_tensors_vs_oracle(N, De, Dh, train, Ly, gpu, egt_lib):
     """EGT_BF16 (BASELINE config 3's dtype): e / e' / de' / de are bfloat16 in HBM, arithmetic fp32.
-    The fp64 oracle gets the SAME bf16-rounded inputs; tolerance is SURVEY §8(c)'s bf16 figure
-    (rtol 2e-2, plus the rounding of the intermediate e_l the oracle does not do)."""
+    The plain fp64 oracle gets the SAME bf16-rounded inputs; the tolerance is the stack contract of BASELINE.md section 2b
+    (tests/util.py: bf16_stack_tol(Ly) -- SURVEY 8(c)'s single-operator rtol 2e-2 up to two blocks, times sqrt(Ly / 2) beyond)."""
+    from util import bf16_stack_tol
     from egt_amd import EGTStack
     from egt_amd.fused import layer_seed
     from oracle import egt_oracle as O, rng_ref
@@ -367,7 +370,7 @@ def test_stack_bf16_edge_tensors_vs_oracle(N, De, Dh, train, Ly, gpu, egt_lib):
     ho, eo = O.stack_forward(h64, e64, mask, layers, num_heads=8, rand_masks=rms)
     flat = [t for lp in layers for t in lp.values()]
     gr = torch.autograd.grad([ho, eo], [h64, e64] + flat, [dh.double(), de.double()])
-    tol = dict(rtol=2e-2, arel=1e-2)
+    tol, ptol = bf16_stack_tol(Ly), bf16_stack_tol(Ly, params=True)
     assert_close(h2, ho, name="h_out", **tol)
     assert_close(e2.float(), eo, name="e_out", **tol)
     assert_close(hg.grad, gr[0], name="dh", **tol)
@@ -375,7 +378,7 @@ def test_stack_bf16_edge_tensors_vs_oracle(N, De, Dh, train, Ly, gpu, egt_lib):
     gi = iter(gr[2:])
     for li, blk in enumerate(st.blocks):
         for k, (m, a_) in PMAP.items():
-            assert_close(getattr(getattr(blk, m), a_).grad, next(gi), name=f"L{li}.{k}", rtol=3e-2, arel=2e-2, l2=3e-2)
+            assert_close(getattr(getattr(blk, m), a_).grad, next(gi), name=f"L{li}.{k}", l2=ptol["rtol"], **ptol)
 
 
 @pytest.mark.parametrize("N,De,Dh", [(37, 48, 48), (64, 64, 64), (40, 8, 32)])
