@@ -152,6 +152,20 @@ def algorithmic_flops(kernel: str, w: dict, scope: str) -> float:
     return per_row * (n_edge * B * N * N * De * De + Ly * B * N * Dh * Dh)
 
 
+def event_pair_overhead_us(n=64):
+    """what an EMPTY hipEvent pair on the launch stream measures (two records back to back): the share of a per-launch figure that
+    is the event machinery, not the kernel and its launch gap.  Median of n pairs, after a synchronisation (untimed phase only)."""
+    st = torch.cuda.current_stream()
+    pairs = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st); b.record(st)
+        pairs.append((a, b))
+    st.synchronize()
+    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in pairs)
+    return ts[len(ts) // 2]
+
+
 def prof_read_all(lib):
     buf = C.create_string_buffer(4096)
     lib.egt_prof_names(buf, 4096)
@@ -235,12 +249,50 @@ def cpu_baseline(w, seconds=12.0, Bs=8):
 
     nthr = torch.get_num_threads()
     ncpu = os.cpu_count() or nthr
-    # the all-cores figure (os.cpu_count() threads) and the 8-core figure.  Each leg is timed TWICE; when the two runs
-    # differ by more than 10 % a third decides (median) -- a baseline that wanders between runs of the same code is not one.
+    try:                                                 # cores this process may really use (affinity mask, cgroup quota)
+        ncpu = min(ncpu, len(os.sched_getaffinity(0)))
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            ncpu = max(1, min(ncpu, int(float(q[0]) / float(q[1]) + 0.5)))
+    except Exception:  # noqa: BLE001
+        pass
+    # the all-cores figure (every core this process may use) and the 8-core figure.  Each leg is timed TWICE; when the
+    # two runs differ by more than 10 % a third decides (median) -- a baseline that wanders between runs of the same code is not one.
+    # The op sequence works on small tensors: beyond a handful of threads torch's intra-op pool only adds hand-off cost, and on a
+    # 256-CPU host ONE step at 256 threads took over a minute (round 5).  So the all-cores leg starts with a probe -- one block on one
+    # graph, at all cores and at 8 threads; when all cores run the probe at less than half the 8-thread rate the full leg is not run
+    # and the all-cores figure is the 8-thread figure scaled by the probe's ratio (marked `extrapolated`): the default bench.py run
+    # has to finish within minutes.
+    def probe(thr):
+        wp = dict(w, Ly=1)
+        hp, ep, mp, dhp, dep = make_inputs(dict(wp, B=1), "cpu", seed=78)
+        hp.requires_grad_(); ep.requires_grad_()
+        lp = [layers[0]]
+        rp = [rms[0][:1]]
+        def one():
+            a2, b2 = O.stack_forward(hp, ep, mp, lp, num_heads=w["H"], rand_masks=rp)
+            torch.autograd.grad([a2, b2], [hp, ep] + list(lp[0].values()), [dhp, dep])
+        torch.set_num_threads(thr)
+        try:
+            one()
+            t_ = time.perf_counter(); n_ = 0
+            while n_ < 3 or (time.perf_counter() - t_ < 0.5 and n_ < 50):
+                one(); n_ += 1
+            return n_ / (time.perf_counter() - t_)
+        finally:
+            torch.set_num_threads(nthr)
+
     legs = [ncpu, 8] if ncpu > 8 else [ncpu]
-    runs = []                                            # (threads, graphs/s, reps, seconds, spread)
+    ratio = None
+    if len(legs) > 1:
+        ratio = probe(ncpu) / probe(8)
+    runs = []                                            # (threads, graphs/s, reps, seconds, spread, extrapolated)
     per = max(2.0, seconds / (2.0 * len(legs)))
-    for thr in legs:
+    for thr in reversed(legs):                           # the 8-thread leg first: the extrapolation needs it
+        if thr == ncpu and ratio is not None and ratio < 0.5:
+            eight = runs[0]
+            runs.append((thr, eight[1] * ratio, 0, 0.0, 0.0, True))
+            continue
         torch.set_num_threads(thr)
         try:
             rates, reps_t, secs_t = [], 0, 0.0
@@ -253,15 +305,18 @@ def cpu_baseline(w, seconds=12.0, Bs=8):
         finally:
             torch.set_num_threads(nthr)
         rs = sorted(rates)
-        runs.append((thr, rs[len(rs) // 2], reps_t, secs_t, (rs[-1] - rs[0]) / rs[len(rs) // 2]))
+        runs.append((thr, rs[len(rs) // 2], reps_t, secs_t, (rs[-1] - rs[0]) / rs[len(rs) // 2], False))
+    runs = runs[::-1] if len(runs) > 1 else runs         # [all cores, 8 threads]
     best = max(runs, key=lambda r: r[1])                 # the baseline is the FASTER thread count
     out = dict(value=best[1], unit="graphs/s", cores=best[0], kind="port",
-               all_cores=dict(threads=runs[0][0], value=runs[0][1], spread=runs[0][4]),
+               all_cores=dict(threads=runs[0][0], value=runs[0][1], spread=runs[0][4], extrapolated=runs[0][5],
+                              probe_ratio_vs_8_threads=ratio),
                eight_cores=(dict(threads=runs[1][0], value=runs[1][1], spread=runs[1][4]) if len(runs) > 1 else None),
                sample=f"{best[2]} fwd+bwd steps of the Ly={w['Ly']} block stack on B={Bs} graphs "
                       f"(N={w['N']}, fp32, torch-CPU restatement of the TF op sequence, "
-                      f"{best[3]:.1f}s, host has {ncpu} cpus; median of {2}-{3} timed runs per thread count: "
-                      + ", ".join(f"{t} threads: {v:.1f} graphs/s (spread {sp:.0%})" for t, v, _, _, sp in runs) + ")")
+                      f"{best[3]:.1f}s, host has {os.cpu_count()} cpus, {ncpu} usable; median of 2-3 timed runs per thread count: "
+                      + ", ".join(f"{t} threads: {v:.1f} graphs/s ({'extrapolated from a one-block probe' if ex else f'spread {sp:.0%}'})"
+                                  for t, v, _, _, sp, ex in runs) + ")")
     return out
 
 
@@ -814,8 +869,9 @@ def main():
         fence()
     # hipEvents around the dominant kernel INSIDE the captured graph: launches captured while the profile is enabled carry their
     # events as external event-record nodes (egt_prof_collect_graph), so the dominant kernel is timed inside the timed region in the
-    # replay mode too.  Every GRAPH_STRIDE-th launch of it (of the 10 per step: launches 0, 3, 6, 9).
-    GRAPH_STRIDE = 3
+    # replay mode too.  Every GRAPH_STRIDE-th launch of it (of the 10 per step: launches 0 and 7 -- an event-record node costs the
+    # replay ~5 us, four pairs per step were 2 % of the headline step).
+    GRAPH_STRIDE = 7
     if args.graph in ("on", "calibrate"):
         from egt_amd import GraphedStep
         if not args.no_prof:
@@ -930,6 +986,7 @@ def main():
             fence()
             lib.egt_prof_enable(0)
             all_prof = prof_read_all(lib)
+    pair_ov = event_pair_overhead_us() if (all_prof and graphed is None) else None   # (eager table only: the replay table's pairs are graph nodes)
     # the one exchange step, timed on its own: hipEvents around the flat-buffer collective
     ar_us = None
     if use_dist:
@@ -1014,7 +1071,11 @@ def main():
             else:
               roof = dict(bound="hbm", kernel=dom, timed_in_region=dom in dom_prof, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                         kernels_table=table_mode,
+                        # sum of (launches x mean) over the table: what the step's kernels AND their launch gaps add up to, plus one event
+                        # pair's own cost per launch (an empty pair measures it: event_pair_overhead_us); `net` has that cost taken out
                         kernels_sum_ms_per_step=sum(v[1] for v in prof.values()) / nprof,
+                        event_pair_overhead_us=pair_ov,
+                        kernels_sum_net_ms_per_step=(sum(v[1] - v[0] * pair_ov * 1e-3 for v in prof.values()) / nprof) if pair_ov is not None else None,
                         frac=(ach / HBM_PEAK_GBS) if ach else None,
                         achievable_peak=HBM_ACHIEVABLE_GBS, frac_of_achievable=(ach / HBM_ACHIEVABLE_GBS) if ach else None,   # the 6.3 TB/s a streaming copy sustains (MI355X_MICROARCH.md, HBM)
                         traffic=traffic, issue=issue, mfma_busy=mfma_busy,
@@ -1022,7 +1083,7 @@ def main():
                                         "FETCH_SIZE / WRITE_SIZE passes of this workload (FETCH doubled per the gfx950 note); not re-measured in this run"
                                         if traffic is not None else None),
                         avg_launch_us=avg_s * 1e6, launches=cnt, algorithmic_bytes_per_launch=ab,
-                        launches_sampled=((f"external hipEvent-record nodes around every {GRAPH_STRIDE}rd launch of the kernel inside the captured graph, read "
+                        launches_sampled=((f"hipEvent-record nodes around every {GRAPH_STRIDE}th launch of the kernel inside the captured graph, read "
                                            f"after every {COLLECT_EVERY}th replay of the timed region") if (dom in dom_prof and graphed is not None) else
                                           f"hipEvents around every {PROF_STRIDE}th launch of the kernel inside the timed region" if dom in dom_prof
                                           else "every launch of the untimed pass"),

@@ -47,6 +47,20 @@ bool stream_capturing(hipStream_t s) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
 }
+// An event-record NODE at the capturing stream's current position.  (hipEventRecordWithFlags(.., hipEventRecordExternal) is the
+// one-call form of this, but the HIP runtime torch 2.10 ships answers it with hipErrorInvalidValue under capture -- probed on the
+// box, tools/micro/graph_event_probe.py; the explicit form below works there: every replay re-records the event.)
+void record_node_in_capture(hipStream_t s, hipEvent_t ev) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t ndeps = 0;
+  if (hipStreamGetCaptureInfo_v2(s, &st, &id, &graph, &deps, &ndeps) != hipSuccess || st != hipStreamCaptureStatusActive) return;
+  hipGraphNode_t node = nullptr;
+  if (hipGraphAddEventRecordNode(&node, graph, deps, ndeps, ev) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (hipStreamUpdateCaptureDependencies(s, &node, 1, hipStreamSetCaptureDependencies) != hipSuccess) (void)hipGetLastError();
+}
 
 hipEvent_t get_event() {
   if (!g_pool.empty()) {
@@ -88,9 +102,8 @@ void egt_prof_begin(const char* name, hipStream_t s, void** tok) {
   auto& e = g_prof[name];
   if (g_stride > 1 && (e.seen++ % g_stride) != 0) return;
   if (stream_capturing(s)) {   // the launch is being captured into a hipGraph: the events become event-record nodes of that graph
-    hipEvent_t a, b;
-    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    (void)hipEventRecordWithFlags(a, s, hipEventRecordExternal);
+    hipEvent_t a = get_event(), b = get_event();   // (from the pool egt_prof_enable filled before the capture began)
+    record_node_in_capture(s, a);
     e.graph_pairs.emplace_back(a, b);
     *tok = (void*)b;
     return;
@@ -103,13 +116,16 @@ void egt_prof_begin(const char* name, hipStream_t s, void** tok) {
 
 void egt_prof_end(void* tok, hipStream_t s) {
   if (!tok) return;
-  if (stream_capturing(s)) (void)hipEventRecordWithFlags((hipEvent_t)tok, s, hipEventRecordExternal);
+  if (stream_capturing(s)) record_node_in_capture(s, (hipEvent_t)tok);
   else (void)hipEventRecord((hipEvent_t)tok, s);
 }
 
 extern "C" int egt_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_enabled = on ? 1 : 0;
+  if (on) {   // events a capture may need exist before it begins (no event creation inside a capturing region)
+    while (g_pool.size() < 256) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; g_pool.push_back(e); }
+  }
   if (on == 2) {  // reset: counts, sums and un-read eager pairs go; the pairs that live inside captured graphs stay with their kernels
     for (auto it = g_prof.begin(); it != g_prof.end();) {
       auto& e = it->second;

@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) c2r[r] = a.pw[16 * 16 + 4 * q + r];
   v4f accT = {0.f, 0.f, 0.f, 0.f}, accR = {0.f, 0.f, 0.f, 0.f};
-  float ssum[4] = {0.f, 0.f, 0.f, 0.f};
+  float ssum = 0.f;   // column p of dGE summed over the pairs 4 s + q of every step (the B operands of the T product): ONE register
   const float hcst = p == 8 ? 1.0f : 0.0f;   // columns 8..15 of the [H_hat | 1] operand
 
   const int ntile = (N + 15) / 16;
@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
       const float* qr = qd + li * QD_LD;
       const float4* qp = reinterpret_cast<const float4*>(qr + q * 16);
       const float4* dp = reinterpret_cast<const float4*>(qr + 64 + q * 16);
-      float dots[2], dAd[2], dq[16];
+      float dots[2], dAd[2];
       {
         float d0 = 0.f, d1 = 0.f, e0 = 0.f, e1 = 0.f;
 #pragma unroll
@@ -611,7 +611,11 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
           d0 = fmaf(v.z, kf.z, d0); d1 = fmaf(v.w, kf.w, d1);
           e0 = fmaf(w.x, vf.x, e0); e1 = fmaf(w.y, vf.y, e1);
           e0 = fmaf(w.z, vf.z, e0); e1 = fmaf(w.w, vf.w, e1);
-          dq[4*u] = kf.x; dq[4*u+1] = kf.y; dq[4*u+2] = kf.z; dq[4*u+3] = kf.w;
+          if (u == 1) {   // two of the four 16-byte pieces of Q / dV_att / K / V in flight at a time (32 registers instead of 64 at the
+                          // kernel's register peak); the pins keep the partial dot products on this side of the fence
+            asm volatile("" : "+v"(d0), "+v"(d1), "+v"(e0), "+v"(e1));
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
         dots[0] = d0; dots[1] = d1; dAd[0] = e0; dAd[1] = e1;
       }
@@ -649,14 +653,13 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
           dge[2 * j + 1] = dH;
         }
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ssum[r] += dge[r];
       // ---- B operands of the weight-gradient products: dGE, then [H_hat | 1 | 0] -- the SAME tile, in DS order ----
       *reinterpret_cast<float4*>(op + p * NRW_OPW + 4 * q) = make_float4(dge[0], dge[1], dge[2], dge[3]);
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) wb1[s4] = op[(4 * s4 + q) * NRW_OPW + p];
       asm volatile("" ::: "memory");
+      ssum += (wb1[0] + wb1[1]) + (wb1[2] + wb1[3]);
       *reinterpret_cast<float2*>(op + p * NRW_OPW + 2 * q) = make_float2(hh[0], hh[1]);
       asm volatile("" ::: "memory");
 #pragma unroll
@@ -665,8 +668,14 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
       // ---- d ehat = Wp'.dGE (channels 2q, 2q+1 in d4[0], d4[1]) ----
       const v4f d4 = nrw_mm<MB, 4>(wdA, nrw_op<MB>(dge[0], dge[1], dge[2], dge[3]), (v4f){0.f, 0.f, 0.f, 0.f});
       // ---- dQ of the row over this tile's 16 keys -> HBM (summed over key tiles by the next prologue / k_node_bwd) ----
+      // (K of the lane's key is read from its LDS tile a second time: sixteen registers held across the softmax phase were what
+      //  spilled the fp32 instances at three workgroups per CU)
+      float dq[16];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { dq[2 * k] *= dA[0]; dq[2 * k + 1] *= dA[1]; }
+      for (int u = 0; u < 4; ++u) {
+        const float4 kf = *reinterpret_cast<const float4*>(kt + u * 256 + lane * 4);
+        dq[4*u] = kf.x * dA[0]; dq[4*u+1] = kf.y * dA[1]; dq[4*u+2] = kf.z * dA[0]; dq[4*u+3] = kf.w * dA[1];
+      }
       a.dqp[(((size_t)b * ntile + mt) * N + l) * 64 + lane] = reduce16_keep_own(dq, p);
       // ---- dK / dV (Q / dV_att of the row re-read: not held across the softmax phase) ----
 #pragma unroll
@@ -725,8 +734,7 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
   }
   NSTMP(4);   // dK / dV stores, parked partials
   // ---- edge-parameter gradient partials of the workgroup: T [16][16] | s [16] | R [16][16] ----
-#pragma unroll
-  for (int r = 0; r < 4; ++r) ssum[r] = row_sum16(ssum[r]);   // sum over the 16 key lanes with the same q
+  ssum = nrw_sum4rows(ssum);   // column p: the four lane rows hold the pairs q, 4 + q, 8 + q, 12 + q
   __syncthreads();
   {
     float* ep = sm + wave * 528;
@@ -737,10 +745,7 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
       ep[row * 16 + col] = row < 8 ? accT[r4] : 0.f;                          // T = rows 0..7 of [xhat | de']^T.dGE (channels >= De: 0)
       ep[272 + ((row + 8) & 15) * 16 + col] = row >= 8 ? accR[r4] : 0.f;      // R = rows 8..15 of [xhat | de']^T.[H_hat | 1]
     }
-    if (p == 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ep[256 + 4 * q + r] = ssum[r];
-    }
+    if (q == 0) ep[256 + p] = ssum;
   }
   __syncthreads();
   float* out = a.epart + (size_t)wg * 528;

@@ -448,7 +448,7 @@ int egt_prof_filter(const char* kernel_name); /* time only this kernel (NULL/"" 
 int egt_prof_stride(int every);               /* time every `every`-th launch of each timed kernel (default 1 = all): an event pair
                                                 * costs the stream a few microseconds, a sample keeps a throughput measurement honest */
 int egt_prof_read(const char* name, int64_t* count, double* total_ms);
-/* Launches captured into a hipGraph while the profile is enabled carry their hipEvents as external event-record nodes of
+/* Launches captured into a hipGraph while the profile is enabled carry their hipEvents as event-record nodes of
  * that graph; every replay re-records them.  After a replay has completed, egt_prof_collect_graph() adds its elapsed times to
  * the kernels' counts / sums (reset_counts != 0: zero them first) and returns the number of event pairs read. */
 int egt_prof_collect_graph(int reset_counts);
