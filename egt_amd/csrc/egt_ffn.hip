@@ -137,13 +137,26 @@ __device__ __forceinline__ void slab_read(v4f (&w)[N], const float* slab_lane) {
 }
 
 // pre-activation tile j of the lane's row: W1p^T . xhat + b1p   (16 MFMA)
-template <int W>
+// TWO: two alternating accumulators (k_ffn_bwd: one wave per SIMD, nothing else fills the 8 idle cycles between dependent MFMAs;
+// the forward's two waves per SIMD cover each other and keep the single chain -- and its bit pattern)
+template <int W, bool TWO = false>
 __device__ __forceinline__ v4f ffn_gemm1(const float* s1, const float* b1s, const float4 (&x)[W / 16], int j, int lane, int q) {
   constexpr int TW = W / 16;
   const float4 bj = *reinterpret_cast<const float4*>(b1s + 16 * j + 4 * q);
   v4f acc = {bj.x, bj.y, bj.z, bj.w};
   v4f w[TW];
   slab_read<TW>(w, s1 + (j * TW * 64 + lane) * 4);
+  if constexpr (TWO) {
+    v4f acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+      acc = MFMA(w[t][0], x[t].x, acc);
+      acc2 = MFMA(w[t][1], x[t].y, acc2);
+      acc = MFMA(w[t][2], x[t].z, acc);
+      acc2 = MFMA(w[t][3], x[t].w, acc2);
+    }
+    return acc + acc2;
+  } else {
 #pragma unroll
   for (int t = 0; t < TW; ++t) {
     acc = MFMA(w[t][0], x[t].x, acc);
@@ -152,6 +165,7 @@ __device__ __forceinline__ v4f ffn_gemm1(const float* s1, const float* b1s, cons
     acc = MFMA(w[t][3], x[t].w, acc);
   }
   return acc;
+  }
 }
 
 // ================================================================== forward =====
@@ -421,12 +435,15 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
   v4f accT1[TW * TH], accT2[TH * TW];   // T1[in 16t+4q+r][hid 16j+pl] = accT1[t*8+j][r] ; T2[hid 16j+4q+r][out 16i+pl] = accT2[j*4+i][r]
 #pragma unroll
   for (int k = 0; k < TW * TH; ++k) { accT1[k] = (v4f){0.f, 0.f, 0.f, 0.f}; accT2[k] = (v4f){0.f, 0.f, 0.f, 0.f}; }
-  v4f sp[TH];                  // per-lane sums of dpre (hid 16j+4q+r)
-  float4 sd[TW];               // per-lane sums of dy   (out 16t+4q+r)
+  // bias-gradient sums, taken from the ROW-axis operands of the weight-gradient products (the lane already holds column 16j + pl of
+  // rows q + 4s there): one register per column tile instead of four per fragment -- 12 registers instead of 48 in a kernel whose
+  // 256 weight-gradient accumulators leave no slack (the W = 64 fp32 instance spilled 20-40 registers before)
+  float sp[TH];                // sums of dpre over rows q + 4s, column hid 16j + pl
+  float sd[TW];                // sums of dy   over rows q + 4s, column out 16i + pl
 #pragma unroll
-  for (int j = 0; j < TH; ++j) sp[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < TH; ++j) sp[j] = 0.f;
 #pragma unroll
-  for (int t = 0; t < TW; ++t) sd[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < TW; ++t) sd[t] = 0.f;
 
   const long ntiles = (a.rows + 15) / 16;
   const long stride = (long)gridDim.x * 4;
@@ -482,7 +499,7 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
       } else {
 #pragma unroll
         for (int j = 0; j < TH; ++j) {
-          const v4f pre = ffn_gemm1<W>(s1, b1s, x, j, lane, q);
+          const v4f pre = ffn_gemm1<W, (W < 64)>(s1, b1s, x, j, lane, q);   // (W = 64: the extra accumulator would spill)
           h[j] = (v4f){ffn_act<ACT>(pre[0]), ffn_act<ACT>(pre[1]), ffn_act<ACT>(pre[2]), ffn_act<ACT>(pre[3])};
         }
       }
@@ -496,7 +513,6 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
 #pragma unroll
       for (int t = 0; t < TW; ++t) {
         dyf[t] = frag_read<FW>(dt, p, q, t);
-        sd[t].x += dyf[t].x; sd[t].y += dyf[t].y; sd[t].z += dyf[t].z; sd[t].w += dyf[t].w;
       }
       Bf8 dyh[NS1], dyl[NS1];
       if constexpr (MM != 0) {
@@ -511,20 +527,22 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
         if constexpr (MM != 0) {
           acc = bf_gemm<NS1, SPLIT>(s3, j * NS1, lane, dyh, dyl, acc);
         } else {
-          v4f w[TW];
+          // two alternating accumulators: a chain of MFMAs on ONE accumulator issues every 40 cycles (dependent latency) instead of
+          // every 32, and with one wave per SIMD nothing else fills the gap
+          v4f w[TW], acc2 = {0.f, 0.f, 0.f, 0.f};
           slab_read<TW>(w, s3 + (j * TW * 64 + lane) * 4);
 #pragma unroll
           for (int t = 0; t < TW; ++t) {
             acc = MFMA(w[t][0], dyf[t].x, acc);
-            acc = MFMA(w[t][1], dyf[t].y, acc);
+            acc2 = MFMA(w[t][1], dyf[t].y, acc2);
             acc = MFMA(w[t][2], dyf[t].z, acc);
-            acc = MFMA(w[t][3], dyf[t].w, acc);
+            acc2 = MFMA(w[t][3], dyf[t].w, acc2);
           }
+          acc += acc2;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] *= ffn_dact<ACT>(h[j][r]);
         dp[j] = acc;
-        sp[j] += acc;
       }
     }
     // ---- weight gradients: contractions over the 16 rows of the tile (row index rho = q + 4s) ----
@@ -536,6 +554,8 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
       for (int i = 0; i < TW; ++i)
 #pragma unroll
         for (int s = 0; s < 4; ++s) bdy[i][s] = elem_read<FW>(dt, q + 4 * s, 16 * i + p);
+#pragma unroll
+      for (int i = 0; i < TW; ++i) sd[i] += (bdy[i][0] + bdy[i][1]) + (bdy[i][2] + bdy[i][3]);
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         lds_sync();
@@ -573,6 +593,7 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const float bd = elem_read<FW>(hd, q + 4 * s, 16 * jj + p);
+            sp[TW * half + jj] += bd;
 #pragma unroll
             for (int t = 0; t < TW; ++t) accT1[t * TH + TW * half + jj] = MFMA(axh[t][s], bd, accT1[t * TH + TW * half + jj]);
           }
@@ -593,15 +614,16 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
         if constexpr (MM != 0) {
           acc = bf_gemm<TW, SPLIT>(s4, i * TW, lane, dph, dpl, acc);
         } else {
-          v4f w[TH];
+          v4f w[TH], acc2 = {0.f, 0.f, 0.f, 0.f};   // (two alternating accumulators, as in the dhid product)
           slab_read<TH>(w, s4 + (i * TH * 64 + lane) * 4);
 #pragma unroll
           for (int j = 0; j < TH; ++j) {
             acc = MFMA(w[j][0], dp[j][0], acc);
-            acc = MFMA(w[j][1], dp[j][1], acc);
+            acc2 = MFMA(w[j][1], dp[j][1], acc2);
             acc = MFMA(w[j][2], dp[j][2], acc);
-            acc = MFMA(w[j][3], dp[j][3], acc);
+            acc2 = MFMA(w[j][3], dp[j][3], acc2);
           }
+          acc += acc2;
         }
         dxh[i] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         m1 += (acc[0] + acc[1]) + (acc[2] + acc[3]);
@@ -653,18 +675,14 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
   {
     float* sw = ssum + wave * (FH + FW);
 #pragma unroll
-    for (int j = 0; j < TH; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = row_sum16(sp[j][r]);
-        if (p == 0) sw[16 * j + 4 * q + r] = v;
-      }
+    for (int j = 0; j < TH; ++j) {
+      const float v = sum_over_q(sp[j]);       // the four lane rows hold rows q, q + 4, q + 8, q + 12 of every tile
+      if (q == 0) sw[16 * j + p] = v;
+    }
 #pragma unroll
     for (int t = 0; t < TW; ++t) {
-      const float v[4] = {row_sum16(sd[t].x), row_sum16(sd[t].y), row_sum16(sd[t].z), row_sum16(sd[t].w)};
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (p == 0) sw[FH + 16 * t + 4 * q + r] = v[r];
+      const float v = sum_over_q(sd[t]);
+      if (q == 0) sw[FH + 16 * t + p] = v;
     }
   }
   if (wave == 2) img_put(img0);

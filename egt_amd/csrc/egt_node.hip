@@ -691,18 +691,17 @@ __global__ void __launch_bounds__(512, 4) k_node_wgrads(WGradArgs wa) {
 }
 
 // ------------------------------------------------------------ final reduce -----
-// 128 outputs per workgroup (32 lanes x one 16-byte piece), the partial axis split over 8 groups of 32 lanes with 4 independent
-// accumulator pieces each: with hundreds of partials per output the loop is latency-bound, so what counts is bytes in flight, and a
-// row of a partial slab is read as 512 contiguous bytes (round 5: 16-byte loads, 24 -> 14 us on the headline stack; the scalar form
-// -- 32 outputs per workgroup -- stays for segments whose length, stride or base address is not a multiple of 16 bytes).
-// Fixed association order: deterministic.
-struct SumSeg { const float* src; float* dst; int n, np, stride, blk0, vec; };   // blk0: first workgroup of the segment in the flat grid
+struct SumSeg { const float* src; float* dst; int n, np, stride, blk0; };   // blk0: first workgroup of the segment in the flat grid
 #define SUM_MAX_SEG 77  // 11 layers x 7 segments: fits the 4 KiB kernel-argument block
 struct SumArgs { SumSeg seg[SUM_MAX_SEG]; int nseg; };
 
+// 32 outputs per workgroup, the partial axis split over 8 groups of 32 lanes with 8 independent
+// accumulators each: with hundreds of partials per output the loop is latency-bound, so what counts
+// is loads in flight (64 per output), not lanes per output.  Fixed association order: deterministic.
 __global__ void __launch_bounds__(256) k_sum_segments(SumArgs s) {
-  __shared__ float4 red[8][32];
-  // flat grid: one workgroup per 128 (32) outputs of some segment; the segment is found by a scalar binary search
+  __shared__ float red[8][32];
+  // flat grid: one workgroup per 32 outputs of some segment (a (max blocks) x (segments) grid launched
+  // four empty workgroups for every working one); the segment is found by a scalar binary search
   int lo = 0, hi = s.nseg - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -710,37 +709,6 @@ __global__ void __launch_bounds__(256) k_sum_segments(SumArgs s) {
   }
   const SumSeg sg = s.seg[lo];
   const int ol = threadIdx.x & 31, pg = threadIdx.x >> 5;
-  if (sg.vec) {
-    const int o = (((int)blockIdx.x - sg.blk0) * 32 + ol) * 4;
-    float4 v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (o < sg.n) {
-      int pi = pg;
-      for (; pi + 24 < sg.np; pi += 32) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float4 w = *reinterpret_cast<const float4*>(sg.src + (size_t)(pi + 8 * k) * sg.stride + o);
-          v[k].x += w.x; v[k].y += w.y; v[k].z += w.z; v[k].w += w.w;
-        }
-      }
-      for (; pi < sg.np; pi += 8) {
-        const float4 w = *reinterpret_cast<const float4*>(sg.src + (size_t)pi * sg.stride + o);
-        v[0].x += w.x; v[0].y += w.y; v[0].z += w.z; v[0].w += w.w;
-      }
-    }
-    red[pg][ol] = make_float4((v[0].x + v[1].x) + (v[2].x + v[3].x), (v[0].y + v[1].y) + (v[2].y + v[3].y),
-                              (v[0].z + v[1].z) + (v[2].z + v[3].z), (v[0].w + v[1].w) + (v[2].w + v[3].w));
-    __syncthreads();
-    if (pg == 0 && o < sg.n) {
-      float4 r;
-#define SUM8(f) (((red[0][ol].f + red[1][ol].f) + (red[2][ol].f + red[3][ol].f)) + ((red[4][ol].f + red[5][ol].f) + (red[6][ol].f + red[7][ol].f)))
-      r.x = SUM8(x); r.y = SUM8(y); r.z = SUM8(z); r.w = SUM8(w);
-#undef SUM8
-      *reinterpret_cast<float4*>(sg.dst + o) = r;
-    }
-    return;
-  }
   const int o = ((int)blockIdx.x - sg.blk0) * 32 + ol;
   float v[8];
 #pragma unroll
@@ -753,11 +721,10 @@ __global__ void __launch_bounds__(256) k_sum_segments(SumArgs s) {
     }
     for (; pi < sg.np; pi += 8) v[0] += sg.src[(size_t)pi * sg.stride + o];
   }
-  float* redf = reinterpret_cast<float*>(&red[0][0]);
-  redf[pg * 32 + ol] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  red[pg][ol] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
   __syncthreads();
   if (pg == 0 && o < sg.n)
-    sg.dst[o] = ((redf[ol] + redf[32 + ol]) + (redf[64 + ol] + redf[96 + ol])) + ((redf[128 + ol] + redf[160 + ol]) + (redf[192 + ol] + redf[224 + ol]));
+    sg.dst[o] = ((red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol])) + ((red[4][ol] + red[5][ol]) + (red[6][ol] + red[7][ol]));
 }
 
 // T[c][i], s[i], R[c][h|8] -> grads of norm_edge, attention_gates, dense_edge_b, dense_edge_r.
@@ -897,9 +864,8 @@ void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, hipStream
     SumArgs s{};
     int nblk = 0, k = 0;
     auto seg = [&](const float* src, float* dst, int cnt, int npart, int stride) {
-      const int vec = (cnt % 4 == 0 && stride % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) ? 1 : 0;
-      s.seg[k] = SumSeg{src, dst, cnt, npart, stride, nblk, vec};
-      nblk += vec ? (cnt + 127) / 128 : (cnt + 31) / 32;
+      s.seg[k] = SumSeg{src, dst, cnt, npart, stride, nblk};
+      nblk += (cnt + 31) / 32;
       ++k;
     };
     for (int l = l0; l < l0 + nl; ++l) {
