@@ -2,6 +2,18 @@
 // k_block_bwd_v4 (mask tensors / ragged N / bf16), k_block_bwd_v5 (LDS-DMA staged e tiles: the headline),
 // k_block_bwd_v4r (narrow edge channels, R rows per iteration) and the weight-gradient epilogue they share.
 #pragma once
+// Cache-policy hints of the streamed tiles (egt_tile.h) in k_block_bwd_v5: e_l is read once (LDS-DMA, non-temporal), de' was written by
+// the launch before and de is the next launch's de' (both cached: 134 MB of the 256 MB memory-side cache at the headline batch).
+// Measured (tools/ab.sh, same box): 100.9 -> 97.7 us; de stores non-temporal 99-100 us, de' loads non-temporal: no change.
+#ifndef EGT_NT_BWD_E
+#define EGT_NT_BWD_E true
+#endif
+#ifndef EGT_NT_BWD_DY
+#define EGT_NT_BWD_DY false
+#endif
+#ifndef EGT_NT_BWD_ST
+#define EGT_NT_BWD_ST false
+#endif
 
 // ================================================================ backward =====
 // Workgroup = (graph b, TL query rows); wave w owns key tiles w, w+4, ...; for each it walks the TL rows.  Q / dV_att /
@@ -460,7 +472,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
     const bool kvalid = RAG ? (p < kv) : true;
     // first e tile of this key tile: in flight while K / V are fetched
     if (RAG && kv < 16) tile_dma_ragged<DE>(et_lds, e_in + (((size_t)b * N + l_begin) * N + m0) * DE, lane, kv);
-    else tile_dma<DE>(et_lds, e_in + (((size_t)b * N + l_begin) * N + m0) * DE, off0);
+    else tile_dma<DE, EGT_NT_BWD_E>(et_lds, e_in + (((size_t)b * N + l_begin) * N + m0) * DE, off0);
     float Kf[16], Vf[16], dKa[16], dVa[16];
     const size_t rowm = (size_t)b * N + (RAG ? min(m, N - 1) : m);
     {
@@ -484,7 +496,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       MaskRegs mr{make_float2(1.f, 1.f), 0};
       // ---- de'(l): requested now, consumed after P1 ----
       TileRegs<DE> td;
-      tile_gload<DE>(td, dey_in + pair0 * DE, lane, kv);
+      tile_gload<DE, EGT_NT_BWD_DY>(td, dey_in + pair0 * DE, lane, kv);
       // ---- e(l) has been in flight for a whole iteration: retire it.  Younger operations of this wave:
       // row l-1's dQ-partial store and its NI de stores, then the NI de' loads just issued ----
       if (li == 0) vm_wait<0>(); else vm_wait<2 * ((G::NF4 + 63) / 64) + 1>();
@@ -524,7 +536,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       // ---- e(l+1) -> the other e buffer (its last reader, row l-1's P5, retired its LDS reads) ----
       if (l + 1 < l_end) {
         if (RAG && kv < 16) tile_dma_ragged<DE>(et_lds + (unsigned)(((li + 1) & 1) * G::TILE_FLOATS * 4), e_in + (pair0 + (size_t)N) * DE, lane, kv);
-        else tile_dma<DE>(et_lds + (unsigned)(((li + 1) & 1) * G::TILE_FLOATS * 4), e_in + (pair0 + (size_t)N) * DE, off0);
+        else tile_dma<DE, EGT_NT_BWD_E>(et_lds + (unsigned)(((li + 1) & 1) * G::TILE_FLOATS * 4), e_in + (pair0 + (size_t)N) * DE, off0);
       }
       SCHED_FENCE();
       // ---- P2: dH_ext = de'.Wr^T ----
@@ -702,7 +714,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
             o.y = dyv.y + rstd * (dxh[t].y - m1 - xh.y * m2);
             o.z = dyv.z + rstd * (dxh[t].z - m1 - xh.z * m2);
             o.w = dyv.w + rstd * (dxh[t].w - m1 - xh.w * m2);
-            if (kvalid) *reinterpret_cast<float4*>(orow + 16 * t) = o;
+            if (kvalid) { if (EGT_NT_BWD_ST) egt_st4_nt(orow + 16 * t, o); else *reinterpret_cast<float4*>(orow + 16 * t) = o; }
           }
         }
         lds_sync();   // the tile reads above retire before the next iteration overwrites dt / DMAs into et

@@ -1,6 +1,15 @@
 // Forward pair kernels of the fused attention block (included by egt_block.hip, which holds the dispatch):
 // k_block_fwd<De,KVL,ML,FULL,BF> and the four-rows-per-iteration k_block_fwd_r4<De,FULL,NW,BF> for narrow edge channels.
 #pragma once
+// Cache-policy hints of the streamed tiles (egt_tile.h).  k_block_fwd reads e_l ONCE: non-temporal, so that it does not push e_{l+1} --
+// which this launch writes and the next one reads, 134 MB of the 256 MB memory-side cache at the headline batch -- out.  Measured
+// (tools/ab.sh, same box): k_block_fwd 60.7 -> 59.0 us; the stores non-temporal instead (nothing retained): 67 us.
+#ifndef EGT_NT_FWD_E
+#define EGT_NT_FWD_E true
+#endif
+#ifndef EGT_NT_FWD_ST
+#define EGT_NT_FWD_ST false
+#endif
 
 // ================================================================= forward =====
 // Workgroup = (graph b, 16 query rows); wave w owns rows l = 16*lg + w + 4*i.
@@ -83,7 +92,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
     if (PFD > 1) it = min(it, total - 1);
     const int l = l0 + wave + 4 * (it / ntile), m0 = (it % ntile) * 16;
     const size_t pair0 = ((size_t)b * N + l) * N + m0;
-    tile_gload<DE>(tr, e_in + pair0 * DE, lane, FULL ? 16 : min(16, N - m0));
+    tile_gload<DE, EGT_NT_FWD_E>(tr, e_in + pair0 * DE, lane, FULL ? 16 : min(16, N - m0));
   };
   if (total > 0) {
 #pragma unroll
@@ -118,8 +127,8 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
     lds_sync();
     if (it_ > 0 && live) {   // stream out e' of the previous tile from the other buffer
       const int itp = it - 1, lp = l0 + wave + 4 * (itp / ntile), m0p = (itp % ntile) * 16;
-      tile_from_lds<DE>(tl0 + (itp & 1) * G::TILE_FLOATS, e_o + (((size_t)b * N + lp) * N + m0p) * DE,
-                        lane, FULL ? 16 : min(16, N - m0p));
+      tile_from_lds<DE, EGT_NT_FWD_ST>(tl0 + (itp & 1) * G::TILE_FLOATS, e_o + (((size_t)b * N + lp) * N + m0p) * DE,
+                                       lane, FULL ? 16 : min(16, N - m0p));
     }
     tile_lds_put<DE>(tl, tr, lane, rows_valid);
     if (PFD == 1) { if (it + 1 < total) prefetch(tr, it + 1); }
@@ -198,7 +207,7 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
     }
     if (it_ + 1 == total) {   // last tile of the wave: flush
       lds_sync();
-      tile_from_lds<DE>(tl, e_o + pair0 * DE, lane, rows_valid);
+      tile_from_lds<DE, EGT_NT_FWD_ST>(tl, e_o + pair0 * DE, lane, rows_valid);
     }
     if (mt == ntile - 1 && live) {
       // ---- merge the 16 key lanes (same q): max, then sums ----

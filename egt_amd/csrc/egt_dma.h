@@ -13,42 +13,45 @@ __device__ __forceinline__ unsigned dma_lane_offset(int lane) {
 // tile's first byte in HBM (wave-uniform), off0 = dma_lane_offset.  Chunk i (rows 4i .. 4i+3 at
 // De = 64) differs from chunk 0 by +1024 i bytes and, for the swizzle, by flipping slot bits 2..3
 // with i: one XOR with 1088 i (the offsets of chunk 0 are < 1024, so the add is an OR is an XOR).
-template <int DE>
-__device__ __forceinline__ void tile_dma(unsigned lds, const float* src, unsigned off0) {
-  constexpr int NI = Geo<DE>::NF4 / 64;
-  static_assert(Geo<DE>::NF4 % 64 == 0 && NI >= 1 && NI <= 4, "whole 1 KiB chunks");
-  unsigned keep, t;
-  // chunk i = rows 4i .. 4i+3: +1024 i bytes and the slot bits flipped by swz(4 i) (an XOR: chunk 0's offsets are < 1024)
-  constexpr unsigned X = DE == 64 ? 1088u : 1024u;
-  constexpr unsigned X1 = X, X2 = 2 * X, X3 = 3 * X;
-  if (NI == 4)
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
-        "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-        "v_xor_b32 %1, %6, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-        "v_xor_b32 %1, %7, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X1), "i"(X2), "i"(X3) : "memory", "scc");
-  else if (NI == 3)
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
-        "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-        "v_xor_b32 %1, %6, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X1), "i"(X2) : "memory", "scc");
-  else if (NI == 2)
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
-        "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X1) : "memory", "scc");
-  else
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep) : "s"(src), "v"(off0), "s"(lds) : "memory");
+// NT: the non-temporal form of the request (a tensor this launch reads once: egt_tile.h, cache-policy hints)
+#define EGT_TILE_DMA_BODY(MOD) \
+  constexpr int NI = Geo<DE>::NF4 / 64; \
+  static_assert(Geo<DE>::NF4 % 64 == 0 && NI >= 1 && NI <= 4, "whole 1 KiB chunks"); \
+  unsigned keep, t; \
+  constexpr unsigned X = DE == 64 ? 1088u : 1024u; \
+  constexpr unsigned X1 = X, X2 = 2 * X, X3 = 3 * X; \
+  if (NI == 4) \
+    asm volatile( \
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2" MOD "\n\t" \
+        "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" MOD "\n\t" \
+        "v_xor_b32 %1, %6, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" MOD "\n\t" \
+        "v_xor_b32 %1, %7, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" MOD "\n\t" \
+        "s_mov_b32 m0, %0" \
+        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X1), "i"(X2), "i"(X3) : "memory", "scc"); \
+  else if (NI == 3) \
+    asm volatile( \
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2" MOD "\n\t" \
+        "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" MOD "\n\t" \
+        "v_xor_b32 %1, %6, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" MOD "\n\t" \
+        "s_mov_b32 m0, %0" \
+        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X1), "i"(X2) : "memory", "scc"); \
+  else if (NI == 2) \
+    asm volatile( \
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2" MOD "\n\t" \
+        "v_xor_b32 %1, %5, %3\n\ts_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" MOD "\n\t" \
+        "s_mov_b32 m0, %0" \
+        : "=&s"(keep), "=&v"(t) : "s"(src), "v"(off0), "s"(lds), "i"(X1) : "memory", "scc"); \
+  else \
+    asm volatile( \
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1" MOD "\n\t" \
+        "s_mov_b32 m0, %0" \
+        : "=&s"(keep) : "s"(src), "v"(off0), "s"(lds) : "memory"); \
   (void)t;
+template <int DE, bool NT = false>
+__device__ __forceinline__ void tile_dma(unsigned lds, const float* src, unsigned off0) {
+  if (NT) { EGT_TILE_DMA_BODY(" nt") } else { EGT_TILE_DMA_BODY("") }
 }
+#undef EGT_TILE_DMA_BODY
 // The same tile when fewer than 16 of its pair rows exist (the last key tile of a ragged N): rows past `rows_valid` would
 // lie in the NEXT query row of the tensor (past its end for the last one), so their pieces are fetched from the last valid row
 // instead -- finite stand-ins that the kernel's key-validity selects keep out of every result.  Same NI instructions as

@@ -21,6 +21,12 @@
 
 #include "egt_tile.h"
 
+// Cache-policy hint (egt_tile.h): the FFN kernels read their input tiles (x; x and dy in the backward) once -- non-temporal loads, so
+// that what they WRITE (the next launch's input) stays in the memory-side cache.
+#ifndef EGT_NT_FFN
+#define EGT_NT_FFN true
+#endif
+
 // geometry of width W (multiple of 16, <= 64): TW channel tiles, hidden 2W = TH tiles
 #define FFN_GEO(W)                                                                          \
   constexpr int FW = (W), FH = 2 * (W), TW = (W) / 16, TH = 2 * TW, SLABF = FW * FH,        \
@@ -190,7 +196,7 @@ __global__ void __launch_bounds__(512, 2) k_ffn_fwd(FfnArgs a) {
   const long stride = (long)gridDim.x * 8;
   long tile = (long)blockIdx.x * 8 + wave;
   TileRegs<FW> tr;
-  if (tile < ntiles) tile_gload<FW>(tr, a.x + tile * TILEF, lane, (int)min(16L, a.rows - tile * 16));
+  if (tile < ntiles) tile_gload<FW, EGT_NT_FFN>(tr, a.x + tile * TILEF, lane, (int)min(16L, a.rows - tile * 16));
   long prev = -1;
   for (int it = 0; tile < ntiles; tile += stride, ++it) {
     const int rows_valid = (int)min(16L, a.rows - tile * 16);
@@ -200,7 +206,7 @@ __global__ void __launch_bounds__(512, 2) k_ffn_fwd(FfnArgs a) {
       tile_from_lds<FW>(tl0 + ((it - 1) & 1) * TILEF, a.y + prev * TILEF, lane, (int)min(16L, a.rows - prev * 16));
     tile_lds_put<FW>(tl, tr, lane, rows_valid);
     const long nxt = tile + stride;
-    if (nxt < ntiles) tile_gload<FW>(tr, a.x + nxt * TILEF, lane, (int)min(16L, a.rows - nxt * 16));
+    if (nxt < ntiles) tile_gload<FW, EGT_NT_FFN>(tr, a.x + nxt * TILEF, lane, (int)min(16L, a.rows - nxt * 16));
     lds_sync();
     float4 x[TW];
 #pragma unroll
@@ -325,7 +331,7 @@ __global__ void __launch_bounds__(512, 2) k_ffn_fwd_bf(FfnArgs a) {
   const long stride = (long)gridDim.x * 8;
   long tile = (long)blockIdx.x * 8 + wave;
   TileRegs<FW> tr;
-  if (tile < ntiles) tile_gload<FW>(tr, a.x + tile * TILEF, lane, (int)min(16L, a.rows - tile * 16));
+  if (tile < ntiles) tile_gload<FW, EGT_NT_FFN>(tr, a.x + tile * TILEF, lane, (int)min(16L, a.rows - tile * 16));
   long prev = -1;
   for (int it = 0; tile < ntiles; tile += stride, ++it) {
     const int rows_valid = (int)min(16L, a.rows - tile * 16);
@@ -335,7 +341,7 @@ __global__ void __launch_bounds__(512, 2) k_ffn_fwd_bf(FfnArgs a) {
       tile_from_lds<FW>(tl0 + ((it - 1) & 1) * TILEF, a.y + prev * TILEF, lane, (int)min(16L, a.rows - prev * 16));
     tile_lds_put<FW>(tl, tr, lane, rows_valid);
     const long nxt = tile + stride;
-    if (nxt < ntiles) tile_gload<FW>(tr, a.x + nxt * TILEF, lane, (int)min(16L, a.rows - nxt * 16));
+    if (nxt < ntiles) tile_gload<FW, EGT_NT_FFN>(tr, a.x + nxt * TILEF, lane, (int)min(16L, a.rows - nxt * 16));
     lds_sync();
     float4 x[TW];
 #pragma unroll
@@ -451,8 +457,8 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
   TileRegs<FW> te, td;
   if (tile < ntiles) {
     const int rv = (int)min(16L, a.rows - tile * 16);
-    tile_gload<FW>(te, a.x + tile * TILEF, lane, rv);
-    tile_gload<FW>(td, a.dy + tile * TILEF, lane, rv);
+    tile_gload<FW, EGT_NT_FFN>(te, a.x + tile * TILEF, lane, rv);
+    tile_gload<FW, EGT_NT_FFN>(td, a.dy + tile * TILEF, lane, rv);
   }
   long prev = -1;
   for (; tile < ntiles; tile += stride) {
@@ -465,8 +471,8 @@ __global__ void __launch_bounds__(256, 1) k_ffn_bwd(FfnArgs a) {
     const long nxt = tile + stride;
     if (nxt < ntiles) {
       const int rv = (int)min(16L, a.rows - nxt * 16);
-      tile_gload<FW>(te, a.x + nxt * TILEF, lane, rv);
-      tile_gload<FW>(td, a.dy + nxt * TILEF, lane, rv);
+      tile_gload<FW, EGT_NT_FFN>(te, a.x + nxt * TILEF, lane, rv);
+      tile_gload<FW, EGT_NT_FFN>(td, a.dy + nxt * TILEF, lane, rv);
     }
     lds_sync();
     // The phases below sit behind opaque always-true guards (a.guard == 0): the uniform branches
