@@ -7,6 +7,10 @@
 // partials reduced by a deterministic second kernel (no float atomics).
 #include "egt_common.h"
 #include "egt_tile.h"
+#ifndef EDGE_NT_IN
+#define EDGE_NT_IN true   // cache-policy hint (egt_tile.h): k_edge_update_fwd reads its e rows once (115 -> 106 us at config 5; the same hint
+                          // on the MFMA-fragment loads of k_edge_proj_* measured as a loss, 180 -> 196 us: not applied there)
+#endif
 
 #define EDGE_H 8
 
@@ -291,7 +295,7 @@ __global__ void __launch_bounds__(256) k_edge_update_fwd(EdgeArgs a) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t row = i / F4;
     const int c = (int)(i % F4) * 4;
-    const float4 ev = *reinterpret_cast<const float4*>(a.e + row * DE + c);
+    const float4 ev = EDGE_NT_IN ? egt_ld4_nt(a.e + row * DE + c) : *reinterpret_cast<const float4*>(a.e + row * DE + c);
     const float4* hp = reinterpret_cast<const float4*>(a.h_hat + row * EDGE_H);
     const float4 h0 = hp[0], h1 = hp[1];
     const float hh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
