@@ -31,6 +31,7 @@ struct BlockArgs {
   float *up_dqkv_sv, *up_spart;
   float *sbo;    // per-workgroup partials of this layer's dense_mha bias gradient
   int spart_n, sbo_n;   // how many workgroup partials the reduction finds in spart / sbo
+  int wpart_n;          // ... and in wpart: the row chunks egt_node_launch_wgrads launched (stored there, read by the reduction)
   int guard;    // backward phase guards (always 0 in production, see k_block_bwd_v4)
   unsigned* dbg; unsigned dbg_t0;   // measurement builds of egt_narrow.hip (-DNRW_TIMING): per-wave section cycle sums
   int prep;     // node kernels: add the edge-weight preparation workgroup

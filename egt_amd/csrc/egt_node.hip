@@ -842,6 +842,7 @@ void egt_node_launch_wgrads(BlockArgs* as, int n, hipStream_t st) {
   const int Dh = a0.Dh;
   const size_t lds = ((size_t)3 * 32 * (Dh + 16) + (size_t)32 * (3 * Dh + 16)) * 4;
   const dim3 grid(egt_node_wgrad_chunks(wa.rows, n), n);
+  for (int l = 0; l < n; ++l) as[l].wpart_n = (int)grid.x;   // what the reduction sums (never re-derived from rows / layers there)
   if (Dh == 64) EGT_LAUNCH("k_node_wgrads", k_node_wgrads<true>, grid, dim3(512), lds, st, wa);
   else EGT_LAUNCH("k_node_wgrads", k_node_wgrads<false>, grid, dim3(512), lds, st, wa);
 }
@@ -871,7 +872,7 @@ void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, hipStream
     for (int l = l0; l < l0 + nl; ++l) {
       BlockArgs& a = as[l];
       const int Dh = a.Dh, D3 = 3 * Dh, SP = D3 + 2 * Dh;
-      const int nwc = egt_node_wgrad_chunks(a.B * a.N, n), WS = Dh * D3 + Dh * Dh;   // (n: the layer count k_node_wgrads was launched with)
+      const int nwc = a.wpart_n, WS = Dh * D3 + Dh * Dh;   // the chunk count egt_node_launch_wgrads stored
       seg(a.wpart, a.g_Wqkv, Dh * D3, nwc, WS);
       seg(a.wpart + Dh * D3, a.g_Wo, Dh * Dh, nwc, WS);
       seg(a.spart, a.g_bqkv, D3, a.spart_n, SP);          // written by k_node_bwd or by the pair kernel's prologue
