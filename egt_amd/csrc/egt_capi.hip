@@ -34,6 +34,9 @@ struct ProfEntry {
   int64_t count = 0;
   double ms = 0.0;
   int64_t seen = 0;   // launches met while enabled (egt_prof_stride samples them)
+  unsigned long long cap_id = 0;   // the stream capture the counter below belongs to
+  int64_t cap_seen = 0;            // launches of this kernel met inside that capture: the stride samples a captured graph from its
+                                   // own first launch (launch 0, stride, 2 stride, ...), whatever ran eagerly before the capture
 };
 std::mutex g_mu;
 int g_enabled = 0;
@@ -43,9 +46,15 @@ std::unordered_map<std::string, ProfEntry> g_prof;
 std::vector<hipEvent_t> g_pool;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_retired;   // graph-resident pairs of a reset profile: their graphs may still replay
 
-bool stream_capturing(hipStream_t s) {
+bool stream_capturing(hipStream_t s, unsigned long long* id = nullptr) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
+  unsigned long long cid = 0;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t ndeps = 0;
+  if (hipStreamGetCaptureInfo_v2(s, &st, &cid, &graph, &deps, &ndeps) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (id) *id = cid;
+  return st == hipStreamCaptureStatusActive;
 }
 // An event-record NODE at the capturing stream's current position.  (hipEventRecordWithFlags(.., hipEventRecordExternal) is the
 // one-call form of this, but the HIP runtime torch 2.10 ships answers it with hipErrorInvalidValue under capture -- probed on the
@@ -100,8 +109,13 @@ void egt_prof_begin(const char* name, hipStream_t s, void** tok) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_filter.empty() && g_filter != name) return;
   auto& e = g_prof[name];
-  if (g_stride > 1 && (e.seen++ % g_stride) != 0) return;
-  if (stream_capturing(s)) {   // the launch is being captured into a hipGraph: the events become event-record nodes of that graph
+  unsigned long long cid = 0;
+  const bool cap = stream_capturing(s, &cid);
+  if (cap) {
+    if (cid != e.cap_id) { e.cap_id = cid; e.cap_seen = 0; }
+    if (g_stride > 1 && (e.cap_seen++ % g_stride) != 0) return;
+  } else if (g_stride > 1 && (e.seen++ % g_stride) != 0) return;
+  if (cap) {   // the launch is being captured into a hipGraph: the events become event-record nodes of that graph
     hipEvent_t a = get_event(), b = get_event();   // (from the pool egt_prof_enable filled before the capture began)
     record_node_in_capture(s, a);
     e.graph_pairs.emplace_back(a, b);
