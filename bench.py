@@ -397,12 +397,18 @@ def run_core(args, w, dev, lib, rank, world, use_dist):
     fence()
     if not args.no_prof:
         lib.egt_prof_filter(dominant.encode()); lib.egt_prof_enable(2)
+    sev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step events: the median beside the wall-clock mean
+    cur = torch.cuda.current_stream()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        sev[i].record(cur)
         step()
+    sev[args.steps].record(cur)
     fence()
     elapsed = time.perf_counter() - t0
     lib.egt_prof_enable(0)
+    step_ms = sorted(sev[i].elapsed_time(sev[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if step_ms else None
     graphs_step = B
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -451,7 +457,7 @@ def run_core(args, w, dev, lib, rank, world, use_dist):
     line = {
         "metric": "graphs/sec EGT fwd+bwd, " + METRIC_OF[args.workload],
         "value": graphs_step * args.steps / elapsed, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": elapsed / args.steps * 1e3, "median_ms_per_step": median_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: core op ([QKV,E,G],mask) -> (V_att,H_hat) fwd+bwd (egt_layers.py:57-143 under autodiff), "
                                "training mode, in-kernel random mask", "scope": "core", "graphs_per_gpu": B, "global_batch": graphs_step,
@@ -506,12 +512,18 @@ def run_block(args, w, dev, lib, rank, world, use_dist):
     fence()
     if not args.no_prof:
         lib.egt_prof_filter(dominant.encode()); lib.egt_prof_enable(2)
+    sev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step events: the median beside the wall-clock mean
+    cur = torch.cuda.current_stream()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        sev[i].record(cur)
         step()
+    sev[args.steps].record(cur)
     fence()
     elapsed = time.perf_counter() - t0
     lib.egt_prof_enable(0)
+    step_ms = sorted(sev[i].elapsed_time(sev[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if step_ms else None
     graphs_step = B
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -556,7 +568,7 @@ def run_block(args, w, dev, lib, rank, world, use_dist):
     line = {
         "metric": "graphs/sec EGT fwd+bwd, " + METRIC_OF[args.workload],
         "value": graphs_step * args.steps / elapsed, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ms_per_step": step_s * 1e3, "median_ms_per_step": median_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: ONE attention block (h,e,mask)->(h',e') fwd+bwd + param grads "
                                "(graph_xformer_model_base.py:192-223 around egt_layers.py:57-143), training mode, in-kernel random mask",
                    "scope": "block", "graphs_per_gpu": B, "global_batch": graphs_step, "N": N, "Dh": Dh, "De": De, "H": H, "d": Dh // H,

@@ -399,16 +399,53 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   // LDS byte address of the wave's e buffers (the kernel's only LDS object is the dynamic array: offset 0)
   const unsigned et_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)et0);
   const unsigned off0 = dma_lane_offset<DE>(lane);
-  for (int i = threadIdx.x; i < nl * 40; i += 256) {
-    const int r = i / 40, f = i % 40;
-    const size_t rowl = (size_t)b * N + l_begin + r;
-    if (a.pro && f >= 16 && f < 32) continue;   // dV_att comes from the prologue below
-    const float* src = f < 16 ? a.qkvp + rowl * QKVP + f * 4
-                     : f < 32 ? a.dvp + rowl * 64 + (f - 16) * 4
-                              : a.stats + rowl * 32 + (f - 32) * 4;
-    float4 v = *reinterpret_cast<const float4*>(src);
-    if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
-    *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
+  // Staged query-side rows AND (fp32 products) the weight slabs: every global load of both is issued before the first LDS store, so
+  // the kernel's start-up pays ONE memory round trip for them instead of one before and one behind the node-side prologue (the slabs
+  // live behind qd, outside the prologue's scratch: they may be filled before it runs).  V5_SLABS_LATE restores the old order (A/B).
+  {
+    float4 sv[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = threadIdx.x + 256 * u, r = i / 40, f = i % 40;
+      const bool ok = i < nl * 40 && !(a.pro && f >= 16 && f < 32);   // dV_att comes from the prologue below
+      const size_t rowl = (size_t)b * N + l_begin + (ok ? r : 0);
+      const float* src = f < 16 ? a.qkvp + rowl * QKVP + f * 4
+                       : f < 32 ? a.dvp + rowl * 64 + (f - 16) * 4
+                                : a.stats + rowl * 32 + (f - 32) * 4;
+      sv[u] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#ifndef V5_SLABS_LATE
+    float sA[G::TILES], sB[G::TILES], sD[G::TILES];
+    if constexpr (MM == 0) {
+#pragma unroll
+      for (int t = 0; t < G::TILES; ++t) {
+        const int i = threadIdx.x + 256 * t, ln = (i >> 2) & 63, u = i & 3, pp = ln & 15, qq = ln >> 4;
+        const int c = 16 * t + 4 * qq + u;
+        const int hd = 2 * (pp >> 2) + (pp & 1);
+        sA[t] = a.pw[c * 16 + pp];
+        sB[t] = ((pp & 2) == 0 && c < DE) ? a.Wr[hd * DE + c] : 0.f;
+        sD[t] = a.pw[(16 * t + pp) * 16 + 4 * qq + u];
+      }
+    }
+#endif
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = threadIdx.x + 256 * u, r = i / 40, f = i % 40;
+      if (i < nl * 40 && !(a.pro && f >= 16 && f < 32)) {
+        float4 v = sv[u];
+        if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
+        *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
+      }
+    }
+#ifndef V5_SLABS_LATE
+    if constexpr (MM == 0) {
+#pragma unroll
+      for (int t = 0; t < G::TILES; ++t) {
+        const int i = threadIdx.x + 256 * t;
+        wsA[i] = sA[t]; wsB[i] = sB[t]; wsD[i] = sD[t];
+      }
+    }
+#endif
   }
   PSTAMP(0);
   if (a.pro) {
@@ -445,7 +482,9 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       parts(a.pw[(16 * t + pp) * 16 + 4 * qq + u], hi, lo);
       D16[(t * 64 + ln) * 8 + u] = hi; D16[(t * 64 + ln) * 8 + 4 + u] = lo;
     }
-  } else
+  }
+#ifdef V5_SLABS_LATE
+  else
   for (int i = threadIdx.x; i < G::TILES * 256; i += 256) {
     const int t = i >> 8, ln = (i >> 2) & 63, u = i & 3, pp = ln & 15, qq = ln >> 4;
     const int c = 16 * t + 4 * qq + u;
@@ -454,6 +493,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
     wsB[i] = ((pp & 2) == 0 && c < DE) ? a.Wr[hd * DE + c] : 0.f;
     wsD[i] = a.pw[(16 * t + pp) * 16 + 4 * qq + u];
   }
+#endif
   float c2r[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) c2r[r] = a.pw[G::DEP * 16 + 4 * q + r];

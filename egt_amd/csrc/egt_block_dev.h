@@ -10,6 +10,17 @@ template <int DE>
 __device__ __forceinline__ v4f project(const float4 (&x)[Geo<DE>::TILES],
                                        const float (&wA)[4 * Geo<DE>::TILES], v4f acc) {
   using G = Geo<DE>;
+#ifdef EGT_PROJECT_TWOACC
+  v4f acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < G::TILES; ++t) {
+    acc = MFMA(wA[4 * t + 0], x[t].x, acc);
+    acc2 = MFMA(wA[4 * t + 1], x[t].y, acc2);
+    acc = MFMA(wA[4 * t + 2], x[t].z, acc);
+    acc2 = MFMA(wA[4 * t + 3], x[t].w, acc2);
+  }
+  return acc + acc2;
+#else
 #pragma unroll
   for (int t = 0; t < G::TILES; ++t) {
     acc = MFMA(wA[4 * t + 0], x[t].x, acc);
@@ -18,6 +29,7 @@ __device__ __forceinline__ v4f project(const float4 (&x)[Geo<DE>::TILES],
     acc = MFMA(wA[4 * t + 3], x[t].w, acc);
   }
   return acc;
+#endif
 }
 
 // Per-pair mask inputs, fetched with the tile prefetch (unconditional, clamped).

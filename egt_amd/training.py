@@ -777,7 +777,7 @@ class PatternSVDScheme(ZincSVDScheme):
         logp = torch.log_softmax(logits.detach(), -1).gather(-1, tgt.clamp(min=0).long()[..., None])[..., 0]
         xs = (-(logp) * w[tgt.clamp(min=0).long()] * m).sum()
         # `loss` is a mean over the batch's padded (graph, node) slots (Keras SUM_OVER_BATCH_SIZE): its epoch figure is the slot-weighted mean
-        slots = torch.tensor(float(m.numel()), device=m.device, dtype=m.dtype)
+        slots = torch.full((), float(m.numel()), device=m.device, dtype=m.dtype)   # (a fill kernel: capturable, unlike a host -> device copy)
         return loss, dict(xent=(xs, m.sum()), acc=(hit, m.sum()), loss=(loss.detach() * slots, slots))
 
 
