@@ -76,17 +76,7 @@ __global__ void __launch_bounds__(64 * V7_WAVES) k_block_bwd_v7(BlockArgs a) {
   const unsigned et_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)et);
   const unsigned dt_lds = et_lds + (unsigned)(G::TILE_FLOATS * 4);
   const unsigned off0 = dma_lane_offset<DE>(lane);
-  for (int i = threadIdx.x; i < nl * 40; i += 64 * V7_WAVES) {
-    const int r = i / 40, f = i % 40;
-    const size_t rowl = (size_t)b * N + l_begin + r;
-    if (a.pro && f >= 16 && f < 32) continue;   // dV_att comes from the prologue below
-    const float* src = f < 16 ? a.qkvp + rowl * QKVP + f * 4
-                     : f < 32 ? a.dvp + rowl * 64 + (f - 16) * 4
-                              : a.stats + rowl * 32 + (f - 32) * 4;
-    float4 v = *reinterpret_cast<const float4*>(src);
-    if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
-    *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
-  }
+  bwd_stage_rows<64 * V7_WAVES, 2>(a, qd, b, l_begin, nl);
   if (a.pro) {
     __syncthreads();
     // two 16-row groups of four waves side by side, each on its own scratch; waves 8..11 only keep the barriers (pnv = 0: every load

@@ -10,17 +10,6 @@ template <int DE>
 __device__ __forceinline__ v4f project(const float4 (&x)[Geo<DE>::TILES],
                                        const float (&wA)[4 * Geo<DE>::TILES], v4f acc) {
   using G = Geo<DE>;
-#ifdef EGT_PROJECT_TWOACC
-  v4f acc2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int t = 0; t < G::TILES; ++t) {
-    acc = MFMA(wA[4 * t + 0], x[t].x, acc);
-    acc2 = MFMA(wA[4 * t + 1], x[t].y, acc2);
-    acc = MFMA(wA[4 * t + 2], x[t].z, acc);
-    acc2 = MFMA(wA[4 * t + 3], x[t].w, acc2);
-  }
-  return acc + acc2;
-#else
 #pragma unroll
   for (int t = 0; t < G::TILES; ++t) {
     acc = MFMA(wA[4 * t + 0], x[t].x, acc);
@@ -29,7 +18,7 @@ __device__ __forceinline__ v4f project(const float4 (&x)[Geo<DE>::TILES],
     acc = MFMA(wA[4 * t + 3], x[t].w, acc);
   }
   return acc;
-#endif
+
 }
 
 // Per-pair mask inputs, fetched with the tile prefetch (unconditional, clamped).
@@ -131,6 +120,25 @@ __device__ __forceinline__ float reduce16_keep_own(const float (&v)[16], int p) 
 #define KV_LD 132  // LDS row stride (floats) of the staged [K|V] rows
 #define QS_LD 68   // LDS row stride of the staged Q rows (reused for the V_att rows of the epilogue)
 
+// Stage K | V of a graph's N keys into LDS rows of stride KV_LD, eight 16-byte loads per thread in flight per round trip (the plain
+// one-element loop compiles to load -> wait -> store per iteration: N * 32 / NT dependent round trips at kernel entry).
+template <int NT>
+__device__ __forceinline__ void fwd_stage_kv(float* kvs, const float* kvsrc, int N) {
+  for (int base = 0; base < N * 32; base += 8 * NT) {
+    float4 kvb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + threadIdx.x + NT * u, row = min(i >> 5, N - 1), f = i & 31;
+      kvb[u] = *reinterpret_cast<const float4*>(kvsrc + (size_t)row * QKVP + 64 + f * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + threadIdx.x + NT * u, row = i >> 5, f = i & 31;
+      if (i < N * 32) *reinterpret_cast<float4*>(kvs + row * KV_LD + f * 4) = kvb[u];
+    }
+  }
+}
+
 // ---- node-side epilogue: the workgroup holds V_att of its 16 rows in qs ----
 //   epi >= 1: h' = V_att.Wo + bo + h                      (dense_mha + res_mha, :136,140)
 //   epi == 2: qkv of the NEXT block = LN(h').Wqkv' + bqkv' (norm_mha + dense_qkv, :109,113), packed
@@ -226,6 +234,34 @@ __device__ __forceinline__ void fwd_node_epilogue_idle(const BlockArgs& a) {
 #define QD_LD 160  // per row: Q[64] | dV_att[64] | stats[32]
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// Stage the query-side rows of a backward workgroup into qd ([row][QD_LD]: Q | dV_att | softmax statistics with the row sum
+// inverted): every thread issues ALL its 16-byte loads before the first LDS store -- ONE memory round trip.  (Written as a plain
+// `for (i = tid; i < nl * 40; i += NT) qd[..] = src[..]` hipcc emits load -> s_waitcnt vmcnt(0) -> ds_write per iteration: two to
+// three dependent round trips at kernel entry, found in round 5 in every backward kernel.)  NT threads, at most NT * NU / 40 rows.
+template <int NT, int NU>
+__device__ __forceinline__ void bwd_stage_rows(const BlockArgs& a, float* qd, int b, int l_begin, int nl) {
+  float4 sv[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int i = threadIdx.x + NT * u, r = i / 40, f = i % 40;
+    const bool ok = i < nl * 40 && !(a.pro && f >= 16 && f < 32);   // (with the fused prologue dV_att is computed there)
+    const size_t rowl = (size_t)b * a.N + l_begin + (ok ? r : 0);
+    const float* src = f < 16 ? a.qkvp + rowl * QKVP + f * 4
+                     : f < 32 ? a.dvp + rowl * 64 + (f - 16) * 4
+                              : a.stats + rowl * 32 + (f - 32) * 4;
+    sv[u] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int i = threadIdx.x + NT * u, r = i / 40, f = i % 40;
+    if (i < nl * 40 && !(a.pro && f >= 16 && f < 32)) {
+      float4 v = sv[u];
+      if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
+      *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
+    }
+  }
+}
+
 // ---- node-side prologue of the backward pair kernel (16 rows, 256 threads; Dh = 8 DK <= 64 as a zero-padded 64-wide row,
 //      see fwd_node_epilogue_t: D64 = the compile-time 64 of the headline geometry) -------------
 // What k_node_bwd does between two pair kernels is local to a node row, so the workgroup that
@@ -292,22 +328,42 @@ __device__ __forceinline__ void bwd_prologue_load_main(const BlockArgs& a, int b
     }
     // partial counts of the layer above (same geometry, same kernels): dQ partials per row = a.NQP (key tiles for the
     // MFMA-tile kernels, 1 for k_narrow_bwd, which reduces its key tiles itself), dK/dV partials per key = a.NLR (row groups)
+    // The three elements of a thread are gathered together, EGT_PRO_UNROLL partials of each per round: 3 * EGT_PRO_UNROLL loads
+    // in flight and ONE wait per round (a loop per element compiles to a `s_waitcnt vmcnt(0)` per element: three serialized
+    // round trips at the head of every backward kernel).  A partial index past an element's count re-reads its last partial
+    // (a cache hit) and adds nothing; each element's partials are still summed in index order.
+    {
+      const float* base[3]; size_t pstride[3]; int NPu[3];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int i = t + u * 256, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
-      const int rr = max(min(r, nv - 1), 0);
-      const int NP = sx == 0 ? a.NQP : a.NLR;
-      const float* base = sx == 0 ? a.up_dqp + ((size_t)b * NP * N + l_begin + rr) * 64 + pos4
-                                  : a.up_dkvp + (((size_t)b * NP * N + l_begin + rr) * 2 + (sx - 1)) * 64 + (pos4 & 63);
-      const size_t pstride = sx == 0 ? (size_t)N * 64 : (size_t)N * 128;
-      float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll EGT_PRO_UNROLL
-      for (int pi = 0; pi < NP; ++pi) {
-        const float4 w = *reinterpret_cast<const float4*>(base + pi * pstride);
-        acc4.x += w.x; acc4.y += w.y; acc4.z += w.z; acc4.w += w.w;
+      for (int u = 0; u < 3; ++u) {
+        const int i = t + u * 256, r = i / 48, pos4 = (i % 48) * 4, sx = pos4 >> 6;
+        const int rr = max(min(r, nv - 1), 0);
+        NPu[u] = sx == 0 ? a.NQP : a.NLR;
+        base[u] = sx == 0 ? a.up_dqp + ((size_t)b * NPu[u] * N + l_begin + rr) * 64 + pos4
+                          : a.up_dkvp + (((size_t)b * NPu[u] * N + l_begin + rr) * 2 + (sx - 1)) * 64 + (pos4 & 63);
+        pstride[u] = sx == 0 ? (size_t)N * 64 : (size_t)N * 128;
+        R.gq[u] = z4;
       }
-      if (r >= nv) acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      R.gq[u] = acc4;
+      const int NPm = max(a.NQP, a.NLR);
+      for (int p0 = 0; p0 < NPm; p0 += EGT_PRO_UNROLL) {
+        float4 w[3][EGT_PRO_UNROLL];
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+          for (int j = 0; j < EGT_PRO_UNROLL; ++j)
+            w[u][j] = *reinterpret_cast<const float4*>(base[u] + (size_t)max(min(p0 + j, NPu[u] - 1), 0) * pstride[u]);
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+          for (int j = 0; j < EGT_PRO_UNROLL; ++j) {
+            const bool in = p0 + j < NPu[u];
+            R.gq[u].x += in ? w[u][j].x : 0.f; R.gq[u].y += in ? w[u][j].y : 0.f;
+            R.gq[u].z += in ? w[u][j].z : 0.f; R.gq[u].w += in ? w[u][j].w : 0.f;
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if ((t + u * 256) / 48 >= nv) R.gq[u] = z4;
     }
     // B operand of d h_ln = dQKV.Wqkv^T: Wqkv[kk = 16 wave + p][48 q .. 48 q + 47] (contraction order c = 48 q + s, c a column of
     // the padded [3][64] row: section c >> 6, channel c & 63)

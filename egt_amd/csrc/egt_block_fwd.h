@@ -43,22 +43,25 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
   const bool gated = (a.flags & EGT_BF_GATE) != 0;
   const bool clip = (a.flags & EGT_BF_CLIP) != 0;
 
+  // Start-up loads in as few memory round trips as possible (round 5: hipcc compiled the staging loops as load -> wait -> LDS store
+  // per iteration, eight dependent round trips per thread at N = 64, and the 44 weight loads of a lane as one more behind them):
+  // the K / V rows go in batches of eight 16-byte loads per thread, the Q rows and the key-mask adds ride in the first batch, and
+  // the lane-constant MFMA operands below are requested BEFORE the first batch is waited for.
+  float4 kvb[8], qb = make_float4(0.f, 0.f, 0.f, 0.f);
+  float kmb = 0.f;
+  const float* kvsrc = a.qkvp + (size_t)b * N * QKVP;
   if (KVL) {
-    const float* src = a.qkvp + (size_t)b * N * QKVP;
-    for (int i = threadIdx.x; i < N * 32; i += 256) {
-      const int row = i >> 5, f = i & 31;
-      *reinterpret_cast<float4*>(kvs + row * KV_LD + f * 4) =
-          *reinterpret_cast<const float4*>(src + (size_t)row * QKVP + 64 + f * 4);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = threadIdx.x + 256 * u, row = min(i >> 5, N - 1), f = i & 31;
+      kvb[u] = *reinterpret_cast<const float4*>(kvsrc + (size_t)row * QKVP + 64 + f * 4);
     }
-    for (int i = threadIdx.x; i < 16 * 16; i += 256) {
-      const int row = i >> 4, f = i & 15, l = min(l0 + row, N - 1);
-      *reinterpret_cast<float4*>(qs + row * QS_LD + f * 4) =
-          *reinterpret_cast<const float4*>(src + (size_t)l * QKVP + f * 4);
+    {
+      const int row = threadIdx.x >> 4, f = threadIdx.x & 15, l = min(l0 + row, N - 1);
+      qb = *reinterpret_cast<const float4*>(kvsrc + (size_t)l * QKVP + f * 4);
     }
-    for (int i = threadIdx.x; i < N; i += 256)
-      kms[i] = (a.km && a.km[(size_t)b * N + i] == 0) ? -EGT_NEG : 0.0f;
+    if ((int)threadIdx.x < N) kmb = (a.km && a.km[(size_t)b * N + threadIdx.x] == 0) ? -EGT_NEG : 0.0f;
   }
-
   // lane-constant MFMA operands
   float wA[4 * G::TILES], wrA[G::TILES][2], c2r[4];
   float4 brv[G::TILES];
@@ -75,7 +78,21 @@ __global__ void __launch_bounds__(256, ((DE <= 16 && !KVL) ? 4 : 2)) k_block_fwd
     brv[t] = (cb < DE) ? make_float4(a.br[cb], a.br[cb + 1], a.br[cb + 2], a.br[cb + 3])
                        : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  if (KVL) __syncthreads();
+  if (KVL) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = threadIdx.x + 256 * u, row = i >> 5, f = i & 31;
+      if (i < N * 32) *reinterpret_cast<float4*>(kvs + row * KV_LD + f * 4) = kvb[u];
+    }
+    *reinterpret_cast<float4*>(qs + (threadIdx.x >> 4) * QS_LD + (threadIdx.x & 15) * 4) = qb;
+    if ((int)threadIdx.x < N) kms[threadIdx.x] = kmb;
+    for (int i = 2048 + threadIdx.x; i < N * 32; i += 256) {   // N > 64: the keys past the first batch
+      const int row = i >> 5, f = i & 31;
+      *reinterpret_cast<float4*>(kvs + row * KV_LD + f * 4) = *reinterpret_cast<const float4*>(kvsrc + (size_t)row * QKVP + 64 + f * 4);
+    }
+    for (int i = 256 + threadIdx.x; i < N; i += 256) kms[i] = (a.km && a.km[(size_t)b * N + i] == 0) ? -EGT_NEG : 0.0f;
+    __syncthreads();
+  }
 
   const int ntile = (N + 15) / 16;
   int nrows = 0;
@@ -287,11 +304,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_fwd_r4(BlockArgs a) {
   const bool clip = (a.flags & EGT_BF_CLIP) != 0;
   {
     const float* src = a.qkvp + (size_t)b * N * QKVP;
-    for (int i = threadIdx.x; i < N * 32; i += NT) {
-      const int row = i >> 5, f = i & 31;
-      *reinterpret_cast<float4*>(kvs + row * KV_LD + f * 4) =
-          *reinterpret_cast<const float4*>(src + (size_t)row * QKVP + 64 + f * 4);
-    }
+    fwd_stage_kv<NT>(kvs, src, N);
     for (int i = threadIdx.x; i < RW * 16; i += NT) {
       const int row = i >> 4, f = i & 15, l = min(lg * RW + row, N - 1);
       *reinterpret_cast<float4*>(qs + row * QS_LD + f * 4) =

@@ -484,17 +484,7 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
   float* qd = sm + AREA;                   // [TL][QD_LD]
   volatile int* pflag = reinterpret_cast<volatile int*>(qd + TL * QD_LD);   // [4]: wave w parked its partial
   if (threadIdx.x < 4) pflag[threadIdx.x] = 0;
-  for (int i = threadIdx.x; i < nl * 40; i += 256) {
-    const int r = i / 40, f = i % 40;
-    const size_t rowl = (size_t)b * N + l_begin + r;
-    if (a.pro && f >= 16 && f < 32) continue;   // dV_att comes from the prologue below
-    const float* src = f < 16 ? a.qkvp + rowl * QKVP + f * 4
-                     : f < 32 ? a.dvp + rowl * 64 + (f - 16) * 4
-                              : a.stats + rowl * 32 + (f - 32) * 4;
-    float4 v = *reinterpret_cast<const float4*>(src);
-    if (f >= 32) v.y = 1.0f / v.y;   // softmax row sum -> reciprocal
-    *reinterpret_cast<float4*>(qd + r * QD_LD + f * 4) = v;
-  }
+  bwd_stage_rows<256, 3>(a, qd, b, l_begin, nl);
   NSTMP(0);   // staging issued
   if (a.pro) {
     __syncthreads();
