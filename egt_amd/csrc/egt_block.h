@@ -90,4 +90,5 @@ void egt_node_launch_bwd(BlockArgs& a, const BlockArgs* dv_layer, bool do_pre, h
 void egt_node_launch_wgrads(BlockArgs* as, int n, hipStream_t st);   // n <= 64 layers
 int egt_node_wgrad_chunks(int rows, int layers);   // row chunks (= partial slots in wpart) of a k_node_wgrads launch over `layers` layers
 void egt_node_launch_prep(BlockArgs* as, int n, hipStream_t st);   // n <= 64 layers
+bool egt_node_launch_pre_stack(BlockArgs* as, int n, hipStream_t st);   // layer 0's k_node_pre + the preparation of all n layers in one launch
 void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, hipStream_t st);

@@ -607,11 +607,13 @@ extern "C" int egt_stack_fwd(const egt_block_desc* desc, int32_t layers, const e
   // edge weights of every layer in one launch; each block's epilogue then finishes the node side
   // (dense_mha + residual) and already produces the next block's packed QKV, so a layer is ONE
   // launch wherever the epilogue covers the geometry
-  egt_node_launch_prep(as, layers, (hipStream_t)stream);
+  // (the preparation rides along with layer 0's k_node_pre as extra workgroups: one launch less in front of every step)
+  for (int l = 0; l < layers; ++l) as[l].prep = 0;
   int prev_epi = 0;
+  if (egt_node_launch_pre_stack(as, layers, (hipStream_t)stream)) prev_epi = 2;   // layer 0's packed QKV rows exist
+  else egt_node_launch_prep(as, layers, (hipStream_t)stream);
   for (int l = 0; l < layers; ++l) {
     BlockArgs& a = as[l];
-    a.prep = 0;
     a.epi = 1;
     if (l + 1 < layers) {
       const BlockArgs& nx = as[l + 1];

@@ -206,10 +206,7 @@ __device__ __forceinline__ void stg_commit_rows(const Stg<NU>& s, float* xs, int
 }
 
 // --------------------------------------------------------------- node: pre -----
-__global__ void __launch_bounds__(512) k_node_pre(BlockArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int NCH = (a.N + NODE_RC - 1) / NODE_RC;
-  if ((int)blockIdx.x == a.B * NCH) { prep_device(a, sm); return; }
+__device__ __forceinline__ void node_pre_rows(const BlockArgs& a, float* sm, int NCH) {
   const int Dh = a.Dh, N = a.N, b = blockIdx.x / NCH, chunk = blockIdx.x % NCH, t = threadIdx.x, ld = Dh + LDP, D3 = 3 * Dh;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), p = lane & 15, q = lane >> 4, NW = blockDim.x >> 6;
   float* xs = sm;                 // [NODE_RC][ld]
@@ -261,6 +258,24 @@ __global__ void __launch_bounds__(512) k_node_pre(BlockArgs a) {
       }
     }
   }
+}
+
+__global__ void __launch_bounds__(512) k_node_pre(BlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int NCH = (a.N + NODE_RC - 1) / NODE_RC;
+  if ((int)blockIdx.x == a.B * NCH) { prep_device(a, sm); return; }
+  node_pre_rows(a, sm, NCH);
+}
+// The first launch of a stack's forward: layer 0's packed QKV rows plus the edge-weight preparation of EVERY layer as NL extra
+// workgroups (k_edge_prep as a launch of its own was ~6.5 us of latency for 10 workgroups in front of every step).
+template <int NL> struct PrepArgsN { PrepLayer L[NL]; int n; };
+template <int NL>
+__global__ void __launch_bounds__(512) k_node_pre_stack(BlockArgs a, PrepArgsN<NL> pa) {
+  static_assert(sizeof(BlockArgs) + sizeof(PrepArgsN<NL>) <= 4096, "kernel-argument block");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int NCH = (a.N + NODE_RC - 1) / NODE_RC, extra = (int)blockIdx.x - a.B * NCH;
+  if (extra >= 0) { prep_layer(pa.L[extra], a.De, (a.flags & EGT_BF_GATE) != 0, sm); return; }
+  node_pre_rows(a, sm, NCH);
 }
 
 // -------------------------------------------------------------- node: post -----
@@ -695,11 +710,14 @@ struct SumSeg { const float* src; float* dst; int n, np, stride, blk0; };   // b
 #define SUM_MAX_SEG 77  // 11 layers x 7 segments: fits the 4 KiB kernel-argument block
 struct SumArgs { SumSeg seg[SUM_MAX_SEG]; int nseg; };
 
-// 32 outputs per workgroup, the partial axis split over 8 groups of 32 lanes with 8 independent
-// accumulators each: with hundreds of partials per output the loop is latency-bound, so what counts
-// is loads in flight (64 per output), not lanes per output.  Fixed association order: deterministic.
-__global__ void __launch_bounds__(256) k_sum_segments(SumArgs s) {
-  __shared__ float red[8][32];
+// 32 outputs per workgroup, the partial axis split over SUM_G groups of 32 lanes, SUM_U loads in flight per lane and ONE wait per
+// round of SUM_U: with hundreds of partials per output the loop is latency-bound, so what counts is loads in flight per output
+// (128) and the number of dependent round trips (512 partials: 4; the 43 row chunks of k_node_wgrads: 1 -- the plain
+// `for (pi ...) v += src[pi]` tail this replaces waited on every load).  Fixed association order: deterministic.
+#define SUM_G 16
+#define SUM_U 8
+__global__ void __launch_bounds__(32 * SUM_G) k_sum_segments(SumArgs s) {
+  __shared__ float red[SUM_G][32];
   // flat grid: one workgroup per 32 outputs of some segment (a (max blocks) x (segments) grid launched
   // four empty workgroups for every working one); the segment is found by a scalar binary search
   int lo = 0, hi = s.nseg - 1;
@@ -710,57 +728,97 @@ __global__ void __launch_bounds__(256) k_sum_segments(SumArgs s) {
   const SumSeg sg = s.seg[lo];
   const int ol = threadIdx.x & 31, pg = threadIdx.x >> 5;
   const int o = ((int)blockIdx.x - sg.blk0) * 32 + ol;
-  float v[8];
+  float v[SUM_U];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) v[k] = 0.f;
+  for (int k = 0; k < SUM_U; ++k) v[k] = 0.f;
   if (o < sg.n) {
+    const float* __restrict__ src = sg.src + o;
     int pi = pg;
-    for (; pi + 56 < sg.np; pi += 64) {
+    for (; pi + SUM_G * (SUM_U - 1) < sg.np; pi += SUM_G * SUM_U) {
+      float w[SUM_U];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] += sg.src[(size_t)(pi + 8 * k) * sg.stride + o];
+      for (int k = 0; k < SUM_U; ++k) w[k] = src[(size_t)(pi + SUM_G * k) * sg.stride];
+#pragma unroll
+      for (int k = 0; k < SUM_U; ++k) v[k] += w[k];
     }
-    for (; pi < sg.np; pi += 8) v[0] += sg.src[(size_t)pi * sg.stride + o];
+    if (pi < sg.np) {   // the last, partial round: an index past the end re-reads the last partial (a cache hit) and adds nothing
+      float w[SUM_U];
+#pragma unroll
+      for (int k = 0; k < SUM_U; ++k) w[k] = src[(size_t)min(pi + SUM_G * k, sg.np - 1) * sg.stride];
+#pragma unroll
+      for (int k = 0; k < SUM_U; ++k) v[k] += pi + SUM_G * k < sg.np ? w[k] : 0.f;
+    }
   }
   red[pg][ol] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
   __syncthreads();
-  if (pg == 0 && o < sg.n)
-    sg.dst[o] = ((red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol])) + ((red[4][ol] + red[5][ol]) + (red[6][ol] + red[7][ol]));
+  if (pg == 0 && o < sg.n) {
+    float r[SUM_G];
+#pragma unroll
+    for (int g = 0; g < SUM_G; ++g) r[g] = red[g][ol];
+#pragma unroll
+    for (int w = 1; w < SUM_G; w *= 2)
+#pragma unroll
+      for (int g = 0; g < SUM_G; g += 2 * w) r[g] += r[g + w];
+    sg.dst[o] = r[0];
+  }
 }
 
 // T[c][i], s[i], R[c][h|8] -> grads of norm_edge, attention_gates, dense_edge_b, dense_edge_r.
-// One workgroup per layer (blockIdx.x), so a whole stack finishes in one launch.
+// One workgroup per layer (blockIdx.x), so a whole stack finishes in one launch.  Every input (the reduced sums and the layer's
+// parameters) is fetched in ONE round of loads into LDS; the arithmetic then reads LDS only (the straight loops -- load, use,
+// store per iteration -- were a chain of ~10 dependent memory round trips for a few KB of work).
 struct EdgeGradLayer {
   const float *ne_g, *ne_b, *Wg, *We, *ered;
   float *g_ne_g, *g_ne_b, *g_Wg, *g_bg, *g_We, *g_be, *g_Wr, *g_br;
 };
 #define EPG_MAX_LAYERS 16
+#define EPG_MAX_DE 64
 struct EdgeGradArgs { EdgeGradLayer L[EPG_MAX_LAYERS]; int De; uint32_t flags; };
 
 __global__ void __launch_bounds__(256) k_edge_param_grads(EdgeGradArgs ga) {
+  constexpr int EPM = 2 * EPG_MAX_DE * 16 + 16, EU = (EPM + 255) / 256, WU = (EPG_MAX_DE * BH + 255) / 256;
+  __shared__ float er[EPM], wg[EPG_MAX_DE * BH], we[EPG_MAX_DE * BH], gam[EPG_MAX_DE], bet[EPG_MAX_DE];
   const EdgeGradLayer a = ga.L[blockIdx.x];
-  const int DE = ga.De, DEP = ((DE + 15) / 16) * 16;
+  const int DE = ga.De, DEP = ((DE + 15) / 16) * 16, EP = 2 * DEP * 16 + 16, t = threadIdx.x;
   const bool gated = (ga.flags & EGT_BF_GATE) != 0;
-  const float* T = a.ered;
-  const float* s = a.ered + DEP * 16;
+  {
+    float e[EU], g[WU], w[WU];
+#pragma unroll
+    for (int u = 0; u < EU; ++u) e[u] = a.ered[min(t + 256 * u, EP - 1)];
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+      const int i = min(t + 256 * u, DE * BH - 1);
+      g[u] = gated ? a.Wg[i] : 0.f;
+      w[u] = a.We[i];
+    }
+    const float pg = a.ne_g[min(t, DE - 1)], pb = a.ne_b[min(t, DE - 1)];
+#pragma unroll
+    for (int u = 0; u < EU; ++u) if (t + 256 * u < EP) er[t + 256 * u] = e[u];
+#pragma unroll
+    for (int u = 0; u < WU; ++u) if (t + 256 * u < DE * BH) { wg[t + 256 * u] = g[u]; we[t + 256 * u] = w[u]; }
+    if (t < DE) { gam[t] = pg; bet[t] = pb; }
+  }
+  __syncthreads();
+  const float* T = er;
+  const float* s = er + DEP * 16;
   const float* R = s + 16;
-  for (int idx = threadIdx.x; idx < DE * 16; idx += 256) {
+  for (int idx = t; idx < DE * 16; idx += 256) {
     const int c = idx >> 4, i = idx & 15, hd = col_head(i);
-    const float v = a.ne_g[c] * T[c * 16 + i] + a.ne_b[c] * s[i];
+    const float v = gam[c] * T[c * 16 + i] + bet[c] * s[i];
     if (col_is_gate(i)) { if (gated) a.g_Wg[c * BH + hd] = v; }
     else a.g_We[c * BH + hd] = v;
   }
-  if (threadIdx.x < 16) {
-    const int i = threadIdx.x, hd = col_head(i);
+  if (t < 16) {
+    const int i = t, hd = col_head(i);
     if (col_is_gate(i)) { if (gated) a.g_bg[hd] = s[i]; }
     else a.g_be[hd] = s[i];
   }
-  for (int c = threadIdx.x; c < DE; c += 256) {
+  for (int c = t; c < DE; c += 256) {
     float dg = 0.f, db = 0.f;
+#pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int hd = col_head(i);
-      float w;
-      if (col_is_gate(i)) w = gated ? a.Wg[c * BH + hd] : 0.f;
-      else w = a.We[c * BH + hd];
+      const float w = col_is_gate(i) ? wg[c * BH + hd] : we[c * BH + hd];   // (wg holds zeros when the block is not gated)
       dg = fmaf(w, T[c * 16 + i], dg);
       db = fmaf(w, s[i], db);
     }
@@ -768,7 +826,7 @@ __global__ void __launch_bounds__(256) k_edge_param_grads(EdgeGradArgs ga) {
     a.g_ne_b[c] = db;
     a.g_br[c] = R[c * 16 + 8];
   }
-  for (int idx = threadIdx.x; idx < BH * DE; idx += 256) {
+  for (int idx = t; idx < BH * DE; idx += 256) {
     const int hd = idx / DE, c = idx % DE;
     a.g_Wr[idx] = R[c * 16 + hd];
   }
@@ -783,6 +841,29 @@ void egt_node_launch_pre(BlockArgs& a, hipStream_t st) {
   if (lds < 1024) lds = 1024;  // prep workgroup scratch
   EGT_MAX_LDS_ONCE(k_node_pre);
   EGT_LAUNCH("k_node_pre", k_node_pre, dim3(a.B * node_chunks(a) + (a.prep ? 1 : 0)), dim3(512), lds, st, a);
+}
+
+// layer 0's k_node_pre with the edge-weight preparation of all `n` layers riding along; false: more layers than the argument
+// block takes (the caller launches k_edge_prep + k_node_pre instead)
+template <int NL>
+static void launch_pre_stack(BlockArgs* as, int n, size_t lds, hipStream_t st) {
+  PrepArgsN<NL> pa{};
+  pa.n = n;
+  for (int l = 0; l < n; ++l) {
+    const BlockArgs& a = as[l];
+    pa.L[l] = PrepLayer{a.ne_g, a.ne_b, a.Wg, a.bg, a.We, a.be, a.pw};
+  }
+  EGT_MAX_LDS_ONCE(k_node_pre_stack<NL>);
+  EGT_LAUNCH("k_node_pre", k_node_pre_stack<NL>, dim3(as[0].B * node_chunks(as[0]) + n), dim3(512), lds, st, as[0], pa);
+}
+bool egt_node_launch_pre_stack(BlockArgs* as, int n, hipStream_t st) {
+  if (n > 56) return false;
+  const BlockArgs& a = as[0];
+  size_t lds = lds_rows(a.Dh, 1) + (size_t)a.Dh * (3 * a.Dh + LDP) * 4;
+  if (lds < 1024) lds = 1024;  // prep workgroup scratch
+  if (n <= 16) launch_pre_stack<16>(as, n, lds, st);
+  else launch_pre_stack<56>(as, n, lds, st);
+  return true;
 }
 
 void egt_node_launch_post(BlockArgs& a, hipStream_t st) {
@@ -882,7 +963,7 @@ void egt_node_launch_reduce(BlockArgs* as, int n, int nwg_bwd, int EP, hipStream
       seg(a.epart, a.ered, EP, nwg_bwd, EP);
     }
     s.nseg = k;
-    EGT_LAUNCH("k_sum_segments", k_sum_segments, dim3(nblk), dim3(256), 0, st, s);
+    EGT_LAUNCH("k_sum_segments", k_sum_segments, dim3(nblk), dim3(32 * SUM_G), 0, st, s);
   }
   for (int l0 = 0; l0 < n; l0 += EPG_MAX_LAYERS) {
     const int nl = (n - l0 < EPG_MAX_LAYERS) ? (n - l0) : EPG_MAX_LAYERS;

@@ -414,6 +414,10 @@ def test_node_side_runs_inside_the_pair_kernels(N, De, Dh, gpu, egt_lib):
         count[name] = cnt.value
     assert count.get("k_block_fwd") == Ly and count.get("k_block_bwd") == Ly, count
     assert count.get("k_node_pre") == 1 and count.get("k_node_post", 0) == 0 and count.get("k_node_bwd") == 1, count
+    # the edge-weight preparation of every layer rides along with k_node_pre (no k_edge_prep launch); the step's launches are the
+    # 2 Ly pair kernels + k_node_pre, k_node_bwd, k_node_wgrads, k_sum_segments, k_edge_param_grads
+    assert count.get("k_edge_prep", 0) == 0, count
+    assert sum(count.values()) == 2 * Ly + 5, count
 
 
 def test_block_bf16_single_block_and_dtype_errors(gpu, egt_lib):
