@@ -932,7 +932,7 @@ def main():
     # around every launch costs ~15% of the step), and of those every PROF_STRIDE-th launch: an event pair costs the stream
     # 4-5 us (ten of them per step were 2.5 % of the headline step), and a stride coprime with the launches per step walks
     # through the layers.  The per-kernel table comes from a second, untimed pass over the same steps below.
-    PROF_STRIDE = 7
+    PROF_STRIDE = 13
     COLLECT_EVERY = 5                    # replay mode: the graph's event pairs are read after every 5th replay (one stream sync each)
     if not args.no_prof:
         lib.egt_prof_filter(args.dominant.encode())

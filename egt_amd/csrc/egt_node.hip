@@ -212,13 +212,25 @@ __device__ __forceinline__ void node_pre_rows(const BlockArgs& a, float* sm, int
   float* xs = sm;                 // [NODE_RC][ld]
   float* ws = xs + NODE_RC * ld;  // Wqkv [Dh][ldw]
   const int ldw = D3 + LDP;
-  stage_weight(ws, ldw, a.Wqkv, Dh, D3);
   const int nct = (D3 + 15) / 16;
   for (int r0 = chunk * NODE_RC; r0 < min(N, (chunk + 1) * NODE_RC); r0 += NODE_RC) {  // one chunk
     const int nr = min(NODE_RC, N - r0), nrp = (nr + 15) & ~15;
     const size_t row0 = (size_t)b * N + r0;
-    __syncthreads();
-    stage_rows(xs, ld, a.h + row0 * Dh, Dh, nr, nrp);
+    if (Dh * D3 / 4 <= 6 * (int)blockDim.x && NODE_RC * (Dh >> 2) <= (int)blockDim.x) {
+      // Wqkv (<= 6 16-byte units per thread) and the chunk's rows (1) in ONE memory round trip: issue, then commit (the staging
+      // helpers one after the other were three dependent round trips at the head of every forward)
+      Stg<6> sW;
+      Stg<1> sX;
+      const bool al = (reinterpret_cast<uintptr_t>(a.Wqkv) & 15) == 0;
+      stg_issue_weight(sW, reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(a.Wqkv) & ~(uintptr_t)15), Dh * D3 / 4);
+      stg_issue_rows(sX, a.h + row0 * Dh, Dh, nr, nrp);
+      stg_pin(sW); stg_pin(sX);
+      stg_commit_weight(sW, ws, ldw, a.Wqkv, al, Dh, D3);
+      stg_commit_rows(sX, xs, ld, Dh, nr, nrp);
+    } else {
+      stage_weight(ws, ldw, a.Wqkv, Dh, D3);
+      stage_rows(xs, ld, a.h + row0 * Dh, Dh, nr, nrp);
+    }
     __syncthreads();
     for (int rb = wave * 4; rb < nrp; rb += 4 * NW) {  // LayerNorm: 16 lanes per row
       float* x = xs + (rb + q) * ld;
@@ -711,10 +723,11 @@ struct SumSeg { const float* src; float* dst; int n, np, stride, blk0; };   // b
 struct SumArgs { SumSeg seg[SUM_MAX_SEG]; int nseg; };
 
 // 32 outputs per workgroup, the partial axis split over SUM_G groups of 32 lanes, SUM_U loads in flight per lane and ONE wait per
-// round of SUM_U: with hundreds of partials per output the loop is latency-bound, so what counts is loads in flight per output
-// (128) and the number of dependent round trips (512 partials: 4; the 43 row chunks of k_node_wgrads: 1 -- the plain
-// `for (pi ...) v += src[pi]` tail this replaces waited on every load).  Fixed association order: deterministic.
-#define SUM_G 16
+// round of SUM_U -- the last, partial round included (a plain `for (pi ...) v += src[pi]` tail waits on every load).  With hundreds
+// of partials per output the loop is latency-bound: what counts is loads in flight per output (64).  SUM_G = 16 (512 threads) measured
+// the same at the headline (24.4-24.8 us either way: the kernel moves its ~78 MB at ~4 TB/s) and 1-2 us slower on the small
+// launches of configs 1 and 4.  Fixed association order: deterministic.
+#define SUM_G 8
 #define SUM_U 8
 __global__ void __launch_bounds__(32 * SUM_G) k_sum_segments(SumArgs s) {
   __shared__ float red[SUM_G][32];

@@ -34,7 +34,7 @@ def _u8c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     if t is None:
         return None
     if t.dtype == torch.bool:
-        t = t.to(torch.uint8)
+        return t.contiguous().view(torch.uint8)    # a bool tensor IS one 0 / 1 byte per element: no conversion kernel per call
     elif t.dtype != torch.uint8:
         t = (t != 0).to(torch.uint8)
     return t.contiguous()
