@@ -41,6 +41,7 @@ WORKLOADS = {
     "zinc500k_n64": dict(B=128, N=64, Dh=64, De=64, H=8, Ly=10, nodes=(9, 37), rand_p=0.1),
     "zinc500k_n64_b1024": dict(B=1024, N=64, Dh=64, De=64, H=8, Ly=10, nodes=(9, 37), rand_p=0.1),   # large-batch sanity
     # the full-occupancy variant of config 2 (every padded slot a real node: n_b = 64)
+    "zinc500k_n64_nomask": dict(B=128, N=64, Dh=64, De=64, H=8, Ly=10, nodes=(9, 37), rand_p=0.0),   # diagnosis: what the in-kernel mask RNG costs
     "zinc500k_n64_full": dict(B=128, N=64, Dh=64, De=64, H=8, Ly=10, nodes=(64, 64), rand_p=0.1),
     # the other BASELINE.json configs' shapes, for reference runs -- not bench lines
     "zinc100k_n37": dict(B=128, N=37, Dh=48, De=48, H=8, Ly=4, nodes=(9, 37), rand_p=0.1),
@@ -68,7 +69,7 @@ WORKLOADS = {
     "synthetic_n512_block": dict(B=8, N=512, Dh=512, De=32, H=8, Ly=1, nodes=(512, 512), rand_p=0.1, scope="block"),
 }
 # what the metric string says after "graphs/sec EGT fwd+bwd, " (BASELINE.json's metric is quoted on the first)
-METRIC_OF = {"zinc500k_n64": "ZINC-500K padded N=64", "zinc500k_n64_b1024": "ZINC-500K padded N=64 (B=1024)",
+METRIC_OF = {"zinc500k_n64": "ZINC-500K padded N=64", "zinc500k_n64_nomask": "ZINC-500K padded N=64 (random_mask_prob = 0)", "zinc500k_n64_b1024": "ZINC-500K padded N=64 (B=1024)",
              "zinc500k_n64_full": "ZINC-500K shapes N=64, every node real (full occupancy)",
              "pattern500k_bmax": "PATTERN-500K shapes padded to the per-batch max (B=16)", "pattern500k_bmax_b128": "PATTERN-500K shapes padded to the per-batch max (B=128)",
              "pattern500k_n188": "PATTERN-500K shapes padded N=188 (B=16)", "pattern500k_n188_b128": "PATTERN-500K shapes padded N=188 (B=128)",
