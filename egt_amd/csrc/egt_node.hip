@@ -628,6 +628,13 @@ __global__ void __launch_bounds__(512, 4) k_node_wgrads(WGradArgs wa) {
     gam[i] = c < Dh ? L.nm_g[c] : 0.f;
     bet[i] = c < Dh ? L.nm_b[c] : 0.f;
   }
+  // (D64: the LayerNorm runs on the prefetched registers: the thread's four channels 4 xc .. 4 xc + 3 of row xr)
+  // (scalar loads: parameter views need not be 16-byte aligned)
+  float4 gam4 = make_float4(0.f, 0.f, 0.f, 0.f), bet4 = gam4;
+  if (D64) {
+    gam4 = make_float4(L.nm_g[xc * 4], L.nm_g[xc * 4 + 1], L.nm_g[xc * 4 + 2], L.nm_g[xc * 4 + 3]);
+    bet4 = make_float4(L.nm_b[xc * 4], L.nm_b[xc * 4 + 1], L.nm_b[xc * 4 + 2], L.nm_b[xc * 4 + 3]);
+  }
   float4 ph, pv, pd, pq[3];
 #define WG_LOAD(R0)                                                                              \
   do {                                                                                           \
@@ -647,6 +654,16 @@ __global__ void __launch_bounds__(512, 4) k_node_wgrads(WGradArgs wa) {
 #define SEL4(ok, v) make_float4((ok) ? (v).x : 0.f, (ok) ? (v).y : 0.f, (ok) ? (v).z : 0.f, (ok) ? (v).w : 0.f)
       if (xok) {
         const bool ok = xr < nr;
+        if (D64) {
+          // norm_mha of the row from the prefetched registers: 16 consecutive lanes hold one row (4 channels each), so the two
+          // row reductions are 16-lane DPP sums and the LDS tile receives h_ln directly -- no in-place LayerNorm pass over the
+          // tile, one barrier less per 32-row step
+          const float mu = sum16((ph.x + ph.y) + (ph.z + ph.w)) * (1.0f / 64);
+          const float4 v = make_float4(ph.x - mu, ph.y - mu, ph.z - mu, ph.w - mu);
+          const float rstd = rsqrtf(sum16(fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)))) * (1.0f / 64) + wa.ln_eps);
+          ph = make_float4(fmaf(v.x * rstd, gam4.x, bet4.x), fmaf(v.y * rstd, gam4.y, bet4.y),
+                           fmaf(v.z * rstd, gam4.z, bet4.z), fmaf(v.w * rstd, gam4.w, bet4.w));
+        }
         *reinterpret_cast<float4*>(xs + xr * ld + xc * 4) = SEL4(ok, ph);
         *reinterpret_cast<float4*>(vs + xr * ld + xc * 4) = SEL4(ok, pv);
         *reinterpret_cast<float4*>(ds + xr * ld + xc * 4) = SEL4(ok, pd);
@@ -658,6 +675,7 @@ __global__ void __launch_bounds__(512, 4) k_node_wgrads(WGradArgs wa) {
     }
     if (r0 + 32 < rend) WG_LOAD(r0 + 32);
     __syncthreads();
+    if (!D64)
     for (int rb = wave * 4; rb < nrp; rb += 4 * NW) {  // norm_mha forward, in place
       float* xr = xs + (rb + q) * ld;
       float v[4], s1 = 0.f;
@@ -671,7 +689,7 @@ __global__ void __launch_bounds__(512, 4) k_node_wgrads(WGradArgs wa) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const int c = p + 16 * i; if (c < Dh) xr[c] = fmaf(v[i] * rstd, gam[i], bet[i]); }
     }
-    __syncthreads();
+    if (!D64) __syncthreads();
     // wave -> (k tile kt = wave/2, half of the column tiles): the h_ln / v_att operand is read
     // once per row step and feeds all of the wave's output tiles
     if (D64 || kt < nkt) {

@@ -147,6 +147,37 @@ def test_fused_stack_matches_composed(gpu, egt_lib):
     assert_close(e1, e2, name="e", rtol=1e-4, arel=5e-5)
 
 
+@pytest.mark.parametrize("Ly", [17, 58])
+def test_deep_stack_one_call_equals_block_calls(Ly, gpu, egt_lib):
+    """the first launch of a stack's forward carries the edge-weight preparation of EVERY layer (k_node_pre_stack: up to 16 / up to 56
+    layers per kernel-argument block; deeper stacks fall back to the separate k_edge_prep launch): forward outputs and every gradient
+    of the one-call stack equal the block-by-block fused calls bit for bit (same kernels, same order of operations)"""
+    from egt_amd import EGTStack
+    torch.manual_seed(Ly)
+    kw = dict(model_height=Ly, model_width=64, edge_width=64, num_heads=8)
+    a = EGTStack(fused=True, **kw).to(gpu).eval()
+    b = EGTStack(fused=True, stack_call=False, **kw).to(gpu).eval()
+    b.load_state_dict(a.state_dict())
+    g = torch.Generator().manual_seed(Ly)
+    h = (0.5 * torch.randn(2, 16, 64, generator=g)).to(gpu); e = (0.5 * torch.randn(2, 16, 16, 64, generator=g)).to(gpu)
+    mask = torch.ones(2, 16, dtype=torch.bool, device=gpu); mask[1, 11:] = False
+    dh = torch.randn(2, 16, 64, generator=g).to(gpu); de = torch.randn(2, 16, 16, 64, generator=g).to(gpu)
+    out = []
+    for st in (a, b):
+        hh = h.clone().requires_grad_(); ee = e.clone().requires_grad_()
+        h2, e2 = st(hh, ee, mask)
+        torch.autograd.backward([h2, e2], [dh, de])
+        out.append((h2.detach(), e2.detach(), hh.grad, ee.grad, {n: p.grad.clone() for n, p in st.named_parameters()}))
+    assert a.last_path == "fused-stack"
+    (h1, e1, dh1, de1, g1), (h2, e2, dh2, de2, g2) = out
+    assert torch.isfinite(h1).all() and torch.isfinite(e1).all()
+    assert torch.equal(h1, h2) and torch.equal(e1, e2)
+    assert_close(dh1, dh2, name="dh", rtol=1e-5, arel=1e-6)
+    assert_close(de1, de2, name="de", rtol=1e-5, arel=1e-6)
+    for n in g1:
+        assert_close(g1[n], g2[n], name=n, rtol=1e-4, arel=1e-5)
+
+
 @pytest.mark.parametrize("N,De,Dh,train", [(24, 64, 64, False), (32, 64, 64, True), (11, 48, 48, False),
                                            (20, 8, 64, True), (80, 16, 64, True), (32, 32, 64, False), (48, 48, 64, True),
                                            (32, 8, 64, True), (128, 8, 64, False),
