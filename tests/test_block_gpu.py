@@ -172,10 +172,12 @@ def test_deep_stack_one_call_equals_block_calls(Ly, gpu, egt_lib):
     (h1, e1, dh1, de1, g1), (h2, e2, dh2, de2, g2) = out
     assert torch.isfinite(h1).all() and torch.isfinite(e1).all()
     assert torch.equal(h1, h2) and torch.equal(e1, e2)
-    assert_close(dh1, dh2, name="dh", rtol=1e-5, arel=1e-6)
-    assert_close(de1, de2, name="de", rtol=1e-5, arel=1e-6)
+    # (the block-by-block backward runs the node side in kernels of its own: same arithmetic, other summation orders -- and under
+    #  EGT_BWD_MATMUL=bf16x3, tests/test_bwd_modes_gpu.py, other split products -- through up to 58 layers)
+    assert_close(dh1, dh2, name="dh", rtol=1e-4, arel=2e-5)
+    assert_close(de1, de2, name="de", rtol=1e-4, arel=2e-5)
     for n in g1:
-        assert_close(g1[n], g2[n], name=n, rtol=1e-4, arel=1e-5)
+        assert_close(g1[n], g2[n], name=n, rtol=1e-3, arel=1e-4)
 
 
 @pytest.mark.parametrize("N,De,Dh,train", [(24, 64, 64, False), (32, 64, 64, True), (11, 48, 48, False),
