@@ -444,10 +444,11 @@ static int launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool t
         }
         if (!ml && !a.bf16) {   // LDS-DMA staged e tiles (k_block_bwd_v5), ragged N included
           const bool x3 = block_env().bwd_mm == EGT_MM_BF16X3;
+          const size_t lds_v5 = ((size_t)V5_AREA(DE) + (size_t)BWD_TL * QD_LD + 3 * ((GG::TILES + 1) / 2) * 512) * 4;
 #define V5_LAUNCH(MM_, RAG_)                                                                                 \
   do {                                                                                                       \
     EGT_MAX_LDS_ONCE(k_block_bwd_v5<DE, MM_, RAG_>);                                                         \
-    EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE, MM_, RAG_>), dim3(L.nwg_bwd), dim3(256), lds_v4, st, a);   \
+    EGT_LAUNCH("k_block_bwd", (k_block_bwd_v5<DE, MM_, RAG_>), dim3(L.nwg_bwd), dim3(256), lds_v5, st, a);   \
   } while (0)
           if (full) { if (x3) V5_LAUNCH(EGT_MM_BF16X3, false); else V5_LAUNCH(0, false); }
           else { if (x3) V5_LAUNCH(EGT_MM_BF16X3, true); else V5_LAUNCH(0, true); }

@@ -354,6 +354,10 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
 // (20 MFMAs of 16 cycles; per-product error 2^-16, fp32 accumulate); the weight-gradient contractions over the
 // pair axis (P4) and everything else stay exact fp32.  Same LDS footprint: a bf16 hi + lo pair is as large as the
 // fp32 value it replaces.
+// floats of k_block_bwd_v5's tile area: four waves x (two e buffers + de' tile + hand-off tiles), and at least the four parity-0 e
+// buffers + the node-side prologue's scratch behind them
+#define V5_AREA(DE_) ((4 * (3 * Geo<DE_>::TILE_FLOATS + 448) > 4 * Geo<DE_>::TILE_FLOATS + BWD_PRO_WS) \
+                          ? 4 * (3 * Geo<DE_>::TILE_FLOATS + 448) : 4 * Geo<DE_>::TILE_FLOATS + BWD_PRO_WS)
 template <int DE, int MM, bool RAG>
 __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   seed_from_device(a);
@@ -377,11 +381,19 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   constexpr int PW = 3 * G::TILE_FLOATS + 256 + 192;
   // one weight slab: [TILES][64 lanes] float4; the bf16 slabs of an odd tile count are padded to whole 32-channel steps
   constexpr int WSLAB = (MM != 0 && NS * 512 > G::TILES * 256) ? NS * 512 : G::TILES * 256;
-  float* et0 = sm + wave * PW;               // e / xhat tile, two buffers (row parity)
-  float* dt = et0 + 2 * G::TILE_FLOATS;      // de' tile
+  // Tile area: the four waves' FIRST e buffers (row parity 0) lie in front of everything else, outside the node-side prologue's
+  // scratch, so a wave's first e tile can be on its way (LDS-DMA) while the prologue runs; the second e buffer, the de' tile and
+  // the two small hand-off tiles of a wave follow, and the prologue's scratch lies over those.
+  constexpr int PW2 = 2 * G::TILE_FLOATS + 256 + 192;
+  float* et0 = sm + wave * G::TILE_FLOATS;   // e / xhat tile, row parity 0
+  float* et1 = sm + 4 * G::TILE_FLOATS + wave * PW2;   // ... row parity 1
+  const int estr = __builtin_amdgcn_readfirstlane((int)(et1 - et0));   // floats from a wave's parity-0 to its parity-1 buffer
+  float* dt = et1 + G::TILE_FLOATS;          // de' tile
   float* sc1 = dt + G::TILE_FLOATS;
   float* sc2 = sc1 + 256;
-  constexpr int AREA = 4 * PW > BWD_PRO_WS ? 4 * PW : BWD_PRO_WS;   // per-wave tiles; also the prologue's scratch
+  constexpr int AREA = V5_AREA(DE);          // per-wave tiles; the prologue's scratch starts behind the parity-0 buffers
+  static_assert(4 * PW == 4 * G::TILE_FLOATS + 4 * PW2 && AREA >= 4 * PW && AREA >= 4 * G::TILE_FLOATS + BWD_PRO_WS, "tile area");
+  float* pro_ws = sm + 4 * G::TILE_FLOATS;
   float* qd = sm + AREA;                     // [TL][QD_LD]
   float* wsA = qd + TL * QD_LD;              // prologue weights   wA[4t+u]
   float* wsB = wsA + WSLAB;                  // dH_ext weights     wrB[4t+u]
@@ -389,9 +401,33 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   // LDS byte address of the wave's e buffers (the kernel's only LDS object is the dynamic array: offset 0)
   const unsigned et_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)et0);
   const unsigned off0 = dma_lane_offset<DE>(lane);
+  // The wave's first key tile: its first e tile (LDS-DMA into the parity-0 buffer), the K / V fragments of its keys and the key-mask
+  // byte are requested FIRST -- ahead of the start-up staging and the node-side prologue, which need ~9 us and touch neither the
+  // parity-0 buffers nor these registers -- so the row loop starts on data that has landed (the first row of a workgroup cost
+  // 8.1 us against 4.35 us for every later one: tools/r05_preloop.sh).
+  const int ntile = RAG ? (N + 15) / 16 : N / 16;
+  float Kf[16], Vf[16];
+  int kmv = 1;
+#define V5_TILE_START(MT_)                                                                                          \
+  do {                                                                                                              \
+    const int m0_ = (MT_) * 16, kv_ = RAG ? min(16, N - m0_) : 16;                                                  \
+    if (RAG && kv_ < 16) tile_dma_ragged<DE>(et_lds, e_in + (((size_t)b * N + l_begin) * N + m0_) * DE, lane, kv_); \
+    else tile_dma<DE, EGT_NT_BWD_E>(et_lds, e_in + (((size_t)b * N + l_begin) * N + m0_) * DE, off0);               \
+    const size_t rowm_ = (size_t)b * N + (RAG ? min(m0_ + p, N - 1) : m0_ + p);                                     \
+    const float4* kp_ = reinterpret_cast<const float4*>(a.qkvp + rowm_ * QKVP + 64 + q * 16);                       \
+    const float4* vp_ = reinterpret_cast<const float4*>(a.qkvp + rowm_ * QKVP + 128 + q * 16);                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                 \
+      const float4 kv4 = kp_[i], vv4 = vp_[i];                                                                      \
+      Kf[4*i] = kv4.x; Kf[4*i+1] = kv4.y; Kf[4*i+2] = kv4.z; Kf[4*i+3] = kv4.w;                                     \
+      Vf[4*i] = vv4.x; Vf[4*i+1] = vv4.y; Vf[4*i+2] = vv4.z; Vf[4*i+3] = vv4.w;                                     \
+    }                                                                                                               \
+    kmv = a.km ? (int)a.km[rowm_] : 1;                                                                              \
+  } while (0)
+  if (wave < ntile) V5_TILE_START(wave);
   // Staged query-side rows AND (fp32 products) the weight slabs: every global load of both is issued before the first LDS store, so
   // the kernel's start-up pays ONE memory round trip for them instead of one before and one behind the node-side prologue (the slabs
   // live behind qd, outside the prologue's scratch: they may be filled before it runs): k_block_bwd_v5 96.9-97.0 -> 95.3-95.7 us (same box).
+  BwdProRegs proR;
   {
     float4 sv[3];
 #pragma unroll
@@ -416,6 +452,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
         sD[t] = a.pw[(16 * t + pp) * 16 + 4 * qq + u];
       }
     }
+    if (a.pro) bwd_node_prologue_load<DE>(a, proR, b, l_begin);   // the prologue's own loads: issued before the first wait of the kernel
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int i = threadIdx.x + 256 * u, r = i / 40, f = i % 40;
@@ -436,7 +473,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   PSTAMP(0);
   if (a.pro) {
     __syncthreads();
-    bwd_node_prologue<DE>(a, sm, qd, b, l_begin, wg);
+    bwd_node_prologue_finish<DE>(a, pro_ws, qd, b, l_begin, wg, proR);
   }
   PSTAMP(1);
   // weight slabs: element (t, lane, u)
@@ -477,44 +514,32 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
 #pragma unroll
   for (int t = 0; t < G::TILES; ++t) { accT[t] = (v4f){0.f, 0.f, 0.f, 0.f}; accR[t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
   float ssum[4] = {0.f, 0.f, 0.f, 0.f};
-  __syncthreads();   // the prologue's scratch (= the tile area) is dead from here: DMA may land in it
+  __syncthreads();   // the prologue's scratch (the tile area behind the parity-0 e buffers) is dead from here
   PSTAMP(2);
 
-  const int ntile = RAG ? (N + 15) / 16 : N / 16;
   for (int mt = wave; mt < ntile; mt += 4) {
     const int m0 = mt * 16, m = m0 + p;
     const int kv = RAG ? min(16, N - m0) : 16;          // valid keys of the tile (wave-uniform)
     const bool kvalid = RAG ? (p < kv) : true;
-    // first e tile of this key tile: in flight while K / V are fetched
-    if (RAG && kv < 16) tile_dma_ragged<DE>(et_lds, e_in + (((size_t)b * N + l_begin) * N + m0) * DE, lane, kv);
-    else tile_dma<DE, EGT_NT_BWD_E>(et_lds, e_in + (((size_t)b * N + l_begin) * N + m0) * DE, off0);
-    float Kf[16], Vf[16], dKa[16], dVa[16];
-    const size_t rowm = (size_t)b * N + (RAG ? min(m, N - 1) : m);
-    {
-      const float4* kp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 64 + q * 16);
-      const float4* vp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 128 + q * 16);
+    // a later key tile of this wave (N > 64): its first e tile is in flight while K / V are fetched
+    if (mt != wave) V5_TILE_START(mt);
+    float dKa[16], dVa[16];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 kv = kp[i], vv = vp[i];
-        Kf[4*i] = kv.x; Kf[4*i+1] = kv.y; Kf[4*i+2] = kv.z; Kf[4*i+3] = kv.w;
-        Vf[4*i] = vv.x; Vf[4*i+1] = vv.y; Vf[4*i+2] = vv.z; Vf[4*i+3] = vv.w;
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { dKa[i] = 0.f; dVa[i] = 0.f; }
-    }
-    const float kadd = (a.km && a.km[rowm] == 0) ? -EGT_NEG : 0.0f;
+    for (int i = 0; i < 16; ++i) { dKa[i] = 0.f; dVa[i] = 0.f; }
+    asm volatile("" : "+v"(kmv));   // (the byte was requested long ago; its first use stays here)
+    const float kadd = kmv == 0 ? -EGT_NEG : 0.0f;
     for (int l = l_begin; l < l_end; ++l) {
       const int li = l - l_begin;
       const size_t rowl = (size_t)b * N + l;
       const size_t pair0 = rowl * N + m0;
-      float* et = et0 + (li & 1) * G::TILE_FLOATS;
+      float* et = et0 + (li & 1) * estr;
       MaskRegs mr{make_float2(1.f, 1.f), 0};
       // ---- de'(l): requested now, consumed after P1 ----
       TileRegs<DE> td;
       tile_gload<DE, EGT_NT_BWD_DY>(td, dey_in + pair0 * DE, lane, kv);
-      // ---- e(l) has been in flight for a whole iteration: retire it.  Younger operations of this wave:
-      // row l-1's dQ-partial store and its NI de stores, then the NI de' loads just issued ----
-      if (li == 0) vm_wait<0>(); else vm_wait<2 * ((G::NF4 + 63) / 64) + 1>();
+      // ---- e(l) has been in flight for a whole iteration (the first one: since kernel entry): retire it.  Younger operations of
+      // this wave: row l-1's dQ-partial store and its NI de stores (none before the first row), then the NI de' loads just issued ----
+      if (li == 0) vm_wait<(G::NF4 + 63) / 64>(); else vm_wait<2 * ((G::NF4 + 63) / 64) + 1>();
       SCHED_FENCE();
       // ---- P1: norm_edge, projections (recompute) ----
       float rstd;
@@ -550,8 +575,8 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       lds_sync();
       // ---- e(l+1) -> the other e buffer (its last reader, row l-1's P5, retired its LDS reads) ----
       if (l + 1 < l_end) {
-        if (RAG && kv < 16) tile_dma_ragged<DE>(et_lds + (unsigned)(((li + 1) & 1) * G::TILE_FLOATS * 4), e_in + (pair0 + (size_t)N) * DE, lane, kv);
-        else tile_dma<DE, EGT_NT_BWD_E>(et_lds + (unsigned)(((li + 1) & 1) * G::TILE_FLOATS * 4), e_in + (pair0 + (size_t)N) * DE, off0);
+        if (RAG && kv < 16) tile_dma_ragged<DE>(et_lds + (unsigned)(((li + 1) & 1) * estr * 4), e_in + (pair0 + (size_t)N) * DE, lane, kv);
+        else tile_dma<DE, EGT_NT_BWD_E>(et_lds + (unsigned)(((li + 1) & 1) * estr * 4), e_in + (pair0 + (size_t)N) * DE, off0);
       }
       SCHED_FENCE();
       // ---- P2: dH_ext = de'.Wr^T ----

@@ -536,6 +536,19 @@ __device__ __forceinline__ void bwd_node_prologue_t(const BlockArgs& a, float* w
   if (a.pro == 2) bwd_prologue_load_main<DE, D64>(a, b, l_begin, R, ptid, pnv);
   bwd_prologue_compute<DE, D64>(a, ws, qd, b, l_begin, wg, R, HOIST, tp, ptid, pnv);
 }
+// The two halves on their own, for a kernel that issues the prologue's loads together with its other start-up requests (one memory
+// round trip for all of them) and runs the arithmetic later: k_block_bwd_v5.
+template <int DE>
+__device__ __forceinline__ void bwd_node_prologue_load(const BlockArgs& a, BwdProRegs& R, int b, int l_begin) {
+  if (a.pro != 2) return;
+  if (a.Dh == 64) bwd_prologue_load_main<DE, true>(a, b, l_begin, R, threadIdx.x, -1);
+  else bwd_prologue_load_main<DE, false>(a, b, l_begin, R, threadIdx.x, -1);
+}
+template <int DE>
+__device__ __forceinline__ void bwd_node_prologue_finish(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg, BwdProRegs& R) {
+  if (a.Dh == 64) bwd_prologue_compute<DE, true>(a, ws, qd, b, l_begin, wg, R, false, nullptr, threadIdx.x, -1);
+  else bwd_prologue_compute<DE, false>(a, ws, qd, b, l_begin, wg, R, false, nullptr, threadIdx.x, -1);
+}
 // ptid / pnv: the calling thread's index inside its 256-thread group and the group's valid rows -- defaults: the workgroup IS the
 // group (threadIdx.x, min(a.TL, N - l_begin)).  k_block_bwd_v7 runs one group per 16 of its 32 rows (wg = the group's partial slot);
 // every thread of the workgroup must make the call (the barriers inside are workgroup barriers), surplus groups with pnv = 0.
