@@ -75,6 +75,35 @@ def run(parts, streams, steps):
     return sum(p[1].shape[0] for p in parts) * steps / dt
 
 
+def run_forked(parts, steps):
+    """both halves inside ONE hipGraph as two parallel branches (fork / join on a second stream during capture)"""
+    from egt_amd import DeviceSeeds, GraphedStep
+    mods = torch.nn.ModuleList([p[0] for p in parts])
+    seeds = DeviceSeeds.attach(mods, "cuda:0")
+    side = torch.cuda.Stream()
+
+    def both():
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            step(parts[1])
+        step(parts[0])
+        cur.wait_stream(side)
+    g = GraphedStep(both, seeds, warmup=2)
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for m in mods.modules():
+        if hasattr(m, "seed_device"):
+            m.seed_device = None
+    return sum(p[1].shape[0] for p in parts) * steps / dt
+
+
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
@@ -85,6 +114,10 @@ def main():
     a, b = make(B // 2, seed=1), make(B // 2, seed=2)
     print(f"two streams, {B // 2} + {B // 2}: {run([a, b], [s0, s1], steps):.0f} graphs/s")
     print(f"   (the same two halves on ONE stream: {run([a, b], [s0, s0], steps):.0f} graphs/s)")
+    try:
+        print(f"   both halves as two parallel branches of ONE hipGraph: {run_forked([a, b], steps):.0f} graphs/s")
+    except Exception as ex:  # noqa: BLE001
+        print("   forked capture failed:", type(ex).__name__, str(ex)[:200])
     del a, b
     na = (B * 5 // 8)
     a, b = make(na, seed=1), make(B - na, seed=2)
