@@ -101,7 +101,7 @@ extern "C" int egt_block_supported(const egt_block_desc* d) { return block_check
 static size_t al(size_t x) { return (x + 63) & ~(size_t)63; }  // in floats
 
 struct BlockLayout {
-  size_t v_att, stats, qkvp, pw_sv, saved_total;   // pw_sv: LN-folded edge weights, prepared by the forward, reused by the backward
+  size_t v_att, stats, qkvp, pw_sv, wfrag_sv, saved_total;   // pw_sv: LN-folded edge weights, wfrag_sv: fragment-major Wqkv / Wo -- prepared by the forward, reused by the backward
   // workspace = [common: dvp dqp[2] dkvp[2]] + per layer [pw epart spart sbo wpart ered dqkv dhbuf]
   // (dqp / dkvp alternate by layer parity: the prologue of layer l-1 reads layer l's partials while
   //  other workgroups of that launch already write their own)
@@ -149,6 +149,7 @@ static BlockLayout layout(const egt_block_desc* d) {
   L.stats = o; o += al(rows * BH * 4);
   L.qkvp = o; o += al(rows * QKVP);
   L.pw_sv = o; o += al((size_t)DEP * 16 + 16);
+  L.wfrag_sv = o; o += al(Dh <= 64 ? WFRAG_FLOATS : 0);
   L.saved_total = o;
   {   // k_block_bwd_v7: fp32 edge tensors of 64 channels, no attention-mask tensor, N = 32 or 64 (a multiple of 32 whose key tiles divide
       // the twelve waves; the graph's V rows live in LDS), and a launch of at least one 32-row workgroup per CU.  It works on pairs of the
@@ -264,6 +265,7 @@ static void bind_common(const egt_block_desc* d, BlockArgs& a, const void* h, co
   a.v_att = saved + L.v_att; a.stats = saved + L.stats; a.qkvp = saved + L.qkvp;
   bind_ws(L, a, ws, ws + L.common_total);
   a.pw = saved + L.pw_sv;
+  a.wfrag = a.Dh <= 64 ? saved + L.wfrag_sv : nullptr;
   a.prep = 1;
 }
 
@@ -381,7 +383,7 @@ static int launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool t
     a.pro = top ? 1 : 2;
     a.sbo_n = L.nwg_bwd;
     if (!top) {
-      a.up_h = above->h; a.up_nm_g = above->nm_g; a.up_Wqkv = above->Wqkv; a.up_dh_out = above->dh_out;
+      a.up_h = above->h; a.up_nm_g = above->nm_g; a.up_Wqkv = above->Wqkv; a.up_wfrag = above->wfrag; a.up_dh_out = above->dh_out;
       a.up_dqp = above->dqp; a.up_dkvp = above->dkvp; a.up_dqkv_sv = above->dqkv_sv; a.up_spart = above->spart;
       above->spart_n = L.nwg_bwd;
     }
@@ -575,6 +577,7 @@ static void bind_layer(const egt_block_desc* d, const StackLayout& S, const Bloc
   // deferred reductions / weight gradients need every layer's partials and dQKV rows at the end
   bind_ws(L, a, ws, ws + L.common_total + L.layer_total * (size_t)l, l & 1);
   a.pw = bs + L.pw_sv;
+  a.wfrag = a.Dh <= 64 ? bs + L.wfrag_sv : nullptr;
   (void)d;
 }
 
@@ -619,7 +622,7 @@ extern "C" int egt_stack_fwd(const egt_block_desc* desc, int32_t layers, const e
     if (l + 1 < layers) {
       const BlockArgs& nx = as[l + 1];
       a.epi = 2;
-      a.nx_nm_g = nx.nm_g; a.nx_nm_b = nx.nm_b; a.nx_Wqkv = nx.Wqkv; a.nx_bqkv = nx.bqkv;
+      a.nx_nm_g = nx.nm_g; a.nx_nm_b = nx.nm_b; a.nx_Wqkv = nx.Wqkv; a.nx_wfrag = nx.wfrag; a.nx_bqkv = nx.bqkv;
       a.nx_qkvp = nx.qkvp;
     }
     DISPATCH_BDE(desc->De, prev_epi = launch_fwd<DE>(a, (hipStream_t)stream, prev_epi == 2));

@@ -154,15 +154,24 @@ __device__ __forceinline__ void fwd_node_epilogue_t(const BlockArgs& a, float* s
     float wo[16], wq[3][16];
     const int c = wave * 16 + p;
     const bool cok = D64 || c < Dh;
+    {   // B operands from the fragment-major weight copies (egt_block.h: WFRAG_FWO / WFRAG_FWQ; zero where the padded row has no
+        // channel): lane-linear 16-byte loads, 16 per lane instead of 64 dword loads at a row stride
+      const int ln = 16 * q + p;
+      const float4* fwo = reinterpret_cast<const float4*>(a.wfrag + WFRAG_FWO) + wave * 256 + ln;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) wo[s] = (D64 || (cok && 4 * s + q < Dh)) ? a.Wo[(4 * s + q) * Dh + c] : 0.f;
-    if (a.epi == 2) {
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const float4 v = fwo[s4 * 64];
+        wo[4 * s4] = v.x; wo[4 * s4 + 1] = v.y; wo[4 * s4 + 2] = v.z; wo[4 * s4 + 3] = v.w;
+      }
+      if (a.epi == 2) {
+        const float4* fwq = reinterpret_cast<const float4*>(a.nx_wfrag + WFRAG_FWQ) + wave * 768 + ln;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int cq = (wave + 4 * j) * 16 + p, gc = (cq >> 6) * Dh + (cq & 63);   // padded column -> column of Wqkv [Dh][3 Dh]
-        const bool qok = D64 || (cq & 63) < Dh;
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) wq[j][s] = (D64 || (qok && 4 * s + q < Dh)) ? a.nx_Wqkv[(4 * s + q) * D3 + gc] : 0.f;
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const float4 v = fwq[(j * 4 + s4) * 64];
+            wq[j][4 * s4] = v.x; wq[j][4 * s4 + 1] = v.y; wq[j][4 * s4 + 2] = v.z; wq[j][4 * s4 + 3] = v.w;
+          }
       }
     }
     const float bo = cok ? a.bo[c] : 0.f;
@@ -306,10 +315,9 @@ template <int DE, bool D64>
 __device__ __forceinline__ void bwd_prologue_load_wo_va(const BlockArgs& a, int b, int l_begin, BwdProRegs& R, int ptid, int pnv) {
   BWD_PRO_COMMON();
   const bool iok = D64 || 16 * wave + p < Dh;   // the lane's dV_att channel exists
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int s = 0; s < 4; ++s)
-    R.wo[s] = (D64 || (iok && 16 * q + 4 * s < Dh)) ? *reinterpret_cast<const float4*>(a.Wo + (size_t)(16 * wave + p) * Dh + 16 * q + 4 * s) : z4;
+    R.wo[s] = reinterpret_cast<const float4*>(a.wfrag + WFRAG_BWO)[(wave * 4 + s) * 64 + lane];   // fragment-major Wo (zero-padded)
 #pragma unroll
   for (int r = 0; r < 4; ++r) R.va[r] = iok ? a.v_att[rc(4 * q + r) * Dh + 16 * wave + p] : 0.f;
 }
@@ -367,12 +375,10 @@ __device__ __forceinline__ void bwd_prologue_load_main(const BlockArgs& a, int b
     }
     // B operand of d h_ln = dQKV.Wqkv^T: Wqkv[kk = 16 wave + p][48 q .. 48 q + 47] (contraction order c = 48 q + s, c a column of
     // the padded [3][64] row: section c >> 6, channel c & 63)
-    const bool kok = D64 || 16 * wave + p < Dh;
+    // -- read from the fragment-major copy (WFRAG_BWQ, zero-padded): one lane-linear 16-byte load per step
 #pragma unroll
-    for (int s = 0; s < 12; ++s) {
-      const int c = 48 * q + 4 * s;
-      R.wq[s] = (D64 || (kok && (c & 63) < Dh)) ? *reinterpret_cast<const float4*>(a.up_Wqkv + (size_t)(16 * wave + p) * (3 * Dh) + (c >> 6) * Dh + (c & 63)) : z4;
-    }
+    for (int s = 0; s < 12; ++s)
+      R.wq[s] = reinterpret_cast<const float4*>(a.up_wfrag + WFRAG_BWQ)[(wave * 12 + s) * 64 + lane];
 }
 
 template <int DE, bool D64>

@@ -43,9 +43,59 @@ __device__ __forceinline__ v4f mm_xwt(const float* xs, int ld, const float* W, i
 
 // ---- edge-weight preparation (runs as one extra workgroup of the first node kernel) ----
 // Wp[c][i] = gamma_c * Wsel[c][head(i)], c2[i] = sum_c beta_c * Wsel[c][head(i)] + bias
-struct PrepLayer { const float *ne_g, *ne_b, *Wg, *bg, *We, *be; float* pw; };
+struct PrepLayer { const float *ne_g, *ne_b, *Wg, *bg, *We, *be; float* pw; const float *Wqkv, *Wo; float* wfrag; };
 
-__device__ void prep_layer(const PrepLayer& a, int De, bool gated, float* red) {
+// one 16-byte piece of the fragment-major weight copies (egt_block.h: WFRAG_*); o = index of the piece
+__device__ __forceinline__ float4 wfrag_piece(const PrepLayer& a, int o, int Dh) {
+  const int D3 = 3 * Dh;
+  float v[4];
+  if (o < 3072) {                       // BWQ
+    const int lane = o & 63, s = (o >> 6) % 12, w = o / 768, p = lane & 15, q = lane >> 4, kk = 16 * w + p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = 48 * q + 4 * s + i, cc = c & 63;
+      v[i] = (kk < Dh && cc < Dh) ? a.Wqkv[(size_t)kk * D3 + (c >> 6) * Dh + cc] : 0.f;
+    }
+  } else if (o < 4096) {                // BWO
+    const int x = o - 3072, lane = x & 63, s = (x >> 6) & 3, w = x >> 8, p = lane & 15, q = lane >> 4, row = 16 * w + p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = 16 * q + 4 * s + i;
+      v[i] = (row < Dh && col < Dh) ? a.Wo[(size_t)row * Dh + col] : 0.f;
+    }
+  } else if (o < 5120) {                // FWO
+    const int x = o - 4096, lane = x & 63, s4 = (x >> 6) & 3, w = x >> 8, p = lane & 15, q = lane >> 4, c = 16 * w + p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = 4 * (4 * s4 + i) + q;
+      v[i] = (c < Dh && k < Dh) ? a.Wo[(size_t)k * Dh + c] : 0.f;
+    }
+  } else {                              // FWQ
+    const int x = o - 5120, lane = x & 63, s4 = (x >> 6) & 3, j = (x >> 8) % 3, w = x / 768, p = lane & 15, q = lane >> 4;
+    const int cq = (w + 4 * j) * 16 + p, gc = (cq >> 6) * Dh + (cq & 63);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = 4 * (4 * s4 + i) + q;
+      v[i] = ((cq & 63) < Dh && k < Dh) ? a.Wqkv[(size_t)k * D3 + gc] : 0.f;
+    }
+  }
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ void prep_wfrag(const PrepLayer& a, int Dh) {
+  if (!a.wfrag || Dh > 64) return;
+  const int NT = blockDim.x;
+  for (int o0 = threadIdx.x; o0 < WFRAG_FLOATS / 4; o0 += 4 * NT) {   // four pieces (16 scalar loads) in flight per thread
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = wfrag_piece(a, min(o0 + u * NT, WFRAG_FLOATS / 4 - 1), Dh);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (o0 + u * NT < WFRAG_FLOATS / 4) reinterpret_cast<float4*>(a.wfrag)[o0 + u * NT] = v[u];
+  }
+}
+
+__device__ void prep_layer(const PrepLayer& a, int De, int Dh, bool gated, float* red) {
+  prep_wfrag(a, Dh);
   const int DEP = ((De + 15) / 16) * 16, t = threadIdx.x;
   for (int idx = t; idx < DEP * 16; idx += blockDim.x) {
     const int c = idx >> 4, i = idx & 15;
@@ -80,16 +130,16 @@ __device__ void prep_layer(const PrepLayer& a, int De, bool gated, float* red) {
   }
 }
 __device__ void prep_device(const BlockArgs& a, float* red) {
-  const PrepLayer L{a.ne_g, a.ne_b, a.Wg, a.bg, a.We, a.be, a.pw};
-  prep_layer(L, a.De, (a.flags & EGT_BF_GATE) != 0, red);
+  const PrepLayer L{a.ne_g, a.ne_b, a.Wg, a.bg, a.We, a.be, a.pw, a.Wqkv, a.Wo, a.wfrag};
+  prep_layer(L, a.De, a.Dh, (a.flags & EGT_BF_GATE) != 0, red);
 }
 
 // the same preparation for every layer of a stack in one launch (one workgroup per layer)
-#define PREP_MAX_LAYERS 64
-struct PrepArgs { PrepLayer L[PREP_MAX_LAYERS]; int De; uint32_t flags; };
+#define PREP_MAX_LAYERS 48   // (80 bytes per layer: the 4 KiB kernel-argument block)
+struct PrepArgs { PrepLayer L[PREP_MAX_LAYERS]; int De, Dh; uint32_t flags; };
 __global__ void __launch_bounds__(256) k_edge_prep(PrepArgs pa) {
   __shared__ float red[256];
-  prep_layer(pa.L[blockIdx.x], pa.De, (pa.flags & EGT_BF_GATE) != 0, red);
+  prep_layer(pa.L[blockIdx.x], pa.De, pa.Dh, (pa.flags & EGT_BF_GATE) != 0, red);
 }
 
 // stage a dense [rows][width] weight matrix into LDS (row stride ldw): 16-byte loads, four in
@@ -286,7 +336,7 @@ __global__ void __launch_bounds__(512) k_node_pre_stack(BlockArgs a, PrepArgsN<N
   static_assert(sizeof(BlockArgs) + sizeof(PrepArgsN<NL>) <= 4096, "kernel-argument block");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int NCH = (a.N + NODE_RC - 1) / NODE_RC, extra = (int)blockIdx.x - a.B * NCH;
-  if (extra >= 0) { prep_layer(pa.L[extra], a.De, (a.flags & EGT_BF_GATE) != 0, sm); return; }
+  if (extra >= 0) { prep_layer(pa.L[extra], a.De, a.Dh, (a.flags & EGT_BF_GATE) != 0, sm); return; }
   node_pre_rows(a, sm, NCH);
 }
 
@@ -882,18 +932,18 @@ static void launch_pre_stack(BlockArgs* as, int n, size_t lds, hipStream_t st) {
   pa.n = n;
   for (int l = 0; l < n; ++l) {
     const BlockArgs& a = as[l];
-    pa.L[l] = PrepLayer{a.ne_g, a.ne_b, a.Wg, a.bg, a.We, a.be, a.pw};
+    pa.L[l] = PrepLayer{a.ne_g, a.ne_b, a.Wg, a.bg, a.We, a.be, a.pw, a.Wqkv, a.Wo, a.wfrag};
   }
   EGT_MAX_LDS_ONCE(k_node_pre_stack<NL>);
   EGT_LAUNCH("k_node_pre", k_node_pre_stack<NL>, dim3(as[0].B * node_chunks(as[0]) + n), dim3(512), lds, st, as[0], pa);
 }
 bool egt_node_launch_pre_stack(BlockArgs* as, int n, hipStream_t st) {
-  if (n > 56) return false;
+  if (n > 40) return false;
   const BlockArgs& a = as[0];
   size_t lds = lds_rows(a.Dh, 1) + (size_t)a.Dh * (3 * a.Dh + LDP) * 4;
   if (lds < 1024) lds = 1024;  // prep workgroup scratch
   if (n <= 16) launch_pre_stack<16>(as, n, lds, st);
-  else launch_pre_stack<56>(as, n, lds, st);
+  else launch_pre_stack<40>(as, n, lds, st);
   return true;
 }
 
@@ -960,13 +1010,16 @@ void egt_node_launch_wgrads(BlockArgs* as, int n, hipStream_t st) {
 }
 
 void egt_node_launch_prep(BlockArgs* as, int n, hipStream_t st) {
-  PrepArgs pa{};
-  pa.De = as[0].De; pa.flags = as[0].flags;
-  for (int l = 0; l < n; ++l) {
-    const BlockArgs& a = as[l];
-    pa.L[l] = PrepLayer{a.ne_g, a.ne_b, a.Wg, a.bg, a.We, a.be, a.pw};
+  for (int l0 = 0; l0 < n; l0 += PREP_MAX_LAYERS) {
+    const int nl = n - l0 < PREP_MAX_LAYERS ? n - l0 : PREP_MAX_LAYERS;
+    PrepArgs pa{};
+    pa.De = as[0].De; pa.Dh = as[0].Dh; pa.flags = as[0].flags;
+    for (int l = 0; l < nl; ++l) {
+      const BlockArgs& a = as[l0 + l];
+      pa.L[l] = PrepLayer{a.ne_g, a.ne_b, a.Wg, a.bg, a.We, a.be, a.pw, a.Wqkv, a.Wo, a.wfrag};
+    }
+    EGT_LAUNCH("k_edge_prep", k_edge_prep, dim3(nl), dim3(256), 0, st, pa);
   }
-  EGT_LAUNCH("k_edge_prep", k_edge_prep, dim3(n), dim3(256), 0, st, pa);
 }
 
 // Reduce the per-workgroup partials of `n` layers (one BlockArgs each, with their own
