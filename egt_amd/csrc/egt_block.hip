@@ -279,10 +279,10 @@ static void bind_common(const egt_block_desc* d, BlockArgs& a, const void* h, co
   }
 
 // The node side inside the pair kernels (fwd_node_epilogue / bwd_node_prologue): H = 8 heads of DK <= 8 channels, i.e. node width
-// Dh = 8 DK <= 64 as a zero-padded 64-wide row; the prologue reads Wo / Wqkv rows as 16-byte pieces.
+// Dh = 8 DK <= 64 as a zero-padded 64-wide row.  (Wo / Wqkv reach those kernels through the fragment-major copies the preparation
+// writes with scalar loads -- WFRAG_*, egt_block.h -- so parameter views that are not 16-byte aligned are covered as well.)
 static bool node_fused_ok(const BlockArgs& a) {
-  return a.Dh == BH * a.DK && a.DK >= 1 && a.DK <= 8 &&
-         ((reinterpret_cast<uintptr_t>(a.Wo) | reinterpret_cast<uintptr_t>(a.Wqkv)) & 15) == 0;
+  return a.Dh == BH * a.DK && a.DK >= 1 && a.DK <= 8 && a.wfrag != nullptr;
 }
 
 // Forward of one block.  `skip_pre`: qkvp (and pw) of this block were already produced (by the
