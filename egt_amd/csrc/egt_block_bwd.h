@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   // The wave's first key tile: its first e tile (LDS-DMA into the parity-0 buffer), the K / V fragments of its keys and the key-mask
   // byte are requested FIRST -- ahead of the start-up staging and the node-side prologue, which need ~9 us and touch neither the
   // parity-0 buffers nor these registers -- so the row loop starts on data that has landed (the first row of a workgroup cost
-  // 8.1 us against 4.35 us for every later one: tools/r05_preloop.sh).
+  // 8.1 us against 4.35 us for every later one: DESIGN_LOG.md, round 5, ablation builds).
   const int ntile = RAG ? (N + 15) / 16 : N / 16;
   float Kf[16], Vf[16];
   int kmv = 1;
