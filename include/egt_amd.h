@@ -272,7 +272,9 @@ int egt_block_supported(const egt_block_desc* desc);
  * Static string; for tests and bench lines (the launch profiler reports every family as "k_block_bwd"). */
 const char* egt_block_bwd_kernel(const egt_block_desc* desc);
 /* bytes of the forward->backward buffer (V_att, softmax row statistics, packed
- * Q/K/V, the LN-folded edge weights) and of the scratch workspace (max of forward and backward needs). */
+ * Q/K/V, the LN-folded edge weights and the MFMA-fragment-major copies of Wqkv / Wo the forward prepares: the backward
+ * must be given the `saved` buffer of ITS forward call, made with the same parameter values) and of the scratch
+ * workspace (max of forward and backward needs). */
 size_t egt_block_saved_bytes(const egt_block_desc* desc);
 size_t egt_block_workspace_bytes(const egt_block_desc* desc);
 
