@@ -684,6 +684,17 @@ def main():
         world = dist.get_world_size()    # what RCCL really connected -- this is what the line reports
         if world != args.gpus:
             raise SystemExit(f"bench.py: RCCL world size {world} != --gpus {args.gpus}")
+        # fail FAST, with RCCL's own error text, if the communicator does not really span N ranks: one tiny all-reduce of ones
+        # (this is also where RCCL builds its rings; without it the first failure would surface inside the timed region)
+        try:
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            nranks = int(round(float(probe.item())))
+        except Exception as ex:   # torch wraps ncclGetErrorString / ncclGetLastError in the exception text
+            raise SystemExit(f"bench.py: RCCL all-reduce probe failed on rank {rank} of {env_world}: {ex}")
+        if nranks != args.gpus:
+            raise SystemExit(f"bench.py: the RCCL communicator reduced over {nranks} ranks, --gpus says {args.gpus}")
 
     from egt_amd import build as _build
     if local_rank == 0:
@@ -699,6 +710,11 @@ def main():
         comm = CapiComm()                # ncclCommInitRank behind the C-ABI; the id travels over the process group once
         if comm.world != world:
             raise SystemExit(f"bench.py: egt_dp world {comm.world} != {world}")
+        probe = torch.ones(1, device=dev)
+        comm.all_reduce_flat(probe, average=False)   # raises RuntimeError carrying ncclGetErrorString (egt_last_error) on failure
+        torch.cuda.synchronize()
+        if int(round(float(probe.item()))) != args.gpus:
+            raise SystemExit(f"bench.py: the egt_dp communicator reduced over {probe.item():.0f} ranks, --gpus says {args.gpus}")
 
     w = dict(WORKLOADS[args.workload])
     if w.get("scope") in ("core", "block"):

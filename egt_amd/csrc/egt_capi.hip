@@ -59,16 +59,17 @@ bool stream_capturing(hipStream_t s, unsigned long long* id = nullptr) {
 // An event-record NODE at the capturing stream's current position.  (hipEventRecordWithFlags(.., hipEventRecordExternal) is the
 // one-call form of this, but the HIP runtime torch 2.10 ships answers it with hipErrorInvalidValue under capture -- probed on the
 // box, tools/micro/graph_event_probe.py; the explicit form below works there: every replay re-records the event.)
-void record_node_in_capture(hipStream_t s, hipEvent_t ev) {
+bool record_node_in_capture(hipStream_t s, hipEvent_t ev) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   unsigned long long id = 0;
   hipGraph_t graph = nullptr;
   const hipGraphNode_t* deps = nullptr;
   size_t ndeps = 0;
-  if (hipStreamGetCaptureInfo_v2(s, &st, &id, &graph, &deps, &ndeps) != hipSuccess || st != hipStreamCaptureStatusActive) return;
+  if (hipStreamGetCaptureInfo_v2(s, &st, &id, &graph, &deps, &ndeps) != hipSuccess || st != hipStreamCaptureStatusActive) { (void)hipGetLastError(); return false; }
   hipGraphNode_t node = nullptr;
-  if (hipGraphAddEventRecordNode(&node, graph, deps, ndeps, ev) != hipSuccess) { (void)hipGetLastError(); return; }
-  if (hipStreamUpdateCaptureDependencies(s, &node, 1, hipStreamSetCaptureDependencies) != hipSuccess) (void)hipGetLastError();
+  if (hipGraphAddEventRecordNode(&node, graph, deps, ndeps, ev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipStreamUpdateCaptureDependencies(s, &node, 1, hipStreamSetCaptureDependencies) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return true;
 }
 
 hipEvent_t get_event() {
@@ -117,7 +118,10 @@ void egt_prof_begin(const char* name, hipStream_t s, void** tok) {
   } else if (g_stride > 1 && (e.seen++ % g_stride) != 0) return;
   if (cap) {   // the launch is being captured into a hipGraph: the events become event-record nodes of that graph
     hipEvent_t a = get_event(), b = get_event();   // (from the pool egt_prof_enable filled before the capture began)
-    record_node_in_capture(s, a);
+    if (!record_node_in_capture(s, a)) {   // no node, no pair: a pair that is never recorded would fail every later read
+      g_pool.push_back(a); g_pool.push_back(b);
+      return;
+    }
     e.graph_pairs.emplace_back(a, b);
     *tok = (void*)b;
     return;
@@ -130,7 +134,7 @@ void egt_prof_begin(const char* name, hipStream_t s, void** tok) {
 
 void egt_prof_end(void* tok, hipStream_t s) {
   if (!tok) return;
-  if (stream_capturing(s)) record_node_in_capture(s, (hipEvent_t)tok);
+  if (stream_capturing(s)) (void)record_node_in_capture(s, (hipEvent_t)tok);
   else (void)hipEventRecord((hipEvent_t)tok, s);
 }
 
@@ -180,6 +184,7 @@ extern "C" int egt_prof_read(const char* name, int64_t* count, double* total_ms)
   for (auto& p : e.pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { e.ms += ms; e.count += 1; }
+    else (void)hipGetLastError();   // a failed read must not leave the thread's sticky error for the next launch check
     g_pool.push_back(p.first);
     g_pool.push_back(p.second);
   }
@@ -203,6 +208,8 @@ extern "C" int egt_prof_collect_graph(int reset_counts) {
       float ms = 0.f;
       if (hipEventQuery(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess && ms > 0.f) {
         e.ms += ms; e.count += 1; ++n;
+      } else {
+        (void)hipGetLastError();   // never-recorded pair (collect before the first replay): legitimate, and not the next launch's error
       }
     }
   }

@@ -11,15 +11,20 @@
 
 #include <mutex>
 
+#include <rccl/rccl.h>   // types and enum values only: every entry point is resolved with dlsym (no link-time dependency)
+
 #include "egt_common.h"
 
 namespace {
-// the slice of the RCCL ABI this file uses (rccl.h: ncclResult_t / ncclDataType_t / ncclRedOp_t are C enums)
-typedef struct ncclComm* ncclComm_t;
-typedef struct { char internal[EGT_DP_ID_BYTES]; } ncclUniqueId;
-enum { kNcclSuccess = 0 };
-enum { kNcclFloat32 = 7 };
-enum { kNcclSum = 0, kNcclAvg = 4 };
+// the slice of the RCCL ABI this file uses, taken from the installed header and pinned at build time: the C-ABI's
+// EGT_DP_ID_BYTES (include/egt_amd.h) is what callers allocate for the id, and the enum values travel as plain ints
+// through the dlsym'd function pointers below
+static_assert(sizeof(ncclUniqueId) == EGT_DP_ID_BYTES, "include/egt_amd.h: EGT_DP_ID_BYTES != sizeof(ncclUniqueId) of <rccl/rccl.h>");
+static_assert(NCCL_UNIQUE_ID_BYTES == EGT_DP_ID_BYTES, "NCCL_UNIQUE_ID_BYTES changed");
+enum { kNcclSuccess = ncclSuccess, kNcclFloat32 = ncclFloat32, kNcclSum = ncclSum, kNcclAvg = ncclAvg };
+static_assert(kNcclSuccess == 0 && kNcclFloat32 == 7 && kNcclSum == 0 && kNcclAvg == 4, "RCCL enum values moved (documented in INTEGRATION.md)");
+static_assert(sizeof(ncclResult_t) == sizeof(int) && sizeof(ncclDataType_t) == sizeof(int) && sizeof(ncclRedOp_t) == sizeof(int),
+              "the function-pointer signatures below pass RCCL's enums as int");
 
 struct Rccl {
   void* so = nullptr;

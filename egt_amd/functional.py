@@ -9,6 +9,8 @@ import ctypes as C
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -104,7 +106,10 @@ class _EGTAttention(torch.autograd.Function):
             # large-head geometry: QK^T / A.V on MFMA tiles (egt_attn_mfma.hip)
             # one workspace for both directions when a backward will follow: q/k/v are packed once (EGT_ATTN_WS_SHARED)
             # (grad mode is always off inside autograd.Function.forward: the backward is announced by ctx.needs_input_grad)
-            shared = any(ctx.needs_input_grad[:3])
+            # Memory: the shared workspace (five packed q/k/v arrays + the dO slot + the dA tiles, ~ the size of h_hat at
+            # N = 512, d = 64) then lives from forward to backward of EVERY MFMA attention node of a deep model;
+            # EGT_ATTN_WS_SHARED=0 opts out (the backward re-packs: one more k_attn_pack section per layer, nothing kept).
+            shared = any(ctx.needs_input_grad[:3]) and os.environ.get("EGT_ATTN_WS_SHARED", "1") != "0"
             if shared:
                 desc.reserved = L.ATTN_WS_SHARED
                 ws = torch.empty(lib.egt_attn_mfma_workspace_bytes(C.byref(desc)), device=qkv.device, dtype=torch.uint8)
@@ -122,8 +127,8 @@ class _EGTAttention(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.desc = desc
         ctx.has = (E is not None, G is not None, M is not None)
-        ctx.mfma_ws = mfma_ws
-        ctx.save_for_backward(qkv, E, G, M, key_mask, rand_mask, drop_keep, v_att, rowstats)
+        # the workspace travels with the saved tensors: freed with them when the graph is (retain_graph=False), not with ctx
+        ctx.save_for_backward(qkv, E, G, M, key_mask, rand_mask, drop_keep, v_att, rowstats, mfma_ws)
         ctx.set_materialize_grads(False)
         if a_tild is None:
             a_tild = torch.empty(0, device=qkv.device)
@@ -133,7 +138,7 @@ class _EGTAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_v_att, d_h_hat, _d_a_tild):
         lib = L.load()
-        qkv, E, G, M, key_mask, rand_mask, drop_keep, v_att, rowstats = ctx.saved_tensors
+        qkv, E, G, M, key_mask, rand_mask, drop_keep, v_att, rowstats, mfma_ws = ctx.saved_tensors
         desc = ctx.desc
         if d_v_att is None:
             d_v_att = torch.zeros_like(v_att)
@@ -143,9 +148,8 @@ class _EGTAttention(torch.autograd.Function):
         d_E = torch.empty_like(E) if E is not None else None
         d_G = torch.empty_like(G) if G is not None else None
         mfma = bool(ctx.cfg.use_mfma and drop_keep is None and lib.egt_attn_mfma_supported(C.byref(desc), 0))
-        if mfma and ctx.mfma_ws is not None:
-            ws = ctx.mfma_ws                      # the forward's workspace: q/k/v operand copies already in place
-            ctx.mfma_ws = None
+        if mfma and mfma_ws is not None:
+            ws = mfma_ws                          # the forward's workspace: q/k/v operand copies already in place
         else:
             desc.reserved = 0
             nbytes = (lib.egt_attn_mfma_workspace_bytes if mfma else lib.egt_attn_bwd_workspace_bytes)(C.byref(desc))

@@ -776,9 +776,11 @@ class PatternSVDScheme(ZincSVDScheme):
         # Keras feeds the mask as sample_weight: the metrics are means over the REAL nodes (losses.py:108-118)
         logp = torch.log_softmax(logits.detach(), -1).gather(-1, tgt.clamp(min=0).long()[..., None])[..., 0]
         xs = (-(logp) * w[tgt.clamp(min=0).long()] * m).sum()
-        # `loss` is a mean over the batch's padded (graph, node) slots (Keras SUM_OVER_BATCH_SIZE): its epoch figure is the slot-weighted mean
-        slots = torch.full((), float(m.numel()), device=m.device, dtype=m.dtype)   # (a fill kernel: capturable, unlike a host -> device copy)
-        return loss, dict(xent=(xs, m.sum()), acc=(hit, m.sum()), loss=(loss.detach() * slots, slots))
+        # `loss` of a batch is a mean over its padded (graph, node) slots (Keras SUM_OVER_BATCH_SIZE); the EPOCH figure Keras reports is
+        # its compiled-loss Mean metric, which LossesContainer updates with sample_weight = the batch dimension (number of graphs):
+        # N is padded per batch, so a slot-weighted epoch mean would differ from the reference's `loss` / `val_loss`
+        graphs = torch.full((), float(m.shape[0]), device=m.device, dtype=m.dtype)   # (a fill kernel: capturable, unlike a host -> device copy)
+        return loss, dict(xent=(xs, m.sum()), acc=(hit, m.sum()), loss=(loss.detach() * graphs, graphs))
 
 
     @torch.no_grad()

@@ -147,10 +147,11 @@ def test_fused_stack_matches_composed(gpu, egt_lib):
     assert_close(e1, e2, name="e", rtol=1e-4, arel=5e-5)
 
 
-@pytest.mark.parametrize("Ly", [17, 58])
+@pytest.mark.parametrize("Ly", [17, 40, 58])
 def test_deep_stack_one_call_equals_block_calls(Ly, gpu, egt_lib):
-    """the first launch of a stack's forward carries the edge-weight preparation of EVERY layer (k_node_pre_stack: up to 16 / up to 56
-    layers per kernel-argument block; deeper stacks fall back to the separate k_edge_prep launch): forward outputs and every gradient
+    """the first launch of a stack's forward carries the edge-weight preparation of EVERY layer (k_node_pre_stack: instantiated for up
+    to 16 / up to 40 layers per kernel-argument block -- Ly = 17 and Ly = 40 run the 40-layer instance, the second at its limit;
+    deeper stacks, Ly = 58, fall back to the separate k_edge_prep launch): forward outputs and every gradient
     of the one-call stack equal the block-by-block fused calls bit for bit (same kernels, same order of operations)"""
     from egt_amd import EGTStack
     torch.manual_seed(Ly)

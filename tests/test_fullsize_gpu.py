@@ -1,8 +1,14 @@
-"""GPU tests at BASELINE.json's full sizes, through size-independent properties (the fp64
-oracle is too slow there): fused == composed, linearity of the backward in the upstream
-gradients, bit-reproducibility, padded-key invariance, exact-zero masking; plus the other
-BASELINE shapes (PATTERN N=120/De=8 ragged tiles, CIFAR10 N=150, synthetic N=512 d=64)
-against the oracle at batch sizes it finishes in seconds."""
+"""GPU tests at BASELINE.json's full sizes: the launch bench.py times (B = 128, N = 64, Dh = De = 64: 512 workgroups,
+XCD remap, `bwd_rows_per_wg` at B = 128, in-kernel RNG, the Ly = 10 one-call stack) against the fp64 oracle -- one block
+on all 128 graphs (every output, every input and parameter gradient), the training-mode stack on sampled graphs (graphs
+are independent: the oracle runs on those alone, with the `rng_ref` replica of the in-kernel masks) -- plus
+size-independent properties (fused == composed, linearity of the backward in the upstream gradients,
+bit-reproducibility, padded-key invariance, exact-zero masking) and the other BASELINE shapes (PATTERN N=120/De=8
+ragged tiles, CIFAR10 N=150, synthetic N=512 d=64) against the oracle."""
+import os
+import subprocess
+import sys
+
 import pytest
 import torch
 
@@ -31,6 +37,107 @@ def _run(blk, h, e, mask, dh, de):
     torch.autograd.backward([h2, e2], [dh, de])
     grads = {n: p.grad.clone() for n, p in blk.named_parameters()}
     return h2.detach(), e2.detach(), h.grad, e.grad, grads
+
+
+# graphs whose workgroups cover every XCD residue of the launch (workgroup = (graph, row group); 4 row groups per graph), first and last
+SAMPLED = [0, 9, 18, 27, 36, 45, 54, 63, 127]
+
+
+def _randomized_block(gpu, seed):
+    """fused EGTBlock with oracle-initialised, perturbed parameters (LN gamma / beta and biases away from 1 / 0)"""
+    from oracle import egt_oracle as O
+    from test_block_gpu import build_block
+    g = torch.Generator().manual_seed(seed)
+    params = O.init_block_params(64, 64, 8, generator=g, randomize_norm=True)
+    attrs = dict(gate_attention=True, edge_activation=None, edge_channel_type="residual")
+    return build_block(dict(Dh=64, De=64), attrs, params, gpu, True), params, attrs
+
+
+def test_zinc500k_full_block_vs_oracle_all_graphs(gpu, egt_lib):
+    """The fused block at the headline batch (the grid bench.py times: 512 workgroups per direction) against the fp64
+    oracle on ALL 128 graphs: h', e', dh, de and every parameter gradient (graph_xformer_model_base.py:192-223)."""
+    from egt_amd import _lib as L
+    from test_block_gpu import PMAP
+    blk, params, attrs = _randomized_block(gpu, 77)
+    blk.eval()
+    h, e, mask, dh, de = _zinc500k_inputs(gpu)
+    import ctypes as C
+    lib = L.load()
+    lib.egt_prof_filter(b""); lib.egt_prof_enable(2)
+    try:
+        hg = h.clone().requires_grad_(); eg = e.clone().requires_grad_()
+        h2, e2 = blk(hg, eg, mask)
+        torch.autograd.backward([h2, e2], [dh, de])
+        torch.cuda.synchronize()
+    finally:
+        lib.egt_prof_enable(0)
+    buf = C.create_string_buffer(4096)
+    lib.egt_prof_names(buf, 4096)
+    names = buf.value.decode().split()
+    assert "k_block_fwd" in names and "k_block_bwd" in names, names   # the fused pair kernels ran, not the composition
+    inp = dict(h=h.cpu(), e=e.cpu(), mask=mask.cpu(), attn_mask=None, rand_mask=None, dh=dh.cpu(), de=de.cpu())
+    ref = CS.block_oracle(inp, params, dict(num_heads=8, **attrs))
+    assert_close(h2, ref["h_out"], name="h_out", **FWD)
+    assert_close(e2, ref["e_out"], name="e_out", **FWD)
+    assert_close(hg.grad, ref["dh"], name="dh", **BWD)
+    assert_close(eg.grad, ref["de"], name="de", **BWD)
+    for b in SAMPLED:   # per-graph too: a wrong workgroup -> graph mapping cannot hide in the batch norm
+        assert_close(e2[b], ref["e_out"][b], name=f"e_out[{b}]", **FWD)
+        assert_close(eg.grad[b], ref["de"][b], name=f"de[{b}]", **BWD)
+        assert_close(h2[b], ref["h_out"][b], name=f"h_out[{b}]", **FWD)
+        assert_close(hg.grad[b], ref["dh"][b], name=f"dh[{b}]", **BWD)
+    for k, (m, a) in PMAP.items():
+        assert_close(getattr(getattr(blk, m), a).grad, ref["dparams"][k], name=k, **BWD)
+
+
+def _stack_vs_oracle_on_sampled_graphs(gpu, graphs):
+    from egt_amd import EGTStack
+    from egt_amd.fused import layer_seed
+    from oracle import egt_oracle as O, rng_ref
+    from test_block_gpu import PMAP
+    B, N, Ly, p = 128, 64, 10, 0.1
+    torch.manual_seed(21)
+    st = EGTStack(model_height=Ly, model_width=64, edge_width=64, num_heads=8, random_mask_prob=p, seed=3, fused=True).to(gpu).train()
+    with torch.no_grad():
+        for prm in st.parameters():
+            if prm.dim() == 1:
+                prm.add_(0.2 * torch.randn_like(prm))
+    h, e, mask, dh, de = _zinc500k_inputs(gpu, seed=4321)
+    hg = h.clone().requires_grad_(); eg = e.clone().requires_grad_()
+    h2, e2 = st(hg, eg, mask)
+    assert st.last_path == "fused-stack"
+    torch.autograd.backward([h2, e2], [dh, de])
+    b0 = st.blocks[0].mha
+    seed = (b0.seed * 0x9E3779B97F4A7C15 + b0._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    layers = [{k: getattr(getattr(blk, m), a_).detach().double().cpu() for k, (m, a_) in PMAP.items()} for blk in st.blocks]
+    idx = torch.tensor(graphs)
+    rms = [torch.from_numpy(rng_ref.random_mask(layer_seed(seed, l), B, N, 8, p))[idx] for l in range(Ly)]
+    h64 = h.cpu()[idx].double().requires_grad_(); e64 = e.cpu()[idx].double().requires_grad_()
+    ho, eo = O.stack_forward(h64, e64, mask.cpu()[idx], layers, num_heads=8, rand_masks=rms)
+    gh, ge = torch.autograd.grad([ho, eo], [h64, e64], [dh.cpu()[idx].double(), de.cpu()[idx].double()])
+    gi = idx.to(gpu)
+    assert_close(h2[gi], ho, name="h_out", rtol=2e-4, arel=5e-5)
+    assert_close(e2[gi], eo, name="e_out", rtol=2e-4, arel=5e-5)
+    assert_close(hg.grad[gi], gh, name="dh", **BWD)
+    assert_close(eg.grad[gi], ge, name="de", **BWD)
+
+
+def test_zinc500k_full_stack_training_vs_oracle_on_sampled_graphs(gpu, egt_lib):
+    """The Ly = 10 one-call stack in training mode at the headline batch (what bench.py's default line runs: in-kernel random
+    masks, `wfrag` prepared by layer 0's extra workgroups): h', e', dh, de of sampled graphs against the fp64 oracle run
+    on those graphs alone with the rng_ref replica of the masks (graph b's mask bits depend on (seed, b, l, m, h) only)."""
+    _stack_vs_oracle_on_sampled_graphs(gpu, [0, 45, 127])
+
+
+def test_zinc500k_full_block_vs_oracle_with_poisoned_lds(gpu, egt_lib):
+    """the same comparisons in a process started with EGT_DEBUG_POISON_LDS=1 (every CU's LDS NaN-filled before each
+    launch: a read of an LDS word the kernel did not write shows up as a NaN in the outputs; the switch is read once)"""
+    env = dict(os.environ, EGT_DEBUG_POISON_LDS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q",
+                        "-k", "vs_oracle_all_graphs or vs_oracle_on_sampled_graphs"],
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "2 passed" in r.stdout, r.stdout[-1000:]
 
 
 def test_zinc500k_full_fused_equals_composed(gpu, egt_lib):

@@ -23,10 +23,11 @@ BWD = dict(rtol=1e-3, arel=1e-4, l2=1e-3, zero_atol=float(os.environ.get("EGT_TE
 # for ONE operator.  A stack of Ly blocks rounds e_l to bfloat16 at Ly storage points on the way up and de_l at Ly on the way
 # down (relative rounding 2^-9 each, independent): against the PLAIN fp64 oracle -- which has no storage rounding -- the error
 # of the end-to-end outputs grows like the square root of the number of storage points.  The contract for a stack of Ly
-# blocks is therefore the single-operator tolerance times max(1, sqrt(Ly / 2)): 2e-2 up to two blocks, 2.83e-2 at the four
-# blocks of config 3, 5.7e-2 at sixteen.
+# blocks is therefore the single-operator tolerance times max(1, sqrt(Ly / 2)) -- applied from the FOUR blocks of config 3 on
+# (2.83e-2; measured worst margin 0.72 of it): stacks of up to three blocks met the plain single-operator 2e-2 before this
+# contract existed and keep it.
 def bf16_stack_tol(layers: int, *, params: bool = False):
-    f = max(1.0, (layers / 2.0) ** 0.5)
+    f = max(1.0, (layers / 2.0) ** 0.5) if layers >= 4 else 1.0
     return dict(rtol=(3e-2 if params else 2e-2) * f, arel=(2e-2 if params else 1e-2) * f)
 
 
