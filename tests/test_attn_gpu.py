@@ -211,11 +211,12 @@ def test_attn_mfma_in_kernel_random_mask(N, d, gpu, egt_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,d", [(48, 64), (37, 16)])
-def test_attn_mfma_shared_workspace_fwd_to_bwd(N, d, gpu, egt_lib):
+def test_attn_mfma_shared_workspace_fwd_to_bwd(N, d, gpu, egt_lib, monkeypatch):
     """EGT_ATTN_WS_SHARED: the forward packs the q / k / v operand copies of BOTH directions into one workspace and the backward
-    adds only dO.  The autograd front-end takes that path whenever an input needs a gradient (ctx.needs_input_grad); a second
-    backward through the same node (retain_graph) finds the workspace spent and re-packs: both must give the same gradients, bit
-    for bit, and the C-ABI pair called by hand with the two workspace modes likewise."""
+    adds only dO.  The autograd front-end takes that path whenever an input needs a gradient (ctx.needs_input_grad); the
+    workspace travels with the node's SAVED tensors (freed with the graph, reused by a second backward under retain_graph);
+    with the opt-out EGT_ATTN_WS_SHARED=0 nothing is kept and the backward re-packs: all three must give the same gradients,
+    bit for bit, and the C-ABI pair called by hand with the two workspace modes likewise."""
     import ctypes as C
     from egt_amd import egt_attention, AttnConfig, _lib as L
     B, H = 2, 8
@@ -227,14 +228,22 @@ def test_attn_mfma_shared_workspace_fwd_to_bwd(N, d, gpu, egt_lib):
     cfg = AttnConfig(num_heads=H, need_a_tild=False, use_mfma=True)
     q = QKV.clone().requires_grad_(); e_ = E.clone().requires_grad_(); g_ = G.clone().requires_grad_()
     V, Hh, _ = egt_attention(q, e_, g_, None, mask.to(gpu), cfg=cfg)
-    assert V.grad_fn.mfma_ws is not None, "a forward that will be differentiated must take the shared workspace"
+    ws_saved = V.grad_fn.saved_tensors[-1]
+    assert ws_saved is not None and ws_saved.dtype == torch.uint8, "a forward that will be differentiated must take the shared workspace"
     torch.autograd.backward([V, Hh], [dV, dH], retain_graph=True)
     first = (q.grad.clone(), e_.grad.clone(), g_.grad.clone())
-    assert V.grad_fn.mfma_ws is None
     q.grad = e_.grad = g_.grad = None
-    torch.autograd.backward([V, Hh], [dV, dH])                       # second pass: the re-packing backward
+    torch.autograd.backward([V, Hh], [dV, dH])                       # second pass through the retained node: same workspace again
     for a, b, n in zip(first, (q.grad, e_.grad, g_.grad), ("dQKV", "dE", "dG")):
         assert torch.equal(a, b), n
+    monkeypatch.setenv("EGT_ATTN_WS_SHARED", "0")                    # the opt-out: nothing kept, the backward re-packs
+    q2 = QKV.clone().requires_grad_(); e2 = E.clone().requires_grad_(); g2 = G.clone().requires_grad_()
+    Vn, Hn, _ = egt_attention(q2, e2, g2, None, mask.to(gpu), cfg=cfg)
+    assert Vn.grad_fn.saved_tensors[-1] is None
+    torch.autograd.backward([Vn, Hn], [dV, dH])
+    for a, b, n in zip(first, (q2.grad, e2.grad, g2.grad), ("dQKV", "dE", "dG")):
+        assert torch.equal(a, b), n + " (re-packing backward)"
+    monkeypatch.delenv("EGT_ATTN_WS_SHARED")
     with torch.no_grad():                                            # no gradient wanted: the forward-only workspace
         V2, Hh2, _ = egt_attention(QKV, E, G, None, mask.to(gpu), cfg=cfg)
     assert torch.equal(V2, V) and torch.equal(Hh2, Hh)
