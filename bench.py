@@ -430,7 +430,12 @@ def run_core(args, w, dev, lib, rank, world, use_dist):
     pairs = B * N * N
     # ALGORITHMIC flops (core op 12 N^2 Dh per graph fwd+bwd): forward QK^T + A.V = 4, backward dP + dV + dK = 6
     # in k_attn_mfma_bwd_kv, dQ = 2 in k_attn_mfma_bwd_q; the backward's recompute of S (2 more) is executed, not counted
-    fl = {"k_attn_mfma_fwd": 4.0 * pairs * Dh, "k_attn_mfma_bwd_kv": 6.0 * pairs * Dh, "k_attn_mfma_bwd_q": 2.0 * pairs * Dh}
+    # algorithmic flops per launch.  The fused pair kernels carry the edge-channel contractions of SURVEY 8(d)'s block count as well:
+    # forward LN-folded projections 2 De 16 + dense_edge_r 2 H De per pair, backward twice that (input + weight gradients)
+    edge_f = 2.0 * De * 2 * H + 2.0 * H * De
+    fl = {"k_attn_mfma_fwd": 4.0 * pairs * Dh, "k_attn_mfma_bwd_kv": 6.0 * pairs * Dh, "k_attn_mfma_bwd_q": 2.0 * pairs * Dh,
+          "k_pair_fwd": pairs * (4.0 * Dh + edge_f), "k_pair_bwd": pairs * (6.0 * Dh + 2.0 * edge_f)}
+    hbm = {"k_pair_fwd": pairs * De * 4 * 2.0, "k_pair_bwd": pairs * (De * 4 * 3.0 + H * 4.0)}   # e in, e' out / e, de' in, de out + the dA tiles
     roof = None
     if prof:
         cnt, ms = dom_prof.get(dominant, prof[dominant])
@@ -507,10 +512,11 @@ def run_block(args, w, dev, lib, rank, world, use_dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    dominant = "k_attn_mfma_bwd_kv"
     for _ in range(max(args.warmup, 6)):                  # rocBLAS picks its kernels on the first calls
         step()
     fence()
+    fused_pair = getattr(blk, "last_path", "") == "fused-pair"   # d = 64 / De = 32: the fused pair operator (k_pair_fwd / k_pair_bwd)
+    dominant = "k_pair_bwd" if fused_pair else "k_attn_mfma_bwd_kv"
     if not args.no_prof:
         lib.egt_prof_filter(dominant.encode()); lib.egt_prof_enable(2)
     sev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step events: the median beside the wall-clock mean
@@ -546,7 +552,12 @@ def run_block(args, w, dev, lib, rank, world, use_dist):
     step_s = elapsed / args.steps
     flops_blk = 3.0 * (6.0 * pairs * De * H + 8.0 * B * N * Dh * Dh + 4.0 * pairs * Dh)
     bytes_blk = B * (5.0 * N * N * De * 4 + 6.0 * N * Dh * 4)
-    fl = {"k_attn_mfma_fwd": 4.0 * pairs * Dh, "k_attn_mfma_bwd_kv": 6.0 * pairs * Dh, "k_attn_mfma_bwd_q": 2.0 * pairs * Dh}
+    # algorithmic flops per launch.  The fused pair kernels carry the edge-channel contractions of SURVEY 8(d)'s block count as well:
+    # forward LN-folded projections 2 De 16 + dense_edge_r 2 H De per pair, backward twice that (input + weight gradients)
+    edge_f = 2.0 * De * 2 * H + 2.0 * H * De
+    fl = {"k_attn_mfma_fwd": 4.0 * pairs * Dh, "k_attn_mfma_bwd_kv": 6.0 * pairs * Dh, "k_attn_mfma_bwd_q": 2.0 * pairs * Dh,
+          "k_pair_fwd": pairs * (4.0 * Dh + edge_f), "k_pair_bwd": pairs * (6.0 * Dh + 2.0 * edge_f)}
+    hbm = {"k_pair_fwd": pairs * De * 4 * 2.0, "k_pair_bwd": pairs * (De * 4 * 3.0 + H * 4.0)}   # e in, e' out / e, de' in, de out + the dA tiles
     roof = None
     if prof and dominant in prof:
         cnt, ms = dom_prof.get(dominant, prof[dominant])
@@ -561,8 +572,13 @@ def run_block(args, w, dev, lib, rank, world, use_dist):
                     library_kernels_ms_per_step=hip_ms, other_ms_per_step=step_s * 1e3 - hip_ms,
                     note="other_ms_per_step = the rocBLAS node-side GEMMs, torch glue and launch gaps (not behind the C-ABI's launch profiler)",
                     kernels={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3, share_of_step=(v[1] / min(args.steps, 10)) / (step_s * 1e3),
-                                     tflops=(fl[k] / (v[1] / v[0] / 1e3) / 1e12) if k in fl else None)
+                                     tflops=(fl[k] / (v[1] / v[0] / 1e3) / 1e12) if k in fl else None,
+                                     hbm_frac=(hbm[k] / (v[1] / v[0] / 1e3) / 1e9 / HBM_PEAK_GBS) if k in hbm else None)
                              for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
+        if dominant in hbm:   # the fused pair kernels sit between both roofs: algorithmic HBM bytes of the dominant one beside its flops
+            roof["hbm_achieved_GBs"] = hbm[dominant] / avg_s / 1e9
+            roof["hbm_frac"] = hbm[dominant] / avg_s / 1e9 / HBM_PEAK_GBS
+            roof["algorithmic_bytes_per_launch"] = hbm[dominant]
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline(w, args.cpu_seconds, Bs=1)
@@ -574,7 +590,9 @@ def run_block(args, w, dev, lib, rank, world, use_dist):
                                "(graph_xformer_model_base.py:192-223 around egt_layers.py:57-143), training mode, in-kernel random mask",
                    "scope": "block", "graphs_per_gpu": B, "global_batch": graphs_step, "N": N, "Dh": Dh, "De": De, "H": H, "d": Dh // H,
                    "random_mask_prob": w["rand_p"], "nodes": list(w["nodes"]),
-                   "path": "composed: k_edge_proj (LN + gates / edge bias) -> MFMA inner op -> k_edge_update (dense_edge_r + residual), rocBLAS node-side Dense",
+                   "path": ("fused pair operator: k_pair_fwd / k_pair_bwd (LN + gates / edge bias -> MFMA inner op -> dense_edge_r + residual in one pair "
+                            "kernel per direction: E, G, H_hat, dE, dG, dH_ext stay in LDS) + k_attn_mfma_bwd_q, rocBLAS node-side Dense") if fused_pair else
+                           "composed: k_edge_proj (LN + gates / edge bias) -> MFMA inner op -> k_edge_update (dense_edge_r + residual), rocBLAS node-side Dense",
                    "parallelism": f"dp{world}", "backend": "rccl" if use_dist else "none (single process)",
                    "tflops_step": flops_blk * (graphs_step / B) / step_s / 1e12},
         "roofline": roof, "cpu_baseline": cpu,

@@ -152,6 +152,11 @@ _OPTIONAL_PROTOS = {
     "egt_stack_fwd": (C.c_int, [C.POINTER(BlockDesc), C.c_int32, C.POINTER(BlockParams)] + [_VP] * 9),
     "egt_stack_bwd": (C.c_int, [C.POINTER(BlockDesc), C.c_int32, C.POINTER(BlockParams)] + [_VP] * 9
                       + [C.POINTER(BlockParams)] + [_VP] * 2),
+    "egt_pair_supported": (C.c_int, [C.POINTER(BlockDesc)]),
+    "egt_pair_workspace_bytes": (C.c_size_t, [C.POINTER(BlockDesc)]),
+    "egt_pair_fwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams)] + [_VP] * 8),
+    "egt_pair_bwd": (C.c_int, [C.POINTER(BlockDesc), C.POINTER(BlockParams)] + [_VP] * 9
+                     + [C.POINTER(BlockParams)] + [_VP] * 2),
     "egt_ffn_supported": (C.c_int, [C.POINTER(FfnDesc)]),
     "egt_ffn_workspace_bytes": (C.c_size_t, [C.POINTER(FfnDesc)]),
     "egt_ffn_fwd": (C.c_int, [C.POINTER(FfnDesc), C.POINTER(FfnParams)] + [_VP] * 4),

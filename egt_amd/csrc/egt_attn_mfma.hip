@@ -1053,6 +1053,8 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_q(AttnMfmaArgs a) {
   }
 }
 
+#include "egt_pair.h"   // the fused pair operator of the same geometry (k_pair_fwd / k_pair_bwd)
+
 // ------------------------------------------------------------------ host glue --
 extern "C" int egt_attn_mfma_supported(const egt_attn_desc* d, int need_a_tild) {
   if (!d || d->dtype != EGT_F32 || d->H != AH) return 0;
@@ -1212,6 +1214,131 @@ extern "C" int egt_attn_mfma_bwd(const egt_attn_desc* desc, const void* qkv, con
     default: launch_bwd<64>(a, (hipStream_t)stream); break;
   }
   EGT_HIP_LAUNCH_CHECK("egt_attn_mfma_bwd");
+  return EGT_OK;
+}
+
+// ---- fused pair operator (egt_pair.h): (V_att, e') = pair(QKV, e, mask) and its backward -------------------------------
+extern "C" int egt_pair_supported(const egt_block_desc* d) {
+  if (!d || d->dtype != EGT_F32 || d->H != AH) return 0;
+  if (d->d != 64 || d->De != 32) return 0;                                   // the instantiated geometry (BASELINE config 5)
+  if (!(d->flags & EGT_BF_GATE)) return 0;                                    // gated attention with edge bias ('residual' edge channels)
+  if (d->flags & (EGT_BF_ATTN_MASK | EGT_BF_NO_EDGE_LN | EGT_BF_SEED_DEVICE)) return 0;
+  if (d->B < 1 || d->N < 1 || d->N > 2048) return 0;
+  if ((size_t)d->B * d->N * d->N * AH > 0xFFFFFFFFull) return 0;              // 32-bit element index of the mask hash
+  return 1;
+}
+
+static size_t pair_partial_floats(const egt_block_desc* d) {   // per-workgroup partials + one reduced image each
+  const size_t nwg = (size_t)d->B * (np_of(d->N) / 16);
+  return (nwg + 1) * ((size_t)d->De * 16 + 16) + (nwg + 1) * ((size_t)AH * d->De + d->De);
+}
+
+// packed operand arrays (all six), row constants, dA tiles, parameter-gradient partials.  The forward writes the q / k / v arrays;
+// with desc->reserved & EGT_ATTN_WS_SHARED the caller hands the SAME untouched workspace to egt_pair_bwd, which then adds only dO
+extern "C" size_t egt_pair_workspace_bytes(const egt_block_desc* d) {
+  if (!egt_pair_supported(d)) return 0;
+  const size_t NP = np_of(d->N), arr = (size_t)d->B * AH * NP * d->d;
+  return (PK_COUNT * arr + (size_t)d->B * AH * NP * 4 + (size_t)d->B * AH * NP * NP + pair_partial_floats(d)) * sizeof(float);
+}
+
+static int pair_fill(const egt_block_desc* d, const egt_block_params* P, const void* qkv, const void* e, const uint8_t* key_mask,
+                     void* workspace, AttnMfmaArgs& a, PairArgs& pa) {
+  if (!egt_pair_supported(d)) EGT_FAIL(EGT_E_SHAPE, "configuration not covered by the fused pair operator (d = 64, De = 32, H = 8, gated, fp32)");
+  if (!P || !qkv || !e || !workspace) EGT_FAIL(EGT_E_NULL, "params/qkv/e/workspace is NULL");
+  if (!P->norm_edge_gamma || !P->norm_edge_beta || !P->attention_gates_kernel || !P->attention_gates_bias || !P->dense_edge_b_kernel ||
+      !P->dense_edge_b_bias || !P->dense_edge_r_kernel || !P->dense_edge_r_bias)
+    EGT_FAIL(EGT_E_NULL, "an edge-side parameter pointer is NULL");
+  if (d->reserved & ~EGT_ATTN_WS_SHARED) EGT_FAIL(EGT_E_FLAGS, "egt_block_desc.reserved: unknown bits 0x%x", d->reserved);
+  a = AttnMfmaArgs{};
+  a.B = d->B; a.N = d->N; a.NP = np_of(d->N); a.d = d->d;
+  a.flags = EGT_F_EDGE_INPUT | EGT_F_GATE_INPUT | ((d->flags & EGT_BF_CLIP) ? EGT_F_CLIP : 0);
+  a.clip_lo = d->clip_lo; a.clip_hi = d->clip_hi;
+  a.scale = 1.0f / sqrtf((float)d->d);
+  a.rm_thr = egt_threshold24(d->random_mask_prob);
+  a.s0 = (uint32_t)(d->seed & 0xFFFFFFFFull); a.s1 = (uint32_t)(d->seed >> 32);
+  a.rng_rm = ((d->flags & EGT_BF_TRAINING) && d->random_mask_prob > 0.0f) ? 1 : 0;
+  a.qkv = (const float*)qkv; a.km = key_mask;
+  a.pk = (float*)workspace;
+  pa = PairArgs{};
+  pa.De = d->De; pa.ln_eps = d->ln_eps;
+  pa.e = (const float*)e;
+  pa.gamma = (const float*)P->norm_edge_gamma; pa.beta = (const float*)P->norm_edge_beta;
+  pa.Wg = (const float*)P->attention_gates_kernel; pa.bg = (const float*)P->attention_gates_bias;
+  pa.We = (const float*)P->dense_edge_b_kernel; pa.be = (const float*)P->dense_edge_b_bias;
+  pa.Wr = (const float*)P->dense_edge_r_kernel; pa.br = (const float*)P->dense_edge_r_bias;
+  return EGT_OK;
+}
+
+extern "C" int egt_pair_fwd(const egt_block_desc* desc, const egt_block_params* params, const void* qkv, const void* e,
+                            const uint8_t* key_mask, void* v_att, void* e_out, void* rowstats, void* workspace, void* stream) {
+  AttnMfmaArgs a; PairArgs pa;
+  int rc = pair_fill(desc, params, qkv, e, key_mask, workspace, a, pa);
+  if (rc) return rc;
+  if (!v_att || !e_out || !rowstats) EGT_FAIL(EGT_E_NULL, "v_att/e_out/rowstats is NULL");
+  a.v_att = (float*)v_att; a.rowstats = (float*)rowstats;
+  pa.e_out = (float*)e_out;
+  a.pack_what = PACK_Q | PACK_KH | PACK_VT | ((desc->reserved & EGT_ATTN_WS_SHARED) ? (PACK_KT | PACK_VH) : 0);
+  hipStream_t st = (hipStream_t)stream;
+  launch_pack<64>(a, st);
+  constexpr int D = 64, DE = 32, HS = (D / 16) * 256;
+  const size_t lds = ((size_t)3 * AH * HS + 2 * (size_t)((a.NP + 16 + 3) & ~3) + (size_t)3 * AH * PT_PL) * sizeof(float);
+  const int grid = a.B * (a.NP / 16);
+  if (a.rng_rm) {
+    EGT_MAX_LDS_ONCE(k_pair_fwd<D, DE, 2>);
+    EGT_LAUNCH("k_pair_fwd", (k_pair_fwd<D, DE, 2>), dim3(grid), dim3(64 * PR_WAVES), lds, st, a, pa);
+  } else {
+    EGT_MAX_LDS_ONCE(k_pair_fwd<D, DE, 1>);
+    EGT_LAUNCH("k_pair_fwd", (k_pair_fwd<D, DE, 1>), dim3(grid), dim3(64 * PR_WAVES), lds, st, a, pa);
+  }
+  EGT_HIP_LAUNCH_CHECK("egt_pair_fwd");
+  return EGT_OK;
+}
+
+// rowstats is read AND written (slot 3 receives delta).  Every edge-side pointer of `grads` is written; d_e may alias d_e_out.
+extern "C" int egt_pair_bwd(const egt_block_desc* desc, const egt_block_params* params, const void* qkv, const void* e,
+                            const uint8_t* key_mask, const void* v_att, void* rowstats, const void* d_v_att, const void* d_e_out,
+                            void* d_qkv, void* d_e, const egt_block_params* grads, void* workspace, void* stream) {
+  AttnMfmaArgs a; PairArgs pa;
+  int rc = pair_fill(desc, params, qkv, e, key_mask, workspace, a, pa);
+  if (rc) return rc;
+  if (!v_att || !rowstats || !d_v_att || !d_e_out || !d_qkv || !d_e || !grads) EGT_FAIL(EGT_E_NULL, "v_att/rowstats/d_v_att/d_e_out/d_qkv/d_e/grads is NULL");
+  if (!grads->norm_edge_gamma || !grads->norm_edge_beta || !grads->attention_gates_kernel || !grads->attention_gates_bias ||
+      !grads->dense_edge_b_kernel || !grads->dense_edge_b_bias || !grads->dense_edge_r_kernel || !grads->dense_edge_r_bias)
+    EGT_FAIL(EGT_E_NULL, "an edge-side gradient pointer is NULL");
+  a.v_att_in = (const float*)v_att; a.rowstats = (float*)rowstats;
+  a.d_v_att = (const float*)d_v_att; a.d_qkv = (float*)d_qkv;
+  pa.d_e_out = (const float*)d_e_out; pa.d_e = (float*)d_e;
+  const size_t arr = (size_t)a.B * AH * a.NP * a.d;
+  a.stats2 = a.pk + (size_t)PK_COUNT * arr;
+  a.ws_dA = a.stats2 + (size_t)a.B * AH * a.NP * 4;
+  constexpr int D = 64, DE = 32, HS = (D / 16) * 256;
+  constexpr int PSZ1 = DE * 16 + 16, PSZ2 = AH * DE + DE;
+  const int nwg = a.B * (a.NP / 16);
+  pa.part_proj = a.ws_dA + (size_t)a.B * AH * a.NP * a.NP;
+  pa.part_upd = pa.part_proj + (size_t)(nwg + 1) * PSZ1;
+  a.pack_what = PACK_O | ((desc->reserved & EGT_ATTN_WS_SHARED) ? 0 : (PACK_Q | PACK_KH | PACK_KT | PACK_VH));
+  hipStream_t st = (hipStream_t)stream;
+  launch_pack<64>(a, st);   // (also the per-row constants, delta = sum_k dO*O among them)
+  const size_t lds = ((size_t)2 * 4 * 2 * HS + (size_t)2 * 3 * AH * PT_PL + (size_t)2 * AH * 64 + (size_t)4 * 2 * 16 * DE + (size_t)3 * (DE / 16) * 64 * 4) * sizeof(float);
+  if (a.rng_rm) {
+    EGT_MAX_LDS_ONCE(k_pair_bwd<D, DE, 2>);
+    EGT_LAUNCH("k_pair_bwd", (k_pair_bwd<D, DE, 2>), dim3(nwg), dim3(64 * PR_WAVES), lds, st, a, pa);
+  } else {
+    EGT_MAX_LDS_ONCE(k_pair_bwd<D, DE, 1>);
+    EGT_LAUNCH("k_pair_bwd", (k_pair_bwd<D, DE, 1>), dim3(nwg), dim3(64 * PR_WAVES), lds, st, a, pa);
+  }
+  {
+    const int qgroups = (a.NP / 16 + QW_TILES - 1) / QW_TILES;
+    const size_t ldsq = (size_t)QW_STAGES * (2 * (D / 16) + 2 * QW_TILES) * 1024;
+    EGT_MAX_LDS_ONCE(k_attn_mfma_bwd_q<D>);
+    EGT_LAUNCH("k_attn_mfma_bwd_q", (k_attn_mfma_bwd_q<D>), dim3(a.B * AH * qgroups), dim3(512), ldsq, st, a);
+  }
+  egt_edge_finish_param_grads(DE, pa.gamma, pa.beta, pa.Wg, pa.We, pa.part_proj, pa.part_upd, nwg,
+                              pa.part_proj + (size_t)nwg * PSZ1, pa.part_upd + (size_t)nwg * PSZ2,
+                              (float*)grads->norm_edge_gamma, (float*)grads->norm_edge_beta, (float*)grads->attention_gates_kernel,
+                              (float*)grads->attention_gates_bias, (float*)grads->dense_edge_b_kernel, (float*)grads->dense_edge_b_bias,
+                              (float*)grads->dense_edge_r_kernel, (float*)grads->dense_edge_r_bias, st);
+  EGT_HIP_LAUNCH_CHECK("egt_pair_bwd");
   return EGT_OK;
 }
 

@@ -89,6 +89,12 @@ __device__ __forceinline__ float row_max16(float v) {
   return v;
 }
 
+// ---- egt_edge.hip, for the fused pair operator (egt_pair.h): edge-parameter gradients from per-workgroup partials ----
+void egt_edge_finish_param_grads(int De, const float* gamma, const float* beta, const float* Wg, const float* We,
+                                 const float* part_proj, const float* part_upd, int n_partials, float* red_proj, float* red_upd,
+                                 float* d_gamma, float* d_beta, float* d_Wg, float* d_bg, float* d_We, float* d_be,
+                                 float* d_Wr, float* d_br, hipStream_t st);
+
 // ---- kernel timing hooks (egt_capi.hip) ---------------------------------------
 int egt_prof_is_enabled();
 void egt_prof_begin(const char* name, hipStream_t s, void** tok);

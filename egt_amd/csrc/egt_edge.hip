@@ -578,6 +578,30 @@ extern "C" int egt_edge_update_fwd(const egt_edge_desc* desc, const void* e, con
   return EGT_OK;
 }
 
+// ---- internal (egt_common.h): finish the edge-parameter gradients from per-workgroup partials in the layouts of k_edge_proj_bwd
+// ([That[De][16] | s[16]]) and k_edge_update_bwd ([dWr[8][De] | dbr[De]]).  Used by the fused pair operator (egt_pair.h), whose
+// backward accumulates the same partials inside its pair kernel.  `red_*`: scratch of one partial image each.
+void egt_edge_finish_param_grads(int De, const float* gamma, const float* beta, const float* Wg, const float* We,
+                                 const float* part_proj, const float* part_upd, int n_partials, float* red_proj, float* red_upd,
+                                 float* d_gamma, float* d_beta, float* d_Wg, float* d_bg, float* d_We, float* d_be,
+                                 float* d_Wr, float* d_br, hipStream_t st) {
+  EdgeArgs a{};
+  a.De = De; a.flags = EGT_EP_LAYERNORM | EGT_EP_GATES;
+  a.gamma = gamma; a.beta = beta; a.Wg = Wg; a.We = We;
+  a.d_gamma = d_gamma; a.d_beta = d_beta; a.d_Wg = d_Wg; a.d_bg = d_bg; a.d_We = d_We; a.d_be = d_be; a.d_Wr = d_Wr; a.d_br = d_br;
+  a.n_partials = 1;
+  DISPATCH_DE(De, {
+    constexpr int PSZ1 = DE * 16 + 16;
+    constexpr int PSZ2 = EDGE_H * DE + DE;
+    EGT_LAUNCH("k_edge_reduce_partials", k_edge_reduce_partials, dim3((PSZ1 + 15) / 16), dim3(256), 0, st, part_proj, PSZ1, n_partials, red_proj);
+    EGT_LAUNCH("k_edge_reduce_partials", k_edge_reduce_partials, dim3((PSZ2 + 15) / 16), dim3(256), 0, st, part_upd, PSZ2, n_partials, red_upd);
+    a.ws = red_proj;
+    EGT_LAUNCH("k_edge_proj_bwd_final", k_edge_proj_bwd_final<DE>, dim3(1), dim3(256), 0, st, a);
+    a.ws = red_upd;
+    EGT_LAUNCH("k_edge_update_bwd_final", k_edge_update_bwd_final<DE>, dim3(1), dim3(256), 0, st, a);
+  });
+}
+
 extern "C" size_t egt_edge_update_bwd_workspace_bytes(const egt_edge_desc* d) {
   if (!d) return 0;
   return (size_t)(EDGE_MAX_PARTIALS + 1) * (EDGE_H * d->De + d->De) * sizeof(float);

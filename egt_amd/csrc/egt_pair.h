@@ -1,0 +1,824 @@
+// Fused pair operator for the large-head geometry (d = 64, H = 8; BASELINE config 5: N = 512, Dh = 512, De = 32):
+//   (V_att, e') = pair(QKV, e, mask)   =   norm_edge -> attention_gates / dense_edge_b -> EGT -> dense_edge_r + res_edge
+//   lib/models/graph_xformer_model_base.py:195-218 around lib/models/egt_layers.py:57-143
+// with E, G, H_hat (and dE, dG, dH_ext in the backward) living only in LDS planes: the [B,N,N,8] tensors of the composed
+// path (k_edge_proj_* -> k_attn_mfma_* -> k_edge_update_*) never reach HBM.  The node-side Dense layers around it
+// (norm_mha, dense_qkv, dense_mha: [B N, 512] x [512, 1536] GEMMs) stay library GEMMs.
+//
+// Included by egt_attn_mfma.hip (same translation unit: packed operand arrays, plane layouts, LDS-DMA helpers, k_attn_pack
+// and k_attn_mfma_bwd_q are shared with the inner-op kernels).
+//
+// Workgroup = (graph, 16 query rows [forward] / 16 keys [backward], ALL 8 heads), 8 waves, one workgroup per CU:
+//   * 4 ATTENTION waves (one per SIMD), two heads each: QK^T / A.V (backward: S, dP, dV, dK) on v_mfma_f32_16x16x4_f32 with
+//     their Q / dO-side operands in registers, the streamed operand tiles in LDS, the [16 x 16] pair values of their heads
+//     read from / written to head-major LDS planes;
+//   * 4 EDGE waves (one per SIMD), four rows of the 16 x 16 pair tile each: the e tile HBM -> registers (lane (p, q) = pair p,
+//     channels 16 t + 4 q + {0..3}: the B-operand layout of the channel contractions), LayerNorm in registers, the
+//     [gamma Wg | gamma We] projection on the matrix core -> G / E planes; H_hat plane -> dense_edge_r on the matrix core ->
+//     e' = e + ... stored from the registers that loaded e; and every vector-memory instruction of the workgroup: the
+//     attention waves' operand tiles by LDS-DMA, e two tiles ahead.
+// Both roles issue MFMAs, so the matrix pipe of a SIMD always has a second wave to draw from while the other is in its
+// VALU / LDS phase (the inner-op kernels pair a compute wave with a loader wave that issues none).
+// Two barriers per tile, neither drains vector memory.
+#pragma once
+
+struct PairArgs {
+  int De;
+  float ln_eps;
+  const float *e, *gamma, *beta, *Wg, *bg, *We, *be, *Wr, *br;
+  float* e_out;
+  // backward
+  const float* d_e_out;
+  float *d_e, *part_proj, *part_upd;   // per-workgroup partials: [That[De][16] | s[16]] and [dWr[8][De] | dbr[De]]
+};
+
+#define PR_WAVES 8
+// LDS hand-off inside ONE wave (its DS operations complete in order): drain lgkmcnt, never vmcnt
+__device__ __forceinline__ void lds_sync_() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+#ifndef PAIR_NT_E
+#define PAIR_NT_E 0   // 1: the forward's e tiles by non-temporal loads (read once; measured before adopting)
+#endif
+// a wave-uniform pointer the compiler cannot prove uniform -> scalar registers (LDS-DMA takes its base address from an SGPR pair)
+__device__ __forceinline__ const float* uni_ptr(const float* p) {
+  const uint64_t v = (uint64_t)(uintptr_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const float*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+typedef float pr_nt_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 egt_ld4_nt_(const float* p) {
+  if (PAIR_NT_E) { const pr_nt_v4f t = __builtin_nontemporal_load(reinterpret_cast<const pr_nt_v4f*>(p)); return make_float4(t[0], t[1], t[2], t[3]); }
+  return *reinterpret_cast<const float4*>(p);
+}
+template <int DE> struct PairGeo { static constexpr int T = DE / 16; };
+
+// LayerNorm of a lane's fragments (two-pass moments like tf.nn.moments, as egt_tile.h: ln_frags); returns rstd
+template <int T_>
+__device__ __forceinline__ float pair_ln(float4 (&x)[T_], float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < T_; ++t) s += (x[t].x + x[t].y) + (x[t].z + x[t].w);
+  const float mu = pair_sum_q(s) * (1.0f / (16 * T_));
+  float v = 0.f;
+#pragma unroll
+  for (int t = 0; t < T_; ++t) {
+    x[t].x -= mu; x[t].y -= mu; x[t].z -= mu; x[t].w -= mu;
+    v = fmaf(x[t].x, x[t].x, v); v = fmaf(x[t].y, x[t].y, v);
+    v = fmaf(x[t].z, x[t].z, v); v = fmaf(x[t].w, x[t].w, v);
+  }
+  const float rstd = rsqrtf(pair_sum_q(v) * (1.0f / (16 * T_)) + eps);
+#pragma unroll
+  for (int t = 0; t < T_; ++t) { x[t].x *= rstd; x[t].y *= rstd; x[t].z *= rstd; x[t].w *= rstd; }
+  return rstd;
+}
+__device__ __forceinline__ float f4get(const float4& v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; }
+
+// LN-folded projection weights of an edge wave (A operands, lane (i = lane&15, q)): wA[t][r] = gamma_c Wcat[c][i], c = 16 t + 4 q + r;
+// bias[r] = b_i' + sum_c beta_c Wcat[c][i'] for the lane's OUTPUT channels i' = 4 q + r.  Wcat = [attention_gates | dense_edge_b].
+template <int DE>
+__device__ __forceinline__ void pair_fold_weights(const PairArgs& pa, int i, int q, float (&wA)[PairGeo<DE>::T][4], float (&bias)[4]) {
+  constexpr int T = PairGeo<DE>::T;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * t + 4 * q + r;
+      wA[t][r] = (i < 8 ? pa.Wg[c * 8 + i] : pa.We[c * 8 + i - 8]) * pa.gamma[c];
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = 4 * q + r;
+    const float* W = o < 8 ? pa.Wg + o : pa.We + (o - 8);
+    float b = o < 8 ? pa.bg[o] : pa.be[o - 8];
+#pragma nounroll
+    for (int c = 0; c < DE; ++c) b = fmaf(pa.beta[c], W[c * 8], b);   // (rolled: unrolled, hipcc loads both matrices into registers at once)
+    bias[r] = b;
+  }
+}
+
+// ================================================================== forward =====
+// LDS: Kb [8 heads][KT tiles] (one stage: K(it+1) lands while the attention waves are in their softmax / A.V phase), Vb two stages,
+// the two per-key additive tables, planes E | G (in) and H_hat (out), one stage each:
+//   barrier B1(it): planes E, G of tile it written, K(it) landed      -> attention: S = K.Q^T          edge: dense_edge_r of tile it-1
+//   barrier B2(it): H_hat(it-1) consumed, E / G(it) read, K(it) read  -> attention: softmax, H_hat, A.V edge: DMA K(it+1), V(it+1); LN + projections of tile it+1
+template <int D, int DE, int V>
+__global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, PairArgs pa) {
+  constexpr int KT = D / 16, DH = D * AH, T = PairGeo<DE>::T, HS = KT * 256;   // HS: floats of one head's operand tile
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = a.N, NP = a.NP, mtiles = NP / 16;
+  const int KA = (NP + 16 + 3) & ~3;
+  float* Kb = sm;                      // [8][HS]
+  float* Vb = Kb + AH * HS;            // [2][8][HS]
+  float* kaddL = Vb + 2 * AH * HS;     // [KA]
+  float* kaddG = kaddL + KA;
+  float* InE = kaddG + KA;             // [8][PT_PL]
+  float* InG = InE + AH * PT_PL;
+  float* Hp = InG + AH * PT_PL;
+  const int wg = egt_xcd_remap(blockIdx.x, gridDim.x);   // the row blocks of a graph share an XCD's L2 (K / V^T of the graph: 2 MB)
+  const int b = __builtin_amdgcn_readfirstlane(wg / mtiles), l0 = __builtin_amdgcn_readfirstlane((wg % mtiles) * 16);   // (the division runs on the VALU: back to scalar registers)
+  const size_t arr = (size_t)a.B * AH * NP * D;
+  const bool clip = (a.flags & EGT_F_CLIP) != 0;
+
+  if (wv >= 4) {
+    // --------------------------------------------------------------------- edge waves ----
+    const int j = wv - 4, p = lane & 15, q = lane >> 4;
+    for (int m = tid - 256; m < NP + 16; m += 256) {
+      float ka = 0.f;
+      if (m >= N) ka = KEY_OFF;
+      else if (a.km && a.km[(size_t)b * N + m] == 0) ka = -EGT_NEG;
+      kaddL[m] = ka;
+      kaddG[m] = m >= N ? 3.0e38f : -ka * L2E;
+    }
+    float wA[T][4], bias[4];
+    pair_fold_weights<DE>(pa, p, q, wA, bias);
+    // dense_edge_r: A[c = 16 t + i][h = q + 4 s] = Wr[h][c]; bias br[16 t + 4 q + r] on the lane's output channels
+    float wU[T][2], brv[T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      wU[t][0] = pa.Wr[q * DE + 16 * t + p];
+      wU[t][1] = pa.Wr[(q + 4) * DE + 16 * t + p];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) brv[t][r] = pa.br[16 * t + 4 * q + r];
+    }
+    // operand tiles of heads 2j, 2j+1 by LDS-DMA
+    const unsigned doff = dma_lane_off(lane);
+    const float* Kh = a.pk + PK_KH * arr + ((size_t)b * AH + 2 * j) * NP * D;
+    const float* VT = a.pk + PK_VT * arr + ((size_t)b * AH + 2 * j) * D * NP;
+    const unsigned kdst = lds_addr(Kb) + (2 * j) * HS * 4, vdst = lds_addr(Vb) + (2 * j) * HS * 4;
+    auto dma_ops = [&](int mt) __attribute__((always_inline)) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int Tt = 0; Tt < KT; ++Tt) {
+          dma_piece(kdst + (hh * KT + Tt) * 1024, uni_ptr(Kh + (size_t)hh * NP * D + (size_t)mt * 16 * D + Tt * 256), doff);
+          dma_piece(vdst + (mt & 1) * (AH * HS * 4) + (hh * KT + Tt) * 1024, uni_ptr(VT + (size_t)hh * D * NP + (size_t)mt * 16 * D + Tt * 256), doff);
+        }
+    };
+    // e fragments of the wave's four rows: lane (p, q): key 16 it + p, channels 16 t + 4 q ..
+    // row r of the wave: a wave-uniform row pointer (scalar registers) + one 32-bit lane offset per tile
+    const float* erow[4];
+    float* orow[4];
+    bool rowok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int l = l0 + 4 * j + r;
+      rowok[r] = l < N;
+      const size_t ro = ((size_t)b * N + min(l, N - 1)) * N * DE;
+      erow[r] = pa.e + ro;
+      orow[r] = pa.e_out + ro;
+    }
+    struct ESet { float4 x[4][T]; };
+    auto eload = [&](ESet& s, int mt) __attribute__((always_inline)) {
+      const uint32_t mo = (uint32_t)min(16 * mt + p, N - 1) * DE + 4 * q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < T; ++t) s.x[r][t] = egt_ld4_nt_(erow[r] + mo + 16 * t);
+    };
+    // LN + projections of tile mt from set s -> planes
+    auto project = [&](const ESet& s) __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float4 x[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) x[t] = s.x[r][t];
+        pair_ln<T>(x, pa.ln_eps);
+        v4f acc = {bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          acc = MFMA(wA[t][0], x[t].x, acc);
+          acc = MFMA(wA[t][1], x[t].y, acc);
+          acc = MFMA(wA[t][2], x[t].z, acc);
+          acc = MFMA(wA[t][3], x[t].w, acc);
+        }
+        // lane holds outputs 4q..4q+3 of pair (row 4j + r, key p): q < 2 gates of heads 4q + i, q >= 2 edge bias of heads 4(q-2) + i
+        float* pl = (q < 2 ? InG : InE) + (4 * (q & 1)) * PT_PL + pt_off(4 * j + r, p);
+        pl[0] = acc[0]; pl[PT_PL] = acc[1]; pl[2 * PT_PL] = acc[2]; pl[3 * PT_PL] = acc[3];
+      }
+    };
+    // e' = e + H_hat.Wr + br of tile mt from set s (the registers that loaded e) and the H_hat planes
+    auto update = [&](const ESet& s, int mt) __attribute__((always_inline)) {
+      const int m = 16 * mt + p;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* hp = Hp + q * PT_PL + pt_off(4 * j + r, p);
+        const float h0 = hp[0], h1 = hp[4 * PT_PL];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          v4f acc = {brv[t][0], brv[t][1], brv[t][2], brv[t][3]};
+          acc = MFMA(wU[t][0], h0, acc);
+          acc = MFMA(wU[t][1], h1, acc);
+          if (rowok[r] && m < N)
+            *reinterpret_cast<float4*>(orow[r] + (uint32_t)m * DE + 4 * q + 16 * t) =
+                make_float4(s.x[r][t].x + acc[0], s.x[r][t].y + acc[1], s.x[r][t].z + acc[2], s.x[r][t].w + acc[3]);
+        }
+      }
+    };
+    ESet S0, S1, S2;
+    dma_ops(0);
+    eload(S0, 0);
+    eload(S1, min(1, mtiles - 1));
+    vm_wait<4 * T>();          // K(0), V(0) and e(0) landed; e(1) may still be in flight
+    project(S0);
+    lds_barrier();             // B1(0)
+    // one trip = [U(it-1)] B2 [DMA(it+1), loads(it+2), project(it+1)] B1; the three register sets rotate: (cur, nxt, pre) = e(it-1), e(it+1)... see below
+    auto trip = [&](int it, ESet& done, ESet& nxt) __attribute__((always_inline)) {
+      // `done` holds e(it-1) (consumed by this trip's update, then refilled with e(it+2)); `nxt` holds e(it+1)
+      if (it > 0) update(done, it - 1);
+      lds_barrier();           // B2(it)
+      if (it + 1 < mtiles) dma_ops(it + 1);
+      eload(done, min(it + 2, mtiles - 1));
+      if (it + 1 < mtiles) {
+        vm_wait<4 * T + 4 * KT>();   // e(it+1) (requested a trip ago) is older than this trip's DMA pieces and loads
+        project(nxt);
+      }
+      vm_wait<4 * T>();        // the DMA pieces landed (only this trip's e loads are younger)
+      lds_barrier();           // B1(it+1)
+    };
+    // set holding e(k) is S[k % 3]: trip(it) updates from S[(it-1) % 3], projects S[(it+1) % 3]
+    int it = 0;
+    for (; it + 2 < mtiles; it += 3) {
+      trip(it, S2, S1);
+      trip(it + 1, S0, S2);
+      trip(it + 2, S1, S0);
+    }
+    if (it < mtiles) { trip(it, S2, S1); ++it; }
+    if (it < mtiles) { trip(it, S0, S2); ++it; }
+    // H_hat of the last tile: its set is S[(mtiles-1) % 3]
+    {
+      const int k = (mtiles - 1) % 3;
+      if (k == 0) update(S0, mtiles - 1); else if (k == 1) update(S1, mtiles - 1); else update(S2, mtiles - 1);
+    }
+  } else {
+    // ---------------------------------------------------------------- attention waves ----
+    const int w = wv, ll = lane & 15, q = lane >> 4;
+    float Qr[2][4 * KT];
+    {
+      const int ltile = l0 >> 4;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const float* Qh = a.pk + PK_QH * arr + ((size_t)b * AH + 2 * w + hh) * NP * D + (size_t)ltile * 16 * D;
+#pragma unroll
+        for (int Tt = 0; Tt < KT; ++Tt) {
+          const float4 v = *reinterpret_cast<const float4*>(Qh + 256 * Tt + ll * 16 + 4 * q);
+          Qr[hh][4 * Tt + 0] = v.x; Qr[hh][4 * Tt + 1] = v.y; Qr[hh][4 * Tt + 2] = v.z; Qr[hh][4 * Tt + 3] = v.w;
+        }
+      }
+    }
+    v4f oacc[2][KT];
+    float mrun[2], lrun[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      mrun[hh] = KEY_OFF; lrun[hh] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) oacc[hh][kt] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+    const int po4 = (2 * w) * PT_PL + pt_off(ll, 4 * q);                       // + hh * PT_PL: the lane's keys 4q..4q+3 of row ll
+    const float* opl = Kb + (2 * w) * HS + ll * 16 + ((q ^ chunk_xor(ll)) << 2);   // + hh * HS + 256 T
+    const int lq = min(l0 + ll, N - 1);
+    lds_barrier();             // B1(0)
+    for (int it = 0; it < mtiles; ++it) {
+      const int m0 = 16 * it;
+      float4 kc[2][KT], e4[2], g4[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int Tt = 0; Tt < KT; ++Tt) kc[hh][Tt] = *reinterpret_cast<const float4*>(opl + hh * HS + Tt * 256);
+      const float4 ka4 = *reinterpret_cast<const float4*>(kaddL + m0 + 4 * q);
+      float4 kg4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (V == 1) kg4 = *reinterpret_cast<const float4*>(kaddG + m0 + 4 * q);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        e4[hh] = *reinterpret_cast<const float4*>(InE + hh * PT_PL + po4);
+        g4[hh] = *reinterpret_cast<const float4*>(InG + hh * PT_PL + po4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- S^T[m][l] = sum_k K[m][k] (d^-1/2 Q)[l][k], two heads ----
+      v4f s[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) s[hh] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int Tt = 0; Tt < KT; ++Tt)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) s[hh] = MFMA(f4get(kc[hh][Tt], u), Qr[hh][4 * Tt + u], s[hh]);
+      lds_barrier();           // B2(it): K(it), E / G(it) are in registers; H_hat(it-1) has been consumed
+      float4 vc[2][KT];
+      const float* vpl = opl + (AH * HS) + (it & 1) * (AH * HS);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int Tt = 0; Tt < KT; ++Tt) vc[hh][Tt] = *reinterpret_cast<const float4*>(vpl + hh * HS + Tt * 256);
+      const float kav[4] = {ka4.x, ka4.y, ka4.z, ka4.w}, kgv[4] = {kg4.x, kg4.y, kg4.z, kg4.w};
+      float pa_[2][4];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int h = 2 * w + hh;
+        float x[4], hv4[4];
+        float tmax = KEY_OFF;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float ah = s[hh][r];
+          if (clip) ah = __builtin_amdgcn_fmed3f(ah, a.clip_lo, a.clip_hi);
+          const float hv = ah + f4get(e4[hh], r);
+          hv4[r] = hv;                                          // H_hat: post-clip, pre-mask (egt_layers.py:85-86)
+          float add = kav[r];
+          if (V == 2) {
+            const int m = min(m0 + 4 * q + r, N - 1);
+            const uint32_t gi = (uint32_t)((((size_t)b * N + lq) * N + m) * AH + h);
+            add += ((egt_hash32(gi, a.s0, a.s1) >> 8) < a.rm_thr) ? -EGT_NEG : 0.0f;
+          }
+          x[r] = hv + add;
+          tmax = fmaxf(tmax, x[r]);
+          const float tg = V == 1 ? exp2_fast(fmaf(f4get(g4[hh], r), -L2E, kgv[r])) : exp2_fast((f4get(g4[hh], r) + add) * -L2E);
+          pa_[hh][r] = __builtin_amdgcn_rcpf(1.0f + tg);
+        }
+        *reinterpret_cast<float4*>(Hp + hh * PT_PL + po4) = make_float4(hv4[0], hv4[1], hv4[2], hv4[3]);
+        tmax = pair_max_q(tmax);
+        const float mnew = fmaxf(mrun[hh], tmax);
+        const float alpha = exp2_fast((mrun[hh] - mnew) * L2E);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pexp = exp2_fast((x[r] - mnew) * L2E);
+          psum += pexp;
+          pa_[hh][r] *= pexp;
+        }
+        psum = pair_sum_q(psum);
+        lrun[hh] = fmaf(lrun[hh], alpha, psum);
+        mrun[hh] = mnew;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          v4f o = oacc[hh][kt];
+          o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+          oacc[hh][kt] = o;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- O^T[k][l] += sum_m V^T[k][m] P^T[m][l] ----
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) oacc[hh][kt] = MFMA(f4get(vc[hh][kt], r), pa_[hh][r], oacc[hh][kt]);
+      lds_barrier();           // B1(it+1)
+    }
+    // ---- finalize: O[l][k] / l_run into the K stage as [row][k][8 heads]; row statistics for the backward ----
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int h = 2 * w + hh, l = l0 + ll;
+      const float inv = 1.0f / lrun[hh];
+      float* vs = sm + (ll * D + 4 * q) * AH + h;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vs[(16 * kt + r) * AH] = oacc[hh][kt][r] * inv;
+      if (l < N && q == 0)
+        *reinterpret_cast<float4*>(a.rowstats + (((size_t)b * N + l) * AH + h) * 4) = make_float4(mrun[hh], lrun[hh], 0.f, 0.f);
+    }
+  }
+  // V_att[l][k * 8 + h]: 16 rows x 512 channels, consecutive threads consecutive 16-byte pieces
+  lds_barrier();
+  for (int p = tid; p < 16 * DH / 4; p += 64 * PR_WAVES) {
+    const int row = p / (DH / 4);
+    if (l0 + row < N)
+      *reinterpret_cast<float4*>(a.v_att + ((size_t)b * N + l0) * DH + (size_t)p * 4) = *reinterpret_cast<const float4*>(sm + (size_t)p * 4);
+  }
+}
+
+// ================================================================= backward =====
+// Launches: k_attn_pack (operand arrays of dV_att, row constants m, 1/l, delta), k_pair_bwd (below), k_attn_mfma_bwd_q (dQ from
+// the dA tiles), then the deterministic reduction of the per-workgroup parameter-gradient partials (k_edge_reduce-style).
+//
+// k_pair_bwd: workgroup = (graph, 16 keys, all 8 heads) walking the query tiles (dK / dV accumulate in registers).
+//   attention wave w owns heads w and w + 4 and works on ONE of them per half-trip: the Q / dO operand stage of a half-trip holds
+//   four heads (32 KB), two stages -> the tiles of the next half-trip land while this one computes, and a wave keeps only one
+//   head's transient state beside the K / V fragments and dK / dV accumulators of its two heads (the transposed operand
+//   forms are read from the same tiles just in time);
+//   edge wave j owns query rows 4j..4j+3 of the tile: PRE(it+1) = e, de' tile -> LayerNorm, G / E projection, dH_ext = de'.Wr^T
+//   -> planes; POST(it-1) = dG / dE / H_hat planes (written by the attention waves IN PLACE of G / E / dH_ext) ->
+//   d ehat = Wp.dGE, LayerNorm backward, de = de' + .. stored; weight gradients T += ehat^T.dGE, R += de'^T.[H_hat | 1] on the
+//   matrix core (accumulators live for the whole workgroup -> deterministic partials).  ehat and de' of a tile stay in the
+//   registers that loaded them from PRE to POST (two register sets, one per trip parity), refilled right after POST.
+//   trip it:  B1(it)  attention: half A (heads 0-3)         edge: DMA half B(it); POST(it-1) + reload e, de' (it+1)
+//             Bm(it)  attention: half B (heads 4-7)         edge: DMA half A(it+1); PRE(it+1); row constants of it+1
+template <int D, int DE, int V>
+__global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, PairArgs pa) {
+  constexpr int KT = D / 16, DH = D * AH, T = PairGeo<DE>::T, HS = KT * 256, TSZ = AH * PT_PL;
+  constexpr int PSZ1 = DE * 16 + 16, PSZ2 = AH * DE + DE;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = a.N, NP = a.NP, mtiles = NP / 16;
+  float* Ops = sm;                         // [2 stages][4 head slots][Q | dO][HS]
+  float* Pl = Ops + 2 * 4 * 2 * HS;        // [2 sets][E | G | X][8][PT_PL]
+  float* statL = Pl + 2 * 3 * TSZ;         // [2 stages][8 heads][16 rows][4]
+  float* scr = statL + 2 * AH * 64;        // [4 edge waves][ehat tile | de' tile][16][DE]
+  float* wtab = scr + 4 * 2 * 16 * DE;     // [wA | wB | wR][T][64 lanes][4]: the edge waves' lane-constant MFMA A operands (24 registers otherwise)
+  const int wg = egt_xcd_remap(blockIdx.x, gridDim.x);
+  const int b = __builtin_amdgcn_readfirstlane(wg / mtiles), mt0 = __builtin_amdgcn_readfirstlane(wg % mtiles), m0 = mt0 * 16;
+  const size_t arr = (size_t)a.B * AH * NP * D;
+  const bool clip = (a.flags & EGT_F_CLIP) != 0;
+
+  if (wv >= 4) {
+    // --------------------------------------------------------------------- edge waves ----
+    const int j = wv - 4, p = lane & 15, q = lane >> 4;
+    float bias[4];
+    {
+      // every edge wave writes the same table (same values: a benign race), then reads only after its own writes completed
+      float wA[T][4];
+      pair_fold_weights<DE>(pa, p, q, wA, bias);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        float wB[4], wR[4];   // d ehat = Wp.dGE: A[c = 16 t + i][o = 4 q + s] = gamma_c Wcat[c][o];  dH_ext = Wr.de': A[h = i (< 8)][c = 16 t + 4 q + r] = Wr[h][c]
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int c = 16 * t + p, o = 4 * q + s;
+          wB[s] = (o < 8 ? pa.Wg[c * 8 + o] : pa.We[c * 8 + o - 8]) * pa.gamma[c];
+          const int c2 = 16 * t + 4 * q + s;
+          wR[s] = p < 8 ? pa.Wr[p * DE + c2] : 0.f;
+        }
+        *reinterpret_cast<float4*>(wtab + ((0 * T + t) * 64 + lane) * 4) = make_float4(wA[t][0], wA[t][1], wA[t][2], wA[t][3]);
+        *reinterpret_cast<float4*>(wtab + ((1 * T + t) * 64 + lane) * 4) = make_float4(wB[0], wB[1], wB[2], wB[3]);
+        *reinterpret_cast<float4*>(wtab + ((2 * T + t) * 64 + lane) * 4) = make_float4(wR[0], wR[1], wR[2], wR[3]);
+      }
+      lds_sync_();
+    }
+    auto wget = [&](int which, int t) __attribute__((always_inline)) { return *reinterpret_cast<const float4*>(wtab + ((which * T + t) * 64 + lane) * 4); };
+    v4f accT[T], accW[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) { accT[t] = (v4f){0.f, 0.f, 0.f, 0.f}; accW[t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+    float4 accS = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned doff = dma_lane_off(lane);
+    // operand tiles: head slot j of a half (head j or j + 4): Q tile then dO tile
+    const float* Qh = a.pk + PK_QH * arr + ((size_t)b * AH + j) * NP * D;
+    const float* Oh = a.pk + PK_OH * arr + ((size_t)b * AH + j) * NP * D;
+    const unsigned odst = lds_addr(Ops) + j * (2 * HS * 4);
+    auto dma_half = [&](int ltile, int half) __attribute__((always_inline)) {
+      const size_t ho = (size_t)half * 4 * NP * D + (size_t)ltile * 16 * D;
+      const unsigned dst = odst + half * (4 * 2 * HS * 4);
+#pragma unroll
+      for (int Tt = 0; Tt < KT; ++Tt) {
+        dma_piece(dst + Tt * 1024, uni_ptr(Qh + ho + Tt * 256), doff);
+        dma_piece(dst + (KT + Tt) * 1024, uni_ptr(Oh + ho + Tt * 256), doff);
+      }
+    };
+    const float* st2 = a.stats2 + ((size_t)b * AH + j + 4 * ((lane >> 4) & 1)) * NP * 4;   // lanes 0..15: head j, 16..31: head j + 4 (upper lanes repeat)
+    auto stat_load = [&](int ltile) __attribute__((always_inline)) {
+      return *reinterpret_cast<const float4*>(st2 + (size_t)(ltile * 16 + (lane & 15)) * 4);
+    };
+    auto stat_put = [&](float4 v, int stage) __attribute__((always_inline)) {
+      if (lane < 32) *reinterpret_cast<float4*>(statL + ((stage * AH + j + 4 * (lane >> 4)) * 16 + (lane & 15)) * 4) = v;
+    };
+    const int mkey = m0 + p;
+    const bool keyok = mkey < N;
+    const uint32_t keyo = (uint32_t)min(mkey, N - 1) * DE + 4 * q;   // the ONE lane offset of every e / de' / de access (row pointers are wave-uniform)
+    const size_t gb = (size_t)b * N * N * DE;
+    struct HSet { float4 x[4][T], df[4][T]; float rstd[4]; };
+    auto raw_load = [&](HSet& s, int r, int ltile) __attribute__((always_inline)) {
+      const size_t ro = gb + (size_t)min(16 * ltile + 4 * j + r, N - 1) * N * DE;
+      const float* er = pa.e + ro;
+      const float* dr = pa.d_e_out + ro;
+#pragma unroll
+      for (int t = 0; t < T; ++t) s.x[r][t] = *reinterpret_cast<const float4*>(er + keyo + 16 * t);
+#pragma unroll
+      for (int t = 0; t < T; ++t) s.df[r][t] = *reinterpret_cast<const float4*>(dr + keyo + 16 * t);
+    };
+    float* xs = scr + j * (2 * 16 * DE);   // ehat tile [16 pairs][DE], 16-byte chunks XORed with (pair & 7)
+    float* dfs = xs + 16 * DE;
+    // plane offsets (ptT_off) of the wave's rows 4j + r: the row enters only through j (the chunk XOR) and r (the dword):
+    //   ptT_off(4j + r, col) = (col << 4) + (((j ^ A[col >> 2]) & 3) << 2) + r,  A = (0, 2, 3, 1)
+    // own pair (col = p): one lane value + r; pairs on the contraction axis (col = 4 s + q): (q << 4) + a wave-uniform term + r
+    const int offp = (p << 4) + (((j ^ chunk_xor(p)) & 3) << 2);
+    const int q16 = q << 4;
+    int offu[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) offu[s4] = 64 * s4 + (((j ^ chunk_xor(4 * s4)) & 3) << 2);
+    // scratch tiles: [pair][channel] with the 16-byte chunk index XORed by (pair & 7)
+    //   own row (pair p), chunk 4 t + q:        p DE + 4 ((4 t + q) ^ (p & 7))
+    //   element (pair 4 s + q, channel 16 t + p): (4 s + q) DE + 16 (t ^ (s & 1)) + 4 ((p >> 2) ^ q) + (p & 3) = lane part + constant
+    const int xw0 = p * DE + ((q ^ (p & 7)) << 2);
+    const int xrd = q * DE + (((p >> 2) ^ q) << 2) + (p & 3);
+    // PRE: tile row r of query tile `ltile` from the raw values in set s -> planes of set `ps`; ehat / de' stay in s
+    auto pre = [&](HSet& s, int r, int ltile, float* ps) __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);   // one row at a time: the allocator has no room for two rows' transients
+      const bool valid = keyok && (16 * ltile + 4 * j + r) < N;
+      s.rstd[r] = pair_ln<T>(s.x[r], pa.ln_eps);
+      v4f acc = {bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float4 wa = wget(0, t);
+        acc = MFMA(wa.x, s.x[r][t].x, acc);
+        acc = MFMA(wa.y, s.x[r][t].y, acc);
+        acc = MFMA(wa.z, s.x[r][t].z, acc);
+        acc = MFMA(wa.w, s.x[r][t].w, acc);
+      }
+      const int off = offp + r;
+      float* pl = ps + (q < 2 ? TSZ : 0) + (4 * (q & 1)) * PT_PL + off;   // q < 2: gates (slot 1), q >= 2: edge bias (slot 0)
+      pl[0] = acc[0]; pl[PT_PL] = acc[1]; pl[2 * PT_PL] = acc[2]; pl[3 * PT_PL] = acc[3];
+      if (!valid) {   // de' of a pair outside the graph must not reach dH (it is added to it) nor the weight gradients
+#pragma unroll
+        for (int t = 0; t < T; ++t) s.df[r][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      v4f ax = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float4 wr = wget(2, t);
+        ax = MFMA(wr.x, s.df[r][t].x, ax);
+        ax = MFMA(wr.y, s.df[r][t].y, ax);
+        ax = MFMA(wr.z, s.df[r][t].z, ax);
+        ax = MFMA(wr.w, s.df[r][t].w, ax);
+      }
+      if (q < 2) {   // rows 4q + i of the product = heads 4q + i
+        float* px = ps + 2 * TSZ + (4 * q) * PT_PL + off;
+        px[0] = ax[0]; px[PT_PL] = ax[1]; px[2 * PT_PL] = ax[2]; px[3 * PT_PL] = ax[3];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // POST: tile row r of query tile `ltile`: the planes of set `ps` now hold dE | dG | H_hat
+    auto post = [&](HSet& s, int r, int ltile, const float* ps) __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int lrow = 4 * j + r, l = 16 * ltile + lrow;
+      const bool valid = keyok && l < N;
+      const int off = offp + r;
+      const float* pd = ps + (q < 2 ? TSZ : 0) + (4 * (q & 1)) * PT_PL + off;
+      const float dp0 = pd[0], dp1 = pd[PT_PL], dp2 = pd[2 * PT_PL], dp3 = pd[3 * PT_PL];   // d(pre-activation) of outputs 4q..4q+3 of pair p
+      float4 dx[T];
+      float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+        const float4 wb = wget(1, t);
+        acc = MFMA(wb.x, dp0, acc);
+        acc = MFMA(wb.y, dp1, acc);
+        acc = MFMA(wb.z, dp2, acc);
+        acc = MFMA(wb.w, dp3, acc);
+        dx[t] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        m1 += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        m2 = fmaf(acc[0], s.x[r][t].x, m2); m2 = fmaf(acc[1], s.x[r][t].y, m2);
+        m2 = fmaf(acc[2], s.x[r][t].z, m2); m2 = fmaf(acc[3], s.x[r][t].w, m2);
+      }
+      m1 = pair_sum_q(m1) * (1.0f / DE);
+      m2 = pair_sum_q(m2) * (1.0f / DE);
+      const float rstd = s.rstd[r];
+      float* orow_ = pa.d_e + gb + (size_t)min(l, N - 1) * N * DE;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float4 xh = s.x[r][t], d0 = s.df[r][t];
+        const float4 o = make_float4(d0.x + rstd * (dx[t].x - m1 - xh.x * m2), d0.y + rstd * (dx[t].y - m1 - xh.y * m2),
+                                     d0.z + rstd * (dx[t].z - m1 - xh.z * m2), d0.w + rstd * (dx[t].w - m1 - xh.w * m2));
+        if (valid) *reinterpret_cast<float4*>(orow_ + keyo + 16 * t) = o;
+      }
+      // weight gradients: both operands need the pairs on the contraction axis: ehat / de' through the wave's scratch tiles
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int ch = xw0 ^ (16 * t);   // (4 t + q) ^ (p & 7): bit 2 of the chunk index <-> bit 4 of the float index
+        *reinterpret_cast<float4*>(xs + ch) = s.x[r][t];
+        *reinterpret_cast<float4*>(dfs + ch) = s.df[r][t];
+      }
+      accS.x += dp0; accS.y += dp1; accS.z += dp2; accS.w += dp3;
+      float aD[4], hA[4];
+      {
+        const int i = p;   // A row: output channel i of [gates | edge bias] / head i of H_hat
+        const float* pi = ps + (i < 8 ? TSZ : 0) + (i & 7) * PT_PL + q16 + r;
+        const float* ph = ps + 2 * TSZ + (i & 7) * PT_PL + q16 + r;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int o2 = offu[s4];
+          aD[s4] = pi[o2];
+          const float hv = ph[o2];
+          hA[s4] = i < 8 ? hv : (i == 8 ? 1.0f : 0.f);   // row 8 = ones: its product row is the bias gradient sum of de'
+        }
+      }
+      lds_sync_();
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int idx = xrd + 4 * s4 * DE + 16 * (t ^ (s4 & 1));            // [pair 4 s + q][channel 16 t + p]
+          accT[t] = MFMA(aD[s4], xs[idx], accT[t]);
+          accW[t] = MFMA(hA[s4], dfs[idx], accW[t]);
+        }
+      lds_sync_();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+    HSet H0, H1;
+    dma_half(0, 0);
+    dma_half(0, 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) raw_load(H0, r, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) raw_load(H1, r, min(1, mtiles - 1));
+    stat_put(stat_load(0), 0);
+    vm_wait<4 * 2 * T>();      // everything but the raw values of tile 1
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pre(H0, r, 0, Pl);
+    vm_wait<0>();
+    lds_barrier();             // B1(0)
+    // trip it: `prev` = set of tile it-1 (POST, then refilled with tile it+1), which PRE then turns into the held set of it+1
+    auto trip = [&](int it, HSet& prev) __attribute__((always_inline)) {
+      float* pprev = Pl + ((it + 1) & 1) * 3 * TSZ;   // planes of tile it-1 (= the set tile it+1 will use)
+      if (it > 0) dma_half(it, 1);                    // half B of this trip (trip 0: issued in the prologue)
+      if (it > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          post(prev, r, it - 1, pprev);
+          raw_load(prev, r, min(it + 1, mtiles - 1));
+        }
+        vm_wait<4 * 2 * T>();  // the DMA pieces of half B landed (only the raw loads, and stores, are younger)
+      }
+      lds_barrier();           // Bm(it)
+      if (it + 1 < mtiles) {
+        dma_half(it + 1, 0);
+        const float4 stn = stat_load(it + 1);
+        if (it > 0) {
+          vm_wait<3 * 2 * T + 2 * KT + 1>(); pre(prev, 0, it + 1, pprev);
+          vm_wait<2 * 2 * T + 2 * KT + 1>(); pre(prev, 1, it + 1, pprev);
+          vm_wait<1 * 2 * T + 2 * KT + 1>(); pre(prev, 2, it + 1, pprev);
+          vm_wait<2 * KT + 1>();             pre(prev, 3, it + 1, pprev);
+        } else {               // trip 0: tile 1's raw values were requested in the prologue
+          vm_wait<2 * KT + 1>();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pre(prev, r, it + 1, pprev);
+        }
+        vm_wait<0>();
+        stat_put(stn, (it + 1) & 1);
+      }
+      lds_barrier();           // B1(it+1)
+    };
+    // the set of tile k is H[k & 1]: trip(it) works on H[(it + 1) & 1]
+    int it = 0;
+    for (; it + 1 < mtiles; it += 2) { trip(it, H1); trip(it + 1, H0); }
+    if (it < mtiles) { trip(it, H1); ++it; }
+    // POST of the last tile
+    {
+      const float* pl = Pl + ((mtiles - 1) & 1) * 3 * TSZ;
+      if ((mtiles - 1) & 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) post(H1, r, mtiles - 1, pl);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) post(H0, r, mtiles - 1, pl);
+      }
+    }
+    // partials of this wave -> the (now idle) other plane set: [That[DE][16] | s[16] | dWr[8][DE] | dbr[DE]]
+    float* red = Pl + (mtiles & 1) * 3 * TSZ + j * (PSZ1 + PSZ2);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        red[(16 * t + p) * 16 + 4 * q + r] = accT[t][r];                 // accT[t][r] = That[c = 16 t + p][o = 4 q + r]
+        const int hrow = 4 * q + r;                                       // accW[t][r] = R[row 4 q + r][c = 16 t + p]
+        if (hrow < 8) red[PSZ1 + hrow * DE + 16 * t + p] = accW[t][r];
+        else if (hrow == 8) red[PSZ1 + AH * DE + 16 * t + p] = accW[t][r];
+      }
+    {
+      const float s0 = row_sum16(accS.x), s1 = row_sum16(accS.y), s2 = row_sum16(accS.z), s3 = row_sum16(accS.w);
+      if (p == 0) { red[DE * 16 + 4 * q] = s0; red[DE * 16 + 4 * q + 1] = s1; red[DE * 16 + 4 * q + 2] = s2; red[DE * 16 + 4 * q + 3] = s3; }
+    }
+  } else {
+    // ---------------------------------------------------------------- attention waves ----
+    const int w = wv, mm = lane & 15, q = lane >> 4;
+    const uint32_t ooff = mm * 16 + 4 * q;
+    float4 Kr[2][KT], Vr[2][KT];
+    float* dAb[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int h = w + 4 * hf;
+      const size_t hb = ((size_t)b * AH + h) * NP * D;
+      const float* Kh = a.pk + PK_KH * arr + hb;
+      const float* Vh = a.pk + PK_VH * arr + hb;
+      dAb[hf] = a.ws_dA + (((size_t)b * AH + h) * mtiles * mtiles + (size_t)mt0) * 256;   // + ltile * mtiles * 256
+#pragma unroll
+      for (int Tt = 0; Tt < KT; ++Tt) {
+        Kr[hf][Tt] = *reinterpret_cast<const float4*>(Kh + (size_t)mt0 * 16 * D + 256 * Tt + ooff);
+        Vr[hf][Tt] = *reinterpret_cast<const float4*>(Vh + (size_t)mt0 * 16 * D + 256 * Tt + ooff);
+      }
+    }
+    float kadd = 0.f;
+    {
+      const int m = m0 + mm;
+      if (m >= N) kadd = KEY_OFF;
+      else if (a.km && a.km[(size_t)b * N + m] == 0) kadd = -EGT_NEG;
+    }
+    const float kaddg = (m0 + mm) < N ? -kadd * L2E : 3.0e38f;
+    const int mc = min(m0 + mm, N - 1);
+    v4f dKacc[2][KT], dVacc[2][KT];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) { dKacc[hf][kt] = (v4f){0.f, 0.f, 0.f, 0.f}; dVacc[hf][kt] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+    const int po4 = ptT_off(4 * q, mm);   // the lane's query rows 4q..4q+3 of key mm: one 16-byte access per plane
+    // operand tiles of head slot w (Q, then dO): row form: lane (row mm, chunk q) b128; transposed: lane (channel mm, q): rows 4q + r
+    const float* oprow = Ops + w * (2 * HS) + mm * 16 + ((q ^ chunk_xor(mm)) << 2);
+    const float* optr = Ops + w * (2 * HS) + (4 * q) * 16 + (((mm >> 2) ^ chunk_xor(4 * q)) << 2) + (mm & 3);
+    lds_barrier();             // B1(0)
+    for (int l0 = 0, it = 0; it < mtiles; l0 += 16, ++it) {
+      float* ps = Pl + (it & 1) * 3 * TSZ;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int h = w + 4 * hf;
+        const float* opr = oprow + hf * (4 * 2 * HS);
+        const float* opt = optr + hf * (4 * 2 * HS);
+        float4 qa[KT], oa[KT];
+#pragma unroll
+        for (int Tt = 0; Tt < KT; ++Tt) {
+          qa[Tt] = *reinterpret_cast<const float4*>(opr + Tt * 256);
+          oa[Tt] = *reinterpret_cast<const float4*>(opr + HS + Tt * 256);
+        }
+        const float4 e4 = *reinterpret_cast<const float4*>(ps + h * PT_PL + po4);
+        const float4 g4 = *reinterpret_cast<const float4*>(ps + TSZ + h * PT_PL + po4);
+        const float4 x4 = *reinterpret_cast<const float4*>(ps + 2 * TSZ + h * PT_PL + po4);
+        float4 stc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stc[r] = *reinterpret_cast<const float4*>(statL + (((it & 1) * AH + h) * 16 + 4 * q + r) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- S[l][m] = sum_k (d^-1/2 Q)[l][k] K[m][k] ; dP[l][m] = sum_k dO[l][k] V[m][k] ----
+        v4f s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int Tt = 0; Tt < KT; ++Tt)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            s = MFMA(f4get(qa[Tt], u), f4get(Kr[hf][Tt], u), s);
+            dp = MFMA(f4get(oa[Tt], u), f4get(Vr[hf][Tt], u), dp);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        float at[4], da[4], dE4[4], dG4[4], hh4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float araw = s[r];
+          float ah = araw;
+          if (clip) ah = __builtin_amdgcn_fmed3f(araw, a.clip_lo, a.clip_hi);
+          float add = kadd;
+          if (V == 2) {
+            const int lq = min(l0 + 4 * q + r, N - 1);
+            const uint32_t gi = (uint32_t)((((size_t)b * N + lq) * N + mc) * AH + h);
+            add += ((egt_hash32(gi, a.s0, a.s1) >> 8) < a.rm_thr) ? -EGT_NEG : 0.0f;
+          }
+          const float hv = ah + f4get(e4, r);
+          const float xx = hv + add;
+          const float S = exp2_fast((xx - stc[r].x) * L2E) * stc[r].y;   // rows past N: 1/l = 0; keys past N: exp2(-inf) = 0
+          const float tg = V == 1 ? exp2_fast(fmaf(f4get(g4, r), -L2E, kaddg)) : exp2_fast((f4get(g4, r) + add) * -L2E);
+          const float g = __builtin_amdgcn_rcpf(1.0f + tg);
+          const float dAt_ = dp[r];
+          const float Sg = S * g;
+          const float dH = fmaf(S, fmaf(dAt_, g, -stc[r].z), f4get(x4, r));
+          at[r] = Sg;
+          da[r] = (clip && ah != araw) ? 0.f : dH;
+          dE4[r] = dH;
+          dG4[r] = dAt_ * Sg * (1.0f - g);
+          hh4[r] = hv;
+        }
+        *reinterpret_cast<float4*>(ps + h * PT_PL + po4) = make_float4(dE4[0], dE4[1], dE4[2], dE4[3]);
+        *reinterpret_cast<float4*>(ps + TSZ + h * PT_PL + po4) = make_float4(dG4[0], dG4[1], dG4[2], dG4[3]);
+        *reinterpret_cast<float4*>(ps + 2 * TSZ + h * PT_PL + po4) = make_float4(hh4[0], hh4[1], hh4[2], hh4[3]);
+        *reinterpret_cast<float4*>(dAb[hf] + (size_t)it * mtiles * 256 + ooff) = make_float4(da[0], da[1], da[2], da[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dV^T[k][m] += sum_l dO[l][k] A[l][m] ; dK^T[k][m] += sum_l (d^-1/2 Q)[l][k] dA[l][m] ----
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float qq = opt[kt * 256 + r * 16];
+            const float oo = opt[HS + kt * 256 + r * 16];
+            dVacc[hf][kt] = MFMA(oo, at[r], dVacc[hf][kt]);
+            dKacc[hf][kt] = MFMA(qq, da[r], dKacc[hf][kt]);
+          }
+        lds_barrier();         // Bm(it) after half A, B1(it+1) after half B
+      }
+    }
+    // dK / dV into the (now idle) operand stages as [key][k][8 heads]: dK in the first 32 KB, dV in the second
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      float* ks = sm + (mm * D + 4 * q) * AH + w + 4 * hf;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ks[(16 * kt + r) * AH] = dKacc[hf][kt][r];
+          ks[16 * DH + (16 * kt + r) * AH] = dVacc[hf][kt][r];
+        }
+    }
+  }
+  lds_barrier();
+  // dK / dV rows of d_qkv: 16 keys x 512 channels each, 16-byte pieces
+  for (int pz = tid; pz < 16 * DH / 4; pz += 64 * PR_WAVES) {
+    const int row = pz / (DH / 4), c = (pz % (DH / 4)) * 4;
+    if (m0 + row < N) {
+      float* o = a.d_qkv + ((size_t)b * N + m0 + row) * 3 * DH + c;
+      *reinterpret_cast<float4*>(o + DH) = *reinterpret_cast<const float4*>(sm + (size_t)pz * 4);
+      *reinterpret_cast<float4*>(o + 2 * DH) = *reinterpret_cast<const float4*>(sm + 16 * DH + (size_t)pz * 4);
+    }
+  }
+  // parameter-gradient partials of the workgroup: the four edge waves' images summed in a fixed order
+  {
+    const float* red = Pl + (mtiles & 1) * 3 * TSZ;
+    for (int i = tid; i < PSZ1 + PSZ2; i += 64 * PR_WAVES) {
+      const float v = (red[i] + red[(PSZ1 + PSZ2) + i]) + (red[2 * (PSZ1 + PSZ2) + i] + red[3 * (PSZ1 + PSZ2) + i]);
+      if (i < PSZ1) pa.part_proj[(size_t)wg * PSZ1 + i] = v;
+      else pa.part_upd[(size_t)wg * PSZ2 + (i - PSZ1)] = v;
+    }
+  }
+}

@@ -242,7 +242,13 @@ class EGTBlock(nn.Module):
             return h, e
         if self._use_fused(h, e, attn_mask, rand_mask):
             from .fused import block_fused
+            self.last_path = "fused"
             return block_fused(self, h, e, mask, attn_mask, rand_mask)
+        if self._use_pair(h, e, attn_mask, rand_mask, node_keep, edge_keep):
+            from .pair import block_pair      # large heads (d = 64): fused pair operator + library GEMMs on the node side
+            self.last_path = "fused-pair"
+            return block_pair(self, h, e, mask)
+        self.last_path = "composed"
         use_ln = ect in ('residual', 'constrained') and not self.add_n_norm
         ne = getattr(self, 'norm_edge', None)
         ag = getattr(self, 'attention_gates', None)
@@ -265,6 +271,12 @@ class EGTBlock(nn.Module):
             e = self.norm_edge(e)                                   # :220-221
         return h, e
 
+    def _use_pair(self, h, e, attn_mask, rand_mask, node_keep, edge_keep):
+        if self.fused is False or self.fused == 'off' or node_keep is not None or edge_keep is not None:
+            return False
+        from . import pair as PZ
+        return PZ.pair_supported(self, h, e, attn_mask, rand_mask)
+
     def _use_fused(self, h, e, attn_mask, rand_mask):
         if self.fused is False or self.fused == 'off':
             return False
@@ -275,7 +287,7 @@ class EGTBlock(nn.Module):
                 raise
             return False
         ok = FZ.block_supported(self, h, e, attn_mask, rand_mask)
-        if not ok and self.fused in (True, 'on'):
+        if not ok and self.fused in (True, 'on') and not self._use_pair(h, e, attn_mask, rand_mask, None, None):
             raise RuntimeError("fused EGT block requested but this configuration is not covered by it")
         return ok
 

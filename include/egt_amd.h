@@ -322,6 +322,28 @@ int egt_stack_bwd(const egt_block_desc* desc, int32_t layers,
                   const void* d_h_out, const void* d_e_out, void* d_h, void* d_e,
                   const egt_block_params* grads, void* workspace, void* stream);
 
+/* ---- the fused pair operator at large heads (BASELINE config 5: N = 512, d = 64, De = 32) ------------------
+ *   (V_att, e') = norm_edge -> attention_gates / dense_edge_b -> EGT([QKV,E,G],mask) -> dense_edge_r + res_edge
+ * Replaces graph_xformer_model_base.py:195-218 (edge_update_residual around mha_block's EGT call, :117-131) with
+ * lib/models/egt_layers.py:57-143 inside, for gated 'residual' edge channels: ONE pair kernel per direction streams
+ * e (and de' in the backward) once; E, G, H_hat, dE, dG, dH_ext exist only in LDS.  At this head width the
+ * node-side Dense layers of mha_block (norm_mha, dense_qkv :109-113, dense_mha :136) are [B N, 512] GEMMs and stay
+ * with the caller (library GEMMs): the operator takes QKV [B,N,3 d H] (channel s*dH + k*H + h, egt_layers.py:73-76)
+ * and returns V_att [B,N,d H].  egt_block_desc / egt_block_params are reused (node-side pointers are ignored);
+ * desc->reserved & EGT_ATTN_WS_SHARED: the caller hands the forward's untouched workspace to the backward
+ * (the q / k / v operand copies are then made once).  In-kernel random mask as in egt_block_fwd. */
+int egt_pair_supported(const egt_block_desc* desc);
+size_t egt_pair_workspace_bytes(const egt_block_desc* desc);
+int egt_pair_fwd(const egt_block_desc* desc, const egt_block_params* params, const void* qkv,
+                 const void* e, const uint8_t* key_mask, void* v_att, void* e_out, void* rowstats,
+                 void* workspace, void* stream);
+/* rowstats [B,N,H,4] is the forward's output (read; slot 3 written).  d_e may alias d_e_out.  Every edge-side
+ * pointer of `grads` is written (norm_edge_*, attention_gates_*, dense_edge_b_*, dense_edge_r_*). */
+int egt_pair_bwd(const egt_block_desc* desc, const egt_block_params* params, const void* qkv,
+                 const void* e, const uint8_t* key_mask, const void* v_att, void* rowstats,
+                 const void* d_v_att, const void* d_e_out, void* d_qkv, void* d_e,
+                 const egt_block_params* grads, void* workspace, void* stream);
+
 /* ---- channel FFN (the step after the attention block in every layer) ----
  * Replaces ffnlr1 / ffnact / ffnlr2 of lib/models/graph_xformer_model_base.py:230-258 as
  * ffn_block applies them (:309-324; pre-norm, no cross-talk, ffn_multiplier = 2):

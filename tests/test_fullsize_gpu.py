@@ -300,9 +300,10 @@ def test_synthetic_n512_d64_mfma_forward_and_backward_vs_oracle(gpu, egt_lib):
 
 
 def test_synthetic_n512_block_scope_vs_oracle(gpu, egt_lib):
-    """BASELINE config 5 at block scope: (h, e, mask) -> (h', e') of ONE block at B=1, N=512, Dh=512 (d=64), De=32
-    (tools/bench_block_cfg5.py's composition: HIP edge projections + MFMA inner op + node-side Dense) forward and
-    backward against block_oracle (graph_xformer_model_base.py:106-145,192-223)."""
+    """BASELINE config 5 at block scope: (h, e, mask) -> (h', e') of ONE block at B=1, N=512, Dh=512 (d=64), De=32 on the
+    FUSED pair operator (k_pair_fwd / k_pair_bwd: E, G, H_hat, dE, dG, dH_ext stay in LDS; node-side Dense layers as library
+    GEMMs) forward and backward against block_oracle (graph_xformer_model_base.py:106-145,192-223); the launch names are read
+    back through egt_prof_names."""
     from oracle import egt_oracle as O
     from test_block_gpu import build_block
     g = torch.Generator().manual_seed(56)
@@ -314,8 +315,20 @@ def test_synthetic_n512_block_scope_vs_oracle(gpu, egt_lib):
     attrs = dict(gate_attention=True, edge_activation=None, edge_channel_type="residual")
     blk = build_block(dict(Dh=Dh, De=De), attrs, params, gpu, "auto").eval()
     hg = h.to(gpu).requires_grad_(); eg = e.to(gpu).requires_grad_()
-    h2, e2 = blk(hg, eg, mask.to(gpu))
-    torch.autograd.backward([h2, e2], [dh.to(gpu), de.to(gpu)])
+    import ctypes as C
+    egt_lib.egt_prof_filter(b""); egt_lib.egt_prof_enable(2)
+    try:
+        h2, e2 = blk(hg, eg, mask.to(gpu))
+        torch.autograd.backward([h2, e2], [dh.to(gpu), de.to(gpu)])
+        torch.cuda.synchronize()
+    finally:
+        egt_lib.egt_prof_enable(0)
+    buf = C.create_string_buffer(4096)
+    egt_lib.egt_prof_names(buf, 4096)
+    names = buf.value.decode().split()
+    assert blk.last_path == "fused-pair" and "k_pair_fwd" in names and "k_pair_bwd" in names, (blk.last_path, names)
+    assert not {"k_edge_proj_fwd", "k_edge_proj_bwd", "k_edge_update_fwd", "k_edge_update_bwd", "k_attn_mfma_fwd", "k_attn_mfma_bwd_kv"} & set(names), names
+    # (no [B,N,N,8] tensor round trip: none of the composed path's projection / inner-op / update launches)
     inp = dict(h=h, e=e, mask=mask, attn_mask=None, rand_mask=None, dh=dh, de=de)
     ref = CS.block_oracle(inp, params, dict(num_heads=8, **attrs))
     assert_close(h2, ref["h_out"], name="h_out", **FWD)
