@@ -1281,7 +1281,7 @@ extern "C" int egt_pair_fwd(const egt_block_desc* desc, const egt_block_params* 
   hipStream_t st = (hipStream_t)stream;
   launch_pack<64>(a, st);
   constexpr int D = 64, DE = 32, HS = (D / 16) * 256;
-  const size_t lds = ((size_t)3 * AH * HS + 2 * (size_t)((a.NP + 16 + 3) & ~3) + (size_t)3 * AH * PT_PL) * sizeof(float);
+  const size_t lds = ((size_t)3 * AH * HS + 2 * (size_t)((a.NP + 16 + 3) & ~3) + (size_t)5 * AH * PT_PL) * sizeof(float);
   const int grid = a.B * (a.NP / 16);
   if (a.rng_rm) {
     EGT_MAX_LDS_ONCE(k_pair_fwd<D, DE, 2>);
@@ -1319,7 +1319,7 @@ extern "C" int egt_pair_bwd(const egt_block_desc* desc, const egt_block_params* 
   a.pack_what = PACK_O | ((desc->reserved & EGT_ATTN_WS_SHARED) ? 0 : (PACK_Q | PACK_KH | PACK_KT | PACK_VH));
   hipStream_t st = (hipStream_t)stream;
   launch_pack<64>(a, st);   // (also the per-row constants, delta = sum_k dO*O among them)
-  const size_t lds = ((size_t)2 * 4 * 2 * HS + (size_t)2 * 3 * AH * PT_PL + (size_t)2 * AH * 64 + (size_t)4 * 2 * 16 * DE + (size_t)3 * (DE / 16) * 64 * 4) * sizeof(float);
+  const size_t lds = ((size_t)2 * 4 * 2 * HS + (size_t)2 * 3 * AH * PT_PL + (size_t)2 * AH * 64 + (size_t)4 * 2 * 16 * DE + (size_t)3 * (DE / 16) * 64 * 4 + 64 * 4 + 4 * 2 * 4 * 16) * sizeof(float);
   if (a.rng_rm) {
     EGT_MAX_LDS_ONCE(k_pair_bwd<D, DE, 2>);
     EGT_LAUNCH("k_pair_bwd", (k_pair_bwd<D, DE, 2>), dim3(nwg), dim3(64 * PR_WAVES), lds, st, a, pa);

@@ -97,9 +97,9 @@ __device__ __forceinline__ void pair_fold_weights(const PairArgs& pa, int i, int
 
 // ================================================================== forward =====
 // LDS: Kb [8 heads][KT tiles] (one stage: K(it+1) lands while the attention waves are in their softmax / A.V phase), Vb two stages,
-// the two per-key additive tables, planes E | G (in) and H_hat (out), one stage each:
-//   barrier B1(it): planes E, G of tile it written, K(it) landed      -> attention: S = K.Q^T          edge: dense_edge_r of tile it-1
-//   barrier B2(it): H_hat(it-1) consumed, E / G(it) read, K(it) read  -> attention: softmax, H_hat, A.V edge: DMA K(it+1), V(it+1); LN + projections of tile it+1
+// the two per-key additive tables, planes E | G (in, two stages) and H_hat (out, one stage):
+//   barrier B1(it): planes E, G of tile it written, K(it) landed      -> attention: S = K.Q^T           edge: dense_edge_r of tile it-1; LN + projections of tile it+1, rows 0-1
+//   barrier B2(it): H_hat(it-1) consumed, K(it) read                  -> attention: softmax, H_hat, A.V edge: DMA K(it+1), V(it+1); e(it+2) requested; rows 2-3 of tile it+1
 template <int D, int DE, int V>
 __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, PairArgs pa) {
   constexpr int KT = D / 16, DH = D * AH, T = PairGeo<DE>::T, HS = KT * 256;   // HS: floats of one head's operand tile
@@ -111,9 +111,9 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
   float* Vb = Kb + AH * HS;            // [2][8][HS]
   float* kaddL = Vb + 2 * AH * HS;     // [KA]
   float* kaddG = kaddL + KA;
-  float* InE = kaddG + KA;             // [8][PT_PL]
+  float* InE = kaddG + KA;             // [2 stages][E | G][8][PT_PL]
   float* InG = InE + AH * PT_PL;
-  float* Hp = InG + AH * PT_PL;
+  float* Hp = InE + 4 * AH * PT_PL;    // [8][PT_PL]
   const int wg = egt_xcd_remap(blockIdx.x, gridDim.x);   // the row blocks of a graph share an XCD's L2 (K / V^T of the graph: 2 MB)
   const int b = __builtin_amdgcn_readfirstlane(wg / mtiles), l0 = __builtin_amdgcn_readfirstlane((wg % mtiles) * 16);   // (the division runs on the VALU: back to scalar registers)
   const size_t arr = (size_t)a.B * AH * NP * D;
@@ -175,10 +175,10 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
 #pragma unroll
         for (int t = 0; t < T; ++t) s.x[r][t] = egt_ld4_nt_(erow[r] + mo + 16 * t);
     };
-    // LN + projections of tile mt from set s -> planes
-    auto project = [&](const ESet& s) __attribute__((always_inline)) {
+    // LN + projections of rows r0, r0 + 1 of a tile from set s -> planes of stage st
+    auto project = [&](const ESet& s, int st, int r0) __attribute__((always_inline)) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = r0; r < r0 + 2; ++r) {
         float4 x[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) x[t] = s.x[r][t];
@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
           acc = MFMA(wA[t][3], x[t].w, acc);
         }
         // lane holds outputs 4q..4q+3 of pair (row 4j + r, key p): q < 2 gates of heads 4q + i, q >= 2 edge bias of heads 4(q-2) + i
-        float* pl = (q < 2 ? InG : InE) + (4 * (q & 1)) * PT_PL + pt_off(4 * j + r, p);
+        float* pl = (q < 2 ? InG : InE) + st * (2 * AH * PT_PL) + (4 * (q & 1)) * PT_PL + pt_off(4 * j + r, p);
         pl[0] = acc[0]; pl[PT_PL] = acc[1]; pl[2 * PT_PL] = acc[2]; pl[3 * PT_PL] = acc[3];
       }
     };
@@ -219,19 +219,20 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
     eload(S0, 0);
     eload(S1, min(1, mtiles - 1));
     vm_wait<4 * T>();          // K(0), V(0) and e(0) landed; e(1) may still be in flight
-    project(S0);
+    project(S0, 0, 0);
+    project(S0, 0, 2);
     lds_barrier();             // B1(0)
     // one trip = [U(it-1)] B2 [DMA(it+1), loads(it+2), project(it+1)] B1; the three register sets rotate: (cur, nxt, pre) = e(it-1), e(it+1)... see below
     auto trip = [&](int it, ESet& done, ESet& nxt) __attribute__((always_inline)) {
       // `done` holds e(it-1) (consumed by this trip's update, then refilled with e(it+2)); `nxt` holds e(it+1)
+      // (the compiler's own vmcnt bookkeeping does not see the LDS-DMA pieces: no DMA may sit between a register load and its first
+      //  use, or the inserted wait would drain pieces that were only just issued.  e(it+1) is first used HERE, before this trip's DMA)
       if (it > 0) update(done, it - 1);
+      if (it + 1 < mtiles) project(nxt, (it + 1) & 1, 0);
       lds_barrier();           // B2(it)
       if (it + 1 < mtiles) dma_ops(it + 1);
       eload(done, min(it + 2, mtiles - 1));
-      if (it + 1 < mtiles) {
-        vm_wait<4 * T + 4 * KT>();   // e(it+1) (requested a trip ago) is older than this trip's DMA pieces and loads
-        project(nxt);
-      }
+      if (it + 1 < mtiles) project(nxt, (it + 1) & 1, 2);
       vm_wait<4 * T>();        // the DMA pieces landed (only this trip's e loads are younger)
       lds_barrier();           // B1(it+1)
     };
@@ -289,8 +290,8 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
       if (V == 1) kg4 = *reinterpret_cast<const float4*>(kaddG + m0 + 4 * q);
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        e4[hh] = *reinterpret_cast<const float4*>(InE + hh * PT_PL + po4);
-        g4[hh] = *reinterpret_cast<const float4*>(InG + hh * PT_PL + po4);
+        e4[hh] = *reinterpret_cast<const float4*>(InE + (it & 1) * (2 * AH * PT_PL) + hh * PT_PL + po4);
+        g4[hh] = *reinterpret_cast<const float4*>(InG + (it & 1) * (2 * AH * PT_PL) + hh * PT_PL + po4);
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- S^T[m][l] = sum_k K[m][k] (d^-1/2 Q)[l][k], two heads ----
@@ -397,7 +398,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
 //   four heads (32 KB), two stages -> the tiles of the next half-trip land while this one computes, and a wave keeps only one
 //   head's transient state beside the K / V fragments and dK / dV accumulators of its two heads (the transposed operand
 //   forms are read from the same tiles just in time);
-//   edge wave j owns query rows 4j..4j+3 of the tile: PRE(it+1) = e, de' tile -> LayerNorm, G / E projection, dH_ext = de'.Wr^T
+//   edge wave j owns query rows j, j + 4, j + 8, j + 12 of the tile (the row enters the plane offsets as a compile-time chunk XOR + the dword j): PRE(it+1) = e, de' tile -> LayerNorm, G / E projection, dH_ext = de'.Wr^T
 //   -> planes; POST(it-1) = dG / dE / H_hat planes (written by the attention waves IN PLACE of G / E / dH_ext) ->
 //   d ehat = Wp.dGE, LayerNorm backward, de = de' + .. stored; weight gradients T += ehat^T.dGE, R += de'^T.[H_hat | 1] on the
 //   matrix core (accumulators live for the whole workgroup -> deterministic partials).  ehat and de' of a tile stay in the
@@ -415,7 +416,8 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
   float* Pl = Ops + 2 * 4 * 2 * HS;        // [2 sets][E | G | X][8][PT_PL]
   float* statL = Pl + 2 * 3 * TSZ;         // [2 stages][8 heads][16 rows][4]
   float* scr = statL + 2 * AH * 64;        // [4 edge waves][ehat tile | de' tile][16][DE]
-  float* wtab = scr + 4 * 2 * 16 * DE;     // [wA | wB | wR][T][64 lanes][4]: the edge waves' lane-constant MFMA A operands (24 registers otherwise)
+  float* wtab = scr + 4 * 2 * 16 * DE;     // [wA | wB | wR][T][64 lanes][4] | bias [64][4]: the edge waves' lane-constant MFMA A operands (28 registers
+                                           // otherwise); then [4 waves][2 sets][4 rows][16] 1 / sigma of the held tiles
   const int wg = egt_xcd_remap(blockIdx.x, gridDim.x);
   const int b = __builtin_amdgcn_readfirstlane(wg / mtiles), mt0 = __builtin_amdgcn_readfirstlane(wg % mtiles), m0 = mt0 * 16;
   const size_t arr = (size_t)a.B * AH * NP * D;
@@ -424,8 +426,8 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
   if (wv >= 4) {
     // --------------------------------------------------------------------- edge waves ----
     const int j = wv - 4, p = lane & 15, q = lane >> 4;
-    float bias[4];
     {
+      float bias[4];
       // every edge wave writes the same table (same values: a benign race), then reads only after its own writes completed
       float wA[T][4];
       pair_fold_weights<DE>(pa, p, q, wA, bias);
@@ -443,6 +445,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
         *reinterpret_cast<float4*>(wtab + ((1 * T + t) * 64 + lane) * 4) = make_float4(wB[0], wB[1], wB[2], wB[3]);
         *reinterpret_cast<float4*>(wtab + ((2 * T + t) * 64 + lane) * 4) = make_float4(wR[0], wR[1], wR[2], wR[3]);
       }
+      *reinterpret_cast<float4*>(wtab + (3 * T * 64 + lane) * 4) = make_float4(bias[0], bias[1], bias[2], bias[3]);
       lds_sync_();
     }
     auto wget = [&](int which, int t) __attribute__((always_inline)) { return *reinterpret_cast<const float4*>(wtab + ((which * T + t) * 64 + lane) * 4); };
@@ -473,39 +476,48 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
     };
     const int mkey = m0 + p;
     const bool keyok = mkey < N;
-    const uint32_t keyo = (uint32_t)min(mkey, N - 1) * DE + 4 * q;   // the ONE lane offset of every e / de' / de access (row pointers are wave-uniform)
+    const uint32_t keyb = ((uint32_t)min(mkey, N - 1) * DE + 4 * q) * 4;   // the ONE lane offset (bytes, 32 bit) of every e / de' / de access: row pointers are wave-uniform
     const size_t gb = (size_t)b * N * N * DE;
-    struct HSet { float4 x[4][T], df[4][T]; float rstd[4]; };
+    struct HSet { float4 x[4][T], df[4][T]; };
+    float* rsd = wtab + 3 * T * 64 * 4 + 64 * 4 + j * (2 * 4 * 16);   // 1 / sigma of the held tiles: [set][row][pair] (8 registers otherwise)
     auto raw_load = [&](HSet& s, int r, int ltile) __attribute__((always_inline)) {
-      const size_t ro = gb + (size_t)min(16 * ltile + 4 * j + r, N - 1) * N * DE;
-      const float* er = pa.e + ro;
-      const float* dr = pa.d_e_out + ro;
+      const size_t ro = (gb + (size_t)min(16 * ltile + 4 * r + j, N - 1) * N * DE) * sizeof(float);   // wave-uniform: scalar registers
+      const char* er = reinterpret_cast<const char*>(pa.e) + ro;
+      const char* dr = reinterpret_cast<const char*>(pa.d_e_out) + ro;
 #pragma unroll
-      for (int t = 0; t < T; ++t) s.x[r][t] = *reinterpret_cast<const float4*>(er + keyo + 16 * t);
+      for (int t = 0; t < T; ++t) s.x[r][t] = *reinterpret_cast<const float4*>(er + keyb + 64 * t);
 #pragma unroll
-      for (int t = 0; t < T; ++t) s.df[r][t] = *reinterpret_cast<const float4*>(dr + keyo + 16 * t);
+      for (int t = 0; t < T; ++t) s.df[r][t] = *reinterpret_cast<const float4*>(dr + keyb + 64 * t);
+    };
+    // de' of a held tile is NOT kept in registers from PRE to POST (two sets x four rows x 8 registers that the allocator does not have:
+    // spill reloads wait on vmcnt(0), i.e. drain the wave's whole prefetch queue): POST reads it again -- a tile this CU streamed one
+    // trip ago, served by L2 / the memory-side cache
+    auto df_load = [&](HSet& s, int r, int ltile) __attribute__((always_inline)) {
+      const char* dr = reinterpret_cast<const char*>(pa.d_e_out) + (gb + (size_t)min(16 * ltile + 4 * r + j, N - 1) * N * DE) * sizeof(float);
+#pragma unroll
+      for (int t = 0; t < T; ++t) s.df[r][t] = *reinterpret_cast<const float4*>(dr + keyb + 64 * t);
     };
     float* xs = scr + j * (2 * 16 * DE);   // ehat tile [16 pairs][DE], 16-byte chunks XORed with (pair & 7)
     float* dfs = xs + 16 * DE;
-    // plane offsets (ptT_off) of the wave's rows 4j + r: the row enters only through j (the chunk XOR) and r (the dword):
-    //   ptT_off(4j + r, col) = (col << 4) + (((j ^ A[col >> 2]) & 3) << 2) + r,  A = (0, 2, 3, 1)
-    // own pair (col = p): one lane value + r; pairs on the contraction axis (col = 4 s + q): (q << 4) + a wave-uniform term + r
-    const int offp = (p << 4) + (((j ^ chunk_xor(p)) & 3) << 2);
-    const int q16 = q << 4;
-    int offu[4];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) offu[s4] = 64 * s4 + (((j ^ chunk_xor(4 * s4)) & 3) << 2);
+    // plane offsets (ptT_off) of the wave's rows 4 r + j: the row enters through r (the chunk XOR, compile time) and j (the dword):
+    //   ptT_off(4 r + j, col) = (col << 4) + (((r ^ A[col >> 2]) & 3) << 2) + j,  A = (0, 2, 3, 1)
+    // own pair (col = p): (p << 4) + j + 4 ((r ^ A[p >> 2]) & 3); pairs on the contraction axis (col = 4 s + q): (q << 4) + j + a
+    // compile-time constant -> ONE address register for the sixteen transposed reads of a row
+    const int offp0 = (p << 4) + j, ap4 = chunk_xor(p) << 2;
+    const int q16 = (q << 4) + j;
     // scratch tiles: [pair][channel] with the 16-byte chunk index XORed by (pair & 7)
     //   own row (pair p), chunk 4 t + q:        p DE + 4 ((4 t + q) ^ (p & 7))
     //   element (pair 4 s + q, channel 16 t + p): (4 s + q) DE + 16 (t ^ (s & 1)) + 4 ((p >> 2) ^ q) + (p & 3) = lane part + constant
     const int xw0 = p * DE + ((q ^ (p & 7)) << 2);
     const int xrd = q * DE + (((p >> 2) ^ q) << 2) + (p & 3);
     // PRE: tile row r of query tile `ltile` from the raw values in set s -> planes of set `ps`; ehat / de' stay in s
-    auto pre = [&](HSet& s, int r, int ltile, float* ps) __attribute__((always_inline)) {
+    auto pre = [&](HSet& s, int set, int r, int ltile, float* ps) __attribute__((always_inline)) {
       __builtin_amdgcn_sched_barrier(0);   // one row at a time: the allocator has no room for two rows' transients
-      const bool valid = keyok && (16 * ltile + 4 * j + r) < N;
-      s.rstd[r] = pair_ln<T>(s.x[r], pa.ln_eps);
-      v4f acc = {bias[0], bias[1], bias[2], bias[3]};
+      const bool valid = keyok && (16 * ltile + 4 * r + j) < N;
+      const float rstd_ = pair_ln<T>(s.x[r], pa.ln_eps);
+      if (q == 0) rsd[(set * 4 + r) * 16 + p] = rstd_;
+      const float4 b4 = wget(3, 0);
+      v4f acc = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const float4 wa = wget(0, t);
@@ -514,7 +526,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
         acc = MFMA(wa.z, s.x[r][t].z, acc);
         acc = MFMA(wa.w, s.x[r][t].w, acc);
       }
-      const int off = offp + r;
+      const int off = offp0 + (ap4 ^ (4 * r));
       float* pl = ps + (q < 2 ? TSZ : 0) + (4 * (q & 1)) * PT_PL + off;   // q < 2: gates (slot 1), q >= 2: edge bias (slot 0)
       pl[0] = acc[0]; pl[PT_PL] = acc[1]; pl[2 * PT_PL] = acc[2]; pl[3 * PT_PL] = acc[3];
       if (!valid) {   // de' of a pair outside the graph must not reach dH (it is added to it) nor the weight gradients
@@ -537,11 +549,15 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
       __builtin_amdgcn_sched_barrier(0);
     };
     // POST: tile row r of query tile `ltile`: the planes of set `ps` now hold dE | dG | H_hat
-    auto post = [&](HSet& s, int r, int ltile, const float* ps) __attribute__((always_inline)) {
+    auto post = [&](HSet& s, int set, int r, int ltile, const float* ps) __attribute__((always_inline)) {
       __builtin_amdgcn_sched_barrier(0);
-      const int lrow = 4 * j + r, l = 16 * ltile + lrow;
+      const int l = 16 * ltile + 4 * r + j;
       const bool valid = keyok && l < N;
-      const int off = offp + r;
+      if (!valid) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) s.df[r][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const int off = offp0 + (ap4 ^ (4 * r));
       const float* pd = ps + (q < 2 ? TSZ : 0) + (4 * (q & 1)) * PT_PL + off;
       const float dp0 = pd[0], dp1 = pd[PT_PL], dp2 = pd[2 * PT_PL], dp3 = pd[3 * PT_PL];   // d(pre-activation) of outputs 4q..4q+3 of pair p
       float4 dx[T];
@@ -561,14 +577,14 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
       }
       m1 = pair_sum_q(m1) * (1.0f / DE);
       m2 = pair_sum_q(m2) * (1.0f / DE);
-      const float rstd = s.rstd[r];
-      float* orow_ = pa.d_e + gb + (size_t)min(l, N - 1) * N * DE;
+      const float rstd = rsd[(set * 4 + r) * 16 + p];
+      char* orow_ = reinterpret_cast<char*>(pa.d_e) + (gb + (size_t)min(l, N - 1) * N * DE) * sizeof(float);
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const float4 xh = s.x[r][t], d0 = s.df[r][t];
         const float4 o = make_float4(d0.x + rstd * (dx[t].x - m1 - xh.x * m2), d0.y + rstd * (dx[t].y - m1 - xh.y * m2),
                                      d0.z + rstd * (dx[t].z - m1 - xh.z * m2), d0.w + rstd * (dx[t].w - m1 - xh.w * m2));
-        if (valid) *reinterpret_cast<float4*>(orow_ + keyo + 16 * t) = o;
+        if (valid) *reinterpret_cast<float4*>(orow_ + keyb + 64 * t) = o;
       }
       // weight gradients: both operands need the pairs on the contraction axis: ehat / de' through the wave's scratch tiles
 #pragma unroll
@@ -581,11 +597,11 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
       float aD[4], hA[4];
       {
         const int i = p;   // A row: output channel i of [gates | edge bias] / head i of H_hat
-        const float* pi = ps + (i < 8 ? TSZ : 0) + (i & 7) * PT_PL + q16 + r;
-        const float* ph = ps + 2 * TSZ + (i & 7) * PT_PL + q16 + r;
+        const float* pi = ps + (i < 8 ? TSZ : 0) + (i & 7) * PT_PL + q16;
+        const float* ph = ps + 2 * TSZ + (i & 7) * PT_PL + q16;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-          const int o2 = offu[s4];
+          const int o2 = 64 * s4 + (((r ^ ((0x78 >> (2 * s4)) & 3)) & 3) << 2);   // compile-time: ptT_off(4 r + j, 4 s + q) - (q << 4) - j
           aD[s4] = pi[o2];
           const float hv = ph[o2];
           hA[s4] = i < 8 ? hv : (i == 8 ? 1.0f : 0.f);   // row 8 = ones: its product row is the bias gradient sum of de'
@@ -614,17 +630,20 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
     stat_put(stat_load(0), 0);
     vm_wait<4 * 2 * T>();      // everything but the raw values of tile 1
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pre(H0, r, 0, Pl);
+    for (int r = 0; r < 4; ++r) pre(H0, 0, r, 0, Pl);
     vm_wait<0>();
     lds_barrier();             // B1(0)
     // trip it: `prev` = set of tile it-1 (POST, then refilled with tile it+1), which PRE then turns into the held set of it+1
-    auto trip = [&](int it, HSet& prev) __attribute__((always_inline)) {
-      float* pprev = Pl + ((it + 1) & 1) * 3 * TSZ;   // planes of tile it-1 (= the set tile it+1 will use)
-      if (it > 0) dma_half(it, 1);                    // half B of this trip (trip 0: issued in the prologue)
+    auto trip = [&](int it, HSet& prev, int set) __attribute__((always_inline)) {
+      float* pprev = Pl + set * 3 * TSZ;              // planes of tile it-1 (= the set tile it+1 will use): (it + 1) & 1 == set, a compile-time constant here
       if (it > 0) {
+        dma_half(it, 1);       // half B of this trip (trip 0: issued in the prologue); BEFORE the register loads below: the compiler's own
+                               // vmcnt bookkeeping does not see the DMA pieces, so none may sit between a load and its first use
+#pragma unroll
+        for (int r = 0; r < 4; ++r) df_load(prev, r, it - 1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          post(prev, r, it - 1, pprev);
+          post(prev, set, r, it - 1, pprev);
           raw_load(prev, r, min(it + 1, mtiles - 1));
         }
         vm_wait<4 * 2 * T>();  // the DMA pieces of half B landed (only the raw loads, and stores, are younger)
@@ -634,14 +653,14 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
         dma_half(it + 1, 0);
         const float4 stn = stat_load(it + 1);
         if (it > 0) {
-          vm_wait<3 * 2 * T + 2 * KT + 1>(); pre(prev, 0, it + 1, pprev);
-          vm_wait<2 * 2 * T + 2 * KT + 1>(); pre(prev, 1, it + 1, pprev);
-          vm_wait<1 * 2 * T + 2 * KT + 1>(); pre(prev, 2, it + 1, pprev);
-          vm_wait<2 * KT + 1>();             pre(prev, 3, it + 1, pprev);
+          vm_wait<3 * 2 * T + 2 * KT + 1>(); pre(prev, set, 0, it + 1, pprev);
+          vm_wait<2 * 2 * T + 2 * KT + 1>(); pre(prev, set, 1, it + 1, pprev);
+          vm_wait<1 * 2 * T + 2 * KT + 1>(); pre(prev, set, 2, it + 1, pprev);
+          vm_wait<2 * KT + 1>();             pre(prev, set, 3, it + 1, pprev);
         } else {               // trip 0: tile 1's raw values were requested in the prologue
           vm_wait<2 * KT + 1>();
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pre(prev, r, it + 1, pprev);
+          for (int r = 0; r < 4; ++r) pre(prev, set, r, it + 1, pprev);
         }
         vm_wait<0>();
         stat_put(stn, (it + 1) & 1);
@@ -650,17 +669,21 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
     };
     // the set of tile k is H[k & 1]: trip(it) works on H[(it + 1) & 1]
     int it = 0;
-    for (; it + 1 < mtiles; it += 2) { trip(it, H1); trip(it + 1, H0); }
-    if (it < mtiles) { trip(it, H1); ++it; }
+    for (; it + 1 < mtiles; it += 2) { trip(it, H1, 1); trip(it + 1, H0, 0); }
+    if (it < mtiles) { trip(it, H1, 1); ++it; }
     // POST of the last tile
     {
       const float* pl = Pl + ((mtiles - 1) & 1) * 3 * TSZ;
       if ((mtiles - 1) & 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) post(H1, r, mtiles - 1, pl);
+        for (int r = 0; r < 4; ++r) df_load(H1, r, mtiles - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) post(H1, 1, r, mtiles - 1, pl);
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) post(H0, r, mtiles - 1, pl);
+        for (int r = 0; r < 4; ++r) df_load(H0, r, mtiles - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) post(H0, 0, r, mtiles - 1, pl);
       }
     }
     // partials of this wave -> the (now idle) other plane set: [That[DE][16] | s[16] | dWr[8][DE] | dbr[DE]]
