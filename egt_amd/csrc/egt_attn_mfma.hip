@@ -1230,7 +1230,7 @@ extern "C" int egt_pair_supported(const egt_block_desc* d) {
 
 static size_t pair_partial_floats(const egt_block_desc* d) {   // per-workgroup partials + one reduced image each
   const size_t nwg = (size_t)d->B * (np_of(d->N) / 16);
-  return (nwg + 1) * ((size_t)d->De * 16 + 16) + (nwg + 1) * ((size_t)AH * d->De + d->De);
+  return (nwg + 1) * ((size_t)d->De * 16 + 16) + (nwg + 1) * ((size_t)AH * d->De + d->De) + 256;   // + the 1 KB store dump (PairArgs::dump)
 }
 
 // packed operand arrays (all six), row constants, dA tiles, parameter-gradient partials.  The forward writes the q / k / v arrays;
@@ -1266,6 +1266,10 @@ static int pair_fill(const egt_block_desc* d, const egt_block_params* P, const v
   pa.Wg = (const float*)P->attention_gates_kernel; pa.bg = (const float*)P->attention_gates_bias;
   pa.We = (const float*)P->dense_edge_b_kernel; pa.be = (const float*)P->dense_edge_b_bias;
   pa.Wr = (const float*)P->dense_edge_r_kernel; pa.br = (const float*)P->dense_edge_r_bias;
+  {   // the last 1 KB of the workspace
+    const size_t NP = np_of(d->N), arr = (size_t)d->B * AH * NP * d->d;
+    pa.dump = (float*)workspace + PK_COUNT * arr + (size_t)d->B * AH * NP * 4 + (size_t)d->B * AH * NP * NP + pair_partial_floats(d) - 256;
+  }
   return EGT_OK;
 }
 
@@ -1281,7 +1285,7 @@ extern "C" int egt_pair_fwd(const egt_block_desc* desc, const egt_block_params* 
   hipStream_t st = (hipStream_t)stream;
   launch_pack<64>(a, st);
   constexpr int D = 64, DE = 32, HS = (D / 16) * 256;
-  const size_t lds = ((size_t)3 * AH * HS + 2 * (size_t)((a.NP + 16 + 3) & ~3) + (size_t)5 * AH * PT_PL) * sizeof(float);
+  const size_t lds = ((size_t)2 * AH * HS + 2 * (size_t)((a.NP + 16 + 3) & ~3) + (size_t)6 * AH * PT_PL) * sizeof(float);
   const int grid = a.B * (a.NP / 16);
   if (a.rng_rm) {
     EGT_MAX_LDS_ONCE(k_pair_fwd<D, DE, 2>);

@@ -30,11 +30,24 @@ struct PairArgs {
   // backward
   const float* d_e_out;
   float *d_e, *part_proj, *part_upd;   // per-workgroup partials: [That[De][16] | s[16]] and [dWr[8][De] | dbr[De]]
+  float* dump;   // 1 KB of workspace: where the lanes of pairs outside the graph send their stores.  Every store of the edge waves is
+                 // issued unconditionally (no branch around it), so the compiler's vmcnt bookkeeping counts it: behind a store it cannot
+                 // count (exec-masked block) the wait for an older prefetch would also wait for that store's completion
 };
 
 #define PR_WAVES 8
 // LDS hand-off inside ONE wave (its DS operations complete in order): drain lgkmcnt, never vmcnt
 __device__ __forceinline__ void lds_sync_() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+// the workgroup barrier of the pair kernels: nothing is scheduled across it (a plain asm barrier orders memory only: hipcc hoisted the
+// next trip's LayerNorm arithmetic above it, i.e. in front of the wait for a tile that had only just been requested)
+__device__ __forceinline__ void pair_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+#ifndef PAIR_EDGE_PRIO
+#define PAIR_EDGE_PRIO 2
+#endif
 #ifndef PAIR_NT_E
 #define PAIR_NT_E 0   // 1: the forward's e tiles by non-temporal loads (read once; measured before adopting)
 #endif
@@ -96,10 +109,14 @@ __device__ __forceinline__ void pair_fold_weights(const PairArgs& pa, int i, int
 }
 
 // ================================================================== forward =====
-// LDS: Kb [8 heads][KT tiles] (one stage: K(it+1) lands while the attention waves are in their softmax / A.V phase), Vb two stages,
-// the two per-key additive tables, planes E | G (in, two stages) and H_hat (out, one stage):
-//   barrier B1(it): planes E, G of tile it written, K(it) landed      -> attention: S = K.Q^T           edge: dense_edge_r of tile it-1; LN + projections of tile it+1, rows 0-1
-//   barrier B2(it): H_hat(it-1) consumed, K(it) read                  -> attention: softmax, H_hat, A.V edge: DMA K(it+1), V(it+1); e(it+2) requested; rows 2-3 of tile it+1
+// One barrier per key tile.  An attention wave stages the K / V^T tiles of ITS OWN two heads by LDS-DMA (it is the only reader of those
+// LDS regions: issue after its own last read, counted vmcnt before its own next read -- no cross-wave hand-off, one stage each);
+// the planes cross the roles through two stages:
+//   barrier(it): E / G planes of tile it written (edge), H_hat planes of tile it-1 written (attention)
+//   tile it:  attention: S = K.Q^T -> DMA K(it+1) -> softmax x gates, H_hat -> stage it&1 -> A.V -> DMA V(it+1)
+//             edge:      dense_edge_r + residual of tile it-1 (H_hat stage (it-1)&1) -> e(it+2) requested -> LN + projections of tile it+1 -> stage (it+1)&1
+// (stamps of the first version -- DMA issued by the edge waves, two barriers -- profiles/r06_pair_stamps_v1.txt: the attention waves
+//  waited at barriers for half of the launch while the edge waves issued the workgroup's vector memory)
 template <int D, int DE, int V>
 __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, PairArgs pa) {
   constexpr int KT = D / 16, DH = D * AH, T = PairGeo<DE>::T, HS = KT * 256;   // HS: floats of one head's operand tile
@@ -108,20 +125,23 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
   const int N = a.N, NP = a.NP, mtiles = NP / 16;
   const int KA = (NP + 16 + 3) & ~3;
   float* Kb = sm;                      // [8][HS]
-  float* Vb = Kb + AH * HS;            // [2][8][HS]
-  float* kaddL = Vb + 2 * AH * HS;     // [KA]
+  float* Vb = Kb + AH * HS;            // [8][HS]
+  float* kaddL = Vb + AH * HS;         // [KA]
   float* kaddG = kaddL + KA;
-  float* InE = kaddG + KA;             // [2 stages][E | G][8][PT_PL]
-  float* InG = InE + AH * PT_PL;
-  float* Hp = InE + 4 * AH * PT_PL;    // [8][PT_PL]
+  float* In = kaddG + KA;              // [2 stages][E | G][8][PT_PL]
+  float* Hp = In + 4 * AH * PT_PL;     // [2 stages][8][PT_PL]
   const int wg = egt_xcd_remap(blockIdx.x, gridDim.x);   // the row blocks of a graph share an XCD's L2 (K / V^T of the graph: 2 MB)
   const int b = __builtin_amdgcn_readfirstlane(wg / mtiles), l0 = __builtin_amdgcn_readfirstlane((wg % mtiles) * 16);   // (the division runs on the VALU: back to scalar registers)
   const size_t arr = (size_t)a.B * AH * NP * D;
   const bool clip = (a.flags & EGT_F_CLIP) != 0;
+  STAMP_DECL;
 
   if (wv >= 4) {
     // --------------------------------------------------------------------- edge waves ----
     const int j = wv - 4, p = lane & 15, q = lane >> 4;
+#if PAIR_EDGE_PRIO
+    __builtin_amdgcn_s_setprio(PAIR_EDGE_PRIO);   // the edge waves are the longer role: the SIMD's issue arbitration (priority, then age) favours them
+#endif
     for (int m = tid - 256; m < NP + 16; m += 256) {
       float ka = 0.f;
       if (m >= N) ka = KEY_OFF;
@@ -140,45 +160,31 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
 #pragma unroll
       for (int r = 0; r < 4; ++r) brv[t][r] = pa.br[16 * t + 4 * q + r];
     }
-    // operand tiles of heads 2j, 2j+1 by LDS-DMA
-    const unsigned doff = dma_lane_off(lane);
-    const float* Kh = a.pk + PK_KH * arr + ((size_t)b * AH + 2 * j) * NP * D;
-    const float* VT = a.pk + PK_VT * arr + ((size_t)b * AH + 2 * j) * D * NP;
-    const unsigned kdst = lds_addr(Kb) + (2 * j) * HS * 4, vdst = lds_addr(Vb) + (2 * j) * HS * 4;
-    auto dma_ops = [&](int mt) __attribute__((always_inline)) {
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int Tt = 0; Tt < KT; ++Tt) {
-          dma_piece(kdst + (hh * KT + Tt) * 1024, uni_ptr(Kh + (size_t)hh * NP * D + (size_t)mt * 16 * D + Tt * 256), doff);
-          dma_piece(vdst + (mt & 1) * (AH * HS * 4) + (hh * KT + Tt) * 1024, uni_ptr(VT + (size_t)hh * D * NP + (size_t)mt * 16 * D + Tt * 256), doff);
-        }
-    };
-    // e fragments of the wave's four rows: lane (p, q): key 16 it + p, channels 16 t + 4 q ..
-    // row r of the wave: a wave-uniform row pointer (scalar registers) + one 32-bit lane offset per tile
-    const float* erow[4];
-    float* orow[4];
+    // row r of the wave: a wave-uniform row pointer (scalar registers) + one 32-bit lane offset (bytes) per tile
+    const char* erow[4];
+    char* orow[4];
     bool rowok[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int l = l0 + 4 * j + r;
       rowok[r] = l < N;
-      const size_t ro = ((size_t)b * N + min(l, N - 1)) * N * DE;
-      erow[r] = pa.e + ro;
-      orow[r] = pa.e_out + ro;
+      const size_t ro = (((size_t)b * N + min(l, N - 1)) * N * DE) * sizeof(float);
+      erow[r] = reinterpret_cast<const char*>(pa.e) + ro;
+      orow[r] = reinterpret_cast<char*>(pa.e_out) + ro;
     }
+    char* dumpl = reinterpret_cast<char*>(pa.dump) + lane * 16;
     struct ESet { float4 x[4][T]; };
     auto eload = [&](ESet& s, int mt) __attribute__((always_inline)) {
-      const uint32_t mo = (uint32_t)min(16 * mt + p, N - 1) * DE + 4 * q;
+      const uint32_t mo = ((uint32_t)min(16 * mt + p, N - 1) * DE + 4 * q) * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int t = 0; t < T; ++t) s.x[r][t] = egt_ld4_nt_(erow[r] + mo + 16 * t);
+        for (int t = 0; t < T; ++t) s.x[r][t] = egt_ld4_nt_(reinterpret_cast<const float*>(erow[r] + mo + 64 * t));
     };
-    // LN + projections of rows r0, r0 + 1 of a tile from set s -> planes of stage st
-    auto project = [&](const ESet& s, int st, int r0) __attribute__((always_inline)) {
+    // LN + projections of a tile from set s -> E / G planes of stage st
+    auto project = [&](const ESet& s, int st) __attribute__((always_inline)) {
 #pragma unroll
-      for (int r = r0; r < r0 + 2; ++r) {
+      for (int r = 0; r < 4; ++r) {
         float4 x[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) x[t] = s.x[r][t];
@@ -191,68 +197,104 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
           acc = MFMA(wA[t][2], x[t].z, acc);
           acc = MFMA(wA[t][3], x[t].w, acc);
         }
-        // lane holds outputs 4q..4q+3 of pair (row 4j + r, key p): q < 2 gates of heads 4q + i, q >= 2 edge bias of heads 4(q-2) + i
-        float* pl = (q < 2 ? InG : InE) + st * (2 * AH * PT_PL) + (4 * (q & 1)) * PT_PL + pt_off(4 * j + r, p);
+        // lane holds outputs 4q..4q+3 of pair (row 4j + r, key p): q < 2 gates of heads 4q + i (plane set 1), q >= 2 edge bias of heads 4(q-2) + i (set 0)
+        float* pl = In + st * (2 * AH * PT_PL) + (q < 2 ? AH * PT_PL : 0) + (4 * (q & 1)) * PT_PL + pt_off(4 * j + r, p);
         pl[0] = acc[0]; pl[PT_PL] = acc[1]; pl[2 * PT_PL] = acc[2]; pl[3 * PT_PL] = acc[3];
       }
     };
-    // e' = e + H_hat.Wr + br of tile mt from set s (the registers that loaded e) and the H_hat planes
+    // e' = e + H_hat.Wr + br of tile mt from set s (the registers that loaded e) and the H_hat planes of stage mt & 1
     auto update = [&](const ESet& s, int mt) __attribute__((always_inline)) {
       const int m = 16 * mt + p;
+      const uint32_t mo = ((uint32_t)min(m, N - 1) * DE + 4 * q) * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float* hp = Hp + q * PT_PL + pt_off(4 * j + r, p);
+        const float* hp = Hp + (mt & 1) * (AH * PT_PL) + q * PT_PL + pt_off(4 * j + r, p);
         const float h0 = hp[0], h1 = hp[4 * PT_PL];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           v4f acc = {brv[t][0], brv[t][1], brv[t][2], brv[t][3]};
           acc = MFMA(wU[t][0], h0, acc);
           acc = MFMA(wU[t][1], h1, acc);
-          if (rowok[r] && m < N)
-            *reinterpret_cast<float4*>(orow[r] + (uint32_t)m * DE + 4 * q + 16 * t) =
-                make_float4(s.x[r][t].x + acc[0], s.x[r][t].y + acc[1], s.x[r][t].z + acc[2], s.x[r][t].w + acc[3]);
+          char* dst = (rowok[r] && m < N) ? orow[r] + mo + 64 * t : dumpl;
+          *reinterpret_cast<float4*>(dst) =
+              make_float4(s.x[r][t].x + acc[0], s.x[r][t].y + acc[1], s.x[r][t].z + acc[2], s.x[r][t].w + acc[3]);
         }
       }
     };
     ESet S0, S1, S2;
-    dma_ops(0);
     eload(S0, 0);
     eload(S1, min(1, mtiles - 1));
-    vm_wait<4 * T>();          // K(0), V(0) and e(0) landed; e(1) may still be in flight
-    project(S0, 0, 0);
-    project(S0, 0, 2);
-    lds_barrier();             // B1(0)
-    // one trip = [U(it-1)] B2 [DMA(it+1), loads(it+2), project(it+1)] B1; the three register sets rotate: (cur, nxt, pre) = e(it-1), e(it+1)... see below
-    auto trip = [&](int it, ESet& done, ESet& nxt) __attribute__((always_inline)) {
-      // `done` holds e(it-1) (consumed by this trip's update, then refilled with e(it+2)); `nxt` holds e(it+1)
-      // (the compiler's own vmcnt bookkeeping does not see the LDS-DMA pieces: no DMA may sit between a register load and its first
-      //  use, or the inserted wait would drain pieces that were only just issued.  e(it+1) is first used HERE, before this trip's DMA)
-      if (it > 0) update(done, it - 1);
-      if (it + 1 < mtiles) project(nxt, (it + 1) & 1, 0);
-      lds_barrier();           // B2(it)
-      if (it + 1 < mtiles) dma_ops(it + 1);
-      eload(done, min(it + 2, mtiles - 1));
-      if (it + 1 < mtiles) project(nxt, (it + 1) & 1, 2);
-      vm_wait<4 * T>();        // the DMA pieces landed (only this trip's e loads are younger)
-      lds_barrier();           // B1(it+1)
+    project(S0, 0);
+    pair_barrier();             // barrier(0)
+    // The set of e(k) is S[k % 3]; trip it updates tile it-1 from S[(it+2) % 3] (then refilled with e(it+2)) and projects e(it+1) from
+    // S[(it+1) % 3]; e(it) waits in the third set.  The first and the last trip are peeled: the steady-state trip is branch-free
+    // straight-line code whose vector-memory order is pinned (update's stores, then the request of e(it+2) a whole trip ahead of its
+    // first use, then the projection) -- at a control-flow merge the compiler's vmcnt bookkeeping takes the conservative side and
+    // drains the prefetch queue, and a load it moves behind the projection loses the trip of latency cover.
+    // (pin: the values of e(it+1) are "produced" here, behind the barrier -- pure arithmetic on them cannot be hoisted above this
+    //  point, i.e. into the previous trip in front of the wait for requests that were only just issued; the requests are a trip old here)
+    auto pin = [&](ESet& s_) __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+          asm volatile("" : "+v"(s_.x[r][t].x), "+v"(s_.x[r][t].y), "+v"(s_.x[r][t].z), "+v"(s_.x[r][t].w));
     };
-    // set holding e(k) is S[k % 3]: trip(it) updates from S[(it-1) % 3], projects S[(it+1) % 3]
-    int it = 0;
-    for (; it + 2 < mtiles; it += 3) {
-      trip(it, S2, S1);
-      trip(it + 1, S0, S2);
-      trip(it + 2, S1, S0);
+    auto steady = [&](int it, ESet& done, ESet& nxt) __attribute__((always_inline)) {
+      STAMP(7);
+      pin(nxt);
+      update(done, it - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(0);
+      eload(done, min(it + 2, mtiles - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(1);
+      project(nxt, (it + 1) & 1);
+      STAMP(2);
+      pair_barrier();           // barrier(it+1)
+      STAMP(3);
+    };
+    {   // trip 0: nothing to update yet
+      eload(S2, min(2, mtiles - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      if (mtiles > 1) project(S1, 1);
+      pair_barrier();
     }
-    if (it < mtiles) { trip(it, S2, S1); ++it; }
-    if (it < mtiles) { trip(it, S0, S2); ++it; }
-    // H_hat of the last tile: its set is S[(mtiles-1) % 3]
-    {
+    int it = 1;
+    for (; it + 3 <= mtiles - 1; it += 3) {
+      steady(it, S0, S2);
+      steady(it + 1, S1, S0);
+      steady(it + 2, S2, S1);
+    }
+    if (it <= mtiles - 2) { steady(it, S0, S2); ++it; }
+    if (it <= mtiles - 2) { steady(it, S1, S0); ++it; }
+    if (mtiles > 1) {          // trip mtiles-1: no tile left to project
+      const int k = it % 3;
+      if (k == 1) update(S0, it - 1); else if (k == 2) update(S1, it - 1); else update(S2, it - 1);
+      pair_barrier();
+    }
+    {   // H_hat of the last tile: its set is S[(mtiles-1) % 3]
       const int k = (mtiles - 1) % 3;
       if (k == 0) update(S0, mtiles - 1); else if (k == 1) update(S1, mtiles - 1); else update(S2, mtiles - 1);
     }
+    STAMP(8);
+    STAMP_OUT(0);
   } else {
     // ---------------------------------------------------------------- attention waves ----
     const int w = wv, ll = lane & 15, q = lane >> 4;
+    // the wave's own operand tiles: K rows / V^T of heads 2w, 2w + 1, four 1 KB pieces per tile
+    const unsigned doff = dma_lane_off(lane);
+    const float* Kh = uni_ptr(a.pk + PK_KH * arr + ((size_t)b * AH + 2 * w) * NP * D);
+    const float* VT = uni_ptr(a.pk + PK_VT * arr + ((size_t)b * AH + 2 * w) * D * NP);
+    const unsigned kdst = lds_addr(Kb) + (2 * w) * HS * 4, vdst = lds_addr(Vb) + (2 * w) * HS * 4;
+    auto dma_tile = [&](unsigned dst, const float* src) __attribute__((always_inline)) {   // src: [2 heads] x (KT pieces), head stride NP * D floats
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int Tt = 0; Tt < KT; ++Tt) dma_piece(dst + (hh * KT + Tt) * 1024, src + (size_t)hh * NP * D + Tt * 256, doff);
+    };
+    dma_tile(kdst, Kh);
+    dma_tile(vdst, VT);
     float Qr[2][4 * KT];
     {
       const int ltile = l0 >> 4;
@@ -277,9 +319,14 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
     const int po4 = (2 * w) * PT_PL + pt_off(ll, 4 * q);                       // + hh * PT_PL: the lane's keys 4q..4q+3 of row ll
     const float* opl = Kb + (2 * w) * HS + ll * 16 + ((q ^ chunk_xor(ll)) << 2);   // + hh * HS + 256 T
     const int lq = min(l0 + ll, N - 1);
-    lds_barrier();             // B1(0)
+    vm_wait<0>();              // (Q fragments in registers, tiles of key tile 0 landed)
+    pair_barrier();             // barrier(0)
+    STAMP(7);
     for (int it = 0; it < mtiles; ++it) {
       const int m0 = 16 * it;
+      const bool more = it + 1 < mtiles;
+      const float* Inb = In + (it & 1) * (2 * AH * PT_PL);
+      if (it > 0) vm_wait<2 * KT>();   // K(it) landed (requested a tile ago; only the V^T(it) pieces are younger)
       float4 kc[2][KT], e4[2], g4[2];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh)
@@ -290,8 +337,8 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
       if (V == 1) kg4 = *reinterpret_cast<const float4*>(kaddG + m0 + 4 * q);
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        e4[hh] = *reinterpret_cast<const float4*>(InE + (it & 1) * (2 * AH * PT_PL) + hh * PT_PL + po4);
-        g4[hh] = *reinterpret_cast<const float4*>(InG + (it & 1) * (2 * AH * PT_PL) + hh * PT_PL + po4);
+        e4[hh] = *reinterpret_cast<const float4*>(Inb + hh * PT_PL + po4);
+        g4[hh] = *reinterpret_cast<const float4*>(Inb + AH * PT_PL + hh * PT_PL + po4);
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- S^T[m][l] = sum_k K[m][k] (d^-1/2 Q)[l][k], two heads ----
@@ -304,13 +351,10 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
         for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) s[hh] = MFMA(f4get(kc[hh][Tt], u), Qr[hh][4 * Tt + u], s[hh]);
-      lds_barrier();           // B2(it): K(it), E / G(it) are in registers; H_hat(it-1) has been consumed
-      float4 vc[2][KT];
-      const float* vpl = opl + (AH * HS) + (it & 1) * (AH * HS);
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int Tt = 0; Tt < KT; ++Tt) vc[hh][Tt] = *reinterpret_cast<const float4*>(vpl + hh * HS + Tt * 256);
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(0);
+      // the K tiles of the next key tile: this wave was their only reader and its reads have returned (the MFMAs above consumed them)
+      if (more) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dma_tile(kdst, Kh + (size_t)(it + 1) * 16 * D); }
       const float kav[4] = {ka4.x, ka4.y, ka4.z, ka4.w}, kgv[4] = {kg4.x, kg4.y, kg4.z, kg4.w};
       float pa_[2][4];
 #pragma unroll
@@ -335,7 +379,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
           const float tg = V == 1 ? exp2_fast(fmaf(f4get(g4[hh], r), -L2E, kgv[r])) : exp2_fast((f4get(g4[hh], r) + add) * -L2E);
           pa_[hh][r] = __builtin_amdgcn_rcpf(1.0f + tg);
         }
-        *reinterpret_cast<float4*>(Hp + hh * PT_PL + po4) = make_float4(hv4[0], hv4[1], hv4[2], hv4[3]);
+        *reinterpret_cast<float4*>(Hp + (it & 1) * (AH * PT_PL) + hh * PT_PL + po4) = make_float4(hv4[0], hv4[1], hv4[2], hv4[3]);
         tmax = pair_max_q(tmax);
         const float mnew = fmaxf(mrun[hh], tmax);
         const float alpha = exp2_fast((mrun[hh] - mnew) * L2E);
@@ -357,6 +401,13 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      STAMP(1);
+      if (more) vm_wait<2 * KT>(); else vm_wait<0>();   // V^T(it) landed (only the K(it+1) pieces just issued are younger)
+      float4 vc[2][KT];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int Tt = 0; Tt < KT; ++Tt) vc[hh][Tt] = *reinterpret_cast<const float4*>(opl + AH * HS + hh * HS + Tt * 256);
       // ---- O^T[k][l] += sum_m V^T[k][m] P^T[m][l] ----
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -364,7 +415,11 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) oacc[hh][kt] = MFMA(f4get(vc[hh][kt], r), pa_[hh][r], oacc[hh][kt]);
-      lds_barrier();           // B1(it+1)
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(2);
+      if (more) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dma_tile(vdst, VT + (size_t)(it + 1) * 16 * D); }
+      pair_barrier();           // barrier(it+1)
+      STAMP(3);
     }
     // ---- finalize: O[l][k] / l_run into the K stage as [row][k][8 heads]; row statistics for the backward ----
 #pragma unroll
@@ -379,9 +434,10 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
       if (l < N && q == 0)
         *reinterpret_cast<float4*>(a.rowstats + (((size_t)b * N + l) * AH + h) * 4) = make_float4(mrun[hh], lrun[hh], 0.f, 0.f);
     }
+    STAMP_OUT(0);
   }
   // V_att[l][k * 8 + h]: 16 rows x 512 channels, consecutive threads consecutive 16-byte pieces
-  lds_barrier();
+  pair_barrier();
   for (int p = tid; p < 16 * DH / 4; p += 64 * PR_WAVES) {
     const int row = p / (DH / 4);
     if (l0 + row < N)
@@ -403,8 +459,10 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
 //   d ehat = Wp.dGE, LayerNorm backward, de = de' + .. stored; weight gradients T += ehat^T.dGE, R += de'^T.[H_hat | 1] on the
 //   matrix core (accumulators live for the whole workgroup -> deterministic partials).  ehat and de' of a tile stay in the
 //   registers that loaded them from PRE to POST (two register sets, one per trip parity), refilled right after POST.
-//   trip it:  B1(it)  attention: half A (heads 0-3)         edge: DMA half B(it); POST(it-1) + reload e, de' (it+1)
-//             Bm(it)  attention: half B (heads 4-7)         edge: DMA half A(it+1); PRE(it+1); row constants of it+1
+//   ONE barrier per trip: an attention wave stages the Q / dO tiles of its own heads itself (it is their only reader: DMA of the next
+//   trip's tile right after its last read of a stage, counted vmcnt before its next read; no cross-wave hand-off), and inside an edge
+//   wave POST(it-1) precedes PRE(it+1) in program order (they share a plane set, and a wave touches only its own rows of it)
+//   trip it:  attention: half A (head w), half B (head w + 4)       edge: POST(it-1) + e, de' requests of it+1; PRE(it+1); row constants of it+1
 template <int D, int DE, int V>
 __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, PairArgs pa) {
   constexpr int KT = D / 16, DH = D * AH, T = PairGeo<DE>::T, HS = KT * 256, TSZ = AH * PT_PL;
@@ -422,10 +480,14 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
   const int b = __builtin_amdgcn_readfirstlane(wg / mtiles), mt0 = __builtin_amdgcn_readfirstlane(wg % mtiles), m0 = mt0 * 16;
   const size_t arr = (size_t)a.B * AH * NP * D;
   const bool clip = (a.flags & EGT_F_CLIP) != 0;
+  STAMP_DECL;
 
   if (wv >= 4) {
     // --------------------------------------------------------------------- edge waves ----
     const int j = wv - 4, p = lane & 15, q = lane >> 4;
+#if PAIR_EDGE_PRIO
+    __builtin_amdgcn_s_setprio(PAIR_EDGE_PRIO);
+#endif
     {
       float bias[4];
       // every edge wave writes the same table (same values: a benign race), then reads only after its own writes completed
@@ -453,20 +515,6 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
 #pragma unroll
     for (int t = 0; t < T; ++t) { accT[t] = (v4f){0.f, 0.f, 0.f, 0.f}; accW[t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
     float4 accS = make_float4(0.f, 0.f, 0.f, 0.f);
-    const unsigned doff = dma_lane_off(lane);
-    // operand tiles: head slot j of a half (head j or j + 4): Q tile then dO tile
-    const float* Qh = a.pk + PK_QH * arr + ((size_t)b * AH + j) * NP * D;
-    const float* Oh = a.pk + PK_OH * arr + ((size_t)b * AH + j) * NP * D;
-    const unsigned odst = lds_addr(Ops) + j * (2 * HS * 4);
-    auto dma_half = [&](int ltile, int half) __attribute__((always_inline)) {
-      const size_t ho = (size_t)half * 4 * NP * D + (size_t)ltile * 16 * D;
-      const unsigned dst = odst + half * (4 * 2 * HS * 4);
-#pragma unroll
-      for (int Tt = 0; Tt < KT; ++Tt) {
-        dma_piece(dst + Tt * 1024, uni_ptr(Qh + ho + Tt * 256), doff);
-        dma_piece(dst + (KT + Tt) * 1024, uni_ptr(Oh + ho + Tt * 256), doff);
-      }
-    };
     const float* st2 = a.stats2 + ((size_t)b * AH + j + 4 * ((lane >> 4) & 1)) * NP * 4;   // lanes 0..15: head j, 16..31: head j + 4 (upper lanes repeat)
     auto stat_load = [&](int ltile) __attribute__((always_inline)) {
       return *reinterpret_cast<const float4*>(st2 + (size_t)(ltile * 16 + (lane & 15)) * 4);
@@ -492,6 +540,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
     // de' of a held tile is NOT kept in registers from PRE to POST (two sets x four rows x 8 registers that the allocator does not have:
     // spill reloads wait on vmcnt(0), i.e. drain the wave's whole prefetch queue): POST reads it again -- a tile this CU streamed one
     // trip ago, served by L2 / the memory-side cache
+    char* dumpl = reinterpret_cast<char*>(pa.dump) + lane * 16;
     auto df_load = [&](HSet& s, int r, int ltile) __attribute__((always_inline)) {
       const char* dr = reinterpret_cast<const char*>(pa.d_e_out) + (gb + (size_t)min(16 * ltile + 4 * r + j, N - 1) * N * DE) * sizeof(float);
 #pragma unroll
@@ -512,7 +561,6 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
     const int xrd = q * DE + (((p >> 2) ^ q) << 2) + (p & 3);
     // PRE: tile row r of query tile `ltile` from the raw values in set s -> planes of set `ps`; ehat / de' stay in s
     auto pre = [&](HSet& s, int set, int r, int ltile, float* ps) __attribute__((always_inline)) {
-      __builtin_amdgcn_sched_barrier(0);   // one row at a time: the allocator has no room for two rows' transients
       const bool valid = keyok && (16 * ltile + 4 * r + j) < N;
       const float rstd_ = pair_ln<T>(s.x[r], pa.ln_eps);
       if (q == 0) rsd[(set * 4 + r) * 16 + p] = rstd_;
@@ -546,11 +594,9 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
         float* px = ps + 2 * TSZ + (4 * q) * PT_PL + off;
         px[0] = ax[0]; px[PT_PL] = ax[1]; px[2 * PT_PL] = ax[2]; px[3 * PT_PL] = ax[3];
       }
-      __builtin_amdgcn_sched_barrier(0);
     };
     // POST: tile row r of query tile `ltile`: the planes of set `ps` now hold dE | dG | H_hat
     auto post = [&](HSet& s, int set, int r, int ltile, const float* ps) __attribute__((always_inline)) {
-      __builtin_amdgcn_sched_barrier(0);
       const int l = 16 * ltile + 4 * r + j;
       const bool valid = keyok && l < N;
       if (!valid) {
@@ -584,7 +630,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
         const float4 xh = s.x[r][t], d0 = s.df[r][t];
         const float4 o = make_float4(d0.x + rstd * (dx[t].x - m1 - xh.x * m2), d0.y + rstd * (dx[t].y - m1 - xh.y * m2),
                                      d0.z + rstd * (dx[t].z - m1 - xh.z * m2), d0.w + rstd * (dx[t].w - m1 - xh.w * m2));
-        if (valid) *reinterpret_cast<float4*>(orow_ + keyb + 64 * t) = o;
+        *reinterpret_cast<float4*>(valid ? orow_ + keyb + 64 * t : dumpl) = o;
       }
       // weight gradients: both operands need the pairs on the contraction axis: ehat / de' through the wave's scratch tiles
 #pragma unroll
@@ -617,60 +663,72 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
           accW[t] = MFMA(hA[s4], dfs[idx], accW[t]);
         }
       lds_sync_();
-      __builtin_amdgcn_sched_barrier(0);
     };
 
     HSet H0, H1;
-    dma_half(0, 0);
-    dma_half(0, 1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) raw_load(H0, r, 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) raw_load(H1, r, min(1, mtiles - 1));
     stat_put(stat_load(0), 0);
-    vm_wait<4 * 2 * T>();      // everything but the raw values of tile 1
 #pragma unroll
     for (int r = 0; r < 4; ++r) pre(H0, 0, r, 0, Pl);
-    vm_wait<0>();
-    lds_barrier();             // B1(0)
+    pair_barrier();             // barrier(0)
     // trip it: `prev` = set of tile it-1 (POST, then refilled with tile it+1), which PRE then turns into the held set of it+1
-    auto trip = [&](int it, HSet& prev, int set) __attribute__((always_inline)) {
-      float* pprev = Pl + set * 3 * TSZ;              // planes of tile it-1 (= the set tile it+1 will use): (it + 1) & 1 == set, a compile-time constant here
-      if (it > 0) {
-        dma_half(it, 1);       // half B of this trip (trip 0: issued in the prologue); BEFORE the register loads below: the compiler's own
-                               // vmcnt bookkeeping does not see the DMA pieces, so none may sit between a load and its first use
+    // (no LDS-DMA in these waves: every vector-memory operation is visible to the compiler, whose own vmcnt waits before the first use of
+    //  a loaded register are then exact.  First and last trip peeled: the steady-state trip is branch-free, its request order pinned)
+    // trip it works on the set of tile it-1 (`prev` = H[(it + 1) & 1], planes Pl + set * 3 TSZ): POST(it-1), refilled row by row with the raw
+    // values of tile it+1, which PRE then turns into the held set of it+1
+    auto steady = [&](int it, HSet& prev, int set) __attribute__((always_inline)) {
+      float* pprev = Pl + set * 3 * TSZ;
+      STAMP(8);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) df_load(prev, r, it - 1);
+      for (int r = 0; r < 4; ++r) df_load(prev, r, it - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          post(prev, set, r, it - 1, pprev);
-          raw_load(prev, r, min(it + 1, mtiles - 1));
-        }
-        vm_wait<4 * 2 * T>();  // the DMA pieces of half B landed (only the raw loads, and stores, are younger)
+      for (int r = 0; r < 4; ++r) {
+        post(prev, set, r, it - 1, pprev);
+        raw_load(prev, r, it + 1);
       }
-      lds_barrier();           // Bm(it)
-      if (it + 1 < mtiles) {
-        dma_half(it + 1, 0);
-        const float4 stn = stat_load(it + 1);
-        if (it > 0) {
-          vm_wait<3 * 2 * T + 2 * KT + 1>(); pre(prev, set, 0, it + 1, pprev);
-          vm_wait<2 * 2 * T + 2 * KT + 1>(); pre(prev, set, 1, it + 1, pprev);
-          vm_wait<1 * 2 * T + 2 * KT + 1>(); pre(prev, set, 2, it + 1, pprev);
-          vm_wait<2 * KT + 1>();             pre(prev, set, 3, it + 1, pprev);
-        } else {               // trip 0: tile 1's raw values were requested in the prologue
-          vm_wait<2 * KT + 1>();
+      STAMP(1);
+      const float4 stn = stat_load(it + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pre(prev, set, r, it + 1, pprev);
-        }
-        vm_wait<0>();
-        stat_put(stn, (it + 1) & 1);
-      }
-      lds_barrier();           // B1(it+1)
+      for (int r = 0; r < 4; ++r) pre(prev, set, r, it + 1, pprev);
+      STAMP(5);
+      stat_put(stn, (it + 1) & 1);
+      STAMP(6);
+      pair_barrier();           // barrier(it+1)
+      STAMP(7);
     };
-    // the set of tile k is H[k & 1]: trip(it) works on H[(it + 1) & 1]
-    int it = 0;
-    for (; it + 1 < mtiles; it += 2) { trip(it, H1, 1); trip(it + 1, H0, 0); }
-    if (it < mtiles) { trip(it, H1, 1); ++it; }
+    {   // trip 0: nothing to POST yet; tile 1's raw values were requested in the prologue
+      if (mtiles > 1) {
+        const float4 stn = stat_load(1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pre(H1, 1, r, 1, Pl + 3 * TSZ);
+        stat_put(stn, 1);
+      }
+      pair_barrier();
+    }
+    int it = 1;
+    for (; it + 1 <= mtiles - 2; it += 2) { steady(it, H0, 0); steady(it + 1, H1, 1); }
+    if (it <= mtiles - 2) { steady(it, H0, 0); ++it; }
+    if (mtiles > 1) {          // trip mtiles-1: POST(mtiles-2), nothing left to prepare
+      if (it & 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) df_load(H0, r, it - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) post(H0, 0, r, it - 1, Pl);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) df_load(H1, r, it - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) post(H1, 1, r, it - 1, Pl + 3 * TSZ);
+      }
+      pair_barrier();
+    }
     // POST of the last tile
     {
       const float* pl = Pl + ((mtiles - 1) & 1) * 3 * TSZ;
@@ -686,6 +744,8 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
         for (int r = 0; r < 4; ++r) post(H0, 0, r, mtiles - 1, pl);
       }
     }
+    STAMP(9);
+    STAMP_OUT(1);
     // partials of this wave -> the (now idle) other plane set: [That[DE][16] | s[16] | dWr[8][DE] | dbr[DE]]
     float* red = Pl + (mtiles & 1) * 3 * TSZ + j * (PSZ1 + PSZ2);
 #pragma unroll
@@ -737,7 +797,25 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
     // operand tiles of head slot w (Q, then dO): row form: lane (row mm, chunk q) b128; transposed: lane (channel mm, q): rows 4q + r
     const float* oprow = Ops + w * (2 * HS) + mm * 16 + ((q ^ chunk_xor(mm)) << 2);
     const float* optr = Ops + w * (2 * HS) + (4 * q) * 16 + (((mm >> 2) ^ chunk_xor(4 * q)) << 2) + (mm & 3);
-    lds_barrier();             // B1(0)
+    // the wave's own operand stages: stage `half` = (Q, dO) tiles of head w + 4 half; four 1 KB pieces per tile
+    const unsigned doff = dma_lane_off(lane);
+    const float* Qh = uni_ptr(a.pk + PK_QH * arr + ((size_t)b * AH + w) * NP * D);
+    const float* Oh = uni_ptr(a.pk + PK_OH * arr + ((size_t)b * AH + w) * NP * D);
+    const unsigned odst = lds_addr(Ops) + w * (2 * HS * 4);
+    auto dma_half = [&](int ltile, int half) __attribute__((always_inline)) {
+      const size_t ho = (size_t)half * 4 * NP * D + (size_t)ltile * 16 * D;
+      const unsigned dst = odst + half * (4 * 2 * HS * 4);
+#pragma unroll
+      for (int Tt = 0; Tt < KT; ++Tt) {
+        dma_piece(dst + Tt * 1024, Qh + ho + Tt * 256, doff);
+        dma_piece(dst + (KT + Tt) * 1024, Oh + ho + Tt * 256, doff);
+      }
+    };
+    dma_half(0, 0);
+    dma_half(0, 1);
+    vm_wait<0>();              // (K / V fragments in registers, both stages of query tile 0 landed)
+    pair_barrier();             // barrier(0)
+    STAMP(8);
     for (int l0 = 0, it = 0; it < mtiles; l0 += 16, ++it) {
       float* ps = Pl + (it & 1) * 3 * TSZ;
 #pragma unroll
@@ -745,6 +823,9 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
         const int h = w + 4 * hf;
         const float* opr = oprow + hf * (4 * 2 * HS);
         const float* opt = optr + hf * (4 * 2 * HS);
+        // this stage landed: requested one half-trip ago; only the other stage's pieces (and the dA store) are younger -- except in the
+        // second half of the last trip, where nothing was requested after it
+        if (it + 1 < mtiles || hf == 0) { if (it > 0 || hf > 0) vm_wait<2 * KT>(); } else vm_wait<0>();
         float4 qa[KT], oa[KT];
 #pragma unroll
         for (int Tt = 0; Tt < KT; ++Tt) {
@@ -768,6 +849,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
             dp = MFMA(f4get(oa[Tt], u), f4get(Vr[hf][Tt], u), dp);
           }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(0);
         float at[4], da[4], dE4[4], dG4[4], hh4[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -799,6 +881,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
         *reinterpret_cast<float4*>(ps + 2 * TSZ + h * PT_PL + po4) = make_float4(hh4[0], hh4[1], hh4[2], hh4[3]);
         *reinterpret_cast<float4*>(dAb[hf] + (size_t)it * mtiles * 256 + ooff) = make_float4(da[0], da[1], da[2], da[3]);
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(1);
         // ---- dV^T[k][m] += sum_l dO[l][k] A[l][m] ; dK^T[k][m] += sum_l (d^-1/2 Q)[l][k] dA[l][m] ----
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
@@ -809,9 +892,14 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
             dVacc[hf][kt] = MFMA(oo, at[r], dVacc[hf][kt]);
             dKacc[hf][kt] = MFMA(qq, da[r], dKacc[hf][kt]);
           }
-        lds_barrier();         // Bm(it) after half A, B1(it+1) after half B
+        STAMP(2);
+        // the stage is free (this wave was its only reader): the same head's tiles of the next query tile
+        if (it + 1 < mtiles) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dma_half(it + 1, hf); }
+        if (hf == 1) pair_barrier();   // barrier(it+1)
+        STAMP(3);
       }
     }
+    STAMP_OUT(1);
     // dK / dV into the (now idle) operand stages as [key][k][8 heads]: dK in the first 32 KB, dV in the second
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
@@ -825,7 +913,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
         }
     }
   }
-  lds_barrier();
+  pair_barrier();
   // dK / dV rows of d_qkv: 16 keys x 512 channels each, 16-byte pieces
   for (int pz = tid; pz < 16 * DH / 4; pz += 64 * PR_WAVES) {
     const int row = pz / (DH / 4), c = (pz % (DH / 4)) * 4;
