@@ -1287,13 +1287,12 @@ extern "C" int egt_pair_fwd(const egt_block_desc* desc, const egt_block_params* 
   constexpr int D = 64, DE = 32, HS = (D / 16) * 256;
   const size_t lds = ((size_t)2 * AH * HS + 2 * (size_t)((a.NP + 16 + 3) & ~3) + (size_t)6 * AH * PT_PL) * sizeof(float);
   const int grid = a.B * (a.NP / 16);
-  if (a.rng_rm) {
-    EGT_MAX_LDS_ONCE(k_pair_fwd<D, DE, 2>);
-    EGT_LAUNCH("k_pair_fwd", (k_pair_fwd<D, DE, 2>), dim3(grid), dim3(64 * PR_WAVES), lds, st, a, pa);
-  } else {
-    EGT_MAX_LDS_ONCE(k_pair_fwd<D, DE, 1>);
-    EGT_LAUNCH("k_pair_fwd", (k_pair_fwd<D, DE, 1>), dim3(grid), dim3(64 * PR_WAVES), lds, st, a, pa);
-  }
+#define PAIR_FWD(V_, F_) do { EGT_MAX_LDS_ONCE(k_pair_fwd<D, DE, V_, F_>); \
+    EGT_LAUNCH("k_pair_fwd", (k_pair_fwd<D, DE, V_, F_>), dim3(grid), dim3(64 * PR_WAVES), lds, st, a, pa); } while (0)
+  const bool full = a.N % 16 == 0;
+  if (a.rng_rm) { if (full) PAIR_FWD(2, true); else PAIR_FWD(2, false); }
+  else { if (full) PAIR_FWD(1, true); else PAIR_FWD(1, false); }
+#undef PAIR_FWD
   EGT_HIP_LAUNCH_CHECK("egt_pair_fwd");
   return EGT_OK;
 }
@@ -1324,13 +1323,12 @@ extern "C" int egt_pair_bwd(const egt_block_desc* desc, const egt_block_params* 
   hipStream_t st = (hipStream_t)stream;
   launch_pack<64>(a, st);   // (also the per-row constants, delta = sum_k dO*O among them)
   const size_t lds = ((size_t)2 * 4 * 2 * HS + (size_t)2 * 3 * AH * PT_PL + (size_t)2 * AH * 64 + (size_t)4 * 2 * 16 * DE + (size_t)3 * (DE / 16) * 64 * 4 + 64 * 4 + 4 * 2 * 4 * 16) * sizeof(float);
-  if (a.rng_rm) {
-    EGT_MAX_LDS_ONCE(k_pair_bwd<D, DE, 2>);
-    EGT_LAUNCH("k_pair_bwd", (k_pair_bwd<D, DE, 2>), dim3(nwg), dim3(64 * PR_WAVES), lds, st, a, pa);
-  } else {
-    EGT_MAX_LDS_ONCE(k_pair_bwd<D, DE, 1>);
-    EGT_LAUNCH("k_pair_bwd", (k_pair_bwd<D, DE, 1>), dim3(nwg), dim3(64 * PR_WAVES), lds, st, a, pa);
-  }
+#define PAIR_BWD(V_, F_) do { EGT_MAX_LDS_ONCE(k_pair_bwd<D, DE, V_, F_>); \
+    EGT_LAUNCH("k_pair_bwd", (k_pair_bwd<D, DE, V_, F_>), dim3(nwg), dim3(64 * PR_WAVES), lds, st, a, pa); } while (0)
+  const bool full = a.N % 16 == 0;
+  if (a.rng_rm) { if (full) PAIR_BWD(2, true); else PAIR_BWD(2, false); }
+  else { if (full) PAIR_BWD(1, true); else PAIR_BWD(1, false); }
+#undef PAIR_BWD
   {
     const int qgroups = (a.NP / 16 + QW_TILES - 1) / QW_TILES;
     const size_t ldsq = (size_t)QW_STAGES * (2 * (D / 16) + 2 * QW_TILES) * 1024;

@@ -580,7 +580,73 @@ extern "C" int egt_edge_update_fwd(const egt_edge_desc* desc, const void* e, con
 
 // ---- internal (egt_common.h): finish the edge-parameter gradients from per-workgroup partials in the layouts of k_edge_proj_bwd
 // ([That[De][16] | s[16]]) and k_edge_update_bwd ([dWr[8][De] | dbr[De]]).  Used by the fused pair operator (egt_pair.h), whose
-// backward accumulates the same partials inside its pair kernel.  `red_*`: scratch of one partial image each.
+// backward accumulates the same partials inside its pair kernel.  Two launches: both partial arrays reduced by one grid (same
+// fixed summation order as k_edge_reduce_partials), then both final stages by one grid of two workgroups.
+__global__ void __launch_bounds__(256) k_pair_reduce_partials(const float* part1, int n1, const float* part2, int n2, int np, float* out1, float* out2) {
+  __shared__ float red[16][17];
+  const int nb1 = (n1 + 15) / 16;
+  const bool first = (int)blockIdx.x < nb1;
+  const float* part = first ? part1 : part2;
+  float* out = first ? out1 : out2;
+  const int n = first ? n1 : n2, blk = first ? blockIdx.x : blockIdx.x - nb1;
+  const int oi = threadIdx.x & 15, pg = threadIdx.x >> 4;
+  const int o = blk * 16 + oi;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  if (o < n) {
+    int pi = pg;
+    for (; pi + 48 < np; pi += 64) {
+      v0 += part[(size_t)pi * n + o];
+      v1 += part[(size_t)(pi + 16) * n + o];
+      v2 += part[(size_t)(pi + 32) * n + o];
+      v3 += part[(size_t)(pi + 48) * n + o];
+    }
+    for (; pi < np; pi += 16) v0 += part[(size_t)pi * n + o];
+  }
+  red[pg][oi] = (v0 + v1) + (v2 + v3);
+  __syncthreads();
+  if (pg == 0 && o < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += red[g][oi];
+    out[o] = s;
+  }
+}
+
+// workgroup 0: the projection side (k_edge_proj_bwd_final with LayerNorm and gates), workgroup 1: dense_edge_r (k_edge_update_bwd_final)
+template <int DE>
+__global__ void __launch_bounds__(256) k_pair_param_final(EdgeArgs a, const float* red_proj, const float* red_upd) {
+  if (blockIdx.x == 1) {
+    constexpr int PSZ = EDGE_H * DE + DE;
+    for (int i = threadIdx.x; i < PSZ; i += 256) {
+      const float s = red_upd[i];
+      if (i < EDGE_H * DE) a.d_Wr[i] = s; else a.d_br[i - EDGE_H * DE] = s;
+    }
+    return;
+  }
+  const float* T = red_proj;
+  const float* s = T + DE * 16;
+  for (int i = threadIdx.x; i < DE * 16; i += 256) {
+    const int k = i >> 4, j = i & 15;
+    const float v = a.gamma[k] * T[i] + a.beta[k] * s[j];
+    if (j < 8) a.d_Wg[k * EDGE_H + j] = v; else a.d_We[k * EDGE_H + (j - 8)] = v;
+  }
+  if (threadIdx.x < 16) {
+    const int j = threadIdx.x;
+    if (j < 8) a.d_bg[j] = s[j]; else a.d_be[j - 8] = s[j];
+  }
+  if (threadIdx.x < DE) {
+    const int k = threadIdx.x;
+    float dg = 0.f, db = 0.f;
+    for (int j = 0; j < 16; ++j) {
+      const float w = (j < 8) ? a.Wg[k * EDGE_H + j] : a.We[k * EDGE_H + (j - 8)];
+      dg = fmaf(w, T[k * 16 + j], dg);
+      db = fmaf(w, s[j], db);
+    }
+    a.d_gamma[k] = dg;
+    a.d_beta[k] = db;
+  }
+}
+
 void egt_edge_finish_param_grads(int De, const float* gamma, const float* beta, const float* Wg, const float* We,
                                  const float* part_proj, const float* part_upd, int n_partials, float* red_proj, float* red_upd,
                                  float* d_gamma, float* d_beta, float* d_Wg, float* d_bg, float* d_We, float* d_be,
@@ -589,16 +655,12 @@ void egt_edge_finish_param_grads(int De, const float* gamma, const float* beta, 
   a.De = De; a.flags = EGT_EP_LAYERNORM | EGT_EP_GATES;
   a.gamma = gamma; a.beta = beta; a.Wg = Wg; a.We = We;
   a.d_gamma = d_gamma; a.d_beta = d_beta; a.d_Wg = d_Wg; a.d_bg = d_bg; a.d_We = d_We; a.d_be = d_be; a.d_Wr = d_Wr; a.d_br = d_br;
-  a.n_partials = 1;
   DISPATCH_DE(De, {
     constexpr int PSZ1 = DE * 16 + 16;
     constexpr int PSZ2 = EDGE_H * DE + DE;
-    EGT_LAUNCH("k_edge_reduce_partials", k_edge_reduce_partials, dim3((PSZ1 + 15) / 16), dim3(256), 0, st, part_proj, PSZ1, n_partials, red_proj);
-    EGT_LAUNCH("k_edge_reduce_partials", k_edge_reduce_partials, dim3((PSZ2 + 15) / 16), dim3(256), 0, st, part_upd, PSZ2, n_partials, red_upd);
-    a.ws = red_proj;
-    EGT_LAUNCH("k_edge_proj_bwd_final", k_edge_proj_bwd_final<DE>, dim3(1), dim3(256), 0, st, a);
-    a.ws = red_upd;
-    EGT_LAUNCH("k_edge_update_bwd_final", k_edge_update_bwd_final<DE>, dim3(1), dim3(256), 0, st, a);
+    EGT_LAUNCH("k_pair_reduce_partials", k_pair_reduce_partials, dim3((PSZ1 + 15) / 16 + (PSZ2 + 15) / 16), dim3(256), 0, st,
+               part_proj, PSZ1, part_upd, PSZ2, n_partials, red_proj, red_upd);
+    EGT_LAUNCH("k_pair_param_final", k_pair_param_final<DE>, dim3(2), dim3(256), 0, st, a, (const float*)red_proj, (const float*)red_upd);
   });
 }
 

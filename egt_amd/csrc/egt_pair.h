@@ -45,6 +45,7 @@ __device__ __forceinline__ void pair_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
+#define PR_CLAMP(x) (FULL ? (x) : min((x), N - 1))
 #ifndef PAIR_EDGE_PRIO
 #define PAIR_EDGE_PRIO 2
 #endif
@@ -117,7 +118,8 @@ __device__ __forceinline__ void pair_fold_weights(const PairArgs& pa, int i, int
 //             edge:      dense_edge_r + residual of tile it-1 (H_hat stage (it-1)&1) -> e(it+2) requested -> LN + projections of tile it+1 -> stage (it+1)&1
 // (stamps of the first version -- DMA issued by the edge waves, two barriers -- profiles/r06_pair_stamps_v1.txt: the attention waves
 //  waited at barriers for half of the launch while the edge waves issued the workgroup's vector memory)
-template <int D, int DE, int V>
+// FULL: N is a multiple of 16 (no ragged tile: every row / key of every tile exists -- the clamps and the store-address selects fold away)
+template <int D, int DE, int V, bool FULL>
 __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, PairArgs pa) {
   constexpr int KT = D / 16, DH = D * AH, T = PairGeo<DE>::T, HS = KT * 256;   // HS: floats of one head's operand tile
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -167,15 +169,15 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int l = l0 + 4 * j + r;
-      rowok[r] = l < N;
-      const size_t ro = (((size_t)b * N + min(l, N - 1)) * N * DE) * sizeof(float);
+      rowok[r] = FULL || l < N;
+      const size_t ro = (((size_t)b * N + PR_CLAMP(l)) * N * DE) * sizeof(float);
       erow[r] = reinterpret_cast<const char*>(pa.e) + ro;
       orow[r] = reinterpret_cast<char*>(pa.e_out) + ro;
     }
     char* dumpl = reinterpret_cast<char*>(pa.dump) + lane * 16;
     struct ESet { float4 x[4][T]; };
     auto eload = [&](ESet& s, int mt) __attribute__((always_inline)) {
-      const uint32_t mo = ((uint32_t)min(16 * mt + p, N - 1) * DE + 4 * q) * 4;
+      const uint32_t mo = ((uint32_t)PR_CLAMP(16 * mt + p) * DE + 4 * q) * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -205,7 +207,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
     // e' = e + H_hat.Wr + br of tile mt from set s (the registers that loaded e) and the H_hat planes of stage mt & 1
     auto update = [&](const ESet& s, int mt) __attribute__((always_inline)) {
       const int m = 16 * mt + p;
-      const uint32_t mo = ((uint32_t)min(m, N - 1) * DE + 4 * q) * 4;
+      const uint32_t mo = ((uint32_t)PR_CLAMP(m) * DE + 4 * q) * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float* hp = Hp + (mt & 1) * (AH * PT_PL) + q * PT_PL + pt_off(4 * j + r, p);
@@ -215,7 +217,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
           v4f acc = {brv[t][0], brv[t][1], brv[t][2], brv[t][3]};
           acc = MFMA(wU[t][0], h0, acc);
           acc = MFMA(wU[t][1], h1, acc);
-          char* dst = (rowok[r] && m < N) ? orow[r] + mo + 64 * t : dumpl;
+          char* dst = (FULL || (rowok[r] && m < N)) ? orow[r] + mo + 64 * t : dumpl;
           *reinterpret_cast<float4*>(dst) =
               make_float4(s.x[r][t].x + acc[0], s.x[r][t].y + acc[1], s.x[r][t].z + acc[2], s.x[r][t].w + acc[3]);
         }
@@ -318,7 +320,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
     }
     const int po4 = (2 * w) * PT_PL + pt_off(ll, 4 * q);                       // + hh * PT_PL: the lane's keys 4q..4q+3 of row ll
     const float* opl = Kb + (2 * w) * HS + ll * 16 + ((q ^ chunk_xor(ll)) << 2);   // + hh * HS + 256 T
-    const int lq = min(l0 + ll, N - 1);
+    const int lq = PR_CLAMP(l0 + ll);
     vm_wait<0>();              // (Q fragments in registers, tiles of key tile 0 landed)
     pair_barrier();             // barrier(0)
     STAMP(7);
@@ -370,7 +372,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
           hv4[r] = hv;                                          // H_hat: post-clip, pre-mask (egt_layers.py:85-86)
           float add = kav[r];
           if (V == 2) {
-            const int m = min(m0 + 4 * q + r, N - 1);
+            const int m = PR_CLAMP(m0 + 4 * q + r);
             const uint32_t gi = (uint32_t)((((size_t)b * N + lq) * N + m) * AH + h);
             add += ((egt_hash32(gi, a.s0, a.s1) >> 8) < a.rm_thr) ? -EGT_NEG : 0.0f;
           }
@@ -463,7 +465,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
 //   trip's tile right after its last read of a stage, counted vmcnt before its next read; no cross-wave hand-off), and inside an edge
 //   wave POST(it-1) precedes PRE(it+1) in program order (they share a plane set, and a wave touches only its own rows of it)
 //   trip it:  attention: half A (head w), half B (head w + 4)       edge: POST(it-1) + e, de' requests of it+1; PRE(it+1); row constants of it+1
-template <int D, int DE, int V>
+template <int D, int DE, int V, bool FULL>
 __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, PairArgs pa) {
   constexpr int KT = D / 16, DH = D * AH, T = PairGeo<DE>::T, HS = KT * 256, TSZ = AH * PT_PL;
   constexpr int PSZ1 = DE * 16 + 16, PSZ2 = AH * DE + DE;
@@ -523,13 +525,13 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
       if (lane < 32) *reinterpret_cast<float4*>(statL + ((stage * AH + j + 4 * (lane >> 4)) * 16 + (lane & 15)) * 4) = v;
     };
     const int mkey = m0 + p;
-    const bool keyok = mkey < N;
-    const uint32_t keyb = ((uint32_t)min(mkey, N - 1) * DE + 4 * q) * 4;   // the ONE lane offset (bytes, 32 bit) of every e / de' / de access: row pointers are wave-uniform
+    const bool keyok = FULL || mkey < N;
+    const uint32_t keyb = ((uint32_t)PR_CLAMP(mkey) * DE + 4 * q) * 4;   // the ONE lane offset (bytes, 32 bit) of every e / de' / de access: row pointers are wave-uniform
     const size_t gb = (size_t)b * N * N * DE;
     struct HSet { float4 x[4][T], df[4][T]; };
     float* rsd = wtab + 3 * T * 64 * 4 + 64 * 4 + j * (2 * 4 * 16);   // 1 / sigma of the held tiles: [set][row][pair] (8 registers otherwise)
     auto raw_load = [&](HSet& s, int r, int ltile) __attribute__((always_inline)) {
-      const size_t ro = (gb + (size_t)min(16 * ltile + 4 * r + j, N - 1) * N * DE) * sizeof(float);   // wave-uniform: scalar registers
+      const size_t ro = (gb + (size_t)PR_CLAMP(16 * ltile + 4 * r + j) * N * DE) * sizeof(float);   // wave-uniform: scalar registers
       const char* er = reinterpret_cast<const char*>(pa.e) + ro;
       const char* dr = reinterpret_cast<const char*>(pa.d_e_out) + ro;
 #pragma unroll
@@ -542,7 +544,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
     // trip ago, served by L2 / the memory-side cache
     char* dumpl = reinterpret_cast<char*>(pa.dump) + lane * 16;
     auto df_load = [&](HSet& s, int r, int ltile) __attribute__((always_inline)) {
-      const char* dr = reinterpret_cast<const char*>(pa.d_e_out) + (gb + (size_t)min(16 * ltile + 4 * r + j, N - 1) * N * DE) * sizeof(float);
+      const char* dr = reinterpret_cast<const char*>(pa.d_e_out) + (gb + (size_t)PR_CLAMP(16 * ltile + 4 * r + j) * N * DE) * sizeof(float);
 #pragma unroll
       for (int t = 0; t < T; ++t) s.df[r][t] = *reinterpret_cast<const float4*>(dr + keyb + 64 * t);
     };
@@ -561,7 +563,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
     const int xrd = q * DE + (((p >> 2) ^ q) << 2) + (p & 3);
     // PRE: tile row r of query tile `ltile` from the raw values in set s -> planes of set `ps`; ehat / de' stay in s
     auto pre = [&](HSet& s, int set, int r, int ltile, float* ps) __attribute__((always_inline)) {
-      const bool valid = keyok && (16 * ltile + 4 * r + j) < N;
+      const bool valid = FULL || (keyok && (16 * ltile + 4 * r + j) < N);
       const float rstd_ = pair_ln<T>(s.x[r], pa.ln_eps);
       if (q == 0) rsd[(set * 4 + r) * 16 + p] = rstd_;
       const float4 b4 = wget(3, 0);
@@ -598,7 +600,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
     // POST: tile row r of query tile `ltile`: the planes of set `ps` now hold dE | dG | H_hat
     auto post = [&](HSet& s, int set, int r, int ltile, const float* ps) __attribute__((always_inline)) {
       const int l = 16 * ltile + 4 * r + j;
-      const bool valid = keyok && l < N;
+      const bool valid = FULL || (keyok && l < N);
       if (!valid) {
 #pragma unroll
         for (int t = 0; t < T; ++t) s.df[r][t] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -624,7 +626,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
       m1 = pair_sum_q(m1) * (1.0f / DE);
       m2 = pair_sum_q(m2) * (1.0f / DE);
       const float rstd = rsd[(set * 4 + r) * 16 + p];
-      char* orow_ = reinterpret_cast<char*>(pa.d_e) + (gb + (size_t)min(l, N - 1) * N * DE) * sizeof(float);
+      char* orow_ = reinterpret_cast<char*>(pa.d_e) + (gb + (size_t)PR_CLAMP(l) * N * DE) * sizeof(float);
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const float4 xh = s.x[r][t], d0 = s.df[r][t];
@@ -787,7 +789,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
       else if (a.km && a.km[(size_t)b * N + m] == 0) kadd = -EGT_NEG;
     }
     const float kaddg = (m0 + mm) < N ? -kadd * L2E : 3.0e38f;
-    const int mc = min(m0 + mm, N - 1);
+    const int mc = PR_CLAMP(m0 + mm);
     v4f dKacc[2][KT], dVacc[2][KT];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
@@ -858,7 +860,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
           if (clip) ah = __builtin_amdgcn_fmed3f(araw, a.clip_lo, a.clip_hi);
           float add = kadd;
           if (V == 2) {
-            const int lq = min(l0 + 4 * q + r, N - 1);
+            const int lq = PR_CLAMP(l0 + 4 * q + r);
             const uint32_t gi = (uint32_t)((((size_t)b * N + lq) * N + mc) * AH + h);
             add += ((egt_hash32(gi, a.s0, a.s1) >> 8) < a.rm_thr) ? -EGT_NEG : 0.0f;
           }

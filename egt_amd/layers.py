@@ -136,6 +136,9 @@ class KerasDense(nn.Module):
         nn.init.xavier_uniform_(self.kernel)
 
     def forward(self, x):
+        if x.is_cuda and x.dim() >= 2 and x.dtype == self.kernel.dtype:
+            # one library GEMM with the bias in its epilogue (x.W + b, keras.layers.Dense) instead of a GEMM and an add
+            return torch.addmm(self.bias, x.reshape(-1, x.shape[-1]), self.kernel).view(*x.shape[:-1], self.kernel.shape[1])
         return x @ self.kernel + self.bias
 
 
