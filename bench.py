@@ -575,6 +575,16 @@ def run_block(args, w, dev, lib, rank, world, use_dist):
                                      tflops=(fl[k] / (v[1] / v[0] / 1e3) / 1e12) if k in fl else None,
                                      hbm_frac=(hbm[k] / (v[1] / v[0] / 1e3) / 1e9 / HBM_PEAK_GBS) if k in hbm else None)
                              for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
+        try:   # HBM bytes / matrix-pipe busy per launch of the dominant kernel from the committed counter passes of this workload (static citation)
+            pmc = (json.load(open(os.path.join(REPO, "profiles", "pmc_mfma.json"))).get(args.workload) or {}).get(dominant) or {}
+            roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+            roof["mfma_busy"] = pmc.get("mfma_busy")
+            roof["issue"] = pmc.get("issue")
+            if pmc:
+                roof["pmc_source"] = ("static: profiles/pmc_mfma.json = committed rocprofv3 --pmc passes of this workload (tools/profile_r06.sh; "
+                                      "HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024); not re-measured in this run")
+        except Exception:  # noqa: BLE001
+            pass
         if dominant in hbm:   # the fused pair kernels sit between both roofs: algorithmic HBM bytes of the dominant one beside its flops
             roof["hbm_achieved_GBs"] = hbm[dominant] / avg_s / 1e9
             roof["hbm_frac"] = hbm[dominant] / avg_s / 1e9 / HBM_PEAK_GBS

@@ -1230,7 +1230,8 @@ extern "C" int egt_pair_supported(const egt_block_desc* d) {
 
 static size_t pair_partial_floats(const egt_block_desc* d) {   // per-workgroup partials + one reduced image each
   const size_t nwg = (size_t)d->B * (np_of(d->N) / 16);
-  return (nwg + 1) * ((size_t)d->De * 16 + 16) + (nwg + 1) * ((size_t)AH * d->De + d->De) + 256;   // + the 1 KB store dump (PairArgs::dump)
+  return (nwg + 1) * ((size_t)d->De * 16 + 16) + (nwg + 1) * ((size_t)AH * d->De + d->De) + 256   // + the 1 KB store dump (PairArgs::dump)
+         + (3 * ((size_t)d->De / 16) + 1) * 64 * 4;                                                      // + the prepared weight table (PairArgs::wprep)
 }
 
 // packed operand arrays (all six), row constants, dA tiles, parameter-gradient partials.  The forward writes the q / k / v arrays;
@@ -1268,7 +1269,9 @@ static int pair_fill(const egt_block_desc* d, const egt_block_params* P, const v
   pa.Wr = (const float*)P->dense_edge_r_kernel; pa.br = (const float*)P->dense_edge_r_bias;
   {   // the last 1 KB of the workspace
     const size_t NP = np_of(d->N), arr = (size_t)d->B * AH * NP * d->d;
-    pa.dump = (float*)workspace + PK_COUNT * arr + (size_t)d->B * AH * NP * 4 + (size_t)d->B * AH * NP * NP + pair_partial_floats(d) - 256;
+    const size_t wt = (3 * ((size_t)d->De / 16) + 1) * 64 * 4;
+    pa.wprep = (float*)workspace + PK_COUNT * arr + (size_t)d->B * AH * NP * 4 + (size_t)d->B * AH * NP * NP + pair_partial_floats(d) - wt;
+    pa.dump = pa.wprep - 256;
   }
   return EGT_OK;
 }
@@ -1285,6 +1288,7 @@ extern "C" int egt_pair_fwd(const egt_block_desc* desc, const egt_block_params* 
   hipStream_t st = (hipStream_t)stream;
   launch_pack<64>(a, st);
   constexpr int D = 64, DE = 32, HS = (D / 16) * 256;
+  EGT_LAUNCH("k_pair_prep", k_pair_prep<DE>, dim3(1), dim3(64), 0, st, pa);
   const size_t lds = ((size_t)2 * AH * HS + 2 * (size_t)((a.NP + 16 + 3) & ~3) + (size_t)6 * AH * PT_PL) * sizeof(float);
   const int grid = a.B * (a.NP / 16);
 #define PAIR_FWD(V_, F_) do { EGT_MAX_LDS_ONCE(k_pair_fwd<D, DE, V_, F_>); \
@@ -1322,6 +1326,7 @@ extern "C" int egt_pair_bwd(const egt_block_desc* desc, const egt_block_params* 
   a.pack_what = PACK_O | ((desc->reserved & EGT_ATTN_WS_SHARED) ? 0 : (PACK_Q | PACK_KH | PACK_KT | PACK_VH));
   hipStream_t st = (hipStream_t)stream;
   launch_pack<64>(a, st);   // (also the per-row constants, delta = sum_k dO*O among them)
+  EGT_LAUNCH("k_pair_prep", k_pair_prep<DE>, dim3(1), dim3(64), 0, st, pa);
   const size_t lds = ((size_t)2 * 4 * 2 * HS + (size_t)2 * 3 * AH * PT_PL + (size_t)2 * AH * 64 + (size_t)4 * 2 * 16 * DE + (size_t)3 * (DE / 16) * 64 * 4 + 64 * 4 + 4 * 2 * 4 * 16) * sizeof(float);
 #define PAIR_BWD(V_, F_) do { EGT_MAX_LDS_ONCE(k_pair_bwd<D, DE, V_, F_>); \
     EGT_LAUNCH("k_pair_bwd", (k_pair_bwd<D, DE, V_, F_>), dim3(nwg), dim3(64 * PR_WAVES), lds, st, a, pa); } while (0)

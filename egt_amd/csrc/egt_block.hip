@@ -41,7 +41,6 @@
 
 #include "egt_block_fwd.h"   // k_block_fwd, k_block_fwd_r4
 #include "egt_block_bwd.h"   // k_block_bwd_v4, k_block_bwd_v5, k_block_bwd_v4r
-#include "egt_block_bwd7.h"  // k_block_bwd_v7 (twelve waves per CU)
 
 // ================================================================ host glue ====
 
@@ -108,7 +107,6 @@ struct BlockLayout {
   size_t dvp, dqp, dkvp, dqp_sz, dkvp_sz, common_total;
   size_t pw, epart, spart, sbo, wpart, ered, dqkv, dhbuf, layer_total;
   int TL, NLR, nwg_bwd, EP;   // TL: query rows per backward workgroup
-  bool v7;                    // geometry of k_block_bwd_v7 (32-row workgroups of twelve waves): two 16-row groups of this layout per workgroup
 };
 
 // Query rows per backward workgroup (<= 16: the MFMA tiles of the node-side prologue):
@@ -151,18 +149,7 @@ static BlockLayout layout(const egt_block_desc* d) {
   L.pw_sv = o; o += al((size_t)DEP * 16 + 16);
   L.wfrag_sv = o; o += al(Dh <= 64 ? WFRAG_FLOATS : 0);
   L.saved_total = o;
-  {   // k_block_bwd_v7: fp32 edge tensors of 64 channels, no attention-mask tensor, N = 32 or 64 (a multiple of 32 whose key tiles divide
-      // the twelve waves; the graph's V rows live in LDS), and a launch of at least one 32-row workgroup per CU.  It works on pairs of the
-      // layout's 16-row groups.  OPT-IN (EGT_BWD_V7=1: every geometry it covers; =2: only launches of at least one 32-row workgroup
-      // per CU): measured 104.7 us per launch at the headline batch against k_block_bwd_v5's 98.6 -- the third
-      // wave per SIMD does not pay, the kernels are bound by instruction issue and the memory path together, not by latency.
-    static const int sw = getenv("EGT_BWD_V7") ? atoi(getenv("EGT_BWD_V7")) : 0;
-    const int nt = d->N / 16;
-    const bool geo = d->dtype == EGT_F32 && d->De == 64 && !(d->flags & EGT_BF_ATTN_MASK) && d->N % 32 == 0 && d->N <= 64 && V7_WAVES % nt == 0;
-    static const bool tl_forced = getenv("EGT_BWD_TL") != nullptr;
-    L.v7 = geo && !tl_forced && (sw == 1 || (sw == 2 && d->B * (d->N / 32) >= egt_device_cus()));
-  }
-  L.TL = L.v7 ? 16 : bwd_rows_per_wg(d);
+  L.TL = bwd_rows_per_wg(d);
   L.NLR = (d->N + L.TL - 1) / L.TL;
   L.nwg_bwd = d->B * L.NLR;
   o = 0;
@@ -207,7 +194,6 @@ extern "C" const char* egt_block_bwd_kernel(const egt_block_desc* d) {
   const bool ml = (d->flags & EGT_BF_ATTN_MASK) != 0, bf = d->dtype == EGT_BF16;
   if (d->De == 8 && !ml && !block_env().no_narrow_bwd) return "k_narrow_bwd";
   if (d->De <= 16 && !ml) return "k_block_bwd_v4r";
-  if (d->De == 64 && L.v7 && !ml && !bf) return "k_block_bwd_v7";
   if (d->De >= 32 && !ml && !bf) return "k_block_bwd_v5";
   return "k_block_bwd_v4";
 }
@@ -428,22 +414,6 @@ static int launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool t
         }
       }
       if constexpr (DE >= 32) {
-        if constexpr (DE == 64) {
-        if (L.v7 && !ml && !a.bf16) {   // twelve waves per CU (k_block_bwd_v7): one workgroup = two of the layout's 16-row groups
-          constexpr int PW7 = 2 * GG::TILE_FLOATS + 256 + 128;
-          size_t area = (size_t)V7_WAVES * PW7;
-          if (area < 3 * BWD_PRO_WS) area = 3 * BWD_PRO_WS;
-          if (area < (size_t)V7_WAVES * 2048) area = (size_t)V7_WAVES * 2048;
-          if (area < (size_t)V7_WAVES * GG::EP) area = (size_t)V7_WAVES * GG::EP;
-          // tile area + 32 staged node rows + weight slabs (wsA, compact wsB, wsD) + the graph's V rows
-          const size_t lds7 = (area + (size_t)V7_ROWS * QD_LD + (size_t)GG::TILES * 256 * 5 / 2 + (size_t)a.N * 64) * 4;
-          a.NLR = L.NLR / 2;                 // dK / dV partials per key (the consumer -- the next prologue / k_node_bwd -- reads a.NLR of its own launch: same value)
-          nep = L.nwg_bwd / 2;
-          EGT_MAX_LDS_ONCE(k_block_bwd_v7<DE>);
-          EGT_LAUNCH("k_block_bwd", (k_block_bwd_v7<DE>), dim3(nep), dim3(64 * V7_WAVES), lds7, st, a);
-          goto pair_done;
-        }
-        }
         if (!ml && !a.bf16) {   // LDS-DMA staged e tiles (k_block_bwd_v5), ragged N included
           const bool x3 = block_env().bwd_mm == EGT_MM_BF16X3;
           const size_t lds_v5 = ((size_t)V5_AREA(DE) + (size_t)BWD_TL * QD_LD + 3 * ((GG::TILES + 1) / 2) * 512) * 4;

@@ -304,8 +304,7 @@ struct BwdProRegs { float4 hx, gq[3], wq[12], wo[4]; float dho[4], gmm[4], va[4]
   const int lnrow = 4 * wave + q;    /* LayerNorm mapping: row 4*wave + q, columns p + 16 i */            \
   /* ragged last row group (N not a multiple of 16): loads are clamped to the graph's last row, the rows  \
      past the end contribute zeros to every sum and are never stored */                                   \
-  const int nv = pnv >= 0 ? pnv : min(a.TL, N - l_begin);  /* valid rows of this 16-row group (<= 16; 0: an idle group of  \
-                                                              k_block_bwd_v7 that only keeps the barriers) */             \
+  const int nv = pnv >= 0 ? pnv : min(a.TL, N - l_begin);  /* valid rows of this 16-row group (<= 16) */                          \
   auto rc = [&](int r) { return row0 + max(min(r, nv - 1), 0); };   /* clamped global row */               \
   const int Dh = D64 ? 64 : a.Dh;                                                                          \
   (void)LD; (void)LD3; (void)lnrow; (void)p; (void)q; (void)rc; (void)Dh
@@ -556,8 +555,8 @@ __device__ __forceinline__ void bwd_node_prologue_finish(const BlockArgs& a, flo
   else bwd_prologue_compute<DE, false>(a, ws, qd, b, l_begin, wg, R, false, nullptr, threadIdx.x, -1);
 }
 // ptid / pnv: the calling thread's index inside its 256-thread group and the group's valid rows -- defaults: the workgroup IS the
-// group (threadIdx.x, min(a.TL, N - l_begin)).  k_block_bwd_v7 runs one group per 16 of its 32 rows (wg = the group's partial slot);
-// every thread of the workgroup must make the call (the barriers inside are workgroup barriers), surplus groups with pnv = 0.
+// group (threadIdx.x, min(a.TL, N - l_begin)).  (A workgroup of several 256-thread groups -- round 5's twelve-wave experiment, in the git
+// history -- passes its own; every thread of the workgroup must make the call: the barriers inside are workgroup barriers.)
 template <int DE, bool HOIST = false>
 __device__ __forceinline__ void bwd_node_prologue(const BlockArgs& a, float* ws, float* qd, int b, int l_begin, int wg, unsigned* tp = nullptr,
                                                   int ptid = -1, int pnv = -1) {

@@ -30,6 +30,7 @@ struct PairArgs {
   // backward
   const float* d_e_out;
   float *d_e, *part_proj, *part_upd;   // per-workgroup partials: [That[De][16] | s[16]] and [dWr[8][De] | dbr[De]]
+  float* wprep;  // [wA | wB | wR][T][64 lanes][4] | bias [64][4]: the edge waves' lane-constant MFMA operands, LN-folded once per launch by k_pair_prep
   float* dump;   // 1 KB of workspace: where the lanes of pairs outside the graph send their stores.  Every store of the edge waves is
                  // issued unconditionally (no branch around it), so the compiler's vmcnt bookkeeping counts it: behind a store it cannot
                  // count (exec-masked block) the wait for an older prefetch would also wait for that store's completion
@@ -103,10 +104,35 @@ __device__ __forceinline__ void pair_fold_weights(const PairArgs& pa, int i, int
     const int o = 4 * q + r;
     const float* W = o < 8 ? pa.Wg + o : pa.We + (o - 8);
     float b = o < 8 ? pa.bg[o] : pa.be[o - 8];
-#pragma nounroll
-    for (int c = 0; c < DE; ++c) b = fmaf(pa.beta[c], W[c * 8], b);   // (rolled: unrolled, hipcc loads both matrices into registers at once)
+#pragma unroll 8
+    for (int c = 0; c < DE; ++c) b = fmaf(pa.beta[c], W[c * 8], b);
     bias[r] = b;
   }
+}
+
+// One wave, once per launch: the LN-folded projection weights in the edge waves' A-operand layout (lane (i = lane&15, q)) -> pa.wprep.
+// (Inside the pair kernels this cost every workgroup ~10 us of dependent global round trips at its head: the bias sums over the channels.)
+template <int DE>
+__global__ void __launch_bounds__(64) k_pair_prep(PairArgs pa) {
+  constexpr int T = PairGeo<DE>::T;
+  const int lane = threadIdx.x, p = lane & 15, q = lane >> 4;
+  float wA[T][4], bias[4];
+  pair_fold_weights<DE>(pa, p, q, wA, bias);
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float wB[4], wR[4];   // d ehat = Wp.dGE: A[c = 16 t + i][o = 4 q + s] = gamma_c Wcat[c][o];  dH_ext = Wr.de': A[h = i (< 8)][c = 16 t + 4 q + r] = Wr[h][c]
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int c = 16 * t + p, o = 4 * q + s;
+      wB[s] = (o < 8 ? pa.Wg[c * 8 + o] : pa.We[c * 8 + o - 8]) * pa.gamma[c];
+      const int c2 = 16 * t + 4 * q + s;
+      wR[s] = p < 8 ? pa.Wr[p * DE + c2] : 0.f;
+    }
+    *reinterpret_cast<float4*>(pa.wprep + ((0 * T + t) * 64 + lane) * 4) = make_float4(wA[t][0], wA[t][1], wA[t][2], wA[t][3]);
+    *reinterpret_cast<float4*>(pa.wprep + ((1 * T + t) * 64 + lane) * 4) = make_float4(wB[0], wB[1], wB[2], wB[3]);
+    *reinterpret_cast<float4*>(pa.wprep + ((2 * T + t) * 64 + lane) * 4) = make_float4(wR[0], wR[1], wR[2], wR[3]);
+  }
+  *reinterpret_cast<float4*>(pa.wprep + (3 * T * 64 + lane) * 4) = make_float4(bias[0], bias[1], bias[2], bias[3]);
 }
 
 // ================================================================== forward =====
@@ -152,7 +178,15 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
       kaddG[m] = m >= N ? 3.0e38f : -ka * L2E;
     }
     float wA[T][4], bias[4];
-    pair_fold_weights<DE>(pa, p, q, wA, bias);
+    {   // LN-folded [gamma Wg | gamma We] and its bias, prepared once per launch (k_pair_prep)
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float4 v = *reinterpret_cast<const float4*>(pa.wprep + (t * 64 + lane) * 4);
+        wA[t][0] = v.x; wA[t][1] = v.y; wA[t][2] = v.z; wA[t][3] = v.w;
+      }
+      const float4 bv = *reinterpret_cast<const float4*>(pa.wprep + (3 * T * 64 + lane) * 4);
+      bias[0] = bv.x; bias[1] = bv.y; bias[2] = bv.z; bias[3] = bv.w;
+    }
     // dense_edge_r: A[c = 16 t + i][h = q + 4 s] = Wr[h][c]; bias br[16 t + 4 q + r] on the lane's output channels
     float wU[T][2], brv[T][4];
 #pragma unroll
@@ -490,26 +524,10 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
 #if PAIR_EDGE_PRIO
     __builtin_amdgcn_s_setprio(PAIR_EDGE_PRIO);
 #endif
-    {
-      float bias[4];
-      // every edge wave writes the same table (same values: a benign race), then reads only after its own writes completed
-      float wA[T][4];
-      pair_fold_weights<DE>(pa, p, q, wA, bias);
+    {   // the prepared table (k_pair_prep) -> LDS: every edge wave writes the same values (a benign race) and reads only after its own writes
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        float wB[4], wR[4];   // d ehat = Wp.dGE: A[c = 16 t + i][o = 4 q + s] = gamma_c Wcat[c][o];  dH_ext = Wr.de': A[h = i (< 8)][c = 16 t + 4 q + r] = Wr[h][c]
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int c = 16 * t + p, o = 4 * q + s;
-          wB[s] = (o < 8 ? pa.Wg[c * 8 + o] : pa.We[c * 8 + o - 8]) * pa.gamma[c];
-          const int c2 = 16 * t + 4 * q + s;
-          wR[s] = p < 8 ? pa.Wr[p * DE + c2] : 0.f;
-        }
-        *reinterpret_cast<float4*>(wtab + ((0 * T + t) * 64 + lane) * 4) = make_float4(wA[t][0], wA[t][1], wA[t][2], wA[t][3]);
-        *reinterpret_cast<float4*>(wtab + ((1 * T + t) * 64 + lane) * 4) = make_float4(wB[0], wB[1], wB[2], wB[3]);
-        *reinterpret_cast<float4*>(wtab + ((2 * T + t) * 64 + lane) * 4) = make_float4(wR[0], wR[1], wR[2], wR[3]);
-      }
-      *reinterpret_cast<float4*>(wtab + (3 * T * 64 + lane) * 4) = make_float4(bias[0], bias[1], bias[2], bias[3]);
+      for (int i = 0; i < 3 * T + 1; ++i)
+        *reinterpret_cast<float4*>(wtab + (i * 64 + lane) * 4) = *reinterpret_cast<const float4*>(pa.wprep + (i * 64 + lane) * 4);
       lds_sync_();
     }
     auto wget = [&](int which, int t) __attribute__((always_inline)) { return *reinterpret_cast<const float4*>(wtab + ((which * T + t) * 64 + lane) * 4); };

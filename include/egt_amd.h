@@ -267,7 +267,7 @@ typedef struct egt_block_params {
 
 /* 1 when the fused kernels cover `desc`, else 0 (caller composes instead). */
 int egt_block_supported(const egt_block_desc* desc);
-/* Name of the backward pair-kernel family the dispatch takes for `desc` when no mask tensor is passed ("k_block_bwd_v7",
+/* Name of the backward pair-kernel family the dispatch takes for `desc` when no mask tensor is passed (
  * "k_block_bwd_v5", "k_block_bwd_v4", "k_block_bwd_v4r", "k_narrow_bwd": DESIGN.md section 4); NULL when `desc` is not covered.
  * Static string; for tests and bench lines (the launch profiler reports every family as "k_block_bwd"). */
 const char* egt_block_bwd_kernel(const egt_block_desc* desc);

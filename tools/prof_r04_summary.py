@@ -19,6 +19,11 @@ XCDS = 8   # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (value / duration
 # measured issue costs (tools/micro/mfma_stream.hip, valu_rates.hip): cycles a SIMD is occupied per instruction
 MFMA_CYC, VALU_CYC = 32.0, 2.5
 KEYS = {"zinc500k_n64": ["k_block_bwd", "k_block_fwd"], "synthetic_n512": ["k_attn_mfma_bwd_kv", "k_attn_mfma_fwd", "k_attn_mfma_bwd_q", "k_attn_pack"]}
+# round 6: the fused pair operator at block scope, and fresh counters for the De = 8 / ZINC-100K lines (PROF_WORKLOADS = the list that was profiled)
+PAIR = ["k_pair_bwd", "k_pair_fwd", "k_attn_mfma_bwd_q", "k_attn_pack"]
+for _wl in os.environ.get("PROF_WORKLOADS", "").split():
+    if _wl not in KEYS:
+        KEYS[_wl] = PAIR if _wl.startswith("synthetic_n512_block") else ["k_block_bwd", "k_block_fwd"]
 
 
 def db_of(d):
@@ -120,11 +125,19 @@ def main():
         pt = json.load(open(ptf))
     except Exception:  # noqa: BLE001
         pt = {}
-    if "zinc500k_n64" in traffic_all:
-        pt["zinc500k_n64"] = {k: v for k, v in traffic_all["zinc500k_n64"].items()}
-        pt["_source_zinc500k_n64"] = f"profiles/{name}_rocprof_summary.md"
+    for wl, tr in traffic_all.items():   # every workload whose FETCH / WRITE passes ran in this profile replaces its entry
+        pt[wl] = {k: v for k, v in tr.items()}
+        pt["_source_" + wl] = f"profiles/{name}_rocprof_summary.md"
+    if traffic_all:
         json.dump(pt, open(ptf, "w"), indent=1)
     if mfma_all:
+        try:   # workloads not profiled this time keep their entries
+            old = json.load(open(os.path.join(REPO, "profiles", "pmc_mfma.json")))
+            for k, v in old.items():
+                if not k.startswith("_") and k not in mfma_all:
+                    mfma_all[k] = v
+        except Exception:  # noqa: BLE001
+            pass
         mfma_all["_source"] = (f"profiles/{name}_rocprof_summary.md (rocprofv3 --pmc, separate passes: FETCH_SIZE; WRITE_SIZE; SQ_* + GRBM_GUI_ACTIVE; SQ_INSTS_*): "
                                "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); "
                                f"issue.frac = (MFMAs x {MFMA_CYC:.0f} + other VALU x {VALU_CYC}) / (1024 x active cycles)")
