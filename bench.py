@@ -484,6 +484,11 @@ def run_block(args, w, dev, lib, rank, world, use_dist):
     from egt_amd import EGTBlock
     from egt_amd.dp import FlatGradAllReduce
     B, N, H, Dh, De = w["B"], w["N"], w["H"], w["Dh"], w["De"]
+    blas = os.environ.get("EGT_BENCH_BLAS", "hipblaslt")   # library of the node-side fp32 GEMMs ([B N, 512] x [512, 1536] ...): hipBLASLt measured ~1 % ahead of the default
+    try:
+        torch.backends.cuda.preferred_blas_library(blas)
+    except Exception:  # noqa: BLE001
+        blas = "default"
     g = torch.Generator().manual_seed(1234 + rank)
     torch.manual_seed(7)                                  # the same parameters on every rank
     blk = EGTBlock(model_width=Dh, edge_width=De, num_heads=H, random_mask_prob=w["rand_p"]).to(dev).train()
@@ -601,7 +606,7 @@ def run_block(args, w, dev, lib, rank, world, use_dist):
                    "scope": "block", "graphs_per_gpu": B, "global_batch": graphs_step, "N": N, "Dh": Dh, "De": De, "H": H, "d": Dh // H,
                    "random_mask_prob": w["rand_p"], "nodes": list(w["nodes"]),
                    "path": ("fused pair operator: k_pair_fwd / k_pair_bwd (LN + gates / edge bias -> MFMA inner op -> dense_edge_r + residual in one pair "
-                            "kernel per direction: E, G, H_hat, dE, dG, dH_ext stay in LDS) + k_attn_mfma_bwd_q, rocBLAS node-side Dense") if fused_pair else
+                            "kernel per direction: E, G, H_hat, dE, dG, dH_ext stay in LDS) + k_attn_mfma_bwd_q; node-side Dense = torch library GEMMs (" + blas + ")") if fused_pair else
                            "composed: k_edge_proj (LN + gates / edge bias) -> MFMA inner op -> k_edge_update (dense_edge_r + residual), rocBLAS node-side Dense",
                    "parallelism": f"dp{world}", "backend": "rccl" if use_dist else "none (single process)",
                    "tflops_step": flops_blk * (graphs_step / B) / step_s / 1e12},

@@ -1326,7 +1326,8 @@ extern "C" int egt_pair_bwd(const egt_block_desc* desc, const egt_block_params* 
   a.pack_what = PACK_O | ((desc->reserved & EGT_ATTN_WS_SHARED) ? 0 : (PACK_Q | PACK_KH | PACK_KT | PACK_VH));
   hipStream_t st = (hipStream_t)stream;
   launch_pack<64>(a, st);   // (also the per-row constants, delta = sum_k dO*O among them)
-  EGT_LAUNCH("k_pair_prep", k_pair_prep<DE>, dim3(1), dim3(64), 0, st, pa);
+  if (!(desc->reserved & EGT_ATTN_WS_SHARED))   // (a shared workspace still holds the forward's table: same parameter values by contract)
+    EGT_LAUNCH("k_pair_prep", k_pair_prep<DE>, dim3(1), dim3(64), 0, st, pa);
   const size_t lds = ((size_t)2 * 4 * 2 * HS + (size_t)2 * 3 * AH * PT_PL + (size_t)2 * AH * 64 + (size_t)4 * 2 * 16 * DE + (size_t)3 * (DE / 16) * 64 * 4 + 64 * 4 + 4 * 2 * 4 * 16) * sizeof(float);
 #define PAIR_BWD(V_, F_) do { EGT_MAX_LDS_ONCE(k_pair_bwd<D, DE, V_, F_>); \
     EGT_LAUNCH("k_pair_bwd", (k_pair_bwd<D, DE, V_, F_>), dim3(nwg), dim3(64 * PR_WAVES), lds, st, a, pa); } while (0)

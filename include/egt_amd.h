@@ -330,8 +330,8 @@ int egt_stack_bwd(const egt_block_desc* desc, int32_t layers,
  * node-side Dense layers of mha_block (norm_mha, dense_qkv :109-113, dense_mha :136) are [B N, 512] GEMMs and stay
  * with the caller (library GEMMs): the operator takes QKV [B,N,3 d H] (channel s*dH + k*H + h, egt_layers.py:73-76)
  * and returns V_att [B,N,d H].  egt_block_desc / egt_block_params are reused (node-side pointers are ignored);
- * desc->reserved & EGT_ATTN_WS_SHARED: the caller hands the forward's untouched workspace to the backward
- * (the q / k / v operand copies are then made once).  In-kernel random mask as in egt_block_fwd. */
+ * desc->reserved & EGT_ATTN_WS_SHARED: the caller hands the forward's untouched workspace to the backward, called
+ * with the same parameter values (the q / k / v operand copies and the LN-folded weight table are then made once).  In-kernel random mask as in egt_block_fwd. */
 int egt_pair_supported(const egt_block_desc* desc);
 size_t egt_pair_workspace_bytes(const egt_block_desc* desc);
 int egt_pair_fwd(const egt_block_desc* desc, const egt_block_params* params, const void* qkv,

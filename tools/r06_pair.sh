@@ -18,7 +18,7 @@ EGT_ATTN_FLAGS=-DEGT_ATTN_STAMPS python tools/pair_stamps.py > $OUT/stamps.txt 2
 tail -50 $OUT/stamps.txt
 fi
 # the node-side GEMM library: hipBLASLt preferred instead of the default
-TORCH_BLAS_PREFER_HIPBLASLT=1 timeout 300 python bench.py --workload synthetic_n512_block --no-cpu-baseline --no-prof > $OUT/bench_block_lt.json 2>> $OUT/bench_block_err.log
+EGT_BENCH_BLAS=default timeout 300 python bench.py --workload synthetic_n512_block --no-cpu-baseline --no-prof > $OUT/bench_block_lt.json 2>> $OUT/bench_block_err.log
 python -c "
 import json
-d=json.loads(open('gpurun_out/r06_pair/bench_block_lt.json').read().strip().splitlines()[-1]); print('hipblaslt preferred:', round(d['value']), d['ms_per_step'])"
+d=json.loads(open('gpurun_out/r06_pair/bench_block_lt.json').read().strip().splitlines()[-1]); print('default BLAS:', round(d['value']), d['ms_per_step'])"
