@@ -52,6 +52,25 @@ def test_argument_validation_without_gpu(egt_lib):
     assert egt_lib.egt_edge_update_fwd(C.byref(e), *([None] * 6)) == L.EGT_E_SHAPE
 
 
+def test_pair_entry_points_validate_without_gpu(egt_lib):
+    """egt_pair_* (the fused pair operator of the large-head geometry): coverage query, workspace size and argument errors -- no launch"""
+    from egt_amd import _lib as L
+    d = L.BlockDesc(B=8, N=512, H=8, d=64, De=32, dtype=L.EGT_F32, flags=L.BF_GATE | L.BF_CLIP, clip_lo=-5, clip_hi=5,
+                    random_mask_prob=0.0, ln_eps=1e-3, reserved=0, seed=0, seed_device=None)
+    assert egt_lib.egt_pair_supported(C.byref(d)) == 1
+    arr = 8 * 8 * 512 * 64
+    nwg = 8 * 32
+    floats = 6 * arr + 8 * 8 * 512 * 4 + 8 * 8 * 512 * 512 + (nwg + 1) * (32 * 16 + 16) + (nwg + 1) * (8 * 32 + 32) + 256 + 7 * 64 * 4
+    assert egt_lib.egt_pair_workspace_bytes(C.byref(d)) == 4 * floats
+    prm = L.BlockParams()
+    assert egt_lib.egt_pair_fwd(C.byref(d), C.byref(prm), *([None] * 8)) == L.EGT_E_NULL      # qkv / e / workspace NULL
+    d.d = 8                                                                                  # the d <= 8 geometry belongs to egt_block_*
+    assert egt_lib.egt_pair_supported(C.byref(d)) == 0 and egt_lib.egt_pair_workspace_bytes(C.byref(d)) == 0
+    assert egt_lib.egt_pair_fwd(C.byref(d), C.byref(prm), *([None] * 8)) == L.EGT_E_SHAPE
+    assert b"fused pair operator" in egt_lib.egt_last_error_string()
+    assert egt_lib.egt_pair_bwd(C.byref(d), C.byref(prm), *([None] * 9), C.byref(prm), None, None) == L.EGT_E_SHAPE
+
+
 def test_dp_entry_points_validate_without_a_communicator(egt_lib):
     """egt_dp_* (SURVEY 8(b)): state queries and argument errors before any communicator exists (no RCCL call)."""
     from egt_amd import _lib as L
