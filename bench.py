@@ -430,12 +430,7 @@ def run_core(args, w, dev, lib, rank, world, use_dist):
     pairs = B * N * N
     # ALGORITHMIC flops (core op 12 N^2 Dh per graph fwd+bwd): forward QK^T + A.V = 4, backward dP + dV + dK = 6
     # in k_attn_mfma_bwd_kv, dQ = 2 in k_attn_mfma_bwd_q; the backward's recompute of S (2 more) is executed, not counted
-    # algorithmic flops per launch.  The fused pair kernels carry the edge-channel contractions of SURVEY 8(d)'s block count as well:
-    # forward LN-folded projections 2 De 16 + dense_edge_r 2 H De per pair, backward twice that (input + weight gradients)
-    edge_f = 2.0 * De * 2 * H + 2.0 * H * De
-    fl = {"k_attn_mfma_fwd": 4.0 * pairs * Dh, "k_attn_mfma_bwd_kv": 6.0 * pairs * Dh, "k_attn_mfma_bwd_q": 2.0 * pairs * Dh,
-          "k_pair_fwd": pairs * (4.0 * Dh + edge_f), "k_pair_bwd": pairs * (6.0 * Dh + 2.0 * edge_f)}
-    hbm = {"k_pair_fwd": pairs * De * 4 * 2.0, "k_pair_bwd": pairs * (De * 4 * 3.0 + H * 4.0)}   # e in, e' out / e, de' in, de out + the dA tiles
+    fl = {"k_attn_mfma_fwd": 4.0 * pairs * Dh, "k_attn_mfma_bwd_kv": 6.0 * pairs * Dh, "k_attn_mfma_bwd_q": 2.0 * pairs * Dh}
     roof = None
     if prof:
         cnt, ms = dom_prof.get(dominant, prof[dominant])

@@ -39,6 +39,16 @@ struct PairArgs {
 #define PR_WAVES 8
 // LDS hand-off inside ONE wave (its DS operations complete in order): drain lgkmcnt, never vmcnt
 __device__ __forceinline__ void lds_sync_() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+// The same hand-off WITHOUT the drain: the LDS executes one wave's DS instructions in program order, so a read issued behind a write of
+// the same wave sees it and a write issued behind a read cannot overtake it -- only the compiler has to keep the order (the waits for
+// the reads' results are its own, at their first use).  PAIR_LDS_NOWAIT=0 restores the drains (A/B).
+#ifndef PAIR_LDS_NOWAIT
+#define PAIR_LDS_NOWAIT 1
+#endif
+__device__ __forceinline__ void lds_order_() {
+  if (PAIR_LDS_NOWAIT) { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+  else lds_sync_();
+}
 // the workgroup barrier of the pair kernels: nothing is scheduled across it (a plain asm barrier orders memory only: hipcc hoisted the
 // next trip's LayerNorm arithmetic above it, i.e. in front of the wait for a tile that had only just been requested)
 __device__ __forceinline__ void pair_barrier() {
@@ -58,6 +68,18 @@ __device__ __forceinline__ const float* uni_ptr(const float* p) {
   const uint64_t v = (uint64_t)(uintptr_t)p;
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
   return (const float*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+// four consecutive 1 KB pieces (4 KB of HBM -> 4 KB of LDS) in one asm block: M0 saved / restored once, advanced by 1 KB per piece; the
+// lane offsets of pieces 1..3 are doff + 1024 i (doff < 1024), kept in registers by the caller.  (Per piece the single-piece form costs
+// 5 scalar instructions + the 64-bit source add: 112 scalar instructions per key tile in an attention wave.)
+__device__ __forceinline__ void dma_pieces4(unsigned lds, const float* src, unsigned o0, unsigned o1, unsigned o2, unsigned o3) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+               "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+               "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+               "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(src), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(lds) : "memory", "scc");
 }
 typedef float pr_nt_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 egt_ld4_nt_(const float* p) {
@@ -323,11 +345,16 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
     const float* Kh = uni_ptr(a.pk + PK_KH * arr + ((size_t)b * AH + 2 * w) * NP * D);
     const float* VT = uni_ptr(a.pk + PK_VT * arr + ((size_t)b * AH + 2 * w) * D * NP);
     const unsigned kdst = lds_addr(Kb) + (2 * w) * HS * 4, vdst = lds_addr(Vb) + (2 * w) * HS * 4;
+    const unsigned doff1 = doff + 1024, doff2 = doff + 2048, doff3 = doff + 3072;
     auto dma_tile = [&](unsigned dst, const float* src) __attribute__((always_inline)) {   // src: [2 heads] x (KT pieces), head stride NP * D floats
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
+      for (int hh = 0; hh < 2; ++hh) {
+        if constexpr (KT == 4) dma_pieces4(dst + hh * KT * 1024, src + (size_t)hh * NP * D, doff, doff1, doff2, doff3);
+        else {
 #pragma unroll
-        for (int Tt = 0; Tt < KT; ++Tt) dma_piece(dst + (hh * KT + Tt) * 1024, src + (size_t)hh * NP * D + Tt * 256, doff);
+          for (int Tt = 0; Tt < KT; ++Tt) dma_piece(dst + (hh * KT + Tt) * 1024, src + (size_t)hh * NP * D + Tt * 256, doff);
+        }
+      }
     };
     dma_tile(kdst, Kh);
     dma_tile(vdst, VT);
@@ -673,7 +700,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
           hA[s4] = i < 8 ? hv : (i == 8 ? 1.0f : 0.f);   // row 8 = ones: its product row is the bias gradient sum of de'
         }
       }
-      lds_sync_();
+      lds_order_();
 #pragma unroll
       for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -682,7 +709,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
           accT[t] = MFMA(aD[s4], xs[idx], accT[t]);
           accW[t] = MFMA(hA[s4], dfs[idx], accW[t]);
         }
-      lds_sync_();
+      lds_order_();
     };
 
     HSet H0, H1;
@@ -822,13 +849,19 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
     const float* Qh = uni_ptr(a.pk + PK_QH * arr + ((size_t)b * AH + w) * NP * D);
     const float* Oh = uni_ptr(a.pk + PK_OH * arr + ((size_t)b * AH + w) * NP * D);
     const unsigned odst = lds_addr(Ops) + w * (2 * HS * 4);
+    const unsigned doff1 = doff + 1024, doff2 = doff + 2048, doff3 = doff + 3072;
     auto dma_half = [&](int ltile, int half) __attribute__((always_inline)) {
       const size_t ho = (size_t)half * 4 * NP * D + (size_t)ltile * 16 * D;
       const unsigned dst = odst + half * (4 * 2 * HS * 4);
+      if constexpr (KT == 4) {
+        dma_pieces4(dst, Qh + ho, doff, doff1, doff2, doff3);
+        dma_pieces4(dst + KT * 1024, Oh + ho, doff, doff1, doff2, doff3);
+      } else {
 #pragma unroll
-      for (int Tt = 0; Tt < KT; ++Tt) {
-        dma_piece(dst + Tt * 1024, Qh + ho + Tt * 256, doff);
-        dma_piece(dst + (KT + Tt) * 1024, Oh + ho + Tt * 256, doff);
+        for (int Tt = 0; Tt < KT; ++Tt) {
+          dma_piece(dst + Tt * 1024, Qh + ho + Tt * 256, doff);
+          dma_piece(dst + (KT + Tt) * 1024, Oh + ho + Tt * 256, doff);
+        }
       }
     };
     dma_half(0, 0);

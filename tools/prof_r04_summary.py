@@ -31,7 +31,15 @@ def db_of(d):
     return sqlite3.connect(f[0]) if f else None
 
 
+# the De = 8 pair kernels are launched under the bench's label "k_block_fwd" / "k_block_bwd" (one label per role: bench.py's kernel table,
+# pmc_traffic.json) but carry their own symbol names in a rocprofv3 database
+ALIAS = {"k_narrow_bwd": "k_block_bwd", "k_narrow_fwd": "k_block_fwd"}
+
+
 def key_of(kn, wl):
+    for sym, k in ALIAS.items():
+        if sym in kn and k in KEYS[wl]:
+            return k
     for k in KEYS[wl]:
         if k in kn:
             return k
