@@ -1289,7 +1289,7 @@ extern "C" int egt_pair_fwd(const egt_block_desc* desc, const egt_block_params* 
   launch_pack<64>(a, st);
   constexpr int D = 64, DE = 32, HS = (D / 16) * 256;
   EGT_LAUNCH("k_pair_prep", k_pair_prep<DE>, dim3(1), dim3(64), 0, st, pa);
-  const size_t lds = ((size_t)2 * AH * HS + 2 * (size_t)((a.NP + 16 + 3) & ~3) + (size_t)6 * AH * PT_PL) * sizeof(float);
+  const size_t lds = ((size_t)2 * AH * HS + 2 * (size_t)((a.NP + 16 + 3) & ~3) + (size_t)6 * AH * PT_PL + 16 + DE) * sizeof(float);
   const int grid = a.B * (a.NP / 16);
 #define PAIR_FWD(V_, F_) do { EGT_MAX_LDS_ONCE(k_pair_fwd<D, DE, V_, F_>); \
     EGT_LAUNCH("k_pair_fwd", (k_pair_fwd<D, DE, V_, F_>), dim3(grid), dim3(64 * PR_WAVES), lds, st, a, pa); } while (0)

@@ -57,6 +57,16 @@ __device__ __forceinline__ void pair_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 #define PR_CLAMP(x) (FULL ? (x) : min((x), N - 1))
+#ifndef PAIR_ABL
+#define PAIR_ABL 0   // timing ablations of k_pair_fwd (results are wrong): 1 attention waves idle, 2 no dense_edge_r / stores, 4 no LN / projections, 8 no e requests
+#endif
+#ifndef PAIR_NT_ST
+#define PAIR_NT_ST 0   // k_pair_fwd: e' stores non-temporal (A/B)
+#endif
+#ifndef PAIR_STAGGER
+#define PAIR_STAGGER 0   // k_pair_fwd: 1 = a workgroup starts on the key tile of its own row block instead of every workgroup on tile `it` in lock step
+                        // (the 16 rows of a workgroup are 64 KB apart: a test for HBM channel camping) -- measured: no difference (145.1-146.2 vs 145.4-146.7 us)
+#endif
 #ifndef PAIR_EDGE_PRIO
 #define PAIR_EDGE_PRIO 2
 #endif
@@ -180,10 +190,17 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
   float* kaddG = kaddL + KA;
   float* In = kaddG + KA;              // [2 stages][E | G][8][PT_PL]
   float* Hp = In + 4 * AH * PT_PL;     // [2 stages][8][PT_PL]
+  float* ctab = Hp + 2 * AH * PT_PL;   // [16] projection bias (output 4q + r) | [DE] dense_edge_r bias: lane-dependent through q only, 12 registers otherwise
   const int wg = egt_xcd_remap(blockIdx.x, gridDim.x);   // the row blocks of a graph share an XCD's L2 (K / V^T of the graph: 2 MB)
   const int b = __builtin_amdgcn_readfirstlane(wg / mtiles), l0 = __builtin_amdgcn_readfirstlane((wg % mtiles) * 16);   // (the division runs on the VALU: back to scalar registers)
   const size_t arr = (size_t)a.B * AH * NP * D;
   const bool clip = (a.flags & EGT_F_CLIP) != 0;
+  // Key-tile order: trip `it` works on key tile (it + row block) mod mtiles.  The online softmax does not care about the order of the keys,
+  // HBM does: the 16 rows of a workgroup are N De 4 bytes apart (64 KB at config 5), so with every workgroup on key tile `it` in lock
+  // step the whole chip reads and writes ONE 2 KB window of every 64 KB period of the e tensor at a time (a fraction of the channels);
+  // staggered, the 32 row blocks of a graph cover the period.
+  const int tstart = PAIR_STAGGER ? (l0 >> 4) % mtiles : 0;
+  auto mt_of = [&](int it) __attribute__((always_inline)) { const int t = it + tstart; return t < mtiles ? t : t - mtiles; };
   STAMP_DECL;
 
   if (wv >= 4) {
@@ -199,24 +216,24 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
       kaddL[m] = ka;
       kaddG[m] = m >= N ? 3.0e38f : -ka * L2E;
     }
-    float wA[T][4], bias[4];
+    float wA[T][4];
     {   // LN-folded [gamma Wg | gamma We] and its bias, prepared once per launch (k_pair_prep)
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const float4 v = *reinterpret_cast<const float4*>(pa.wprep + (t * 64 + lane) * 4);
         wA[t][0] = v.x; wA[t][1] = v.y; wA[t][2] = v.z; wA[t][3] = v.w;
       }
-      const float4 bv = *reinterpret_cast<const float4*>(pa.wprep + (3 * T * 64 + lane) * 4);
-      bias[0] = bv.x; bias[1] = bv.y; bias[2] = bv.z; bias[3] = bv.w;
+      // (every edge wave writes the same values: a benign race; read back only behind the first barrier)
+      if (p == 0) *reinterpret_cast<float4*>(ctab + 4 * q) = *reinterpret_cast<const float4*>(pa.wprep + (3 * T * 64 + lane) * 4);
+      if (lane < DE / 4) *reinterpret_cast<float4*>(ctab + 16 + 4 * lane) = *reinterpret_cast<const float4*>(pa.br + 4 * lane);
+      lds_sync_();
     }
-    // dense_edge_r: A[c = 16 t + i][h = q + 4 s] = Wr[h][c]; bias br[16 t + 4 q + r] on the lane's output channels
-    float wU[T][2], brv[T][4];
+    // dense_edge_r: A[c = 16 t + i][h = q + 4 s] = Wr[h][c]; bias br[16 t + 4 q + r] on the lane's output channels (ctab)
+    float wU[T][2];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       wU[t][0] = pa.Wr[q * DE + 16 * t + p];
       wU[t][1] = pa.Wr[(q + 4) * DE + 16 * t + p];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) brv[t][r] = pa.br[16 * t + 4 * q + r];
     }
     // row r of the wave: a wave-uniform row pointer (scalar registers) + one 32-bit lane offset (bytes) per tile
     const char* erow[4];
@@ -247,7 +264,8 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
 #pragma unroll
         for (int t = 0; t < T; ++t) x[t] = s.x[r][t];
         pair_ln<T>(x, pa.ln_eps);
-        v4f acc = {bias[0], bias[1], bias[2], bias[3]};
+        const float4 b4 = *reinterpret_cast<const float4*>(ctab + 4 * q);
+        v4f acc = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           acc = MFMA(wA[t][0], x[t].x, acc);
@@ -261,27 +279,51 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
       }
     };
     // e' = e + H_hat.Wr + br of tile mt from set s (the registers that loaded e) and the H_hat planes of stage mt & 1
-    auto update = [&](const ESet& s, int mt) __attribute__((always_inline)) {
-      const int m = 16 * mt + p;
-      const uint32_t mo = ((uint32_t)PR_CLAMP(m) * DE + 4 * q) * 4;
+    auto update_compute = [&](const ESet& s, int itx, ESet& ov) __attribute__((always_inline)) {   // itx: the trip that produced the planes
+      // all eight plane reads, then the sixteen MFMAs as eight independent chains issued crosswise (no dependent back-to-back pair), then
+      // the eight stores: written row by row the compiler keeps row r's read -> MFMA -> MFMA -> add -> store chain together and the wave
+      // sits out every latency of it in turn (ablation: 36 us of the 142 us launch)
+      float h0[4], h1[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float* hp = Hp + (mt & 1) * (AH * PT_PL) + q * PT_PL + pt_off(4 * j + r, p);
-        const float h0 = hp[0], h1 = hp[4 * PT_PL];
+        const float* hp = Hp + (itx & 1) * (AH * PT_PL) + q * PT_PL + pt_off(4 * j + r, p);
+        h0[r] = hp[0]; h1[r] = hp[4 * PT_PL];
+      }
+      v4f acc[4][T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float4 b4 = *reinterpret_cast<const float4*>(ctab + 16 + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r][t] = MFMA(wU[t][0], h0[r], ((v4f){b4.x, b4.y, b4.z, b4.w}));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[r][t] = MFMA(wU[t][1], h1[r], acc[r][t]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+          ov.x[r][t] = make_float4(s.x[r][t].x + acc[r][t][0], s.x[r][t].y + acc[r][t][1], s.x[r][t].z + acc[r][t][2], s.x[r][t].w + acc[r][t][3]);
+    };
+    // ... and its stores (timing ablation PAIR_ABL & 16: without them the launch is 38 us shorter -- 113 of 151 us -- although the write
+    // bandwidth they need is a fraction of the chip's; non-temporal stores: +14 us)
+    auto update_store = [&](const ESet& ov, int itx) __attribute__((always_inline)) {
+      if (PAIR_ABL & 16) return;   // (timing ablation: no stores)
+      const int m = 16 * mt_of(itx) + p;
+      const uint32_t mo = ((uint32_t)PR_CLAMP(m) * DE + 4 * q) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          v4f acc = {brv[t][0], brv[t][1], brv[t][2], brv[t][3]};
-          acc = MFMA(wU[t][0], h0, acc);
-          acc = MFMA(wU[t][1], h1, acc);
           char* dst = (FULL || (rowok[r] && m < N)) ? orow[r] + mo + 64 * t : dumpl;
-          *reinterpret_cast<float4*>(dst) =
-              make_float4(s.x[r][t].x + acc[0], s.x[r][t].y + acc[1], s.x[r][t].z + acc[2], s.x[r][t].w + acc[3]);
+          *reinterpret_cast<float4*>(dst) = ov.x[r][t];
         }
-      }
     };
+    auto update = [&](const ESet& s, int itx) __attribute__((always_inline)) { ESet ov; update_compute(s, itx, ov); update_store(ov, itx); };
     ESet S0, S1, S2;
-    eload(S0, 0);
-    eload(S1, min(1, mtiles - 1));
+    eload(S0, mt_of(0));
+    eload(S1, mt_of(min(1, mtiles - 1)));
     project(S0, 0);
     pair_barrier();             // barrier(0)
     // The set of e(k) is S[k % 3]; trip it updates tile it-1 from S[(it+2) % 3] (then refilled with e(it+2)) and projects e(it+1) from
@@ -301,19 +343,21 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
     auto steady = [&](int it, ESet& done, ESet& nxt) __attribute__((always_inline)) {
       STAMP(7);
       pin(nxt);
-      update(done, it - 1);
+      if (!(PAIR_ABL & 2)) update(done, it - 1);
       __builtin_amdgcn_sched_barrier(0);
       STAMP(0);
-      eload(done, min(it + 2, mtiles - 1));
+      // (requesting e(it+2) BEFORE the stores -- vmcnt retires in order, so that the next trip's wait for it would not cover them -- was
+      //  built and measured: 159-160 us against 146-147; the order below stays)
+      if (!(PAIR_ABL & 8)) eload(done, mt_of(min(it + 2, mtiles - 1)));
       __builtin_amdgcn_sched_barrier(0);
       STAMP(1);
-      project(nxt, (it + 1) & 1);
+      if (!(PAIR_ABL & 4)) project(nxt, (it + 1) & 1);
       STAMP(2);
       pair_barrier();           // barrier(it+1)
       STAMP(3);
     };
     {   // trip 0: nothing to update yet
-      eload(S2, min(2, mtiles - 1));
+      eload(S2, mt_of(min(2, mtiles - 1)));
       __builtin_amdgcn_sched_barrier(0);
       if (mtiles > 1) project(S1, 1);
       pair_barrier();
@@ -356,8 +400,8 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
         }
       }
     };
-    dma_tile(kdst, Kh);
-    dma_tile(vdst, VT);
+    dma_tile(kdst, Kh + (size_t)mt_of(0) * 16 * D);
+    dma_tile(vdst, VT + (size_t)mt_of(0) * 16 * D);
     float Qr[2][4 * KT];
     {
       const int ltile = l0 >> 4;
@@ -386,9 +430,10 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
     pair_barrier();             // barrier(0)
     STAMP(7);
     for (int it = 0; it < mtiles; ++it) {
-      const int m0 = 16 * it;
+      const int m0 = 16 * mt_of(it);
       const bool more = it + 1 < mtiles;
       const float* Inb = In + (it & 1) * (2 * AH * PT_PL);
+      if (PAIR_ABL & 1) { pair_barrier(); continue; }
       if (it > 0) vm_wait<2 * KT>();   // K(it) landed (requested a tile ago; only the V^T(it) pieces are younger)
       float4 kc[2][KT], e4[2], g4[2];
 #pragma unroll
@@ -417,7 +462,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
       __builtin_amdgcn_sched_barrier(0);
       STAMP(0);
       // the K tiles of the next key tile: this wave was their only reader and its reads have returned (the MFMAs above consumed them)
-      if (more) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dma_tile(kdst, Kh + (size_t)(it + 1) * 16 * D); }
+      if (more) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dma_tile(kdst, Kh + (size_t)mt_of(it + 1) * 16 * D); }
       const float kav[4] = {ka4.x, ka4.y, ka4.z, ka4.w}, kgv[4] = {kg4.x, kg4.y, kg4.z, kg4.w};
       float pa_[2][4];
 #pragma unroll
@@ -480,7 +525,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
           for (int hh = 0; hh < 2; ++hh) oacc[hh][kt] = MFMA(f4get(vc[hh][kt], r), pa_[hh][r], oacc[hh][kt]);
       __builtin_amdgcn_sched_barrier(0);
       STAMP(2);
-      if (more) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dma_tile(vdst, VT + (size_t)(it + 1) * 16 * D); }
+      if (more) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dma_tile(vdst, VT + (size_t)mt_of(it + 1) * 16 * D); }
       pair_barrier();           // barrier(it+1)
       STAMP(3);
     }
