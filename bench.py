@@ -67,6 +67,7 @@ WORKLOADS = {
     # all parameter gradients.  d = 64 is outside the fused pair kernels (d <= 8): the composed path -- HIP edge projections / edge
     # update (egt_edge.hip) + the MFMA inner op + rocBLAS node-side Dense
     "synthetic_n512_block": dict(B=8, N=512, Dh=512, De=32, H=8, Ly=1, nodes=(512, 512), rand_p=0.1, scope="block"),
+    "synthetic_n512_block_b32": dict(B=32, N=512, Dh=512, De=32, H=8, Ly=1, nodes=(512, 512), rand_p=0.1, scope="block"),   # four rounds of workgroups, node-side GEMMs with 16 k rows
     "synthetic_n512_block_nomask": dict(B=8, N=512, Dh=512, De=32, H=8, Ly=1, nodes=(512, 512), rand_p=0.0, scope="block"),   # diagnosis: what the in-kernel mask RNG costs
 }
 # what the metric string says after "graphs/sec EGT fwd+bwd, " (BASELINE.json's metric is quoted on the first)
@@ -80,6 +81,7 @@ METRIC_OF = {"zinc500k_n64": "ZINC-500K padded N=64", "zinc500k_n64_nomask": "ZI
              "pattern500k_n120_pad128_b128": "PATTERN-500K shapes padded N=128 (B=128)",
              "synthetic_n512": "synthetic dense N=512 heads=8 d=64 (core op)", "synthetic_n512_b32": "synthetic dense N=512 heads=8 d=64 (core op, B=32)",
              "synthetic_n512_block": "synthetic dense N=512 heads=8 d=64 (block op)",
+             "synthetic_n512_block_b32": "synthetic dense N=512 heads=8 d=64 (block op, B=32)",
              "synthetic_n512_block_nomask": "synthetic dense N=512 heads=8 d=64 (block op, random_mask_prob = 0)"}
 FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
 

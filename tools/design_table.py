@@ -19,6 +19,7 @@ ROWS = [("zinc500k_n64", "`zinc500k_n64` (2, headline: B = 128, N = 64, De = 64,
         ("synthetic_n512", "`synthetic_n512` (5, core-op scope, B = 8; `bound = mfma`)"),
         ("synthetic_n512_b32", "`synthetic_n512_b32`"),
         ("synthetic_n512_block", "`synthetic_n512_block` (5, block scope, FUSED pair operator)"),
+        ("synthetic_n512_block_b32", "`synthetic_n512_block_b32` (the same at B = 32)"),
         ("scope_layers", "`--scope layers` (ZINC, attention block + node / edge FFN per layer)"),
         ("scope_model", "`--scope model` (whole ZINC model)")]
 

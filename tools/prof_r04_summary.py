@@ -150,7 +150,7 @@ def main():
                                "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); "
                                f"issue.frac = (MFMAs x {MFMA_CYC:.0f} + other VALU x {VALU_CYC}) / (1024 x active cycles)")
         json.dump(mfma_all, open(os.path.join(REPO, "profiles", "pmc_mfma.json"), "w"), indent=1)
-    for wl in ("cifar10_n150", "pattern500k_n120_b128", "zinc100k_n37", "pattern500k_n120", "synthetic_n512_b32", "synthetic_n512_block",
+    for wl in ("cifar10_n150", "pattern500k_n120_b128", "zinc100k_n37", "pattern500k_n120", "synthetic_n512_b32", "synthetic_n512_block", "synthetic_n512_block_b32",
                "zinc500k_n64_full", "pattern500k_bmax", "pattern500k_bmax_b128", "pattern500k_n188", "pattern500k_n188_b128", "cifar10_n150_fp32",
                "driver_style", "graph_on", "graph_off", "scope_layers", "scope_model"):
         try:
