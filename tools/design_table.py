@@ -30,7 +30,10 @@ def load(n):
             return json.loads(ln)
 
 
+import os
 for n, label in ROWS:
+    if not os.path.exists(f"profiles/{PRE}_bench_{n}.json"):
+        continue   # (a workload this profile run did not include)
     d = load(n); r = d["roofline"]; k = r.get("kernels") or {}
     sm = d["config"].get("step_mode"); sm = sm.get("chosen") if isinstance(sm, dict) else (sm or "—")
     nk = 4 if ("synthetic" in n or "scope" in n) else 2
