@@ -60,6 +60,9 @@ __device__ __forceinline__ void pair_barrier() {
 #ifndef PAIR_ABL
 #define PAIR_ABL 0   // timing ablations of k_pair_fwd (results are wrong): 1 attention waves idle, 2 no dense_edge_r / stores, 4 no LN / projections, 8 no e requests
 #endif
+#ifndef PAIR_ST_SC
+#define PAIR_ST_SC 0   // k_pair_fwd: e' stores with scope bits (1: sc1, 2: sc0 sc1 -- write-through forms that drop the line from L2); A/B
+#endif
 #ifndef PAIR_NT_ST
 #define PAIR_NT_ST 0   // k_pair_fwd: e' stores non-temporal (A/B)
 #endif
@@ -317,7 +320,10 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           char* dst = (FULL || (rowok[r] && m < N)) ? orow[r] + mo + 64 * t : dumpl;
-          *reinterpret_cast<float4*>(dst) = ov.x[r][t];
+          const pr_nt_v4f o4 = {ov.x[r][t].x, ov.x[r][t].y, ov.x[r][t].z, ov.x[r][t].w};
+          if (PAIR_ST_SC == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(o4) : "memory");
+          else if (PAIR_ST_SC == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(o4) : "memory");
+          else *reinterpret_cast<pr_nt_v4f*>(dst) = o4;
         }
     };
     auto update = [&](const ESet& s, int itx) __attribute__((always_inline)) { ESet ov; update_compute(s, itx, ov); update_store(ov, itx); };

@@ -53,9 +53,12 @@ def _compare(blk, out, ref):
         assert_close(getattr(getattr(blk, m), a).grad, ref["dparams"][k], name=k, **BWD)
 
 
-@pytest.mark.parametrize("B,N,nodes", [(2, 48, [48, 31]), (1, 37, [29]), (2, 16, [16, 9]), (1, 100, [100])])
+@pytest.mark.parametrize("B,N,nodes", [(2, 48, [48, 31]), (1, 37, [29]), (2, 16, [16, 9]), (1, 100, [100]),
+                                       (3, 24, [24, 0, 7]), (1, 8, [5]), (5, 32, [32, 17, 1, 32, 20])])
 def test_pair_block_vs_oracle(B, N, nodes, gpu, egt_lib):
-    """key padding inside and across key tiles, N not a multiple of 16 (ragged last tile), a single tile, several tiles"""
+    """key padding inside and across key tiles, N not a multiple of 16 (ragged last tile), a single tile, several tiles; a graph without
+    any node (every key masked: the reference's all-masked rows, egt_layers.py:91-108), a tile smaller than the MFMA tile, workgroup counts
+    that are not a multiple of the 8 XCDs (no remap)"""
     inp, params, c = _case(B, N, nodes, seed=100 + N)
     blk = build_block(c, ATTRS, params, gpu, "auto").eval()
     egt_lib.egt_prof_filter(b""); egt_lib.egt_prof_enable(2)
