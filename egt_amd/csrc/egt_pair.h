@@ -60,6 +60,10 @@ __device__ __forceinline__ void pair_barrier() {
 #ifndef PAIR_ABL
 #define PAIR_ABL 0   // timing ablations of k_pair_fwd (results are wrong): 1 attention waves idle, 2 no dense_edge_r / stores, 4 no LN / projections, 8 no e requests
 #endif
+#ifndef PAIR_BWD_NT
+#define PAIR_BWD_NT 4   // k_pair_bwd cache-policy hints: 1 e tiles non-temporal, 2 de' first read, 4 de' second read (POST).  Measured (same box, us per launch):
+                        // 0: 263.3-263.4, 1: 265.6-266.2, 4: 246.8-255.5, 5: 249.4-253.9 -> the re-read of de' (a tile nobody reads again) is non-temporal
+#endif
 #ifndef PAIR_ST_SC
 #define PAIR_ST_SC 0   // k_pair_fwd: e' stores with scope bits (1: sc1, 2: sc0 sc1 -- write-through forms that drop the line from L2); A/B
 #endif
@@ -95,6 +99,11 @@ __device__ __forceinline__ void dma_pieces4(unsigned lds, const float* src, unsi
                : "=&s"(keep) : "s"(src), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(lds) : "memory", "scc");
 }
 typedef float pr_nt_v4f __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 pr_ld4(const char* p) {
+  if (NT) { const pr_nt_v4f t = __builtin_nontemporal_load(reinterpret_cast<const pr_nt_v4f*>(p)); return make_float4(t[0], t[1], t[2], t[3]); }
+  return *reinterpret_cast<const float4*>(p);
+}
 __device__ __forceinline__ float4 egt_ld4_nt_(const float* p) {
   if (PAIR_NT_E) { const pr_nt_v4f t = __builtin_nontemporal_load(reinterpret_cast<const pr_nt_v4f*>(p)); return make_float4(t[0], t[1], t[2], t[3]); }
   return *reinterpret_cast<const float4*>(p);
@@ -631,9 +640,9 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
       const char* er = reinterpret_cast<const char*>(pa.e) + ro;
       const char* dr = reinterpret_cast<const char*>(pa.d_e_out) + ro;
 #pragma unroll
-      for (int t = 0; t < T; ++t) s.x[r][t] = *reinterpret_cast<const float4*>(er + keyb + 64 * t);
+      for (int t = 0; t < T; ++t) s.x[r][t] = pr_ld4<(PAIR_BWD_NT & 1) != 0>(er + keyb + 64 * t);
 #pragma unroll
-      for (int t = 0; t < T; ++t) s.df[r][t] = *reinterpret_cast<const float4*>(dr + keyb + 64 * t);
+      for (int t = 0; t < T; ++t) s.df[r][t] = pr_ld4<(PAIR_BWD_NT & 2) != 0>(dr + keyb + 64 * t);
     };
     // de' of a held tile is NOT kept in registers from PRE to POST (two sets x four rows x 8 registers that the allocator does not have:
     // spill reloads wait on vmcnt(0), i.e. drain the wave's whole prefetch queue): POST reads it again -- a tile this CU streamed one
@@ -642,7 +651,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
     auto df_load = [&](HSet& s, int r, int ltile) __attribute__((always_inline)) {
       const char* dr = reinterpret_cast<const char*>(pa.d_e_out) + (gb + (size_t)PR_CLAMP(16 * ltile + 4 * r + j) * N * DE) * sizeof(float);
 #pragma unroll
-      for (int t = 0; t < T; ++t) s.df[r][t] = *reinterpret_cast<const float4*>(dr + keyb + 64 * t);
+      for (int t = 0; t < T; ++t) s.df[r][t] = pr_ld4<(PAIR_BWD_NT & 4) != 0>(dr + keyb + 64 * t);
     };
     float* xs = scr + j * (2 * 16 * DE);   // ehat tile [16 pairs][DE], 16-byte chunks XORed with (pair & 7)
     float* dfs = xs + 16 * DE;
