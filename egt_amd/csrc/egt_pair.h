@@ -74,6 +74,9 @@ __device__ __forceinline__ void pair_barrier() {
 #define PAIR_STAGGER 0   // k_pair_fwd: 1 = a workgroup starts on the key tile of its own row block instead of every workgroup on tile `it` in lock step
                         // (the 16 rows of a workgroup are 64 KB apart: a test for HBM channel camping) -- measured: no difference (145.1-146.2 vs 145.4-146.7 us)
 #endif
+#ifndef PAIR_BWD_ABL
+#define PAIR_BWD_ABL 0   // timing ablations of k_pair_bwd (results are wrong): 1 first reads of e / de', 2 de stores, 4 the POST re-read of de' -- on the tile of trip 0 (cache hits)
+#endif
 #ifndef PAIR_EDGE_PRIO
 #define PAIR_EDGE_PRIO 2
 #endif
@@ -631,46 +634,62 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
     };
     const int mkey = m0 + p;
     const bool keyok = FULL || mkey < N;
-    const uint32_t keyb = ((uint32_t)PR_CLAMP(mkey) * DE + 4 * q) * 4;   // the ONE lane offset (bytes, 32 bit) of every e / de' / de access: row pointers are wave-uniform
+    // Rows of the wave: in row group r (rows 4 r .. 4 r + 3 of the tile) the lanes of key p work on row 4 r + sk, sk = (j + p) & 3 -- the
+    // four waves cover the four rows of every key (a Latin square).  With ONE row per wave-instruction (the first version: row 4 r + j)
+    // every plane access of the wave has the same (row & 3): its 32 lanes reach 8 of the 32 banks, a 4-way conflict on the 20 plane
+    // instructions per row (SQ_LDS_BANK_CONFLICT was 47 % of SQ_LDS_IDX_ACTIVE); skewed, a lane group's 32 addresses fall on 32 banks.
+    const int sk = (j + p) & 3;
+    const uint32_t rowB = (uint32_t)N * DE * 4;                          // bytes of one query row of e
+    const uint32_t keyb = ((uint32_t)PR_CLAMP(mkey) * DE + 4 * q) * 4;   // lane offset (bytes, 32 bit) inside a row
+    const uint32_t keybs = keyb + sk * rowB;                             // ... plus the lane's row inside a row group: the ONE lane offset of every e / de' / de access (FULL)
     const size_t gb = (size_t)b * N * N * DE;
+    // address of the lane's pair in row group r of query tile ltile: wave-uniform base (scalar registers) + 32-bit lane offset
+    auto rowaddr = [&](const float* base, int ltile, int r, uint32_t& lo, int kind = 1) __attribute__((always_inline)) {
+      if (PAIR_BWD_ABL & kind) ltile = 0;   // (timing ablation: every trip on the tile of trip 0 -- cache-resident)
+      if (FULL) { lo = keybs; return reinterpret_cast<const char*>(base) + (gb + (size_t)(16 * ltile + 4 * r) * N * DE) * sizeof(float); }
+      lo = keyb + (uint32_t)min(16 * ltile + 4 * r + sk, N - 1) * rowB;   // (N <= 2048: < 2^30)
+      return reinterpret_cast<const char*>(base) + gb * sizeof(float);
+    };
     struct HSet { float4 x[4][T], df[4][T]; };
     float* rsd = wtab + 3 * T * 64 * 4 + 64 * 4 + j * (2 * 4 * 16);   // 1 / sigma of the held tiles: [set][row][pair] (8 registers otherwise)
     auto raw_load = [&](HSet& s, int r, int ltile) __attribute__((always_inline)) {
-      const size_t ro = (gb + (size_t)PR_CLAMP(16 * ltile + 4 * r + j) * N * DE) * sizeof(float);   // wave-uniform: scalar registers
-      const char* er = reinterpret_cast<const char*>(pa.e) + ro;
-      const char* dr = reinterpret_cast<const char*>(pa.d_e_out) + ro;
+      uint32_t lo;
+      const char* er = rowaddr(pa.e, ltile, r, lo);
+      const char* dr = rowaddr(pa.d_e_out, ltile, r, lo);
 #pragma unroll
-      for (int t = 0; t < T; ++t) s.x[r][t] = pr_ld4<(PAIR_BWD_NT & 1) != 0>(er + keyb + 64 * t);
+      for (int t = 0; t < T; ++t) s.x[r][t] = pr_ld4<(PAIR_BWD_NT & 1) != 0>(er + lo + 64 * t);
 #pragma unroll
-      for (int t = 0; t < T; ++t) s.df[r][t] = pr_ld4<(PAIR_BWD_NT & 2) != 0>(dr + keyb + 64 * t);
+      for (int t = 0; t < T; ++t) s.df[r][t] = pr_ld4<(PAIR_BWD_NT & 2) != 0>(dr + lo + 64 * t);
     };
     // de' of a held tile is NOT kept in registers from PRE to POST (two sets x four rows x 8 registers that the allocator does not have:
     // spill reloads wait on vmcnt(0), i.e. drain the wave's whole prefetch queue): POST reads it again -- a tile this CU streamed one
     // trip ago, served by L2 / the memory-side cache
     char* dumpl = reinterpret_cast<char*>(pa.dump) + lane * 16;
     auto df_load = [&](HSet& s, int r, int ltile) __attribute__((always_inline)) {
-      const char* dr = reinterpret_cast<const char*>(pa.d_e_out) + (gb + (size_t)PR_CLAMP(16 * ltile + 4 * r + j) * N * DE) * sizeof(float);
+      uint32_t lo;
+      const char* dr = rowaddr(pa.d_e_out, ltile, r, lo, 4);
 #pragma unroll
-      for (int t = 0; t < T; ++t) s.df[r][t] = pr_ld4<(PAIR_BWD_NT & 4) != 0>(dr + keyb + 64 * t);
+      for (int t = 0; t < T; ++t) s.df[r][t] = pr_ld4<(PAIR_BWD_NT & 4) != 0>(dr + lo + 64 * t);
     };
-    float* xs = scr + j * (2 * 16 * DE);   // ehat tile [16 pairs][DE], 16-byte chunks XORed with (pair & 7)
-    float* dfs = xs + 16 * DE;
-    // plane offsets (ptT_off) of the wave's rows 4 r + j: the row enters through r (the chunk XOR, compile time) and j (the dword):
-    //   ptT_off(4 r + j, col) = (col << 4) + (((r ^ A[col >> 2]) & 3) << 2) + j,  A = (0, 2, 3, 1)
-    // own pair (col = p): (p << 4) + j + 4 ((r ^ A[p >> 2]) & 3); pairs on the contraction axis (col = 4 s + q): (q << 4) + j + a
-    // compile-time constant -> ONE address register for the sixteen transposed reads of a row
-    const int offp0 = (p << 4) + j, ap4 = chunk_xor(p) << 2;
-    const int q16 = (q << 4) + j;
-    // scratch tiles: [pair][channel] with the 16-byte chunk index XORed by (pair & 7)
-    //   own row (pair p), chunk 4 t + q:        p DE + 4 ((4 t + q) ^ (p & 7))
-    //   element (pair 4 s + q, channel 16 t + p): (4 s + q) DE + 16 (t ^ (s & 1)) + 4 ((p >> 2) ^ q) + (p & 3) = lane part + constant
-    const int xw0 = p * DE + ((q ^ (p & 7)) << 2);
-    const int xrd = q * DE + (((p >> 2) ^ q) << 2) + (p & 3);
+    float* xs = scr + j * (2 * 16 * DE);   // [ehat tile | de' tile]: layout below
+    // plane offsets (ptT_off) of the lane's rows 4 r + sk: the row enters through r (the chunk XOR, compile time) and sk (the dword):
+    //   ptT_off(4 r + sk, col) = (col << 4) + (((r ^ A[col >> 2]) & 3) << 2) + sk,  A = (0, 2, 3, 1)
+    // own pair (col = p): (p << 4) + sk + 4 ((r ^ A[p >> 2]) & 3); pairs on the contraction axis (col = 4 s + q, row 4 r + ((j + q) & 3)):
+    // (q << 4) + ((j + q) & 3) + a compile-time constant -> ONE address register for the sixteen transposed reads of a row
+    const int offp0 = (p << 4) + sk, ap4 = chunk_xor(p) << 2;
+    const int q16 = (q << 4) + ((j + q) & 3);   // pair 4 s + q on the contraction axis: its row is 4 r + ((j + q) & 3)
+    // scratch tiles: [channel block t][pair][16 channels], the 16-byte chunk index XORed by (pair >> 1) & 3
+    //   own row (pair p), chunk q of block t:     256 t + 16 p + 4 (q ^ ((p >> 1) & 3))                   (b128 stores: 8-lane groups on 32 banks)
+    //   element (pair 4 s + q, channel 16 t + p): 256 t + 64 s + [16 q + 4 ((p >> 2) ^ (q >> 1)) + (p & 3)] ^ 8 (s & 1)
+    //     (b32 reads: the pairs q, q + 1 of a 32-lane group are 16 floats apart -> the two halves of the banks.  The first layout,
+    //      [pair][DE] with the chunk XORed by pair & 7, put both on the same 16 banks: 2-way on the 16 reads of a row)
+    const int xw0 = 16 * p + ((q ^ ((p >> 1) & 3)) << 2);
+    const int xrd0 = 16 * q + (((p >> 2) ^ (q >> 1)) << 2) + (p & 3), xrd1 = xrd0 ^ 8;   // s even / odd
     // PRE: tile row r of query tile `ltile` from the raw values in set s -> planes of set `ps`; ehat / de' stay in s
     auto pre = [&](HSet& s, int set, int r, int ltile, float* ps) __attribute__((always_inline)) {
-      const bool valid = FULL || (keyok && (16 * ltile + 4 * r + j) < N);
+      const bool valid = FULL || (keyok && (16 * ltile + 4 * r + sk) < N);
       const float rstd_ = pair_ln<T>(s.x[r], pa.ln_eps);
-      if (q == 0) rsd[(set * 4 + r) * 16 + p] = rstd_;
+      if (q == 0) rsd[(set * 4 + r) * 16 + p] = rstd_;   // (the exec-masked block also keeps hipcc from clustering the four rows' LayerNorm sums in front of the wait for the LAST row's loads)
       const float4 b4 = wget(3, 0);
       v4f acc = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
@@ -704,7 +723,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
     };
     // POST: tile row r of query tile `ltile`: the planes of set `ps` now hold dE | dG | H_hat
     auto post = [&](HSet& s, int set, int r, int ltile, const float* ps) __attribute__((always_inline)) {
-      const int l = 16 * ltile + 4 * r + j;
+      const int l = 16 * ltile + 4 * r + sk;
       const bool valid = FULL || (keyok && l < N);
       if (!valid) {
 #pragma unroll
@@ -731,20 +750,21 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
       m1 = pair_sum_q(m1) * (1.0f / DE);
       m2 = pair_sum_q(m2) * (1.0f / DE);
       const float rstd = rsd[(set * 4 + r) * 16 + p];
-      char* orow_ = reinterpret_cast<char*>(pa.d_e) + (gb + (size_t)PR_CLAMP(l) * N * DE) * sizeof(float);
+      uint32_t lo;
+      char* orow_ = const_cast<char*>(rowaddr(pa.d_e, ltile, r, lo, 2));
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const float4 xh = s.x[r][t], d0 = s.df[r][t];
         const float4 o = make_float4(d0.x + rstd * (dx[t].x - m1 - xh.x * m2), d0.y + rstd * (dx[t].y - m1 - xh.y * m2),
                                      d0.z + rstd * (dx[t].z - m1 - xh.z * m2), d0.w + rstd * (dx[t].w - m1 - xh.w * m2));
-        *reinterpret_cast<float4*>(valid ? orow_ + keyb + 64 * t : dumpl) = o;
+        *reinterpret_cast<float4*>(valid ? orow_ + lo + 64 * t : dumpl) = o;
       }
       // weight gradients: both operands need the pairs on the contraction axis: ehat / de' through the wave's scratch tiles
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        const int ch = xw0 ^ (16 * t);   // (4 t + q) ^ (p & 7): bit 2 of the chunk index <-> bit 4 of the float index
+        const int ch = xw0 + 256 * t;
         *reinterpret_cast<float4*>(xs + ch) = s.x[r][t];
-        *reinterpret_cast<float4*>(dfs + ch) = s.df[r][t];
+        *reinterpret_cast<float4*>(xs + 16 * DE + ch) = s.df[r][t];
       }
       accS.x += dp0; accS.y += dp1; accS.z += dp2; accS.w += dp3;
       float aD[4], hA[4];
@@ -754,9 +774,10 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
         const float* ph = ps + 2 * TSZ + (i & 7) * PT_PL + q16;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-          const int o2 = 64 * s4 + (((r ^ ((0x78 >> (2 * s4)) & 3)) & 3) << 2);   // compile-time: ptT_off(4 r + j, 4 s + q) - (q << 4) - j
+          const int o2 = 64 * s4 + (((r ^ ((0x78 >> (2 * s4)) & 3)) & 3) << 2);   // compile-time: ptT_off(4 r + sk', 4 s + q) - q16
           aD[s4] = pi[o2];
-          const float hv = ph[o2];
+          float hv = ph[o2];
+          asm volatile("" : "+v"(hv));   // (an unconditional read: as an operand of the select alone hipcc sinks it into an exec-masked block)
           hA[s4] = i < 8 ? hv : (i == 8 ? 1.0f : 0.f);   // row 8 = ones: its product row is the bias gradient sum of de'
         }
       }
@@ -765,9 +786,9 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
       for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-          const int idx = xrd + 4 * s4 * DE + 16 * (t ^ (s4 & 1));            // [pair 4 s + q][channel 16 t + p]
+          const int idx = ((s4 & 1) ? xrd1 : xrd0) + 64 * s4 + 256 * t;       // [pair 4 s + q][channel 16 t + p]
           accT[t] = MFMA(aD[s4], xs[idx], accT[t]);
-          accW[t] = MFMA(hA[s4], dfs[idx], accW[t]);
+          accW[t] = MFMA(hA[s4], xs[16 * DE + idx], accW[t]);
         }
       lds_order_();
     };
@@ -901,11 +922,17 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) { dKacc[hf][kt] = (v4f){0.f, 0.f, 0.f, 0.f}; dVacc[hf][kt] = (v4f){0.f, 0.f, 0.f, 0.f}; }
     const int po4 = ptT_off(4 * q, mm);   // the lane's query rows 4q..4q+3 of key mm: one 16-byte access per plane
-    // operand tiles of head slot w (Q, then dO): row form: lane (row mm, chunk q) b128; transposed: lane (channel mm, q): rows 4q + r
-    const float* oprow = Ops + w * (2 * HS) + mm * 16 + ((q ^ chunk_xor(mm)) << 2);
+    // operand tiles of head slot w (Q, then dO): row form: lane (row mm, chunk q) b128; transposed: lane (channel mm, q): rows 4q + r.
+    // Tile row rho lives in LDS row rho ^ ((rho >> 2) & 1) (rows 4-7 and 12-15 swapped in pairs -- the DMA's lane -> source mapping is
+    // free): the transposed b32 reads of a 32-lane group touch rows r and 4 + r, which 16-float rows put on the same 16 banks (2-way on
+    // the 32 reads of a half-trip); swapped, row 4 + r sits in an odd-even exchanged line and the group covers 32 banks.  Step r of a lane
+    // still reads tile row 4q + r: from LDS row 4q + (r ^ (q & 1)) = 4q + r +- (q & 1) (two base addresses, no arithmetic in the loop).
+    const float* oprow = Ops + w * (2 * HS) + (mm ^ ((mm >> 2) & 1)) * 16 + ((q ^ chunk_xor(mm)) << 2);
     const float* optr = Ops + w * (2 * HS) + (4 * q) * 16 + (((mm >> 2) ^ chunk_xor(4 * q)) << 2) + (mm & 3);
+    const float* optr_e = optr + (q & 1) * 16;   // steps 0, 2: LDS row 4q + r + (q & 1)
+    const float* optr_o = optr - (q & 1) * 16;   // steps 1, 3: LDS row 4q + r - (q & 1)
     // the wave's own operand stages: stage `half` = (Q, dO) tiles of head w + 4 half; four 1 KB pieces per tile
-    const unsigned doff = dma_lane_off(lane);
+    const unsigned doff = dma_lane_off(lane ^ (((lane >> 4) & 1) << 2));   // LDS slot of row sigma <- source row sigma ^ ((sigma >> 2) & 1) (same chunk XOR: it depends on sigma >> 2 only)
     const float* Qh = uni_ptr(a.pk + PK_QH * arr + ((size_t)b * AH + w) * NP * D);
     const float* Oh = uni_ptr(a.pk + PK_OH * arr + ((size_t)b * AH + w) * NP * D);
     const unsigned odst = lds_addr(Ops) + w * (2 * HS * 4);
@@ -935,7 +962,8 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
       for (int hf = 0; hf < 2; ++hf) {
         const int h = w + 4 * hf;
         const float* opr = oprow + hf * (4 * 2 * HS);
-        const float* opt = optr + hf * (4 * 2 * HS);
+        const float* opt_e = optr_e + hf * (4 * 2 * HS);
+        const float* opt_o = optr_o + hf * (4 * 2 * HS);
         // this stage landed: requested one half-trip ago; only the other stage's pieces (and the dA store) are younger -- except in the
         // second half of the last trip, where nothing was requested after it
         if (it + 1 < mtiles || hf == 0) { if (it > 0 || hf > 0) vm_wait<2 * KT>(); } else vm_wait<0>();
@@ -1000,6 +1028,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_bwd(AttnMfmaArgs a, P
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
+            const float* opt = (r & 1) ? opt_o : opt_e;
             const float qq = opt[kt * 256 + r * 16];
             const float oo = opt[HS + kt * 256 + r * 16];
             dVacc[hf][kt] = MFMA(oo, at[r], dVacc[hf][kt]);
