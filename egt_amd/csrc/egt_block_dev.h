@@ -554,6 +554,12 @@ __device__ __forceinline__ void bwd_node_prologue_finish(const BlockArgs& a, flo
   if (a.Dh == 64) bwd_prologue_compute<DE, true>(a, ws, qd, b, l_begin, wg, R, false, nullptr, threadIdx.x, -1);
   else bwd_prologue_compute<DE, false>(a, ws, qd, b, l_begin, wg, R, false, nullptr, threadIdx.x, -1);
 }
+// the barriers of bwd_node_prologue, for waves of a workgroup that take no part in it (a.pro is uniform)
+__device__ __forceinline__ void bwd_node_prologue_idle(const BlockArgs& a) {
+  if (a.pro == 2) { __syncthreads(); __syncthreads(); }
+  __syncthreads();
+  __syncthreads();
+}
 // ptid / pnv: the calling thread's index inside its 256-thread group and the group's valid rows -- defaults: the workgroup IS the
 // group (threadIdx.x, min(a.TL, N - l_begin)).  (A workgroup of several 256-thread groups -- round 5's twelve-wave experiment, in the git
 // history -- passes its own; every thread of the workgroup must make the call: the barriers inside are workgroup barriers.)

@@ -457,8 +457,12 @@ void egt_narrow_launch_fwd(BlockArgs& a, hipStream_t st) {
 // earlier one (both waves sit on one CU: plain stores, acknowledged before an LDS flag goes up; no LDS park area).
 #define NRW_OPW 20                                   // row stride of the operand tile (floats): 16-byte aligned rows, spread banks
 #define NRW_M_WAVE (2048 + 16 * NRW_OPW)             // floats per wave: K [4][64][4] | V [4][64][4] | operand tile [16][NRW_OPW]
-template <bool BF, int FEAT>
-__global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
+// NW waves per workgroup: 4, or 8 for a launch with at most one workgroup per CU (BASELINE config 4 as specified: B = 16 per GPU, 240
+// workgroups -- with four waves every SIMD holds ONE wave and a 16-pair step costs it 2.8 k cycles against 1.45 k per SIMD when
+// three waves interleave; the section timers: 56 % of such a workgroup is its row loop).  Eight waves split the key tiles eight ways;
+// the node-side prologue stays four waves' work (the others meet its barriers), whose scratch lies below the tile areas of waves 4-7.
+template <bool BF, int FEAT, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) k_narrow_bwd(BlockArgs a) {
   seed_from_device(a);
 #ifdef NRW_TIMING
   unsigned nacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nlast = (unsigned)__builtin_amdgcn_s_memtime();
@@ -476,47 +480,27 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
   const bool gated = FEAT >= 0 ? (FEAT & NRW_F_GATED) != 0 : (a.flags & EGT_BF_GATE) != 0;
   const bool clip = FEAT >= 0 ? (FEAT & NRW_F_CLIP) != 0 : (a.flags & EGT_BF_CLIP) != 0;
   const bool ln_on = (a.flags & EGT_BF_NO_EDGE_LN) == 0;
-  constexpr int AREA = 4 * NRW_M_WAVE > BWD_PRO_WS ? 4 * NRW_M_WAVE : BWD_PRO_WS;
-  static_assert(4 * 528 <= AREA, "edge partial staging must fit the per-wave area");
+  constexpr int AREA = NW * NRW_M_WAVE > BWD_PRO_WS ? NW * NRW_M_WAVE : BWD_PRO_WS;
+  static_assert(NW * 528 <= AREA, "edge partial staging must fit the per-wave area");
   float* kt = sm + wave * NRW_M_WAVE;      // [4 u][64 lanes][4]: K[4u .. 4u+3] of (key p, head pair q)
   float* vt = kt + 1024;                   // the same for V
   float* op = vt + 1024;                   // [16 pairs][NRW_OPW]
   float* qd = sm + AREA;                   // [TL][QD_LD]
-  volatile int* pflag = reinterpret_cast<volatile int*>(qd + TL * QD_LD);   // [4]: wave w parked its partial
-  if (threadIdx.x < 4) pflag[threadIdx.x] = 0;
-  bwd_stage_rows<256, 3>(a, qd, b, l_begin, nl);
+  volatile int* pflag = reinterpret_cast<volatile int*>(qd + TL * QD_LD);   // [NW]: wave w parked its partial
+  if (threadIdx.x < NW) pflag[threadIdx.x] = 0;
+  bwd_stage_rows<64 * NW, NW == 4 ? 3 : 2>(a, qd, b, l_begin, nl);
   NSTMP(0);   // staging issued
-  if (a.pro) {
-    __syncthreads();
-    bwd_node_prologue<NRW_DE>(a, sm, qd, b, l_begin, wg);
-  }
-  __syncthreads();   // prologue scratch dead, qd rows complete
-  NSTMP(1);   // node-side prologue
-  // ---- A operands (lane = row m = p of the product, k index q) and the accumulator preload ----
-  const int jm = p & 3, hm = 2 * (p >> 2) + jm;   // rows 4q'+0, 4q'+1 of a result carry head / channel 2q'+0, 2q'+1; rows 4q'+2, 4q'+3 are unused
-  float c2r[4];
-  const NrwOp<MV, 2> pwA = nrw_op<MV>(a.pw[(2 * q) * 16 + p], a.pw[(2 * q + 1) * 16 + p]);           // [gates | E] column p from channels 2q, 2q+1
-  const NrwOp<MB, 2> wrA = nrw_op<MB>(jm < 2 ? a.Wr[hm * NRW_DE + 2 * q] : 0.0f,                       // dH_ext of head hm from de' channels 2q, 2q+1
-                                      jm < 2 ? a.Wr[hm * NRW_DE + 2 * q + 1] : 0.0f);
-  const NrwOp<MB, 4> wdA = nrw_op<MB>(jm < 2 ? a.pw[hm * 16 + 4 * q] : 0.0f, jm < 2 ? a.pw[hm * 16 + 4 * q + 1] : 0.0f,   // d ehat of channel hm from
-                                      jm < 2 ? a.pw[hm * 16 + 4 * q + 2] : 0.0f, jm < 2 ? a.pw[hm * 16 + 4 * q + 3] : 0.0f);  // dGE columns 4q .. 4q+3
-#pragma unroll
-  for (int r = 0; r < 4; ++r) c2r[r] = a.pw[16 * 16 + 4 * q + r];
-  v4f accT = {0.f, 0.f, 0.f, 0.f}, accR = {0.f, 0.f, 0.f, 0.f};
-  float ssum = 0.f;   // column p of dGE summed over the pairs 4 s + q of every step (the B operands of the T product): ONE register
-  const float hcst = p == 8 ? 1.0f : 0.0f;   // columns 8..15 of the [H_hat | 1] operand
-
   const int ntile = (N + 15) / 16;
-  // Work of a wave: key tiles w, w+4, ... when the tile count is a multiple of 4 (or < 4); otherwise the ntile x nl (tile, row)
-  // steps are cut into four CONTIGUOUS equal ranges and a tile that straddles two ranges is shared by neighbouring waves.
+  // Work of a wave: key tiles w, w+NW, ... when the tile count is a multiple of NW (or < NW); otherwise the ntile x nl (tile, row)
+  // steps are cut into NW CONTIGUOUS equal ranges and a tile that straddles two ranges is shared by neighbouring waves.
 #ifdef NRW_NO_BALANCE
   const bool balance = false;
 #else
-  const bool balance = ntile >= 4 && (ntile & 3) != 0;
+  const bool balance = ntile >= NW && (ntile % NW) != 0;
 #endif
   const int T = ntile * nl;
-  const int t0 = balance ? (wave * T) >> 2 : 0, t1 = balance ? ((wave + 1) * T) >> 2 : 0;
-  const int mt_first = balance ? t0 / nl : wave, mt_last = balance ? (t1 - 1) / nl : ntile - 1, mt_step = balance ? 1 : 4;
+  const int t0 = balance ? (wave * T) / NW : 0, t1 = balance ? ((wave + 1) * T) / NW : 0;
+  const int mt_first = balance ? t0 / nl : wave, mt_last = balance ? (t1 - 1) / nl : ntile - 1, mt_step = balance ? 1 : NW;
   // e / de' run two steps ahead of the (tile, row) sequence, ACROSS tile boundaries: the last two rows of a tile request the first
   // two rows of the wave's next tile (a tile switch then costs the K / V round trip only)
   const size_t ugraph = (size_t)b * N * N;      // wave-uniform pair index of the graph's first pair
@@ -531,6 +515,46 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
       if (++cli >= ((balance && cmt == mt_last) ? t1 - cmt * nl : nl)) { cli = 0; cmt += mt_step; }
     }
   };
+  // K / V of the lane's key of tile mt -> the wave's LDS tiles
+  auto fill_kv = [&](int mt) __attribute__((always_inline)) {
+    const size_t rowm = (size_t)b * N + min(mt * 16 + p, N - 1);
+    const float4* kp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 64 + q * 16);
+    const float4* vp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 128 + q * 16);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {   // (the previous tile's reads of kt / vt are earlier in program order)
+      *reinterpret_cast<float4*>(kt + u * 256 + lane * 4) = kp[u];
+      *reinterpret_cast<float4*>(vt + u * 256 + lane * 4) = vp[u];
+    }
+  };
+  // ---- A operands (lane = row m = p of the product, k index q) and the accumulator preload ----
+  const int jm = p & 3, hm = 2 * (p >> 2) + jm;   // rows 4q'+0, 4q'+1 of a result carry head / channel 2q'+0, 2q'+1; rows 4q'+2, 4q'+3 are unused
+  float c2r[4];
+  NrwOp<MV, 2> pwA;
+  NrwOp<MB, 2> wrA;
+  NrwOp<MB, 4> wdA;
+  auto load_weights = [&]() __attribute__((always_inline)) {
+    pwA = nrw_op<MV>(a.pw[(2 * q) * 16 + p], a.pw[(2 * q + 1) * 16 + p]);           // [gates | E] column p from channels 2q, 2q+1
+    wrA = nrw_op<MB>(jm < 2 ? a.Wr[hm * NRW_DE + 2 * q] : 0.0f,                       // dH_ext of head hm from de' channels 2q, 2q+1
+                     jm < 2 ? a.Wr[hm * NRW_DE + 2 * q + 1] : 0.0f);
+    wdA = nrw_op<MB>(jm < 2 ? a.pw[hm * 16 + 4 * q] : 0.0f, jm < 2 ? a.pw[hm * 16 + 4 * q + 1] : 0.0f,   // d ehat of channel hm from
+                     jm < 2 ? a.pw[hm * 16 + 4 * q + 2] : 0.0f, jm < 2 ? a.pw[hm * 16 + 4 * q + 3] : 0.0f);  // dGE columns 4q .. 4q+3
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c2r[r] = a.pw[16 * 16 + 4 * q + r];
+  };
+  // (Eight waves, measured and not kept: waves 4-7 fetching their weights, first K / V tiles and first e / de' rows while waves 0-3 run
+  //  the prologue -- its own loads queue behind them: prologue 16.8 k -> 22.0 k cycles, launch 35.7 -> 36.6 us; the two waves of a SIMD
+  //  taking turns at s_setprio 1 step by step -- the older wave's 26 k / the younger's 37 k cycles become 29 k / 37 k: the same launch.)
+  if (a.pro) {
+    __syncthreads();
+    if (NW == 4 || wave < 4) bwd_node_prologue<NRW_DE>(a, sm, qd, b, l_begin, wg);
+    else bwd_node_prologue_idle(a);   // the prologue is four waves' work: the others only meet its barriers
+  }
+  __syncthreads();   // prologue scratch dead, qd rows complete
+  NSTMP(1);   // node-side prologue
+  load_weights();
+  v4f accT = {0.f, 0.f, 0.f, 0.f}, accR = {0.f, 0.f, 0.f, 0.f};
+  float ssum = 0.f;   // column p of dGE summed over the pairs 4 s + q of every step (the B operands of the T product): ONE register
+  const float hcst = p == 8 ? 1.0f : 0.0f;   // columns 8..15 of the [H_hat | 1] operand
   request(0);
   request(1);
   for (int mt = mt_first; mt <= mt_last; mt += mt_step) {
@@ -541,17 +565,9 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
     const int mc = kvalid ? m : N - 1;
     const size_t rowm = (size_t)b * N + mc;
     float dKa[16], dVa[16];
-    {
-      const float4* kp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 64 + q * 16);
-      const float4* vp = reinterpret_cast<const float4*>(a.qkvp + rowm * QKVP + 128 + q * 16);
+    fill_kv(mt);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {   // (the previous tile's reads of kt / vt are earlier in program order)
-        *reinterpret_cast<float4*>(kt + u * 256 + lane * 4) = kp[u];
-        *reinterpret_cast<float4*>(vt + u * 256 + lane * 4) = vp[u];
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { dKa[i] = 0.f; dVa[i] = 0.f; }
-    }
+    for (int i = 0; i < 16; ++i) { dKa[i] = 0.f; dVa[i] = 0.f; }
     const float kadd = (a.km && a.km[rowm] == 0) ? -EGT_NEG : 0.0f;
     const MaskRegs mr{make_float2(1.f, 1.f), 0};
     const uint32_t pcol = (uint32_t)((size_t)b * N * N + mc);   // pair index of (row 0 of the graph, key mc), mod 2^32: the mask-RNG counter
@@ -739,11 +755,14 @@ __global__ void __launch_bounds__(256, 3) k_narrow_bwd(BlockArgs a) {
   }
   __syncthreads();
   float* out = a.epart + (size_t)wg * 528;
-  for (int i = threadIdx.x; i < 528; i += 256)
-    out[i] = (sm[i] + sm[528 + i]) + (sm[2 * 528 + i] + sm[3 * 528 + i]);
+  for (int i = threadIdx.x; i < 528; i += 64 * NW) {
+    float v = (sm[i] + sm[528 + i]) + (sm[2 * 528 + i] + sm[3 * 528 + i]);
+    if (NW == 8) v += (sm[4 * 528 + i] + sm[5 * 528 + i]) + (sm[6 * 528 + i] + sm[7 * 528 + i]);
+    out[i] = v;
+  }
 #ifdef NRW_TIMING
   NSTMP(5);   // workgroup partials (waits for the slowest wave)
-  if (a.dbg && lane == 0) {
+  if (a.dbg && lane == 0 && wave < 4) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = nacc[i];
   }
@@ -771,12 +790,17 @@ static void nrw_timing_report() {
 void egt_narrow_launch_bwd(BlockArgs& a, int nwg, hipStream_t st) {
   const int full = NRW_F_GATED | NRW_F_CLIP;
   const int feat = ((a.flags & EGT_BF_GATE) ? NRW_F_GATED : 0) | ((a.flags & EGT_BF_CLIP) ? NRW_F_CLIP : 0);
-  constexpr int AREA = 4 * NRW_M_WAVE > BWD_PRO_WS ? 4 * NRW_M_WAVE : BWD_PRO_WS;
-  const size_t lds = ((size_t)AREA + BWD_TL * QD_LD + 4) * 4;   // 47 KB: three workgroups per CU
+  constexpr int AREA4 = 4 * NRW_M_WAVE > BWD_PRO_WS ? 4 * NRW_M_WAVE : BWD_PRO_WS, AREA8 = 8 * NRW_M_WAVE;
+  static_assert(AREA8 >= BWD_PRO_WS, "tile areas of eight waves cover the prologue's scratch");
+  static const int nw_forced = getenv("EGT_NRW_BWD_WAVES") ? atoi(getenv("EGT_NRW_BWD_WAVES")) : 0;   // 4 | 8 (tests, A/B)
+  const bool w8 = nw_forced == 8 || (nw_forced != 4 && nwg <= egt_device_cus() && a.N >= 64);   // at most one workgroup per CU: eight waves share its key tiles
+  const size_t lds = ((size_t)(w8 ? AREA8 : AREA4) + BWD_TL * QD_LD + 8) * 4;   // four waves: 47 KB, three workgroups per CU
 #define NRW_BWD(BF_, FEAT_)                                                                     \
   do {                                                                                            \
-    EGT_MAX_LDS_ONCE(k_narrow_bwd<BF_, FEAT_>);                                                    \
-    EGT_LAUNCH("k_block_bwd", (k_narrow_bwd<BF_, FEAT_>), dim3(nwg), dim3(256), lds, st, a);      \
+    if (w8) { EGT_MAX_LDS_ONCE(k_narrow_bwd<BF_, FEAT_, 8>);                                       \
+              EGT_LAUNCH("k_block_bwd", (k_narrow_bwd<BF_, FEAT_, 8>), dim3(nwg), dim3(512), lds, st, a); } \
+    else { EGT_MAX_LDS_ONCE(k_narrow_bwd<BF_, FEAT_, 4>);                                          \
+           EGT_LAUNCH("k_block_bwd", (k_narrow_bwd<BF_, FEAT_, 4>), dim3(nwg), dim3(256), lds, st, a); } \
   } while (0)
 #ifdef NRW_TIMING
   if (g_nt_n < nwg) {

@@ -55,6 +55,15 @@ def test_forward_waves_per_workgroup(waves):
     _run({"EGT_NRW_FWD_WAVES": waves})
 
 
+@pytest.mark.parametrize("waves", ["4", "8"])
+def test_backward_waves_per_workgroup(waves):
+    """k_narrow_bwd splits a workgroup's key tiles over 4 waves, or over 8 when the launch has at most one workgroup per CU
+    (egt_narrow_launch_bwd; the node-side prologue stays four waves' work).  The tiny test batches take 8 by default from N = 64
+    up; both sizes are forced here for every geometry (balanced (tile, row) ranges with parked partials, waves without a key tile)."""
+    _run({"EGT_NRW_BWD_WAVES": waves})
+    _run({"EGT_NRW_BWD_WAVES": waves, "EGT_BWD_TL": "16"})
+
+
 @pytest.mark.parametrize("rows", ["16", "4"])
 def test_backward_rows_per_workgroup(rows):
     """The De = 8 backward takes 16, 8 or 4 query rows per workgroup (egt_block.hip: bwd_rows_per_wg; small batches get 8 so
