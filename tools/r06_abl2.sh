@@ -2,7 +2,7 @@
 # same-box A/B of k_pair_bwd build variants (egt_amd/lib/var/libegt_<name>.so): bwd / fwd us per launch, graphs/s
 OUT=gpurun_out/r06_abl2; mkdir -p $OUT
 V=$PWD/egt_amd/lib/var
-for rep in 1 2; do
+for rep in ${REPS:-1 2}; do
   for v in "$@"; do
     L=$V/libegt_$v.so; [ $v = new ] && L=""
     EGT_AMD_LIB=$L timeout 300 python bench.py --workload ${WL:-synthetic_n512_block} --no-cpu-baseline > $OUT/b_${v}_$rep.json 2>> $OUT/err.log
