@@ -147,11 +147,14 @@ __device__ __forceinline__ void fwd_stage_kv(float* kvs, const float* kvsrc, int
 // c = k * 8 + head is the same index in the padded and in the natural row, so the padding is the columns c >= Dh: their weights,
 // biases and inputs read as zero, their outputs are never stored, the LayerNorm divides by Dh and keeps them at zero.  D64: Dh is
 // the compile-time 64 of the headline geometry (no guards).
+// The epilogue's global inputs (weight fragments, bias, residual rows) live in this register set between `fwd_epilogue_load` (every load
+// issued: one memory round trip, which a kernel can put under a phase of its own -- k_narrow_fwd: under the merge of its key ranges) and
+// `fwd_epilogue_compute`.
+struct FwdEpiRegs { float wo[16], wq[3][16], bo, hres[4]; };
 template <bool D64>
-__device__ __forceinline__ void fwd_node_epilogue_t(const BlockArgs& a, float* sm, float* qs, int b, int l0, int nrows, int N,
-                                                    int wave, int p, int q) {   // rows [l0, l0 + nrows) of graph b, nrows <= 16 (<= 0: nothing to store)
-    const int Dh = D64 ? 64 : a.Dh, D3 = 3 * Dh;
-    float wo[16], wq[3][16];
+__device__ __forceinline__ void fwd_epilogue_load(const BlockArgs& a, FwdEpiRegs& R, int b, int l0, int N, int wave, int p, int q) {
+    const int Dh = D64 ? 64 : a.Dh;
+    float (&wo)[16] = R.wo; float (&wq)[3][16] = R.wq;
     const int c = wave * 16 + p;
     const bool cok = D64 || c < Dh;
     {   // B operands from the fragment-major weight copies (egt_block.h: WFRAG_FWO / WFRAG_FWQ; zero where the padded row has no
@@ -174,10 +177,18 @@ __device__ __forceinline__ void fwd_node_epilogue_t(const BlockArgs& a, float* s
           }
       }
     }
-    const float bo = cok ? a.bo[c] : 0.f;
-    float hres[4];
+    R.bo = cok ? a.bo[c] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) hres[r] = cok ? a.h[((size_t)b * N + min(l0 + 4 * q + r, N - 1)) * Dh + c] : 0.f;
+    for (int r = 0; r < 4; ++r) R.hres[r] = cok ? a.h[((size_t)b * N + min(l0 + 4 * q + r, N - 1)) * Dh + c] : 0.f;
+}
+template <bool D64>
+__device__ __forceinline__ void fwd_epilogue_compute(const BlockArgs& a, const FwdEpiRegs& R, float* sm, float* qs, int b, int l0, int nrows, int N,
+                                                     int wave, int p, int q) {   // rows [l0, l0 + nrows) of graph b, nrows <= 16 (<= 0: nothing to store)
+    const int Dh = D64 ? 64 : a.Dh;
+    const float (&wo)[16] = R.wo; const float (&wq)[3][16] = R.wq; const float (&hres)[4] = R.hres;
+    const float bo = R.bo;
+    const int c = wave * 16 + p;
+    const bool cok = D64 || c < Dh;
     __syncthreads();   // every row's V_att is in qs; the tile area is idle from here on
     float* hs = sm;    // [16][QS_LD]
     v4f acc = {bo, bo, bo, bo};
@@ -228,10 +239,27 @@ __device__ __forceinline__ void fwd_node_epilogue_t(const BlockArgs& a, float* s
       }
     }
   }
+template <bool D64>
+__device__ __forceinline__ void fwd_node_epilogue_t(const BlockArgs& a, float* sm, float* qs, int b, int l0, int nrows, int N,
+                                                    int wave, int p, int q) {
+  FwdEpiRegs R;
+  fwd_epilogue_load<D64>(a, R, b, l0, N, wave, p, q);
+  fwd_epilogue_compute<D64>(a, R, sm, qs, b, l0, nrows, N, wave, p, q);
+}
 __device__ __forceinline__ void fwd_node_epilogue(const BlockArgs& a, float* sm, float* qs, int b, int l0, int nrows, int N,
                                                   int wave, int p, int q) {
   if (a.Dh == 64) fwd_node_epilogue_t<true>(a, sm, qs, b, l0, nrows, N, wave, p, q);
   else fwd_node_epilogue_t<false>(a, sm, qs, b, l0, nrows, N, wave, p, q);
+}
+// the two halves on their own (a.Dh == 64 decided by the caller once)
+__device__ __forceinline__ void fwd_node_epilogue_load(const BlockArgs& a, FwdEpiRegs& R, int b, int l0, int N, int wave, int p, int q) {
+  if (a.Dh == 64) fwd_epilogue_load<true>(a, R, b, l0, N, wave, p, q);
+  else fwd_epilogue_load<false>(a, R, b, l0, N, wave, p, q);
+}
+__device__ __forceinline__ void fwd_node_epilogue_finish(const BlockArgs& a, const FwdEpiRegs& R, float* sm, float* qs, int b, int l0, int nrows, int N,
+                                                         int wave, int p, int q) {
+  if (a.Dh == 64) fwd_epilogue_compute<true>(a, R, sm, qs, b, l0, nrows, N, wave, p, q);
+  else fwd_epilogue_compute<false>(a, R, sm, qs, b, l0, nrows, N, wave, p, q);
 }
 
 // the barriers of fwd_node_epilogue, for waves of a workgroup that take no part in it (a.epi is uniform)

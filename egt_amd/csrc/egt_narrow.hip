@@ -179,8 +179,15 @@ template <bool BF, int NS> __device__ __forceinline__ v4f nrw_mm(const NrwOp<BF,
 #ifndef NRW_FWDM_OCC
 #define NRW_FWDM_OCC 3
 #endif
-template <bool BF, int FEAT, int NW>
+// HR ("half rows", with NW = 8): workgroup = (graph, EIGHT query rows) for launches whose 16-row grid would leave half of the CUs
+// without a workgroup (config 4 as specified: B = 16, N = 120 -> 128 workgroups of 16 rows on 256 CUs).  Lanes p < 8 and p >= 8 work on the
+// same row p & 7 and on the even / odd key of a step's key pair (a row's 64-byte segment per request instead of 32); their online-softmax
+// states are merged across the lane pair (p, p ^ 8) before the waves' key ranges are.
+template <bool BF, int FEAT, int NW, bool HR>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_fwd(BlockArgs a) {
+  static_assert(!HR || (NW == 8 && NRW_KB % 2 == 0), "half-row workgroups: eight waves, key blocks of an even size");
+  constexpr int RG = HR ? 8 : 16;            // query rows per workgroup
+  constexpr int KS = HR ? NRW_KB / 2 : NRW_KB;   // key steps per block
   seed_from_device(a);
 #ifdef NRW_TIMING
   unsigned nacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nlast = (unsigned)__builtin_amdgcn_s_memtime();
@@ -191,18 +198,20 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p = lane & 15, q = lane >> 4;   // matrix-core lanes
   const int N = a.N;
-  const int lgroups = (N + 15) / 16;
+  const int lgroups = (N + RG - 1) / RG;
   const int wg = a.xcd ? egt_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   int b, lg;
-  egt_group_order(wg, a.B, lgroups, N, b, lg);
+  egt_group_order(wg, a.B, lgroups, N, b, lg, RG);
+  const int hp = HR ? (p >> 3) : 0;          // HR: the lane's key of a key pair
   float* kvw = sm + wave * NRW_KV_CHUNK;
   float* kmw = sm + NW * NRW_KV_CHUNK + wave * NRW_KB;
   float* qs = sm + NRW_FWD_AREA(NW);
   const bool gated = FEAT >= 0 ? (FEAT & NRW_F_GATED) != 0 : (a.flags & EGT_BF_GATE) != 0;
   const bool clip = FEAT >= 0 ? (FEAT & NRW_F_CLIP) != 0 : (a.flags & EGT_BF_CLIP) != 0;
   const bool ln_on = (a.flags & EGT_BF_NO_EDGE_LN) == 0;
-  const int l = lg * 16 + p;
+  const int l = lg * RG + (HR ? (p & 7) : p);
   const bool row_ok = l < N;
+  const bool row_own = row_ok && (!HR || p < 8);   // the lane that writes the row's V_att / statistics
   const size_t rowl = (size_t)b * N + min(l, N - 1);
 
   // ---- lane constants: Q of the row (heads 2q, 2q+1); A operands of the two channel contractions ----
@@ -241,7 +250,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
   auto fetch_e = [&](int blk) __attribute__((always_inline)) {
     const int m0 = blk * NRW_KB;
 #pragma unroll
-    for (int kk = 0; kk < NRW_KB; ++kk) eb[kk] = LD::uload(a.e, (NRW_ABL & 2) ? (size_t)kk : ugraph + min(m0 + kk, N - 1), loff);
+    for (int kk = 0; kk < KS; ++kk) {
+      if (HR) {   // keys m0 + 2 kk + hp: wave-uniform pair index of the even key, the odd key through the lane offset (never past the row's last key)
+        const int k0 = m0 + 2 * kk;
+        eb[kk] = LD::uload(a.e, ugraph + min(k0, N - 1), loff + ((hp != 0 && k0 + 1 < N) ? NRW_DE : 0));
+      } else eb[kk] = LD::uload(a.e, (NRW_ABL & 2) ? (size_t)kk : ugraph + min(m0 + kk, N - 1), loff);
+    }
   };
   auto fetch_kv = [&](int blk) __attribute__((always_inline)) {   // K / V of the block come from L2: requested half a block ahead
     const int m0 = blk * NRW_KB;
@@ -268,15 +282,16 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
       *reinterpret_cast<v4f*>(kvw + (f >> 5) * 128 + (f & 31) * 4) = kvr[u];
     }
     if (lane < NRW_KB) kmw[lane] = kmr;
-    float2 ev[NRW_KB];
+    float2 ev[KS];
 #pragma unroll
-    for (int kk = 0; kk < NRW_KB; ++kk) ev[kk] = LD::cvt(eb[kk]);
+    for (int kk = 0; kk < KS; ++kk) ev[kk] = LD::cvt(eb[kk]);
     if (blk + 1 < blk1) fetch_e(blk + 1);
     lds_sync();
-    float xl[NRW_KB][2], gl[NRW_KB][2];
+    float xl[KS][2], gl[KS][2];
 #pragma unroll
-    for (int kk = 0; kk < NRW_KB; ++kk) {
-      const int m = m0 + kk;
+    for (int kk = 0; kk < KS; ++kk) {
+      const int kl = HR ? 2 * kk + hp : kk;   // the lane's key inside the block
+      const int m = m0 + kl;
       // ---- norm_edge: the pair's 8 channels sit in the quad, two per lane (two-pass moments) ----
       float x0 = ev[kk].x, x1 = ev[kk].y;
       const float mu = ln_on ? nrw_sum4rows(x0 + x1) * 0.125f : 0.0f;
@@ -289,7 +304,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
       // ---- scaled QK^T, clip, + E (egt_layers.py:79-86) ----
       float Kf[16];
       {
-        const float4* kp = reinterpret_cast<const float4*>(kvw + kk * 128 + q * 16);
+        const float4* kp = reinterpret_cast<const float4*>(kvw + kl * 128 + q * 16);
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const float4 v = kp[u]; Kf[4*u] = v.x; Kf[4*u+1] = v.y; Kf[4*u+2] = v.z; Kf[4*u+3] = v.w; }
       }
@@ -306,8 +321,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
         gl[kk][j] = acc[2 * j];
       }
       const MaskRegs mr{make_float2(1.f, 1.f), 0};
-      if (!(NRW_ABL & 8)) apply_masks<false>(a, kmw[kk], mr, (size_t)(((uint32_t)pair_row + (uint32_t)m) * (uint32_t)BH), q, xl[kk], gl[kk]);   // (counter mod 2^32)
-      if (kk >= nv) { xl[kk][0] = -3.0e38f; xl[kk][1] = -3.0e38f; }   // past the graph's last key: probability exactly 0
+      if (!(NRW_ABL & 8)) apply_masks<false>(a, kmw[kl], mr, (size_t)(((uint32_t)pair_row + (uint32_t)m) * (uint32_t)BH), q, xl[kk], gl[kk]);   // (counter mod 2^32)
+      if (kl >= nv) { xl[kk][0] = -3.0e38f; xl[kk][1] = -3.0e38f; }   // past the graph's last key: probability exactly 0
       // ---- dense_edge_r + res_edge: e' = e + H_hat.Wr + br, the lane's two channels ----
       float2 eo;
       {
@@ -316,8 +331,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
         eo.x = t[0];
         eo.y = t[1];
       }
-      if (row_ok && kk < nv && !(NRW_ABL & 1)) LD::ustore(a.e_out, ugraph + m, loff, eo);
-      if ((NRW_ABL & 1) && eo.x == 123.456f) LD::ustore(a.e_out, ugraph + m, loff, eo);
+      if (row_ok && kl < nv && !(NRW_ABL & 1)) LD::ustore(a.e_out, ugraph + (m - hp), loff + hp * NRW_DE, eo);   // (m - hp: wave-uniform)
+      if ((NRW_ABL & 1) && eo.x == 123.456f) LD::ustore(a.e_out, ugraph + (m - hp), loff + hp * NRW_DE, eo);
     }
     if (blk + 1 < blk1) fetch_kv(blk + 1);   // (after the logits phase: its registers are free again)
     // ---- one online-softmax step for the block, x gate, A.V: the row's state never leaves the lane ----
@@ -325,7 +340,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
     for (int j = 0; j < 2; ++j) {
       float mn = mx[j];
 #pragma unroll
-      for (int kk = 0; kk < NRW_KB; ++kk) mn = nrw_max(mn, xl[kk][j]);
+      for (int kk = 0; kk < KS; ++kk) mn = nrw_max(mn, xl[kk][j]);
       const float alpha = (NRW_ABL & 16) ? (mx[j] - mn) : __expf(mx[j] - mn);
       mx[j] = mn;
       sum[j] *= alpha;
@@ -333,10 +348,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
       for (int k = 0; k < 8; ++k) O[2 * k + j] *= alpha;
     }
 #pragma unroll
-    for (int kk = 0; kk < NRW_KB; ++kk) {
+    for (int kk = 0; kk < KS; ++kk) {
+      const int kl = HR ? 2 * kk + hp : kk;
       float Vf[16];
       {
-        const float4* vp = reinterpret_cast<const float4*>(kvw + kk * 128 + 64 + q * 16);
+        const float4* vp = reinterpret_cast<const float4*>(kvw + kl * 128 + 64 + q * 16);
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const float4 v = vp[u]; Vf[4*u] = v.x; Vf[4*u+1] = v.y; Vf[4*u+2] = v.z; Vf[4*u+3] = v.w; }
       }
@@ -356,7 +372,24 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
     for (int blk = blk0; blk < bfull; ++blk) block(blk, NRW_KB);
     if (blk1 > nfull && blk0 <= nfull) block(nfull, N - nfull * NRW_KB);   // the graph's ragged last block
   }
+  if (HR) {   // the two key subsets of a row: lanes (p, p ^ 8) -- both lanes end up with the merged state, lane p < 8 is the one used
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float mo = __shfl_xor(mx[j], 8), so = __shfl_xor(sum[j], 8);
+      const float mn = fmaxf(mx[j], mo);
+      const float f0 = __expf(mx[j] - mn), f1 = __expf(mo - mn);
+      mx[j] = mn;
+      sum[j] = fmaf(sum[j], f0, so * f1);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) O[2 * k + j] = fmaf(O[2 * k + j], f0, __shfl_xor(O[2 * k + j], 8) * f1);
+    }
+  }
   NSTMP(1);   // key loop
+  // the node-side epilogue's weight fragments / bias / residual rows: requested now, landed by the time the key ranges are merged
+  // (eight waves: two waves per SIMD at most, the 69 registers are there; with four waves the kernel runs three workgroups per CU at <= 128)
+  const bool epi_on = a.epi && !(NRW_ABL & 32);
+  FwdEpiRegs epiR;
+  if (NW == 8 && epi_on && wave < 4) fwd_node_epilogue_load(a, epiR, b, lg * RG, N, wave, lane & 15, lane >> 4);
   // ---- merge the key ranges (waves 1 .. NW-1 -> LDS -> wave 0), write V_att / statistics ----
   __syncthreads();   // every wave is done with its K/V chunk: the area becomes the merge buffer
   float* mg = sm;    // [NW - 1][20][64]
@@ -385,10 +418,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float2 vo = make_float2(O[2 * k] / sum[0], O[2 * k + 1] / sum[1]);
-      if (row_ok && k < a.DK) *reinterpret_cast<float2*>(a.v_att + rowl * a.Dh + k * BH + 2 * q) = vo;
-      if (a.epi) *reinterpret_cast<float2*>(qs + p * QS_LD + k * BH + 2 * q) = vo;
+      if (row_own && k < a.DK) *reinterpret_cast<float2*>(a.v_att + rowl * a.Dh + k * BH + 2 * q) = vo;
+      if (a.epi && (!HR || p < 8)) *reinterpret_cast<float2*>(qs + p * QS_LD + k * BH + 2 * q) = vo;
     }
-    if (row_ok) {
+    if (row_own) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         float* st = a.stats + (rowl * BH + 2 * q + j) * 4;
@@ -399,8 +432,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? NRW_FWDM_OCC : 1) k_narrow_
   }
   NSTMP(2);   // sync + merge of the key quarters
   // node-side epilogue on the 16 rows (its own lane roles: MFMA layout); its staging rows reuse the merge area
-  if (a.epi && !(NRW_ABL & 32)) {
-    if (NW == 4 || wave < 4) fwd_node_epilogue(a, sm, qs, b, lg * 16, min(16, N - lg * 16), N, wave, lane & 15, lane >> 4);
+  if (epi_on) {
+    if (NW == 4) fwd_node_epilogue(a, sm, qs, b, lg * RG, min(RG, N - lg * RG), N, wave, lane & 15, lane >> 4);
+    else if (wave < 4) fwd_node_epilogue_finish(a, epiR, sm, qs, b, lg * RG, min(RG, N - lg * RG), N, wave, lane & 15, lane >> 4);
     else fwd_node_epilogue_idle(a);   // the epilogue is four waves' work: the others only meet its barriers
   }
 #ifdef NRW_TIMING
@@ -419,9 +453,12 @@ static const char* const g_nf_names[] = {"constants + first requests", "key loop
 static NrwTimer g_nf{"k_narrow_fwd", g_nf_names, 4};
 #endif
 void egt_narrow_launch_fwd(BlockArgs& a, hipStream_t st) {
-  const dim3 grid(a.B * ((a.N + 15) / 16));
+  const int grid16 = a.B * ((a.N + 15) / 16);
   static const int nw_forced = getenv("EGT_NRW_FWD_WAVES") ? atoi(getenv("EGT_NRW_FWD_WAVES")) : 0;   // 4 | 8 (tests, A/B)
-  const bool w8 = nw_forced == 8 || (nw_forced != 4 && (int)grid.x <= egt_device_cus() && a.N >= 64);   // one workgroup per CU at most: eight key ranges
+  static const int hr_forced = getenv("EGT_NRW_FWD_HALF") ? atoi(getenv("EGT_NRW_FWD_HALF")) : -1;    // 0 | 1 (tests, A/B)
+  const bool w8 = nw_forced == 8 || (nw_forced != 4 && grid16 <= egt_device_cus() && a.N >= 64);   // one workgroup per CU at most: eight key ranges
+  const bool hr = w8 && (hr_forced == 1 || (hr_forced != 0 && 2 * grid16 <= egt_device_cus()));       // ... per two CUs: eight-row workgroups
+  const dim3 grid(hr ? a.B * ((a.N + 7) / 8) : grid16);
   const dim3 block(w8 ? 512 : 256);
 #ifdef NRW_TIMING
   { static bool reg = false; if (!reg) { reg = true; atexit([] { g_nf.report(); }); } }
@@ -431,8 +468,9 @@ void egt_narrow_launch_fwd(BlockArgs& a, hipStream_t st) {
   const int full = NRW_F_GATED | NRW_F_CLIP;
   const int feat = ((a.flags & EGT_BF_GATE) ? NRW_F_GATED : 0) | ((a.flags & EGT_BF_CLIP) ? NRW_F_CLIP : 0);
 #define NRW_FWD(BF_, FEAT_) do { \
-    if (w8) { EGT_MAX_LDS_ONCE(k_narrow_fwd<BF_, FEAT_, 8>); EGT_LAUNCH("k_block_fwd", (k_narrow_fwd<BF_, FEAT_, 8>), grid, block, lds, st, a); } \
-    else { EGT_LAUNCH("k_block_fwd", (k_narrow_fwd<BF_, FEAT_, 4>), grid, block, lds, st, a); } } while (0)
+    if (hr) { EGT_MAX_LDS_ONCE(k_narrow_fwd<BF_, FEAT_, 8, true>); EGT_LAUNCH("k_block_fwd", (k_narrow_fwd<BF_, FEAT_, 8, true>), grid, block, lds, st, a); } \
+    else if (w8) { EGT_MAX_LDS_ONCE(k_narrow_fwd<BF_, FEAT_, 8, false>); EGT_LAUNCH("k_block_fwd", (k_narrow_fwd<BF_, FEAT_, 8, false>), grid, block, lds, st, a); } \
+    else { EGT_LAUNCH("k_block_fwd", (k_narrow_fwd<BF_, FEAT_, 4, false>), grid, block, lds, st, a); } } while (0)
   if (a.bf16) { if (feat == full) NRW_FWD(true, NRW_F_GATED | NRW_F_CLIP); else NRW_FWD(true, NRW_F_RUNTIME); }
   else { if (feat == full) NRW_FWD(false, NRW_F_GATED | NRW_F_CLIP); else NRW_FWD(false, NRW_F_RUNTIME); }
 #undef NRW_FWD

@@ -52,7 +52,14 @@ def test_forward_waves_per_workgroup(waves):
     """k_narrow_fwd splits a workgroup's key range over 4 waves, or over 8 when the launch has at most one workgroup per CU
     (egt_narrow_launch_fwd).  The tiny test batches take 8 by default from N = 64 up; both sizes are forced here for every
     geometry (8 waves on N = 37 leaves waves with an empty key range)."""
-    _run({"EGT_NRW_FWD_WAVES": waves})
+    _run({"EGT_NRW_FWD_WAVES": waves, "EGT_NRW_FWD_HALF": "0"})
+
+
+def test_forward_half_row_workgroups():
+    """With eight waves and a 16-row grid of at most half the CUs, k_narrow_fwd takes EIGHT query rows per workgroup (lanes p and p ^ 8
+    share a row and split a step's key pair; egt_narrow_launch_fwd).  The tiny test batches take that form by default from N = 64 up
+    (the run above switches it off); here it is forced together with the eight waves for every geometry, N = 37 and ragged N included."""
+    _run({"EGT_NRW_FWD_WAVES": "8", "EGT_NRW_FWD_HALF": "1"})
 
 
 @pytest.mark.parametrize("waves", ["4", "8"])

@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SETTINGS = [{}, {"EGT_BWD_TL": "16", "EGT_NRW_FWD_WAVES": "4", "EGT_NRW_BWD_WAVES": "4"}, {"EGT_BWD_TL": "11", "EGT_NRW_BWD_WAVES": "8"}, {"EGT_BWD_TL": "5", "EGT_NRW_FWD_WAVES": "8"}]
+SETTINGS = [{}, {"EGT_BWD_TL": "16", "EGT_NRW_FWD_WAVES": "4", "EGT_NRW_BWD_WAVES": "4"}, {"EGT_BWD_TL": "11", "EGT_NRW_BWD_WAVES": "8"}, {"EGT_BWD_TL": "5", "EGT_NRW_FWD_WAVES": "8", "EGT_NRW_FWD_HALF": "0"}, {"EGT_NRW_FWD_WAVES": "8", "EGT_NRW_FWD_HALF": "1"}]
 
 
 def child(ncase, seed):
