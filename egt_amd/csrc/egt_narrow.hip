@@ -526,6 +526,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) k_narrow_bwd(BlockAr
   float* qd = sm + AREA;                   // [TL][QD_LD]
   volatile int* pflag = reinterpret_cast<volatile int*>(qd + TL * QD_LD);   // [NW]: wave w parked its partial
   if (threadIdx.x < NW) pflag[threadIdx.x] = 0;
+  // eight waves (two per SIMD at most: the registers are there): the node-side prologue's own global inputs -- the partial gather
+  // included -- are requested by waves 0-3 ahead of the row staging and its barrier instead of behind them
+  BwdProRegs proR;
+  if (NW == 8 && wave < 4) bwd_node_prologue_load<NRW_DE>(a, proR, b, l_begin);
   bwd_stage_rows<64 * NW, NW == 4 ? 3 : 2>(a, qd, b, l_begin, nl);
   NSTMP(0);   // staging issued
   const int ntile = (N + 15) / 16;
@@ -581,10 +585,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) k_narrow_bwd(BlockAr
   };
   // (Eight waves, measured and not kept: waves 4-7 fetching their weights, first K / V tiles and first e / de' rows while waves 0-3 run
   //  the prologue -- its own loads queue behind them: prologue 16.8 k -> 22.0 k cycles, launch 35.7 -> 36.6 us; the two waves of a SIMD
-  //  taking turns at s_setprio 1 step by step -- the older wave's 26 k / the younger's 37 k cycles become 29 k / 37 k: the same launch.)
+  //  taking turns at s_setprio 1 step by step -- the older wave's 26 k / the younger's 37 k cycles become 29 k / 37 k: the same launch;
+  //  waves 4-7 entering the row loop 0.5 k / 1.3 k / 2.6 k cycles late (s_sleep: out of lock step): 35.7 / 35.8 / 36.3 against 36.0 us.)
   if (a.pro) {
     __syncthreads();
-    if (NW == 4 || wave < 4) bwd_node_prologue<NRW_DE>(a, sm, qd, b, l_begin, wg);
+    if (NW == 4) bwd_node_prologue<NRW_DE>(a, sm, qd, b, l_begin, wg);
+    else if (wave < 4) bwd_node_prologue_finish<NRW_DE>(a, sm, qd, b, l_begin, wg, proR);
     else bwd_node_prologue_idle(a);   // the prologue is four waves' work: the others only meet its barriers
   }
   __syncthreads();   // prologue scratch dead, qd rows complete
