@@ -304,6 +304,9 @@ __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :
 __device__ __forceinline__ unsigned dma_lane_off(int lane) {   // source byte offset (inside a 1 KB block) of the chunk that lands in slot `lane`
   return (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ chunk_xor(lane >> 2)) << 4));
 }
+#ifndef ATTN_BWD_SWAP
+#define ATTN_BWD_SWAP 1   // k_attn_mfma_bwd_kv: operand-tile rows pair-swapped in LDS (A/B: 0)
+#endif
 #define OPS_STAGE 32768   // bytes of one operand stage: 4 heads x (two 4 KB tiles)
 #define OPS_BYTES (2 * OPS_STAGE)
 
@@ -643,7 +646,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
     const int crow = lt >> 4, ccol = lt & 15;   // query row, key of each 16 x 16 sub-tile; the group's 4 heads (16 bytes)
     const float* Qh = a.pk + PK_QH * arr + hb;  // this loader wave feeds head h
     const float* Oh = a.pk + PK_OH * arr + hb;
-    const unsigned doff = dma_lane_off(lane);
+    const unsigned doff = dma_lane_off(ATTN_BWD_SWAP ? lane ^ (((lane >> 4) & 1) << 2) : lane);   // (swap: LDS row sigma <- tile row sigma ^ ((sigma >> 2) & 1), see the compute waves)
     const unsigned ops0 = lds_addr(sm) + w * (KT * 2048);   // head w: Q tile, then dO tile
     auto dma_ops = [&](int ltile, int stage) __attribute__((always_inline)) {
       const float* qs = Qh + (size_t)ltile * 16 * D;
@@ -782,13 +785,18 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
   const int po4 = w * PT_PL + ptT_off(4 * q, mm);   // this lane's query rows 4q..4q+3 of key mm inside a sub-tile: one 16-byte access
   // operand tiles of head w (Q, then dO): row form: lane (row mm, chunk q) b128; transposed form: lane (channel mm, q):
   // rows 4q + r, dword mm & 3 of chunk mm >> 2
-  const float* oprow = sm + w * (KT * 512) + mm * 16 + ((q ^ chunk_xor(mm)) << 2);
+  // (ATTN_BWD_SWAP: tile rows 4-7 / 12-15 pair-swapped in LDS, as in k_pair_bwd: the transposed b32 reads of a 32-lane group touch
+  //  tile rows r and 4 + r -- the same 16 banks with 16-float rows, 2-way on the 32 reads of a tile; swapped, the group covers 32 banks)
+  const float* oprow = sm + w * (KT * 512) + (ATTN_BWD_SWAP ? mm ^ ((mm >> 2) & 1) : mm) * 16 + ((q ^ chunk_xor(mm)) << 2);
   const float* optr = sm + w * (KT * 512) + (4 * q) * 16 + (((mm >> 2) ^ chunk_xor(4 * q)) << 2) + (mm & 3);
+  const float* optr_e = optr + (ATTN_BWD_SWAP ? (q & 1) * 16 : 0);   // steps 0, 2: LDS row 4q + r + (q & 1)
+  const float* optr_o = optr - (ATTN_BWD_SWAP ? (q & 1) * 16 : 0);   // steps 1, 3: LDS row 4q + r - (q & 1)
   lds_barrier();
   STAMP(0);
   for (int l0 = 0, it = 0; it < mtiles; l0 += 16, ++it) {
     const float* opr = oprow + (it & 1) * (OPS_STAGE / 4);
-    const float* opt = optr + (it & 1) * (OPS_STAGE / 4);
+    const float* opt_e = optr_e + (it & 1) * (OPS_STAGE / 4);
+    const float* opt_o = optr_o + (it & 1) * (OPS_STAGE / 4);
     const float* Inb = In + (it & 1) * NIN * TS;
     float* Ob = Out + (it & 1) * 2 * TS;
     float4 qa[KT], oa[KT];   // row operands first: the S / dP MFMAs start as soon as they land, everything else lands behind them
@@ -875,6 +883,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_mfma_bwd_kv(AttnMfmaArgs a) {
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        const float* opt = (r & 1) ? opt_o : opt_e;
         const float qq = opt[kt * 256 + r * 16];
         const float oo = opt[KT * 256 + kt * 256 + r * 16];
 #pragma unroll
