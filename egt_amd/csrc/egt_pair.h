@@ -58,7 +58,7 @@ __device__ __forceinline__ void pair_barrier() {
 }
 #define PR_CLAMP(x) (FULL ? (x) : min((x), N - 1))
 #ifndef PAIR_ABL
-#define PAIR_ABL 0   // timing ablations of k_pair_fwd (results are wrong): 1 attention waves idle, 2 no dense_edge_r / stores, 4 no LN / projections, 8 no e requests
+#define PAIR_ABL 0   // timing ablations of k_pair_fwd (results are wrong): 1 attention waves idle, 2 no dense_edge_r / stores, 4 no LN / projections, 8 no e requests, 16 no e' stores, 32 / 64 e loads / e' stores on the tile of trip 0 (cache hits)
 #endif
 #ifndef PAIR_BWD_NT
 #define PAIR_BWD_NT 4   // k_pair_bwd cache-policy hints: 1 e tiles non-temporal, 2 de' first read, 4 de' second read (POST).  Measured (same box, us per launch):
@@ -265,6 +265,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
     char* dumpl = reinterpret_cast<char*>(pa.dump) + lane * 16;
     struct ESet { float4 x[4][T]; };
     auto eload = [&](ESet& s, int mt) __attribute__((always_inline)) {
+      if (PAIR_ABL & 32) mt = 0;   // (timing ablation: every trip reads the tile of trip 0 -- cache-resident)
       const uint32_t mo = ((uint32_t)PR_CLAMP(16 * mt + p) * DE + 4 * q) * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES, 2) k_pair_fwd(AttnMfmaArgs a, P
     // bandwidth they need is a fraction of the chip's; non-temporal stores: +14 us)
     auto update_store = [&](const ESet& ov, int itx) __attribute__((always_inline)) {
       if (PAIR_ABL & 16) return;   // (timing ablation: no stores)
-      const int m = 16 * mt_of(itx) + p;
+      const int m = 16 * ((PAIR_ABL & 64) ? 0 : mt_of(itx)) + p;   // (64: timing ablation, every trip stores to the tile of trip 0)
       const uint32_t mo = ((uint32_t)PR_CLAMP(m) * DE + 4 * q) * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r)

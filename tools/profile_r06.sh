@@ -13,7 +13,7 @@ cd "$(dirname "$0")/.."
 if [ -z "$QUICK" ]; then
   timeout 2700 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
 fi
-FULLPMC="zinc500k_n64 synthetic_n512 synthetic_n512_block"
+FULLPMC="zinc500k_n64 synthetic_n512 synthetic_n512_block synthetic_n512_block_b32"
 HBMPMC="cifar10_n150 pattern500k_n120 pattern500k_n120_b128 zinc100k_n37"   # fresh HBM-byte counters for the lines whose entries dated from round 3
 export PROF_WORKLOADS="$FULLPMC $HBMPMC"
 for WL in $FULLPMC $HBMPMC; do
@@ -38,7 +38,7 @@ timeout 300 python bench.py --steps 20 --warmup 10 > $OUT/bench_driver_style.jso
 timeout 300 python bench.py --graph on --no-cpu-baseline --no-graph-leg > $OUT/bench_graph_on.json 2>> $OUT/bench_err.log
 timeout 300 python bench.py --graph off --no-cpu-baseline --no-graph-leg > $OUT/bench_graph_off.json 2>> $OUT/bench_err.log
 if [ -z "$QUICK" ]; then
-  for WL in synthetic_n512_b32 synthetic_n512_block_b32 zinc500k_n64_full pattern500k_bmax pattern500k_bmax_b128 pattern500k_n188 pattern500k_n188_b128 cifar10_n150_fp32; do
+  for WL in synthetic_n512_b32 zinc500k_n64_full pattern500k_bmax pattern500k_bmax_b128 pattern500k_n188 pattern500k_n188_b128 cifar10_n150_fp32; do
     timeout 300 python bench.py --workload $WL --no-cpu-baseline > $OUT/bench_$WL.json 2>> $OUT/bench_err.log
   done
   for SC in layers model; do
