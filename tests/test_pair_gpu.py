@@ -136,3 +136,17 @@ def test_pair_no_clip_and_refusals(gpu, egt_lib):
         setattr(d2, field, val)
         assert egt_lib.egt_pair_supported(C.byref(d2)) == 0, (field, val)
         assert egt_lib.egt_pair_workspace_bytes(C.byref(d2)) == 0
+
+
+def test_random_pair_geometries():
+    """tools/sweep_pair.py: random batch / N / node counts / clip / training-mode geometries against the fp64 oracle (a short run;
+    the tool takes a case count and EGT_SWEEP_SEED for longer ones -- profiles/r06_sweep_pair.log: 40 cases)."""
+    import os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "sweep_pair.py"), "12"], cwd=repo, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "failures: 0" in r.stdout
