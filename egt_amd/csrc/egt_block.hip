@@ -114,7 +114,9 @@ struct BlockLayout {
 //    (config 3: 225 -> 216 us per launch; N = 120: 162 -> 156 us);
 //  * a launch of at most one 16-row workgroup per CU (BASELINE config 4 as specified: B = 16, N = 120 -> 128 workgroups on
 //    256 CUs) takes 8 rows per workgroup: twice the partial slots, each prologue on a half-filled tile, every CU busy
-//    (pattern500k_n120, per launch: B = 16: 59.0 us at 16 rows, 43.3 at 8, 47.9 at 6; B = 32: 63.0 / 59.5 / 65.5).
+//    (pattern500k_n120, per launch: B = 16: 59.0 us at 16 rows, 43.3 at 8, 47.9 at 6; B = 32: 63.0 / 59.5 / 65.5) -- round 6, with
+//    the eight-wave k_narrow_bwd for such launches: the shortest groups of >= 8 rows that keep the launch at ONE workgroup per CU
+//    (N = 120: B = 16 -> 8 rows, B = 24 -> 12 rows: 51.5 -> 42.5 us, B = 32 -> 15 rows: 54.0 -> 48.4 us against 8 rows);
 //    Smaller groups never pay beyond that: the per-workgroup work that does not shrink with the rows (prologue, K / V tiles,
 //    partial sums) takes over (B = 128, N = 150: 225 us at 16 rows, 253 at 12, 295 at 8).
 // EGT_BWD_TL = 4 .. 16 overrides, for every De (tests, sweeps: tools/dbg/nrw_tlsweep.sh).
@@ -132,7 +134,15 @@ static int bwd_rows_per_wg(const egt_block_desc* d) {
     if (g < groups) g = groups;
     return (d->N + g - 1) / g;
   }
-  if (d->B * groups <= egt_device_cus()) return d->N > 8 ? 8 : BWD_TL;
+  if (d->B * groups <= egt_device_cus()) {
+    // a launch of at most one 16-row workgroup per CU (it runs the eight-wave k_narrow_bwd): the shortest groups of >= 8 rows that still give
+    // every CU at most ONE workgroup -- B = 16: N = 120 -> 8 rows (240 workgroups), N = 188 -> 12 rows (256; with 8 rows the launch was
+    // 368 four-wave workgroups: 71.4 us against 58.4, `pattern500k_n188` 9.4 k -> 10.9 k graphs/s)
+    if (d->N <= 8) return BWD_TL;
+    for (int tl = 8; tl < BWD_TL; ++tl)
+      if (d->B * ((d->N + tl - 1) / tl) <= egt_device_cus()) return tl;
+    return BWD_TL;
+  }
   return (d->N + groups - 1) / groups;
 }
 
