@@ -426,7 +426,7 @@ static int launch_bwd(BlockArgs& a, const BlockLayout& L, hipStream_t st, bool t
       if constexpr (DE >= 32) {
         if (!ml && !a.bf16) {   // LDS-DMA staged e tiles (k_block_bwd_v5), ragged N included
           const bool x3 = block_env().bwd_mm == EGT_MM_BF16X3;
-          const size_t lds_v5 = ((size_t)V5_AREA(DE) + (size_t)BWD_TL * QD_LD + 3 * ((GG::TILES + 1) / 2) * 512) * 4;
+          const size_t lds_v5 = ((size_t)V5_AREA(DE) + (size_t)BWD_TL * QD_LD + 3 * ((GG::TILES + 1) / 2) * 512 + 4) * 4;   // (+ 4: the parked-partial flags)
 #define V5_LAUNCH(MM_, RAG_)                                                                                 \
   do {                                                                                                       \
     EGT_MAX_LDS_ONCE(k_block_bwd_v5<DE, MM_, RAG_>);                                                         \

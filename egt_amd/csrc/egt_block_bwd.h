@@ -356,6 +356,9 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v4(BlockArgs a) {
 // fp32 value it replaces.
 // floats of k_block_bwd_v5's tile area: four waves x (two e buffers + de' tile + hand-off tiles), and at least the four parity-0 e
 // buffers + the node-side prologue's scratch behind them
+#ifndef V5_BALANCE
+#define V5_BALANCE 1   // k_block_bwd_v5: balanced (tile, row) ranges when the key-tile count is not a multiple of 4 (A/B: 0)
+#endif
 #define V5_AREA(DE_) ((4 * (3 * Geo<DE_>::TILE_FLOATS + 448) > 4 * Geo<DE_>::TILE_FLOATS + BWD_PRO_WS) \
                           ? 4 * (3 * Geo<DE_>::TILE_FLOATS + 448) : 4 * Geo<DE_>::TILE_FLOATS + BWD_PRO_WS)
 template <int DE, int MM, bool RAG>
@@ -398,6 +401,8 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   float* wsA = qd + TL * QD_LD;              // prologue weights   wA[4t+u]
   float* wsB = wsA + WSLAB;                  // dH_ext weights     wrB[4t+u]
   float* wsD = wsB + WSLAB;                  // d(ehat) weights    wD[t][s]
+  volatile int* pflag = reinterpret_cast<volatile int*>(wsD + WSLAB);   // [4]: wave w parked the partial of the tile it shares with wave w - 1
+  if (threadIdx.x < 4) pflag[threadIdx.x] = 0;
   // LDS byte address of the wave's e buffers (the kernel's only LDS object is the dynamic array: offset 0)
   const unsigned et_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)et0);
   const unsigned off0 = dma_lane_offset<DE>(lane);
@@ -406,13 +411,24 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   // parity-0 buffers nor these registers -- so the row loop starts on data that has landed (the first row of a workgroup cost
   // 8.1 us against 4.35 us for every later one: DESIGN_LOG.md, round 5, ablation builds).
   const int ntile = RAG ? (N + 15) / 16 : N / 16;
+  // Work of a wave: key tiles w, w + 4, ... when the tile count is a multiple of 4 (or < 3); otherwise (N = 37: three tiles for four
+  // waves -- one wave idle in the row loop; N = 100: seven) the ntile x nl (tile, row) steps are cut into four CONTIGUOUS equal
+  // ranges: a tile that straddles two ranges is shared by neighbouring waves, whose dK / dV meet in the tile's partial slot (the later
+  // wave parks its sum there, the earlier one adds its own: same CU, an LDS flag -- as k_narrow_bwd does).  At least three tiles: a
+  // range is then never shorter than 3/4 of a tile and no tile has more than two waves.
+  const bool balance = RAG && V5_BALANCE && ntile >= 3 && (ntile & 3) != 0;
+  const int T_ = ntile * nl;
+  const int t0 = balance ? (wave * T_) >> 2 : 0, t1 = balance ? ((wave + 1) * T_) >> 2 : 0;
+  const bool have = balance ? t1 > t0 : wave < ntile;
+  const int mt_first = balance ? t0 / nl : wave, mt_last = balance ? (t1 - 1) / nl : ntile - 1, mt_step = balance ? 1 : 4;
+  const int r0_first = balance ? t0 - mt_first * nl : 0;
   float Kf[16], Vf[16];
   int kmv = 1;
-#define V5_TILE_START(MT_)                                                                                          \
+#define V5_TILE_START(MT_, ROW_)                                                                                    \
   do {                                                                                                              \
     const int m0_ = (MT_) * 16, kv_ = RAG ? min(16, N - m0_) : 16;                                                  \
-    if (RAG && kv_ < 16) tile_dma_ragged<DE>(et_lds, e_in + (((size_t)b * N + l_begin) * N + m0_) * DE, lane, kv_); \
-    else tile_dma<DE, EGT_NT_BWD_E>(et_lds, e_in + (((size_t)b * N + l_begin) * N + m0_) * DE, off0);               \
+    if (RAG && kv_ < 16) tile_dma_ragged<DE>(et_lds, e_in + (((size_t)b * N + l_begin + (ROW_)) * N + m0_) * DE, lane, kv_); \
+    else tile_dma<DE, EGT_NT_BWD_E>(et_lds, e_in + (((size_t)b * N + l_begin + (ROW_)) * N + m0_) * DE, off0);      \
     const size_t rowm_ = (size_t)b * N + (RAG ? min(m0_ + p, N - 1) : m0_ + p);                                     \
     const float4* kp_ = reinterpret_cast<const float4*>(a.qkvp + rowm_ * QKVP + 64 + q * 16);                       \
     const float4* vp_ = reinterpret_cast<const float4*>(a.qkvp + rowm_ * QKVP + 128 + q * 16);                      \
@@ -423,7 +439,7 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
     }                                                                                                               \
     kmv = a.km ? (int)a.km[rowm_] : 1;                                                                              \
   } while (0)
-  if (wave < ntile) V5_TILE_START(wave);
+  if (have) V5_TILE_START(mt_first, r0_first);
   // Staged query-side rows AND (fp32 products) the weight slabs: every global load of both is issued before the first LDS store, so
   // the kernel's start-up pays ONE memory round trip for them instead of one before and one behind the node-side prologue (the slabs
   // live behind qd, outside the prologue's scratch: they may be filled before it runs): k_block_bwd_v5 96.9-97.0 -> 95.3-95.7 us (same box).
@@ -517,29 +533,33 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
   __syncthreads();   // the prologue's scratch (the tile area behind the parity-0 e buffers) is dead from here
   PSTAMP(2);
 
-  for (int mt = wave; mt < ntile; mt += 4) {
+  for (int mt = mt_first; have && mt <= mt_last; mt += mt_step) {
+    const int r0 = (balance && mt == mt_first) ? r0_first : 0;            // rows [r0, r1) of the workgroup's nl
+    const int r1 = (balance && mt == mt_last) ? t1 - mt * nl : nl;
     const int m0 = mt * 16, m = m0 + p;
     const int kv = RAG ? min(16, N - m0) : 16;          // valid keys of the tile (wave-uniform)
     const bool kvalid = RAG ? (p < kv) : true;
     // a later key tile of this wave (N > 64): its first e tile is in flight while K / V are fetched
-    if (mt != wave) V5_TILE_START(mt);
+    if (mt != mt_first) V5_TILE_START(mt, r0);
     float dKa[16], dVa[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dKa[i] = 0.f; dVa[i] = 0.f; }
     asm volatile("" : "+v"(kmv));   // (the byte was requested long ago; its first use stays here)
     const float kadd = kmv == 0 ? -EGT_NEG : 0.0f;
-    for (int l = l_begin; l < l_end; ++l) {
-      const int li = l - l_begin;
+    const int l_first = l_begin + r0, l_stop = l_begin + r1;
+    for (int l = l_first; l < l_stop; ++l) {
+      const int li = l - l_begin;      // row of the workgroup (qd)
+      const int lj = l - l_first;      // row of this wave's tile segment (e buffer parity, first-row wait)
       const size_t rowl = (size_t)b * N + l;
       const size_t pair0 = rowl * N + m0;
-      float* et = et0 + (li & 1) * estr;
+      float* et = et0 + (lj & 1) * estr;
       MaskRegs mr{make_float2(1.f, 1.f), 0};
       // ---- de'(l): requested now, consumed after P1 ----
       TileRegs<DE> td;
       tile_gload<DE, EGT_NT_BWD_DY>(td, dey_in + pair0 * DE, lane, kv);
       // ---- e(l) has been in flight for a whole iteration (the first one: since kernel entry): retire it.  Younger operations of
       // this wave: row l-1's dQ-partial store and its NI de stores (none before the first row), then the NI de' loads just issued ----
-      if (li == 0) vm_wait<(G::NF4 + 63) / 64>(); else vm_wait<2 * ((G::NF4 + 63) / 64) + 1>();
+      if (lj == 0) vm_wait<(G::NF4 + 63) / 64>(); else vm_wait<2 * ((G::NF4 + 63) / 64) + 1>();
       SCHED_FENCE();
       // ---- P1: norm_edge, projections (recompute) ----
       float rstd;
@@ -574,9 +594,9 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
       tile_lds_put<DE>(dt, td, lane, kv);   // (the compiler's own vmcnt wait for de' sits here; rows past kv are zero-filled)
       lds_sync();
       // ---- e(l+1) -> the other e buffer (its last reader, row l-1's P5, retired its LDS reads) ----
-      if (l + 1 < l_end) {
-        if (RAG && kv < 16) tile_dma_ragged<DE>(et_lds + (unsigned)(((li + 1) & 1) * estr * 4), e_in + (pair0 + (size_t)N) * DE, lane, kv);
-        else tile_dma<DE, EGT_NT_BWD_E>(et_lds + (unsigned)(((li + 1) & 1) * estr * 4), e_in + (pair0 + (size_t)N) * DE, off0);
+      if (l + 1 < l_stop) {
+        if (RAG && kv < 16) tile_dma_ragged<DE>(et_lds + (unsigned)(((lj + 1) & 1) * estr * 4), e_in + (pair0 + (size_t)N) * DE, lane, kv);
+        else tile_dma<DE, EGT_NT_BWD_E>(et_lds + (unsigned)(((lj + 1) & 1) * estr * 4), e_in + (pair0 + (size_t)N) * DE, off0);
       }
       SCHED_FENCE();
       // ---- P2: dH_ext = de'.Wr^T ----
@@ -763,12 +783,30 @@ __global__ void __launch_bounds__(256, 2) k_block_bwd_v5(BlockArgs a) {
     }
     float4* ko = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 0) * 4 + q) * 16);
     float4* vo = reinterpret_cast<float4*>(a.dkvp + (((((size_t)b * a.NLR + lr) * N + m) * 2 + 1) * 4 + q) * 16);
+    if (balance && r1 < nl && r0 == 0) {   // the tile's last rows were done by the next wave, at the START of its range: its partial sits in the slot
+      while (pflag[wave + 1] == 0) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (kvalid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 kk = ko[i], vv = vo[i];
+          dKa[4*i] += kk.x; dKa[4*i+1] += kk.y; dKa[4*i+2] += kk.z; dKa[4*i+3] += kk.w;
+          dVa[4*i] += vv.x; dVa[4*i+1] += vv.y; dVa[4*i+2] += vv.z; dVa[4*i+3] += vv.w;
+        }
+      }
+    }
     if (kvalid) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         ko[i] = make_float4(dKa[4*i], dKa[4*i+1], dKa[4*i+2], dKa[4*i+3]);
         vo[i] = make_float4(dVa[4*i], dVa[4*i+1], dVa[4*i+2], dVa[4*i+3]);
       }
+    }
+    if (balance && r0 > 0) {   // the tile's first rows belong to the previous wave: what was just stored is this wave's partial, parked in the
+                               // slot (same CU: the stores are acknowledged by the L2 before the flag goes up, the slot was never in this L1)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) pflag[wave] = 1;
     }
   }
 #pragma unroll
