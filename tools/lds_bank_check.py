@@ -90,5 +90,34 @@ def main():
     print("transposed-plane chunk permutations (b128 read, b128 write, scatter):", best[:6])
 
 
+def pair_bwd():
+    """k_pair_bwd (egt_pair.h), round 6: the edge waves' plane accesses with one row per wave-instruction (first version) and with the rows of a
+    row group skewed over the lanes; the transposed scratch; the attention waves' transposed operand reads with the tile rows as stored
+    and pair-swapped.  Wave j = 1; lane = p + 16 q."""
+    TSZ, DE, j = 8 * PT_PL, 32, 1
+    print("\nk_pair_bwd (worst LDS cycles per 32-lane group; 1 = conflict free)")
+    for skew in (0, 1):
+        row = (lambda r, c: 4 * r + ((j + c) & 3)) if skew else (lambda r, c: 4 * r + j)
+        tag = "rows skewed over the lanes" if skew else "one row per wave-instruction"
+        for r in (0, 2):
+            report(f"  {tag}: PRE / d ehat plane b32, row group {r}",
+                   worst(B32_GROUPS, lambda l: (TSZ if (l >> 4) < 2 else 0) + 4 * ((l >> 4) & 1) * PT_PL + ptT_off(row(r, l & 15), l & 15), 1, 32))
+            report(f"  {tag}: weight-gradient A operand (dGE) b32, row group {r}",
+                   worst(B32_GROUPS, lambda l: (TSZ if (l & 15) < 8 else 0) + (l & 7) * PT_PL + ptT_off(row(r, l >> 4), l >> 4), 1, 32))
+    for name, wr, rd in (("[pair][DE], chunk ^ (pair & 7)", lambda p_, q_, t: p_ * DE + 4 * ((4 * t + q_) ^ (p_ & 7)),
+                          lambda pr, ch: pr * DE + 4 * ((ch >> 2) ^ (pr & 7)) + (ch & 3)),
+                         ("[block][pair][16], chunk ^ ((pair >> 1) & 3)", lambda p_, q_, t: 256 * t + 16 * p_ + 4 * (q_ ^ ((p_ >> 1) & 3)),
+                          lambda pr, ch: 256 * (ch >> 4) + 16 * pr + 4 * (((ch & 15) >> 2) ^ ((pr >> 1) & 3)) + (ch & 3))):
+        report(f"  scratch {name}: b128 write", worst(W128_GROUPS, lambda l: wr(l & 15, l >> 4, 0), 4, 32))
+        w = max(worst(B32_GROUPS, lambda l, s4=s4, t=t: rd(4 * s4 + (l >> 4), 16 * t + (l & 15)), 1, 32) for s4 in range(4) for t in range(2))
+        report(f"  scratch {name}: transposed b32 reads", w)
+    for name, pi in (("as stored", lambda r: r), ("rows 4-7 / 12-15 pair-swapped", lambda r: r ^ ((r >> 2) & 1))):
+        w = max(worst(B32_GROUPS, lambda l, r=r: pi(4 * (l >> 4) + r) * 16 + 4 * ((((l & 15) >> 2) ^ A_T[l >> 4]) & 3) + (l & 3), 1, 32) for r in range(4))
+        report(f"  operand tile {name}: transposed b32 reads", w)
+        report(f"  operand tile {name}: row-form b128 reads",
+               worst(B128_GROUPS, lambda l: pi(l & 15) * 16 + 4 * (((l >> 4) ^ A_T[(l & 15) >> 2]) & 3), 4, 64))
+
+
 if __name__ == "__main__":
     main()
+    pair_bwd()
