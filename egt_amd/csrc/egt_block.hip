@@ -128,9 +128,13 @@ static int bwd_rows_per_wg(const egt_block_desc* d) {
     // equal groups (16 whenever N is a multiple of 16); a launch that leaves slots empty takes more, shorter groups while they
     // still fit one round and keep 8 rows (ZINC-100K, B = 128, N = 37: 3 x 13 rows = 384 workgroups on 512 slots -> 4 x 10 rows:
     // k_block_bwd 73.6 -> 64.3 us; 5 x 8 rows = 640 workgroups is a second round: 92.9 us)
+    // ... and 4 rows when even four-row groups leave every CU at most ONE workgroup (B = 16 per GPU at the headline shapes -- a
+    // global batch of 128 over 8 GPUs: 64 sixteen-row workgroups on 512 slots -> 256 four-row ones: 23.8 k -> 30.1 k graphs/s with the
+    // forward's same rule; at B = 24 / 32 four rows measure the same as / below eight: profiles/r06_pair_abl2.txt)
     const int slots = 2 * egt_device_cus();
     int g = slots / (d->B > 0 ? d->B : 1);
-    if (g > (d->N + 7) / 8) g = (d->N + 7) / 8;
+    const int cap = d->B * ((d->N + 3) / 4) <= slots / 2 ? (d->N + 3) / 4 : (d->N + 7) / 8;
+    if (g > cap) g = cap;
     if (g < groups) g = groups;
     return (d->N + g - 1) / g;
   }
@@ -302,8 +306,11 @@ static int launch_fwd(BlockArgs& a, hipStream_t st, bool skip_pre) {
   a.RGF = 16;
   {
     static const int forced = getenv("EGT_FWD_ROWS") ? atoi(getenv("EGT_FWD_ROWS")) : 0;   // 4 .. 16 (tests)
-    int g = (2 * egt_device_cus()) / (a.B > 0 ? a.B : 1);
-    if (g > (a.N + 7) / 8) g = (a.N + 7) / 8;
+    const int slots = 2 * egt_device_cus();
+    int g = slots / (a.B > 0 ? a.B : 1);
+    // (at least 8 rows per group -- 4 when even four-row groups leave every CU at most one workgroup: bwd_rows_per_wg has the numbers)
+    const int cap = a.B * ((a.N + 3) / 4) <= slots / 2 ? (a.N + 3) / 4 : (a.N + 7) / 8;
+    if (g > cap) g = cap;
     if (g > lgroups) a.RGF = (((a.N + g - 1) / g + 3) / 4) * 4;
     if (forced >= 4 && forced <= 16) a.RGF = forced;
   }
